@@ -1,0 +1,821 @@
+/*
+ * knox_oracle.c -- CPU ORACLE for the KnoxDB pack-scan hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  It is a plain-C restatement of the
+ * reference's Go algorithms (blockwatch-cc/knoxdb, /root/reference) used only as the
+ * checker in tests/, in __graft_entry__.smoke() and as bench.py's `cpu_baseline` leg.
+ * Nothing under knoxdb_amd/ may include, link, import or call it.
+ *
+ * Parity pin: the compare kernels and the bitset helpers are checked against the
+ * reference's own golden vectors (tests/golden/cmp_cases.json <- internal/cmp/tests/<type>.go,
+ * tests/golden/bitset_cases.json <- internal/bitset/tests/{pop,run}.go) and the fixed-width
+ * xxh3 against internal/hash/xxh3_test.go:14-31.  The reducers have NO tests in the
+ * reference (internal/reducer holds 0 test lines): their restatement is "parity unpinned"
+ * and is cross-checked only by hand-derived cases and an exact-arithmetic checker.
+ * XXH3-64 of byte strings comes from the un-vendored dependency github.com/zeebo/xxh3
+ * v1.1.0 (go.mod:18); it is restated from the published XXH3 specification and pinned
+ * against vectors generated with the independent python `xxhash` package
+ * (tests/golden/make_xxh3_bytes_golden.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Built with -ffp-contract=off: Go on amd64 never fuses a*b+c.
+ *
+ * Go -> C precedence traps are parenthesised explicitly.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KO_EXPORT __attribute__((visibility("default")))
+
+/* types.BlockType  internal/types/block.go:20-36 */
+enum { KO_I64 = 1, KO_I32 = 2, KO_I16 = 3, KO_I8 = 4, KO_U64 = 5, KO_U32 = 6, KO_U16 = 7, KO_U8 = 8,
+       KO_F64 = 9, KO_F32 = 10, KO_BYTES = 12 };
+/* types.FilterMode internal/types/mode.go:13-27 */
+enum { KO_EQ = 1, KO_NE = 2, KO_GT = 3, KO_GE = 4, KO_LT = 5, KO_LE = 6, KO_RG = 9 };
+/* reducer funcs    internal/reducer/reducer.go:25-45 */
+enum { KO_R_SUM = 0, KO_R_FIRST = 1, KO_R_LAST = 2, KO_R_MIN = 3, KO_R_MAX = 4, KO_R_MEAN = 5,
+       KO_R_VAR = 6, KO_R_STD = 7, KO_R_COUNT = 8 };
+
+/* ------------------------------------------------------------------------------------------
+ * bitset helpers: internal/bitset/generic/utils.go:12-24
+ * ---------------------------------------------------------------------------------------- */
+static inline int64_t bit_field_len(int64_t n) { return ((n + 7) & ~(int64_t)7) >> 3; }
+static inline uint8_t bytemask(int64_t size) { return (uint8_t)(0xff >> (7 - ((size - 1) & 7))); }
+static inline int pop8(uint8_t b) { return __builtin_popcount(b); }
+
+KO_EXPORT int64_t ko_bit_field_len(int64_t n) { return bit_field_len(n); }
+KO_EXPORT int ko_bytemask(int64_t size) { return bytemask(size); }
+
+/* ------------------------------------------------------------------------------------------
+ * compare kernels: internal/cmp/number.go:13-243 (integers), internal/cmp/float.go:13-242
+ * (floats).  8 compares -> one byte (bit k = row idx+k), full bytes are overwritten, the
+ * tail rows are OR-ed into byte n/8 (callers pass a zeroed bitset), returns the popcount.
+ * ---------------------------------------------------------------------------------------- */
+#define KO_CMP1(NAME, T, EXPR)                                                                  \
+    static int64_t NAME(const T *src, int64_t len, T val, uint8_t *res) {                       \
+        int64_t cnt = 0, n = len / 8, idx = 0;                                                  \
+        for (int64_t i = 0; i < n; i++) {                                                       \
+            uint8_t b = 0;                                                                      \
+            for (int k = 0; k < 8; k++) {                                                       \
+                T v = src[idx + k];                                                             \
+                b = (uint8_t)(b + ((uint8_t)((EXPR) ? 1 : 0) << k));                            \
+            }                                                                                   \
+            res[i] = b;                                                                         \
+            cnt += pop8(b);                                                                     \
+            idx += 8;                                                                           \
+        }                                                                                       \
+        if (len % 8 > 0) {                                                                      \
+            for (int64_t i = 0; idx + i < len; i++) {                                           \
+                T v = src[idx + i];                                                             \
+                if (EXPR) { res[n] |= (uint8_t)(0x1 << i); cnt++; }                             \
+            }                                                                                   \
+        }                                                                                       \
+        return cnt;                                                                             \
+    }
+
+/* integer Between: number.go:211-243  diff := U(b-a); hit iff U(v-a) <= diff */
+#define KO_CMP_BW_INT(NAME, T, U)                                                               \
+    static int64_t NAME(const T *src, int64_t len, T a, T b, uint8_t *res) {                    \
+        U diff = (U)((U)b - (U)a);                                                              \
+        int64_t cnt = 0, n = len / 8, idx = 0;                                                  \
+        for (int64_t i = 0; i < n; i++) {                                                       \
+            uint8_t x = 0;                                                                      \
+            for (int k = 0; k < 8; k++) {                                                       \
+                U d = (U)((U)src[idx + k] - (U)a);                                              \
+                x = (uint8_t)(x + ((uint8_t)(d <= diff ? 1 : 0) << k));                         \
+            }                                                                                   \
+            res[i] = x;                                                                         \
+            cnt += pop8(x);                                                                     \
+            idx += 8;                                                                           \
+        }                                                                                       \
+        if (len % 8 > 0) {                                                                      \
+            for (int64_t i = 0; idx + i < len; i++) {                                           \
+                U d = (U)((U)src[idx + i] - (U)a);                                              \
+                if (d <= diff) { res[n] |= (uint8_t)(0x1 << i); cnt++; }                        \
+            }                                                                                   \
+        }                                                                                       \
+        return cnt;                                                                             \
+    }
+
+/* float Between: float.go:211-242  a <= v && v <= b */
+#define KO_CMP_BW_FLT(NAME, T)                                                                  \
+    static int64_t NAME(const T *src, int64_t len, T a, T b, uint8_t *res) {                    \
+        int64_t cnt = 0, n = len / 8, idx = 0;                                                  \
+        for (int64_t i = 0; i < n; i++) {                                                       \
+            uint8_t x = 0;                                                                      \
+            for (int k = 0; k < 8; k++) {                                                       \
+                T v = src[idx + k];                                                             \
+                x = (uint8_t)(x + ((uint8_t)((a <= v && v <= b) ? 1 : 0) << k));                \
+            }                                                                                   \
+            res[i] = x;                                                                         \
+            cnt += pop8(x);                                                                     \
+            idx += 8;                                                                           \
+        }                                                                                       \
+        if (len % 8 > 0) {                                                                      \
+            for (int64_t i = 0; idx + i < len; i++) {                                           \
+                T v = src[idx + i];                                                             \
+                if (a <= v && v <= b) { res[n] |= (uint8_t)(0x1 << i); cnt++; }                 \
+            }                                                                                   \
+        }                                                                                       \
+        return cnt;                                                                             \
+    }
+
+#define KO_CMP_FAMILY(P, T)                                                                     \
+    KO_CMP1(P##_eq, T, v == val)                                                                \
+    KO_CMP1(P##_ne, T, v != val)                                                                \
+    KO_CMP1(P##_lt, T, v < val)                                                                 \
+    KO_CMP1(P##_le, T, v <= val)                                                                \
+    KO_CMP1(P##_gt, T, v > val)                                                                 \
+    KO_CMP1(P##_ge, T, v >= val)
+
+KO_CMP_FAMILY(cmp_i64, int64_t)  KO_CMP_BW_INT(cmp_i64_bw, int64_t, uint64_t)
+KO_CMP_FAMILY(cmp_i32, int32_t)  KO_CMP_BW_INT(cmp_i32_bw, int32_t, uint32_t)
+KO_CMP_FAMILY(cmp_i16, int16_t)  KO_CMP_BW_INT(cmp_i16_bw, int16_t, uint16_t)
+KO_CMP_FAMILY(cmp_i8, int8_t)    KO_CMP_BW_INT(cmp_i8_bw, int8_t, uint8_t)
+KO_CMP_FAMILY(cmp_u64, uint64_t) KO_CMP_BW_INT(cmp_u64_bw, uint64_t, uint64_t)
+KO_CMP_FAMILY(cmp_u32, uint32_t) KO_CMP_BW_INT(cmp_u32_bw, uint32_t, uint32_t)
+KO_CMP_FAMILY(cmp_u16, uint16_t) KO_CMP_BW_INT(cmp_u16_bw, uint16_t, uint16_t)
+KO_CMP_FAMILY(cmp_u8, uint8_t)   KO_CMP_BW_INT(cmp_u8_bw, uint8_t, uint8_t)
+KO_CMP_FAMILY(cmp_f64, double)   KO_CMP_BW_FLT(cmp_f64_bw, double)
+KO_CMP_FAMILY(cmp_f32, float)    KO_CMP_BW_FLT(cmp_f32_bw, float)
+
+#define KO_DISPATCH(P, T)                                                                       \
+    {                                                                                           \
+        const T *s = (const T *)src;                                                            \
+        T va = a ? *(const T *)a : (T)0, vb = b ? *(const T *)b : (T)0;                         \
+        switch (op) {                                                                           \
+        case KO_EQ: return P##_eq(s, n, va, bits);                                              \
+        case KO_NE: return P##_ne(s, n, va, bits);                                              \
+        case KO_LT: return P##_lt(s, n, va, bits);                                              \
+        case KO_LE: return P##_le(s, n, va, bits);                                              \
+        case KO_GT: return P##_gt(s, n, va, bits);                                              \
+        case KO_GE: return P##_ge(s, n, va, bits);                                              \
+        case KO_RG: return P##_bw(s, n, va, vb, bits);                                          \
+        default: return -1;                                                                     \
+        }                                                                                       \
+    }
+
+/* Exported dispatch mirrors the exported func vars of internal/cmp/cmp.go:6-114
+ * (`Int64Less(src, val, bits) int64`, `Int64Between(src, a, b, bits) int64`).
+ * `bits` must hold (n+7)/8 bytes and be zeroed by the caller (reader.go:334). */
+KO_EXPORT int64_t ko_cmp(int dtype, int op, const void *src, int64_t n, const void *a, const void *b,
+                         uint8_t *bits) {
+    if (n <= 0 || src == NULL) return 0; /* cmp/tests/int64.go:212-213: l0 / nil -> 0, nothing written */
+    switch (dtype) {
+    case KO_I64: KO_DISPATCH(cmp_i64, int64_t)
+    case KO_I32: KO_DISPATCH(cmp_i32, int32_t)
+    case KO_I16: KO_DISPATCH(cmp_i16, int16_t)
+    case KO_I8:  KO_DISPATCH(cmp_i8, int8_t)
+    case KO_U64: KO_DISPATCH(cmp_u64, uint64_t)
+    case KO_U32: KO_DISPATCH(cmp_u32, uint32_t)
+    case KO_U16: KO_DISPATCH(cmp_u16, uint16_t)
+    case KO_U8:  KO_DISPATCH(cmp_u8, uint8_t)
+    case KO_F64: KO_DISPATCH(cmp_f64, double)
+    case KO_F32: KO_DISPATCH(cmp_f32, float)
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bitset combinators: internal/bitset/generic/bitset.go:13-330
+ * ---------------------------------------------------------------------------------------- */
+KO_EXPORT void ko_bits_and(uint8_t *dst, const uint8_t *src, int64_t size) { /* :13-49 */
+    if (size <= 0) return;
+    int64_t l = (size + 7) >> 3;
+    for (int64_t i = 0; i < l; i++) dst[i] &= src[i];
+    dst[l - 1] &= bytemask(size);
+}
+KO_EXPORT void ko_bits_andnot(uint8_t *dst, const uint8_t *src, int64_t size) { /* :115-151 dst &^= src */
+    if (size <= 0) return;
+    int64_t l = (size + 7) >> 3;
+    for (int64_t i = 0; i < l; i++) dst[i] &= (uint8_t)~src[i];
+    dst[l - 1] &= bytemask(size);
+}
+KO_EXPORT void ko_bits_or(uint8_t *dst, const uint8_t *src, int64_t size) { /* :153-189 */
+    if (size <= 0) return;
+    int64_t l = (size + 7) >> 3;
+    for (int64_t i = 0; i < l; i++) dst[i] |= src[i];
+    dst[l - 1] &= bytemask(size);
+}
+KO_EXPORT void ko_bits_xor(uint8_t *dst, const uint8_t *src, int64_t size) { /* :257-293 */
+    if (size <= 0) return;
+    int64_t l = (size + 7) >> 3;
+    for (int64_t i = 0; i < l; i++) dst[i] ^= src[i];
+    dst[l - 1] &= bytemask(size);
+}
+KO_EXPORT void ko_bits_neg(uint8_t *src, int64_t size) { /* :295-330 */
+    if (size <= 0) return;
+    int64_t l = (size + 7) >> 3;
+    for (int64_t i = 0; i < l; i++) src[i] = (uint8_t)~src[i];
+    src[l - 1] &= bytemask(size);
+}
+/* AndFlag :51-113 -> flags bit0 = any, bit1 = all */
+KO_EXPORT int ko_bits_and_flag(uint8_t *dst, const uint8_t *src, int64_t size) {
+    int64_t l = size >> 3;
+    uint8_t any = 0, all = 0xff;
+    for (int64_t i = 0; i < l; i++) {
+        dst[i] &= src[i];
+        any |= dst[i];
+        all &= dst[i];
+    }
+    if ((size & 7) != 0) {
+        dst[l] &= src[l];
+        dst[l] &= bytemask(size);
+        any |= dst[l];
+        all &= (uint8_t)(dst[l] | (uint8_t)~bytemask(size));
+    }
+    return (any != 0 ? 1 : 0) | (all == 0xff ? 2 : 0);
+}
+/* OrFlag :191-255 */
+KO_EXPORT int ko_bits_or_flag(uint8_t *dst, const uint8_t *src, int64_t size) {
+    int64_t l = size >> 3;
+    uint8_t any = 0, all = 0xff;
+    for (int64_t i = 0; i < l; i++) {
+        dst[i] |= src[i];
+        any |= dst[i];
+        all &= dst[i];
+    }
+    if ((size & 7) != 0) {
+        dst[l] |= src[l];
+        dst[l] &= bytemask(size);
+        any |= dst[l];
+        all &= (uint8_t)(dst[l] | (uint8_t)~bytemask(size));
+    }
+    return (any != 0 ? 1 : 0) | (all == 0xff ? 2 : 0);
+}
+/* PopCount :332-353: 64-bit words over src[:(size-1)>>3], remaining bytes except the last,
+ * then the last byte masked by bytemask(size).  len(src) == (size+7)>>3. */
+KO_EXPORT int64_t ko_bits_popcount(const uint8_t *src, int64_t size) {
+    if (size <= 0) return 0;
+    int64_t len = (size + 7) >> 3, cnt = 0;
+    int64_t words = ((size - 1) >> 3) / 8;
+    for (int64_t w = 0; w < words; w++) {
+        uint64_t v;
+        memcpy(&v, src + 8 * w, 8);
+        cnt += __builtin_popcountll(v);
+    }
+    for (int64_t i = (len - 1) & ~(int64_t)7; i < len - 1; i++) cnt += pop8(src[i]);
+    cnt += pop8((uint8_t)(src[len - 1] & bytemask(size)));
+    return cnt;
+}
+/* Indexes :355-396: masks the last byte IN PLACE, emits ascending row ids.  The reference walks
+ * a 256x8 decode table of 1-based bit positions added to a running base that starts at
+ * 0xffffffff; emitting (byte_index*8 + bit) for each set bit LSB-first is the same sequence. */
+KO_EXPORT int64_t ko_bits_indexes(uint8_t *src, int64_t size, uint32_t *dst) {
+    if (size <= 0) return 0;
+    int64_t len = (size + 7) >> 3, j = 0;
+    src[len - 1] &= bytemask(size);
+    for (int64_t i = 0; i < len; i++) {
+        uint8_t b = src[i];
+        while (b) {
+            int k = __builtin_ctz(b);
+            dst[j++] = (uint32_t)(i * 8 + k);
+            b &= (uint8_t)(b - 1);
+        }
+    }
+    return j;
+}
+/* Bitset.One :520-531 / fill helper: all bytes 0xff, last masked */
+KO_EXPORT void ko_bits_one(uint8_t *dst, int64_t size) {
+    if (size <= 0) return;
+    int64_t l = (size + 7) >> 3;
+    memset(dst, 0xff, (size_t)l);
+    dst[l - 1] &= bytemask(size);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * reducers: internal/reducer/reducer.go:138-429 -- scalar fold over the selected rows in
+ * ascending row order.  `bits` == NULL selects every row.  The reducer's time.Time bookkeeping
+ * ("unseen" = zero time) is modelled by `seen`; `row` reports the row whose timestamp the
+ * reducer would hold (first row for count/sum/first/mean/var/std, the adopted row for
+ * min/max, the last row for last).  The result of type T is written to out[0..sizeof(T));
+ * returns seen (Value()'s second result).
+ * ---------------------------------------------------------------------------------------- */
+#define KO_SELECTED(i) (bits == NULL || ((bits[(i) >> 3] >> ((i)&7)) & 1))
+
+#define KO_REDUCE(NAME, T)                                                                      \
+    static int NAME(int func, const T *src, int64_t n, const uint8_t *bits, void *out,          \
+                    int64_t *row_out) {                                                         \
+        int seen = 0;                                                                           \
+        int64_t row = -1, cnt = 0;                                                              \
+        T v = 0;                                                                                \
+        double mean = 0, m2 = 0;                                                                \
+        for (int64_t i = 0; i < n; i++) {                                                       \
+            if (!KO_SELECTED(i)) continue;                                                      \
+            T x = src[i];                                                                       \
+            switch (func) {                                                                     \
+            case KO_R_COUNT: /* :138-148 counts in type T */                                    \
+                if (!seen) row = i;                                                             \
+                v = (T)(v + 1);                                                                 \
+                break;                                                                          \
+            case KO_R_SUM: /* :168-178 r.v += v */                                              \
+                if (!seen) row = i;                                                             \
+                v = (T)(v + x);                                                                 \
+                break;                                                                          \
+            case KO_R_FIRST: /* :198-208 */                                                     \
+                if (!seen) { row = i; v = x; }                                                  \
+                break;                                                                          \
+            case KO_R_LAST: /* :228-236 */                                                      \
+                row = i; v = x;                                                                 \
+                break;                                                                          \
+            case KO_R_MAX: /* :256-266 replace iff unseen || r.v < v */                         \
+                if (!seen || v < x) { row = i; v = x; }                                         \
+                break;                                                                          \
+            case KO_R_MIN: /* :286-296 replace iff unseen || r.v > v */                         \
+                if (!seen || v > x) { row = i; v = x; }                                         \
+                break;                                                                          \
+            case KO_R_MEAN: { /* :318-331 Welford */                                            \
+                if (cnt == 0) row = i;                                                          \
+                cnt++;                                                                          \
+                double delta = (double)x - mean;                                                \
+                mean += delta / (double)cnt;                                                    \
+                break;                                                                          \
+            }                                                                                   \
+            case KO_R_VAR: case KO_R_STD: { /* :352-429 */                                      \
+                if (cnt == 0) row = i;                                                          \
+                cnt++;                                                                          \
+                double delta = (double)x - mean;                                                \
+                mean += delta / (double)cnt;                                                    \
+                m2 += delta * ((double)x - mean);                                               \
+                break;                                                                          \
+            }                                                                                   \
+            default: return -1;                                                                 \
+            }                                                                                   \
+            seen = 1;                                                                           \
+        }                                                                                       \
+        T r = v;                                                                                \
+        if (func == KO_R_MEAN) r = (T)mean; /* Value() = T(r.mean) :339 */                      \
+        if (func == KO_R_VAR) r = (cnt < 2) ? (T)NAN : (T)(m2 / (double)(cnt - 1));             \
+        if (func == KO_R_STD) r = (cnt < 2) ? (T)NAN : (T)sqrt(m2 / (double)(cnt - 1));         \
+        memcpy(out, &r, sizeof(T));                                                             \
+        if (row_out) *row_out = row;                                                            \
+        return seen;                                                                            \
+    }
+
+/* Go converts NaN/out-of-range float->int implementation-defined; the path never feeds
+ * var/std of <2 rows into an integer column in the tests, keep the cast quiet. */
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Woverflow"
+KO_REDUCE(reduce_i64, int64_t)
+KO_REDUCE(reduce_i32, int32_t)
+KO_REDUCE(reduce_i16, int16_t)
+KO_REDUCE(reduce_i8, int8_t)
+KO_REDUCE(reduce_u64, uint64_t)
+KO_REDUCE(reduce_u32, uint32_t)
+KO_REDUCE(reduce_u16, uint16_t)
+KO_REDUCE(reduce_u8, uint8_t)
+KO_REDUCE(reduce_f64, double)
+KO_REDUCE(reduce_f32, float)
+#pragma GCC diagnostic pop
+
+KO_EXPORT int ko_reduce(int dtype, int func, const void *src, int64_t n, const uint8_t *bits, void *out,
+                        int64_t *row_out) {
+    switch (dtype) {
+    case KO_I64: return reduce_i64(func, (const int64_t *)src, n, bits, out, row_out);
+    case KO_I32: return reduce_i32(func, (const int32_t *)src, n, bits, out, row_out);
+    case KO_I16: return reduce_i16(func, (const int16_t *)src, n, bits, out, row_out);
+    case KO_I8:  return reduce_i8(func, (const int8_t *)src, n, bits, out, row_out);
+    case KO_U64: return reduce_u64(func, (const uint64_t *)src, n, bits, out, row_out);
+    case KO_U32: return reduce_u32(func, (const uint32_t *)src, n, bits, out, row_out);
+    case KO_U16: return reduce_u16(func, (const uint16_t *)src, n, bits, out, row_out);
+    case KO_U8:  return reduce_u8(func, (const uint8_t *)src, n, bits, out, row_out);
+    case KO_F64: return reduce_f64(func, (const double *)src, n, bits, out, row_out);
+    case KO_F32: return reduce_f32(func, (const float *)src, n, bits, out, row_out);
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exact-arithmetic checker for float64 sum / mean (no reference counterpart: this is the
+ * yardstick for the "<= 1 ulp" gate, SURVEY.md section 7 "Float aggregate parity").
+ * A 2240-bit two's-complement fixed-point accumulator with LSB = 2^-1074 holds the exact sum
+ * of any number of finite doubles; conversion back rounds to nearest-even ONCE.
+ * ---------------------------------------------------------------------------------------- */
+#define KO_ACC_LIMBS 36
+typedef struct { uint64_t w[KO_ACC_LIMBS]; int has_nan, has_pinf, has_ninf; } ko_acc;
+
+static void acc_add_shifted(ko_acc *a, uint64_t m, int shift, int negative) {
+    int li = shift >> 6, off = shift & 63;
+    uint64_t lo = m << off, hi = off ? (m >> (64 - off)) : 0;
+    if (!negative) {
+        unsigned __int128 c = (unsigned __int128)a->w[li] + lo;
+        a->w[li] = (uint64_t)c;
+        c = (unsigned __int128)a->w[li + 1] + hi + (uint64_t)(c >> 64);
+        a->w[li + 1] = (uint64_t)c;
+        uint64_t carry = (uint64_t)(c >> 64);
+        for (int i = li + 2; carry && i < KO_ACC_LIMBS; i++) {
+            a->w[i] += carry;
+            carry = (a->w[i] == 0);
+        }
+    } else {
+        uint64_t borrow = a->w[li] < lo;
+        a->w[li] -= lo;
+        uint64_t t = a->w[li + 1], s = hi + borrow; /* hi < 2^63 so no overflow */
+        borrow = t < s;
+        a->w[li + 1] = t - s;
+        for (int i = li + 2; borrow && i < KO_ACC_LIMBS; i++) {
+            borrow = (a->w[i] == 0);
+            a->w[i] -= 1;
+        }
+    }
+}
+static void acc_add(ko_acc *a, double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    int e = (int)((u >> 52) & 0x7ff);
+    uint64_t m = u & 0xfffffffffffffULL;
+    int neg = (int)(u >> 63);
+    if (e == 0x7ff) {
+        if (m) a->has_nan = 1; else if (neg) a->has_ninf = 1; else a->has_pinf = 1;
+        return;
+    }
+    if (e == 0) { if (!m) return; acc_add_shifted(a, m, 0, neg); return; }
+    acc_add_shifted(a, m | (1ULL << 52), e - 1, neg);
+}
+/* |value| of a non-negative limb array with an extra sticky flag -> nearest-even double */
+static double limbs_to_double(const uint64_t *w, int sticky_in) {
+    int top = KO_ACC_LIMBS - 1;
+    while (top >= 0 && w[top] == 0) top--;
+    if (top < 0) return 0.0;
+    int msb = top * 64 + (63 - __builtin_clzll(w[top])); /* bit index of the leading one */
+    if (msb <= 52) { /* fits exactly (denormal or small normal): value = w[0] * 2^-1074 */
+        return ldexp((double)w[0], -1074);
+    }
+    int lsb = msb - 52; /* lowest kept bit */
+    uint64_t mant = 0;
+    for (int b = msb; b >= lsb; b--) mant = (mant << 1) | ((w[b >> 6] >> (b & 63)) & 1);
+    int rb = lsb - 1;
+    int round_bit = (int)((w[rb >> 6] >> (rb & 63)) & 1);
+    int sticky = sticky_in;
+    for (int b = rb - 1; b >= 0 && !sticky; b--) sticky |= (int)((w[b >> 6] >> (b & 63)) & 1);
+    if (round_bit && (sticky || (mant & 1))) mant++;
+    return ldexp((double)mant, lsb - 1074); /* mant may be 2^53: ldexp handles it, inf on overflow */
+}
+static double acc_result(const ko_acc *a, int64_t div_n) {
+    if (a->has_nan || (a->has_pinf && a->has_ninf)) return NAN;
+    if (a->has_pinf) return INFINITY;
+    if (a->has_ninf) return -INFINITY;
+    uint64_t w[KO_ACC_LIMBS];
+    memcpy(w, a->w, sizeof w);
+    int neg = (int)(w[KO_ACC_LIMBS - 1] >> 63);
+    if (neg) { /* two's complement negate */
+        uint64_t carry = 1;
+        for (int i = 0; i < KO_ACC_LIMBS; i++) {
+            w[i] = ~w[i] + carry;
+            carry = (carry && w[i] == 0);
+        }
+    }
+    int sticky = 0;
+    if (div_n > 1) { /* long division by a 63-bit divisor, remainder -> sticky */
+        unsigned __int128 rem = 0;
+        for (int i = KO_ACC_LIMBS - 1; i >= 0; i--) {
+            unsigned __int128 cur = (rem << 64) | w[i];
+            w[i] = (uint64_t)(cur / (uint64_t)div_n);
+            rem = cur % (uint64_t)div_n;
+        }
+        sticky = rem != 0;
+    }
+    double r = limbs_to_double(w, sticky);
+    return neg ? -r : r;
+}
+/* exact sum (and exact_sum / count, rounded once) of the selected float64 rows */
+KO_EXPORT int64_t ko_exact_sum_f64(const double *src, int64_t n, const uint8_t *bits, double *sum_out,
+                                   double *mean_out) {
+    ko_acc a;
+    memset(&a, 0, sizeof a);
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (!KO_SELECTED(i)) continue;
+        acc_add(&a, src[i]);
+        cnt++;
+    }
+    if (sum_out) *sum_out = acc_result(&a, 1);
+    if (mean_out) *mean_out = cnt ? acc_result(&a, cnt) : 0.0;
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * xxh3 for fixed-width integers: internal/hash/xxh3.go:11-58, :244-254
+ * ---------------------------------------------------------------------------------------- */
+#define KEY32_000 0xbe4ba423ULL
+#define KEY32_004 0x396cfeb8ULL
+#define KEY64_008 0x1cad21f72c81017cULL
+#define KEY64_016 0xdb979083e96dd4deULL
+#define PRIME64_2 14029467366897019727ULL
+#define PRIME64_3 1609587929392839161ULL
+static inline uint64_t rol64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t avalanche_small(uint64_t x) { /* :247-254 */
+    x ^= x >> 33; x *= PRIME64_2; x ^= x >> 29; x *= PRIME64_3; x ^= x >> 32;
+    return x;
+}
+KO_EXPORT uint64_t ko_xxh3_u64(uint64_t val) { /* :22-33 */
+    uint64_t input64 = (val >> 32) + (val << 32);
+    uint64_t h = input64 ^ (KEY64_008 ^ KEY64_016);
+    h ^= rol64(h, 49) ^ rol64(h, 24);
+    h *= 0x9fb21c651e98df25ULL;
+    h ^= (h >> 35) + 8;
+    h *= 0x9fb21c651e98df25ULL;
+    h ^= (h >> 28);
+    return h;
+}
+KO_EXPORT uint64_t ko_xxh3_u32(uint32_t val) { /* :35-46 */
+    uint64_t input64 = (uint64_t)val + ((uint64_t)val << 32);
+    uint64_t h = input64 ^ (KEY64_008 ^ KEY64_016);
+    h ^= rol64(h, 49) ^ rol64(h, 24);
+    h *= 0x9fb21c651e98df25ULL;
+    h ^= (h >> 35) + 4;
+    h *= 0x9fb21c651e98df25ULL;
+    h ^= (h >> 28);
+    return h;
+}
+KO_EXPORT uint64_t ko_xxh3_u16(uint16_t val) { /* :48-52  uint64(val)*(1<<24+1)>>8 + 2<<8 */
+    uint64_t h = (((uint64_t)val * ((1ULL << 24) + 1)) >> 8) + (2ULL << 8);
+    h ^= KEY32_000 ^ KEY32_004;
+    return avalanche_small(h);
+}
+KO_EXPORT uint64_t ko_xxh3_u8(uint8_t val) { /* :54-58  uint64(val)*(1<<24+1<<16+1) + 1<<8 */
+    uint64_t h = ((uint64_t)val * ((1ULL << 24) + (1ULL << 16) + 1)) + (1ULL << 8);
+    h ^= KEY32_000 ^ KEY32_004;
+    return avalanche_small(h);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * XXH3-64 of a byte string, seed 0, default secret -- hash.Hash = zeebo/xxh3.Hash
+ * (internal/hash/hash.go:26; dependency github.com/zeebo/xxh3 v1.1.0, go.mod:18, NOT vendored).
+ * Restated from the published XXH3 specification (xxHash v0.8 doc/xxhash_spec.md).
+ * ---------------------------------------------------------------------------------------- */
+static const uint8_t K_SECRET[192] = {
+    0xb8, 0xfe, 0x6c, 0x39, 0x23, 0xa4, 0x4b, 0xbe, 0x7c, 0x01, 0x81, 0x2c, 0xf7, 0x21, 0xad, 0x1c,
+    0xde, 0xd4, 0x6d, 0xe9, 0x83, 0x90, 0x97, 0xdb, 0x72, 0x40, 0xa4, 0xa4, 0xb7, 0xb3, 0x67, 0x1f,
+    0xcb, 0x79, 0xe6, 0x4e, 0xcc, 0xc0, 0xe5, 0x78, 0x82, 0x5a, 0xd0, 0x7d, 0xcc, 0xff, 0x72, 0x21,
+    0xb8, 0x08, 0x46, 0x74, 0xf7, 0x43, 0x24, 0x8e, 0xe0, 0x35, 0x90, 0xe6, 0x81, 0x3a, 0x26, 0x4c,
+    0x3c, 0x28, 0x52, 0xbb, 0x91, 0xc3, 0x00, 0xcb, 0x88, 0xd0, 0x65, 0x8b, 0x1b, 0x53, 0x2e, 0xa3,
+    0x71, 0x64, 0x48, 0x97, 0xa2, 0x0d, 0xf9, 0x4e, 0x38, 0x19, 0xef, 0x46, 0xa9, 0xde, 0xac, 0xd8,
+    0xa8, 0xfa, 0x76, 0x3f, 0xe3, 0x9c, 0x34, 0x3f, 0xf9, 0xdc, 0xbb, 0xc7, 0xc7, 0x0b, 0x4f, 0x1d,
+    0x8a, 0x51, 0xe0, 0x4b, 0xcd, 0xb4, 0x59, 0x31, 0xc8, 0x9f, 0x7e, 0xc9, 0xd9, 0x78, 0x73, 0x64,
+    0xea, 0xc5, 0xac, 0x83, 0x34, 0xd3, 0xeb, 0xc3, 0xc5, 0x81, 0xa0, 0xff, 0xfa, 0x13, 0x63, 0xeb,
+    0x17, 0x0d, 0xdd, 0x51, 0xb7, 0xf0, 0xda, 0x49, 0xd3, 0x16, 0x55, 0x26, 0x29, 0xd4, 0x68, 0x9e,
+    0x2b, 0x16, 0xbe, 0x58, 0x7d, 0x47, 0xa1, 0xfc, 0x8f, 0xf8, 0xb8, 0xd1, 0x7a, 0xd0, 0x31, 0xce,
+    0x45, 0xcb, 0x3a, 0x8f, 0x95, 0x16, 0x04, 0x28, 0xaf, 0xd7, 0xfb, 0xca, 0xbb, 0x4b, 0x40, 0x7e,
+};
+#define XP32_1 0x9E3779B1U
+#define XP32_2 0x85EBCA77U
+#define XP32_3 0xC2B2AE3DU
+#define XP64_1 0x9E3779B185EBCA87ULL
+#define XP64_2 0xC2B2AE3D27D4EB4FULL
+#define XP64_3 0x165667B19E3779F9ULL
+#define XP64_4 0x85EBCA77C2B2AE63ULL
+#define XP64_5 0x27D4EB2F165667C5ULL
+#define XPMX1 0x165667919E3779F9ULL
+#define XPMX2 0x9FB21C651E98DF25ULL
+static inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint64_t mul128_fold64(uint64_t a, uint64_t b) {
+    unsigned __int128 p = (unsigned __int128)a * b;
+    return (uint64_t)p ^ (uint64_t)(p >> 64);
+}
+static inline uint64_t xxh64_avalanche(uint64_t h) {
+    h ^= h >> 33; h *= XP64_2; h ^= h >> 29; h *= XP64_3; h ^= h >> 32;
+    return h;
+}
+static inline uint64_t xxh3_avalanche(uint64_t h) {
+    h ^= h >> 37; h *= XPMX1; h ^= h >> 32;
+    return h;
+}
+static inline uint64_t rrmxmx(uint64_t h, uint64_t len) {
+    h ^= rol64(h, 49) ^ rol64(h, 24);
+    h *= XPMX2;
+    h ^= (h >> 35) + len;
+    h *= XPMX2;
+    return h ^ (h >> 28);
+}
+static inline uint64_t mix16(const uint8_t *in, const uint8_t *sec) {
+    return mul128_fold64(rd64(in) ^ rd64(sec), rd64(in + 8) ^ rd64(sec + 8));
+}
+static void xxh3_accumulate_512(uint64_t *acc, const uint8_t *in, const uint8_t *sec) {
+    for (int i = 0; i < 8; i++) {
+        uint64_t dv = rd64(in + 8 * i), dk = dv ^ rd64(sec + 8 * i);
+        acc[i ^ 1] += dv;
+        acc[i] += (dk & 0xFFFFFFFFULL) * (dk >> 32);
+    }
+}
+static void xxh3_scramble(uint64_t *acc, const uint8_t *sec) {
+    for (int i = 0; i < 8; i++) {
+        uint64_t a = acc[i];
+        a ^= a >> 47;
+        a ^= rd64(sec + 8 * i);
+        a *= XP32_1;
+        acc[i] = a;
+    }
+}
+static uint64_t xxh3_merge(const uint64_t *acc, const uint8_t *sec, uint64_t start) {
+    uint64_t r = start;
+    for (int i = 0; i < 4; i++) r += mul128_fold64(acc[2 * i] ^ rd64(sec + 16 * i), acc[2 * i + 1] ^ rd64(sec + 16 * i + 8));
+    return xxh3_avalanche(r);
+}
+KO_EXPORT uint64_t ko_xxh3_bytes(const uint8_t *in, int64_t len) {
+    const uint8_t *s = K_SECRET;
+    if (len == 0) return xxh64_avalanche(rd64(s + 56) ^ rd64(s + 64));
+    if (len <= 3) {
+        uint8_t c1 = in[0], c2 = in[len >> 1], c3 = in[len - 1];
+        uint32_t comb = ((uint32_t)c1 << 16) | ((uint32_t)c2 << 24) | (uint32_t)c3 | ((uint32_t)len << 8);
+        uint64_t flip = (uint64_t)(rd32(s) ^ rd32(s + 4));
+        return xxh64_avalanche((uint64_t)comb ^ flip);
+    }
+    if (len <= 8) {
+        uint32_t i1 = rd32(in), i2 = rd32(in + len - 4);
+        uint64_t flip = rd64(s + 8) ^ rd64(s + 16);
+        uint64_t i64 = (uint64_t)i2 + ((uint64_t)i1 << 32);
+        return rrmxmx(i64 ^ flip, (uint64_t)len);
+    }
+    if (len <= 16) {
+        uint64_t f1 = rd64(s + 24) ^ rd64(s + 32), f2 = rd64(s + 40) ^ rd64(s + 48);
+        uint64_t lo = rd64(in) ^ f1, hi = rd64(in + len - 8) ^ f2;
+        uint64_t acc = (uint64_t)len + __builtin_bswap64(lo) + hi + mul128_fold64(lo, hi);
+        return xxh3_avalanche(acc);
+    }
+    if (len <= 128) {
+        uint64_t acc = (uint64_t)len * XP64_1;
+        if (len > 32) {
+            if (len > 64) {
+                if (len > 96) { acc += mix16(in + 48, s + 96); acc += mix16(in + len - 64, s + 112); }
+                acc += mix16(in + 32, s + 64); acc += mix16(in + len - 48, s + 80);
+            }
+            acc += mix16(in + 16, s + 32); acc += mix16(in + len - 32, s + 48);
+        }
+        acc += mix16(in, s); acc += mix16(in + len - 16, s + 16);
+        return xxh3_avalanche(acc);
+    }
+    if (len <= 240) {
+        uint64_t acc = (uint64_t)len * XP64_1;
+        int rounds = (int)(len / 16);
+        for (int i = 0; i < 8; i++) acc += mix16(in + 16 * i, s + 16 * i);
+        acc = xxh3_avalanche(acc);
+        for (int i = 8; i < rounds; i++) acc += mix16(in + 16 * i, s + 16 * (i - 8) + 3);
+        acc += mix16(in + len - 16, s + 136 - 17);
+        return xxh3_avalanche(acc);
+    }
+    uint64_t acc[8] = {XP32_3, XP64_1, XP64_2, XP64_3, XP64_4, XP32_2, XP64_5, XP32_1};
+    const int64_t stripes_per_block = (192 - 64) / 8, block_len = 64 * stripes_per_block;
+    int64_t nblocks = (len - 1) / block_len;
+    for (int64_t b = 0; b < nblocks; b++) {
+        for (int64_t t = 0; t < stripes_per_block; t++) xxh3_accumulate_512(acc, in + b * block_len + t * 64, s + t * 8);
+        xxh3_scramble(acc, s + 192 - 64);
+    }
+    int64_t nstripes = ((len - 1) - block_len * nblocks) / 64;
+    for (int64_t t = 0; t < nstripes; t++) xxh3_accumulate_512(acc, in + nblocks * block_len + t * 64, s + t * 8);
+    xxh3_accumulate_512(acc, in + len - 64, s + 192 - 64 - 7);
+    return xxh3_merge(acc, s + 11, (uint64_t)len * XP64_1);
+}
+
+/* hash.HashT internal/hash/hash.go:67-92: ints hash their unsigned bit pattern by width,
+ * floats hash their IEEE bytes with the []byte hash (:45-53). */
+KO_EXPORT uint64_t ko_hash_value(int dtype, const void *val) {
+    switch (dtype) {
+    case KO_I64: case KO_U64: { uint64_t v; memcpy(&v, val, 8); return ko_xxh3_u64(v); }
+    case KO_I32: case KO_U32: { uint32_t v; memcpy(&v, val, 4); return ko_xxh3_u32(v); }
+    case KO_I16: case KO_U16: { uint16_t v; memcpy(&v, val, 2); return ko_xxh3_u16(v); }
+    case KO_I8:  case KO_U8:  { uint8_t v;  memcpy(&v, val, 1); return ko_xxh3_u8(v); }
+    case KO_F64: return ko_xxh3_bytes((const uint8_t *)val, 8);
+    case KO_F32: return ko_xxh3_bytes((const uint8_t *)val, 4);
+    default: return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bloom filter: internal/filter/bloom/bloom.go:46-60 (NewFilter), :130-176 (probe/add, k=4),
+ * :182-184 (Contains).  Serialized form = [k][m/8 bytes], m a power of two.
+ * ---------------------------------------------------------------------------------------- */
+KO_EXPORT int64_t ko_bloom_pow2(int64_t m) { /* bloom.go:242-249 pow2(): next power of two >= m, minimum 8 */
+    int64_t p = 8;
+    while (p < m) p <<= 1;
+    return p;
+}
+KO_EXPORT void ko_bloom_add(uint8_t *buf, int64_t buf_len, uint64_t h) { /* addUnroll4 :162-169 */
+    uint8_t *bits = buf + 1;
+    uint32_t mask = (uint32_t)((buf_len - 1) * 8 - 1), h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+    for (int i = 0; i < (int)buf[0]; i++) {
+        bits[(h0 & mask) >> 3] |= (uint8_t)(1 << (h0 & 7));
+        h0 += h1;
+    }
+}
+KO_EXPORT int ko_bloom_contains(const uint8_t *buf, int64_t buf_len, uint64_t h) { /* :136-150, :182 */
+    const uint8_t *bits = buf + 1;
+    uint32_t mask = (uint32_t)((buf_len - 1) * 8 - 1), h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+    for (int i = 0; i < (int)buf[0]; i++) {
+        if ((bits[(h0 & mask) >> 3] & (1 << (h0 & 7))) == 0) return 0;
+        h0 += h1;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bytes column: pkg/stringx/pool.go:45-58 (ptr = off<<32 | len), match.go:20-84
+ * mask == NULL: every byte of bits (incl. partial last byte) is overwritten, returns count.
+ * mask != NULL: only bits.Set(i) for mask-selected matching rows, returns -1 (count unknown).
+ * ---------------------------------------------------------------------------------------- */
+KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const uint8_t *buf, const uint8_t *val,
+                                 int64_t vlen, uint8_t *bits, const uint8_t *mask) {
+    int want_eq = (op == KO_EQ);
+    if (op != KO_EQ && op != KO_NE) return -2;
+    if (mask) {
+        for (int64_t i = 0; i < n; i++) {
+            if (!((mask[i >> 3] >> (i & 7)) & 1)) continue;
+            uint32_t ofs = (uint32_t)(ptr[i] >> 32), len = (uint32_t)ptr[i];
+            int eq = (len == (uint32_t)vlen) && (len == 0 || memcmp(buf + ofs, val, len) == 0);
+            if (eq == want_eq) bits[i >> 3] |= (uint8_t)(1 << (i & 7));
+        }
+        return -1;
+    }
+    int64_t cnt = 0;
+    uint8_t b = 0;
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t ofs = (uint32_t)(ptr[i] >> 32), len = (uint32_t)ptr[i];
+        int k = (int)(i & 7);
+        int eq = (len == (uint32_t)vlen) && (len == 0 || memcmp(buf + ofs, val, len) == 0);
+        uint8_t bit = (uint8_t)(eq == want_eq);
+        b |= (uint8_t)(bit << k);
+        cnt += bit;
+        if (k == 7) { bits[i >> 3] = b; b = 0; }
+    }
+    if ((n & 7) > 0) bits[n >> 3] = b;
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic column generator (shared SPEC with the device generator in
+ * knoxdb_amd/csrc/knox_kernels.hip: both sides implement DESIGN.md "synthetic data" from the
+ * text, neither calls the other).  Counter based so any row can be produced independently:
+ *   r(i) = mix64(i + mix64(seed)),  mix64 = splitmix64 finalizer with the golden-gamma add.
+ * kinds: 0 uniform int in [lo, lo+span) via mulhi (span==0 -> raw r); 1 float64 grid
+ * k*2^-10, k in [0,2^20); 2 float64 uniform [0,1) = (r>>11)*2^-53; 3 row id (+lo);
+ * 4 float64 "semantic" mix: 2^-20 of rows are NaN/+Inf/-Inf/-0/+0, the rest uniform in
+ * [-2^20, 2^20).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static inline uint64_t gen_u64(int kind, uint64_t seedmix, uint64_t i, int64_t lo, uint64_t span) {
+    uint64_t r = mix64(i + seedmix);
+    switch (kind) {
+    case 0: return span ? (uint64_t)lo + (uint64_t)(((unsigned __int128)r * span) >> 64) : r;
+    case 1: { double d = (double)(r >> 44) * 0x1p-10; uint64_t u; memcpy(&u, &d, 8); return u; }
+    case 2: { double d = (double)(r >> 11) * 0x1p-53; uint64_t u; memcpy(&u, &d, 8); return u; }
+    case 3: return i + (uint64_t)lo;
+    case 4: {
+        if ((r & 0xfffff) == 0) {
+            static const uint64_t sp[5] = {0x7ff8000000000000ULL, 0x7ff0000000000000ULL, 0xfff0000000000000ULL,
+                                           0x8000000000000000ULL, 0x0000000000000000ULL};
+            return sp[(r >> 20) % 5];
+        }
+        double d = ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0x1p21;
+        uint64_t u; memcpy(&u, &d, 8); return u;
+    }
+    default: return 0;
+    }
+}
+KO_EXPORT int ko_generate(int dtype, int kind, uint64_t seed, int64_t first_row, int64_t n, int64_t lo,
+                          uint64_t span, void *dst) {
+    uint64_t sm = mix64(seed);
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t u = gen_u64(kind, sm, (uint64_t)(first_row + i), lo, span);
+        switch (dtype) {
+        case KO_I64: case KO_U64: case KO_F64: ((uint64_t *)dst)[i] = u; break;
+        case KO_I32: case KO_U32: ((uint32_t *)dst)[i] = (uint32_t)u; break;
+        case KO_F32: { double d; memcpy(&d, &u, 8); ((float *)dst)[i] = (kind == 1 || kind == 2 || kind == 4) ? (float)d : (float)(int64_t)u; break; }
+        case KO_I16: case KO_U16: ((uint16_t *)dst)[i] = (uint16_t)u; break;
+        case KO_I8: case KO_U8: ((uint8_t *)dst)[i] = (uint8_t)u; break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CPU baseline leg ("port"): what the reference does for `Between + sum` on one materialized
+ * int64 pack -- cmp kernel -> bitset (match_num.go:559-566 -> cmp.Int64Between), bitset ->
+ * selection vector (reader.go:432 bits.Indexes), then one SumReducer.Reduce per selected row
+ * (result.go:134-150 -> reducer.go:173).  Scalar, single thread, like the reference's
+ * one-goroutine pack loop (pack/table/query.go:195-219).
+ * ---------------------------------------------------------------------------------------- */
+KO_EXPORT int64_t ko_scan_i64_bw_sum(const int64_t *src, int64_t n, int64_t pack_rows, int64_t a, int64_t b,
+                                     uint8_t *bits, uint32_t *sel_scratch, int64_t *sum_out) {
+    int64_t total = 0, sum = 0;
+    for (int64_t p = 0; p < n; p += pack_rows) {
+        int64_t len = (n - p < pack_rows) ? n - p : pack_rows;
+        uint8_t *pb = bits + (p >> 3);
+        memset(pb, 0, (size_t)bit_field_len(len));
+        int64_t cnt = cmp_i64_bw(src + p, len, a, b, pb);
+        if (cnt == 0) continue; /* reader.go:338 bits.None() -> skip pack */
+        int64_t k = ko_bits_indexes(pb, len, sel_scratch);
+        for (int64_t j = 0; j < k; j++) sum = (int64_t)((uint64_t)sum + (uint64_t)src[p + sel_scratch[j]]);
+        total += cnt;
+    }
+    *sum_out = sum;
+    return total;
+}

@@ -1,0 +1,213 @@
+"""ctypes binding of the CPU oracle (oracle/knox_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py -- never by anything under knoxdb_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libknox_oracle.so")
+
+# enums shared with the reference (internal/types/block.go:20-36, mode.go:13-27)
+I64, I32, I16, I8, U64, U32, U16, U8, F64, F32, BYTES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12
+EQ, NE, GT, GE, LT, LE, RG = 1, 2, 3, 4, 5, 6, 9
+R_SUM, R_FIRST, R_LAST, R_MIN, R_MAX, R_MEAN, R_VAR, R_STD, R_COUNT = range(9)
+
+NP = {I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8, U64: np.uint64, U32: np.uint32,
+      U16: np.uint16, U8: np.uint8, F64: np.float64, F32: np.float32}
+NAME = {"i64": I64, "i32": I32, "i16": I16, "i8": I8, "u64": U64, "u32": U32, "u16": U16, "u8": U8,
+        "f64": F64, "f32": F32}
+OPNAME = {"eq": EQ, "ne": NE, "gt": GT, "ge": GE, "lt": LT, "le": LE, "bw": RG}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "knox_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, i64, u64, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int
+        L.ko_cmp.restype = i64
+        L.ko_cmp.argtypes = [i32, i32, vp, i64, vp, vp, vp]
+        for f in ("and", "andnot", "or", "xor"):
+            getattr(L, "ko_bits_" + f).restype = None
+            getattr(L, "ko_bits_" + f).argtypes = [vp, vp, i64]
+        L.ko_bits_neg.restype = None
+        L.ko_bits_neg.argtypes = [vp, i64]
+        L.ko_bits_one.restype = None
+        L.ko_bits_one.argtypes = [vp, i64]
+        for f in ("and_flag", "or_flag"):
+            getattr(L, "ko_bits_" + f).restype = i32
+            getattr(L, "ko_bits_" + f).argtypes = [vp, vp, i64]
+        L.ko_bits_popcount.restype = i64
+        L.ko_bits_popcount.argtypes = [vp, i64]
+        L.ko_bits_indexes.restype = i64
+        L.ko_bits_indexes.argtypes = [vp, i64, vp]
+        L.ko_reduce.restype = i32
+        L.ko_reduce.argtypes = [i32, i32, vp, i64, vp, vp, C.POINTER(i64)]
+        L.ko_exact_sum_f64.restype = i64
+        L.ko_exact_sum_f64.argtypes = [vp, i64, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for f, t in (("u64", u64), ("u32", C.c_uint32), ("u16", C.c_uint16), ("u8", C.c_uint8)):
+            getattr(L, "ko_xxh3_" + f).restype = u64
+            getattr(L, "ko_xxh3_" + f).argtypes = [t]
+        L.ko_xxh3_bytes.restype = u64
+        L.ko_xxh3_bytes.argtypes = [C.c_char_p, i64]
+        L.ko_hash_value.restype = u64
+        L.ko_hash_value.argtypes = [i32, vp]
+        L.ko_bloom_pow2.restype = i64
+        L.ko_bloom_pow2.argtypes = [i64]
+        L.ko_bloom_add.restype = None
+        L.ko_bloom_add.argtypes = [vp, i64, u64]
+        L.ko_bloom_contains.restype = i32
+        L.ko_bloom_contains.argtypes = [vp, i64, u64]
+        L.ko_bytes_match.restype = i64
+        L.ko_bytes_match.argtypes = [i32, vp, i64, vp, C.c_char_p, i64, vp, vp]
+        L.ko_generate.restype = i32
+        L.ko_generate.argtypes = [i32, i32, u64, i64, i64, i64, u64, vp]
+        L.ko_scan_i64_bw_sum.restype = i64
+        L.ko_scan_i64_bw_sum.argtypes = [vp, i64, i64, i64, i64, vp, vp, C.POINTER(i64)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def bitfield_len(n):
+    return (n + 7) >> 3
+
+
+def cmp(dtype, op, src, a, b=None, poison=0):
+    """Run a compare kernel; returns (bits ndarray[(n+7)/8], count).  With poison=k the buffer
+    carries k trailing 0xfa bytes that are asserted untouched (cmp/tests/tests.go:24-48)."""
+    src = np.ascontiguousarray(src, dtype=NP[dtype])
+    n = src.size
+    buf = np.zeros(bitfield_len(n) + poison, dtype=np.uint8)
+    buf[bitfield_len(n):] = 0xFA
+    av = np.array([a], dtype=NP[dtype])
+    bv = np.array([b if b is not None else 0], dtype=NP[dtype])
+    cnt = lib().ko_cmp(dtype, op, _p(src) if n else None, n, _p(av), _p(bv), _p(buf))
+    assert (buf[bitfield_len(n):] == 0xFA).all(), "boundary violation"
+    return buf[:bitfield_len(n)], cnt
+
+
+def bits_op(name, dst, src, size):
+    dst = np.array(dst, dtype=np.uint8, copy=True)
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    getattr(lib(), "ko_bits_" + name)(_p(dst), _p(src), size)
+    return dst
+
+
+def bits_flag_op(name, dst, src, size):
+    dst = np.array(dst, dtype=np.uint8, copy=True)
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    f = getattr(lib(), "ko_bits_" + name + "_flag")(_p(dst), _p(src), size)
+    return dst, bool(f & 1), bool(f & 2)
+
+
+def bits_neg(src, size):
+    d = np.array(src, dtype=np.uint8, copy=True)
+    lib().ko_bits_neg(_p(d), size)
+    return d
+
+
+def bits_one(size):
+    d = np.zeros(bitfield_len(size), dtype=np.uint8)
+    lib().ko_bits_one(_p(d), size)
+    return d
+
+
+def popcount(buf, size):
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    return lib().ko_bits_popcount(_p(buf) if buf.size else None, size)
+
+
+def indexes(buf, size):
+    buf = np.array(buf, dtype=np.uint8, copy=True)
+    out = np.zeros(size + 8, dtype=np.uint32)
+    k = lib().ko_bits_indexes(_p(buf) if buf.size else None, size, _p(out))
+    return out[:k].copy()
+
+
+def reduce(dtype, func, src, bits=None):
+    """Sequential reducer over selected rows; returns (value, seen, row)."""
+    src = np.ascontiguousarray(src, dtype=NP[dtype])
+    out = np.zeros(1, dtype=NP[dtype])
+    row = C.c_int64(-1)
+    b = np.ascontiguousarray(bits, dtype=np.uint8) if bits is not None else None
+    seen = lib().ko_reduce(dtype, func, _p(src), src.size, _p(b), _p(out), C.byref(row))
+    return out[0], bool(seen), row.value
+
+
+def exact_sum_f64(src, bits=None):
+    src = np.ascontiguousarray(src, dtype=np.float64)
+    s, m = C.c_double(), C.c_double()
+    b = np.ascontiguousarray(bits, dtype=np.uint8) if bits is not None else None
+    cnt = lib().ko_exact_sum_f64(_p(src), src.size, _p(b), C.byref(s), C.byref(m))
+    return s.value, m.value, cnt
+
+
+def xxh3_bytes(data):
+    return lib().ko_xxh3_bytes(bytes(data), len(data))
+
+
+def hash_value(dtype, val):
+    v = np.array([val], dtype=NP[dtype])
+    return lib().ko_hash_value(dtype, _p(v))
+
+
+def bloom_new(cardinality, factor):
+    """bloom.NewFilter(cardinality*factor*8) -> serialized [k=4][m/8 zero bytes]"""
+    m = lib().ko_bloom_pow2(cardinality * factor * 8)
+    buf = np.zeros(1 + (m >> 3), dtype=np.uint8)
+    buf[0] = 4
+    return buf
+
+
+def bloom_add(buf, h):
+    lib().ko_bloom_add(_p(buf), buf.size, h)
+
+
+def bloom_contains(buf, h):
+    return bool(lib().ko_bloom_contains(_p(buf), buf.size, h))
+
+
+def bytes_match(op, ptr, buf, val, mask=None, bits=None):
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    n = ptr.size
+    out = np.zeros(bitfield_len(n), dtype=np.uint8) if bits is None else np.array(bits, dtype=np.uint8, copy=True)
+    m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+    cnt = lib().ko_bytes_match(op, _p(ptr), n, _p(buf), bytes(val), len(val), _p(out), _p(m))
+    return out, cnt
+
+
+def generate(dtype, kind, seed, first_row, n, lo=0, span=0):
+    out = np.zeros(n, dtype=NP[dtype])
+    rc = lib().ko_generate(dtype, kind, seed, first_row, n, lo, span, _p(out))
+    assert rc == 0
+    return out
+
+
+def scan_i64_bw_sum(src, pack_rows, a, b):
+    src = np.ascontiguousarray(src, dtype=np.int64)
+    n = src.size
+    bits = np.zeros(bitfield_len(n), dtype=np.uint8)
+    sel = np.zeros(pack_rows + 8, dtype=np.uint32)
+    s = C.c_int64()
+    cnt = lib().ko_scan_i64_bw_sum(_p(src), n, pack_rows, a, b, _p(bits), _p(sel), C.byref(s))
+    return bits, cnt, s.value

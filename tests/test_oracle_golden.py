@@ -1,0 +1,157 @@
+"""The CPU oracle against every golden vector the reference's own tests hold for the path
+(SURVEY.md 8c).  Mirrors internal/cmp/tests/tests.go:24-48 (count, exact bytes, poison tail),
+internal/bitset/generic/bitset_test.go, internal/hash/xxh3_test.go."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CMP = json.load(open(os.path.join(G, "cmp_cases.json")))["cases"]
+BITS = json.load(open(os.path.join(G, "bitset_cases.json")))
+
+
+def _src(c):
+    dt = O.NAME[c["dtype"]]
+    if c["dtype"] == "f64":
+        return np.array(c["src"], dtype=np.uint64).view(np.float64), dt
+    if c["dtype"] == "f32":
+        return np.array(c["src"], dtype=np.uint32).view(np.float32), dt
+    return np.array(c["src"], dtype=O.NP[dt]), dt
+
+
+def _scalar(c, key):
+    if c["dtype"] == "f64":
+        return np.array([c[key]], dtype=np.uint64).view(np.float64)[0]
+    if c["dtype"] == "f32":
+        return np.array([c[key]], dtype=np.uint32).view(np.float32)[0]
+    return c[key]
+
+
+@pytest.mark.parametrize("dtype", sorted(O.NAME))
+def test_cmp_golden(dtype):
+    cases = [c for c in CMP if c["dtype"] == dtype]
+    assert len(cases) > 100
+    for c in cases:
+        src, dt = _src(c)
+        bits, cnt = O.cmp(dt, O.OPNAME[c["op"]], src, _scalar(c, "a"), _scalar(c, "b"), poison=32)
+        tag = "%s/%s/%s" % (dtype, c["op"], c["name"])
+        assert cnt == c["count"], tag
+        assert bits.tobytes().hex() == c["result"], tag
+
+
+def test_popcount_cases():
+    for c in BITS["pop"]:
+        src = np.frombuffer(bytes.fromhex(c["source"]), dtype=np.uint8)
+        assert O.popcount(src, c["size"]) == c["count"], c["name"]
+
+
+def _fill(size, val):
+    b = np.full(O.bitfield_len(size), val, dtype=np.uint8)
+    if b.size:
+        b[-1] &= 0xFF >> (7 - ((size - 1) & 7))
+    return b
+
+
+def test_popcount_patterns():
+    # generic/bitset_test.go:31-47
+    for sz in BITS["sizes"]:
+        for pt in BITS["patterns"]:
+            buf = _fill(sz, pt)
+            assert O.popcount(buf, sz) == int(np.unpackbits(buf).sum())
+
+
+def test_indexes_cases():
+    for c in BITS["run"]:
+        buf = np.frombuffer(bytes.fromhex(c["buf"]), dtype=np.uint8)
+        idx = O.indexes(buf, c["size"])
+        assert idx.tolist() == c["idx"], c["name"]
+
+
+@pytest.mark.parametrize("op", ["and", "andnot", "or", "xor"])
+def test_combinators_vs_self_zeros_ones(op):
+    # generic/bitset_test.go:49-330: dst op src for src in {same, zeros, ones}
+    for sz in BITS["sizes"]:
+        zeros, ones = _fill(sz, 0), _fill(sz, 0xFF)
+        for pt in BITS["patterns"]:
+            src = _fill(sz, pt)
+            exp = {
+                "and": (src, zeros, src), "andnot": (zeros, src, zeros),
+                "or": (src, src, ones), "xor": (zeros, src, O.bits_neg(src, sz)),
+            }[op]
+            for other, want in zip((src, zeros, ones), exp):
+                got = O.bits_op(op, src, other, sz)
+                assert (got == want).all(), (op, sz, pt)
+
+
+def test_and_flag_or_flag():
+    # generic/bitset_test.go:101-211, :331-440: (any, all) over the valid bits
+    for sz in BITS["sizes"]:
+        zeros, ones = _fill(sz, 0), _fill(sz, 0xFF)
+        for pt in BITS["patterns"]:
+            src = _fill(sz, pt)
+            pc = int(np.unpackbits(src).sum())
+            d, any_, all_ = O.bits_flag_op("and", src, src, sz)
+            assert (d == src).all() and any_ == (pc > 0) and all_ == (pc == sz)
+            d, any_, all_ = O.bits_flag_op("and", src, zeros, sz)
+            assert (d == zeros).all() and not any_ and not all_
+            d, any_, all_ = O.bits_flag_op("and", src, ones, sz)
+            assert (d == src).all() and any_ == (pc > 0) and all_ == (pc == sz)
+            d, any_, all_ = O.bits_flag_op("or", src, zeros, sz)
+            assert (d == src).all() and any_ == (pc > 0) and all_ == (pc == sz)
+            d, any_, all_ = O.bits_flag_op("or", src, ones, sz)
+            assert (d == ones).all() and any_ and all_
+
+
+def test_neg():
+    for sz in BITS["sizes"]:
+        for pt in BITS["patterns"]:
+            src = _fill(sz, pt)
+            neg = O.bits_neg(src, sz)
+            assert int(np.unpackbits(neg).sum()) == sz - int(np.unpackbits(src).sum())
+            assert (O.bits_neg(neg, sz) == src).all()
+
+
+def test_xxh3_fixed_width_kat():
+    kat = json.load(open(os.path.join(G, "xxh3_kat.json")))
+    for i in range(8):
+        data = bytes(range(i, i + 8))
+        assert O.lib().ko_xxh3_u64(int.from_bytes(data, "little")) == kat["u64"][i]
+        assert O.lib().ko_xxh3_u32(int.from_bytes(data[:4], "little")) == kat["u32"][i]
+        # the []byte hash of the same 8 / 4 bytes is the same function (hash.go:45-53 vs :67-92)
+        assert O.xxh3_bytes(data) == kat["u64"][i]
+        assert O.xxh3_bytes(data[:4]) == kat["u32"][i]
+
+
+def test_xxh3_small_widths_match_bytes_hash():
+    # xxh3_u16 / xxh3_u8 are the 1-3 byte XXH3 path specialised (xxh3.go:48-58)
+    for v in (0, 1, 0x7F, 0x80, 0xFF):
+        assert O.lib().ko_xxh3_u8(v) == O.xxh3_bytes(bytes([v]))
+    for v in (0, 1, 0x1234, 0xFFFF, 0x8000):
+        assert O.lib().ko_xxh3_u16(v) == O.xxh3_bytes(v.to_bytes(2, "little"))
+
+
+def test_xxh3_bytes_golden():
+    g = json.load(open(os.path.join(G, "xxh3_bytes.json")))
+    for n, want in g["digests"].items():
+        n = int(n)
+        data = bytes((i * 131 + 7) & 0xFF for i in range(n))
+        assert O.xxh3_bytes(data) == want, n
+
+
+def test_bloom_no_false_negatives():
+    # internal/filter/bloom/bloom_test.go:18-150 (property: added => contained; fp rate sane)
+    rng = np.random.default_rng(7)
+    keys = rng.integers(0, 2**63, size=4096, dtype=np.uint64)
+    f = O.bloom_new(4096, 2)
+    assert f.size == 1 + 8192 and f[0] == 4
+    hs = [O.lib().ko_xxh3_u64(int(k)) for k in keys]
+    for h in hs:
+        O.bloom_add(f, h)
+    assert all(O.bloom_contains(f, h) for h in hs)
+    other = rng.integers(2**63, 2**64 - 1, size=20000, dtype=np.uint64)
+    fp = sum(O.bloom_contains(f, O.lib().ko_xxh3_u64(int(k))) for k in other) / other.size
+    assert fp < 10 * 0.002394  # design p for factor 2, pack/stats/filter.go:303-311
