@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: 1B-row int64 range filter + sum per GPU (BASELINE.json
+configs[1]; configs[4] when launched with N > 1 ranks).
+
+A "step" is one pass of the hot path over the whole resident shard: the fused scan kernel
+evaluates `Between(-2^38, 2^38)` on 2^30 int64 rows (1024 packs of 2^20), writes the LSB-first
+selection bitset, the per-pack popcounts and the wrapping int64 sum + count.  Inputs are
+generated on the device (counter-based generator) and are resident in HBM when the
+timed region starts.  For N > 1 each rank owns a contiguous pack range (no data-path
+collective); only the 100-byte partial aggregate crosses xGMI (RCCL all-gather) each step.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+BYTES_PER_ROW = 8.125  # 8 B value read + 1/8 B bitset written
+
+
+def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts):
+    """The oracle's literal restatement of the reference flow (cmp -> Indexes -> SumReducer per
+    row), one thread like the reference's one-goroutine pack loop, on the first `sample_rows`
+    rows of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    x = O.generate(O.I64, 0, 2, 0, sample_rows, lo=-(1 << 40), span=1 << 41)
+    t0 = time.perf_counter()
+    bits, cnt, s = O.scan_i64_bw_sum(x, pack_rows, a, b)
+    dt = time.perf_counter() - t0
+    ok = None
+    if gpu_pack_counts is not None:
+        ok = int(gpu_pack_counts[: sample_rows // pack_rows].sum()) == int(cnt)
+    return {"value": sample_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "first %d rows (%d packs of 2^20) of the same workload, oracle/knox_oracle.c ko_scan_i64_bw_sum "
+                      "(cmp_bw -> Indexes -> SumReducer per row), %.1f s, gcc -O2" % (sample_rows, sample_rows // pack_rows, dt),
+            "gb_per_s": sample_rows * BYTES_PER_ROW / dt / 1e9, "matches_gpu_counts": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows-log2", type=int, default=30, help="rows per GPU = 2^k (default 2^30 = the 1B-row config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log2", type=int, default=29)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=-1)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    import knoxdb_amd as K
+    from knoxdb_amd import And, Leaf
+    from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc
+    from knoxdb_amd import dist as kdist
+
+    n_rows = 1 << args.rows_log2
+    pack_rows = 1 << 20 if n_rows >= (1 << 20) else n_rows
+    n_packs = n_rows // pack_rows
+    a, b = -(1 << 38), 1 << 38
+    seed = 2 if world == 1 else 20 + rank  # cfg 2 seed 2, cfg 5 seeds 20..27
+    ctx = K.Context(local_rank)
+    if args.blocks_per_cu or args.variant >= 0:
+        ctx.set_tuning(args.blocks_per_cu, args.variant)
+    # rank r owns global packs [r*n_packs, (r+1)*n_packs): row ids are offset by row_base
+    first_pack, _ = kdist.shard_range(n_packs * world, rank, world)
+    row_base = first_pack * pack_rows
+    col = ctx.generate(BlockType.Int64, 0, seed, n_rows, first_row=0, lo=-(1 << 40), span=1 << 41, pack_rows=pack_rows)
+    bits = ctx.bits(n_rows)
+    plan = ctx.plan(And(Leaf(0, FilterMode.Range, a, b)), [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
+    ctx.sync()
+
+    def step():
+        ctx.scan_async(plan, bits_out=bits, pack_counts=True, row_base=row_base)
+        res = ctx.scan_collect(plan, n_packs)
+        if dist is not None:
+            merged, total = kdist.allgather_states(res.states, res.count, device=torch.device("cuda", local_rank))
+            return res, merged, total
+        return res, res.states, res.count
+
+    for _ in range(args.warmup):
+        step()
+    ctx.L.knox_prof_enable(ctx.h, 1)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, merged, total = step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    kms, kn = C.c_double(), C.c_int()
+    ctx.L.knox_prof_read(ctx.h, C.byref(kms), C.byref(kn))
+    ctx.L.knox_prof_enable(ctx.h, 0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = kms.value / max(1, kn.value)
+    achieved = n_rows * BYTES_PER_ROW / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    total_rows = n_rows * world * args.steps
+    value = total_rows / elapsed
+    sum_val = int(K.agg_value(merged[0], ReducerFunc.Sum)[0])
+
+    out = {
+        "metric": "scanned rows/sec + achieved HBM GB/s, 1B-row int64 range filter+sum",
+        "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[%d]: %s x 2^%d int64 rows, pack size 2^20, Between[-2^38,2^38] (25%% sel.) "
+                               "+ sum + count, bitset + per-pack counts emitted" % (1 if world == 1 else 4, "%d GPU" % world, args.rows_log2),
+                   "rows_per_gpu": n_rows, "pack_rows": pack_rows, "parallelism": "pack-sharded x%d" % world,
+                   "selected_rows": int(total), "sum_mod_2^64": sum_val},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": kernel_ms,
+                     "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW},
+        "whole_step_gb_per_s": n_rows * BYTES_PER_ROW / (elapsed / args.steps) / 1e9,
+    }
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            out["roofline"]["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = min(n_rows, 1 << args.cpu_sample_log2)
+        out["cpu_baseline"] = cpu_baseline(sample, pack_rows, a, b, res.pack_counts)
+    if rank == 0:
+        print(json.dumps(out))
+    col.free()
+    bits.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+/*
+ * knoxgpu.h -- C ABI of libknoxgpu.so: the MI355X (gfx950) pack-scan path for KnoxDB.
+ *
+ * Drop-in boundary for ONE path of blockwatch-cc/knoxdb: predicate comparators
+ * (internal/cmp) -> bitset combinators (internal/bitset) -> aggregate reducers
+ * (internal/reducer), as entered through filter.Match (internal/operator/filter/
+ * match_core.go:14).  Everything is plain C: pointers, sizes, integer codes.  A Go host
+ * binds these with cgo (INTEGRATION.md shows the shim); tests bind them with ctypes.
+ *
+ * Citations are file:line relative to the reference checkout.
+ *
+ * Conventions
+ *   - every function returns int: 0 = KNOX_OK, <0 = knox_err (knox_strerror names it),
+ *     except knox_cmp which returns the match count (>=0) or a negative knox_err.
+ *   - dtype codes are types.BlockType (internal/types/block.go:20-36); op codes are
+ *     types.FilterMode (internal/types/mode.go:13-27); reducer codes follow
+ *     internal/reducer/reducer.go:25-45.
+ *   - bitsets are LSB-first: row i <-> byte i>>3, bit i&7 (internal/bitset/bitset.go:23-29);
+ *     (n+7)/8 bytes; bits >= n in the last byte are 0; nothing is written past that byte
+ *     (the reference's poison-tail test, internal/cmp/tests/tests.go:24-48).
+ *   - host pointers passed in are never retained after the call returns (cgo rule);
+ *     device memory is owned by the knox_* handle that allocated it.
+ *   - one knox_ctx = one device + one HIP stream; a ctx is not re-entrant, use one ctx per
+ *     host thread (the reference runs one goroutine per query, pack/table/query.go:195-219).
+ */
+#ifndef KNOXGPU_H
+#define KNOXGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNOX_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------- */
+enum knox_err {
+    KNOX_OK = 0,
+    KNOX_E_INVALID = -1,     /* bad argument (null handle, unknown dtype/op, misaligned ptr) */
+    KNOX_E_NODEVICE = -2,    /* no HIP device / HIP runtime failure at open */
+    KNOX_E_HIP = -3,         /* a HIP call failed (knox_last_hip_error has the code)    */
+    KNOX_E_NOMEM = -4,       /* host or device allocation failed                          */
+    KNOX_E_UNSUPPORTED = -5, /* valid request this build does not implement               */
+    KNOX_E_COMM = -6,        /* RCCL failure / not initialised                            */
+    KNOX_E_RANGE = -7        /* row/size out of range                                     */
+};
+
+/* ---- types.BlockType (internal/types/block.go:20-36) -------------------------------- */
+enum knox_dtype {
+    KNOX_INT64 = 1, KNOX_INT32 = 2, KNOX_INT16 = 3, KNOX_INT8 = 4,
+    KNOX_UINT64 = 5, KNOX_UINT32 = 6, KNOX_UINT16 = 7, KNOX_UINT8 = 8,
+    KNOX_FLOAT64 = 9, KNOX_FLOAT32 = 10, KNOX_BOOL = 11, KNOX_BYTES = 12
+};
+
+/* ---- types.FilterMode (internal/types/mode.go:13-27) -------------------------------- */
+enum knox_op {
+    KNOX_EQ = 1, KNOX_NE = 2, KNOX_GT = 3, KNOX_GE = 4, KNOX_LT = 5, KNOX_LE = 6,
+    KNOX_RANGE = 9 /* Between [a,b] */, KNOX_TRUE = 11, KNOX_FALSE = 12
+};
+
+/* ---- reducer functions (internal/reducer/reducer.go:25-45) -------------------------- */
+enum knox_reducer {
+    KNOX_R_SUM = 0, KNOX_R_FIRST = 1, KNOX_R_LAST = 2, KNOX_R_MIN = 3, KNOX_R_MAX = 4,
+    KNOX_R_MEAN = 5, KNOX_R_VAR = 6, KNOX_R_STD = 7, KNOX_R_COUNT = 8
+};
+
+typedef struct knox_ctx knox_ctx;   /* device + stream + workspace                       */
+typedef struct knox_col knox_col;   /* one column resident in HBM (many packs, contiguous)*/
+typedef struct knox_bits knox_bits; /* one device-resident bitset                         */
+
+/* ---- library / context -------------------------------------------------------------- */
+int knox_abi_version(void);
+const char *knox_strerror(int err);
+int knox_device_count(int *count);
+int knox_last_hip_error(const knox_ctx *ctx); /* hipError_t of the last failing HIP call  */
+
+/* Opens device `device`, creates the ctx's own stream and workspace.                    */
+int knox_ctx_open(int device, knox_ctx **out);
+/* Same, but launches on an existing hipStream_t (e.g. the caller's stream).              */
+int knox_ctx_open_stream(int device, void *hip_stream, knox_ctx **out);
+int knox_ctx_close(knox_ctx *ctx);
+int knox_ctx_sync(knox_ctx *ctx);
+void *knox_ctx_stream(knox_ctx *ctx); /* hipStream_t */
+/* HIP-event stopwatch on the ctx stream (for achieved-GB/s measurement).                 */
+int knox_timer_start(knox_ctx *ctx);
+int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms      */
+/* Tuning knobs (0 keeps the default): workgroups per CU of the streaming kernels.        */
+int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
+/* Per-kernel stopwatch: while enabled, every launch of the dominant streaming kernel
+ * (scan / reduce) is bracketed by HIP events on the ctx stream; knox_prof_read syncs, returns
+ * the summed kernel time and launch count since the last read, and resets.                */
+int knox_prof_enable(knox_ctx *ctx, int on);
+int knox_prof_read(knox_ctx *ctx, double *total_ms, int *launches);
+
+/* ---- finest boundary: the cmp func vars --------------------------------------------- *
+ * Replaces `func(src []T, val T, bits []byte) int64` / `func(src []T, a, b T, bits []byte)
+ * int64` (internal/cmp/cmp.go:6-114, rebound in cmp_amd64.go:14-218, called from
+ * operator/filter/match_num.go:348-566).  HOST pointers; synchronous; `a`/`b` point to one
+ * value of the column type (`b` only for KNOX_RANGE).  `bits` must hold (n+7)/8 bytes and be
+ * zeroed by the caller (reader.go:334).  n == 0 or src == NULL returns 0 and writes nothing.
+ * Stages src through pinned memory to HBM, runs the same kernels as knox_scan.            */
+int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, size_t n, const void *a,
+                 const void *b, uint8_t *bits);
+
+/* ---- columns resident in HBM -------------------------------------------------------- *
+ * A knox_col is the device image of one column of a run of packs: the decoded vectors
+ * block.NewAccessor[T](b).Slice() (internal/block/access.go:87-91) of consecutive packs,
+ * concatenated.  pack_rows is the reference's PackSize (a multiple of 64; the last pack may
+ * be short).  Upload goes host -> pinned ring -> hipMemcpyAsync.                           */
+int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, size_t pack_rows,
+                    knox_col **out);
+/* Bytes column in StringPool layout (pkg/stringx/pool.go:45-58): ptr[i] = off<<32 | len.  */
+int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf,
+                          size_t buf_len, size_t pack_rows, knox_col **out);
+/* Borrow memory that already lives on the device (16-byte aligned); never freed by knox.  */
+int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows,
+                  knox_col **out);
+/* Synthetic column generated on the device (DESIGN.md "synthetic data"; counter based):
+ * kind 0 uniform integer in [lo, lo+span) (span 0 = raw 64 bits), 1 float grid k*2^-10,
+ * 2 float uniform [0,1), 3 row id + lo, 4 float mix with NaN/Inf/+-0.                    */
+int knox_col_generate(knox_ctx *ctx, int dtype, int kind, uint64_t seed, uint64_t first_row,
+                      size_t n_rows, int64_t lo, uint64_t span, size_t pack_rows, knox_col **out);
+int knox_col_download(knox_ctx *ctx, const knox_col *col, size_t first_row, size_t n_rows, void *host);
+int knox_col_free(knox_col *col);
+size_t knox_col_rows(const knox_col *col);
+int knox_col_dtype(const knox_col *col);
+void *knox_col_device_ptr(const knox_col *col);
+
+/* ---- device bitsets: internal/bitset/bitset.go:30-35 + generic/bitset.go:13-435 ------ */
+int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out); /* zeroed           */
+int knox_bits_free(knox_bits *b);
+size_t knox_bits_size(const knox_bits *b);
+void *knox_bits_device_ptr(const knox_bits *b);
+int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host);  /* (size+7)/8 bytes */
+int knox_bits_download(knox_ctx *ctx, const knox_bits *b, uint8_t *host);
+int knox_bits_zero(knox_ctx *ctx, knox_bits *b);                         /* Bitset.Zero :533 */
+int knox_bits_one(knox_ctx *ctx, knox_bits *b);                          /* Bitset.One  :520 */
+int knox_bits_copy(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);
+int knox_bits_and(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);     /* And    :13  */
+int knox_bits_andnot(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);  /* AndNot :115 */
+int knox_bits_or(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);      /* Or     :153 */
+int knox_bits_xor(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);     /* Xor    :257 */
+int knox_bits_neg(knox_ctx *ctx, knox_bits *b);                             /* Neg    :295 */
+/* AndFlag :51 / OrFlag :191 -- also report any / all over the valid bits.                 */
+int knox_bits_and_flag(knox_ctx *ctx, knox_bits *dst, const knox_bits *src, int *any, int *all);
+int knox_bits_or_flag(knox_ctx *ctx, knox_bits *dst, const knox_bits *src, int *any, int *all);
+int knox_bits_popcount(knox_ctx *ctx, const knox_bits *b, int64_t *count);  /* PopCount :332 */
+/* popcount of consecutive segments of seg_bits (a multiple of 64): the per-pack counts.   */
+int knox_bits_popcount_segments(knox_ctx *ctx, const knox_bits *b, size_t seg_bits, int64_t *counts,
+                                size_t n_counts);
+/* Indexes :355 / Bitset.Indexes iterator.go:269: ascending uint32 row ids.  `capacity`
+ * entries available in `rows` (host); *n_out receives the number written (= popcount).     */
+int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t capacity, size_t *n_out);
+
+/* ---- predicate tree + fused scan ---------------------------------------------------- *
+ * Replaces filter.Match(node, pkg, stats, bits) (operator/filter/match_core.go:14-215) for
+ * every pack of the resident columns in ONE pass, plus the reducers that the reference
+ * feeds row-at-a-time afterwards (query/result.go:134-150 -> reducer.go:138-349).
+ *
+ * The tree is flattened to postfix: leaves push, AND/OR pop `nchild` operands.
+ * Leaf = filter.Filter{Type, Mode, Index, Value} (operator/filter/filter.go:22-30):
+ * `col` indexes the cols[] array, a/b hold the value bits of the column type (little-endian,
+ * zero-extended to 64 bit; b only for KNOX_RANGE).  Bytes leaves (EQ/NE) pass val/val_len.  */
+enum knox_node_kind { KNOX_NODE_LEAF = 0, KNOX_NODE_AND = 1, KNOX_NODE_OR = 2 };
+typedef struct knox_pred {
+    int32_t kind;   /* knox_node_kind */
+    int32_t nchild; /* AND / OR: number of operands popped */
+    int32_t col;    /* leaf: index into cols[] */
+    int32_t op;     /* leaf: knox_op */
+    uint64_t a, b;  /* leaf: value bits */
+    const uint8_t *val; /* bytes leaf: value */
+    uint64_t val_len;
+} knox_pred;
+
+typedef struct knox_agg {
+    int32_t func; /* knox_reducer */
+    int32_t col;  /* index into cols[] */
+} knox_agg;
+
+/* Partial aggregate state of one column over the selected rows: everything any reducer of
+ * internal/reducer/reducer.go needs, in a form that merges exactly across blocks and GPUs. */
+typedef struct knox_agg_state {
+    int32_t dtype;
+    uint32_t flags;     /* bit0: state valid */
+    int64_t count;      /* selected rows */
+    uint64_t isum;      /* wrapping sum of the raw value bits (integers: SumReducer mod 2^64) */
+    double fsum_hi;     /* double-double sum of float64(v): hi + lo */
+    double fsum_lo;
+    uint64_t min_bits, max_bits;     /* value at min_row / max_row (raw bits, zero-extended) */
+    uint64_t first_bits, last_bits;  /* value at first_row / last_row */
+    int64_t min_row, max_row;        /* global row id of the adopted value, -1 = none       */
+    int64_t first_row, last_row;     /* first / last selected global row id, -1 = none      */
+} knox_agg_state;
+
+typedef struct knox_scan_out {
+    int64_t count;          /* total selected rows (sum of per-pack popcounts) */
+    int64_t rows_scanned;   /* rows actually read (pruned packs excluded)      */
+} knox_scan_out;
+
+/* One scan over rows [0, n_rows) of the given columns (all the same length).
+ *   bits_out     nullable; receives the selection bitset of all rows (pack p's bitset is the
+ *                slice starting at bit p*pack_rows -- pack_rows is a multiple of 8).
+ *   pack_counts  nullable HOST array of n_packs int64: per-pack popcount (Bitset.ResetCount).
+ *   pack_skip    nullable HOST array of n_packs bytes: 1 = pack pruned by the caller's
+ *                statistics (zone map / bloom, pack/stats/match.go:112-195): treated as
+ *                "no row matches" and not read.
+ *   aggs/states  n_aggs reducers; states[i] receives the merged state for aggs[i].col
+ *                (finalize with knox_agg_value).  row ids are offset by row_base.           */
+int knox_scan(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols,
+              const knox_agg *aggs, int n_aggs, uint64_t row_base, const uint8_t *pack_skip,
+              knox_bits *bits_out, int64_t *pack_counts, knox_agg_state *states, knox_scan_out *out);
+/* Enqueue-only variant for benchmarking: identical work, results are left in ctx-owned pinned
+ * memory and fetched with knox_scan_collect after knox_ctx_sync.                            */
+int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols,
+                    const knox_agg *aggs, int n_aggs, uint64_t row_base, const uint8_t *pack_skip,
+                    knox_bits *bits_out, int want_pack_counts);
+int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_state *states, int n_aggs,
+                      knox_scan_out *out);
+
+/* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
+int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,
+                uint64_t row_base, knox_agg_state *state);
+/* Literal sequential reducer (one lane, row order) -- reproduces reducer.go bit for bit,
+ * including Welford mean/var; slow, used for parity tests on small inputs.                  */
+int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, int func,
+                           void *value_out /* one T */, int *seen, int64_t *row);
+
+/* Reducer.Value() from a state: writes one value of the column type to value_out, *seen as
+ * Value()'s second result, *row = the row whose timestamp Time() would report.
+ * sum/mean of float columns are the correctly rounded exact sum / exact mean.   */
+int knox_agg_value(const knox_agg_state *state, int func, void *value_out, int *seen, int64_t *row);
+/* Merge n states of consecutive row ranges (rank order = row order) -- pure host code.      */
+int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out);
+
+/* ---- bloom pre-filter: internal/filter/bloom/bloom.go:136-150,182 -------------------- *
+ * filters: n_packs serialized filters [k][m/8 bytes] concatenated; offsets[n_packs+1] gives
+ * each filter's byte range (offsets[p]==offsets[p+1]: pack has no filter -> maybe).
+ * maybe_out[p] = 1 if pack p may contain hash h (Contains), else 0.                          */
+int knox_bloom_probe(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs,
+                     uint64_t h, uint8_t *maybe_out);
+/* hash.HashT for fixed-width values (internal/hash/hash.go:67-92, xxh3.go:22-58): the hash a
+ * numeric Equal matcher probes with (match_num.go:339-346).  Float types hash their bytes.   */
+uint64_t knox_hash_value(int dtype, const void *val);
+/* Build per-pack bloom filters on the device for an 8-byte column (xxh3_u64 of the raw bits,
+ * pack/stats/filter.go:296-360) -- used to set up config 4; factor = bytes per value.        */
+int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, uint8_t *filters_out,
+                         size_t filters_cap, uint64_t *offsets_out /* n_packs+1 */);
+
+/* ---- multi-GPU: final aggregate only ------------------------------------------------- *
+ * One process per GPU.  Rank 0 creates an id, every rank receives it out of band (the host's
+ * own rendezvous) and joins; knox_comm_allgather_states gathers each rank's state over
+ * RCCL (xGMI) and merges them in rank order with knox_agg_combine on every rank.            */
+#define KNOX_COMM_ID_BYTES 128
+int knox_comm_unique_id(uint8_t id[KNOX_COMM_ID_BYTES]);
+int knox_comm_init(knox_ctx *ctx, int n_ranks, int rank, const uint8_t id[KNOX_COMM_ID_BYTES]);
+int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *mine, int n_states,
+                               knox_agg_state *merged /* n_states */, int64_t *count_inout);
+int knox_comm_destroy(knox_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNOXGPU_H */

@@ -1,0 +1,1531 @@
+// knox_abi.hip -- C ABI (include/knoxgpu.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: contexts, HBM-resident columns with a pinned staging
+// ring (hipMemcpyAsync), the predicate-tree planner (postfix tree -> key-space leaves + truth
+// table, or a multi-pass plan over scratch bitsets), result collection, exact finalisation of
+// reducer values, and the RCCL exchange of partial aggregate states.
+//
+// There is NO CPU fallback: if the HIP runtime or the device is missing every entry point
+// fails with KNOX_E_NODEVICE / KNOX_E_HIP.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>  // types only: librccl is dlopen'ed on first knox_comm_* call
+
+#include "../../include/knoxgpu.h"
+#include "knox_kernels.h"
+
+using namespace knox;
+
+#define KNOX_API extern "C" __attribute__((visibility("default")))
+
+static_assert(sizeof(knox_agg_state) == sizeof(AggStateDev), "knox_agg_state layout");
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct knox_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_hip = 0;
+    int n_cus = 256;
+    int blocks_per_cu = 8;
+    int variant = 0;
+    // staging ring (pinned) for host -> HBM uploads
+    static constexpr size_t kStageBytes = 32u << 20;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // grow-only device scratch
+    DevBuf partials;     // AggPartial[(grid+1) * slots]
+    DevBuf states;       // AggStateDev[slots] + int64 count
+    DevBuf tmp_vals;     // knox_cmp: staged values
+    DevBuf tmp_bits;     // scratch bitset(s)
+    DevBuf pack_skip;    // device copy of the caller's pack_skip bytes
+    DevBuf pack_counts;  // int64 per pack
+    DevBuf misc;         // flags / counters / small outputs
+    DevBuf idx_scratch;  // indexes: block offsets
+    DevBuf idx_rows;     // indexes: row ids
+    DevBuf bytes_val;    // bytes leaf value
+    // pinned result mirror
+    void *h_res = nullptr;
+    size_t h_res_cap = 0;
+    void *h_packs = nullptr;
+    size_t h_packs_cap = 0;
+    // last async scan (for knox_scan_collect)
+    int last_slots = 0;
+    int last_agg_slot[16];
+    int last_n_aggs = 0;
+    size_t last_n_packs = 0;
+    bool last_has_pack_counts = false;
+    uint64_t last_rows_scanned = 0;
+    // per-kernel stopwatch (knox_prof_*)
+    bool prof = false;
+    static constexpr int kProfRing = 512;
+    hipEvent_t prof_ev[2 * kProfRing] = {};
+    int prof_n = 0;
+    // RCCL
+    void *rccl = nullptr;
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    DevBuf comm_buf;
+};
+
+struct knox_col {
+    knox_ctx *ctx;
+    int dtype;
+    int width;  // bytes per value; bytes column: 8 (ptr words)
+    size_t n_rows;
+    size_t pack_rows;
+    void *dev;      // values, or ptr[] for a bytes column
+    uint8_t *buf;   // bytes column payload
+    size_t buf_len;
+    bool owned;
+};
+
+struct knox_bits {
+    knox_ctx *ctx;
+    size_t size;
+    uint64_t *dev;
+    size_t cap_bytes;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+#define HIPCHK(ctx, call)                              \
+    do {                                               \
+        hipError_t _e = (call);                        \
+        if (_e != hipSuccess) {                        \
+            if (ctx) (ctx)->last_hip = (int)_e;        \
+            return KNOX_E_HIP;                         \
+        }                                              \
+    } while (0)
+
+static int dtype_width(int dtype) {
+    switch (dtype) {
+    case KNOX_INT64: case KNOX_UINT64: case KNOX_FLOAT64: return 8;
+    case KNOX_INT32: case KNOX_UINT32: case KNOX_FLOAT32: return 4;
+    case KNOX_INT16: case KNOX_UINT16: return 2;
+    case KNOX_INT8: case KNOX_UINT8: return 1;
+    default: return 0;
+    }
+}
+static bool dtype_is_float(int dtype) { return dtype == KNOX_FLOAT64 || dtype == KNOX_FLOAT32; }
+static bool dtype_is_signed(int dtype) { return dtype >= KNOX_INT64 && dtype <= KNOX_INT8; }
+static uint32_t dtype_flavor(int dtype) { return dtype_is_float(dtype) ? FL_FLOAT : dtype_is_signed(dtype) ? FL_SIGNED : FL_UNSIGNED; }
+
+static int ensure(knox_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes) return KNOX_OK;
+    if (b.p) {
+        // the stream may still be using the old buffer
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = std::max<size_t>(bytes, 4096);
+    cap = (cap + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        b.p = nullptr;
+        return KNOX_E_NOMEM;
+    }
+    b.cap = cap;
+    return KNOX_OK;
+}
+
+static int ensure_host(knox_ctx *ctx, void *&p, size_t &cap, size_t bytes) {
+    if (cap >= bytes) return KNOX_OK;
+    if (p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t c = std::max<size_t>(bytes, 4096);
+    hipError_t e = hipHostMalloc(&p, c, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        p = nullptr;
+        return KNOX_E_NOMEM;
+    }
+    cap = c;
+    return KNOX_OK;
+}
+
+static inline size_t bits_bytes(size_t size_bits) { return (size_bits + 7) >> 3; }
+static inline size_t bits_padded(size_t size_bits) { return ((size_bits + 63) >> 6) << 3; }
+
+// ------------------------------------------------------------------------------------------------
+// library / context
+// ------------------------------------------------------------------------------------------------
+KNOX_API int knox_abi_version(void) { return KNOX_ABI_VERSION; }
+
+KNOX_API const char *knox_strerror(int err) {
+    switch (err) {
+    case KNOX_OK: return "ok";
+    case KNOX_E_INVALID: return "invalid argument";
+    case KNOX_E_NODEVICE: return "no HIP device";
+    case KNOX_E_HIP: return "HIP runtime error";
+    case KNOX_E_NOMEM: return "out of memory";
+    case KNOX_E_UNSUPPORTED: return "unsupported request";
+    case KNOX_E_COMM: return "RCCL error";
+    case KNOX_E_RANGE: return "out of range";
+    default: return "unknown error";
+    }
+}
+
+KNOX_API int knox_device_count(int *count) {
+    if (!count) return KNOX_E_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return KNOX_E_NODEVICE;
+    }
+    *count = n;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_last_hip_error(const knox_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) {
+    if (!out) return KNOX_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return KNOX_E_NODEVICE;
+    if (device < 0 || device >= n) return KNOX_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return KNOX_E_NODEVICE;
+    knox_ctx *c = new (std::nothrow) knox_ctx();
+    if (!c) return KNOX_E_NOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    if (use_ext) {
+        c->stream = (hipStream_t)ext_stream;
+        c->own_stream = false;
+    } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return KNOX_E_HIP;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return KNOX_E_HIP;
+    }
+    const char *env = getenv("KNOX_BLOCKS_PER_CU");
+    if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
+    env = getenv("KNOX_VARIANT");
+    if (env) c->variant = atoi(env);
+    *out = c;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_open(int device, knox_ctx **out) { return ctx_open(device, nullptr, false, out); }
+KNOX_API int knox_ctx_open_stream(int device, void *hip_stream, knox_ctx **out) { return ctx_open(device, hip_stream, true, out); }
+
+KNOX_API int knox_ctx_close(knox_ctx *ctx) {
+    if (!ctx) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) knox_comm_destroy(ctx);
+    DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
+                      &ctx->misc, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
+    for (DevBuf *b : bufs)
+        if (b->p) hipFree(b->p);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage[i]) hipHostFree(ctx->stage[i]);
+        if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
+    }
+    for (hipEvent_t e : ctx->prof_ev)
+        if (e) hipEventDestroy(e);
+    if (ctx->h_res) hipHostFree(ctx->h_res);
+    if (ctx->h_packs) hipHostFree(ctx->h_packs);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_sync(knox_ctx *ctx) {
+    if (!ctx) return KNOX_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KNOX_OK;
+}
+
+KNOX_API void *knox_ctx_stream(knox_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+KNOX_API int knox_timer_start(knox_ctx *ctx) {
+    if (!ctx) return KNOX_E_INVALID;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms) {
+    if (!ctx || !elapsed_ms) return KNOX_E_INVALID;
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (blocks_per_cu > 0) ctx->blocks_per_cu = blocks_per_cu;
+    if (variant >= 0) ctx->variant = variant;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_prof_enable(knox_ctx *ctx, int on) {
+    if (!ctx) return KNOX_E_INVALID;
+    ctx->prof = on != 0;
+    ctx->prof_n = 0;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_prof_read(knox_ctx *ctx, double *total_ms, int *launches) {
+    if (!ctx || !total_ms || !launches) return KNOX_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double t = 0;
+    for (int i = 0; i < ctx->prof_n; i++) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = ctx->prof_n;
+    ctx->prof_n = 0;
+    return KNOX_OK;
+}
+
+// bracket the dominant kernel launch with events when the stopwatch is on
+static void prof_mark(knox_ctx *ctx, int which) {
+    if (!ctx->prof || ctx->prof_n >= knox_ctx::kProfRing) return;
+    hipEvent_t &e = ctx->prof_ev[2 * ctx->prof_n + which];
+    if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; return; }
+    hipEventRecord(e, ctx->stream);
+    if (which == 1) ctx->prof_n++;
+}
+
+// ------------------------------------------------------------------------------------------------
+// staging: host -> pinned ring -> HBM (two slots, copy of chunk i+1 overlaps the DMA of chunk i)
+// ------------------------------------------------------------------------------------------------
+static int stage_init(knox_ctx *ctx) {
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->stage[i]) {
+            hipError_t e = hipHostMalloc(&ctx->stage[i], knox_ctx::kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                ctx->last_hip = (int)e;
+                ctx->stage[i] = nullptr;
+                return KNOX_E_NOMEM;
+            }
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+        }
+    }
+    return KNOX_OK;
+}
+
+static int upload(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return KNOX_OK;
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    size_t off = 0;
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (off < bytes) {
+        const size_t n = std::min(bytes - off, knox_ctx::kStageBytes);
+        if (used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[slot]));
+        memcpy(ctx->stage[slot], (const char *)src + off, n);
+        HIPCHK(ctx, hipMemcpyAsync((char *)dst + off, ctx->stage[slot], n, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+        used[slot] = true;
+        slot ^= 1;
+        off += n;
+    }
+    // the caller's memory is not referenced after return; the ring is: wait for the last DMAs
+    for (int i = 0; i < 2; i++)
+        if (used[i]) HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[i]));
+    return KNOX_OK;
+}
+
+static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return KNOX_OK;
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    size_t off = 0;
+    while (off < bytes) {
+        const size_t n = std::min(bytes - off, knox_ctx::kStageBytes);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->stage[0], (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy((char *)dst + off, ctx->stage[0], n);
+        off += n;
+    }
+    return KNOX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// columns
+// ------------------------------------------------------------------------------------------------
+static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bool alloc, knox_col **out) {
+    if (!ctx || !out) return KNOX_E_INVALID;
+    *out = nullptr;
+    const int w = dtype == KNOX_BYTES ? 8 : dtype_width(dtype);
+    if (w == 0) return KNOX_E_INVALID;
+    if (pack_rows == 0) pack_rows = n_rows ? n_rows : 64;
+    knox_col *c = new (std::nothrow) knox_col();
+    if (!c) return KNOX_E_NOMEM;
+    c->ctx = ctx;
+    c->dtype = dtype;
+    c->width = w;
+    c->n_rows = n_rows;
+    c->pack_rows = pack_rows;
+    c->dev = nullptr;
+    c->buf = nullptr;
+    c->buf_len = 0;
+    c->owned = alloc;
+    if (alloc) {
+        // pad to a whole 16-byte vector so the streaming kernels never read past the allocation
+        size_t bytes = ((n_rows * (size_t)w + 255) & ~(size_t)255) + 256;
+        hipError_t e = hipMalloc(&c->dev, bytes);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            delete c;
+            return KNOX_E_NOMEM;
+        }
+    }
+    *out = c;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || (n_rows && !host) || dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = col_new(ctx, dtype, n_rows, pack_rows, true, out);
+    if (rc) return rc;
+    rc = upload(ctx, (*out)->dev, host, n_rows * (size_t)(*out)->width);
+    if (rc) {
+        knox_col_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+KNOX_API int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf, size_t buf_len,
+                                   size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || (n_rows && !ptr) || (buf_len && !buf)) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    // every (off, len) must lie inside buf: the device never reads out of bounds
+    for (size_t i = 0; i < n_rows; i++) {
+        const uint64_t off = ptr[i] >> 32, len = ptr[i] & 0xffffffffull;
+        if (off + len > buf_len) return KNOX_E_RANGE;
+    }
+    int rc = col_new(ctx, KNOX_BYTES, n_rows, pack_rows, true, out);
+    if (rc) return rc;
+    knox_col *c = *out;
+    hipError_t e = hipMalloc((void **)&c->buf, buf_len + 256);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        knox_col_free(c);
+        *out = nullptr;
+        return KNOX_E_NOMEM;
+    }
+    c->buf_len = buf_len;
+    rc = upload(ctx, c->dev, ptr, n_rows * 8);
+    if (!rc) rc = upload(ctx, c->buf, buf, buf_len);
+    if (rc) {
+        knox_col_free(c);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+KNOX_API int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || (n_rows && !device_ptr) || dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    if (((uintptr_t)device_ptr & 15) != 0) return KNOX_E_INVALID;
+    int rc = col_new(ctx, dtype, n_rows, pack_rows, false, out);
+    if (rc) return rc;
+    (*out)->dev = device_ptr;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_generate(knox_ctx *ctx, int dtype, int kind, uint64_t seed, uint64_t first_row, size_t n_rows, int64_t lo,
+                               uint64_t span, size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || dtype == KNOX_BYTES || kind < 0 || kind > 4) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = col_new(ctx, dtype, n_rows, pack_rows, true, out);
+    if (rc) return rc;
+    hipError_t e = launch_generate(ctx->stream, (*out)->width, dtype == KNOX_FLOAT32, kind, seed, first_row, n_rows, lo, span, (*out)->dev);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        knox_col_free(*out);
+        *out = nullptr;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_download(knox_ctx *ctx, const knox_col *col, size_t first_row, size_t n_rows, void *host) {
+    if (!ctx || !col || (n_rows && !host)) return KNOX_E_INVALID;
+    if (first_row + n_rows > col->n_rows) return KNOX_E_RANGE;
+    hipSetDevice(ctx->device);
+    return download(ctx, host, (const char *)col->dev + first_row * (size_t)col->width, n_rows * (size_t)col->width);
+}
+
+KNOX_API int knox_col_free(knox_col *col) {
+    if (!col) return KNOX_E_INVALID;
+    hipSetDevice(col->ctx->device);
+    hipStreamSynchronize(col->ctx->stream);
+    if (col->owned && col->dev) hipFree(col->dev);
+    if (col->buf) hipFree(col->buf);
+    delete col;
+    return KNOX_OK;
+}
+
+KNOX_API size_t knox_col_rows(const knox_col *col) { return col ? col->n_rows : 0; }
+KNOX_API int knox_col_dtype(const knox_col *col) { return col ? col->dtype : 0; }
+KNOX_API void *knox_col_device_ptr(const knox_col *col) { return col ? col->dev : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+// device bitsets
+// ------------------------------------------------------------------------------------------------
+KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) {
+    if (!ctx || !out) return KNOX_E_INVALID;
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    knox_bits *b = new (std::nothrow) knox_bits();
+    if (!b) return KNOX_E_NOMEM;
+    b->ctx = ctx;
+    b->size = size_bits;
+    b->cap_bytes = bits_padded(size_bits) + 64;
+    hipError_t e = hipMalloc((void **)&b->dev, b->cap_bytes);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        delete b;
+        return KNOX_E_NOMEM;
+    }
+    e = hipMemsetAsync(b->dev, 0, b->cap_bytes, ctx->stream);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        hipFree(b->dev);
+        delete b;
+        return KNOX_E_HIP;
+    }
+    *out = b;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bits_free(knox_bits *b) {
+    if (!b) return KNOX_E_INVALID;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    if (b->dev) hipFree(b->dev);
+    delete b;
+    return KNOX_OK;
+}
+
+KNOX_API size_t knox_bits_size(const knox_bits *b) { return b ? b->size : 0; }
+KNOX_API void *knox_bits_device_ptr(const knox_bits *b) { return b ? (void *)b->dev : nullptr; }
+
+KNOX_API int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host) {
+    if (!ctx || !b || (b->size && !host)) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemsetAsync(b->dev, 0, b->cap_bytes, ctx->stream));
+    return upload(ctx, b->dev, host, bits_bytes(b->size));
+}
+
+KNOX_API int knox_bits_download(knox_ctx *ctx, const knox_bits *b, uint8_t *host) {
+    if (!ctx || !b || (b->size && !host)) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    return download(ctx, host, b->dev, bits_bytes(b->size));
+}
+
+static int bitop(knox_ctx *ctx, int op, knox_bits *dst, const knox_bits *src, int *any, int *all) {
+    if (!ctx || !dst) return KNOX_E_INVALID;
+    const bool binary = (op == BIT_AND || op == BIT_ANDNOT || op == BIT_OR || op == BIT_XOR || op == BIT_COPY);
+    if (binary && (!src || src->size != dst->size)) return KNOX_E_INVALID;  // size mismatch is a no-op in Go (bitset.go:400-518); an error here
+    hipSetDevice(ctx->device);
+    uint32_t *flags = nullptr;
+    if (any || all) {
+        int rc = ensure(ctx, ctx->misc, 256);
+        if (rc) return rc;
+        flags = (uint32_t *)ctx->misc.p;
+        HIPCHK(ctx, hipMemsetAsync(flags, 0, 8, ctx->stream));
+    }
+    hipError_t e = launch_bitop(ctx->stream, op, dst->dev, src ? src->dev : nullptr, dst->size, flags);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    if (flags) {
+        uint32_t h[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(h, flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (any) *any = h[0] != 0;
+        if (all) *all = (dst->size > 0) && (h[1] == 0);
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bits_zero(knox_ctx *ctx, knox_bits *b) {
+    if (!ctx || !b) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipMemsetAsync(b->dev, 0, b->cap_bytes, ctx->stream));
+    return KNOX_OK;
+}
+KNOX_API int knox_bits_one(knox_ctx *ctx, knox_bits *b) { return bitop(ctx, BIT_ONE, b, nullptr, nullptr, nullptr); }
+KNOX_API int knox_bits_copy(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop(ctx, BIT_COPY, dst, src, nullptr, nullptr); }
+KNOX_API int knox_bits_and(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop(ctx, BIT_AND, dst, src, nullptr, nullptr); }
+KNOX_API int knox_bits_andnot(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop(ctx, BIT_ANDNOT, dst, src, nullptr, nullptr); }
+KNOX_API int knox_bits_or(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop(ctx, BIT_OR, dst, src, nullptr, nullptr); }
+KNOX_API int knox_bits_xor(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop(ctx, BIT_XOR, dst, src, nullptr, nullptr); }
+KNOX_API int knox_bits_neg(knox_ctx *ctx, knox_bits *b) { return bitop(ctx, BIT_NEG, b, nullptr, nullptr, nullptr); }
+KNOX_API int knox_bits_and_flag(knox_ctx *ctx, knox_bits *dst, const knox_bits *src, int *any, int *all) {
+    int a = 0, l = 0;
+    int rc = bitop(ctx, BIT_AND, dst, src, &a, &l);
+    if (any) *any = a;
+    if (all) *all = l;
+    return rc;
+}
+KNOX_API int knox_bits_or_flag(knox_ctx *ctx, knox_bits *dst, const knox_bits *src, int *any, int *all) {
+    int a = 0, l = 0;
+    int rc = bitop(ctx, BIT_OR, dst, src, &a, &l);
+    if (any) *any = a;
+    if (all) *all = l;
+    return rc;
+}
+
+KNOX_API int knox_bits_popcount(knox_ctx *ctx, const knox_bits *b, int64_t *count) {
+    if (!ctx || !b || !count) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure(ctx, ctx->misc, 256);
+    if (rc) return rc;
+    unsigned long long *d = (unsigned long long *)((char *)ctx->misc.p + 64);
+    HIPCHK(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipError_t e = launch_popcount(ctx->stream, b->dev, b->size, d);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    unsigned long long h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *count = (int64_t)h;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bits_popcount_segments(knox_ctx *ctx, const knox_bits *b, size_t seg_bits, int64_t *counts, size_t n_counts) {
+    if (!ctx || !b || !counts || seg_bits == 0 || (seg_bits & 63)) return KNOX_E_INVALID;
+    const size_t n_seg = (b->size + seg_bits - 1) / seg_bits;
+    if (n_counts < n_seg) return KNOX_E_RANGE;
+    hipSetDevice(ctx->device);
+    int rc = ensure(ctx, ctx->pack_counts, n_seg * 8 + 8);
+    if (rc) return rc;
+    hipError_t e = launch_popcount_segments(ctx->stream, b->dev, b->size, seg_bits, (int64_t *)ctx->pack_counts.p, n_seg);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return download(ctx, counts, ctx->pack_counts.p, n_seg * 8);
+}
+
+KNOX_API int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t capacity, size_t *n_out) {
+    if (!ctx || !b || !n_out || (capacity && !rows)) return KNOX_E_INVALID;
+    if (b->size > 0xffffffffull) return KNOX_E_RANGE;  // uint32 row ids (pack-local in the reference)
+    hipSetDevice(ctx->device);
+    const size_t nwords = (b->size + 63) >> 6;
+    const size_t nblocks = (nwords + 127) / 128;
+    int rc = ensure(ctx, ctx->idx_scratch, (nblocks + 2) * 4);
+    if (!rc) rc = ensure(ctx, ctx->idx_rows, std::max<size_t>(capacity, 1) * 4);
+    if (!rc) rc = ensure(ctx, ctx->misc, 256);
+    if (rc) return rc;
+    unsigned long long *d_n = (unsigned long long *)((char *)ctx->misc.p + 128);
+    hipError_t e = launch_indexes(ctx->stream, b->dev, b->size, (uint32_t *)ctx->idx_scratch.p, (uint32_t *)ctx->idx_rows.p, capacity, d_n);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    unsigned long long h = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = (size_t)h;
+    if (h > capacity) return KNOX_E_RANGE;
+    return download(ctx, rows, ctx->idx_rows.p, (size_t)h * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// predicate planning: (dtype, mode, a, b) -> key-space leaf + negation
+// ------------------------------------------------------------------------------------------------
+struct LeafHost {
+    uint64_t lo = 0, diff = 0;
+    bool neg = false;
+    bool is_float = false;
+};
+
+static inline uint64_t wmask(int w) { return w == 8 ? ~0ull : ((1ull << (8 * w)) - 1); }
+
+static uint64_t host_fkey(uint64_t u, int w) {
+    if (w == 8) return u ^ ((uint64_t)((int64_t)u >> 63) | (1ull << 63));
+    const uint32_t x = (uint32_t)u;
+    return (uint64_t)(x ^ ((uint32_t)((int32_t)x >> 31) | 0x80000000u));
+}
+
+static int make_leaf(int dtype, int op, uint64_t a, uint64_t b, LeafHost &out) {
+    const int w = dtype_width(dtype);
+    if (w == 0) return KNOX_E_INVALID;
+    const uint64_t m = wmask(w);
+    a &= m;
+    b &= m;
+    out = LeafHost();
+    auto full = [&](bool negate) { out.lo = 0; out.diff = m; out.neg = negate; };
+    if (op == KNOX_TRUE) { full(false); out.is_float = false; return KNOX_OK; }
+    if (op == KNOX_FALSE) { full(true); out.is_float = false; return KNOX_OK; }
+    if (!dtype_is_float(dtype)) {
+        const uint64_t MIN = dtype_is_signed(dtype) ? (1ull << (8 * w - 1)) : 0;
+        const uint64_t MAX = dtype_is_signed(dtype) ? (MIN - 1) & m : m;
+        switch (op) {
+        case KNOX_EQ: out.lo = a; out.diff = 0; break;
+        case KNOX_NE: out.lo = a; out.diff = 0; out.neg = true; break;
+        case KNOX_LE: out.lo = MIN; out.diff = (a - MIN) & m; break;
+        case KNOX_GT: out.lo = MIN; out.diff = (a - MIN) & m; out.neg = true; break;
+        case KNOX_GE: out.lo = a; out.diff = (MAX - a) & m; break;
+        case KNOX_LT: out.lo = a; out.diff = (MAX - a) & m; out.neg = true; break;
+        case KNOX_RANGE: out.lo = a; out.diff = (b - a) & m; break;  // wrap-around set when a > b, number.go:211-243
+        default: return KNOX_E_UNSUPPORTED;
+        }
+        return KNOX_OK;
+    }
+    out.is_float = true;
+    const uint64_t sign = 1ull << (8 * w - 1);
+    const uint64_t expm = w == 8 ? 0x7ff0000000000000ull : 0x7f800000ull;
+    auto isnan_ = [&](uint64_t u) { return (u & (m ^ sign)) > expm; };
+    auto iszero = [&](uint64_t u) { return (u & (m ^ sign)) == 0; };
+    auto klo = [&](uint64_t u) { return iszero(u) ? host_fkey(sign, w) : host_fkey(u, w); };  // -0 is the lower key
+    auto khi = [&](uint64_t u) { return iszero(u) ? host_fkey(0, w) : host_fkey(u, w); };
+    const uint64_t KMIN = host_fkey(sign | expm, w), KMAX = host_fkey(expm, w);  // -Inf, +Inf
+    switch (op) {
+    case KNOX_EQ:
+    case KNOX_NE:
+        if (isnan_(a)) full(true);
+        else { out.lo = klo(a); out.diff = khi(a) - klo(a); }
+        if (op == KNOX_NE) out.neg = !out.neg;  // the only op true on NaN (float.go:46-77)
+        break;
+    case KNOX_LT:
+        if (isnan_(a) || klo(a) == KMIN) full(true);
+        else { out.lo = KMIN; out.diff = klo(a) - 1 - KMIN; }
+        break;
+    case KNOX_LE:
+        if (isnan_(a)) full(true);
+        else { out.lo = KMIN; out.diff = khi(a) - KMIN; }
+        break;
+    case KNOX_GT:
+        if (isnan_(a) || khi(a) == KMAX) full(true);
+        else { out.lo = khi(a) + 1; out.diff = KMAX - out.lo; }
+        break;
+    case KNOX_GE:
+        if (isnan_(a)) full(true);
+        else { out.lo = klo(a); out.diff = KMAX - out.lo; }
+        break;
+    case KNOX_RANGE:
+        if (isnan_(a) || isnan_(b) || klo(a) > khi(b)) full(true);  // a <= v && v <= b, float.go:211-242
+        else { out.lo = klo(a); out.diff = khi(b) - klo(a); }
+        break;
+    default: return KNOX_E_UNSUPPORTED;
+    }
+    return KNOX_OK;
+}
+
+// boolean function of the leaf hits -> truth table (bit idx = value for hits == idx)
+static int make_truth_table(const knox_pred *nodes, int n_nodes, const std::vector<int> &leaf_of_node, const std::vector<bool> &leaf_neg,
+                            int n_leaves, uint64_t &tt) {
+    tt = 0;
+    for (uint32_t idx = 0; idx < (1u << n_leaves); idx++) {
+        bool st[64];
+        int sp = 0;
+        for (int i = 0; i < n_nodes; i++) {
+            const knox_pred &p = nodes[i];
+            if (p.kind == KNOX_NODE_LEAF) {
+                if (sp >= 64) return KNOX_E_INVALID;
+                const int l = leaf_of_node[i];
+                st[sp++] = (((idx >> l) & 1) != 0) != leaf_neg[l];
+            } else {
+                const int k = p.nchild;
+                if (k < 0 || k > sp) return KNOX_E_INVALID;
+                bool v = (p.kind == KNOX_NODE_AND);  // empty AND = true, empty OR = false (match_core.go:45-56,131-138)
+                for (int j = 0; j < k; j++) {
+                    const bool c = st[sp - 1 - j];
+                    v = (p.kind == KNOX_NODE_AND) ? (v && c) : (v || c);
+                }
+                sp -= k;
+                st[sp++] = v;
+            }
+        }
+        if (sp != 1) return KNOX_E_INVALID;
+        if (st[0]) tt |= 1ull << idx;
+    }
+    return KNOX_OK;
+}
+
+// which aggregate work a reducer needs from the kernels
+static int agg_need(int func, int dtype, unsigned &need) {
+    switch (func) {
+    case KNOX_R_COUNT: break;
+    case KNOX_R_SUM: need |= dtype_is_float(dtype) ? A_FSUM : A_ISUM; break;
+    case KNOX_R_MEAN: need |= A_FSUM; break;
+    case KNOX_R_MIN: case KNOX_R_MAX: need |= A_MINMAX | (dtype_is_float(dtype) ? A_FIRSTLAST : 0u); break;
+    case KNOX_R_FIRST: case KNOX_R_LAST: need |= A_FIRSTLAST; break;
+    default: return KNOX_E_UNSUPPORTED;  // var/std: knox_reduce_sequential
+    }
+    return KNOX_OK;
+}
+static unsigned agg_class(unsigned need) {
+    if (need == 0) return 0;
+    if (need == A_ISUM) return A_ISUM;
+    if ((need & A_ISUM) == 0) return A_FSUM | A_MINMAX | A_FIRSTLAST;
+    return A_ALL;
+}
+
+static uint32_t pack_shift_for(size_t pack_rows, int width) {
+    if (pack_rows == 0 || (pack_rows & (pack_rows - 1))) return 255;
+    const size_t wave_rows = (size_t)tile_rows(width) / kWavesPerBlock;
+    if (pack_rows < wave_rows) return 255;
+    uint32_t s = 0;
+    while (((size_t)1 << s) < pack_rows) s++;
+    return s;
+}
+
+// single fused pass: leaves (same width) + optional aggregate column, into partial slot `slot`
+static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_col *const *lcols, int n_leaves, uint64_t tt,
+                     const knox_col *agg_col, unsigned agg, size_t n_rows, size_t pack_rows, uint64_t row_base,
+                     const uint8_t *d_skip, uint32_t *bits, int slot, int grid, int dtype_for_state) {
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    for (int l = 0; l < n_leaves; l++) {
+        a.leaf[l].col = lcols[l]->dev;
+        a.leaf[l].lo = lh[l].lo;
+        a.leaf[l].diff = lh[l].diff;
+        a.leaf[l].is_float = lh[l].is_float ? 1 : 0;
+    }
+    a.tt = tt;
+    bool sep = false;
+    if (agg_col) {
+        a.agg_col = agg_col->dev;
+        a.agg_flavor = dtype_flavor(agg_col->dtype);
+        sep = agg_col->dev != lcols[0]->dev;
+    }
+    const uint64_t tr = (uint64_t)tile_rows(width);
+    a.n_tiles = n_rows / tr;
+    a.n_rows = n_rows;
+    a.row_base = row_base;
+    a.bits = bits;
+    a.pack_skip = d_skip;
+    a.pack_shift = d_skip ? pack_shift_for(pack_rows, width) : 255;
+    a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
+    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
+    if (slot != 15) prof_mark(ctx, 0);
+    hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, ctx->variant, a);
+    if (slot != 15) prof_mark(ctx, 1);
+    if (e == hipSuccess) e = launch_scan_tail(ctx->stream, width, n_leaves, agg, g, a);
+    if (e == hipSuccess)
+        e = launch_finalize(ctx->stream, width, a.partials, g + 1, agg_col ? agg_col->dev : nullptr, row_base, dtype_for_state,
+                            (AggStateDev *)ctx->states.p + slot, (int64_t *)((AggStateDev *)ctx->states.p + 16) + slot);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
+static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, unsigned agg, size_t n_rows, uint64_t row_base,
+                      int slot, int grid) {
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.agg_col = col->dev;
+    a.agg_flavor = dtype_flavor(col->dtype);
+    const uint64_t tr = (uint64_t)tile_rows(col->width);
+    a.n_tiles = n_rows / tr;
+    a.n_rows = n_rows;
+    a.row_base = row_base;
+    a.mask = mask;
+    a.pack_shift = 255;
+    a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
+    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
+    hipError_t e = launch_reduce(ctx->stream, col->width, agg, g, a);
+    if (e == hipSuccess)
+        e = launch_finalize(ctx->stream, col->width, a.partials, g + 1, col->dev, row_base, col->dtype, (AggStateDev *)ctx->states.p + slot,
+                            (int64_t *)((AggStateDev *)ctx->states.p + 16) + slot);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
+// one leaf -> its own bitset (multi-pass plan)
+static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *col, size_t n_rows, uint64_t *bits, const uint8_t *d_skip,
+                            int grid) {
+    if (col->dtype == KNOX_BYTES) {
+        if (p.op != KNOX_EQ && p.op != KNOX_NE) return KNOX_E_UNSUPPORTED;
+        if (p.val_len > 0xffffffffull || (p.val_len && !p.val)) return KNOX_E_INVALID;
+        int rc = ensure(ctx, ctx->bytes_val, (size_t)p.val_len + 16);
+        if (rc) return rc;
+        if (p.val_len) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, p.val, (size_t)p.val_len, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host value not retained
+        }
+        hipError_t e = launch_bytes_match(ctx->stream, p.op == KNOX_EQ, (const uint64_t *)col->dev, n_rows, col->buf,
+                                          (const uint8_t *)ctx->bytes_val.p, (uint32_t)p.val_len, (uint8_t *)bits, nullptr, nullptr);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return KNOX_E_HIP;
+        }
+        return KNOX_OK;
+    }
+    LeafHost lh;
+    int rc = make_leaf(col->dtype, p.op, p.a, p.b, lh);
+    if (rc) return rc;
+    const uint64_t tt = lh.neg ? 0x1ull : 0x2ull;
+    const knox_col *lc[1] = {col};
+    // slot 15 is a throw-away partial slot for intermediate leaves
+    return run_fused(ctx, col->width, &lh, lc, 1, tt, nullptr, 0, n_rows, col->pack_rows, 0, d_skip, (uint32_t *)bits, 15, grid, col->dtype);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan
+// ------------------------------------------------------------------------------------------------
+KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols,
+                             const knox_agg *aggs, int n_aggs, uint64_t row_base, const uint8_t *pack_skip, knox_bits *bits_out,
+                             int want_pack_counts) {
+    if (!ctx || !nodes || n_nodes <= 0 || !cols || n_cols <= 0 || n_aggs < 0 || n_aggs > 14 || (n_aggs && !aggs)) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    const size_t n_rows = cols[0]->n_rows;
+    const size_t pack_rows = cols[0]->pack_rows;
+    for (int i = 0; i < n_cols; i++)
+        if (!cols[i] || cols[i]->n_rows != n_rows || cols[i]->ctx != ctx) return KNOX_E_INVALID;
+    if (bits_out && bits_out->size != n_rows) return KNOX_E_INVALID;
+    if ((want_pack_counts || pack_skip) && (pack_rows == 0 || (pack_rows & 63))) return KNOX_E_INVALID;
+    const size_t n_packs = pack_rows ? (n_rows + pack_rows - 1) / pack_rows : 0;
+
+    // ---- leaves
+    std::vector<int> leaf_of_node(n_nodes, -1);
+    std::vector<int> leaf_nodes;
+    for (int i = 0; i < n_nodes; i++) {
+        if (nodes[i].kind == KNOX_NODE_LEAF) {
+            if (nodes[i].col < 0 || nodes[i].col >= n_cols) return KNOX_E_INVALID;
+            leaf_of_node[i] = (int)leaf_nodes.size();
+            leaf_nodes.push_back(i);
+        } else if (nodes[i].kind != KNOX_NODE_AND && nodes[i].kind != KNOX_NODE_OR) {
+            return KNOX_E_INVALID;
+        }
+    }
+    const int n_leaves = (int)leaf_nodes.size();
+    if (n_leaves == 0) return KNOX_E_INVALID;
+
+    // ---- aggregate columns: distinct columns, union of needed work
+    int agg_cols[14], n_agg_cols = 0;
+    unsigned agg_needs[14];
+    for (int i = 0; i < n_aggs; i++) {
+        if (aggs[i].col < 0 || aggs[i].col >= n_cols || cols[aggs[i].col]->dtype == KNOX_BYTES) return KNOX_E_INVALID;
+        int s = -1;
+        for (int j = 0; j < n_agg_cols; j++)
+            if (agg_cols[j] == aggs[i].col) s = j;
+        if (s < 0) {
+            s = n_agg_cols++;
+            agg_cols[s] = aggs[i].col;
+            agg_needs[s] = 0;
+        }
+        int rc = agg_need(aggs[i].func, cols[aggs[i].col]->dtype, agg_needs[s]);
+        if (rc) return rc;
+        ctx->last_agg_slot[i] = s;
+    }
+    ctx->last_n_aggs = n_aggs;
+    const int n_slots = std::max(1, n_agg_cols);
+    ctx->last_slots = n_slots;
+
+    // ---- workspace
+    const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
+    int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
+    if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->states.p, 0, sizeof(AggStateDev) * 16 + 8 * 16, ctx->stream));
+    const uint8_t *d_skip = nullptr;
+    uint64_t rows_scanned = n_rows;
+    if (pack_skip && n_packs) {
+        rc = ensure(ctx, ctx->pack_skip, n_packs + 16);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pack_skip.p, pack_skip, n_packs, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host array not retained
+        d_skip = (const uint8_t *)ctx->pack_skip.p;
+        for (size_t p = 0; p < n_packs; p++)
+            if (pack_skip[p]) rows_scanned -= std::min(pack_rows, n_rows - p * pack_rows);
+    }
+    ctx->last_rows_scanned = rows_scanned;
+
+    // ---- can the whole tree run as one fused pass?
+    bool fused = n_leaves <= kMaxLeaves;
+    int width = 0;
+    for (int l = 0; l < n_leaves && fused; l++) {
+        const knox_col *c = cols[nodes[leaf_nodes[l]].col];
+        if (c->dtype == KNOX_BYTES) fused = false;
+        else if (width == 0) width = c->width;
+        else if (c->width != width) fused = false;
+    }
+    const bool need_bits = bits_out != nullptr || want_pack_counts || !fused || n_agg_cols > 1 ||
+                           (n_agg_cols == 1 && fused && cols[agg_cols[0]]->width != width);
+    uint64_t *bits = bits_out ? bits_out->dev : nullptr;
+    if (need_bits && !bits) {
+        rc = ensure(ctx, ctx->tmp_bits, (bits_padded(n_rows) + 64) * 8);  // result + up to 7 stack temporaries
+        if (rc) return rc;
+        bits = (uint64_t *)ctx->tmp_bits.p;
+        HIPCHK(ctx, hipMemsetAsync(bits, 0, bits_padded(n_rows) + 64, ctx->stream));
+    }
+
+    int first_reduce_slot = 0;
+    if (fused) {
+        LeafHost lh[kMaxLeaves];
+        const knox_col *lc[kMaxLeaves];
+        std::vector<bool> neg(n_leaves);
+        for (int l = 0; l < n_leaves; l++) {
+            const knox_pred &p = nodes[leaf_nodes[l]];
+            lc[l] = cols[p.col];
+            rc = make_leaf(lc[l]->dtype, p.op, p.a, p.b, lh[l]);
+            if (rc) return rc;
+            neg[l] = lh[l].neg;
+        }
+        // the aggregate column rides in the same pass when it has the leaves' width; put it
+        // first among the leaves if it is one of them so its registers are reused
+        const knox_col *ac = nullptr;
+        unsigned acls = 0;
+        if (n_agg_cols >= 1 && cols[agg_cols[0]]->width == width) {
+            ac = cols[agg_cols[0]];
+            acls = agg_class(agg_needs[0]);
+            first_reduce_slot = 1;
+        }
+        std::vector<int> lof = leaf_of_node;
+        if (ac) {
+            for (int l = 1; l < n_leaves; l++) {
+                if (lc[l]->dev == ac->dev && lc[0]->dev != ac->dev) {
+                    std::swap(lc[0], lc[l]);
+                    std::swap(lh[0], lh[l]);
+                    const bool t = neg[0]; neg[0] = neg[l]; neg[l] = t;
+                    for (int i = 0; i < n_nodes; i++) {
+                        if (lof[i] == 0) lof[i] = l;
+                        else if (lof[i] == l) lof[i] = 0;
+                    }
+                    break;
+                }
+            }
+        }
+        uint64_t tt;
+        rc = make_truth_table(nodes, n_nodes, lof, neg, n_leaves, tt);
+        if (rc) return rc;
+        rc = run_fused(ctx, width, lh, lc, n_leaves, tt, ac, acls, n_rows, pack_rows, row_base, d_skip, (uint32_t *)bits, 0, grid,
+                       ac ? ac->dtype : lc[0]->dtype);
+        if (rc) return rc;
+    } else {
+        // multi-pass plan: each leaf into a scratch bitset, postfix combine with the bitset
+        // kernels (exactly the reference's MatchAnd / MatchOr data flow, match_core.go:45-215)
+        if (bits_out == nullptr && bits == nullptr) return KNOX_E_INVALID;
+        const size_t stride = (bits_padded(n_rows) + 64) / 8;  // uint64 words per scratch bitset
+        rc = ensure(ctx, ctx->tmp_bits, stride * 8 * 8);
+        if (rc) return rc;
+        if (!bits_out) bits = (uint64_t *)ctx->tmp_bits.p;
+        uint64_t *pool = (uint64_t *)ctx->tmp_bits.p;
+        // stack slot 0 aliases the result buffer
+        auto slot_ptr = [&](int s) { return s == 0 ? bits : pool + (size_t)s * stride; };
+        int sp = 0;
+        for (int i = 0; i < n_nodes; i++) {
+            const knox_pred &p = nodes[i];
+            if (p.kind == KNOX_NODE_LEAF) {
+                if (sp >= 7) return KNOX_E_UNSUPPORTED;
+                uint64_t *dst = slot_ptr(sp);
+                HIPCHK(ctx, hipMemsetAsync(dst, 0, bits_padded(n_rows) + 8, ctx->stream));
+                rc = run_leaf_to_bits(ctx, p, cols[p.col], n_rows, dst, d_skip, grid);
+                if (rc) return rc;
+                sp++;
+            } else {
+                const int k = p.nchild;
+                if (k < 0 || k > sp) return KNOX_E_INVALID;
+                if (k == 0) {
+                    if (sp >= 7) return KNOX_E_UNSUPPORTED;
+                    uint64_t *dst = slot_ptr(sp);
+                    hipError_t e = p.kind == KNOX_NODE_AND ? launch_bitop(ctx->stream, BIT_ONE, dst, nullptr, n_rows, nullptr)
+                                                           : hipMemsetAsync(dst, 0, bits_padded(n_rows) + 8, ctx->stream);
+                    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+                    sp++;
+                    continue;
+                }
+                uint64_t *dst = slot_ptr(sp - k);
+                for (int j = 1; j < k; j++) {
+                    hipError_t e = launch_bitop(ctx->stream, p.kind == KNOX_NODE_AND ? BIT_AND : BIT_OR, dst, slot_ptr(sp - k + j), n_rows, nullptr);
+                    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+                }
+                sp -= (k - 1);
+            }
+        }
+        if (sp != 1) return KNOX_E_INVALID;
+        // total count (slot 0 count word) from the final bitset
+        unsigned long long *d_cnt = (unsigned long long *)((int64_t *)((AggStateDev *)ctx->states.p + 16));
+        hipError_t e = launch_popcount(ctx->stream, bits, n_rows, d_cnt);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+        first_reduce_slot = 0;
+    }
+
+    // ---- remaining aggregate columns: masked reduce over the result bitset
+    for (int s = first_reduce_slot; s < n_agg_cols; s++) {
+        rc = run_reduce(ctx, cols[agg_cols[s]], (const uint32_t *)bits, agg_class(agg_needs[s]) ? agg_class(agg_needs[s]) : A_ISUM, n_rows, row_base, s, grid);
+        if (rc) return rc;
+    }
+
+    // ---- per-pack counts from the bitset
+    ctx->last_has_pack_counts = false;
+    ctx->last_n_packs = n_packs;
+    if (want_pack_counts && n_packs) {
+        rc = ensure(ctx, ctx->pack_counts, n_packs * 8 + 8);
+        if (!rc) rc = ensure_host(ctx, ctx->h_packs, ctx->h_packs_cap, n_packs * 8);
+        if (rc) return rc;
+        hipError_t e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)ctx->pack_counts.p, n_packs);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_packs, ctx->pack_counts.p, n_packs * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->last_has_pack_counts = true;
+    }
+    // ---- small results -> pinned mirror
+    rc = ensure_host(ctx, ctx->h_res, ctx->h_res_cap, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_res, ctx->states.p, sizeof(AggStateDev) * 16 + 8 * 16, hipMemcpyDeviceToHost, ctx->stream));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_state *states, int n_aggs, knox_scan_out *out) {
+    if (!ctx || n_aggs < 0 || (n_aggs && !states)) return KNOX_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->h_res) return KNOX_E_INVALID;
+    const AggStateDev *st = (const AggStateDev *)ctx->h_res;
+    const int64_t *counts = (const int64_t *)(st + 16);
+    if (n_aggs > ctx->last_n_aggs) return KNOX_E_RANGE;
+    for (int i = 0; i < n_aggs; i++) memcpy(&states[i], &st[ctx->last_agg_slot[i]], sizeof(knox_agg_state));
+    if (out) {
+        out->count = counts[0];
+        out->rows_scanned = (int64_t)ctx->last_rows_scanned;
+    }
+    if (pack_counts) {
+        if (!ctx->last_has_pack_counts) return KNOX_E_INVALID;
+        memcpy(pack_counts, ctx->h_packs, ctx->last_n_packs * 8);
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_scan(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols, const knox_agg *aggs,
+                       int n_aggs, uint64_t row_base, const uint8_t *pack_skip, knox_bits *bits_out, int64_t *pack_counts,
+                       knox_agg_state *states, knox_scan_out *out) {
+    int rc = knox_scan_async(ctx, nodes, n_nodes, cols, n_cols, aggs, n_aggs, row_base, pack_skip, bits_out, pack_counts != nullptr);
+    if (rc) return rc;
+    return knox_scan_collect(ctx, pack_counts, states, n_aggs, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// knox_cmp: the finest boundary (host slices in, host bitset out)
+// ------------------------------------------------------------------------------------------------
+KNOX_API int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, size_t n, const void *a, const void *b, uint8_t *bits) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (n == 0 || src == nullptr) return 0;  // cmp/tests/int64.go:212-213
+    const int w = dtype_width(dtype);
+    if (w == 0 || !bits || !a || (op == KNOX_RANGE && !b)) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    uint64_t av = 0, bv = 0;
+    memcpy(&av, a, (size_t)w);
+    if (b) memcpy(&bv, b, (size_t)w);
+    LeafHost lh;
+    int rc = make_leaf(dtype, op, av, bv, lh);
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->tmp_vals, n * (size_t)w + 512);
+    if (!rc) rc = ensure(ctx, ctx->tmp_bits, (bits_padded(n) + 64) * 8);
+    const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
+    if (!rc) rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
+    if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (rc) return rc;
+    rc = upload(ctx, ctx->tmp_vals.p, src, n * (size_t)w);
+    if (rc) return rc;
+    knox_col tmp;
+    tmp.ctx = ctx; tmp.dtype = dtype; tmp.width = w; tmp.n_rows = n; tmp.pack_rows = n; tmp.dev = ctx->tmp_vals.p;
+    tmp.buf = nullptr; tmp.buf_len = 0; tmp.owned = false;
+    const knox_col *lc[1] = {&tmp};
+    const uint64_t tt = lh.neg ? 0x1ull : 0x2ull;
+    rc = run_fused(ctx, w, &lh, lc, 1, tt, nullptr, 0, n, n, 0, nullptr, (uint32_t *)ctx->tmp_bits.p, 0, grid, dtype);
+    if (rc) return rc;
+    int64_t cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&cnt, (int64_t *)((AggStateDev *)ctx->states.p + 16), 8, hipMemcpyDeviceToHost, ctx->stream));
+    rc = download(ctx, bits, ctx->tmp_bits.p, bits_bytes(n));  // exactly (n+7)/8 bytes: poison tail untouched
+    if (rc) return rc;
+    return cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reducers
+// ------------------------------------------------------------------------------------------------
+KNOX_API int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, uint64_t row_base, knox_agg_state *state) {
+    if (!ctx || !col || !state || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
+    int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
+    if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (rc) return rc;
+    rc = run_reduce(ctx, col, mask ? (const uint32_t *)mask->dev : nullptr, A_ALL, col->n_rows, row_base, 0, grid);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(state, ctx->states.p, sizeof(knox_agg_state), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, int func, void *value_out, int *seen,
+                                    int64_t *row) {
+    if (!ctx || !col || !value_out || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
+    if (func < 0 || func > 8) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = ensure(ctx, ctx->misc, 256);
+    if (rc) return rc;
+    uint64_t *d = (uint64_t *)((char *)ctx->misc.p + 192);
+    hipError_t e = launch_reduce_sequential(ctx->stream, col->dtype, func, col->dev, col->n_rows, mask ? (const uint8_t *)mask->dev : nullptr, d);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    uint64_t h[3] = {0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(value_out, &h[0], (size_t)col->width);
+    if (seen) *seen = (int)h[1];
+    if (row) *row = h[2] == ~0ull ? -1 : (int64_t)h[2];
+    return KNOX_OK;
+}
+
+// ---- Reducer.Value() from a merged state (pure host code) ------------------------------------
+static void store_value(int dtype, void *out, uint64_t bits) { memcpy(out, &bits, (size_t)dtype_width(dtype)); }
+
+static double dd_to_double(double hi, double lo) {
+    if (!(fabs(hi) <= 1.7976931348623157e308)) return hi;
+    return (double)((__float128)hi + (__float128)lo);
+}
+
+KNOX_API int knox_agg_value(const knox_agg_state *st, int func, void *value_out, int *seen, int64_t *row) {
+    if (!st || !value_out) return KNOX_E_INVALID;
+    const int dtype = st->dtype;
+    const int w = dtype_width(dtype);
+    if (w == 0) return KNOX_E_INVALID;
+    const bool isf = dtype_is_float(dtype);
+    const bool any = st->count > 0;
+    if (seen) *seen = any ? 1 : 0;
+    if (row) *row = any ? st->first_row : -1;
+    uint64_t zero = 0;
+    memcpy(value_out, &zero, (size_t)w);
+    if (!any) return KNOX_OK;
+    auto as_f64 = [&](uint64_t bits) {
+        if (dtype == KNOX_FLOAT64) { double d; memcpy(&d, &bits, 8); return d; }
+        float f; uint32_t u = (uint32_t)bits; memcpy(&f, &u, 4); return (double)f;
+    };
+    auto put_float = [&](double d) {
+        if (dtype == KNOX_FLOAT64) memcpy(value_out, &d, 8);
+        else { float f = (float)d; memcpy(value_out, &f, 4); }
+    };
+    switch (func) {
+    case KNOX_R_COUNT: {  // CountReducer counts in T (reducer.go:138-148)
+        if (isf) put_float(dtype == KNOX_FLOAT64 ? (double)st->count : (double)(float)st->count);
+        else store_value(dtype, value_out, (uint64_t)st->count);
+        break;
+    }
+    case KNOX_R_SUM:
+        if (isf) put_float(dd_to_double(st->fsum_hi, st->fsum_lo));
+        else store_value(dtype, value_out, st->isum);  // wraps in T like Go
+        break;
+    case KNOX_R_MEAN: {
+        // exact_sum / n rounded once (reference: sequential Welford, see DESIGN.md on parity)
+        double mean;
+        if (!(fabs(st->fsum_hi) <= 1.7976931348623157e308)) mean = st->fsum_hi;
+        else mean = (double)(((__float128)st->fsum_hi + (__float128)st->fsum_lo) / (__float128)st->count);
+        if (isf) put_float(mean);
+        else if (dtype_is_signed(dtype)) store_value(dtype, value_out, (uint64_t)(int64_t)mean);  // T(r.mean) truncates toward zero
+        else store_value(dtype, value_out, (uint64_t)mean);
+        break;
+    }
+    case KNOX_R_FIRST:
+        store_value(dtype, value_out, st->first_bits);
+        if (row) *row = st->first_row;
+        break;
+    case KNOX_R_LAST:
+        store_value(dtype, value_out, st->last_bits);
+        if (row) *row = st->last_row;
+        break;
+    case KNOX_R_MIN:
+    case KNOX_R_MAX: {
+        // a NaN first value is adopted and then sticks (reducer.go:256-296): r.v < NaN and r.v > NaN are false
+        if (isf && isnan(as_f64(st->first_bits))) {
+            store_value(dtype, value_out, st->first_bits);
+            if (row) *row = st->first_row;
+            break;
+        }
+        const bool mn = func == KNOX_R_MIN;
+        if ((mn ? st->min_row : st->max_row) < 0) {  // unreachable for ints; floats: all later values NaN handled above
+            store_value(dtype, value_out, st->first_bits);
+            if (row) *row = st->first_row;
+            break;
+        }
+        store_value(dtype, value_out, mn ? st->min_bits : st->max_bits);
+        if (row) *row = mn ? st->min_row : st->max_row;
+        break;
+    }
+    default:
+        return KNOX_E_UNSUPPORTED;
+    }
+    return KNOX_OK;
+}
+
+static uint64_t order_key(int dtype, uint64_t bits) {
+    const int w = dtype_width(dtype);
+    const uint64_t m = wmask(w), sign = 1ull << (8 * w - 1);
+    bits &= m;
+    if (dtype_is_float(dtype)) {
+        if ((bits & (m ^ sign)) == 0) return host_fkey(0, w);  // +-0 share a key
+        return host_fkey(bits, w);
+    }
+    return dtype_is_signed(dtype) ? (bits ^ sign) : bits;
+}
+
+KNOX_API int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out) {
+    if (!states || !out || n <= 0) return KNOX_E_INVALID;
+    knox_agg_state r = states[0];
+    for (int i = 1; i < n; i++) {
+        const knox_agg_state &s = states[i];
+        if (s.dtype != r.dtype) return KNOX_E_INVALID;
+        r.flags |= s.flags;
+        r.count += s.count;
+        r.isum += s.isum;
+        {   // double-double add, same form as the device merge
+            double hi = r.fsum_hi, lo = r.fsum_lo;
+            double sum = hi + s.fsum_hi;
+            double bb = sum - hi;
+            double e = (hi - (sum - bb)) + (s.fsum_hi - bb);
+            if (!(fabs(sum) <= 1.7976931348623157e308)) e = 0.0;
+            r.fsum_lo = lo + s.fsum_lo + e;
+            r.fsum_hi = sum;
+        }
+        if (s.min_row >= 0) {
+            const uint64_t ks = order_key(r.dtype, s.min_bits), kr = order_key(r.dtype, r.min_bits);
+            if (r.min_row < 0 || ks < kr || (ks == kr && s.min_row < r.min_row)) { r.min_bits = s.min_bits; r.min_row = s.min_row; }
+        }
+        if (s.max_row >= 0) {
+            const uint64_t ks = order_key(r.dtype, s.max_bits), kr = order_key(r.dtype, r.max_bits);
+            if (r.max_row < 0 || ks > kr || (ks == kr && s.max_row < r.max_row)) { r.max_bits = s.max_bits; r.max_row = s.max_row; }
+        }
+        if (s.first_row >= 0 && (r.first_row < 0 || s.first_row < r.first_row)) { r.first_row = s.first_row; r.first_bits = s.first_bits; }
+        if (s.last_row >= 0 && (r.last_row < 0 || s.last_row > r.last_row)) { r.last_row = s.last_row; r.last_bits = s.last_bits; }
+    }
+    *out = r;
+    return KNOX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bloom
+// ------------------------------------------------------------------------------------------------
+static inline uint64_t h_rol64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t h_rrmxmx(uint64_t h, uint64_t len) {
+    h ^= h_rol64(h, 49) ^ h_rol64(h, 24);
+    h *= 0x9fb21c651e98df25ull;
+    h ^= (h >> 35) + len;
+    h *= 0x9fb21c651e98df25ull;
+    return h ^ (h >> 28);
+}
+static uint64_t h_avalanche_small(uint64_t x) {
+    x ^= x >> 33; x *= 14029467366897019727ull; x ^= x >> 29; x *= 1609587929392839161ull; x ^= x >> 32;
+    return x;
+}
+
+// internal/hash/hash.go:67-92 + xxh3.go:22-58.  float32/float64 hash their IEEE bytes with the
+// []byte hash, which for 4 and 8 byte inputs is the same 4..8 byte XXH3 branch as u32 / u64.
+KNOX_API uint64_t knox_hash_value(int dtype, const void *val) {
+    if (!val) return 0;
+    const uint64_t K = 0x1cad21f72c81017cull ^ 0xdb979083e96dd4deull;
+    switch (dtype_width(dtype)) {
+    case 8: { uint64_t v; memcpy(&v, val, 8); return h_rrmxmx(((v >> 32) + (v << 32)) ^ K, 8); }
+    case 4: { uint32_t v; memcpy(&v, val, 4); return h_rrmxmx(((uint64_t)v + ((uint64_t)v << 32)) ^ K, 4); }
+    case 2: { uint16_t v; memcpy(&v, val, 2); uint64_t h = (((uint64_t)v * ((1ull << 24) + 1)) >> 8) + (2ull << 8); return h_avalanche_small(h ^ (0xbe4ba423ull ^ 0x396cfeb8ull)); }
+    case 1: { uint8_t v; memcpy(&v, val, 1); uint64_t h = ((uint64_t)v * ((1ull << 24) + (1ull << 16) + 1)) + (1ull << 8); return h_avalanche_small(h ^ (0xbe4ba423ull ^ 0x396cfeb8ull)); }
+    default: return 0;
+    }
+}
+
+KNOX_API int knox_bloom_probe(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs, uint64_t h, uint8_t *maybe_out) {
+    if (!ctx || !offsets || !maybe_out || (n_packs && offsets[n_packs] && !filters)) return KNOX_E_INVALID;
+    if (n_packs == 0) return KNOX_OK;
+    hipSetDevice(ctx->device);
+    for (size_t p = 0; p < n_packs; p++) {
+        if (offsets[p + 1] < offsets[p]) return KNOX_E_INVALID;
+        const uint64_t len = offsets[p + 1] - offsets[p];
+        if (len > 1 && ((len - 1) & (len - 2)) != 0) return KNOX_E_INVALID;  // m must be a power of two (bloom.go:83-101)
+    }
+    const size_t fbytes = (size_t)offsets[n_packs];
+    const size_t total = fbytes + 16 + (n_packs + 1) * 8 + n_packs + 64;
+    int rc = ensure(ctx, ctx->tmp_vals, total);
+    if (rc) return rc;
+    uint8_t *d_f = (uint8_t *)ctx->tmp_vals.p;
+    uint64_t *d_o = (uint64_t *)(d_f + ((fbytes + 15) & ~(size_t)15));
+    uint8_t *d_m = (uint8_t *)(d_o + n_packs + 1);
+    rc = upload(ctx, d_f, filters, fbytes);
+    if (!rc) rc = upload(ctx, d_o, offsets, (n_packs + 1) * 8);
+    if (rc) return rc;
+    hipError_t e = launch_bloom_probe(ctx->stream, d_f, d_o, n_packs, h, d_m);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return download(ctx, maybe_out, d_m, n_packs);
+}
+
+KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, uint8_t *filters_out, size_t filters_cap, uint64_t *offsets_out) {
+    if (!ctx || !col || col->width != 8 || col->dtype == KNOX_BYTES || factor <= 0 || !offsets_out) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    const size_t n_packs = col->pack_rows ? (col->n_rows + col->pack_rows - 1) / col->pack_rows : 0;
+    uint64_t off = 0;
+    for (size_t p = 0; p < n_packs; p++) {
+        const size_t rows = std::min(col->pack_rows, col->n_rows - p * col->pack_rows);
+        uint64_t m = 8;  // bloom.go:242-249 pow2: next power of two >= cardinality*factor*8 bits
+        while (m < (uint64_t)rows * (uint64_t)factor * 8) m <<= 1;
+        offsets_out[p] = off;
+        off += 1 + (m >> 3);
+    }
+    offsets_out[n_packs] = off;
+    if (off > filters_cap || (off && !filters_out)) return KNOX_E_RANGE;
+    int rc = ensure(ctx, ctx->tmp_vals, (size_t)off + 16 + (n_packs + 1) * 8 + 64);
+    if (rc) return rc;
+    uint8_t *d_f = (uint8_t *)ctx->tmp_vals.p;
+    uint64_t *d_o = (uint64_t *)(d_f + (((size_t)off + 15) & ~(size_t)15));
+    HIPCHK(ctx, hipMemsetAsync(d_f, 0, ((size_t)off + 15) & ~(size_t)15, ctx->stream));
+    rc = upload(ctx, d_o, offsets_out, (n_packs + 1) * 8);
+    if (rc) return rc;
+    hipError_t e = launch_bloom_build_u64(ctx->stream, (const uint64_t *)col->dev, col->n_rows, col->pack_rows, d_f, d_o);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return download(ctx, filters_out, d_f, (size_t)off);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL: exchange of the final partial aggregates only (pack shards never move)
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return KNOX_OK;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return KNOX_E_COMM;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) return KNOX_E_COMM;
+    g_rccl.lib = lib;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_unique_id(uint8_t id[KNOX_COMM_ID_BYTES]) {
+    if (!id) return KNOX_E_INVALID;
+    static_assert(sizeof(ncclUniqueId) == KNOX_COMM_ID_BYTES, "ncclUniqueId size");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return KNOX_E_COMM;
+    memcpy(id, &u, sizeof u);
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_init(knox_ctx *ctx, int n_ranks, int rank, const uint8_t id[KNOX_COMM_ID_BYTES]) {
+    if (!ctx || !id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return KNOX_E_INVALID;
+    int rc = rccl_load();
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    if (g_rccl.CommInitRank(&ctx->comm, n_ranks, u, rank) != ncclSuccess) {
+        ctx->comm = nullptr;
+        return KNOX_E_COMM;
+    }
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *mine, int n_states, knox_agg_state *merged, int64_t *count_inout) {
+    if (!ctx || n_states < 0 || n_states > 14 || (n_states && (!mine || !merged))) return KNOX_E_INVALID;
+    if (!ctx->comm) return KNOX_E_COMM;
+    hipSetDevice(ctx->device);
+    // payload per rank: n_states states + one int64 count
+    const size_t per = sizeof(knox_agg_state) * (size_t)n_states + 8;
+    const size_t total = per * (size_t)ctx->n_ranks;
+    int rc = ensure(ctx, ctx->comm_buf, per + total + 64);
+    if (rc) return rc;
+    std::vector<uint8_t> h(per + total);
+    if (n_states) memcpy(h.data(), mine, sizeof(knox_agg_state) * (size_t)n_states);
+    int64_t c = count_inout ? *count_inout : 0;
+    memcpy(h.data() + per - 8, &c, 8);
+    uint8_t *d_send = (uint8_t *)ctx->comm_buf.p;
+    uint8_t *d_recv = d_send + ((per + 63) & ~(size_t)63);
+    rc = ensure(ctx, ctx->comm_buf, ((per + 63) & ~(size_t)63) + total + 64);
+    if (rc) return rc;
+    d_send = (uint8_t *)ctx->comm_buf.p;
+    d_recv = d_send + ((per + 63) & ~(size_t)63);
+    HIPCHK(ctx, hipMemcpyAsync(d_send, h.data(), per, hipMemcpyHostToDevice, ctx->stream));
+    if (g_rccl.AllGather(d_send, d_recv, per, ncclUint8, ctx->comm, ctx->stream) != ncclSuccess) return KNOX_E_COMM;
+    HIPCHK(ctx, hipMemcpyAsync(h.data() + per, d_recv, total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // deterministic merge in rank order on every rank (rank order == global row order)
+    std::vector<knox_agg_state> tmp((size_t)ctx->n_ranks);
+    for (int s = 0; s < n_states; s++) {
+        for (int r = 0; r < ctx->n_ranks; r++) memcpy(&tmp[(size_t)r], h.data() + per + per * (size_t)r + sizeof(knox_agg_state) * (size_t)s, sizeof(knox_agg_state));
+        rc = knox_agg_combine(tmp.data(), ctx->n_ranks, &merged[s]);
+        if (rc) return rc;
+    }
+    if (count_inout) {
+        int64_t sum = 0;
+        for (int r = 0; r < ctx->n_ranks; r++) {
+            int64_t v;
+            memcpy(&v, h.data() + per + per * (size_t)r + per - 8, 8);
+            sum += v;
+        }
+        *count_inout = sum;
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_destroy(knox_ctx *ctx) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+    return KNOX_OK;
+}

@@ -1,0 +1,114 @@
+// knox_kernels.h -- internal interface between the C ABI (knox_abi.hip) and the gfx950
+// kernels (knox_kernels.hip).  Not installed; the public surface is include/knoxgpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace knox {
+
+constexpr int kBlock = 256;          // threads per workgroup = 4 wave64
+constexpr int kWavesPerBlock = 4;
+constexpr int kUnroll = 4;           // 16-byte loads in flight per lane per column
+constexpr int kMaxLeaves = 4;        // leaves evaluated by one fused pass (truth table 2^4 bits)
+constexpr uint64_t kNoRow = ~0ull;
+
+// aggregate work a pass performs (template mask)
+enum : unsigned { A_ISUM = 1, A_FSUM = 2, A_MINMAX = 4, A_FIRSTLAST = 8, A_ALL = 15 };
+// value flavour of the aggregated column
+enum : unsigned { FL_SIGNED = 0, FL_UNSIGNED = 1, FL_FLOAT = 2 };
+
+// One leaf in "key space": hit <=> U(key(x) - lo) <= diff, key = float order key or raw bits.
+struct LeafDev {
+    const void *col;
+    uint64_t lo;
+    uint64_t diff;
+    uint32_t is_float;
+    uint32_t _pad;
+};
+
+// Mergeable partial aggregate (one per workgroup, merged in block order by finalize).
+struct AggPartial {
+    uint64_t count;
+    uint64_t isum;
+    double hi, lo;
+    uint64_t minkey, minrow;
+    uint64_t maxkey, maxrow;
+    uint64_t firstrow, lastrow;
+};
+
+struct ScanArgs {
+    LeafDev leaf[kMaxLeaves];
+    uint64_t tt;            // truth table over the leaf hit bits (bit index = sum hit_l << l)
+    const void *agg_col;    // aggregated column (may alias leaf[0].col)
+    uint32_t agg_flavor;
+    uint32_t pack_shift;    // log2(pack_rows), or 255: no per-pack skipping
+    const uint8_t *pack_skip;
+    uint64_t n_tiles;       // full tiles handled by the streaming kernel
+    uint64_t n_rows;        // all rows (tail kernel covers [n_tiles*tile_rows, n_rows))
+    uint64_t row_base;      // global id of local row 0
+    uint32_t *bits;         // output bitset (nullable)
+    const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)
+    AggPartial *partials;   // [grid] (+1 slot for the tail at index grid)
+};
+
+// mirror of knox_agg_state (include/knoxgpu.h) written by the finalize kernel
+struct AggStateDev {
+    int32_t dtype;
+    uint32_t flags;
+    int64_t count;
+    uint64_t isum;
+    double fsum_hi, fsum_lo;
+    uint64_t min_bits, max_bits, first_bits, last_bits;
+    int64_t min_row, max_row, first_row, last_row;
+};
+
+int tile_rows(int width);  // rows per workgroup tile of the streaming kernels
+
+// Streaming scan: evaluates the leaves' truth table for n_tiles full tiles, writes bitset
+// words, accumulates count + aggregates into partials[0..grid).  width = bytes per value.
+hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, bool agg_separate,
+                       int grid, int variant, const ScanArgs &a);
+// Tail / small-n path: rows [n_tiles*tile_rows, n_rows), byte-granular stores, one workgroup,
+// partial written to partials[tail_slot].
+hipError_t launch_scan_tail(hipStream_t s, int width, int n_leaves, unsigned agg, int tail_slot,
+                            const ScanArgs &a);
+// Masked reduce: aggregates agg_col over rows selected by a.mask (or all rows).
+hipError_t launch_reduce(hipStream_t s, int width, unsigned agg, int grid, const ScanArgs &a);
+// Merge partials[0..n_partials) in order, fetch the adopted values, write the state and the
+// total count.
+hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials, int n_partials,
+                           const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out,
+                           int64_t *count_out);
+
+// bitset combinators on 64-bit words (buffers padded to a multiple of 8 bytes)
+enum BitOp { BIT_AND = 0, BIT_ANDNOT = 1, BIT_OR = 2, BIT_XOR = 3, BIT_NEG = 4, BIT_COPY = 5, BIT_ONE = 6 };
+hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *src, uint64_t size_bits,
+                        uint32_t *flags_any_all /* nullable: [0]=any (or), [1]=not-all (or) */);
+hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bits,
+                           unsigned long long *count_out /* pre-zeroed */);
+hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
+                                    int64_t *counts, uint64_t n_seg);
+// bitset -> ascending uint32 row ids; scratch holds ceil(size/8192)+1 uint32 block offsets
+hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
+                          uint32_t *rows_out, uint64_t capacity, unsigned long long *n_out);
+
+// bytes column EQ / NE (StringPool layout)
+hipError_t launch_bytes_match(hipStream_t s, bool want_eq, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                              const uint8_t *val, uint32_t vlen, uint8_t *bits, const uint8_t *mask,
+                              unsigned long long *count_out /* pre-zeroed */);
+
+// bloom probe / build
+hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,
+                              uint64_t h, uint8_t *maybe_out);
+hipError_t launch_bloom_build_u64(hipStream_t s, const uint64_t *col, uint64_t n_rows, uint64_t pack_rows,
+                                  uint8_t *filters, const uint64_t *offsets);
+
+// synthetic columns
+hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint64_t seed, uint64_t first_row,
+                           uint64_t n_rows, int64_t lo, uint64_t span, void *dst);
+
+// literal sequential reducer (one lane)
+hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows,
+                                    const uint8_t *mask, uint64_t *out3 /* value bits, seen, row */);
+
+}  // namespace knox

@@ -1,0 +1,1015 @@
+// knox_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the KnoxDB pack-scan path.
+//
+// What runs here replaces, for decoded column vectors resident in HBM:
+//   internal/cmp/number.go:13-243, float.go:13-242      predicate -> LSB-first bitset + count
+//   internal/bitset/generic/bitset.go:13-435            and/andnot/or/xor/neg(+flags)/popcount/indexes
+//   internal/reducer/reducer.go:138-349                 count/sum/min/max/first/last/mean state
+//   pkg/stringx/match.go:20-84                          bytes EQ / NE
+//   internal/filter/bloom/bloom.go:136-150              bloom probe
+//
+// Design (DESIGN.md has the long form):
+//   * HBM-bound integer work: no MFMA, no LDS staging of values.  Every lane issues kUnroll
+//     16-byte loads per column per iteration (1 KiB per wave instruction, fully coalesced),
+//     a 256-thread workgroup streams 16 KiB contiguous per column per iteration.
+//   * All compare modes of all types are ONE integer range test in "key space":
+//         hit = U(key(x) - lo) <= diff
+//     ints use their raw bits (two's-complement differences are order independent, this is
+//     the reference's own Between form number.go:211-243); floats map through the IEEE
+//     order key (sign-flip trick) so NaN falls outside every range and -0 == +0 is handled
+//     by the host's choice of bounds.  NE / empty / full are negations folded into a truth
+//     table over the leaf hits, which also evaluates any AND/OR tree of <= 4 leaves in
+//     registers (filter.Match, match_core.go:14-215, without scratch bitsets).
+//   * A lane owns K = 16/sizeof(T) ADJACENT rows, so a wave64 ballot would interleave bits.
+//     Instead each lane builds its K-bit result and the 32-bit bitset word is assembled with
+//     a DPP xor-butterfly OR over the 32/K lanes that share the word (quad_perm, quad_perm,
+//     row_half_mirror, row_mirror): VALU only, no LDS, bit i of word w == row 32*w + i.
+//   * Aggregates are per-lane registers over the grid-stride loop, then wave shuffle ->
+//     LDS -> one partial per workgroup -> ordered merge in a finalize kernel.  No float
+//     atomics anywhere: results are bitwise reproducible for a given grid.
+//   * float sums are double-double (error-free TwoSum) so the rounded result is the exact
+//     sum rounded once; integer sums wrap mod 2^64 exactly like Go.
+#include "knox_kernels.h"
+
+namespace knox {
+
+// ---------------------------------------------------------------------------------------------
+// width traits
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte global_load_dwordx4
+
+template <int W> struct WT;
+template <> struct WT<8> { using U = uint64_t; static constexpr int K = 2;  static constexpr U MASK = ~0ull;   static constexpr U SIGN = 1ull << 63; };
+template <> struct WT<4> { using U = uint32_t; static constexpr int K = 4;  static constexpr U MASK = ~0u;     static constexpr U SIGN = 1u << 31; };
+template <> struct WT<2> { using U = uint32_t; static constexpr int K = 8;  static constexpr U MASK = 0xffffu; static constexpr U SIGN = 1u << 15; };
+template <> struct WT<1> { using U = uint32_t; static constexpr int K = 16; static constexpr U MASK = 0xffu;   static constexpr U SIGN = 1u << 7; };
+
+int tile_rows(int width) { return 64 * (16 / width) * kUnroll * kWavesPerBlock; }
+
+template <int W> __device__ __forceinline__ typename WT<W>::U elem(const u32x4 &r, int j) {
+    const uint32_t d[4] = {r.x, r.y, r.z, r.w};
+    if constexpr (W == 8) {
+        return ((uint64_t)d[2 * j + 1] << 32) | d[2 * j];
+    } else if constexpr (W == 4) {
+        return d[j];
+    } else if constexpr (W == 2) {
+        return (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+    } else {
+        return (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    }
+}
+
+// IEEE order key: monotone map of float bit patterns onto unsigned integers
+// (-NaN < -Inf < ... < -0 < +0 < ... < +Inf < +NaN).
+template <int W> __device__ __forceinline__ typename WT<W>::U fkey(typename WT<W>::U u) {
+    if constexpr (W == 8) {
+        return u ^ ((uint64_t)((int64_t)u >> 63) | (1ull << 63));
+    } else if constexpr (W == 4) {
+        return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+    } else {
+        return u;
+    }
+}
+
+template <bool NT> __device__ __forceinline__ u32x4 ld16(const u32x4 *p) {
+    if constexpr (NT) {
+        return __builtin_nontemporal_load(p);
+    } else {
+        return *p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bitset word assembly: lane holds q (K bits, rows K*lane .. K*lane+K-1 of the wave-load);
+// the G = 32/K lanes sharing a 32-bit word OR their shifted pieces with a DPP butterfly.
+// Needs all 64 lanes active (true in the streaming kernels).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+template <int K> __device__ __forceinline__ uint32_t pack_word(uint32_t q, int lane) {
+    constexpr int G = 32 / K;
+    uint32_t w = q << (K * (lane & (G - 1)));
+    if constexpr (G >= 2) w |= dpp_mov<0xB1>(w);   // quad_perm [1,0,3,2]  lane ^ 1
+    if constexpr (G >= 4) w |= dpp_mov<0x4E>(w);   // quad_perm [2,3,0,1]  lane ^ 2
+    if constexpr (G >= 8) w |= dpp_mov<0x141>(w);  // row_half_mirror      lane -> 7 - lane (of 8)
+    if constexpr (G >= 16) w |= dpp_mov<0x140>(w); // row_mirror           lane -> 15 - lane (of 16)
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// aggregate accumulator
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double h2, double l2) {
+    // error-free TwoSum (Knuth); a non-finite running sum keeps its value, not NaN residue
+    double s = hi + h2;
+    double bb = s - hi;
+    double e = (hi - (s - bb)) + (h2 - bb);
+    if (!(__builtin_fabs(s) <= 1.7976931348623157e308)) e = 0.0;
+    lo = lo + l2 + e;
+    hi = s;
+}
+
+struct Acc {
+    uint64_t count, isum;
+    double hi, lo;
+    uint64_t minkey, minrow, maxkey, maxrow, firstrow, lastrow1;  // lastrow1 = row + 1, 0 = none
+    __device__ __forceinline__ void init() {
+        count = 0; isum = 0; hi = 0.0; lo = 0.0;
+        minkey = 0; minrow = kNoRow; maxkey = 0; maxrow = kNoRow; firstrow = kNoRow; lastrow1 = 0;
+    }
+    __device__ __forceinline__ void merge(const Acc &b) {
+        count += b.count;
+        isum += b.isum;
+        dd_add(hi, lo, b.hi, b.lo);
+        if (b.minrow != kNoRow && (minrow == kNoRow || b.minkey < minkey || (b.minkey == minkey && b.minrow < minrow))) {
+            minkey = b.minkey; minrow = b.minrow;
+        }
+        if (b.maxrow != kNoRow && (maxrow == kNoRow || b.maxkey > maxkey || (b.maxkey == maxkey && b.maxrow < maxrow))) {
+            maxkey = b.maxkey; maxrow = b.maxrow;
+        }
+        firstrow = b.firstrow < firstrow ? b.firstrow : firstrow;
+        lastrow1 = b.lastrow1 > lastrow1 ? b.lastrow1 : lastrow1;
+    }
+};
+
+// value -> float64 exactly as Go's float64(v) conversion of the column type
+template <int W> __device__ __forceinline__ double to_f64(typename WT<W>::U e, uint32_t flavor) {
+    if (flavor == FL_FLOAT) {
+        if constexpr (W == 8) return __longlong_as_double((long long)e);
+        else return (double)__uint_as_float((uint32_t)e);
+    } else if (flavor == FL_SIGNED) {
+        if constexpr (W == 8) return (double)(int64_t)e;
+        else if constexpr (W == 4) return (double)(int32_t)e;
+        else if constexpr (W == 2) return (double)(int16_t)e;
+        else return (double)(int8_t)e;
+    } else {
+        if constexpr (W == 8) return (double)(uint64_t)e;
+        else return (double)(uint32_t)e;
+    }
+}
+
+// One selected-or-not row into the accumulator.  Rows arrive in increasing order per lane.
+template <int W, unsigned AGG>
+__device__ __forceinline__ void acc_update(Acc &acc, typename WT<W>::U e, uint32_t hit, uint64_t row, uint32_t flavor) {
+    using U = typename WT<W>::U;
+    if constexpr ((AGG & A_ISUM) != 0) {
+        acc.isum += hit ? (uint64_t)e : 0ull;
+    }
+    if constexpr ((AGG & A_FSUM) != 0) {
+        double x = to_f64<W>(e, flavor);
+        x = hit ? x : 0.0;
+        dd_add(acc.hi, acc.lo, x, 0.0);
+    }
+    if constexpr ((AGG & A_MINMAX) != 0) {
+        // MinReducer / MaxReducer (reducer.go:256-296): strict compare, first occurrence wins;
+        // a NaN is never adopted over a number (finalize handles "first value is NaN").
+        const bool isf = flavor == FL_FLOAT;
+        const U mag = e & (WT<W>::MASK ^ WT<W>::SIGN);
+        U fk = fkey<W>(e);
+        if (mag == 0) fk = WT<W>::SIGN;  // -0 and +0 compare equal: one key
+        U expmask;
+        if constexpr (W == 8) expmask = 0x7ff0000000000000ull; else expmask = 0x7f800000u;
+        const bool isnan = isf && (mag > expmask);
+        const U xs = (flavor == FL_SIGNED) ? WT<W>::SIGN : (U)0;
+        const uint64_t okey = isf ? (uint64_t)fk : (uint64_t)(e ^ xs);
+        const bool cand = hit && !isnan;
+        if (cand && (acc.minrow == kNoRow || okey < acc.minkey)) { acc.minkey = okey; acc.minrow = row; }
+        if (cand && (acc.maxrow == kNoRow || okey > acc.maxkey)) { acc.maxkey = okey; acc.maxrow = row; }
+    }
+    if constexpr ((AGG & A_FIRSTLAST) != 0) {
+        if (hit) {
+            if (acc.firstrow == kNoRow) acc.firstrow = row;
+            acc.lastrow1 = row + 1;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int off) {
+    return (uint64_t)__shfl_down((unsigned long long)v, off, 64);
+}
+__device__ __forceinline__ double shfl_down_f64(double v, int off) { return __shfl_down(v, off, 64); }
+
+__device__ __forceinline__ void wave_reduce(Acc &a) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Acc b;
+        b.count = shfl_down_u64(a.count, off);
+        b.isum = shfl_down_u64(a.isum, off);
+        b.hi = shfl_down_f64(a.hi, off);
+        b.lo = shfl_down_f64(a.lo, off);
+        b.minkey = shfl_down_u64(a.minkey, off);
+        b.minrow = shfl_down_u64(a.minrow, off);
+        b.maxkey = shfl_down_u64(a.maxkey, off);
+        b.maxrow = shfl_down_u64(a.maxrow, off);
+        b.firstrow = shfl_down_u64(a.firstrow, off);
+        b.lastrow1 = shfl_down_u64(a.lastrow1, off);
+        a.merge(b);
+    }
+}
+
+// wave shuffle -> LDS -> thread 0 writes the workgroup partial
+__device__ __forceinline__ void block_reduce_store(Acc &acc, AggPartial *out) {
+    __shared__ Acc sm[kBlock / 64];
+    wave_reduce(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Acc t = sm[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) t.merge(sm[w]);
+        AggPartial p;
+        p.count = t.count; p.isum = t.isum; p.hi = t.hi; p.lo = t.lo;
+        p.minkey = t.minkey; p.minrow = t.minrow; p.maxkey = t.maxkey; p.maxrow = t.maxrow;
+        p.firstrow = t.firstrow; p.lastrow = t.lastrow1;
+        *out = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming scan kernel
+// ---------------------------------------------------------------------------------------------
+template <int W, int NL, unsigned AGG, bool SEP, bool NT>
+__global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;                       // rows per wave-load
+    constexpr int WAVE_ROWS = RPL * kUnroll;
+    constexpr int TILE = WAVE_ROWS * kWavesPerBlock;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    Acc acc;
+    acc.init();
+    uint32_t cnt32 = 0;
+
+    U lo[NL], diff[NL];
+    bool isf[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        lo[l] = (U)a.leaf[l].lo;
+        diff[l] = (U)a.leaf[l].diff;
+        isf[l] = a.leaf[l].is_float != 0;
+    }
+    const uint64_t tt = a.tt;
+    const uint32_t flavor = a.agg_flavor;
+
+    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;  // wave-uniform
+        if (a.pack_skip != nullptr && a.pack_shift != 255u) {
+            // pack pruned by the caller's statistics: no row can match, do not read it
+            if (a.pack_skip[row0 >> a.pack_shift]) {
+                if (a.bits != nullptr) {
+                    uint32_t *w = a.bits + (row0 >> 5);
+                    for (int i = lane; i < WAVE_ROWS / 32; i += 64) w[i] = 0u;
+                }
+                continue;
+            }
+        }
+        const uint64_t vec0 = row0 / K + lane;
+        u32x4 r[NL][kUnroll];
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const u32x4 *p = (const u32x4 *)a.leaf[l].col + vec0;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<NT>(p + u * 64);
+        }
+        u32x4 ra[kUnroll];
+        if constexpr (SEP && AGG != 0) {
+            const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) ra[u] = ld16<NT>(p + u * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            uint32_t q = 0;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                uint32_t idx = 0;
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    U x = elem<W>(r[l][u], j);
+                    if constexpr (W >= 4) x = isf[l] ? fkey<W>(x) : x;
+                    const uint32_t h = (((U)(x - lo[l])) & WT<W>::MASK) <= diff[l] ? 1u : 0u;
+                    idx |= h << l;
+                }
+                q |= (uint32_t)((tt >> idx) & 1ull) << j;
+            }
+            cnt32 += __builtin_popcount(q);
+            if (a.bits != nullptr) {
+                const uint32_t w = pack_word<K>(q, lane);
+                if ((lane & (G - 1)) == 0) a.bits[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] = w;
+            }
+            if constexpr (AGG != 0) {
+                const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    U e;
+                    if constexpr (SEP) e = elem<W>(ra[u], j); else e = elem<W>(r[0][u], j);
+                    acc_update<W, AGG>(acc, e, (q >> j) & 1u, rbase + j, flavor);
+                }
+            }
+        }
+    }
+    acc.count = cnt32;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked reduce kernel: selection comes from an existing bitset (or all rows)
+// ---------------------------------------------------------------------------------------------
+template <int W, unsigned AGG>
+__global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr int WAVE_ROWS = RPL * kUnroll;
+    constexpr int TILE = WAVE_ROWS * kWavesPerBlock;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    Acc acc;
+    acc.init();
+    uint32_t cnt32 = 0;
+    const uint32_t flavor = a.agg_flavor;
+    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;
+        const uint64_t vec0 = row0 / K + lane;
+        u32x4 ra[kUnroll];
+        uint32_t mw[kUnroll];
+        const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            ra[u] = ld16<false>(p + u * 64);
+            mw[u] = a.mask ? a.mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t q = (mw[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+            cnt32 += __builtin_popcount(q);
+            const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
+#pragma unroll
+            for (int j = 0; j < K; j++) acc_update<W, AGG>(acc, elem<W>(ra[u], j), (q >> j) & 1u, rbase + j, flavor);
+        }
+    }
+    acc.count = cnt32;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail / small-n kernel: rows [n_tiles*TILE, n_rows), any n, byte-granular stores so nothing is
+// written past byte (n+7)/8 - 1 and the bits >= n of the last byte stay 0 (poison-tail rule,
+// internal/cmp/tests/tests.go:24-48).  One workgroup; thread t owns output bytes t, t+256, ...
+// ---------------------------------------------------------------------------------------------
+template <int W> __device__ __forceinline__ typename WT<W>::U load_elem(const void *col, uint64_t row) {
+    if constexpr (W == 8) return ((const uint64_t *)col)[row];
+    else if constexpr (W == 4) return ((const uint32_t *)col)[row];
+    else if constexpr (W == 2) return ((const uint16_t *)col)[row];
+    else return ((const uint8_t *)col)[row];
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) scan_tail_kernel(const ScanArgs a, int n_leaves, int tail_slot, int reduce_mode) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr uint64_t TILE = (uint64_t)64 * K * kUnroll * kWavesPerBlock;
+    const uint64_t start = a.n_tiles * TILE;
+    Acc acc;
+    acc.init();
+    if (start < a.n_rows) {
+        const uint64_t nrows = a.n_rows - start;
+        const uint64_t nbytes = (nrows + 7) >> 3;
+        const uint8_t *mask8 = (const uint8_t *)a.mask;
+        for (uint64_t b = threadIdx.x; b < nbytes; b += blockDim.x) {
+            uint32_t out = 0;
+            uint32_t mbyte = 0xffu;
+            if (reduce_mode && mask8) mbyte = mask8[(start >> 3) + b];
+#pragma unroll 1
+            for (int k = 0; k < 8; k++) {
+                const uint64_t row = start + 8 * b + k;
+                if (row >= a.n_rows) break;
+                uint32_t hit;
+                if (reduce_mode) {
+                    hit = (mbyte >> k) & 1u;
+                } else {
+                    uint32_t idx = 0;
+                    bool skipped = false;
+                    if (a.pack_skip != nullptr && a.pack_shift != 255u) skipped = a.pack_skip[row >> a.pack_shift] != 0;
+                    for (int l = 0; l < n_leaves; l++) {
+                        U x = load_elem<W>(a.leaf[l].col, row);
+                        if constexpr (W >= 4) x = a.leaf[l].is_float ? fkey<W>(x) : x;
+                        const uint32_t h = (((U)(x - (U)a.leaf[l].lo)) & WT<W>::MASK) <= (U)a.leaf[l].diff ? 1u : 0u;
+                        idx |= h << l;
+                    }
+                    hit = skipped ? 0u : (uint32_t)((a.tt >> idx) & 1ull);
+                }
+                out |= hit << k;
+                acc.count += hit;
+                if (a.agg_col != nullptr) acc_update<W, A_ALL>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, a.agg_flavor);
+            }
+            if (a.bits != nullptr && !reduce_mode) ((uint8_t *)a.bits)[(start >> 3) + b] = (uint8_t)out;
+        }
+    }
+    block_reduce_store(acc, a.partials + tail_slot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: ordered merge of the workgroup partials, fetch adopted values
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *partials, int n_partials, const void *agg_col,
+                                                          uint64_t row_base, int dtype, AggStateDev *state_out,
+                                                          int64_t *count_out) {
+    __shared__ Acc sm[kBlock / 64];
+    Acc acc;
+    acc.init();
+    for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
+        const AggPartial p = partials[i];
+        Acc b;
+        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo;
+        b.minkey = p.minkey; b.minrow = p.minrow; b.maxkey = p.maxkey; b.maxrow = p.maxrow;
+        b.firstrow = p.firstrow; b.lastrow1 = p.lastrow;
+        acc.merge(b);
+    }
+    wave_reduce(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Acc t = sm[0];
+        for (int w = 1; w < kBlock / 64; w++) t.merge(sm[w]);
+        if (count_out) *count_out = (int64_t)t.count;
+        if (state_out) {
+            AggStateDev s;
+            s.dtype = dtype;
+            s.flags = 1u;
+            s.count = (int64_t)t.count;
+            s.isum = t.isum;
+            s.fsum_hi = t.hi;
+            s.fsum_lo = t.lo;
+            s.min_row = t.minrow == kNoRow ? -1 : (int64_t)t.minrow;
+            s.max_row = t.maxrow == kNoRow ? -1 : (int64_t)t.maxrow;
+            s.first_row = t.firstrow == kNoRow ? -1 : (int64_t)t.firstrow;
+            s.last_row = t.lastrow1 == 0 ? -1 : (int64_t)(t.lastrow1 - 1);
+            s.min_bits = (agg_col && s.min_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.minrow - row_base) : 0;
+            s.max_bits = (agg_col && s.max_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.maxrow - row_base) : 0;
+            s.first_bits = (agg_col && s.first_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.firstrow - row_base) : 0;
+            s.last_bits = (agg_col && s.last_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.lastrow1 - 1 - row_base) : 0;
+            *state_out = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+#define KNOX_LAUNCH(KERN, GRID, ...)                                                           \
+    do {                                                                                       \
+        hipLaunchKernelGGL(KERN, dim3(GRID), dim3(kBlock), 0, s, __VA_ARGS__);                 \
+        return hipGetLastError();                                                              \
+    } while (0)
+
+template <int W, int NL, unsigned AGG, bool SEP>
+static hipError_t scan_nt(hipStream_t s, int grid, int variant, const ScanArgs &a) {
+    if constexpr (W == 8) {
+        if (variant == 1) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true>), grid, a);
+    }
+    KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, false>), grid, a);
+}
+
+template <int W, int NL>
+static hipError_t scan_agg(hipStream_t s, unsigned agg, bool sep, int grid, int variant, const ScanArgs &a) {
+    // aggregate classes instantiated: none | isum | float-full | all
+    if (agg == 0) return scan_nt<W, NL, 0, false>(s, grid, variant, a);
+    if (agg == A_ISUM) return sep ? scan_nt<W, NL, A_ISUM, true>(s, grid, variant, a) : scan_nt<W, NL, A_ISUM, false>(s, grid, variant, a);
+    if ((agg & A_ISUM) == 0) {
+        constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+        return sep ? scan_nt<W, NL, FF, true>(s, grid, variant, a) : scan_nt<W, NL, FF, false>(s, grid, variant, a);
+    }
+    return sep ? scan_nt<W, NL, A_ALL, true>(s, grid, variant, a) : scan_nt<W, NL, A_ALL, false>(s, grid, variant, a);
+}
+
+template <int W>
+static hipError_t scan_nl(hipStream_t s, int nl, unsigned agg, bool sep, int grid, int variant, const ScanArgs &a) {
+    switch (nl) {
+    case 1: return scan_agg<W, 1>(s, agg, sep, grid, variant, a);
+    case 2: return scan_agg<W, 2>(s, agg, sep, grid, variant, a);
+    case 3: return scan_agg<W, 3>(s, agg, sep, grid, variant, a);
+    case 4: return scan_agg<W, 4>(s, agg, sep, grid, variant, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, bool agg_separate, int grid, int variant,
+                       const ScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+    switch (width) {
+    case 8: return scan_nl<8>(s, n_leaves, agg, agg_separate, grid, variant, a);
+    case 4: return scan_nl<4>(s, n_leaves, agg, agg_separate, grid, variant, a);
+    case 2: return scan_nl<2>(s, n_leaves, agg, agg_separate, grid, variant, a);
+    case 1: return scan_nl<1>(s, n_leaves, agg, agg_separate, grid, variant, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_scan_tail(hipStream_t s, int width, int n_leaves, unsigned agg, int tail_slot, const ScanArgs &a) {
+    (void)agg;
+    switch (width) {
+    case 8: KNOX_LAUNCH((scan_tail_kernel<8>), 1, a, n_leaves, tail_slot, 0);
+    case 4: KNOX_LAUNCH((scan_tail_kernel<4>), 1, a, n_leaves, tail_slot, 0);
+    case 2: KNOX_LAUNCH((scan_tail_kernel<2>), 1, a, n_leaves, tail_slot, 0);
+    case 1: KNOX_LAUNCH((scan_tail_kernel<1>), 1, a, n_leaves, tail_slot, 0);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int W> static hipError_t reduce_w(hipStream_t s, unsigned agg, int grid, const ScanArgs &a) {
+    hipError_t e = hipSuccess;
+    if (grid > 0) {
+        if ((agg & ~A_ISUM) == 0) hipLaunchKernelGGL((reduce_kernel<W, A_ISUM>), dim3(grid), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((reduce_kernel<W, A_ALL>), dim3(grid), dim3(kBlock), 0, s, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((scan_tail_kernel<W>), dim3(1), dim3(kBlock), 0, s, a, 0, grid, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce(hipStream_t s, int width, unsigned agg, int grid, const ScanArgs &a) {
+    switch (width) {
+    case 8: return reduce_w<8>(s, agg, grid, a);
+    case 4: return reduce_w<4>(s, agg, grid, a);
+    case 2: return reduce_w<2>(s, agg, grid, a);
+    case 1: return reduce_w<1>(s, agg, grid, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials, int n_partials, const void *agg_col,
+                           uint64_t row_base, int dtype, AggStateDev *state_out, int64_t *count_out) {
+    switch (width) {
+    case 8: KNOX_LAUNCH((finalize_kernel<8>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+    case 4: KNOX_LAUNCH((finalize_kernel<4>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+    case 2: KNOX_LAUNCH((finalize_kernel<2>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+    case 1: KNOX_LAUNCH((finalize_kernel<1>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bitset combinators (internal/bitset/generic/bitset.go:13-330) on 64-bit words.
+// The last word is masked to `size` bits (bytemask semantics extended to the padded word).
+// flags[0] |= any set bit, flags[1] |= any valid bit clear (all == !flags[1]).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t valid_mask(uint64_t word, uint64_t nwords, uint64_t size_bits) {
+    if (word + 1 < nwords || (size_bits & 63) == 0) return ~0ull;
+    return (~0ull) >> (64 - (size_bits & 63));
+}
+
+template <int OP>
+__global__ void __launch_bounds__(kBlock) bitop_kernel(uint64_t *dst, const uint64_t *src, uint64_t nwords,
+                                                       uint64_t size_bits, uint32_t *flags) {
+    uint64_t any = 0, notall = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t vm = valid_mask(i, nwords, size_bits);
+        uint64_t d = dst[i];
+        uint64_t sv = 0;
+        if constexpr (OP == BIT_AND || OP == BIT_ANDNOT || OP == BIT_OR || OP == BIT_XOR || OP == BIT_COPY) sv = src[i];
+        if constexpr (OP == BIT_AND) d &= sv;
+        if constexpr (OP == BIT_ANDNOT) d &= ~sv;
+        if constexpr (OP == BIT_OR) d |= sv;
+        if constexpr (OP == BIT_XOR) d ^= sv;
+        if constexpr (OP == BIT_NEG) d = ~d;
+        if constexpr (OP == BIT_COPY) d = sv;
+        if constexpr (OP == BIT_ONE) d = ~0ull;
+        d &= vm;
+        dst[i] = d;
+        any |= d;
+        notall |= (~d) & vm;
+    }
+    if (flags != nullptr) {
+        const bool wany = __any(any != 0);
+        const bool wnot = __any(notall != 0);
+        if ((threadIdx.x & 63) == 0) {
+            if (wany) atomicOr(&flags[0], 1u);
+            if (wnot) atomicOr(&flags[1], 1u);
+        }
+    }
+}
+
+hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *src, uint64_t size_bits, uint32_t *flags) {
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    if (nwords == 0) return hipSuccess;
+    uint64_t g = (nwords + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    const int grid = (int)g;
+    switch (op) {
+    case BIT_AND: KNOX_LAUNCH((bitop_kernel<BIT_AND>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_ANDNOT: KNOX_LAUNCH((bitop_kernel<BIT_ANDNOT>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_OR: KNOX_LAUNCH((bitop_kernel<BIT_OR>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_XOR: KNOX_LAUNCH((bitop_kernel<BIT_XOR>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_NEG: KNOX_LAUNCH((bitop_kernel<BIT_NEG>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_COPY: KNOX_LAUNCH((bitop_kernel<BIT_COPY>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_ONE: KNOX_LAUNCH((bitop_kernel<BIT_ONE>), grid, dst, src, nwords, size_bits, flags);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// PopCount generic/bitset.go:332-353
+__global__ void __launch_bounds__(kBlock) popcount_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                          unsigned long long *out) {
+    uint64_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x)
+        c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bits, unsigned long long *count_out) {
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    if (nwords == 0) return hipSuccess;
+    uint64_t g = (nwords + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    KNOX_LAUNCH(popcount_kernel, (int)g, bits, nwords, size_bits, count_out);
+}
+
+// per-segment popcount: one workgroup per segment (seg_bits multiple of 64)
+__global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                              uint64_t seg_words, int64_t *counts, uint64_t n_seg) {
+    __shared__ uint64_t sm[kBlock / 64];
+    for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const uint64_t w0 = seg * seg_words;
+        uint64_t w1 = w0 + seg_words;
+        if (w1 > nwords) w1 = nwords;
+        uint64_t c = 0;
+        for (uint64_t i = w0 + threadIdx.x; i < w1; i += blockDim.x) c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) counts[seg] = (int64_t)(sm[0] + sm[1] + sm[2] + sm[3]);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
+                                    int64_t *counts, uint64_t n_seg) {
+    if (n_seg == 0) return hipSuccess;
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    uint64_t g = n_seg > 65535 ? 65535 : n_seg;
+    KNOX_LAUNCH(popcount_seg_kernel, (int)g, bits, nwords, size_bits, seg_bits >> 6, counts, n_seg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Indexes (generic/bitset.go:355-396): bitset -> ascending uint32 row ids.
+// chunk = 8192 bits = 128 words per workgroup; counts -> exclusive scan -> ordered write.
+// ---------------------------------------------------------------------------------------------
+constexpr int kIdxWords = 128;
+
+__global__ void __launch_bounds__(kBlock) idx_count_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                           uint32_t *block_counts) {
+    __shared__ uint32_t sm[kBlock / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * kIdxWords + threadIdx.x;
+    uint32_t c = 0;
+    if (threadIdx.x < kIdxWords && i < nwords) c = __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// single workgroup exclusive scan in place; total written to counts[n] and *n_out
+__global__ void __launch_bounds__(1024) idx_scan_kernel(uint32_t *counts, uint64_t n, unsigned long long *n_out) {
+    __shared__ uint32_t sm[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? counts[i] : 0;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t t = threadIdx.x >= (unsigned)off ? sm[threadIdx.x - off] : 0;
+            __syncthreads();
+            sm[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = sm[threadIdx.x];
+        if (i < n) counts[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[n] = carry;
+        *n_out = carry;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) idx_write_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                           const uint32_t *block_offsets, uint32_t *rows_out, uint64_t capacity) {
+    __shared__ uint32_t sm[kIdxWords];
+    const uint64_t i = (uint64_t)blockIdx.x * kIdxWords + threadIdx.x;
+    uint64_t w = 0;
+    if (threadIdx.x < kIdxWords && i < nwords) w = bits[i] & valid_mask(i, nwords, size_bits);
+    const uint32_t c = __builtin_popcountll(w);
+    if (threadIdx.x < kIdxWords) sm[threadIdx.x] = c;
+    __syncthreads();
+    // inclusive scan over 128 entries
+    for (int off = 1; off < kIdxWords; off <<= 1) {
+        uint32_t t = 0;
+        if (threadIdx.x < kIdxWords && threadIdx.x >= (unsigned)off) t = sm[threadIdx.x - off];
+        __syncthreads();
+        if (threadIdx.x < kIdxWords) sm[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (threadIdx.x < kIdxWords && c) {
+        uint64_t o = (uint64_t)block_offsets[blockIdx.x] + sm[threadIdx.x] - c;
+        const uint32_t row0 = (uint32_t)(i << 6);
+        while (w) {
+            const int k = __builtin_ctzll(w);
+            if (o < capacity) rows_out[o] = row0 + k;
+            o++;
+            w &= w - 1;
+        }
+    }
+}
+
+hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch, uint32_t *rows_out,
+                          uint64_t capacity, unsigned long long *n_out) {
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    const uint64_t nblocks = (nwords + kIdxWords - 1) / kIdxWords;
+    if (nblocks == 0) return hipMemsetAsync(n_out, 0, sizeof(*n_out), s);
+    hipLaunchKernelGGL(idx_count_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bits, nwords, size_bits, scratch);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, nblocks, n_out);
+    hipLaunchKernelGGL(idx_write_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bits, nwords, size_bits, scratch, rows_out,
+                       capacity);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// bytes column EQ / NE: pkg/stringx/match.go:20-84, layout pool.go:45-58 (ptr = off<<32 | len)
+// one lane = one string; wave ballot -> 8 result bytes written by lanes 0..7
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bytes_equal(const uint8_t *p, const uint8_t *v, uint32_t n) {
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, p + i, 8);
+        __builtin_memcpy(&y, v + i, 8);
+        if (x != y) return false;
+    }
+    for (; i < n; i++)
+        if (p[i] != v[i]) return false;
+    return true;
+}
+
+__global__ void __launch_bounds__(kBlock) bytes_match_kernel(int want_eq, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                                                             const uint8_t *val, uint32_t vlen, uint8_t *bits,
+                                                             const uint8_t *mask, unsigned long long *count_out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    uint64_t cnt = 0;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            const uint64_t p = ptr[row];
+            const uint32_t ofs = (uint32_t)(p >> 32), len = (uint32_t)p;
+            const bool eq = (len == vlen) && bytes_equal(buf + ofs, val, len);
+            m = want_eq ? eq : !eq;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                const uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) bits[bi] |= (uint8_t)(byte & mask[bi]);  // only bits.Set(i) for masked rows
+                else bits[bi] = byte;                                         // overwrite incl. partial last byte
+            }
+        }
+        if (lane == 0) cnt += __builtin_popcountll(ballot);
+    }
+    if (lane == 0 && cnt && count_out) atomicAdd(count_out, (unsigned long long)cnt);
+}
+
+hipError_t launch_bytes_match(hipStream_t s, bool want_eq, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                              const uint8_t *val, uint32_t vlen, uint8_t *bits, const uint8_t *mask,
+                              unsigned long long *count_out) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    KNOX_LAUNCH(bytes_match_kernel, (int)g, want_eq ? 1 : 0, ptr, n_rows, buf, val, vlen, bits, mask, count_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bloom filter: internal/filter/bloom/bloom.go:136-150 (probe), :162-169 (add), xxh3.go:22-33
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rol64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xxh3_u64(uint64_t val) {
+    const uint64_t input64 = (val >> 32) + (val << 32);
+    uint64_t h = input64 ^ (0x1cad21f72c81017cull ^ 0xdb979083e96dd4deull);
+    h ^= rol64(h, 49) ^ rol64(h, 24);
+    h *= 0x9fb21c651e98df25ull;
+    h ^= (h >> 35) + 8;
+    h *= 0x9fb21c651e98df25ull;
+    h ^= (h >> 28);
+    return h;
+}
+
+__global__ void __launch_bounds__(kBlock) bloom_probe_kernel(const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,
+                                                             uint64_t h, uint8_t *maybe_out) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_packs) return;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) {  // no filter for this pack: cannot exclude it
+        maybe_out[p] = 1;
+        return;
+    }
+    const uint8_t *buf = filters + o0;
+    const uint8_t *bits = buf + 1;
+    const uint32_t k = buf[0];
+    const uint32_t mask = (uint32_t)((o1 - o0 - 1) * 8 - 1);
+    uint32_t h0 = (uint32_t)h;
+    const uint32_t h1 = (uint32_t)(h >> 32);
+    uint8_t ok = 1;
+    for (uint32_t i = 0; i < k; i++) {
+        if ((bits[(h0 & mask) >> 3] & (1u << (h0 & 7))) == 0) { ok = 0; break; }
+        h0 += h1;
+    }
+    maybe_out[p] = ok;
+}
+
+hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs, uint64_t h,
+                              uint8_t *maybe_out) {
+    if (n_packs == 0) return hipSuccess;
+    KNOX_LAUNCH(bloom_probe_kernel, (int)((n_packs + kBlock - 1) / kBlock), filters, offsets, n_packs, h, maybe_out);
+}
+
+// one workgroup per pack; filters pre-zeroed by the host; k byte = 4 (bloom.go:48-60)
+__global__ void __launch_bounds__(kBlock) bloom_build_kernel(const uint64_t *col, uint64_t n_rows, uint64_t pack_rows,
+                                                             uint8_t *filters, const uint64_t *offsets) {
+    const uint64_t p = blockIdx.x;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    uint8_t *buf = filters + o0;
+    if (threadIdx.x == 0) buf[0] = 4;
+    const uint64_t bits_off = o0 + 1;  // byte offset of bit array inside `filters`
+    const uint32_t mask = (uint32_t)((o1 - o0 - 1) * 8 - 1);
+    uint64_t r0 = p * pack_rows, r1 = r0 + pack_rows;
+    if (r1 > n_rows) r1 = n_rows;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const uint64_t h = xxh3_u64(col[r]);
+        uint32_t h0 = (uint32_t)h;
+        const uint32_t h1 = (uint32_t)(h >> 32);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t byte_addr = bits_off + ((h0 & mask) >> 3);
+            const uint32_t bit = 1u << (h0 & 7);
+            // byte-granular OR through the aligned 32-bit word that contains the byte
+            uint32_t *word = (uint32_t *)(filters + (byte_addr & ~3ull));
+            atomicOr(word, bit << (8 * (byte_addr & 3)));
+            h0 += h1;
+        }
+    }
+}
+
+hipError_t launch_bloom_build_u64(hipStream_t s, const uint64_t *col, uint64_t n_rows, uint64_t pack_rows, uint8_t *filters,
+                                  const uint64_t *offsets) {
+    const uint64_t n_packs = (n_rows + pack_rows - 1) / pack_rows;
+    if (n_packs == 0) return hipSuccess;
+    KNOX_LAUNCH(bloom_build_kernel, (int)n_packs, col, n_rows, pack_rows, filters, offsets);
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic columns (DESIGN.md "synthetic data"): r(i) = mix64(i + mix64(seed))
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t gen_u64(int kind, uint64_t seedmix, uint64_t i, int64_t lo, uint64_t span) {
+    const uint64_t r = mix64(i + seedmix);
+    switch (kind) {
+    case 0: return span ? (uint64_t)lo + __umul64hi(r, span) : r;
+    case 1: return (uint64_t)__double_as_longlong((double)(r >> 44) * 0x1p-10);
+    case 2: return (uint64_t)__double_as_longlong((double)(r >> 11) * 0x1p-53);
+    case 3: return i + (uint64_t)lo;
+    case 4: {
+        if ((r & 0xfffff) == 0) {
+            const uint64_t sel = (r >> 20) % 5;
+            return sel == 0 ? 0x7ff8000000000000ull : sel == 1 ? 0x7ff0000000000000ull : sel == 2 ? 0xfff0000000000000ull
+                 : sel == 3 ? 0x8000000000000000ull : 0ull;
+        }
+        const double d = ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0x1p21;
+        return (uint64_t)__double_as_longlong(d);
+    }
+    default: return 0;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) generate_kernel(int to_f32, int kind, uint64_t seedmix, uint64_t first_row,
+                                                          uint64_t n_rows, int64_t lo, uint64_t span, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t u = gen_u64(kind, seedmix, first_row + i, lo, span);
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = u;
+        else if constexpr (W == 4) {
+            if (to_f32) {
+                const float f = (kind == 1 || kind == 2 || kind == 4) ? (float)__longlong_as_double((long long)u) : (float)(int64_t)u;
+                ((float *)dst)[i] = f;
+            } else ((uint32_t *)dst)[i] = (uint32_t)u;
+        } else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)u;
+        else ((uint8_t *)dst)[i] = (uint8_t)u;
+    }
+}
+
+hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                           int64_t lo, uint64_t span, void *dst) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    const uint64_t sm = mix64(seed);
+    switch (width) {
+    case 8: KNOX_LAUNCH((generate_kernel<8>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    case 4: KNOX_LAUNCH((generate_kernel<4>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    case 2: KNOX_LAUNCH((generate_kernel<2>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    case 1: KNOX_LAUNCH((generate_kernel<1>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// literal sequential reducers (one lane, row order): internal/reducer/reducer.go:138-429
+// bit-for-bit the Go fold incl. Welford mean/var -- parity-test mode only, O(n) latency bound.
+// out[0] = value bits (T in the low bytes), out[1] = seen, out[2] = row (as uint64, ~0 = none)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void reduce_seq_kernel(int func, const T *src, uint64_t n, const uint8_t *bits, uint64_t *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool seen = false;
+    uint64_t row = ~0ull, cnt = 0;
+    T v = 0;
+    double mean = 0, m2 = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (bits != nullptr && !((bits[i >> 3] >> (i & 7)) & 1)) continue;
+        const T x = src[i];
+        switch (func) {
+        case 8: if (!seen) row = i; v = (T)(v + 1); break;                       // count :138-148
+        case 0: if (!seen) row = i; v = (T)(v + x); break;                       // sum   :168-178
+        case 1: if (!seen) { row = i; v = x; } break;                            // first :198-208
+        case 2: row = i; v = x; break;                                           // last  :228-236
+        case 4: if (!seen || v < x) { row = i; v = x; } break;                   // max   :256-266
+        case 3: if (!seen || v > x) { row = i; v = x; } break;                   // min   :286-296
+        case 5: { if (cnt == 0) row = i; cnt++; double d = (double)x - mean; mean += d / (double)cnt; break; }
+        case 6: case 7: {
+            if (cnt == 0) row = i;
+            cnt++;
+            double d = (double)x - mean;
+            mean += d / (double)cnt;
+            m2 += d * ((double)x - mean);
+            break;
+        }
+        default: break;
+        }
+        seen = true;
+    }
+    T r = v;
+    if (func == 5) r = (T)mean;
+    if (func == 6) r = (cnt < 2) ? (T)__builtin_nan("") : (T)(m2 / (double)(cnt - 1));
+    if (func == 7) r = (cnt < 2) ? (T)__builtin_nan("") : (T)__builtin_sqrt(m2 / (double)(cnt - 1));
+    uint64_t raw = 0;
+    __builtin_memcpy(&raw, &r, sizeof(T));
+    out[0] = raw;
+    out[1] = seen ? 1 : 0;
+    out[2] = row;
+}
+
+hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows, const uint8_t *mask,
+                                    uint64_t *out3) {
+#define KNOX_SEQ(T) hipLaunchKernelGGL((reduce_seq_kernel<T>), dim3(1), dim3(64), 0, s, func, (const T *)col, n_rows, mask, out3); break
+    switch (dtype) {
+    case 1: KNOX_SEQ(int64_t);
+    case 2: KNOX_SEQ(int32_t);
+    case 3: KNOX_SEQ(int16_t);
+    case 4: KNOX_SEQ(int8_t);
+    case 5: KNOX_SEQ(uint64_t);
+    case 6: KNOX_SEQ(uint32_t);
+    case 7: KNOX_SEQ(uint16_t);
+    case 8: KNOX_SEQ(uint8_t);
+    case 9: KNOX_SEQ(double);
+    case 10: KNOX_SEQ(float);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_SEQ
+    return hipGetLastError();
+}
+
+}  // namespace knox

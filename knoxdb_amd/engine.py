@@ -1,0 +1,369 @@
+"""Host-side plumbing over the C ABI (include/knoxgpu.h) used by tests and bench.py.
+
+Thin on purpose: every call goes straight into libknoxgpu.so; nothing here computes a result.
+The names follow the reference: a Context scans Columns (runs of packs) with a filter tree of
+Leaf / And / Or nodes (filter.Node, internal/operator/filter/node.go:29) and reducers
+(internal/reducer/reducer.go:129).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Agg, AggState, KnoxError, Pred, ScanOut, check
+from .types import FROM_NP, NP_DTYPE, BlockType, FilterMode, ReducerFunc, value_bits
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Leaf:
+    """filter.Filter{Index, Mode, Value} (operator/filter/filter.go:22-30)."""
+
+    def __init__(self, col, mode, a, b=None):
+        self.col, self.mode, self.a, self.b = col, FilterMode(mode), a, b
+
+
+class And:
+    def __init__(self, *children):
+        self.children = children
+
+
+class Or:
+    def __init__(self, *children):
+        self.children = children
+
+
+def _flatten(node, cols, out, keep):
+    if isinstance(node, Leaf):
+        c = cols[node.col]
+        p = Pred()
+        p.kind, p.nchild, p.col, p.op = 0, 0, node.col, int(node.mode)
+        if c.dtype == BlockType.Bytes:
+            val = bytes(node.a)
+            keep.append(val)
+            p.val, p.val_len = val, len(val)
+        else:
+            p.a = value_bits(c.dtype, node.a)
+            p.b = value_bits(c.dtype, node.b) if node.b is not None else 0
+        out.append(p)
+        return
+    for ch in node.children:
+        _flatten(ch, cols, out, keep)
+    p = Pred()
+    p.kind = 1 if isinstance(node, And) else 2
+    p.nchild = len(node.children)
+    out.append(p)
+
+
+class Column:
+    def __init__(self, ctx, handle, dtype, keep=None, pack_rows=0):
+        self.ctx, self.h, self.dtype, self._keep = ctx, handle, BlockType(dtype), keep
+        self.pack_rows = pack_rows or _lib.lib().knox_col_rows(handle)
+
+    @property
+    def rows(self):
+        return _lib.lib().knox_col_rows(self.h)
+
+    @property
+    def device_ptr(self):
+        return _lib.lib().knox_col_device_ptr(self.h)
+
+    def download(self, first=0, n=None):
+        n = self.rows - first if n is None else n
+        out = np.empty(n, dtype=NP_DTYPE[self.dtype])
+        check(_lib.lib().knox_col_download(self.ctx.h, self.h, first, n, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            _lib.lib().knox_col_free(self.h)
+            self.h = None
+
+
+class Bits:
+    """bitset.Bitset resident on the device (internal/bitset/bitset.go:30-35)."""
+
+    def __init__(self, ctx, size):
+        self.ctx, self.size = ctx, size
+        h = C.c_void_p()
+        check(_lib.lib().knox_bits_alloc(ctx.h, size, C.byref(h)))
+        self.h = h
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint8)
+        assert host.size == (self.size + 7) >> 3
+        check(_lib.lib().knox_bits_upload(self.ctx.h, self.h, _ptr(host) if host.size else None))
+        return self
+
+    def bytes(self, poison=0):
+        n = (self.size + 7) >> 3
+        out = np.full(n + poison, 0xFA, dtype=np.uint8)
+        check(_lib.lib().knox_bits_download(self.ctx.h, self.h, _ptr(out) if n else None))
+        assert (out[n:] == 0xFA).all(), "boundary violation"
+        return out[:n]
+
+    def _un(self, name):
+        check(getattr(_lib.lib(), "knox_bits_" + name)(self.ctx.h, self.h))
+        return self
+
+    def _bin(self, name, other):
+        check(getattr(_lib.lib(), "knox_bits_" + name)(self.ctx.h, self.h, other.h))
+        return self
+
+    def zero(self):
+        return self._un("zero")
+
+    def one(self):
+        return self._un("one")
+
+    def neg(self):
+        return self._un("neg")
+
+    def and_(self, o):
+        return self._bin("and", o)
+
+    def andnot(self, o):
+        return self._bin("andnot", o)
+
+    def or_(self, o):
+        return self._bin("or", o)
+
+    def xor(self, o):
+        return self._bin("xor", o)
+
+    def copy_from(self, o):
+        return self._bin("copy", o)
+
+    def _flag(self, name, o):
+        a, l = C.c_int(), C.c_int()
+        check(getattr(_lib.lib(), "knox_bits_" + name)(self.ctx.h, self.h, o.h, C.byref(a), C.byref(l)))
+        return bool(a.value), bool(l.value)
+
+    def and_flag(self, o):
+        return self._flag("and_flag", o)
+
+    def or_flag(self, o):
+        return self._flag("or_flag", o)
+
+    def count(self):
+        c = C.c_int64()
+        check(_lib.lib().knox_bits_popcount(self.ctx.h, self.h, C.byref(c)))
+        return c.value
+
+    def segment_counts(self, seg_bits):
+        n = (self.size + seg_bits - 1) // seg_bits
+        out = np.zeros(n, dtype=np.int64)
+        check(_lib.lib().knox_bits_popcount_segments(self.ctx.h, self.h, seg_bits, _ptr(out), n))
+        return out
+
+    def indexes(self, capacity=None):
+        cap = self.size + 8 if capacity is None else capacity
+        out = np.zeros(max(cap, 1), dtype=np.uint32)
+        n = C.c_size_t()
+        check(_lib.lib().knox_bits_indexes(self.ctx.h, self.h, _ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def free(self):
+        if self.h:
+            _lib.lib().knox_bits_free(self.h)
+            self.h = None
+
+
+class ScanResult:
+    def __init__(self, count, rows_scanned, pack_counts, states, aggs, cols):
+        self.count, self.rows_scanned, self.pack_counts = count, rows_scanned, pack_counts
+        self.states, self._aggs, self._cols = states, aggs, cols
+
+    def value(self, i):
+        """Reducer.Value() of aggregate i -> (value, seen, row)."""
+        func, col = self._aggs[i]
+        return agg_value(self.states[i], func)
+
+
+def agg_value(state, func):
+    dtype = BlockType(state.dtype)
+    out = np.zeros(1, dtype=NP_DTYPE[dtype])
+    seen, row = C.c_int(), C.c_int64()
+    check(_lib.lib().knox_agg_value(C.byref(state), int(func), _ptr(out), C.byref(seen), C.byref(row)))
+    return out[0], bool(seen.value), row.value
+
+
+def agg_combine(states):
+    arr = (AggState * len(states))(*states)
+    out = AggState()
+    check(_lib.lib().knox_agg_combine(arr, len(states), C.byref(out)))
+    return out
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        L = _lib.lib()
+        h = C.c_void_p()
+        if stream is None:
+            check(L.knox_ctx_open(device, C.byref(h)), "knox_ctx_open")
+        else:
+            check(L.knox_ctx_open_stream(device, C.c_void_p(stream), C.byref(h)), "knox_ctx_open_stream")
+        self.h, self.L = h, L
+
+    def close(self):
+        if self.h:
+            self.L.knox_ctx_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        check(self.L.knox_ctx_sync(self.h))
+
+    def set_tuning(self, blocks_per_cu=0, variant=-1):
+        check(self.L.knox_ctx_set_tuning(self.h, blocks_per_cu, variant))
+
+    def timer_start(self):
+        check(self.L.knox_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.L.knox_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # -- finest boundary: cmp.Int64Less(src, val, bits) int64 etc. (internal/cmp/cmp.go:6-114)
+    def cmp(self, dtype, mode, src, a, b=None, poison=32):
+        dtype = BlockType(dtype)
+        src = np.ascontiguousarray(src, dtype=NP_DTYPE[dtype])
+        n = src.size
+        nb = (n + 7) >> 3
+        buf = np.zeros(nb + poison, dtype=np.uint8)
+        buf[nb:] = 0xFA
+        av = np.array([a], dtype=NP_DTYPE[dtype])
+        bv = np.array([b if b is not None else 0], dtype=NP_DTYPE[dtype])
+        cnt = self.L.knox_cmp(self.h, int(dtype), int(mode), _ptr(src) if n else None, n, _ptr(av), _ptr(bv), _ptr(buf))
+        if cnt < 0:
+            raise KnoxError(int(cnt), "knox_cmp")
+        assert (buf[nb:] == 0xFA).all(), "boundary violation"
+        return buf[:nb], cnt
+
+    # -- columns
+    def upload(self, arr, pack_rows=0):
+        arr = np.ascontiguousarray(arr)
+        dtype = FROM_NP[arr.dtype]
+        h = C.c_void_p()
+        check(self.L.knox_col_upload(self.h, int(dtype), _ptr(arr) if arr.size else None, arr.size, pack_rows, C.byref(h)))
+        return Column(self, h, dtype, pack_rows=pack_rows)
+
+    def upload_bytes(self, ptr, buf, pack_rows=0):
+        ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        h = C.c_void_p()
+        check(self.L.knox_col_upload_bytes(self.h, _ptr(ptr) if ptr.size else None, ptr.size,
+                                           _ptr(buf) if buf.size else None, buf.size, pack_rows, C.byref(h)))
+        return Column(self, h, BlockType.Bytes, pack_rows=pack_rows)
+
+    def wrap(self, dtype, device_ptr, n_rows, pack_rows=0, keep=None):
+        h = C.c_void_p()
+        check(self.L.knox_col_wrap(self.h, int(dtype), C.c_void_p(device_ptr), n_rows, pack_rows, C.byref(h)))
+        return Column(self, h, dtype, keep, pack_rows=pack_rows)
+
+    def generate(self, dtype, kind, seed, n_rows, first_row=0, lo=0, span=0, pack_rows=0):
+        h = C.c_void_p()
+        check(self.L.knox_col_generate(self.h, int(dtype), kind, seed, first_row, n_rows, lo, span, pack_rows, C.byref(h)))
+        return Column(self, h, dtype, pack_rows=pack_rows)
+
+    def bits(self, size):
+        return Bits(self, size)
+
+    # -- filter.Match over every resident pack + reducers
+    def _plan(self, tree, cols, aggs):
+        nodes, keep = [], []
+        if isinstance(tree, Leaf):
+            tree = And(tree)  # root is always an AND node (operator/filter/node.go:25-28)
+        _flatten(tree, cols, nodes, keep)
+        parr = (Pred * len(nodes))(*nodes)
+        carr = (C.c_void_p * len(cols))(*[c.h for c in cols])
+        aggs = [(ReducerFunc(f), c) for f, c in (aggs or [])]
+        aarr = (Agg * max(1, len(aggs)))()
+        for i, (f, c) in enumerate(aggs):
+            aarr[i].func, aarr[i].col = int(f), c
+        return parr, len(nodes), carr, aggs, aarr, keep
+
+    def scan(self, tree, cols, aggs=None, bits_out=None, pack_counts=False, pack_skip=None, row_base=0):
+        parr, nn, carr, aggs, aarr, keep = self._plan(tree, cols, aggs)
+        n_rows = cols[0].rows
+        skip = np.ascontiguousarray(pack_skip, dtype=np.uint8) if pack_skip is not None else None
+        pc = None
+        if pack_counts:
+            prow = self._pack_rows(cols[0])
+            pc = np.zeros((n_rows + prow - 1) // prow if prow else 0, dtype=np.int64)
+        states = (AggState * max(1, len(aggs)))()
+        out = ScanOut()
+        check(self.L.knox_scan(self.h, parr, nn, carr, len(cols), aarr, len(aggs), row_base, _ptr(skip),
+                               bits_out.h if bits_out is not None else None, _ptr(pc), states, C.byref(out)), "knox_scan")
+        return ScanResult(out.count, out.rows_scanned, pc, [states[i] for i in range(len(aggs))], aggs, cols)
+
+    def scan_async(self, plan, bits_out=None, pack_counts=False, row_base=0, pack_skip=None):
+        parr, nn, carr, aggs, aarr, keep = plan
+        skip = np.ascontiguousarray(pack_skip, dtype=np.uint8) if pack_skip is not None else None
+        check(self.L.knox_scan_async(self.h, parr, nn, carr, len(carr), aarr, len(aggs), row_base, _ptr(skip),
+                                     bits_out.h if bits_out is not None else None, 1 if pack_counts else 0), "knox_scan_async")
+
+    def scan_collect(self, plan, n_packs=0):
+        parr, nn, carr, aggs, aarr, keep = plan
+        states = (AggState * max(1, len(aggs)))()
+        out = ScanOut()
+        pc = np.zeros(n_packs, dtype=np.int64) if n_packs else None
+        check(self.L.knox_scan_collect(self.h, _ptr(pc), states, len(aggs), C.byref(out)), "knox_scan_collect")
+        return ScanResult(out.count, out.rows_scanned, pc, [states[i] for i in range(len(aggs))], aggs, None)
+
+    def plan(self, tree, cols, aggs=None):
+        return self._plan(tree, cols, aggs)
+
+    def _pack_rows(self, col):
+        return col.pack_rows or col.rows
+
+    def reduce(self, col, mask=None, row_base=0):
+        st = AggState()
+        check(self.L.knox_reduce(self.h, col.h, mask.h if mask is not None else None, row_base, C.byref(st)))
+        return st
+
+    def reduce_sequential(self, col, func, mask=None):
+        out = np.zeros(1, dtype=NP_DTYPE[col.dtype])
+        seen, row = C.c_int(), C.c_int64()
+        check(self.L.knox_reduce_sequential(self.h, col.h, mask.h if mask is not None else None, int(func), _ptr(out),
+                                            C.byref(seen), C.byref(row)))
+        return out[0], bool(seen.value), row.value
+
+    # -- bloom
+    def bloom_probe(self, filters, offsets, h):
+        filters = np.ascontiguousarray(filters, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(n, dtype=np.uint8)
+        check(self.L.knox_bloom_probe(self.h, _ptr(filters) if filters.size else None, _ptr(offsets), n, h, _ptr(out)))
+        return out
+
+    def bloom_build_u64(self, col, factor, pack_rows):
+        n_packs = (col.rows + pack_rows - 1) // pack_rows
+        m = 8
+        while m < pack_rows * factor * 8:
+            m <<= 1
+        cap = n_packs * (1 + (m >> 3)) + 64
+        filters = np.zeros(cap, dtype=np.uint8)
+        offsets = np.zeros(n_packs + 1, dtype=np.uint64)
+        check(self.L.knox_bloom_build_u64(self.h, col.h, factor, _ptr(filters), cap, _ptr(offsets)))
+        return filters[:int(offsets[-1])], offsets
+
+
+def hash_value(dtype, v):
+    a = np.array([v], dtype=NP_DTYPE[BlockType(dtype)])
+    return _lib.lib().knox_hash_value(int(dtype), _ptr(a))
+
+
+def device_count():
+    n = C.c_int()
+    rc = _lib.lib().knox_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

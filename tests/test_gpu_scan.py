@@ -1,0 +1,260 @@
+"""GPU parity for the fused scan (filter.Match over resident packs + reducers) through the
+C ABI, against the oracle's MatchAnd / MatchOr + sequential reducers."""
+import math
+
+import numpy as np
+import pytest
+
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf, Or
+from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc
+from oracle import oracle as O
+from helpers import oracle_match, rand_col
+
+pytestmark = pytest.mark.gpu
+
+R = ReducerFunc
+R2O = {R.Sum: O.R_SUM, R.First: O.R_FIRST, R.Last: O.R_LAST, R.Min: O.R_MIN, R.Max: O.R_MAX, R.Mean: O.R_MEAN, R.Count: O.R_COUNT}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def _same(a, b):
+    return a == b or (isinstance(a, (float, np.floating)) and math.isnan(a) and math.isnan(b))
+
+
+def _ulp_dist(a, b):
+    ia, ib = np.array([a, b], dtype=np.float64).view(np.int64)
+    ia = ia if ia >= 0 else np.int64(-(2**63)) - ia
+    ib = ib if ib >= 0 else np.int64(-(2**63)) - ib
+    return abs(int(ia) - int(ib))
+
+
+def check_scan(ctx, tree, host_cols, aggs, pack_rows, n):
+    dev = [ctx.upload(c, pack_rows) if not isinstance(c, tuple) else ctx.upload_bytes(c[0], c[1], pack_rows) for c in host_cols]
+    for d in dev:
+        d.pack_rows = pack_rows
+    bits = ctx.bits(n)
+    res = ctx.scan(tree, dev, aggs=aggs, bits_out=bits, pack_counts=True)
+    want = oracle_match(tree if not isinstance(tree, Leaf) else And(tree), host_cols, n)
+    got = bits.bytes(poison=32)
+    assert (got == want).all(), "bitset mismatch"
+    assert res.count == O.popcount(want, n)
+    # per-pack counts == popcount of each pack's slice (Bitset.ResetCount semantics)
+    for p, c in enumerate(res.pack_counts):
+        lo = p * pack_rows
+        ln = min(pack_rows, n - lo)
+        assert c == O.popcount(want[lo // 8:lo // 8 + (ln + 7) // 8], ln), p
+    for i, (f, ci) in enumerate(aggs or []):
+        col = host_cols[ci]
+        dt = int({np.dtype(v): k for k, v in K.types.NP_DTYPE.items()}[col.dtype])
+        gv, gseen, grow = res.value(i)
+        if f == R.Mean or (f == R.Sum and col.dtype.kind == "f"):
+            xs = col.astype(np.float64)
+            s, m, cnt = O.exact_sum_f64(xs, want)
+            exact = (m if f == R.Mean else s)
+            if col.dtype == np.float32 or col.dtype.kind != "f":
+                exact = col.dtype.type(exact) if not (col.dtype.kind != "f" and math.isnan(exact)) else exact
+            assert gseen == (cnt > 0)
+            if cnt:
+                if col.dtype.kind == "f":
+                    assert _same(gv, exact) or _ulp_dist(float(gv), float(exact)) <= 1, (f, gv, exact)
+                else:
+                    assert int(gv) == int(exact), (f, gv, exact)  # T(mean) truncation of the exact mean
+            continue
+        wv, wseen, wrow = O.reduce(dt, R2O[f], col, want)
+        assert gseen == wseen, (f, gseen, wseen)
+        assert _same(gv, wv), (f, gv, wv)
+        if f in (R.Min, R.Max, R.First, R.Last) and wseen:
+            assert grow == wrow, (f, grow, wrow)
+    for d in dev:
+        d.free()
+    bits.free()
+    return res
+
+
+SIZES = [100, 2048, 2049, 4096 + 77, 3 * 65536 + 11]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_int64_between_sum(ctx, n):
+    rng = np.random.default_rng(n)
+    x = O.generate(O.I64, 0, 2, 0, n, lo=-(1 << 40), span=1 << 41)
+    tree = And(Leaf(0, FilterMode.Range, -(1 << 38), 1 << 38))
+    check_scan(ctx, tree, [x], [(R.Sum, 0), (R.Count, 0), (R.Min, 0), (R.Max, 0), (R.First, 0), (R.Last, 0), (R.Mean, 0)], 1024, n)
+
+
+@pytest.mark.parametrize("bt", [BlockType.Int64, BlockType.Uint64, BlockType.Float64, BlockType.Int32, BlockType.Uint32,
+                                BlockType.Float32, BlockType.Int16, BlockType.Uint16, BlockType.Int8, BlockType.Uint8])
+def test_single_leaf_all_types_all_aggs(ctx, bt):
+    rng = np.random.default_rng(int(bt))
+    for n in (777, 16384 + 100, 70000):
+        x = rand_col(bt, n, rng)
+        for op in (FilterMode.Le, FilterMode.NotEqual, FilterMode.Range):
+            a, b = x[3], x[5]
+            if op == FilterMode.Range and x.dtype.kind == "f" and not (a <= b):
+                a, b = b, a
+            tree = And(Leaf(0, op, a, b))
+            aggs = [(R.Sum, 0), (R.Count, 0), (R.Min, 0), (R.Max, 0), (R.First, 0), (R.Last, 0)]
+            if x.dtype.kind != "f" or True:
+                aggs.append((R.Mean, 0))
+            if x.dtype.kind == "f":
+                # sums containing Inf/NaN follow IEEE: keep them, exact checker handles specials
+                pass
+            check_scan(ctx, tree, [x], aggs, 256, n)
+
+
+def test_two_float_predicates_anded_min_max_mean(ctx):
+    # BASELINE config 3 shape: A >= 256 AND B < 0.5, min/max/mean(A) + count
+    n = 5 * 65536 + 333
+    a = O.generate(O.F64, 1, 3, 0, n)
+    b = O.generate(O.F64, 2, 4, 0, n)
+    tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
+    res = check_scan(ctx, tree, [a, b], [(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Count, 0), (R.Sum, 0)], 65536, n)
+    # exact-sum dataset: the float sum must be bit-identical to the literal sequential sum
+    want = oracle_match(tree, [a, b], n)
+    assert res.value(4)[0] == O.reduce(O.F64, O.R_SUM, a, want)[0]
+
+
+def test_semantic_float_set_nan_inf_zero(ctx):
+    n = 40000
+    a = O.generate(O.F64, 4, 7, 0, n)
+    a[0] = np.nan  # first selected value NaN -> sticky for min/max
+    tree = And(Leaf(0, FilterMode.NotEqual, 1.0))
+    check_scan(ctx, tree, [a], [(R.Min, 0), (R.Max, 0), (R.First, 0), (R.Last, 0), (R.Count, 0)], 4096, n)
+    a[0] = 3.0
+    check_scan(ctx, tree, [a], [(R.Min, 0), (R.Max, 0)], 4096, n)
+    z = np.array([0.0, -0.0, 5.0, -0.0, 0.0] * 1000)
+    check_scan(ctx, And(Leaf(0, FilterMode.Le, 0.0)), [z], [(R.Min, 0), (R.Max, 0), (R.Last, 0)], 512, z.size)
+    z = -z
+    check_scan(ctx, And(Leaf(0, FilterMode.Ge, 0.0)), [z], [(R.Min, 0), (R.Max, 0)], 512, z.size)
+
+
+def test_trees_fused_up_to_four_leaves(ctx):
+    rng = np.random.default_rng(21)
+    n = 2 * 65536 + 77
+    cols = [rand_col(BlockType.Int64, n, rng), rand_col(BlockType.Uint64, n, rng), rand_col(BlockType.Float64, n, rng),
+            rand_col(BlockType.Int64, n, rng)]
+    L = Leaf
+    trees = [
+        And(L(0, FilterMode.Gt, 0), L(1, FilterMode.Lt, 30)),
+        And(Or(L(0, FilterMode.Equal, 5), L(1, FilterMode.Equal, 5))),
+        And(L(0, FilterMode.Ge, -10), Or(L(1, FilterMode.Le, 10), L(2, FilterMode.Gt, 50.0)), L(3, FilterMode.NotEqual, 0)),
+        And(Or(And(L(0, FilterMode.Lt, 0), L(2, FilterMode.Range, -100.0, 100.0)), L(3, FilterMode.Range, -5, 5))),
+        And(L(2, FilterMode.NotEqual, float("nan")), L(2, FilterMode.Le, float("inf"))),
+        And(L(0, FilterMode.True_, 0), L(1, FilterMode.Ge, 0)),
+        And(L(0, FilterMode.False_, 0)),
+        And(Or()),  # empty OR = no match; empty AND = all
+        And(),
+    ]
+    for t in trees:
+        check_scan(ctx, t, cols, [(R.Sum, 0), (R.Max, 3), (R.Count, 1)], 16384, n)
+
+
+def test_trees_multipass_many_leaves_and_mixed_widths(ctx):
+    rng = np.random.default_rng(22)
+    n = 65536 + 4097
+    cols = [rand_col(BlockType.Int64, n, rng), rand_col(BlockType.Int32, n, rng), rand_col(BlockType.Uint8, n, rng),
+            rand_col(BlockType.Float32, n, rng), rand_col(BlockType.Int16, n, rng)]
+    L = Leaf
+    t1 = And(L(0, FilterMode.Gt, -20), L(1, FilterMode.Lt, 30), L(2, FilterMode.NotEqual, 7))
+    t2 = And(Or(L(0, FilterMode.Equal, 5), L(0, FilterMode.Equal, 6), L(0, FilterMode.Equal, 7), L(0, FilterMode.Equal, 8),
+                L(0, FilterMode.Equal, 9), L(0, FilterMode.Lt, -40)), L(0, FilterMode.NotEqual, 9))
+    t3 = And(Or(L(3, FilterMode.Gt, 10.0), And(L(4, FilterMode.Range, -10, 10), L(1, FilterMode.Ge, 0))), L(2, FilterMode.Le, 200))
+    for t in (t1, t2, t3):
+        check_scan(ctx, t, cols, [(R.Sum, 1), (R.Min, 3), (R.Max, 4), (R.Count, 0), (R.Mean, 2)], 4096, n)
+
+
+def test_bytes_column_eq_ne_and_mixed_tree(ctx):
+    rng = np.random.default_rng(23)
+    n = 20000 + 13
+    keys = [bytes(rng.integers(0, 256, size=32, dtype=np.uint8)) for _ in range(50)] + [b"", b"short", b"x" * 100]
+    pick = rng.integers(0, len(keys), size=n)
+    vals = [keys[i] for i in pick]
+    buf = np.frombuffer(b"".join(vals), dtype=np.uint8)
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    ids = np.arange(n, dtype=np.uint64)
+    for key in (keys[0], keys[7], b"", b"short", b"absent-key"):
+        for op in (FilterMode.Equal, FilterMode.NotEqual):
+            check_scan(ctx, And(Leaf(0, op, key)), [(ptr, buf), ids], [(R.Count, 1), (R.Sum, 1)], 1024, n)
+    check_scan(ctx, And(Leaf(0, FilterMode.Equal, keys[3]), Leaf(1, FilterMode.Lt, 10000)), [(ptr, buf), ids], [(R.Max, 1)], 1024, n)
+
+
+def test_pack_skip_is_an_optimisation_only(ctx):
+    # packs pruned by a bloom / zone map (no false negatives) produce the same bitset, fewer rows read
+    n, pack = 8 * 4096, 4096
+    x = np.arange(n, dtype=np.int64)
+    col = ctx.upload(x, pack)
+    col.pack_rows = pack
+    bits = ctx.bits(n)
+    tree = And(Leaf(0, FilterMode.Range, 4096 * 3 + 5, 4096 * 3 + 900))
+    skip = np.ones(8, dtype=np.uint8)
+    skip[3] = 0
+    res = ctx.scan(tree, [col], aggs=[(R.Sum, 0)], bits_out=bits, pack_counts=True, pack_skip=skip)
+    want, cnt = O.cmp(O.I64, O.RG, x, 4096 * 3 + 5, 4096 * 3 + 900)
+    assert (bits.bytes() == want).all() and res.count == cnt == 896
+    assert res.rows_scanned == 4096 and res.pack_counts.tolist() == [0, 0, 0, 896, 0, 0, 0, 0]
+    assert res.value(0)[0] == int(x[(x >= 4096 * 3 + 5) & (x <= 4096 * 3 + 900)].sum())
+    col.free()
+    bits.free()
+
+
+def test_row_base_offsets_row_ids(ctx):
+    x = np.array([5, 1, 9, 1, 9], dtype=np.int64).repeat(1000)
+    col = ctx.upload(x, 1024)
+    res = ctx.scan(And(Leaf(0, FilterMode.Ge, 0)), [col], aggs=[(R.Min, 0), (R.Max, 0), (R.Last, 0)], row_base=1 << 33)
+    assert res.value(0)[2] == (1 << 33) + 1000 and res.value(1)[2] == (1 << 33) + 2000 and res.value(2)[2] == (1 << 33) + 4999
+    col.free()
+
+
+def test_reduce_sequential_is_literal_reference_fold(ctx):
+    # slow single-lane mode reproduces reducer.go bit for bit (incl. Welford mean / var / std)
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal(5000) * 1e3).astype(np.float64)
+    bits_h = np.packbits(rng.random(5000) < 0.5, bitorder="little")
+    col = ctx.upload(x)
+    m = ctx.bits(5000).upload(bits_h)
+    for f in range(9):
+        got = ctx.reduce_sequential(col, f, m)
+        want = O.reduce(O.F64, f, x, bits_h)
+        assert _same(got[0], want[0]) and got[1] == want[1] and got[2] == want[2], f
+    xi = rng.integers(-1000, 1000, 3000).astype(np.int32)
+    ci = ctx.upload(xi)
+    for f in range(9):
+        if f in (6, 7):
+            continue  # T(NaN) for ints is implementation defined
+        got, want = ctx.reduce_sequential(ci, f), O.reduce(O.I32, f, xi)
+        assert got == want, f
+    col.free(); ci.free(); m.free()
+
+
+def test_masked_reduce_matches_oracle(ctx):
+    rng = np.random.default_rng(32)
+    n = 3 * 16384 + 5
+    for bt in (BlockType.Int64, BlockType.Float64, BlockType.Int16, BlockType.Uint8, BlockType.Float32):
+        x = rand_col(bt, n, rng)
+        if x.dtype.kind == "f":
+            x[np.isinf(x) | np.isnan(x)] = 1.0
+        bits_h = np.packbits(rng.random(n) < 0.4, bitorder="little")
+        col = ctx.upload(x)
+        m = ctx.bits(n).upload(bits_h)
+        st = ctx.reduce(col, m)
+        dt = int(bt)
+        for fk, fo in ((R.Count, O.R_COUNT), (R.Min, O.R_MIN), (R.Max, O.R_MAX), (R.First, O.R_FIRST), (R.Last, O.R_LAST)):
+            got, want = K.agg_value(st, fk), O.reduce(dt, fo, x, bits_h)
+            assert _same(got[0], want[0]) and got[1] == want[1], (bt, fk, got, want)
+        if x.dtype.kind != "f":
+            assert K.agg_value(st, R.Sum)[0] == O.reduce(dt, O.R_SUM, x, bits_h)[0]
+        else:
+            s, mean, cnt = O.exact_sum_f64(x.astype(np.float64), bits_h)
+            assert _ulp_dist(float(K.agg_value(st, R.Sum)[0]), float(x.dtype.type(s))) <= 1
+        st_all = ctx.reduce(col, None)
+        assert K.agg_value(st_all, R.Count)[0] == x.dtype.type(n) or x.dtype.itemsize < 8
+        col.free(); m.free()
