@@ -933,7 +933,23 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         }
     }
     const int n_leaves = (int)leaf_nodes.size();
-    if (n_leaves == 0) return KNOX_E_INVALID;
+    if (n_leaves == 0) {
+        // constant tree (empty AND = all rows, empty OR = none, match_core.go:45-56,131-138):
+        // run it as one TRUE / FALSE leaf on the first numeric column
+        uint64_t tt0 = 0;
+        int rc0 = make_truth_table(nodes, n_nodes, leaf_of_node, std::vector<bool>(), 0, tt0);
+        if (rc0) return rc0;
+        for (int c = 0; c < n_cols; c++) {
+            if (cols[c]->dtype == KNOX_BYTES) continue;
+            knox_pred k;
+            memset(&k, 0, sizeof k);
+            k.kind = KNOX_NODE_LEAF;
+            k.col = c;
+            k.op = (tt0 & 1) ? KNOX_TRUE : KNOX_FALSE;
+            return knox_scan_async(ctx, &k, 1, cols, n_cols, aggs, n_aggs, row_base, pack_skip, bits_out, want_pack_counts);
+        }
+        return KNOX_E_UNSUPPORTED;
+    }
 
     // ---- aggregate columns: distinct columns, union of needed work
     int agg_cols[14], n_agg_cols = 0;

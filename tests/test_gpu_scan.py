@@ -56,6 +56,13 @@ def check_scan(ctx, tree, host_cols, aggs, pack_rows, n):
         gv, gseen, grow = res.value(i)
         if f == R.Mean or (f == R.Sum and col.dtype.kind == "f"):
             xs = col.astype(np.float64)
+            if col.dtype.kind == "f":
+                selm = np.unpackbits(want, bitorder="little")[:n].astype(bool)
+                big = np.abs(xs[selm & np.isfinite(xs)]) > 1e300
+                if big.sum() > 1:
+                    # partial sums leave the float64 range: the result is order dependent in the
+                    # reference too (sequential `r.v += v` overflows to Inf at some prefix)
+                    continue
             s, m, cnt = O.exact_sum_f64(xs, want)
             exact = (m if f == R.Mean else s)
             if col.dtype == np.float32 or col.dtype.kind != "f":
@@ -241,7 +248,8 @@ def test_masked_reduce_matches_oracle(ctx):
     for bt in (BlockType.Int64, BlockType.Float64, BlockType.Int16, BlockType.Uint8, BlockType.Float32):
         x = rand_col(bt, n, rng)
         if x.dtype.kind == "f":
-            x[np.isinf(x) | np.isnan(x)] = 1.0
+            # keep partial sums inside the float range: overflowing sums are order dependent
+            x[np.isinf(x) | np.isnan(x) | (np.abs(x) > 1e30)] = 1.0
         bits_h = np.packbits(rng.random(n) < 0.4, bitorder="little")
         col = ctx.upload(x)
         m = ctx.bits(n).upload(bits_h)
