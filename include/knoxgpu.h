@@ -44,7 +44,8 @@ enum knox_err {
     KNOX_E_NOMEM = -4,       /* host or device allocation failed                          */
     KNOX_E_UNSUPPORTED = -5, /* valid request this build does not implement               */
     KNOX_E_COMM = -6,        /* RCCL failure / not initialised                            */
-    KNOX_E_RANGE = -7        /* row/size out of range                                     */
+    KNOX_E_RANGE = -7,       /* row/size out of range                                     */
+    KNOX_E_BUSY = -8         /* result ring full: knox_scan_collect before the next async */
 };
 
 /* ---- types.BlockType (internal/types/block.go:20-36) -------------------------------- */
@@ -93,6 +94,8 @@ int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
  * the summed kernel time and launch count since the last read, and resets.                */
 int knox_prof_enable(knox_ctx *ctx, int on);
 int knox_prof_read(knox_ctx *ctx, double *total_ms, int *launches);
+/* Same, but returns each launch's duration (up to cap entries, in launch order).             */
+int knox_prof_read_each(knox_ctx *ctx, float *ms, int cap, int *launches);
 
 /* ---- finest boundary: the cmp func vars --------------------------------------------- *
  * Replaces `func(src []T, val T, bits []byte) int64` / `func(src []T, a, b T, bits []byte)
@@ -211,8 +214,10 @@ typedef struct knox_scan_out {
 int knox_scan(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols,
               const knox_agg *aggs, int n_aggs, uint64_t row_base, const uint8_t *pack_skip,
               knox_bits *bits_out, int64_t *pack_counts, knox_agg_state *states, knox_scan_out *out);
-/* Enqueue-only variant for benchmarking: identical work, results are left in ctx-owned pinned
- * memory and fetched with knox_scan_collect after knox_ctx_sync.                            */
+/* Enqueue-only variant: identical work; the results land in one of 4 ctx-owned pinned result
+ * slots.  knox_scan_collect waits for and returns the OLDEST uncollected scan (FIFO), so a
+ * host can keep up to 4 scans in flight -- enqueue scan i+1, then collect scan i -- and the
+ * device never idles between packs of work.  A 5th uncollected async returns KNOX_E_BUSY.   */
 int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols,
                     const knox_agg *aggs, int n_aggs, uint64_t row_base, const uint8_t *pack_skip,
                     knox_bits *bits_out, int want_pack_counts);

@@ -43,8 +43,8 @@ struct knox_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_hip = 0;
     int n_cus = 256;
-    int blocks_per_cu = 8;
-    int variant = 0;
+    int blocks_per_cu = 2;  // 2 x 256 threads per CU measured fastest for pure streaming (profiles/r01_sweep.txt)
+    int variant = 1;  // 1 = non-temporal streaming loads/stores (default), 0 = plain (8-byte types only)
     // staging ring (pinned) for host -> HBM uploads
     static constexpr size_t kStageBytes = 32u << 20;
     void *stage[2] = {nullptr, nullptr};
@@ -60,18 +60,23 @@ struct knox_ctx {
     DevBuf idx_scratch;  // indexes: block offsets
     DevBuf idx_rows;     // indexes: row ids
     DevBuf bytes_val;    // bytes leaf value
-    // pinned result mirror
-    void *h_res = nullptr;
-    size_t h_res_cap = 0;
-    void *h_packs = nullptr;
-    size_t h_packs_cap = 0;
-    // last async scan (for knox_scan_collect)
-    int last_slots = 0;
-    int last_agg_slot[16];
-    int last_n_aggs = 0;
-    size_t last_n_packs = 0;
-    bool last_has_pack_counts = false;
-    uint64_t last_rows_scanned = 0;
+    // ring of pinned result mirrors: up to kResRing scans may be in flight (software
+    // pipelining: enqueue scan i+1 before collecting scan i keeps the device busy)
+    struct ResSlot {
+        void *h_res = nullptr;
+        size_t h_res_cap = 0;
+        void *h_packs = nullptr;
+        size_t h_packs_cap = 0;
+        hipEvent_t done = nullptr;
+        int agg_slot[16];
+        int n_aggs = 0;
+        size_t n_packs = 0;
+        bool has_pack_counts = false;
+        uint64_t rows_scanned = 0;
+    };
+    static constexpr int kResRing = 4;
+    ResSlot res[kResRing];
+    uint64_t res_head = 0, res_tail = 0;  // head: next slot to fill, tail: oldest uncollected
     // per-kernel stopwatch (knox_prof_*)
     bool prof = false;
     static constexpr int kProfRing = 512;
@@ -186,6 +191,7 @@ KNOX_API const char *knox_strerror(int err) {
     case KNOX_E_UNSUPPORTED: return "unsupported request";
     case KNOX_E_COMM: return "RCCL error";
     case KNOX_E_RANGE: return "out of range";
+    case KNOX_E_BUSY: return "too many scans in flight: collect one first";
     default: return "unknown error";
     }
 }
@@ -253,8 +259,11 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     }
     for (hipEvent_t e : ctx->prof_ev)
         if (e) hipEventDestroy(e);
-    if (ctx->h_res) hipHostFree(ctx->h_res);
-    if (ctx->h_packs) hipHostFree(ctx->h_packs);
+    for (auto &r : ctx->res) {
+        if (r.h_res) hipHostFree(r.h_res);
+        if (r.h_packs) hipHostFree(r.h_packs);
+        if (r.done) hipEventDestroy(r.done);
+    }
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -309,6 +318,16 @@ KNOX_API int knox_prof_read(knox_ctx *ctx, double *total_ms, int *launches) {
     }
     *total_ms = t;
     *launches = ctx->prof_n;
+    ctx->prof_n = 0;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_prof_read_each(knox_ctx *ctx, float *ms, int cap, int *launches) {
+    if (!ctx || !ms || !launches || cap < 0) return KNOX_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = ctx->prof_n < cap ? ctx->prof_n : cap;
+    for (int i = 0; i < n; i++) HIPCHK(ctx, hipEventElapsedTime(&ms[i], ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    *launches = n;
     ctx->prof_n = 0;
     return KNOX_OK;
 }
@@ -834,6 +853,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     a.bits = bits;
     a.pack_skip = d_skip;
     a.pack_shift = d_skip ? pack_shift_for(pack_rows, width) : 255;
+    a.debug = ctx->variant == 2 ? 1u : 0u;  // variant 2: diagnostics, bitset assembled but not stored
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
     if (slot != 15) prof_mark(ctx, 0);
@@ -912,6 +932,8 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                              int want_pack_counts) {
     if (!ctx || !nodes || n_nodes <= 0 || !cols || n_cols <= 0 || n_aggs < 0 || n_aggs > 14 || (n_aggs && !aggs)) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
+    if (ctx->res_head - ctx->res_tail >= (uint64_t)knox_ctx::kResRing) return KNOX_E_BUSY;  // collect first
+    knox_ctx::ResSlot &slot = ctx->res[ctx->res_head % knox_ctx::kResRing];
     const size_t n_rows = cols[0]->n_rows;
     const size_t pack_rows = cols[0]->pack_rows;
     for (int i = 0; i < n_cols; i++)
@@ -966,11 +988,9 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         }
         int rc = agg_need(aggs[i].func, cols[aggs[i].col]->dtype, agg_needs[s]);
         if (rc) return rc;
-        ctx->last_agg_slot[i] = s;
+        slot.agg_slot[i] = s;
     }
-    ctx->last_n_aggs = n_aggs;
-    const int n_slots = std::max(1, n_agg_cols);
-    ctx->last_slots = n_slots;
+    slot.n_aggs = n_aggs;
 
     // ---- workspace
     const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
@@ -989,7 +1009,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         for (size_t p = 0; p < n_packs; p++)
             if (pack_skip[p]) rows_scanned -= std::min(pack_rows, n_rows - p * pack_rows);
     }
-    ctx->last_rows_scanned = rows_scanned;
+    slot.rows_scanned = rows_scanned;
 
     // ---- can the whole tree run as one fused pass?
     bool fused = n_leaves <= kMaxLeaves;
@@ -1108,39 +1128,44 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     }
 
     // ---- per-pack counts from the bitset
-    ctx->last_has_pack_counts = false;
-    ctx->last_n_packs = n_packs;
+    slot.has_pack_counts = false;
+    slot.n_packs = n_packs;
     if (want_pack_counts && n_packs) {
         rc = ensure(ctx, ctx->pack_counts, n_packs * 8 + 8);
-        if (!rc) rc = ensure_host(ctx, ctx->h_packs, ctx->h_packs_cap, n_packs * 8);
+        if (!rc) rc = ensure_host(ctx, slot.h_packs, slot.h_packs_cap, n_packs * 8);
         if (rc) return rc;
         hipError_t e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)ctx->pack_counts.p, n_packs);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_packs, ctx->pack_counts.p, n_packs * 8, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->last_has_pack_counts = true;
+        HIPCHK(ctx, hipMemcpyAsync(slot.h_packs, ctx->pack_counts.p, n_packs * 8, hipMemcpyDeviceToHost, ctx->stream));
+        slot.has_pack_counts = true;
     }
-    // ---- small results -> pinned mirror
-    rc = ensure_host(ctx, ctx->h_res, ctx->h_res_cap, sizeof(AggStateDev) * 16 + 8 * 16);
+    // ---- small results -> this scan's pinned mirror, then its completion event
+    rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_res, ctx->states.p, sizeof(AggStateDev) * 16 + 8 * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(slot.h_res, ctx->states.p, sizeof(AggStateDev) * 16 + 8 * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (!slot.done) HIPCHK(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(slot.done, ctx->stream));
+    ctx->res_head++;
     return KNOX_OK;
 }
 
 KNOX_API int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_state *states, int n_aggs, knox_scan_out *out) {
     if (!ctx || n_aggs < 0 || (n_aggs && !states)) return KNOX_E_INVALID;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ctx->h_res) return KNOX_E_INVALID;
-    const AggStateDev *st = (const AggStateDev *)ctx->h_res;
+    if (ctx->res_tail == ctx->res_head) return KNOX_E_INVALID;  // nothing in flight
+    knox_ctx::ResSlot &slot = ctx->res[ctx->res_tail % knox_ctx::kResRing];
+    HIPCHK(ctx, hipEventSynchronize(slot.done));  // waits for THIS scan only, later ones keep running
+    ctx->res_tail++;
+    const AggStateDev *st = (const AggStateDev *)slot.h_res;
     const int64_t *counts = (const int64_t *)(st + 16);
-    if (n_aggs > ctx->last_n_aggs) return KNOX_E_RANGE;
-    for (int i = 0; i < n_aggs; i++) memcpy(&states[i], &st[ctx->last_agg_slot[i]], sizeof(knox_agg_state));
+    if (n_aggs > slot.n_aggs) return KNOX_E_RANGE;
+    for (int i = 0; i < n_aggs; i++) memcpy(&states[i], &st[slot.agg_slot[i]], sizeof(knox_agg_state));
     if (out) {
         out->count = counts[0];
-        out->rows_scanned = (int64_t)ctx->last_rows_scanned;
+        out->rows_scanned = (int64_t)slot.rows_scanned;
     }
     if (pack_counts) {
-        if (!ctx->last_has_pack_counts) return KNOX_E_INVALID;
-        memcpy(pack_counts, ctx->h_packs, ctx->last_n_packs * 8);
+        if (!slot.has_pack_counts) return KNOX_E_INVALID;
+        memcpy(pack_counts, slot.h_packs, slot.n_packs * 8);
     }
     return KNOX_OK;
 }
@@ -1148,6 +1173,8 @@ KNOX_API int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_sta
 KNOX_API int knox_scan(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col *const *cols, int n_cols, const knox_agg *aggs,
                        int n_aggs, uint64_t row_base, const uint8_t *pack_skip, knox_bits *bits_out, int64_t *pack_counts,
                        knox_agg_state *states, knox_scan_out *out) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;  // collect the async scans first (FIFO)
     int rc = knox_scan_async(ctx, nodes, n_nodes, cols, n_cols, aggs, n_aggs, row_base, pack_skip, bits_out, pack_counts != nullptr);
     if (rc) return rc;
     return knox_scan_collect(ctx, pack_counts, states, n_aggs, out);

@@ -48,6 +48,7 @@ struct ScanArgs {
     uint64_t row_base;      // global id of local row 0
     uint32_t *bits;         // output bitset (nullable)
     const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)
+    uint32_t debug;         // diagnostics: bit0 = compute the bitset words but skip the global store
     AggPartial *partials;   // [grid] (+1 slot for the tail at index grid)
 };
 

@@ -228,7 +228,9 @@ __device__ __forceinline__ void block_reduce_store(Acc &acc, AggPartial *out) {
 // ---------------------------------------------------------------------------------------------
 // streaming scan kernel
 // ---------------------------------------------------------------------------------------------
-template <int W, int NL, unsigned AGG, bool SEP, bool NT>
+// ANYF: at least one leaf column is a float (its values go through the IEEE order key);
+// integer-only instantiations carry no key code at all.
+template <int W, int NL, unsigned AGG, bool SEP, bool ANYF>
 __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     using U = typename WT<W>::U;
     constexpr int K = WT<W>::K;
@@ -236,8 +238,11 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     constexpr int RPL = 64 * K;                       // rows per wave-load
     constexpr int WAVE_ROWS = RPL * kUnroll;
     constexpr int TILE = WAVE_ROWS * kWavesPerBlock;
+    constexpr uint32_t QMASK = (K == 32) ? 0xffffffffu : ((1u << K) - 1u);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][WAVE_ROWS / 32];
 
     Acc acc;
     acc.init();
@@ -251,8 +256,11 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
         diff[l] = (U)a.leaf[l].diff;
         isf[l] = a.leaf[l].is_float != 0;
     }
-    const uint64_t tt = a.tt;
+    const uint32_t tt = (uint32_t)a.tt;  // <= 16 table entries for <= 4 leaves
+    // single leaf: q = in-range bits, then (q & m1) | (~q & m0) applies hit / negated / constant
+    const uint32_t m1 = (tt & 2u) ? QMASK : 0u, m0 = (tt & 1u) ? QMASK : 0u;
     const uint32_t flavor = a.agg_flavor;
+    const int qshift = K * (lane & (G - 1));
 
     for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;  // wave-uniform
@@ -272,41 +280,84 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
         for (int l = 0; l < NL; l++) {
             const u32x4 *p = (const u32x4 *)a.leaf[l].col + vec0;
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<NT>(p + u * 64);
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<true>(p + u * 64);
         }
         u32x4 ra[kUnroll];
         if constexpr (SEP && AGG != 0) {
             const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) ra[u] = ld16<NT>(p + u * 64);
+            for (int u = 0; u < kUnroll; u++) ra[u] = ld16<true>(p + u * 64);
         }
+        uint32_t q[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            uint32_t q = 0;
+            uint32_t qq = 0;
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                uint32_t idx = 0;
+                if constexpr (NL == 1) {
+                    U x = elem<W>(r[0][u], j);
+                    if constexpr (ANYF && W >= 4) x = fkey<W>(x);  // one leaf and ANYF: it is the float one
+                    qq |= ((((U)(x - lo[0])) & WT<W>::MASK) <= diff[0] ? 1u : 0u) << j;
+                } else {
+                    uint32_t idx = 0;
 #pragma unroll
-                for (int l = 0; l < NL; l++) {
-                    U x = elem<W>(r[l][u], j);
-                    if constexpr (W >= 4) x = isf[l] ? fkey<W>(x) : x;
-                    const uint32_t h = (((U)(x - lo[l])) & WT<W>::MASK) <= diff[l] ? 1u : 0u;
-                    idx |= h << l;
+                    for (int l = 0; l < NL; l++) {
+                        U x = elem<W>(r[l][u], j);
+                        if constexpr (ANYF && W >= 4) x = isf[l] ? fkey<W>(x) : x;
+                        idx |= ((((U)(x - lo[l])) & WT<W>::MASK) <= diff[l] ? 1u : 0u) << l;
+                    }
+                    qq |= ((tt >> idx) & 1u) << j;
                 }
-                q |= (uint32_t)((tt >> idx) & 1ull) << j;
             }
-            cnt32 += __builtin_popcount(q);
-            if (a.bits != nullptr) {
-                const uint32_t w = pack_word<K>(q, lane);
-                if ((lane & (G - 1)) == 0) a.bits[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] = w;
+            if constexpr (NL == 1) qq = (qq & m1) | (~qq & m0);
+            q[u] = qq;
+            cnt32 += __builtin_popcount(qq);
+        }
+        if (a.bits != nullptr) {
+            // assemble the 32-bit words (4 independent DPP chains), stage them in LDS so the wave's
+            // bitset leaves as ONE 16-byte-per-lane store
+            uint32_t w[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) w[u] = q[u] << qshift;
+            if constexpr (G >= 2) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0xB1>(w[u]);   // quad_perm [1,0,3,2]
             }
-            if constexpr (AGG != 0) {
+            if constexpr (G >= 4) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0x4E>(w[u]);   // quad_perm [2,3,0,1]
+            }
+            if constexpr (G >= 8) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0x141>(w[u]);  // row_half_mirror
+            }
+            if constexpr (G >= 16) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0x140>(w[u]);  // row_mirror
+            }
+            if ((lane & (G - 1)) == 0) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) stage[wave][u * (64 / G) + (lane / G)] = w[u];
+            }
+            // LDS ops of one wave execute in order: the read below sees the words written above
+            constexpr int NV = WAVE_ROWS / 128;  // 16-byte vectors of bitset per wave iteration
+            if (lane < NV) {
+                const u32x4 v = ((const u32x4 *)stage[wave])[lane];
+                u32x4 *dst = (u32x4 *)(a.bits + (row0 >> 5)) + lane;
+                // streaming (nt) store; debug bit0 = diagnostics build of the launch: words are
+                // assembled but never leave the CU (prices the HBM write traffic alone)
+                if (!(a.debug & 1u) || v.x == 0x12345678u) __builtin_nontemporal_store(v, dst);
+            }
+        }
+        if constexpr (AGG != 0) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                     U e;
                     if constexpr (SEP) e = elem<W>(ra[u], j); else e = elem<W>(r[0][u], j);
-                    acc_update<W, AGG>(acc, e, (q >> j) & 1u, rbase + j, flavor);
+                    acc_update<W, AGG>(acc, e, (q[u] >> j) & 1u, rbase + j, flavor);
                 }
             }
         }
@@ -470,8 +521,11 @@ __global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *part
 
 template <int W, int NL, unsigned AGG, bool SEP>
 static hipError_t scan_nt(hipStream_t s, int grid, int variant, const ScanArgs &a) {
-    if constexpr (W == 8) {
-        if (variant == 1) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true>), grid, a);
+    (void)variant;
+    bool anyf = false;
+    for (int l = 0; l < NL; l++) anyf = anyf || a.leaf[l].is_float != 0;
+    if constexpr (W >= 4) {
+        if (anyf) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true>), grid, a);
     }
     KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, false>), grid, a);
 }

@@ -264,5 +264,5 @@ def test_masked_reduce_matches_oracle(ctx):
             s, mean, cnt = O.exact_sum_f64(x.astype(np.float64), bits_h)
             assert _ulp_dist(float(K.agg_value(st, R.Sum)[0]), float(x.dtype.type(s))) <= 1
         st_all = ctx.reduce(col, None)
-        assert K.agg_value(st_all, R.Count)[0] == x.dtype.type(n) or x.dtype.itemsize < 8
+        assert st_all.count == n
         col.free(); m.free()

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into one small text summary that is
+committed under profiles/.  usage: prof_summary.py gpurun_out/prof_<tag> > profiles/<name>.txt"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def short(name):
+    name = name.replace("knox::", "")
+    return name[:90]
+
+
+print("# rocprofv3 summary of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (%s)" % os.path.basename(root))
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n## kernel stats (--kernel-trace --stats)")
+    print("%-92s %7s %12s %12s %8s" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
+    for r in csv.DictReader(open(f)):
+        print("%-92s %7s %12s %12s %8s" % (short(r["Name"]), r["Calls"], r["AverageNs"], r["TotalDurationNs"], r["Percentage"]))
+tj = os.path.join(root, "trace_bench.json")
+if os.path.exists(tj):
+    print("\n## bench line under the profiler\n" + open(tj).read().strip())
+for sub in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    if not os.path.isdir(sub):
+        continue
+    for f in glob.glob(os.path.join(sub, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print("\n## PMC pass %s (per-dispatch mean over dispatches)" % os.path.basename(sub))
+        for k, ctrs in agg.items():
+            if "scan_kernel" not in k and "popcount_seg" not in k:
+                continue
+            print(k)
+            for c, vals in sorted(ctrs.items()):
+                print("    %-24s n=%-4d mean=%.6g" % (c, len(vals), sum(vals) / len(vals)))
