@@ -184,6 +184,87 @@ __device__ __forceinline__ void acc_update(Acc &acc, typename WT<W>::U e, uint32
     }
 }
 
+// Wave-uniform bounds for the min/max fast path: a selected value can only become the wave's
+// min (max) if its order key is below (above) the best key any lane of the wave holds.
+struct WaveMM {
+    uint64_t smin, smax;
+    __device__ __forceinline__ void init() { smin = ~0ull; smax = 0ull; }
+};
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// One 16-byte load (K adjacent rows of this lane, selection bits q) into the accumulator.
+// Same results as K calls of acc_update, organised so the common case is cheap:
+//   * sums: error-free TwoSum per selected value (no branch; a non-finite running sum keeps an
+//     IEEE-correct `hi`, its `lo` is ignored by every consumer);
+//   * min/max: one compare pair per value against the WAVE-wide best keys; only when some lane
+//     beats them (O(log n) times per wave) does the exact per-value update run;
+//   * first/last: from the lowest / highest set bit of q, once per load.
+template <int W, unsigned AGG>
+__device__ __forceinline__ void acc_load(Acc &acc, WaveMM &wm, const u32x4 &r, uint32_t q, uint64_t rbase, uint32_t flavor) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    if constexpr ((AGG & A_ISUM) != 0) {
+#pragma unroll
+        for (int j = 0; j < K; j++) acc.isum += ((q >> j) & 1u) ? (uint64_t)elem<W>(r, j) : 0ull;
+    }
+    if constexpr ((AGG & A_FSUM) != 0) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            double x = to_f64<W>(elem<W>(r, j), flavor);
+            x = ((q >> j) & 1u) ? x : 0.0;
+            const double s = acc.hi + x;
+            const double bb = s - acc.hi;
+            acc.lo += (acc.hi - (s - bb)) + (x - bb);
+            acc.hi = s;
+        }
+    }
+    if constexpr ((AGG & A_MINMAX) != 0) {
+        const bool isf = flavor == FL_FLOAT;
+        const U xs = (flavor == FL_SIGNED) ? WT<W>::SIGN : (U)0;
+        bool trig = false;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const U e = elem<W>(r, j);
+            // raw order key (a -0 / NaN key may trigger spuriously; the exact path sorts it out)
+            const uint64_t key = isf ? (uint64_t)fkey<W>(e) : (uint64_t)(e ^ xs);
+            trig = trig || (((q >> j) & 1u) && (key < wm.smin || key > wm.smax));
+        }
+        if (__any(trig)) {
+#pragma unroll
+            for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r, j), (q >> j) & 1u, rbase + j, flavor);
+            wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
+            wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
+        }
+    }
+    if constexpr ((AGG & A_FIRSTLAST) != 0) {
+        if (q != 0) {
+            if (acc.firstrow == kNoRow) acc.firstrow = rbase + (uint64_t)__builtin_ctz(q);
+            acc.lastrow1 = rbase + (uint64_t)(32 - __builtin_clz(q));
+        }
+    }
+}
+
 __device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int off) {
     return (uint64_t)__shfl_down((unsigned long long)v, off, 64);
 }
@@ -246,6 +327,8 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
 
     Acc acc;
     acc.init();
+    WaveMM wm;
+    wm.init();
     uint32_t cnt32 = 0;
 
     U lo[NL], diff[NL];
@@ -353,12 +436,8 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                    U e;
-                    if constexpr (SEP) e = elem<W>(ra[u], j); else e = elem<W>(r[0][u], j);
-                    acc_update<W, AGG>(acc, e, (q[u] >> j) & 1u, rbase + j, flavor);
-                }
+                if constexpr (SEP) acc_load<W, AGG>(acc, wm, ra[u], q[u], rbase, flavor);
+                else acc_load<W, AGG>(acc, wm, r[0][u], q[u], rbase, flavor);
             }
         }
     }
@@ -380,6 +459,8 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
     const int wave = threadIdx.x >> 6;
     Acc acc;
     acc.init();
+    WaveMM wm;
+    wm.init();
     uint32_t cnt32 = 0;
     const uint32_t flavor = a.agg_flavor;
     for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -390,7 +471,7 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
         const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            ra[u] = ld16<false>(p + u * 64);
+            ra[u] = ld16<true>(p + u * 64);
             mw[u] = a.mask ? a.mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
         }
 #pragma unroll
@@ -398,8 +479,7 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
             const uint32_t q = (mw[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
             cnt32 += __builtin_popcount(q);
             const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
-#pragma unroll
-            for (int j = 0; j < K; j++) acc_update<W, AGG>(acc, elem<W>(ra[u], j), (q >> j) & 1u, rbase + j, flavor);
+            acc_load<W, AGG>(acc, wm, ra[u], q, rbase, flavor);
         }
     }
     acc.count = cnt32;

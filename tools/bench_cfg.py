@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Secondary configs of BASELINE.json (not the headline): steady-state kernel time + achieved GB/s.
+  cfg3: 2^30 float64 rows x 2 columns, `A >= 256 AND B < 0.5`, min/max/mean(A) + count
+  cfg4: 2^30 uint64 ids, per-pack bloom (factor 2) probe then EQ, count
+"""
+import argparse, ctypes as C, json, os, statistics, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf
+from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc as R
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cfg", type=int, default=3)
+ap.add_argument("--rows-log2", type=int, default=30)
+ap.add_argument("--steps", type=int, default=40)
+args = ap.parse_args()
+n, pack = 1 << args.rows_log2, 1 << 20
+ctx = K.Context(0)
+ctx.L.knox_prof_enable(ctx.h, 1)
+
+def timed(plan, bits, steps, pack_counts=True, skip=None):
+    ctx.scan_async(plan, bits_out=bits, pack_counts=pack_counts, pack_skip=skip)
+    for _ in range(steps - 1):
+        ctx.scan_async(plan, bits_out=bits, pack_counts=pack_counts, pack_skip=skip)
+        res = ctx.scan_collect(plan, n // pack if pack_counts else 0)
+    res = ctx.scan_collect(plan, n // pack if pack_counts else 0)
+    ms = (C.c_float * 512)(); k = C.c_int()
+    ctx.L.knox_prof_read_each(ctx.h, ms, 512, C.byref(k))
+    v = [ms[i] for i in range(k.value)]
+    return statistics.median(v[len(v) // 3:]), res
+
+if args.cfg == 3:
+    a = ctx.generate(BlockType.Float64, 1, 3, n, pack_rows=pack)
+    b = ctx.generate(BlockType.Float64, 2, 4, n, pack_rows=pack)
+    bits = ctx.bits(n)
+    tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
+    for name, aggs in (("count", [(R.Count, 0)]), ("min/max/mean", [(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Count, 0)])):
+        plan = ctx.plan(tree, [a, b], aggs=aggs)
+        ms, res = timed(plan, bits, args.steps)
+        gbs = n * 16.125 / ms / 1e6
+        vals = [res.value(i)[0] for i in range(len(aggs))]
+        print(json.dumps({"cfg": 3, "aggs": name, "kernel_ms": ms, "rows_per_s": n / ms * 1e3, "achieved_GBs": gbs,
+                          "frac_8TBs": gbs / 8000, "count": res.count, "values": [float(v) for v in vals]}))
+elif args.cfg == 4:
+    ids = ctx.generate(BlockType.Uint64, 0, 5, n, lo=0, span=0, pack_rows=pack)   # raw 64-bit ids
+    bits = ctx.bits(n)
+    t0 = time.perf_counter()
+    filters, offsets = ctx.bloom_build_u64(ids, 2, pack)
+    t_build = time.perf_counter() - t0
+    present = ids.download(777 * pack + 12345, 1)[0]
+    for name, key in (("present", present), ("absent", np.uint64(0x123456789ABCDEF))):
+        h = K.hash_value(BlockType.Uint64, key)
+        t0 = time.perf_counter()
+        maybe = ctx.bloom_probe(filters, offsets, h)
+        t_probe = time.perf_counter() - t0
+        plan = ctx.plan(And(Leaf(0, FilterMode.Equal, key)), [ids], aggs=[(R.Count, 0)])
+        ms_full, r_full = timed(plan, bits, args.steps)
+        ms_pruned, r_pruned = timed(plan, bits, args.steps, skip=(1 - maybe).astype(np.uint8))
+        scanned = int(maybe.sum())
+        print(json.dumps({"cfg": 4, "key": name, "packs_maybe": scanned, "packs": n // pack, "count_full": r_full.count,
+                          "count_pruned": r_pruned.count, "kernel_ms_full": ms_full, "kernel_ms_pruned": ms_pruned,
+                          "full_GBs": n * 8.125 / ms_full / 1e6, "pruned_GBs_over_scanned_packs": scanned * pack * 8.125 / ms_pruned / 1e6 if scanned else None,
+                          "effective_rows_per_s_incl_pruned": n / ms_pruned * 1e3, "bloom_build_s": t_build, "bloom_probe_s": t_probe,
+                          "filter_bytes": int(offsets[-1])}))
