@@ -24,6 +24,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
 tj = os.path.join(root, "trace_bench.json")
 if os.path.exists(tj):
     print("\n## bench line under the profiler\n" + open(tj).read().strip())
+traffic = {}
 for sub in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(sub):
         continue
@@ -38,3 +39,20 @@ for sub in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             print(k)
             for c, vals in sorted(ctrs.items()):
                 print("    %-24s n=%-4d mean=%.6g" % (c, len(vals), sum(vals) / len(vals)))
+                if "scan_kernel" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+                    traffic[c] = sum(vals) / len(vals)
+
+if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+    # half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for
+    # 16-B-per-lane streaming stores.
+    fetch_b = traffic["FETCH_SIZE"] * 1024 * 2
+    write_b = traffic["WRITE_SIZE"] * 1024
+    import json
+    t = {"kernel": "knox::scan_kernel<8,1,ISUM> (headline)", "FETCH_SIZE_KiB_raw": traffic["FETCH_SIZE"],
+         "WRITE_SIZE_KiB_raw": traffic["WRITE_SIZE"], "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b,
+         "hbm_bytes_per_launch": fetch_b + write_b, "source": os.path.basename(root),
+         "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM section)"}
+    print("\n## HBM traffic per launch of the headline kernel\n" + json.dumps(t))
+    if len(sys.argv) > 2:
+        json.dump(t, open(sys.argv[2], "w"), indent=1)
