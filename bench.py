@@ -65,14 +65,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # KNOX_BENCH_BACKEND=gloo is a rehearsal mode only (several ranks sharing one GPU on a 1-GPU box)
+    backend = os.environ.get("KNOX_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    local_rank = device_index
 
     import numpy as np
     import knoxdb_amd as K
@@ -102,7 +108,8 @@ def main():
     def collect():
         res = ctx.scan_collect(plan, n_packs)
         if dist is not None:
-            merged, total = kdist.allgather_states(res.states, res.count, device=torch.device("cuda", local_rank))
+            merged, total = kdist.allgather_states(res.states, res.count,
+                                                   device=torch.device("cuda", local_rank) if backend == "nccl" else None)
             return res, merged, total
         return res, res.states, res.count
 
@@ -134,7 +141,7 @@ def main():
     ctx.L.knox_prof_read(ctx.h, C.byref(kms), C.byref(kn))
     ctx.L.knox_prof_enable(ctx.h, 0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -160,7 +167,7 @@ def main():
         "whole_step_gb_per_s": n_rows * BYTES_PER_ROW / (elapsed / args.steps) / 1e9,
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr):
+    if os.path.exists(tr) and args.rows_log2 == 30:
         try:
             out["roofline"]["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
         except Exception:
