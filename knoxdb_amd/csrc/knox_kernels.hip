@@ -213,55 +213,112 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// One 16-byte load (K adjacent rows of this lane, selection bits q) into the accumulator.
-// Same results as K calls of acc_update, organised so the common case is cheap:
-//   * sums: error-free TwoSum per selected value (no branch; a non-finite running sum keeps an
-//     IEEE-correct `hi`, its `lo` is ignored by every consumer);
+// ---- compile-time value flavour helpers (FLV = FL_SIGNED / FL_UNSIGNED / FL_FLOAT) -------------
+template <int W, unsigned FLV> __device__ __forceinline__ double to_f64_c(typename WT<W>::U e) {
+    if constexpr (FLV == FL_FLOAT) {
+        if constexpr (W == 8) return __longlong_as_double((long long)e);
+        else return (double)__uint_as_float((uint32_t)e);
+    } else if constexpr (FLV == FL_SIGNED) {
+        if constexpr (W == 8) return (double)(int64_t)e;
+        else if constexpr (W == 4) return (double)(int32_t)e;
+        else if constexpr (W == 2) return (double)(int16_t)e;
+        else return (double)(int8_t)e;
+    } else {
+        if constexpr (W == 8) return (double)(uint64_t)e;
+        else return (double)(uint32_t)e;
+    }
+}
+// raw order key (floats: a -0 / NaN key may trigger the exact path spuriously, never miss it)
+template <int W, unsigned FLV> __device__ __forceinline__ uint64_t okey_raw(typename WT<W>::U e) {
+    if constexpr (FLV == FL_FLOAT) return (uint64_t)fkey<W>(e);
+    else if constexpr (FLV == FL_SIGNED) return (uint64_t)(e ^ WT<W>::SIGN);
+    else return (uint64_t)e;
+}
+
+// first / last selected row of a lane, tracked per wave iteration: the lane's result bits of
+// the kUnroll loads packed into one word + the iteration's first row; decoded once at the end.
+struct FirstLast {
+    uint64_t first_row0, last_row0, first_qq, last_qq;
+    __device__ __forceinline__ void init() { first_row0 = 0; last_row0 = 0; first_qq = 0; last_qq = 0; }
+    __device__ __forceinline__ void update(uint64_t row0, uint64_t qq) {
+        if (qq != 0) {
+            if (first_qq == 0) { first_qq = qq; first_row0 = row0; }
+            last_qq = qq;
+            last_row0 = row0;
+        }
+    }
+    template <int K> __device__ __forceinline__ void finish(Acc &acc, uint64_t row_base, int lane) const {
+        constexpr int RPL = 64 * K;
+        if (first_qq != 0) {
+            const int b = __builtin_ctzll(first_qq);
+            acc.firstrow = row_base + first_row0 + (uint64_t)(b / K) * RPL + (uint64_t)lane * K + (uint64_t)(b % K);
+        }
+        if (last_qq != 0) {
+            const int b = 63 - __builtin_clzll(last_qq);
+            acc.lastrow1 = row_base + last_row0 + (uint64_t)(b / K) * RPL + (uint64_t)lane * K + (uint64_t)(b % K) + 1;
+        }
+    }
+};
+
+// One wave iteration (kUnroll 16-byte loads of this lane, selection bits q[u]) into the
+// accumulator.  Same results as one acc_update per row, organised so the common case is cheap:
+//   * sums: error-free TwoSum per selected value, no branch (a non-finite running sum keeps an
+//     IEEE-correct `hi`; its `lo` is ignored by every consumer);
 //   * min/max: one compare pair per value against the WAVE-wide best keys; only when some lane
 //     beats them (O(log n) times per wave) does the exact per-value update run;
-//   * first/last: from the lowest / highest set bit of q, once per load.
-template <int W, unsigned AGG>
-__device__ __forceinline__ void acc_load(Acc &acc, WaveMM &wm, const u32x4 &r, uint32_t q, uint64_t rbase, uint32_t flavor) {
-    using U = typename WT<W>::U;
+//   * first/last: FirstLast::update once per iteration.
+template <int W, unsigned AGG, unsigned FLV>
+__device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, const u32x4 (&r)[kUnroll],
+                                         const uint32_t (&q)[kUnroll], uint64_t row0, uint64_t row_base, int lane) {
     constexpr int K = WT<W>::K;
+    constexpr int RPL = 64 * K;
     if constexpr ((AGG & A_ISUM) != 0) {
 #pragma unroll
-        for (int j = 0; j < K; j++) acc.isum += ((q >> j) & 1u) ? (uint64_t)elem<W>(r, j) : 0ull;
+        for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+            for (int j = 0; j < K; j++) acc.isum += ((q[u] >> j) & 1u) ? (uint64_t)elem<W>(r[u], j) : 0ull;
+        }
     }
     if constexpr ((AGG & A_FSUM) != 0) {
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-            double x = to_f64<W>(elem<W>(r, j), flavor);
-            x = ((q >> j) & 1u) ? x : 0.0;
-            const double s = acc.hi + x;
-            const double bb = s - acc.hi;
-            acc.lo += (acc.hi - (s - bb)) + (x - bb);
-            acc.hi = s;
+        for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                double x = to_f64_c<W, FLV>(elem<W>(r[u], j));
+                x = ((q[u] >> j) & 1u) ? x : 0.0;
+                const double s = acc.hi + x;
+                const double bb = s - acc.hi;
+                acc.lo += (acc.hi - (s - bb)) + (x - bb);
+                acc.hi = s;
+            }
         }
     }
     if constexpr ((AGG & A_MINMAX) != 0) {
-        const bool isf = flavor == FL_FLOAT;
-        const U xs = (flavor == FL_SIGNED) ? WT<W>::SIGN : (U)0;
         bool trig = false;
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-            const U e = elem<W>(r, j);
-            // raw order key (a -0 / NaN key may trigger spuriously; the exact path sorts it out)
-            const uint64_t key = isf ? (uint64_t)fkey<W>(e) : (uint64_t)(e ^ xs);
-            trig = trig || (((q >> j) & 1u) && (key < wm.smin || key > wm.smax));
+        for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const uint64_t key = okey_raw<W, FLV>(elem<W>(r[u], j));
+                trig = trig || (((q[u] >> j) & 1u) && (key < wm.smin || key > wm.smax));
+            }
         }
         if (__any(trig)) {
+#pragma unroll 1
+            for (int u = 0; u < kUnroll; u++) {
+                const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
 #pragma unroll
-            for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r, j), (q >> j) & 1u, rbase + j, flavor);
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+            }
             wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
             wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
         }
     }
     if constexpr ((AGG & A_FIRSTLAST) != 0) {
-        if (q != 0) {
-            if (acc.firstrow == kNoRow) acc.firstrow = rbase + (uint64_t)__builtin_ctz(q);
-            acc.lastrow1 = rbase + (uint64_t)(32 - __builtin_clz(q));
-        }
+        uint64_t qq = 0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) qq |= (uint64_t)q[u] << (u * K);
+        fl.update(row0, qq);
     }
 }
 
@@ -311,7 +368,7 @@ __device__ __forceinline__ void block_reduce_store(Acc &acc, AggPartial *out) {
 // ---------------------------------------------------------------------------------------------
 // ANYF: at least one leaf column is a float (its values go through the IEEE order key);
 // integer-only instantiations carry no key code at all.
-template <int W, int NL, unsigned AGG, bool SEP, bool ANYF>
+template <int W, int NL, unsigned AGG, bool SEP, bool ANYF, unsigned FLV>
 __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     using U = typename WT<W>::U;
     constexpr int K = WT<W>::K;
@@ -329,6 +386,8 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     acc.init();
     WaveMM wm;
     wm.init();
+    FirstLast fl;
+    fl.init();
     uint32_t cnt32 = 0;
 
     U lo[NL], diff[NL];
@@ -342,7 +401,6 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     const uint32_t tt = (uint32_t)a.tt;  // <= 16 table entries for <= 4 leaves
     // single leaf: q = in-range bits, then (q & m1) | (~q & m0) applies hit / negated / constant
     const uint32_t m1 = (tt & 2u) ? QMASK : 0u, m0 = (tt & 1u) ? QMASK : 0u;
-    const uint32_t flavor = a.agg_flavor;
     const int qshift = K * (lane & (G - 1));
 
     for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -433,22 +491,19 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             }
         }
         if constexpr (AGG != 0) {
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
-                if constexpr (SEP) acc_load<W, AGG>(acc, wm, ra[u], q[u], rbase, flavor);
-                else acc_load<W, AGG>(acc, wm, r[0][u], q[u], rbase, flavor);
-            }
+            if constexpr (SEP) agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
+            else agg_iter<W, AGG, FLV>(acc, wm, fl, r[0], q, row0, a.row_base, lane);
         }
     }
     acc.count = cnt32;
+    if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
     block_reduce_store(acc, a.partials + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
 // masked reduce kernel: selection comes from an existing bitset (or all rows)
 // ---------------------------------------------------------------------------------------------
-template <int W, unsigned AGG>
+template <int W, unsigned AGG, unsigned FLV>
 __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
     constexpr int K = WT<W>::K;
     constexpr int G = 32 / K;
@@ -461,28 +516,29 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
     acc.init();
     WaveMM wm;
     wm.init();
+    FirstLast fl;
+    fl.init();
     uint32_t cnt32 = 0;
-    const uint32_t flavor = a.agg_flavor;
     for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;
         const uint64_t vec0 = row0 / K + lane;
         u32x4 ra[kUnroll];
-        uint32_t mw[kUnroll];
+        uint32_t q[kUnroll];
         const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             ra[u] = ld16<true>(p + u * 64);
-            mw[u] = a.mask ? a.mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+            q[u] = a.mask ? a.mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            const uint32_t q = (mw[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
-            cnt32 += __builtin_popcount(q);
-            const uint64_t rbase = a.row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
-            acc_load<W, AGG>(acc, wm, ra[u], q, rbase, flavor);
+            q[u] = (q[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+            cnt32 += __builtin_popcount(q[u]);
         }
+        agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
     }
     acc.count = cnt32;
+    if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
     block_reduce_store(acc, a.partials + blockIdx.x);
 }
 
@@ -599,27 +655,35 @@ __global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *part
         return hipGetLastError();                                                              \
     } while (0)
 
-template <int W, int NL, unsigned AGG, bool SEP>
-static hipError_t scan_nt(hipStream_t s, int grid, int variant, const ScanArgs &a) {
-    (void)variant;
+template <int W, int NL, unsigned AGG, bool SEP, unsigned FLV>
+static hipError_t scan_anyf(hipStream_t s, int grid, const ScanArgs &a) {
     bool anyf = false;
     for (int l = 0; l < NL; l++) anyf = anyf || a.leaf[l].is_float != 0;
     if constexpr (W >= 4) {
-        if (anyf) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true>), grid, a);
+        if (anyf) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true, FLV>), grid, a);
     }
-    KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, false>), grid, a);
+    KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, false, FLV>), grid, a);
+}
+
+template <int W, int NL, unsigned AGG, unsigned FLV>
+static hipError_t scan_sep(hipStream_t s, bool sep, int grid, const ScanArgs &a) {
+    return sep ? scan_anyf<W, NL, AGG, true, FLV>(s, grid, a) : scan_anyf<W, NL, AGG, false, FLV>(s, grid, a);
 }
 
 template <int W, int NL>
 static hipError_t scan_agg(hipStream_t s, unsigned agg, bool sep, int grid, int variant, const ScanArgs &a) {
-    // aggregate classes instantiated: none | isum | float-full | all
-    if (agg == 0) return scan_nt<W, NL, 0, false>(s, grid, variant, a);
-    if (agg == A_ISUM) return sep ? scan_nt<W, NL, A_ISUM, true>(s, grid, variant, a) : scan_nt<W, NL, A_ISUM, false>(s, grid, variant, a);
-    if ((agg & A_ISUM) == 0) {
-        constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
-        return sep ? scan_nt<W, NL, FF, true>(s, grid, variant, a) : scan_nt<W, NL, FF, false>(s, grid, variant, a);
+    (void)variant;
+    // aggregate classes instantiated: none | isum | full-without-isum (per flavour) | all (ints)
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if (agg == 0) return scan_anyf<W, NL, 0, false, FL_SIGNED>(s, grid, a);
+    if (agg == A_ISUM) return scan_sep<W, NL, A_ISUM, FL_SIGNED>(s, sep, grid, a);
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) return scan_sep<W, NL, FF, FL_FLOAT>(s, sep, grid, a);
     }
-    return sep ? scan_nt<W, NL, A_ALL, true>(s, grid, variant, a) : scan_nt<W, NL, A_ALL, false>(s, grid, variant, a);
+    if ((agg & A_ISUM) == 0) {
+        return a.agg_flavor == FL_SIGNED ? scan_sep<W, NL, FF, FL_SIGNED>(s, sep, grid, a) : scan_sep<W, NL, FF, FL_UNSIGNED>(s, sep, grid, a);
+    }
+    return a.agg_flavor == FL_SIGNED ? scan_sep<W, NL, A_ALL, FL_SIGNED>(s, sep, grid, a) : scan_sep<W, NL, A_ALL, FL_UNSIGNED>(s, sep, grid, a);
 }
 
 template <int W>
@@ -657,10 +721,21 @@ hipError_t launch_scan_tail(hipStream_t s, int width, int n_leaves, unsigned agg
 }
 
 template <int W> static hipError_t reduce_w(hipStream_t s, unsigned agg, int grid, const ScanArgs &a) {
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
     hipError_t e = hipSuccess;
     if (grid > 0) {
-        if ((agg & ~A_ISUM) == 0) hipLaunchKernelGGL((reduce_kernel<W, A_ISUM>), dim3(grid), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((reduce_kernel<W, A_ALL>), dim3(grid), dim3(kBlock), 0, s, a);
+        bool done = false;
+        if constexpr (W >= 4) {
+            if (a.agg_flavor == FL_FLOAT) {
+                hipLaunchKernelGGL((reduce_kernel<W, FF, FL_FLOAT>), dim3(grid), dim3(kBlock), 0, s, a);
+                done = true;
+            }
+        }
+        if (!done) {
+            if ((agg & ~A_ISUM) == 0) hipLaunchKernelGGL((reduce_kernel<W, A_ISUM, FL_SIGNED>), dim3(grid), dim3(kBlock), 0, s, a);
+            else if (a.agg_flavor == FL_SIGNED) hipLaunchKernelGGL((reduce_kernel<W, A_ALL, FL_SIGNED>), dim3(grid), dim3(kBlock), 0, s, a);
+            else hipLaunchKernelGGL((reduce_kernel<W, A_ALL, FL_UNSIGNED>), dim3(grid), dim3(kBlock), 0, s, a);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
