@@ -87,7 +87,8 @@ void *knox_ctx_stream(knox_ctx *ctx); /* hipStream_t */
 /* HIP-event stopwatch on the ctx stream (for achieved-GB/s measurement).                 */
 int knox_timer_start(knox_ctx *ctx);
 int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms      */
-/* Tuning knobs (0 keeps the default): workgroups per CU of the streaming kernels.        */
+/* Tuning knobs: workgroups per CU of the streaming kernels (0 = auto, <0 keeps the current
+ * value); variant: 1 = default, 2 = diagnostics (bitset assembled, never stored), <0 keeps.  */
 int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
 /* Per-kernel stopwatch: while enabled, every launch of the dominant streaming kernel
  * (scan / reduce) is bracketed by HIP events on the ctx stream; knox_prof_read syncs, returns
@@ -240,18 +241,26 @@ int knox_agg_value(const knox_agg_state *state, int func, void *value_out, int *
 int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out);
 
 /* ---- bloom pre-filter: internal/filter/bloom/bloom.go:136-150,182 -------------------- *
- * filters: n_packs serialized filters [k][m/8 bytes] concatenated; offsets[n_packs+1] gives
- * each filter's byte range (offsets[p]==offsets[p+1]: pack has no filter -> maybe).
- * maybe_out[p] = 1 if pack p may contain hash h (Contains), else 0.                          */
-int knox_bloom_probe(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs,
-                     uint64_t h, uint8_t *maybe_out);
+ * A knox_bloom holds the per-pack filters of one column resident on the device: n_packs
+ * serialized filters [k][m/8 bytes] (bloom.go:48-60,83-101) concatenated, offsets[n_packs+1]
+ * giving each filter's byte range (offsets[p] == offsets[p+1]: pack has no filter -> maybe).  */
+typedef struct knox_bloom knox_bloom;
+int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs,
+                      knox_bloom **out);
+/* Build the per-pack filters on the device for an 8-byte column: xxh3_u64 of the raw value
+ * bits, k = 4, m = pow2(pack_rows * factor * 8) bits (pack/stats/filter.go:296-360; factor =
+ * FilterType.Factor(), bytes per value).  Sets up config 4.                                 */
+int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out);
+size_t knox_bloom_packs(const knox_bloom *b);
+size_t knox_bloom_bytes(const knox_bloom *b);
+int knox_bloom_download(knox_ctx *ctx, const knox_bloom *b, uint8_t *filters, size_t filters_cap,
+                        uint64_t *offsets /* n_packs+1 */);
+/* Filter.Contains(h) for every pack: maybe_out[p] = 1 if pack p may contain hash h.          */
+int knox_bloom_probe(knox_ctx *ctx, const knox_bloom *b, uint64_t h, uint8_t *maybe_out);
+int knox_bloom_free(knox_bloom *b);
 /* hash.HashT for fixed-width values (internal/hash/hash.go:67-92, xxh3.go:22-58): the hash a
  * numeric Equal matcher probes with (match_num.go:339-346).  Float types hash their bytes.   */
 uint64_t knox_hash_value(int dtype, const void *val);
-/* Build per-pack bloom filters on the device for an 8-byte column (xxh3_u64 of the raw bits,
- * pack/stats/filter.go:296-360) -- used to set up config 4; factor = bytes per value.        */
-int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, uint8_t *filters_out,
-                         size_t filters_cap, uint64_t *offsets_out /* n_packs+1 */);
 
 /* ---- multi-GPU: final aggregate only ------------------------------------------------- *
  * One process per GPU.  Rank 0 creates an id, every rank receives it out of band (the host's

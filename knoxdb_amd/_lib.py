@@ -104,9 +104,14 @@ SIGNATURES = {
     "knox_reduce_sequential": (_i, [_vp, _vp, _vp, _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_value": (_i, [C.POINTER(AggState), _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_combine": (_i, [C.POINTER(AggState), _i, C.POINTER(AggState)]),
-    "knox_bloom_probe": (_i, [_vp, _vp, _vp, _sz, _u64, _vp]),
+    "knox_bloom_upload": (_i, [_vp, _vp, _vp, _sz, _pp]),
+    "knox_bloom_build_u64": (_i, [_vp, _vp, _i, _pp]),
+    "knox_bloom_packs": (_sz, [_vp]),
+    "knox_bloom_bytes": (_sz, [_vp]),
+    "knox_bloom_download": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "knox_bloom_probe": (_i, [_vp, _vp, _u64, _vp]),
+    "knox_bloom_free": (_i, [_vp]),
     "knox_hash_value": (_u64, [_i, _vp]),
-    "knox_bloom_build_u64": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "knox_comm_unique_id": (_i, [_vp]),
     "knox_comm_init": (_i, [_vp, _i, _i, _vp]),
     "knox_comm_allgather_states": (_i, [_vp, C.POINTER(AggState), _i, C.POINTER(AggState), C.POINTER(_i64)]),

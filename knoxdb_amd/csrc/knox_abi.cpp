@@ -43,7 +43,8 @@ struct knox_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_hip = 0;
     int n_cus = 256;
-    int blocks_per_cu = 2;  // 2 x 256 threads per CU measured fastest for pure streaming (profiles/r01_sweep.txt)
+    int blocks_per_cu = 0;  // 0 = auto: 2 workgroups/CU for pure streaming passes, 3 when the pass carries
+                            // float/min-max aggregates or several leaves (profiles/r01_sweep_blocks_per_cu.txt)
     int variant = 1;  // 1 = non-temporal streaming loads/stores (default), 0 = plain (8-byte types only)
     // staging ring (pinned) for host -> HBM uploads
     static constexpr size_t kStageBytes = 32u << 20;
@@ -295,7 +296,7 @@ KNOX_API int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms) {
 
 KNOX_API int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant) {
     if (!ctx) return KNOX_E_INVALID;
-    if (blocks_per_cu > 0) ctx->blocks_per_cu = blocks_per_cu;
+    if (blocks_per_cu >= 0) ctx->blocks_per_cu = blocks_per_cu;
     if (variant >= 0) ctx->variant = variant;
     return KNOX_OK;
 }
@@ -827,10 +828,22 @@ static uint32_t pack_shift_for(size_t pack_rows, int width) {
     return s;
 }
 
+// Packs pruned by the caller's statistics.  d_skip: one byte per pack (tail kernel); d_live: the
+// compact list of surviving packs the streaming kernel walks; h_skip: the caller's array (only
+// read before the call returns) for zeroing the pruned bitset ranges.
+struct SkipPlan {
+    const uint8_t *d_skip = nullptr;
+    const uint32_t *d_live = nullptr;
+    uint32_t n_live = 0;
+    const uint8_t *h_skip = nullptr;
+    size_t n_packs = 0;
+    bool used = false;  // out: the streaming kernel really skipped the pruned packs
+};
+
 // single fused pass: leaves (same width) + optional aggregate column, into partial slot `slot`
 static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_col *const *lcols, int n_leaves, uint64_t tt,
                      const knox_col *agg_col, unsigned agg, size_t n_rows, size_t pack_rows, uint64_t row_base,
-                     const uint8_t *d_skip, uint32_t *bits, int slot, int grid, int dtype_for_state) {
+                     SkipPlan *skip, uint32_t *bits, int slot, int grid, int dtype_for_state) {
     ScanArgs a;
     memset(&a, 0, sizeof a);
     for (int l = 0; l < n_leaves; l++) {
@@ -849,13 +862,48 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     const uint64_t tr = (uint64_t)tile_rows(width);
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;
+    a.tail_first_row = a.n_tiles * tr;
     a.row_base = row_base;
     a.bits = bits;
-    a.pack_skip = d_skip;
-    a.pack_shift = d_skip ? pack_shift_for(pack_rows, width) : 255;
+    if (skip && skip->d_skip) {
+        a.pack_skip = skip->d_skip;
+        a.pack_shift = pack_shift_for(pack_rows, width);
+        const bool pow2 = pack_rows && !(pack_rows & (pack_rows - 1));
+        if (skip->d_live && pow2 && pack_rows >= tr && n_rows % pack_rows == 0) {
+            // compact mode: walk only the surviving packs; zero the pruned ranges of the bitset
+            uint32_t sh = 0;
+            while (((uint64_t)tr << sh) < pack_rows) sh++;
+            a.live_packs = skip->d_live;
+            a.tpp_shift = sh;
+            a.n_tiles = (uint64_t)skip->n_live << sh;
+            skip->used = true;
+            if (bits) {
+                size_t runs = 0;
+                for (size_t p = 0; p < skip->n_packs; p++)
+                    if (skip->h_skip[p] && (p == 0 || !skip->h_skip[p - 1])) runs++;
+                const size_t pack_bytes = pack_rows >> 3;
+                if (runs > 16) {
+                    HIPCHK(ctx, hipMemsetAsync(bits, 0, skip->n_packs * pack_bytes, ctx->stream));
+                } else {
+                    for (size_t p = 0; p < skip->n_packs;) {
+                        if (!skip->h_skip[p]) { p++; continue; }
+                        size_t e = p;
+                        while (e < skip->n_packs && skip->h_skip[e]) e++;
+                        HIPCHK(ctx, hipMemsetAsync((uint8_t *)bits + p * pack_bytes, 0, (e - p) * pack_bytes, ctx->stream));
+                        p = e;
+                    }
+                }
+            }
+        }
+    } else {
+        a.pack_shift = 255;
+    }
     a.debug = ctx->variant == 2 ? 1u : 0u;  // variant 2: diagnostics, bitset assembled but not stored
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
-    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
+    // auto occupancy: the pure streaming passes run best at 2 workgroups per CU, VALU-heavier ones at 3
+    const bool heavy = n_leaves > 1 || (agg_col && (agg & ~A_ISUM) != 0);
+    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (heavy ? 3 : 2);
+    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
     if (slot != 15) prof_mark(ctx, 0);
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, ctx->variant, a);
     if (slot != 15) prof_mark(ctx, 1);
@@ -879,6 +927,7 @@ static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, 
     const uint64_t tr = (uint64_t)tile_rows(col->width);
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;
+    a.tail_first_row = a.n_tiles * tr;
     a.row_base = row_base;
     a.mask = mask;
     a.pack_shift = 255;
@@ -896,8 +945,7 @@ static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, 
 }
 
 // one leaf -> its own bitset (multi-pass plan)
-static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *col, size_t n_rows, uint64_t *bits, const uint8_t *d_skip,
-                            int grid) {
+static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *col, size_t n_rows, uint64_t *bits, int grid) {
     if (col->dtype == KNOX_BYTES) {
         if (p.op != KNOX_EQ && p.op != KNOX_NE) return KNOX_E_UNSUPPORTED;
         if (p.val_len > 0xffffffffull || (p.val_len && !p.val)) return KNOX_E_INVALID;
@@ -921,7 +969,9 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
     const uint64_t tt = lh.neg ? 0x1ull : 0x2ull;
     const knox_col *lc[1] = {col};
     // slot 15 is a throw-away partial slot for intermediate leaves
-    return run_fused(ctx, col->width, &lh, lc, 1, tt, nullptr, 0, n_rows, col->pack_rows, 0, d_skip, (uint32_t *)bits, 15, grid, col->dtype);
+    // pruned packs cannot contain matches of the whole tree, but a single leaf of it may match there:
+    // leaves are evaluated everywhere, the result is identical (pruning is an optimisation only)
+    return run_fused(ctx, col->width, &lh, lc, 1, tt, nullptr, 0, n_rows, col->pack_rows, 0, nullptr, (uint32_t *)bits, 15, grid, col->dtype);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -993,23 +1043,34 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     slot.n_aggs = n_aggs;
 
     // ---- workspace
-    const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 3));
     int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->states.p, 0, sizeof(AggStateDev) * 16 + 8 * 16, ctx->stream));
-    const uint8_t *d_skip = nullptr;
-    uint64_t rows_scanned = n_rows;
+    SkipPlan skip;
+    uint64_t rows_pruned = 0;
     if (pack_skip && n_packs) {
-        rc = ensure(ctx, ctx->pack_skip, n_packs + 16);
+        std::vector<uint32_t> live;
+        live.reserve(n_packs);
+        for (size_t p = 0; p < n_packs; p++) {
+            if (pack_skip[p]) rows_pruned += std::min(pack_rows, n_rows - p * pack_rows);
+            else live.push_back((uint32_t)p);
+        }
+        const size_t live_off = (n_packs + 15) & ~(size_t)15;
+        rc = ensure(ctx, ctx->pack_skip, live_off + live.size() * 4 + 16);
         if (rc) return rc;
         HIPCHK(ctx, hipMemcpyAsync(ctx->pack_skip.p, pack_skip, n_packs, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host array not retained
-        d_skip = (const uint8_t *)ctx->pack_skip.p;
-        for (size_t p = 0; p < n_packs; p++)
-            if (pack_skip[p]) rows_scanned -= std::min(pack_rows, n_rows - p * pack_rows);
+        if (!live.empty())
+            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->pack_skip.p + live_off, live.data(), live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are not retained
+        skip.d_skip = (const uint8_t *)ctx->pack_skip.p;
+        skip.d_live = (const uint32_t *)((const char *)ctx->pack_skip.p + live_off);
+        skip.n_live = (uint32_t)live.size();
+        skip.h_skip = pack_skip;
+        skip.n_packs = n_packs;
     }
-    slot.rows_scanned = rows_scanned;
+    slot.rows_scanned = n_rows;
 
     // ---- can the whole tree run as one fused pass?
     bool fused = n_leaves <= kMaxLeaves;
@@ -1069,9 +1130,10 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         uint64_t tt;
         rc = make_truth_table(nodes, n_nodes, lof, neg, n_leaves, tt);
         if (rc) return rc;
-        rc = run_fused(ctx, width, lh, lc, n_leaves, tt, ac, acls, n_rows, pack_rows, row_base, d_skip, (uint32_t *)bits, 0, grid,
-                       ac ? ac->dtype : lc[0]->dtype);
+        rc = run_fused(ctx, width, lh, lc, n_leaves, tt, ac, acls, n_rows, pack_rows, row_base, pack_skip ? &skip : nullptr, (uint32_t *)bits, 0,
+                       grid, ac ? ac->dtype : lc[0]->dtype);
         if (rc) return rc;
+        if (skip.used) slot.rows_scanned = n_rows - rows_pruned;
     } else {
         // multi-pass plan: each leaf into a scratch bitset, postfix combine with the bitset
         // kernels (exactly the reference's MatchAnd / MatchOr data flow, match_core.go:45-215)
@@ -1090,7 +1152,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                 if (sp >= 7) return KNOX_E_UNSUPPORTED;
                 uint64_t *dst = slot_ptr(sp);
                 HIPCHK(ctx, hipMemsetAsync(dst, 0, bits_padded(n_rows) + 8, ctx->stream));
-                rc = run_leaf_to_bits(ctx, p, cols[p.col], n_rows, dst, d_skip, grid);
+                rc = run_leaf_to_bits(ctx, p, cols[p.col], n_rows, dst, grid);
                 if (rc) return rc;
                 sp++;
             } else {
@@ -1197,7 +1259,7 @@ KNOX_API int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, siz
     if (rc) return rc;
     rc = ensure(ctx, ctx->tmp_vals, n * (size_t)w + 512);
     if (!rc) rc = ensure(ctx, ctx->tmp_bits, (bits_padded(n) + 64) * 8);
-    const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 3));
     if (!rc) rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
@@ -1224,7 +1286,7 @@ KNOX_API int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *ma
     if (!ctx || !col || !state || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;
     if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
-    const int grid = std::max(1, ctx->n_cus * ctx->blocks_per_cu);
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 3));
     int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
@@ -1412,60 +1474,119 @@ KNOX_API uint64_t knox_hash_value(int dtype, const void *val) {
     }
 }
 
-KNOX_API int knox_bloom_probe(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs, uint64_t h, uint8_t *maybe_out) {
-    if (!ctx || !offsets || !maybe_out || (n_packs && offsets[n_packs] && !filters)) return KNOX_E_INVALID;
-    if (n_packs == 0) return KNOX_OK;
-    hipSetDevice(ctx->device);
+struct knox_bloom {
+    knox_ctx *ctx;
+    uint8_t *d_filters = nullptr;
+    uint64_t *d_offsets = nullptr;
+    uint8_t *d_maybe = nullptr;
+    size_t n_packs = 0, bytes = 0;
+    std::vector<uint64_t> h_offsets;
+};
+
+static int bloom_alloc(knox_ctx *ctx, const uint64_t *offsets, size_t n_packs, knox_bloom **out) {
+    *out = nullptr;
     for (size_t p = 0; p < n_packs; p++) {
         if (offsets[p + 1] < offsets[p]) return KNOX_E_INVALID;
         const uint64_t len = offsets[p + 1] - offsets[p];
         if (len > 1 && ((len - 1) & (len - 2)) != 0) return KNOX_E_INVALID;  // m must be a power of two (bloom.go:83-101)
     }
-    const size_t fbytes = (size_t)offsets[n_packs];
-    const size_t total = fbytes + 16 + (n_packs + 1) * 8 + n_packs + 64;
-    int rc = ensure(ctx, ctx->tmp_vals, total);
-    if (rc) return rc;
-    uint8_t *d_f = (uint8_t *)ctx->tmp_vals.p;
-    uint64_t *d_o = (uint64_t *)(d_f + ((fbytes + 15) & ~(size_t)15));
-    uint8_t *d_m = (uint8_t *)(d_o + n_packs + 1);
-    rc = upload(ctx, d_f, filters, fbytes);
-    if (!rc) rc = upload(ctx, d_o, offsets, (n_packs + 1) * 8);
-    if (rc) return rc;
-    hipError_t e = launch_bloom_probe(ctx->stream, d_f, d_o, n_packs, h, d_m);
-    if (e != hipSuccess) {
-        ctx->last_hip = (int)e;
-        return KNOX_E_HIP;
+    knox_bloom *b = new (std::nothrow) knox_bloom();
+    if (!b) return KNOX_E_NOMEM;
+    b->ctx = ctx;
+    b->n_packs = n_packs;
+    b->bytes = (size_t)offsets[n_packs];
+    b->h_offsets.assign(offsets, offsets + n_packs + 1);
+    if (hipMalloc((void **)&b->d_filters, b->bytes + 64) != hipSuccess || hipMalloc((void **)&b->d_offsets, (n_packs + 1) * 8 + 64) != hipSuccess ||
+        hipMalloc((void **)&b->d_maybe, n_packs + 64) != hipSuccess) {
+        if (b->d_filters) hipFree(b->d_filters);
+        if (b->d_offsets) hipFree(b->d_offsets);
+        delete b;
+        return KNOX_E_NOMEM;
     }
-    return download(ctx, maybe_out, d_m, n_packs);
+    int rc = upload(ctx, b->d_offsets, offsets, (n_packs + 1) * 8);
+    if (rc) {
+        knox_bloom_free(b);
+        return rc;
+    }
+    *out = b;
+    return KNOX_OK;
 }
 
-KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, uint8_t *filters_out, size_t filters_cap, uint64_t *offsets_out) {
-    if (!ctx || !col || col->width != 8 || col->dtype == KNOX_BYTES || factor <= 0 || !offsets_out) return KNOX_E_INVALID;
+KNOX_API int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs, knox_bloom **out) {
+    if (!ctx || !offsets || !out || (n_packs && offsets[n_packs] && !filters)) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
-    const size_t n_packs = col->pack_rows ? (col->n_rows + col->pack_rows - 1) / col->pack_rows : 0;
+    int rc = bloom_alloc(ctx, offsets, n_packs, out);
+    if (rc) return rc;
+    rc = upload(ctx, (*out)->d_filters, filters, (*out)->bytes);
+    if (rc) {
+        knox_bloom_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out) {
+    if (!ctx || !col || !out || col->width != 8 || col->dtype == KNOX_BYTES || factor <= 0 || col->pack_rows == 0) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    const size_t n_packs = (col->n_rows + col->pack_rows - 1) / col->pack_rows;
+    std::vector<uint64_t> offsets(n_packs + 1);
     uint64_t off = 0;
     for (size_t p = 0; p < n_packs; p++) {
         const size_t rows = std::min(col->pack_rows, col->n_rows - p * col->pack_rows);
         uint64_t m = 8;  // bloom.go:242-249 pow2: next power of two >= cardinality*factor*8 bits
         while (m < (uint64_t)rows * (uint64_t)factor * 8) m <<= 1;
-        offsets_out[p] = off;
+        offsets[p] = off;
         off += 1 + (m >> 3);
     }
-    offsets_out[n_packs] = off;
-    if (off > filters_cap || (off && !filters_out)) return KNOX_E_RANGE;
-    int rc = ensure(ctx, ctx->tmp_vals, (size_t)off + 16 + (n_packs + 1) * 8 + 64);
+    offsets[n_packs] = off;
+    int rc = bloom_alloc(ctx, offsets.data(), n_packs, out);
     if (rc) return rc;
-    uint8_t *d_f = (uint8_t *)ctx->tmp_vals.p;
-    uint64_t *d_o = (uint64_t *)(d_f + (((size_t)off + 15) & ~(size_t)15));
-    HIPCHK(ctx, hipMemsetAsync(d_f, 0, ((size_t)off + 15) & ~(size_t)15, ctx->stream));
-    rc = upload(ctx, d_o, offsets_out, (n_packs + 1) * 8);
-    if (rc) return rc;
-    hipError_t e = launch_bloom_build_u64(ctx->stream, (const uint64_t *)col->dev, col->n_rows, col->pack_rows, d_f, d_o);
+    knox_bloom *b = *out;
+    hipError_t e = hipMemsetAsync(b->d_filters, 0, b->bytes, ctx->stream);
+    if (e == hipSuccess) e = launch_bloom_build_u64(ctx->stream, (const uint64_t *)col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        knox_bloom_free(b);
+        *out = nullptr;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
+KNOX_API size_t knox_bloom_packs(const knox_bloom *b) { return b ? b->n_packs : 0; }
+KNOX_API size_t knox_bloom_bytes(const knox_bloom *b) { return b ? b->bytes : 0; }
+
+KNOX_API int knox_bloom_download(knox_ctx *ctx, const knox_bloom *b, uint8_t *filters, size_t filters_cap, uint64_t *offsets) {
+    if (!ctx || !b || !offsets || (b->bytes && !filters)) return KNOX_E_INVALID;
+    if (filters_cap < b->bytes) return KNOX_E_RANGE;
+    hipSetDevice(ctx->device);
+    memcpy(offsets, b->h_offsets.data(), (b->n_packs + 1) * 8);
+    return download(ctx, filters, b->d_filters, b->bytes);
+}
+
+KNOX_API int knox_bloom_probe(knox_ctx *ctx, const knox_bloom *b, uint64_t h, uint8_t *maybe_out) {
+    if (!ctx || !b || (b->n_packs && !maybe_out)) return KNOX_E_INVALID;
+    if (b->n_packs == 0) return KNOX_OK;
+    hipSetDevice(ctx->device);
+    hipError_t e = launch_bloom_probe(ctx->stream, b->d_filters, b->d_offsets, b->n_packs, h, b->d_maybe);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         return KNOX_E_HIP;
     }
-    return download(ctx, filters_out, d_f, (size_t)off);
+    HIPCHK(ctx, hipMemcpyAsync(maybe_out, b->d_maybe, b->n_packs, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bloom_free(knox_bloom *b) {
+    if (!b) return KNOX_E_INVALID;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    if (b->d_filters) hipFree(b->d_filters);
+    if (b->d_offsets) hipFree(b->d_offsets);
+    if (b->d_maybe) hipFree(b->d_maybe);
+    delete b;
+    return KNOX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -41,10 +41,13 @@ struct ScanArgs {
     uint64_t tt;            // truth table over the leaf hit bits (bit index = sum hit_l << l)
     const void *agg_col;    // aggregated column (may alias leaf[0].col)
     uint32_t agg_flavor;
-    uint32_t pack_shift;    // log2(pack_rows), or 255: no per-pack skipping
+    uint32_t pack_shift;    // log2(pack_rows), or 255: no per-pack skipping (tail kernel only)
     const uint8_t *pack_skip;
+    const uint32_t *live_packs;  // streaming kernel: compact list of packs to scan (nullable = all)
+    uint32_t tpp_shift;          // log2(tiles per pack) when live_packs is set
     uint64_t n_tiles;       // full tiles handled by the streaming kernel
-    uint64_t n_rows;        // all rows (tail kernel covers [n_tiles*tile_rows, n_rows))
+    uint64_t n_rows;        // all rows
+    uint64_t tail_first_row; // tail kernel covers [tail_first_row, n_rows)
     uint64_t row_base;      // global id of local row 0
     uint32_t *bits;         // output bitset (nullable)
     const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)

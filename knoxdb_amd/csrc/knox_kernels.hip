@@ -403,18 +403,12 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     const uint32_t m1 = (tt & 2u) ? QMASK : 0u, m0 = (tt & 1u) ? QMASK : 0u;
     const int qshift = K * (lane & (G - 1));
 
-    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (uint64_t vt = blockIdx.x; vt < a.n_tiles; vt += gridDim.x) {
+        // packs pruned by the caller's statistics are never touched: with a live-pack list the
+        // virtual tile index walks only the surviving packs (their bitset ranges were zeroed by the host)
+        uint64_t tile = vt;
+        if (a.live_packs != nullptr) tile = ((uint64_t)a.live_packs[vt >> a.tpp_shift] << a.tpp_shift) + (vt & ((1ull << a.tpp_shift) - 1));
         const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;  // wave-uniform
-        if (a.pack_skip != nullptr && a.pack_shift != 255u) {
-            // pack pruned by the caller's statistics: no row can match, do not read it
-            if (a.pack_skip[row0 >> a.pack_shift]) {
-                if (a.bits != nullptr) {
-                    uint32_t *w = a.bits + (row0 >> 5);
-                    for (int i = lane; i < WAVE_ROWS / 32; i += 64) w[i] = 0u;
-                }
-                continue;
-            }
-        }
         const uint64_t vec0 = row0 / K + lane;
         u32x4 r[NL][kUnroll];
 #pragma unroll
@@ -557,9 +551,7 @@ template <int W> __device__ __forceinline__ typename WT<W>::U load_elem(const vo
 template <int W>
 __global__ void __launch_bounds__(kBlock) scan_tail_kernel(const ScanArgs a, int n_leaves, int tail_slot, int reduce_mode) {
     using U = typename WT<W>::U;
-    constexpr int K = WT<W>::K;
-    constexpr uint64_t TILE = (uint64_t)64 * K * kUnroll * kWavesPerBlock;
-    const uint64_t start = a.n_tiles * TILE;
+    const uint64_t start = a.tail_first_row;
     Acc acc;
     acc.init();
     if (start < a.n_rows) {

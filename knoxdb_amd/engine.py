@@ -338,24 +338,45 @@ class Context:
         return out[0], bool(seen.value), row.value
 
     # -- bloom
-    def bloom_probe(self, filters, offsets, h):
+    def bloom_upload(self, filters, offsets):
         filters = np.ascontiguousarray(filters, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        n = offsets.size - 1
-        out = np.zeros(n, dtype=np.uint8)
-        check(self.L.knox_bloom_probe(self.h, _ptr(filters) if filters.size else None, _ptr(offsets), n, h, _ptr(out)))
+        h = C.c_void_p()
+        check(self.L.knox_bloom_upload(self.h, _ptr(filters) if filters.size else None, _ptr(offsets), offsets.size - 1, C.byref(h)))
+        return Bloom(self, h)
+
+    def bloom_build_u64(self, col, factor):
+        h = C.c_void_p()
+        check(self.L.knox_bloom_build_u64(self.h, col.h, factor, C.byref(h)))
+        return Bloom(self, h)
+
+
+class Bloom:
+    """Per-pack bloom filters of one column, resident on the device (bloom.Filter per pack)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def packs(self):
+        return _lib.lib().knox_bloom_packs(self.h)
+
+    def download(self):
+        nbytes = _lib.lib().knox_bloom_bytes(self.h)
+        filters = np.zeros(nbytes, dtype=np.uint8)
+        offsets = np.zeros(self.packs + 1, dtype=np.uint64)
+        check(_lib.lib().knox_bloom_download(self.ctx.h, self.h, _ptr(filters) if nbytes else None, nbytes, _ptr(offsets)))
+        return filters, offsets
+
+    def probe(self, h):
+        out = np.zeros(self.packs, dtype=np.uint8)
+        check(_lib.lib().knox_bloom_probe(self.ctx.h, self.h, h, _ptr(out)))
         return out
 
-    def bloom_build_u64(self, col, factor, pack_rows):
-        n_packs = (col.rows + pack_rows - 1) // pack_rows
-        m = 8
-        while m < pack_rows * factor * 8:
-            m <<= 1
-        cap = n_packs * (1 + (m >> 3)) + 64
-        filters = np.zeros(cap, dtype=np.uint8)
-        offsets = np.zeros(n_packs + 1, dtype=np.uint64)
-        check(self.L.knox_bloom_build_u64(self.h, col.h, factor, _ptr(filters), cap, _ptr(offsets)))
-        return filters[:int(offsets[-1])], offsets
+    def free(self):
+        if self.h:
+            _lib.lib().knox_bloom_free(self.h)
+            self.h = None
 
 
 def hash_value(dtype, v):

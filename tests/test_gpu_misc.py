@@ -34,7 +34,8 @@ def test_bloom_build_and_probe(ctx):
     pack, n = 4096, 16 * 4096
     ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) ^ np.uint64(0xABCDEF)
     col = ctx.upload(ids, pack)
-    filters, offsets = ctx.bloom_build_u64(col, 2, pack)
+    bloom = ctx.bloom_build_u64(col, 2)
+    filters, offsets = bloom.download()
     # device-built filters are byte-identical to the reference construction (bloom.go:48-60,162-169)
     for p in range(16):
         f = O.bloom_new(pack, 2)
@@ -43,14 +44,18 @@ def test_bloom_build_and_probe(ctx):
         assert (filters[int(offsets[p]):int(offsets[p + 1])] == f).all(), p
     present = ids[5 * pack + 17]
     h = K.hash_value(BlockType.Uint64, present)
-    maybe = ctx.bloom_probe(filters, offsets, h)
+    maybe = bloom.probe(h)
     want = [int(O.bloom_contains(filters[int(offsets[p]):int(offsets[p + 1])], h)) for p in range(16)]
     assert maybe.tolist() == want and maybe[5] == 1
     absent = np.uint64(12345678901234567)
     h2 = K.hash_value(BlockType.Uint64, absent)
-    maybe2 = ctx.bloom_probe(filters, offsets, h2)
+    maybe2 = bloom.probe(h2)
     want2 = [int(O.bloom_contains(filters[int(offsets[p]):int(offsets[p + 1])], h2)) for p in range(16)]
     assert maybe2.tolist() == want2
+    # filters uploaded from the host (the reference's serialized form) probe identically
+    up = ctx.bloom_upload(filters, offsets)
+    assert up.probe(h).tolist() == want and up.probe(h2).tolist() == want2
+    up.free()
     # pruned scan == full scan (config 4 shape: bloom pre-filter then EQ, count)
     col.pack_rows = pack
     bits = ctx.bits(n)
@@ -60,7 +65,7 @@ def test_bloom_build_and_probe(ctx):
     r2 = ctx.scan(And(Leaf(0, FilterMode.Equal, present)), [col], aggs=[(ReducerFunc.Count, 0)], bits_out=bits)
     assert (b1 == bits.bytes()).all() and r1.count == r2.count == 1
     assert r1.rows_scanned == int(maybe.sum()) * pack
-    col.free(); bits.free()
+    col.free(); bits.free(); bloom.free()
 
 
 def test_large_scan_properties(ctx):

@@ -46,13 +46,14 @@ elif args.cfg == 4:
     ids = ctx.generate(BlockType.Uint64, 0, 5, n, lo=0, span=0, pack_rows=pack)   # raw 64-bit ids
     bits = ctx.bits(n)
     t0 = time.perf_counter()
-    filters, offsets = ctx.bloom_build_u64(ids, 2, pack)
+    bloom = ctx.bloom_build_u64(ids, 2)
+    ctx.sync()
     t_build = time.perf_counter() - t0
     present = ids.download(777 * pack + 12345, 1)[0]
     for name, key in (("present", present), ("absent", np.uint64(0x123456789ABCDEF))):
         h = K.hash_value(BlockType.Uint64, key)
         t0 = time.perf_counter()
-        maybe = ctx.bloom_probe(filters, offsets, h)
+        maybe = bloom.probe(h)
         t_probe = time.perf_counter() - t0
         plan = ctx.plan(And(Leaf(0, FilterMode.Equal, key)), [ids], aggs=[(R.Count, 0)])
         ms_full, r_full = timed(plan, bits, args.steps)
@@ -62,4 +63,4 @@ elif args.cfg == 4:
                           "count_pruned": r_pruned.count, "kernel_ms_full": ms_full, "kernel_ms_pruned": ms_pruned,
                           "full_GBs": n * 8.125 / ms_full / 1e6, "pruned_GBs_over_scanned_packs": scanned * pack * 8.125 / ms_pruned / 1e6 if scanned else None,
                           "effective_rows_per_s_incl_pruned": n / ms_pruned * 1e3, "bloom_build_s": t_build, "bloom_probe_s": t_probe,
-                          "filter_bytes": int(offsets[-1])}))
+                          "filter_bytes": int(ctx.L.knox_bloom_bytes(bloom.h))}))
