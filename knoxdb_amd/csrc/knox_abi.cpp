@@ -828,6 +828,22 @@ static uint32_t pack_shift_for(size_t pack_rows, int width) {
     return s;
 }
 
+// Wave iterations per tile: a wave stages the bitset words of `iters` consecutive iterations and
+// writes them as one burst (whole 128-B lines).  Measured over 14 column placements x iters
+// {1,2,4,8,16} x {2,3} workgroups/CU (tools/placement_matrix.py, profiles/r01_placement_matrix.txt):
+// iters = 2 is the fastest everywhere (7.0 TB/s typical, 5.9 TB/s on the slow placements, vs
+// 6.7 / 5.5 TB/s at iters = 1).  Short inputs keep tiles small so every CU gets work.
+static uint32_t pick_iters(knox_ctx *ctx, size_t n_rows, int width, size_t pack_rows_or_0) {
+    const char *env = getenv("KNOX_ITERS");
+    uint32_t it = env && atoi(env) > 0 ? (uint32_t)atoi(env) : 2u;
+    if (it > (uint32_t)kMaxIters) it = kMaxIters;
+    const uint64_t base = (uint64_t)tile_rows(width);
+    const uint64_t want_tiles = (uint64_t)ctx->n_cus * 8;
+    while (it > 1 && n_rows / (base * it) < want_tiles) it >>= 1;
+    if (pack_rows_or_0) while (it > 1 && (pack_rows_or_0 % (base * it)) != 0) it >>= 1;
+    return it;
+}
+
 // Packs pruned by the caller's statistics.  d_skip: one byte per pack (tail kernel); d_live: the
 // compact list of surviving packs the streaming kernel walks; h_skip: the caller's array (only
 // read before the call returns) for zeroing the pruned bitset ranges.
@@ -859,7 +875,9 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
         a.agg_flavor = dtype_flavor(agg_col->dtype);
         sep = agg_col->dev != lcols[0]->dev;
     }
-    const uint64_t tr = (uint64_t)tile_rows(width);
+    const bool want_skip = skip && skip->d_skip && skip->d_live && pack_rows && !(pack_rows & (pack_rows - 1)) && n_rows % pack_rows == 0;
+    a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0);
+    const uint64_t tr = (uint64_t)tile_rows(width) * a.iters;
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;
     a.tail_first_row = a.n_tiles * tr;
@@ -924,7 +942,8 @@ static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, 
     memset(&a, 0, sizeof a);
     a.agg_col = col->dev;
     a.agg_flavor = dtype_flavor(col->dtype);
-    const uint64_t tr = (uint64_t)tile_rows(col->width);
+    a.iters = pick_iters(ctx, n_rows, col->width, 0);
+    const uint64_t tr = (uint64_t)tile_rows(col->width) * a.iters;
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;
     a.tail_first_row = a.n_tiles * tr;

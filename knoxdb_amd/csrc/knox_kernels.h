@@ -9,6 +9,7 @@ namespace knox {
 constexpr int kBlock = 256;          // threads per workgroup = 4 wave64
 constexpr int kWavesPerBlock = 4;
 constexpr int kUnroll = 4;           // 16-byte loads in flight per lane per column
+constexpr int kMaxIters = 16;        // wave iterations whose bitset words are staged before one burst store
 constexpr int kMaxLeaves = 4;        // leaves evaluated by one fused pass (truth table 2^4 bits)
 constexpr uint64_t kNoRow = ~0ull;
 
@@ -52,6 +53,7 @@ struct ScanArgs {
     uint32_t *bits;         // output bitset (nullable)
     const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)
     uint32_t debug;         // diagnostics: bit0 = compute the bitset words but skip the global store
+    uint32_t iters;         // wave iterations per tile (1..kMaxIters): tile = iters * tile_rows(width)
     AggPartial *partials;   // [grid] (+1 slot for the tail at index grid)
 };
 

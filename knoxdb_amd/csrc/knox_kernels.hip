@@ -375,12 +375,12 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     constexpr int G = 32 / K;
     constexpr int RPL = 64 * K;                       // rows per wave-load
     constexpr int WAVE_ROWS = RPL * kUnroll;
-    constexpr int TILE = WAVE_ROWS * kWavesPerBlock;
     constexpr uint32_t QMASK = (K == 32) ? 0xffffffffu : ((1u << K) - 1u);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][WAVE_ROWS / 32];
+    // the wave's bitset words of up to kMaxIters iterations, written out as one contiguous burst
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][kMaxIters * WAVE_ROWS / 32];
 
     Acc acc;
     acc.init();
@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     FirstLast fl;
     fl.init();
     uint32_t cnt32 = 0;
+    const uint32_t iters = a.iters;
 
     U lo[NL], diff[NL];
     bool isf[NL];
@@ -408,7 +409,11 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
         // virtual tile index walks only the surviving packs (their bitset ranges were zeroed by the host)
         uint64_t tile = vt;
         if (a.live_packs != nullptr) tile = ((uint64_t)a.live_packs[vt >> a.tpp_shift] << a.tpp_shift) + (vt & ((1ull << a.tpp_shift) - 1));
-        const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;  // wave-uniform
+        // a wave owns iters*WAVE_ROWS consecutive rows of the tile (one contiguous bitset burst)
+        const uint64_t wrow0 = (tile * kWavesPerBlock + (uint64_t)wave) * iters * WAVE_ROWS;
+#pragma unroll 1
+        for (uint32_t it = 0; it < iters; it++) {
+        const uint64_t row0 = wrow0 + (uint64_t)it * WAVE_ROWS;  // wave-uniform
         const uint64_t vec0 = row0 / K + lane;
         u32x4 r[NL][kUnroll];
 #pragma unroll
@@ -472,21 +477,25 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             }
             if ((lane & (G - 1)) == 0) {
 #pragma unroll
-                for (int u = 0; u < kUnroll; u++) stage[wave][u * (64 / G) + (lane / G)] = w[u];
-            }
-            // LDS ops of one wave execute in order: the read below sees the words written above
-            constexpr int NV = WAVE_ROWS / 128;  // 16-byte vectors of bitset per wave iteration
-            if (lane < NV) {
-                const u32x4 v = ((const u32x4 *)stage[wave])[lane];
-                u32x4 *dst = (u32x4 *)(a.bits + (row0 >> 5)) + lane;
-                // streaming (nt) store; debug bit0 = diagnostics build of the launch: words are
-                // assembled but never leave the CU (prices the HBM write traffic alone)
-                if (!(a.debug & 1u) || v.x == 0x12345678u) __builtin_nontemporal_store(v, dst);
+                for (int u = 0; u < kUnroll; u++) stage[wave][it * (WAVE_ROWS / 32) + u * (64 / G) + (lane / G)] = w[u];
             }
         }
         if constexpr (AGG != 0) {
             if constexpr (SEP) agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
             else agg_iter<W, AGG, FLV>(acc, wm, fl, r[0], q, row0, a.row_base, lane);
+        }
+        }  // it
+        if (a.bits != nullptr) {
+            // LDS ops of one wave execute in order: the reads below see the words written above.
+            // One burst of iters * WAVE_ROWS/8 contiguous bytes per wave (1 KiB for 8-byte types at
+            // 16 iterations): whole 128-B lines, 16-byte-per-lane streaming (nt) stores.
+            const uint32_t nv = iters * (WAVE_ROWS / 128);  // 16-byte vectors
+            u32x4 *dst = (u32x4 *)(a.bits + (wrow0 >> 5));
+            for (uint32_t v = lane; v < nv; v += 64) {
+                const u32x4 x = ((const u32x4 *)stage[wave])[v];
+                // debug bit0 = diagnostics: words are assembled but never leave the CU
+                if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
+            }
         }
     }
     acc.count = cnt32;
@@ -503,7 +512,6 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
     constexpr int G = 32 / K;
     constexpr int RPL = 64 * K;
     constexpr int WAVE_ROWS = RPL * kUnroll;
-    constexpr int TILE = WAVE_ROWS * kWavesPerBlock;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     Acc acc;
@@ -513,8 +521,12 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
     FirstLast fl;
     fl.init();
     uint32_t cnt32 = 0;
+    const uint32_t iters = a.iters;
     for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint64_t row0 = tile * TILE + (uint64_t)wave * WAVE_ROWS;
+        const uint64_t wrow0 = (tile * kWavesPerBlock + (uint64_t)wave) * iters * WAVE_ROWS;
+#pragma unroll 1
+        for (uint32_t it = 0; it < iters; it++) {
+        const uint64_t row0 = wrow0 + (uint64_t)it * WAVE_ROWS;
         const uint64_t vec0 = row0 / K + lane;
         u32x4 ra[kUnroll];
         uint32_t q[kUnroll];
@@ -530,6 +542,7 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(const ScanArgs a) {
             cnt32 += __builtin_popcount(q[u]);
         }
         agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
+        }  // it
     }
     acc.count = cnt32;
     if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
