@@ -58,6 +58,7 @@ enum knox_dtype {
 /* ---- types.FilterMode (internal/types/mode.go:13-27) -------------------------------- */
 enum knox_op {
     KNOX_EQ = 1, KNOX_NE = 2, KNOX_GT = 3, KNOX_GE = 4, KNOX_LT = 5, KNOX_LE = 6,
+    KNOX_IN = 7, KNOX_NOTIN = 8 /* value in / not in a set: val = array of column-type values */,
     KNOX_RANGE = 9 /* Between [a,b] */, KNOX_TRUE = 11, KNOX_FALSE = 12
 };
 
@@ -166,7 +167,9 @@ int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t 
  * The tree is flattened to postfix: leaves push, AND/OR pop `nchild` operands.
  * Leaf = filter.Filter{Type, Mode, Index, Value} (operator/filter/filter.go:22-30):
  * `col` indexes the cols[] array, a/b hold the value bits of the column type (little-endian,
- * zero-extended to 64 bit; b only for KNOX_RANGE).  Bytes leaves (EQ/NE) pass val/val_len.  */
+ * zero-extended to 64 bit; b only for KNOX_RANGE).  Bytes leaves (EQ/NE) pass val/val_len;
+ * KNOX_IN / KNOX_NOTIN leaves pass the set as val = array of column-type values, val_len =
+ * its length in BYTES (numInSetMatcher / floatInSetMatcher, match_num.go:593-808).           */
 enum knox_node_kind { KNOX_NODE_LEAF = 0, KNOX_NODE_AND = 1, KNOX_NODE_OR = 2 };
 typedef struct knox_pred {
     int32_t kind;   /* knox_node_kind */

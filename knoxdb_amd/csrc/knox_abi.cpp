@@ -964,6 +964,8 @@ static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, 
 }
 
 // one leaf -> its own bitset (multi-pass plan)
+static uint64_t order_key(int dtype, uint64_t bits);
+
 static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *col, size_t n_rows, uint64_t *bits, int grid) {
     if (col->dtype == KNOX_BYTES) {
         if (p.op != KNOX_EQ && p.op != KNOX_NE) return KNOX_E_UNSUPPORTED;
@@ -976,6 +978,42 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
         }
         hipError_t e = launch_bytes_match(ctx->stream, p.op == KNOX_EQ, (const uint64_t *)col->dev, n_rows, col->buf,
                                           (const uint8_t *)ctx->bytes_val.p, (uint32_t)p.val_len, (uint8_t *)bits, nullptr, nullptr);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return KNOX_E_HIP;
+        }
+        return KNOX_OK;
+    }
+    if (p.op == KNOX_IN || p.op == KNOX_NOTIN) {
+        // sorted unique canonical order keys of the set (NaN dropped: never a member; +-0 one key)
+        const size_t w = (size_t)col->width;
+        if (p.val_len % w != 0 || (p.val_len && !p.val)) return KNOX_E_INVALID;
+        const size_t cnt = (size_t)(p.val_len / w);
+        if (cnt > 0xffffffffu) return KNOX_E_RANGE;
+        std::vector<uint64_t> keys;
+        keys.reserve(cnt);
+        const bool isf = dtype_is_float(col->dtype);
+        const uint64_t m = wmask((int)w), sign = 1ull << (8 * w - 1), expm = w == 8 ? 0x7ff0000000000000ull : 0x7f800000ull;
+        for (size_t i = 0; i < cnt; i++) {
+            uint64_t v = 0;
+            memcpy(&v, p.val + i * w, w);
+            if (isf) {
+                if ((v & (m ^ sign)) > expm) continue;
+                keys.push_back(order_key(col->dtype, v));
+            } else {
+                keys.push_back(order_key(col->dtype, v));
+            }
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        int rc = ensure(ctx, ctx->bytes_val, keys.size() * 8 + 16);
+        if (rc) return rc;
+        if (!keys.empty()) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vector not retained
+        }
+        hipError_t e = launch_inset(ctx->stream, col->width, dtype_flavor(col->dtype), p.op == KNOX_NOTIN, col->dev, n_rows,
+                                    (const uint64_t *)ctx->bytes_val.p, (uint32_t)keys.size(), (uint8_t *)bits, nullptr);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return KNOX_E_HIP;
@@ -1096,7 +1134,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     int width = 0;
     for (int l = 0; l < n_leaves && fused; l++) {
         const knox_col *c = cols[nodes[leaf_nodes[l]].col];
-        if (c->dtype == KNOX_BYTES) fused = false;
+        if (c->dtype == KNOX_BYTES || nodes[leaf_nodes[l]].op == KNOX_IN || nodes[leaf_nodes[l]].op == KNOX_NOTIN) fused = false;
         else if (width == 0) width = c->width;
         else if (c->width != width) fused = false;
     }

@@ -103,6 +103,11 @@ hipError_t launch_bytes_match(hipStream_t s, bool want_eq, const uint64_t *ptr, 
                               const uint8_t *val, uint32_t vlen, uint8_t *bits, const uint8_t *mask,
                               unsigned long long *count_out /* pre-zeroed */);
 
+// IN / NOT IN: membership of the value's canonical order key in a sorted key set (binary search);
+// matching rows are OR-ed into bits (bits.Set), only mask-selected rows are tested when mask != null
+hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
+                        const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask);
+
 // bloom probe / build
 hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,
                               uint64_t h, uint8_t *maybe_out);

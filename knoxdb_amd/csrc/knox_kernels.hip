@@ -1021,6 +1021,73 @@ hipError_t launch_bytes_match(hipStream_t s, bool want_eq, const uint64_t *ptr, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// IN / NOT IN set matchers (operator/filter/match_num.go:672-690,789-808, match_float.go:57-73):
+// one lane = one row; the value's canonical order key (floats: -0 -> +0, NaN never a member) is
+// looked up by binary search in the sorted key set; wave ballot -> 8 result bytes OR-ed into bits.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) inset_kernel(uint32_t flavor, int negate, const void *col, uint64_t n_rows,
+                                                       const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+    using U = typename WT<W>::U;
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            const U e = load_elem<W>(col, row);
+            const U mag = e & (WT<W>::MASK ^ WT<W>::SIGN);
+            uint64_t key;
+            bool isnan = false;
+            if (flavor == FL_FLOAT) {
+                U expmask;
+                if constexpr (W == 8) expmask = 0x7ff0000000000000ull; else expmask = 0x7f800000u;
+                isnan = mag > expmask;
+                key = (mag == 0) ? (uint64_t)WT<W>::SIGN : (uint64_t)fkey<W>(e);
+            } else {
+                key = (flavor == FL_SIGNED) ? (uint64_t)(e ^ WT<W>::SIGN) : (uint64_t)e;
+            }
+            bool found = false;
+            if (!isnan) {
+                uint32_t lo = 0, hi = n_keys;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t k = keys[mid];
+                    if (k < key) lo = mid + 1; else hi = mid;
+                }
+                found = lo < n_keys && keys[lo] == key;
+            }
+            m = negate ? !found : found;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) byte &= mask[bi];
+                if (byte) bits[bi] |= byte;
+            }
+        }
+    }
+}
+
+hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
+                        const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    switch (width) {
+    case 8: KNOX_LAUNCH((inset_kernel<8>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 4: KNOX_LAUNCH((inset_kernel<4>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 2: KNOX_LAUNCH((inset_kernel<2>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 1: KNOX_LAUNCH((inset_kernel<1>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bloom filter: internal/filter/bloom/bloom.go:136-150 (probe), :162-169 (add), xxh3.go:22-33
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t rol64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }

@@ -44,6 +44,10 @@ def _flatten(node, cols, out, keep):
             val = bytes(node.a)
             keep.append(val)
             p.val, p.val_len = val, len(val)
+        elif node.mode in (FilterMode.In, FilterMode.NotIn):
+            val = np.ascontiguousarray(node.a, dtype=NP_DTYPE[c.dtype]).tobytes()
+            keep.append(val)
+            p.val, p.val_len = val, len(val)
         else:
             p.a = value_bits(c.dtype, node.a)
             p.b = value_bits(c.dtype, node.b) if node.b is not None else 0

@@ -31,6 +31,8 @@ class FilterMode(enum.IntEnum):
     Ge = 4
     Lt = 5
     Le = 6
+    In = 7
+    NotIn = 8
     Range = 9
     True_ = 11
     False_ = 12

@@ -745,6 +745,45 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
 }
 
 /* ------------------------------------------------------------------------------------------
+ * IN / NOT IN set matchers on materialized blocks:
+ *   integers  numInSetMatcher / numNotInSetMatcher.MatchVector  operator/filter/match_num.go:672-690, :789-808
+ *             (membership of uint64(v) in a set built from uint64(T(x)), i.e. equality on T)
+ *   floats    floatInSetMatcher / floatNotInSetMatcher.MatchVector  operator/filter/match_float.go:57-73
+ *             (OrderedFloats.Contains = IEEE equality: NaN is never a member, -0 == +0)
+ * Only bits.Set(i): matching rows are OR-ed into `bits`; with a mask only mask-selected rows are tested.
+ * ---------------------------------------------------------------------------------------- */
+#define KO_INSET(NAME, T)                                                                       \
+    static void NAME(int negate, const T *src, int64_t n, const T *set, int64_t nset,           \
+                     uint8_t *bits, const uint8_t *mask) {                                      \
+        for (int64_t i = 0; i < n; i++) {                                                       \
+            if (mask && !((mask[i >> 3] >> (i & 7)) & 1)) continue;                             \
+            int found = 0;                                                                      \
+            for (int64_t k = 0; k < nset && !found; k++) found = (set[k] == src[i]);            \
+            if (found != negate) bits[i >> 3] |= (uint8_t)(1 << (i & 7));                       \
+        }                                                                                       \
+    }
+KO_INSET(inset_i64, int64_t) KO_INSET(inset_i32, int32_t) KO_INSET(inset_i16, int16_t) KO_INSET(inset_i8, int8_t)
+KO_INSET(inset_u64, uint64_t) KO_INSET(inset_u32, uint32_t) KO_INSET(inset_u16, uint16_t) KO_INSET(inset_u8, uint8_t)
+KO_INSET(inset_f64, double) KO_INSET(inset_f32, float)
+
+KO_EXPORT int ko_inset(int dtype, int negate, const void *src, int64_t n, const void *set, int64_t nset, uint8_t *bits,
+                       const uint8_t *mask) {
+    switch (dtype) {
+    case KO_I64: inset_i64(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_I32: inset_i32(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_I16: inset_i16(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_I8:  inset_i8(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_U64: inset_u64(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_U32: inset_u32(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_U16: inset_u16(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_U8:  inset_u8(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_F64: inset_f64(negate, src, n, set, nset, bits, mask); return 0;
+    case KO_F32: inset_f32(negate, src, n, set, nset, bits, mask); return 0;
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic column generator (shared SPEC with the device generator in
  * knoxdb_amd/csrc/knox_kernels.hip: both sides implement DESIGN.md "synthetic data" from the
  * text, neither calls the other).  Counter based so any row can be produced independently:

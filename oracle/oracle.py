@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libknox_oracle.so")
 
 # enums shared with the reference (internal/types/block.go:20-36, mode.go:13-27)
 I64, I32, I16, I8, U64, U32, U16, U8, F64, F32, BYTES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12
-EQ, NE, GT, GE, LT, LE, RG = 1, 2, 3, 4, 5, 6, 9
+EQ, NE, GT, GE, LT, LE, IN, NIN, RG = 1, 2, 3, 4, 5, 6, 7, 8, 9
 R_SUM, R_FIRST, R_LAST, R_MIN, R_MAX, R_MEAN, R_VAR, R_STD, R_COUNT = range(9)
 
 NP = {I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8, U64: np.uint64, U32: np.uint32,
@@ -75,6 +75,8 @@ def lib():
         L.ko_bloom_contains.argtypes = [vp, i64, u64]
         L.ko_bytes_match.restype = i64
         L.ko_bytes_match.argtypes = [i32, vp, i64, vp, C.c_char_p, i64, vp, vp]
+        L.ko_inset.restype = i32
+        L.ko_inset.argtypes = [i32, i32, vp, i64, vp, i64, vp, vp]
         L.ko_generate.restype = i32
         L.ko_generate.argtypes = [i32, i32, u64, i64, i64, i64, u64, vp]
         L.ko_scan_i64_bw_sum.restype = i64
@@ -194,6 +196,16 @@ def bytes_match(op, ptr, buf, val, mask=None, bits=None):
     m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
     cnt = lib().ko_bytes_match(op, _p(ptr), n, _p(buf), bytes(val), len(val), _p(out), _p(m))
     return out, cnt
+
+
+def inset(dtype, negate, src, values, mask=None, bits=None):
+    src = np.ascontiguousarray(src, dtype=NP[dtype])
+    vals = np.ascontiguousarray(values, dtype=NP[dtype])
+    out = np.zeros(bitfield_len(src.size), dtype=np.uint8) if bits is None else np.array(bits, dtype=np.uint8, copy=True)
+    m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+    rc = lib().ko_inset(dtype, int(bool(negate)), _p(src), src.size, _p(vals) if vals.size else None, vals.size, _p(out), _p(m))
+    assert rc == 0
+    return out
 
 
 def generate(dtype, kind, seed, first_row, n, lo=0, span=0):

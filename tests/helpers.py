@@ -13,6 +13,8 @@ def oracle_leaf(leaf, host_cols):
         bits, _ = O.bytes_match(int(leaf.mode), col[0], col[1], bytes(leaf.a))
         return bits
     dt = int({v: k for k, v in NP_DTYPE.items()}[col.dtype.type])
+    if leaf.mode in (FilterMode.In, FilterMode.NotIn):
+        return O.inset(dt, leaf.mode == FilterMode.NotIn, col, np.asarray(leaf.a, dtype=col.dtype))
     if leaf.mode == FilterMode.True_:
         return O.bits_one(col.size)
     if leaf.mode == FilterMode.False_:

@@ -266,3 +266,24 @@ def test_masked_reduce_matches_oracle(ctx):
         st_all = ctx.reduce(col, None)
         assert st_all.count == n
         col.free(); m.free()
+
+
+def test_in_and_not_in_sets(ctx):
+    # numInSetMatcher / numNotInSetMatcher / floatInSetMatcher (match_num.go:593-808, match_float.go)
+    rng = np.random.default_rng(41)
+    n = 3 * 4096 + 19
+    for bt in (BlockType.Int64, BlockType.Int32, BlockType.Uint16, BlockType.Int8, BlockType.Uint64, BlockType.Float64, BlockType.Float32):
+        x = rand_col(bt, n, rng)
+        sets = [x[rng.integers(0, n, size=5)], x[:1], x[rng.integers(0, n, size=300)], np.zeros(0, dtype=x.dtype)]
+        if x.dtype.kind == "f":
+            sets.append(np.array([np.nan, 0.0, 5.0], dtype=x.dtype))   # NaN is never a member; 0.0 also matches -0.0
+            sets.append(np.array([-0.0, np.inf], dtype=x.dtype))
+        else:
+            info = np.iinfo(x.dtype)
+            sets.append(np.array([info.min, info.max, 0], dtype=x.dtype))
+        for s in sets:
+            for mode in (FilterMode.In, FilterMode.NotIn):
+                check_scan(ctx, And(Leaf(0, mode, s)), [x], [(R.Count, 0), (R.Min, 0)], 1024, n)
+    a, b = rand_col(BlockType.Int64, n, rng), rand_col(BlockType.Float64, n, rng)
+    tree = And(Leaf(0, FilterMode.In, np.array([5, 6, 7, -3, 0], dtype=np.int64)), Or(Leaf(1, FilterMode.Gt, 0.0), Leaf(0, FilterMode.NotIn, np.array([5], dtype=np.int64))))
+    check_scan(ctx, tree, [a, b], [(R.Sum, 0), (R.Max, 1)], 2048, n)

@@ -126,3 +126,15 @@ def test_cpu_baseline_leg_matches_pieces():
     bits, cnt, s = O.scan_i64_bw_sum(x, 4096, -(1 << 38), 1 << 38)
     sel = (x >= -(1 << 38)) & (x <= (1 << 38))
     assert cnt == int(sel.sum()) and s == int(x[sel].sum())
+
+
+def test_inset_semantics():
+    x = np.array([5, -3, 7, 5, 0, -128, 127], dtype=np.int8)
+    assert O.inset(O.I8, False, x, [5, -128]).tolist() == [0b00101001]
+    assert O.inset(O.I8, True, x, [5, -128]).tolist() == [0b01010110]
+    # mask: only mask-selected rows are tested, result OR-ed into bits (bits.Set)
+    assert O.inset(O.I8, False, x, [5, -128], mask=np.array([0b00100001], np.uint8), bits=np.array([0b01000000], np.uint8)).tolist() == [0b01100001]
+    f = np.array([0.0, -0.0, np.nan, 1.5, np.inf])
+    assert O.inset(O.F64, False, f, [np.nan, 0.0]).tolist() == [0b00011 & 0b11111]
+    assert O.inset(O.F64, True, f, [np.nan, 0.0]).tolist() == [0b11100]
+    assert O.inset(O.F64, False, f, []).tolist() == [0]

@@ -30,7 +30,18 @@ def timed(plan, bits, steps, pack_counts=True, skip=None):
     v = [ms[i] for i in range(k.value)]
     return statistics.median(v[len(v) // 3:]), res
 
-if args.cfg == 3:
+if args.cfg == 0:
+    # PCIe-inclusive ingest: pageable host memory -> pinned ring -> HBM (knox_col_upload), then one scan
+    m = 1 << min(args.rows_log2, 28)
+    host = np.arange(m, dtype=np.int64)
+    t0 = time.perf_counter(); col = ctx.upload(host, pack); ctx.sync(); t_up = time.perf_counter() - t0
+    bits = ctx.bits(m)
+    plan = ctx.plan(And(Leaf(0, FilterMode.Range, 5, m // 4)), [col], aggs=[(R.Sum, 0)])
+    t0 = time.perf_counter(); ctx.scan_async(plan, bits_out=bits); res = ctx.scan_collect(plan, 0); t_scan = time.perf_counter() - t0
+    t0 = time.perf_counter(); b, c = ctx.cmp(BlockType.Int64, FilterMode.Lt, host[:1 << 16], 127); t_cmp = time.perf_counter() - t0
+    print(json.dumps({"cfg": "pcie", "rows": m, "upload_s": t_up, "upload_GBs": m * 8 / t_up / 1e9, "first_scan_s": t_scan,
+                      "pcie_inclusive_rows_per_s": m / (t_up + t_scan), "knox_cmp_2^16_rows_s": t_cmp}))
+elif args.cfg == 3:
     a = ctx.generate(BlockType.Float64, 1, 3, n, pack_rows=pack)
     b = ctx.generate(BlockType.Float64, 2, 4, n, pack_rows=pack)
     bits = ctx.bits(n)
