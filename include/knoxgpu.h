@@ -119,6 +119,15 @@ int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, s
 /* Bytes column in StringPool layout (pkg/stringx/pool.go:45-58): ptr[i] = off<<32 | len.  */
 int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf,
                           size_t buf_len, size_t pack_rows, knox_col **out);
+/* Ingest the ON-DISK raw containers of consecutive packs without a host decode pass ("next"
+ * row f2): bufs[i] is the container of pack i as stored by RawContainer.Store /
+ * FloatRawContainer.Store (internal/encode/int_raw.go:73-94, float_raw.go:73-89):
+ * [7][uvarint n values][LE values] for integer types, [15][uvarint n bytes][LE values] for
+ * floats, uvarint = pkg/num/varint.go (SQLite4-style prefix varint).  The payloads are staged
+ * straight into one contiguous HBM column.  Any other container type: KNOX_E_UNSUPPORTED (the
+ * caller decodes it on the host as today).                                                  */
+int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens,
+                                   size_t n_bufs, size_t pack_rows, knox_col **out);
 /* Borrow memory that already lives on the device (16-byte aligned); never freed by knox.  */
 int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows,
                   knox_col **out);

@@ -474,6 +474,56 @@ KNOX_API int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_
     return rc;
 }
 
+// pkg/num/varint.go:161-197 (SQLite4-style prefix varint); returns bytes consumed, 0 on short input
+static int knox_uvarint(const uint8_t *b, size_t len, uint64_t *out) {
+    if (len == 0) return 0;
+    const uint8_t b0 = b[0];
+    const int need = b0 <= 240 ? 1 : b0 <= 248 ? 2 : (int)b0 - 246;
+    if ((size_t)need > len) return 0;
+    if (b0 <= 240) { *out = b0; return 1; }
+    if (b0 <= 248) { *out = 240 + ((uint64_t)(b0 - 241) << 8) + b[1]; return 2; }
+    if (b0 == 249) { *out = 2288 + ((uint64_t)b[1] << 8) + b[2]; return 3; }
+    if (b0 == 250) { *out = ((uint64_t)b[1] << 16) + ((uint64_t)b[2] << 8) + b[3]; return 4; }
+    uint64_t x = ((uint64_t)b[1] << 24) + ((uint64_t)b[2] << 16) + ((uint64_t)b[3] << 8) + b[4];
+    for (int i = 5; i < need; i++) x = (x << 8) + b[i];
+    *out = x;
+    return need;
+}
+
+KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
+                                            size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || (n_bufs && (!bufs || !lens))) return KNOX_E_INVALID;
+    const int w = dtype_width(dtype);
+    if (w == 0) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    const uint8_t want = dtype_is_float(dtype) ? 15 /* TFloatRaw */ : 7 /* TIntRaw */;
+    std::vector<std::pair<const uint8_t *, size_t>> payload(n_bufs);
+    size_t total = 0;
+    for (size_t i = 0; i < n_bufs; i++) {
+        if (!bufs[i] || lens[i] < 2) return KNOX_E_INVALID;
+        if (bufs[i][0] != want) return KNOX_E_UNSUPPORTED;  // encoded container: host decode path
+        uint64_t v = 0;
+        const int k = knox_uvarint(bufs[i] + 1, lens[i] - 1, &v);
+        if (k == 0) return KNOX_E_INVALID;
+        const uint64_t n = dtype_is_float(dtype) ? v / (uint64_t)w : v;  // floats store the BYTE count (float_raw.go:75)
+        if (1 + (uint64_t)k + n * (uint64_t)w > lens[i]) return KNOX_E_RANGE;
+        payload[i] = {bufs[i] + 1 + k, (size_t)n};
+        total += (size_t)n;
+    }
+    int rc = col_new(ctx, dtype, total, pack_rows, true, out);
+    if (rc) return rc;
+    size_t row = 0;
+    for (size_t i = 0; i < n_bufs && !rc; i++) {
+        rc = upload(ctx, (char *)(*out)->dev + row * (size_t)w, payload[i].first, payload[i].second * (size_t)w);
+        row += payload[i].second;
+    }
+    if (rc) {
+        knox_col_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
 KNOX_API int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows, knox_col **out) {
     if (!ctx || !out || (n_rows && !device_ptr) || dtype == KNOX_BYTES) return KNOX_E_INVALID;
     if (((uintptr_t)device_ptr & 15) != 0) return KNOX_E_INVALID;

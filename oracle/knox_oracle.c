@@ -784,6 +784,69 @@ KO_EXPORT int ko_inset(int dtype, int negate, const void *src, int64_t n, const 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Raw on-disk containers ("next" row f2): pkg/num/varint.go:85-197 (SQLite4-style prefix varint,
+ * NOT LEB128) and internal/encode/int_raw.go:73-94, float_raw.go:73-89.
+ *   integers: [TIntRaw = 7 ][uvarint number of VALUES][little-endian values]
+ *   floats:   [TFloatRaw=15][uvarint number of BYTES ][little-endian values]
+ * ---------------------------------------------------------------------------------------- */
+KO_EXPORT int ko_put_uvarint(uint8_t *b, uint64_t x) { /* varint.go:85-159 */
+    if (x <= 240) { b[0] = (uint8_t)x; return 1; }
+    if (x <= 2287) { uint64_t y = x - 240; b[0] = (uint8_t)((y >> 8) + 241); b[1] = (uint8_t)y; return 2; }
+    if (x <= 67823) { uint64_t y = x - 2288; b[0] = 249; b[1] = (uint8_t)(y >> 8); b[2] = (uint8_t)y; return 3; }
+    if (x <= 0xffffff) { b[0] = 250; b[1] = (uint8_t)(x >> 16); b[2] = (uint8_t)(x >> 8); b[3] = (uint8_t)x; return 4; }
+    uint64_t w = x >> 32;
+    int hi = w == 0 ? 0 : w <= 0xff ? 1 : w <= 0xffff ? 2 : w <= 0xffffff ? 3 : 4; /* bytes of w */
+    b[0] = (uint8_t)(251 + hi);
+    for (int i = 0; i < hi; i++) b[1 + i] = (uint8_t)(w >> (8 * (hi - 1 - i)));
+    b[1 + hi] = (uint8_t)(x >> 24); b[2 + hi] = (uint8_t)(x >> 16); b[3 + hi] = (uint8_t)(x >> 8); b[4 + hi] = (uint8_t)x;
+    return 5 + hi;
+}
+KO_EXPORT int ko_uvarint(const uint8_t *b, uint64_t *out) { /* varint.go:161-197 */
+    uint8_t b0 = b[0];
+    if (b0 <= 240) { *out = b0; return 1; }
+    if (b0 <= 248) { *out = 240 + ((uint64_t)(b0 - 241) << 8) + b[1]; return 2; }
+    if (b0 == 249) { *out = 2288 + ((uint64_t)b[1] << 8) + b[2]; return 3; }
+    if (b0 == 250) { *out = ((uint64_t)b[1] << 16) + ((uint64_t)b[2] << 8) + b[3]; return 4; }
+    uint64_t x = ((uint64_t)b[1] << 24) + ((uint64_t)b[2] << 16) + ((uint64_t)b[3] << 8) + b[4];
+    if (b0 == 251) { *out = x; return 5; }
+    if (b0 == 252) { *out = (x << 8) + b[5]; return 6; }
+    if (b0 == 253) { *out = (x << 16) + ((uint64_t)b[5] << 8) + b[6]; return 7; }
+    if (b0 == 254) { *out = (x << 24) + ((uint64_t)b[5] << 16) + ((uint64_t)b[6] << 8) + b[7]; return 8; }
+    *out = (x << 32) + ((uint64_t)b[5] << 24) + ((uint64_t)b[6] << 16) + ((uint64_t)b[7] << 8) + b[8];
+    return 9;
+}
+static int ko_width(int dtype) {
+    switch (dtype) {
+    case KO_I64: case KO_U64: case KO_F64: return 8;
+    case KO_I32: case KO_U32: case KO_F32: return 4;
+    case KO_I16: case KO_U16: return 2;
+    case KO_I8: case KO_U8: return 1;
+    default: return 0;
+    }
+}
+/* RawContainer.Store / FloatRawContainer.Store: returns bytes written */
+KO_EXPORT int64_t ko_raw_container_store(int dtype, const void *values, int64_t n, uint8_t *dst) {
+    int w = ko_width(dtype), isf = (dtype == KO_F64 || dtype == KO_F32);
+    if (!w) return -1;
+    int64_t o = 0;
+    dst[o++] = isf ? 15 : 7;
+    o += ko_put_uvarint(dst + o, isf ? (uint64_t)n * (uint64_t)w : (uint64_t)n);
+    memcpy(dst + o, values, (size_t)n * (size_t)w);
+    return o + n * w;
+}
+/* RawContainer.Load / FloatRawContainer.Load: returns the number of values, copies them to out */
+KO_EXPORT int64_t ko_raw_container_load(int dtype, const uint8_t *buf, int64_t len, void *out, int64_t cap) {
+    int w = ko_width(dtype), isf = (dtype == KO_F64 || dtype == KO_F32);
+    if (!w || len < 2 || buf[0] != (isf ? 15 : 7)) return -1; /* ErrInvalidType */
+    uint64_t v;
+    int k = ko_uvarint(buf + 1, &v);
+    int64_t n = isf ? (int64_t)(v / (uint64_t)w) : (int64_t)v;
+    if (1 + k + n * w > len || n > cap) return -2;
+    memcpy(out, buf + 1 + k, (size_t)n * (size_t)w);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic column generator (shared SPEC with the device generator in
  * knoxdb_amd/csrc/knox_kernels.hip: both sides implement DESIGN.md "synthetic data" from the
  * text, neither calls the other).  Counter based so any row can be produced independently:

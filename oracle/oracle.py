@@ -77,6 +77,14 @@ def lib():
         L.ko_bytes_match.argtypes = [i32, vp, i64, vp, C.c_char_p, i64, vp, vp]
         L.ko_inset.restype = i32
         L.ko_inset.argtypes = [i32, i32, vp, i64, vp, i64, vp, vp]
+        L.ko_put_uvarint.restype = i32
+        L.ko_put_uvarint.argtypes = [vp, u64]
+        L.ko_uvarint.restype = i32
+        L.ko_uvarint.argtypes = [vp, C.POINTER(u64)]
+        L.ko_raw_container_store.restype = i64
+        L.ko_raw_container_store.argtypes = [i32, vp, i64, vp]
+        L.ko_raw_container_load.restype = i64
+        L.ko_raw_container_load.argtypes = [i32, vp, i64, vp, i64]
         L.ko_generate.restype = i32
         L.ko_generate.argtypes = [i32, i32, u64, i64, i64, i64, u64, vp]
         L.ko_scan_i64_bw_sum.restype = i64
@@ -206,6 +214,35 @@ def inset(dtype, negate, src, values, mask=None, bits=None):
     rc = lib().ko_inset(dtype, int(bool(negate)), _p(src), src.size, _p(vals) if vals.size else None, vals.size, _p(out), _p(m))
     assert rc == 0
     return out
+
+
+def put_uvarint(x):
+    b = np.zeros(9, dtype=np.uint8)
+    n = lib().ko_put_uvarint(_p(b), x)
+    return b[:n].tobytes()
+
+
+def uvarint(buf):
+    b = np.frombuffer(bytes(buf) + b"\0" * 9, dtype=np.uint8).copy()
+    v = C.c_uint64()
+    n = lib().ko_uvarint(_p(b), C.byref(v))
+    return v.value, n
+
+
+def raw_container_store(dtype, values):
+    values = np.ascontiguousarray(values, dtype=NP[dtype])
+    out = np.zeros(values.nbytes + 16, dtype=np.uint8)
+    n = lib().ko_raw_container_store(dtype, _p(values) if values.size else None, values.size, _p(out))
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def raw_container_load(dtype, buf):
+    b = np.frombuffer(bytes(buf), dtype=np.uint8).copy()
+    out = np.zeros(len(buf) // np.dtype(NP[dtype]).itemsize + 1, dtype=NP[dtype])
+    n = lib().ko_raw_container_load(dtype, _p(b), b.size, _p(out), out.size)
+    assert n >= 0, n
+    return out[:n].copy()
 
 
 def generate(dtype, kind, seed, first_row, n, lo=0, span=0):
