@@ -237,6 +237,16 @@ int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col
 int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_state *states, int n_aggs,
                       knox_scan_out *out);
 
+/* Matcher.MatchRangeVectors (operator/filter/match.go:66-71; numeric forms match_num.go:357-371,
+ * 396-403, 429-434, 460-465, 491-496, 522-527, 573-588): vectorized zone-map test over the
+ * per-pack min / max statistics columns (one row per pack) -- which packs MAY contain a match.
+ *   EQ: min <= v && max >= v (AND mask)      RANGE: min <= to && max >= from (AND mask)
+ *   NE: mask, or all ones                    GT/GE: max > / >= v      LT/LE: min < / <= v
+ * (the single-column forms ignore the mask exactly like the reference's MatchVector does).
+ * The result feeds knox_scan's pack_skip ("next" row f3: pruning without a host round trip). */
+int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op, uint64_t a,
+                             uint64_t b, const knox_bits *mask /* nullable */, knox_bits *bits);
+
 /* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
 int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,
                 uint64_t row_base, knox_agg_state *state);

@@ -1350,6 +1350,39 @@ KNOX_API int knox_scan(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_
 }
 
 // ------------------------------------------------------------------------------------------------
+// zone-map test over the statistics columns (Matcher.MatchRangeVectors)
+// ------------------------------------------------------------------------------------------------
+KNOX_API int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op, uint64_t a, uint64_t b,
+                                      const knox_bits *mask, knox_bits *bits) {
+    if (!ctx || !mins || !maxs || !bits || mins->n_rows != maxs->n_rows || mins->dtype != maxs->dtype || bits->size != mins->n_rows) return KNOX_E_INVALID;
+    if (mask && mask->size != bits->size) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    knox_col *cols[2] = {const_cast<knox_col *>(mins), const_cast<knox_col *>(maxs)};
+    knox_pred p[3];
+    memset(p, 0, sizeof p);
+    int n = 0;
+    bool and_mask = false;
+    switch (op) {
+    case KNOX_EQ:     // min <= v && max >= v
+        p[0].op = KNOX_LE; p[0].col = 0; p[0].a = a; p[1].op = KNOX_GE; p[1].col = 1; p[1].a = a; p[2].kind = KNOX_NODE_AND; p[2].nchild = 2; n = 3; and_mask = true; break;
+    case KNOX_RANGE:  // min <= to && max >= from
+        p[0].op = KNOX_LE; p[0].col = 0; p[0].a = b; p[1].op = KNOX_GE; p[1].col = 1; p[1].a = a; p[2].kind = KNOX_NODE_AND; p[2].nchild = 2; n = 3; and_mask = true; break;
+    case KNOX_GT: p[0].op = KNOX_GT; p[0].col = 1; p[0].a = a; n = 1; break;  // max > v
+    case KNOX_GE: p[0].op = KNOX_GE; p[0].col = 1; p[0].a = a; n = 1; break;  // max >= v
+    case KNOX_LT: p[0].op = KNOX_LT; p[0].col = 0; p[0].a = a; n = 1; break;  // min < v
+    case KNOX_LE: p[0].op = KNOX_LE; p[0].col = 0; p[0].a = a; n = 1; break;  // min <= v
+    case KNOX_NE: case KNOX_NOTIN:  // undecided, always true: bits.Copy(mask) or bits.One()
+        return mask ? knox_bits_copy(ctx, bits, mask) : knox_bits_one(ctx, bits);
+    default: return KNOX_E_UNSUPPORTED;
+    }
+    knox_scan_out out;
+    int rc = knox_scan(ctx, p, n, cols, 2, nullptr, 0, 0, nullptr, bits, nullptr, nullptr, &out);
+    if (rc) return rc;
+    if (and_mask && mask) rc = knox_bits_and(ctx, bits, mask);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // knox_cmp: the finest boundary (host slices in, host bitset out)
 // ------------------------------------------------------------------------------------------------
 KNOX_API int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, size_t n, const void *a, const void *b, uint8_t *bits) {

@@ -339,6 +339,15 @@ class Context:
     def _pack_rows(self, col):
         return col.pack_rows or col.rows
 
+    def match_range_vectors(self, mins, maxs, mode, a, b=None, mask=None, bits=None):
+        """Matcher.MatchRangeVectors over per-pack min / max statistics columns -> packs that may match."""
+        out = bits if bits is not None else self.bits(mins.rows)
+        av = value_bits(mins.dtype, a)
+        bv = value_bits(mins.dtype, b) if b is not None else 0
+        check(self.L.knox_match_range_vectors(self.h, mins.h, maxs.h, int(mode), av, bv, mask.h if mask is not None else None, out.h),
+              "knox_match_range_vectors")
+        return out
+
     def reduce(self, col, mask=None, row_base=0):
         st = AggState()
         check(self.L.knox_reduce(self.h, col.h, mask.h if mask is not None else None, row_base, C.byref(st)))

@@ -114,3 +114,43 @@ def test_rccl_single_rank_roundtrip(ctx):
     assert cnt.value == 10000 and out[0].isum == st.isum and out[0].max_row == 9999
     assert L.knox_comm_destroy(ctx.h) == 0
     col.free()
+
+
+def test_zone_map_pruning_match_range_vectors(ctx):
+    """'Next' row f3: the statistics walk on the device.  Per-pack min/max columns -> packs that may
+    match (numeric MatchRangeVectors, match_num.go:357-588), then the pruned scan equals the full scan."""
+    rng = np.random.default_rng(51)
+    pack, n_packs = 2048, 64
+    # clustered data: pack p holds values around 1000*p
+    x = (np.repeat(np.arange(n_packs) * 1000, pack) + rng.integers(0, 900, pack * n_packs)).astype(np.int64)
+    mins_h = x.reshape(n_packs, pack).min(axis=1)
+    maxs_h = x.reshape(n_packs, pack).max(axis=1)
+    col = ctx.upload(x, pack)
+    mins, maxs = ctx.upload(mins_h), ctx.upload(maxs_h)
+    mask_h = np.packbits(rng.random(n_packs) < 0.7, bitorder="little")
+    mask = ctx.bits(n_packs).upload(mask_h)
+    maskb = np.unpackbits(mask_h, bitorder="little")[:n_packs].astype(bool)
+    v, frm, to = 17450, 9100, 13020
+    cases = [(FilterMode.Equal, v, None, (mins_h <= v) & (maxs_h >= v), True),
+             (FilterMode.Range, frm, to, (mins_h <= to) & (maxs_h >= frm), True),
+             (FilterMode.Gt, v, None, maxs_h > v, False), (FilterMode.Ge, v, None, maxs_h >= v, False),
+             (FilterMode.Lt, v, None, mins_h < v, False), (FilterMode.Le, v, None, mins_h <= v, False),
+             (FilterMode.NotEqual, v, None, np.ones(n_packs, bool), True)]
+    for mode, a, b, want, masked in cases:
+        for m in (None, mask):
+            got = ctx.match_range_vectors(mins, maxs, mode, a, b, mask=m)
+            w = want & maskb if (m is not None and masked) else want
+            assert (np.unpackbits(got.bytes(), bitorder="little")[:n_packs].astype(bool) == w).all(), (mode, m is not None)
+            got.free()
+    # prune + scan == full scan
+    maybe = ctx.match_range_vectors(mins, maxs, FilterMode.Range, frm, to)
+    skip = 1 - np.unpackbits(maybe.bytes(), bitorder="little")[:n_packs]
+    bits = ctx.bits(x.size)
+    tree = And(Leaf(0, FilterMode.Range, frm, to))
+    r1 = ctx.scan(tree, [col], aggs=[(ReducerFunc.Sum, 0)], bits_out=bits, pack_skip=skip.astype(np.uint8))
+    b1 = bits.bytes().copy()
+    r2 = ctx.scan(tree, [col], aggs=[(ReducerFunc.Sum, 0)], bits_out=bits)
+    assert (b1 == bits.bytes()).all() and r1.count == r2.count and r1.value(0)[0] == r2.value(0)[0]
+    assert r1.rows_scanned == int((1 - skip).sum()) * pack < x.size
+    for h in (col, mins, maxs, mask, maybe, bits):
+        h.free()
