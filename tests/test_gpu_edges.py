@@ -1,0 +1,170 @@
+"""GPU edge cases and error behaviour of the C ABI: empty / ragged inputs, odd pack sizes, the
+result ring, borrowed device memory on a caller's stream, error codes instead of crashes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf, Or, _lib
+from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc as R
+from oracle import oracle as O
+from helpers import oracle_match, rand_col
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def test_empty_column_scan(ctx):
+    col = ctx.upload(np.zeros(0, np.int64), 1024)
+    bits = ctx.bits(0)
+    res = ctx.scan(And(Leaf(0, FilterMode.Ge, 0)), [col], aggs=[(R.Sum, 0), (R.Min, 0)], bits_out=bits)
+    assert res.count == 0 and bits.bytes().size == 0
+    assert res.value(0) == (0, False, -1) and res.value(1)[1] is False   # Value() of an unseen reducer
+    assert bits.count() == 0 and bits.indexes().size == 0
+    col.free(); bits.free()
+
+
+@pytest.mark.parametrize("pack_rows", [64, 192, 1000 * 64, 4096])
+def test_odd_pack_sizes_and_short_last_pack(ctx, pack_rows):
+    rng = np.random.default_rng(pack_rows)
+    n = 7 * pack_rows + pack_rows // 2 + 3 if pack_rows > 64 else 1000
+    n -= n % 1  # any n
+    x = rand_col(BlockType.Int32, n, rng)
+    col = ctx.upload(x, pack_rows)
+    bits = ctx.bits(n)
+    tree = And(Leaf(0, FilterMode.Gt, 3))
+    n_packs = (n + pack_rows - 1) // pack_rows
+    skip = (rng.random(n_packs) < 0.3).astype(np.uint8)
+    want, cnt = O.cmp(O.I32, O.GT, x, 3)
+    # zero the rows of skipped packs in the expectation only if they hold no match (contract); here we
+    # give skip flags that are TRUE to the contract by pruning only packs without matches
+    per_pack = [int(np.unpackbits(want, bitorder="little")[p * pack_rows:min(n, (p + 1) * pack_rows)].sum()) for p in range(n_packs)]
+    skip = np.array([1 if (skip[p] and per_pack[p] == 0) else 0 for p in range(n_packs)], dtype=np.uint8)
+    res = ctx.scan(tree, [col], aggs=[(R.Count, 0)], bits_out=bits, pack_counts=True, pack_skip=skip)
+    assert (bits.bytes(poison=16) == want).all() and res.count == cnt
+    assert res.pack_counts.tolist() == per_pack
+    col.free(); bits.free()
+
+
+def test_result_ring_is_fifo_and_bounded(ctx):
+    x = np.arange(100000, dtype=np.int64)
+    col = ctx.upload(x, 1024)
+    plans = [ctx.plan(And(Leaf(0, FilterMode.Lt, k)), [col], aggs=[(R.Count, 0)]) for k in (10, 200, 3000, 40000, 5)]
+    for p in plans[:4]:
+        ctx.scan_async(p)
+    with pytest.raises(K.KnoxError) as e:   # a 5th uncollected scan
+        ctx.scan_async(plans[4])
+    assert e.value.code == -8
+    with pytest.raises(K.KnoxError) as e:   # the synchronous form refuses to jump the queue
+        ctx.scan(And(Leaf(0, FilterMode.Lt, 1)), [col])
+    assert e.value.code == -8
+    assert [ctx.scan_collect(p).count for p in plans[:4]] == [10, 200, 3000, 40000]
+    with pytest.raises(K.KnoxError):        # nothing left to collect
+        ctx.scan_collect(plans[0])
+    col.free()
+
+
+def test_error_codes_instead_of_crashes(ctx):
+    L = _lib.lib()
+    x = ctx.upload(np.arange(1000, dtype=np.int64), 128)
+    y = ctx.upload(np.arange(999, dtype=np.int64), 128)
+    with pytest.raises(K.KnoxError) as e:     # columns of different length
+        ctx.scan(And(Leaf(0, FilterMode.Lt, 5), Leaf(1, FilterMode.Lt, 5)), [x, y])
+    assert e.value.code == -1
+    with pytest.raises(K.KnoxError) as e:     # bitset of the wrong size
+        ctx.scan(And(Leaf(0, FilterMode.Lt, 5)), [x], bits_out=ctx.bits(999))
+    assert e.value.code == -1
+    with pytest.raises(K.KnoxError) as e:     # var / std are not fused
+        ctx.scan(And(Leaf(0, FilterMode.Lt, 5)), [x], aggs=[(R.Var, 0)])
+    assert e.value.code == -5
+    a, b = ctx.bits(100), ctx.bits(101)
+    with pytest.raises(K.KnoxError):          # size mismatch: error here, silent no-op in Go
+        a.and_(b)
+    h = C.c_void_p()
+    assert L.knox_col_upload(ctx.h, 99, None, 0, 0, C.byref(h)) == -1          # unknown dtype
+    assert L.knox_col_wrap(ctx.h, 1, C.c_void_p(8), 10, 0, C.byref(h)) == -1   # misaligned device pointer
+    assert L.knox_cmp(None, 1, 1, None, 0, None, None, None) == -1
+    assert L.knox_ctx_open(12345, C.byref(h)) == -1
+    ptr = np.array([(0 << 32) | 9999], dtype=np.uint64)                        # (off,len) outside buf
+    assert L.knox_col_upload_bytes(ctx.h, ptr.ctypes.data_as(C.c_void_p), 1, np.zeros(4, np.uint8).ctypes.data_as(C.c_void_p), 4, 0, C.byref(h)) == -7
+    for o in (x, y, a, b):
+        o.free()
+
+
+_TORCH_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch                      # torch's HIP runtime must initialise before libknoxgpu's
+t = torch.arange(0, 1 << 20, dtype=torch.int64, device="cuda") * 3 - 1000
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf
+from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc as R
+s = torch.cuda.current_stream()
+c = K.Context(0, stream=s.cuda_stream)
+col = c.wrap(BlockType.Int64, t.data_ptr(), t.numel(), 1 << 16, keep=t)
+bits = c.bits(t.numel())
+res = c.scan(And(Leaf(0, FilterMode.Range, 0, 999999)), [col], aggs=[(R.Sum, 0), (R.Count, 0)], bits_out=bits)
+h = t.cpu().numpy()
+sel = (h >= 0) & (h <= 999999)
+assert res.count == int(sel.sum()) and int(res.value(0)[0]) == int(h[sel].sum())
+assert (bits.bytes() == np.packbits(sel, bitorder="little")).all()
+col.free(); bits.free(); c.close()
+assert int(t[5].item()) == -985   # borrowed memory is never freed by knox
+print("torch-borrowed ok")
+"""
+
+
+def test_borrowed_torch_memory_on_the_callers_stream():
+    # own process: torch bundles its own HIP runtime, which has to come up before libknoxgpu's
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _TORCH_SCRIPT % root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "torch-borrowed ok" in out.stdout, out.stdout + out.stderr
+
+
+def _free_device_memory():
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_many_alloc_free_cycles_do_not_leak(ctx):
+    ctx.sync()
+    free0 = _free_device_memory()
+    for _ in range(30):
+        col = ctx.generate(BlockType.Int64, 0, 1, 1 << 22, lo=0, span=100)
+        bits = ctx.bits(1 << 22)
+        ctx.scan(And(Leaf(0, FilterMode.Lt, 50)), [col], aggs=[(R.Sum, 0)], bits_out=bits)
+        col.free(); bits.free()
+    assert free0 - _free_device_memory() < (64 << 20)
+
+
+def test_four_leaf_mixed_float_int_tree_all_widths(ctx):
+    rng = np.random.default_rng(77)
+    n = 50000 + 13
+    for bts in ((BlockType.Int32, BlockType.Float32, BlockType.Uint32, BlockType.Int32),
+                (BlockType.Int16, BlockType.Uint16, BlockType.Int16, BlockType.Uint16),
+                (BlockType.Int8, BlockType.Uint8, BlockType.Uint8, BlockType.Int8),
+                (BlockType.Float64, BlockType.Int64, BlockType.Uint64, BlockType.Float64)):
+        cols = [rand_col(b, n, rng) for b in bts]
+        L = Leaf
+        tree = And(Or(L(0, FilterMode.Lt, cols[0][1]), L(1, FilterMode.Ge, cols[1][2])), Or(L(2, FilterMode.NotEqual, cols[2][3]), L(3, FilterMode.Range, cols[3][4], cols[3][4])))
+        dev = [ctx.upload(c, 4096) for c in cols]
+        bits = ctx.bits(n)
+        res = ctx.scan(tree, dev, aggs=[(R.Count, 0)], bits_out=bits)
+        want = oracle_match(tree, cols, n)
+        assert (bits.bytes(poison=8) == want).all() and res.count == O.popcount(want, n), bts
+        for d in dev:
+            d.free()
+        bits.free()
