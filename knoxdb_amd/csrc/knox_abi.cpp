@@ -966,7 +966,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     } else {
         a.pack_shift = 255;
     }
-    a.debug = ctx->variant == 2 ? 1u : 0u;  // variant 2: diagnostics, bitset assembled but not stored
+    a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
     // auto occupancy: the pure streaming passes run best at 2 workgroups per CU, VALU-heavier ones at 3
     const bool heavy = n_leaves > 1 || (agg_col && (agg & ~A_ISUM) != 0);
@@ -975,9 +975,10 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     if (slot != 15) prof_mark(ctx, 0);
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, ctx->variant, a);
     if (slot != 15) prof_mark(ctx, 1);
-    if (e == hipSuccess) e = launch_scan_tail(ctx->stream, width, n_leaves, agg, g, a);
+    const bool has_tail = a.tail_first_row < a.n_rows;
+    if (e == hipSuccess && has_tail) e = launch_scan_tail(ctx->stream, width, n_leaves, agg, g, a);
     if (e == hipSuccess)
-        e = launch_finalize(ctx->stream, width, a.partials, g + 1, agg_col ? agg_col->dev : nullptr, row_base, dtype_for_state,
+        e = launch_finalize(ctx->stream, width, a.partials, g + (has_tail ? 1 : 0), agg_col ? agg_col->dev : nullptr, row_base, dtype_for_state,
                             (AggStateDev *)ctx->states.p + slot, (int64_t *)((AggStateDev *)ctx->states.p + 16) + slot);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
@@ -1154,7 +1155,11 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->states.p, 0, sizeof(AggStateDev) * 16 + 8 * 16, ctx->stream));
+    // device result block: [16 states][16 int64 counts][n_packs int64 pack counts] -> ONE D2H copy
+    const size_t res_base = sizeof(AggStateDev) * 16 + 8 * 16;
+    const size_t res_bytes = res_base + (want_pack_counts ? n_packs * 8 : 0);
+    rc = ensure(ctx, ctx->states, res_bytes + 64);
+    if (rc) return rc;
     SkipPlan skip;
     uint64_t rows_pruned = 0;
     if (pack_skip && n_packs) {
@@ -1285,6 +1290,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         if (sp != 1) return KNOX_E_INVALID;
         // total count (slot 0 count word) from the final bitset
         unsigned long long *d_cnt = (unsigned long long *)((int64_t *)((AggStateDev *)ctx->states.p + 16));
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
         hipError_t e = launch_popcount(ctx->stream, bits, n_rows, d_cnt);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         first_reduce_slot = 0;
@@ -1300,18 +1306,14 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     slot.has_pack_counts = false;
     slot.n_packs = n_packs;
     if (want_pack_counts && n_packs) {
-        rc = ensure(ctx, ctx->pack_counts, n_packs * 8 + 8);
-        if (!rc) rc = ensure_host(ctx, slot.h_packs, slot.h_packs_cap, n_packs * 8);
-        if (rc) return rc;
-        hipError_t e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)ctx->pack_counts.p, n_packs);
+        hipError_t e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)((char *)ctx->states.p + res_base), n_packs);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-        HIPCHK(ctx, hipMemcpyAsync(slot.h_packs, ctx->pack_counts.p, n_packs * 8, hipMemcpyDeviceToHost, ctx->stream));
         slot.has_pack_counts = true;
     }
-    // ---- small results -> this scan's pinned mirror, then its completion event
-    rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, sizeof(AggStateDev) * 16 + 8 * 16);
+    // ---- small results -> this scan's pinned mirror (one copy), then its completion event
+    rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, res_bytes);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(slot.h_res, ctx->states.p, sizeof(AggStateDev) * 16 + 8 * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(slot.h_res, ctx->states.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (!slot.done) HIPCHK(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(slot.done, ctx->stream));
     ctx->res_head++;
@@ -1334,7 +1336,7 @@ KNOX_API int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_sta
     }
     if (pack_counts) {
         if (!slot.has_pack_counts) return KNOX_E_INVALID;
-        memcpy(pack_counts, slot.h_packs, slot.n_packs * 8);
+        memcpy(pack_counts, (const char *)slot.h_res + sizeof(AggStateDev) * 16 + 8 * 16, slot.n_packs * 8);
     }
     return KNOX_OK;
 }

@@ -494,7 +494,9 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             for (uint32_t v = lane; v < nv; v += 64) {
                 const u32x4 x = ((const u32x4 *)stage[wave])[v];
                 // debug bit0 = diagnostics: words are assembled but never leave the CU
-                if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
+                if (a.debug & 2u) dst[v] = x;  // diagnostics: plain (L2 write-back) store
+                else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
+                else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
             }
         }
     }
@@ -856,7 +858,18 @@ __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bi
         uint64_t w1 = w0 + seg_words;
         if (w1 > nwords) w1 = nwords;
         uint64_t c = 0;
-        for (uint64_t i = w0 + threadIdx.x; i < w1; i += blockDim.x) c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+        if (((w0 | w1) & 1) == 0 && w1 < nwords) {
+            // whole 16-byte vectors, no partial last word in this segment: 16 B per lane, 4 loads in flight
+            const u32x4 *v = (const u32x4 *)(bits + w0);
+            const uint64_t nvec = (w1 - w0) >> 1;
+#pragma unroll 4
+            for (uint64_t k = threadIdx.x; k < nvec; k += blockDim.x) {
+                const u32x4 x = v[k];
+                c += __builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w);
+            }
+        } else {
+            for (uint64_t i = w0 + threadIdx.x; i < w1; i += blockDim.x) c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;

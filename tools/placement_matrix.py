@@ -23,14 +23,18 @@ def run(col, steps):
     v = [ms[i] for i in range(k.value)]
     return n * 8.125 / statistics.median(v[len(v) // 2:]) / 1e6
 run(cols[0], 60)
-configs = [(it, bpc) for bpc in (2, 3) for it in (1, 2, 4, 8, 16)]
-print("col | " + " ".join("i%-2d/b%d" % c for c in configs))
+mode = sys.argv[3] if len(sys.argv) > 3 else "iters"
+if mode == "iters":
+    configs = [(it, bpc, 1) for bpc in (2, 3) for it in (1, 2, 4, 8, 16)]
+else:  # store flavours at iters=2, 2 WG/CU: nt (1), none (2), plain (3), write-through (4)
+    configs = [(2, 2, v) for v in (1, 2, 3, 4)]
+print("col | " + " ".join("i%-2d/b%d/v%d" % c for c in configs))
 res = []
 for ci, col in enumerate(cols):
     row = []
-    for it, bpc in configs:
+    for it, bpc, var in configs:
         os.environ["KNOX_ITERS"] = str(it)
-        ctx.set_tuning(bpc, -1)
+        ctx.set_tuning(bpc, var)
         row.append(run(col, 14))
     res.append(row)
     print("%3d | " % ci + " ".join("%6.0f" % x for x in row))
