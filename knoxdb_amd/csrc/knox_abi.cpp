@@ -969,8 +969,11 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
     // auto occupancy: the pure streaming passes run best at 2 workgroups per CU, VALU-heavier ones at 3
-    const bool heavy = n_leaves > 1 || (agg_col && (agg & ~A_ISUM) != 0);
-    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (heavy ? 3 : 2);
+    // (profiles/r01_sweep_blocks_per_cu.txt): 8-byte / 4-byte integer streaming 2 WG/CU; float or min-max
+    // aggregates, several leaves, 2-byte types 3; 1-byte types and float32 sums (VALU bound) 8
+    const bool heavy = n_leaves > 1 || (agg_col && (agg & ~A_ISUM) != 0) || width == 2;
+    const bool very_heavy = width == 1 || (width == 4 && agg_col && (agg & A_FSUM) != 0);
+    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (very_heavy ? 8 : heavy ? 3 : 2);
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
     if (slot != 15) prof_mark(ctx, 0);
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, ctx->variant, a);
@@ -1151,7 +1154,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     slot.n_aggs = n_aggs;
 
     // ---- workspace
-    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 3));
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8));
     int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
@@ -1401,7 +1404,7 @@ KNOX_API int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, siz
     if (rc) return rc;
     rc = ensure(ctx, ctx->tmp_vals, n * (size_t)w + 512);
     if (!rc) rc = ensure(ctx, ctx->tmp_bits, (bits_padded(n) + 64) * 8);
-    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 3));
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8));
     if (!rc) rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
@@ -1428,7 +1431,7 @@ KNOX_API int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *ma
     if (!ctx || !col || !state || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;
     if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
-    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 3));
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8));
     int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;

@@ -163,7 +163,7 @@ class Bits:
         return out
 
     def indexes(self, capacity=None):
-        cap = self.size + 8 if capacity is None else capacity
+        cap = self.count() + 8 if capacity is None else capacity  # Bitset.Indexes pads the result by 7 (iterator.go:277-289)
         out = np.zeros(max(cap, 1), dtype=np.uint32)
         n = C.c_size_t()
         check(_lib.lib().knox_bits_indexes(self.ctx.h, self.h, _ptr(out), cap, C.byref(n)))

@@ -29,6 +29,14 @@ if args.dtype == "i64":
     col = ctx.generate(BlockType.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=1 << 20)
     tree = And(Leaf(0, FilterMode.Range, -(1 << 38), 1 << 38))
     bpr = 8.125
+elif args.dtype in ("i32", "i16", "u8", "f32"):
+    bt, w, lo, span, a, b = {"i32": (BlockType.Int32, 4, -(1 << 30), 1 << 31, -(1 << 28), 1 << 28),
+                             "i16": (BlockType.Int16, 2, -(1 << 15), 1 << 16, -(1 << 13), 1 << 13),
+                             "u8": (BlockType.Uint8, 1, 0, 256, 64, 127),
+                             "f32": (BlockType.Float32, 4, 0, 0, 0.25, 0.5)}[args.dtype]
+    col = ctx.generate(bt, 2 if args.dtype == "f32" else 0, 2, n, lo=lo, span=span, pack_rows=1 << 20)
+    tree = And(Leaf(0, FilterMode.Range, a, b))
+    bpr = w + 0.125
 else:
     col = ctx.generate(BlockType.Float64, 1, 3, n, pack_rows=1 << 20)
     tree = And(Leaf(0, FilterMode.Ge, 256.0))
@@ -60,5 +68,5 @@ for r in range(args.rounds + 1):
 print("%-6s %-4s %-10s %10s %10s %10s %8s" % ("bpc", "var", "mode", "median_ms", "min_ms", "GB/s(med)", "frac8T"))
 for c in configs:
     med, mn = statistics.median(times[c]), min(times[c])
-    gbs = n * (8.0 if c[2] == "count" else bpr) / (med * 1e-3) / 1e9
+    gbs = n * ((bpr - 0.125) if c[2] == "count" else bpr) / (med * 1e-3) / 1e9
     print("%-6d %-4d %-10s %10.4f %10.4f %10.1f %8.3f" % (c[0], c[1], c[2], med, mn, gbs, gbs / 8000))
