@@ -1005,7 +1005,8 @@ static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, 
     a.mask = mask;
     a.pack_shift = 255;
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
-    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
+    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (col->width == 1 || (col->width == 4 && dtype_is_float(col->dtype)) ? 8 : 3);
+    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
     hipError_t e = launch_reduce(ctx->stream, col->width, agg, g, a);
     if (e == hipSuccess)
         e = launch_finalize(ctx->stream, col->width, a.partials, g + 1, col->dev, row_base, col->dtype, (AggStateDev *)ctx->states.p + slot,
