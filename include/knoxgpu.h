@@ -250,6 +250,19 @@ int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col
 /* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
 int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,
                 uint64_t row_base, knox_agg_state *state);
+/* Time-window aggregation ("next" row f1): what pkg/series feeds row-at-a-time into
+ * NativeBucket.Push (internal/reducer/bucket_native.go:104-159): one reducer per window
+ * [t_from + k*step, t_from + (k+1)*step), k < n_buckets, over the rows `mask` selects.
+ * time_col is an int64 column (the reference's time field is int64 internally) that must be
+ * NON-DECREASING over the scanned rows -- then every window is one contiguous row range and the
+ * result equals the reference's for any reducer; out-of-order timestamps (which the reference
+ * handles by inserting reducers) return KNOX_E_UNSUPPORTED so the caller keeps the host path.
+ * states[k] is the window's mergeable state (count == 0: the reference created no reducer).
+ * flags bit0: the caller guarantees the order, skip the verification pass.                   */
+int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
+                        const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
+                        size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states);
+
 /* Literal sequential reducer (one lane, row order) -- reproduces reducer.go bit for bit,
  * including Welford mean/var; slow, used for parity tests on small inputs.                  */
 int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, int func,

@@ -103,6 +103,7 @@ SIGNATURES = {
     "knox_scan_collect": (_i, [_vp, _vp, C.POINTER(AggState), _i, C.POINTER(ScanOut)]),
     "knox_match_range_vectors": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _vp, _vp]),
     "knox_reduce": (_i, [_vp, _vp, _vp, _u64, C.POINTER(AggState)]),
+    "knox_reduce_buckets": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(AggState)]),
     "knox_reduce_sequential": (_i, [_vp, _vp, _vp, _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_value": (_i, [C.POINTER(AggState), _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_combine": (_i, [C.POINTER(AggState), _i, C.POINTER(AggState)]),

@@ -421,7 +421,8 @@ static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bo
     if (alloc) {
         // pad to a whole 16-byte vector so the streaming kernels never read past the allocation
         size_t bytes = ((n_rows * (size_t)w + 255) & ~(size_t)255) + 256;
-        hipError_t e = hipMalloc(&c->dev, bytes);
+        const char *fl = getenv("KNOX_COL_MALLOC_FLAGS");  // diagnostics: hipExtMallocWithFlags flag (e.g. 4 = contiguous)
+        hipError_t e = (fl && atoi(fl) > 0) ? hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl)) : hipMalloc(&c->dev, bytes);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             delete c;
@@ -1441,6 +1442,80 @@ KNOX_API int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *ma
     HIPCHK(ctx, hipMemcpyAsync(state, ctx->states.p, sizeof(knox_agg_state), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KNOX_OK;
+}
+
+KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
+                                 int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
+    if (!ctx || !time_col || !value_col || !states || step <= 0 || n_buckets == 0 || n_buckets > (1u << 26)) return KNOX_E_INVALID;
+    if (time_col->dtype != KNOX_INT64 || value_col->dtype == KNOX_BYTES || time_col->n_rows != value_col->n_rows) return KNOX_E_INVALID;
+    if (mask && mask->size != value_col->n_rows) return KNOX_E_INVALID;
+    // every window edge must be representable
+    if ((__int128)t_from + (__int128)step * (__int128)n_buckets > (__int128)INT64_MAX) return KNOX_E_RANGE;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    const size_t n_rows = value_col->n_rows;
+    int rc = ensure(ctx, ctx->misc, 256);
+    if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + (n_buckets + 2) * 4 + 64);
+    if (rc) return rc;
+    // 1. order check (one streaming pass over the time column) unless the caller vouches for it
+    uint32_t *d_flag = (uint32_t *)((char *)ctx->misc.p + 32);
+    if (!(flags & 1)) {
+        HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    }
+    // 2. first row of every window edge
+    uint64_t *d_start = (uint64_t *)ctx->idx_scratch.p;
+    hipError_t e = launch_bucket_bounds(ctx->stream, (const int64_t *)time_col->dev, n_rows, t_from, step, n_buckets, d_start);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    std::vector<uint64_t> start(n_buckets + 1);
+    uint32_t unsorted = 0;
+    HIPCHK(ctx, hipMemcpyAsync(start.data(), d_start, (n_buckets + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!(flags & 1)) HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (unsorted) return KNOX_E_UNSUPPORTED;  // out-of-order timestamps: the reference's insert path, host only
+    // 3. work items: each window's row range cut into chunks
+    const uint64_t chunk = 1u << 16;
+    std::vector<BucketItem> items;
+    std::vector<uint32_t> item_start(n_buckets + 1);
+    for (size_t k = 0; k < n_buckets; k++) {
+        item_start[k] = (uint32_t)items.size();
+        for (uint64_t b = start[k]; b < start[k + 1]; b += chunk) {
+            BucketItem it;
+            it.begin = b;
+            it.end = std::min<uint64_t>(b + chunk, start[k + 1]);
+            it.bucket = (uint32_t)k;
+            it._pad = 0;
+            items.push_back(it);
+        }
+    }
+    item_start[n_buckets] = (uint32_t)items.size();
+    const size_t n_items = items.size();
+    const size_t off_items = 0, off_istart = (n_items * sizeof(BucketItem) + 63) & ~(size_t)63;
+    const size_t off_partials = (off_istart + (n_buckets + 1) * 4 + 63) & ~(size_t)63;
+    const size_t off_states = (off_partials + n_items * sizeof(AggPartial) + 63) & ~(size_t)63;
+    rc = ensure(ctx, ctx->tmp_vals, off_states + n_buckets * sizeof(AggStateDev) + 64);
+    if (rc) return rc;
+    char *base = (char *)ctx->tmp_vals.p;
+    if (n_items) HIPCHK(ctx, hipMemcpyAsync(base + off_items, items.data(), n_items * sizeof(BucketItem), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(base + off_istart, item_start.data(), (n_buckets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors are not retained
+    // 4. reduce every work item, then merge per window in row order
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.agg_col = value_col->dev;
+    a.agg_flavor = dtype_flavor(value_col->dtype);
+    a.mask = mask ? (const uint32_t *)mask->dev : nullptr;
+    a.n_rows = n_rows;
+    a.row_base = row_base;
+    a.partials = (AggPartial *)(base + off_partials);
+    const int grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cus * 8);
+    e = launch_bucket_reduce(ctx->stream, value_col->width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
+    if (e == hipSuccess)
+        e = launch_bucket_finalize(ctx->stream, value_col->width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, value_col->dev,
+                                   row_base, value_col->dtype, (AggStateDev *)(base + off_states));
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    return download(ctx, states, base + off_states, n_buckets * sizeof(AggStateDev));
 }
 
 KNOX_API int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, int func, void *value_out, int *seen,

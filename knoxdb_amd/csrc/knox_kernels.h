@@ -86,6 +86,23 @@ hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials,
                            const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out,
                            int64_t *count_out);
 
+// ---- time-window (bucket) aggregation over a non-decreasing int64 time column ----------------
+struct BucketItem {        // one work item: a chunk of one window's contiguous row range
+    uint64_t begin, end;   // rows [begin, end)
+    uint32_t bucket;
+    uint32_t _pad;
+};
+// flag[0] |= 1 if time[i] > time[i+1] for some i
+hipError_t launch_sorted_check(hipStream_t s, const int64_t *time, uint64_t n_rows, uint32_t *flag);
+// row_start[k] = first row with time >= t_from + k*step, k = 0..n_buckets
+hipError_t launch_bucket_bounds(hipStream_t s, const int64_t *time, uint64_t n_rows, int64_t t_from, int64_t step,
+                                uint64_t n_buckets, uint64_t *row_start);
+// one partial per work item (a.partials[item]); a.agg_col / a.agg_flavor / a.mask / a.row_base as in launch_reduce
+hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items);
+// state_out[k] = ordered merge of partials[item_start[k] .. item_start[k+1])
+hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                  const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out);
+
 // bitset combinators on 64-bit words (buffers padded to a multiple of 8 bytes)
 enum BitOp { BIT_AND = 0, BIT_ANDNOT = 1, BIT_OR = 2, BIT_XOR = 3, BIT_NEG = 4, BIT_COPY = 5, BIT_ONE = 6 };
 hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *src, uint64_t size_bits,

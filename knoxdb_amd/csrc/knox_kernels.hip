@@ -251,11 +251,13 @@ struct FirstLast {
         constexpr int RPL = 64 * K;
         if (first_qq != 0) {
             const int b = __builtin_ctzll(first_qq);
-            acc.firstrow = row_base + first_row0 + (uint64_t)(b / K) * RPL + (uint64_t)lane * K + (uint64_t)(b % K);
+            const uint64_t r = row_base + first_row0 + (uint64_t)(b / K) * RPL + (uint64_t)lane * K + (uint64_t)(b % K);
+            acc.firstrow = r < acc.firstrow ? r : acc.firstrow;
         }
         if (last_qq != 0) {
             const int b = 63 - __builtin_clzll(last_qq);
-            acc.lastrow1 = row_base + last_row0 + (uint64_t)(b / K) * RPL + (uint64_t)lane * K + (uint64_t)(b % K) + 1;
+            const uint64_t r1 = row_base + last_row0 + (uint64_t)(b / K) * RPL + (uint64_t)lane * K + (uint64_t)(b % K) + 1;
+            acc.lastrow1 = r1 > acc.lastrow1 ? r1 : acc.lastrow1;
         }
     }
 };
@@ -767,6 +769,184 @@ hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials,
     case 4: KNOX_LAUNCH((finalize_kernel<4>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
     case 2: KNOX_LAUNCH((finalize_kernel<2>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
     case 1: KNOX_LAUNCH((finalize_kernel<1>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-window aggregation ("next" row f1): pkg/series/series.go:192-246 -> NativeBucket.Push
+// (internal/reducer/bucket_native.go:104-159) keeps one reducer per window [from + k*step,
+// from + (k+1)*step).  With a non-decreasing time column every window is ONE contiguous row range:
+// the ranges come from a binary search per window edge, are cut into work items, each work item is
+// reduced by one workgroup with the same exact machinery as the global aggregates, and the
+// partials of a window are merged in row order.  Out-of-order timestamps (which the reference
+// handles by inserting reducers, :123-141) are detected and refused: the caller keeps the host path.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) sorted_check_kernel(const int64_t *time, uint64_t n_rows, uint32_t *flag) {
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    const uint64_t npairs = n_rows >> 1;  // 16-byte vectors of two timestamps
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < ((npairs + 63) & ~63ull); v += (uint64_t)gridDim.x * blockDim.x) {
+        int64_t e0 = INT64_MIN, e1 = INT64_MIN;
+        const bool in = v < npairs;
+        if (in) {
+            const u32x4 r = ld16<true>((const u32x4 *)time + v);
+            e0 = (int64_t)(((uint64_t)r.y << 32) | r.x);
+            e1 = (int64_t)(((uint64_t)r.w << 32) | r.z);
+            bad = bad || e0 > e1;
+        }
+        int64_t nxt = (int64_t)__shfl_down((unsigned long long)e0, 1, 64);  // first timestamp of the next lane's pair
+        if (lane == 63 || v + 1 >= npairs) nxt = (2 * v + 2 < n_rows) ? time[2 * v + 2] : INT64_MAX;
+        if (in) bad = bad || e1 > nxt;
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_sorted_check(hipStream_t s, const int64_t *time, uint64_t n_rows, uint32_t *flag) {
+    if (n_rows < 2) return hipSuccess;
+    uint64_t g = ((n_rows >> 1) + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    if (g == 0) g = 1;
+    KNOX_LAUNCH(sorted_check_kernel, (int)g, time, n_rows, flag);
+}
+
+__global__ void __launch_bounds__(kBlock) bucket_bounds_kernel(const int64_t *time, uint64_t n_rows, int64_t t_from, int64_t step,
+                                                               uint64_t n_buckets, uint64_t *row_start) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_buckets) return;
+    const int64_t edge = t_from + (int64_t)k * step;  // host checked: no overflow
+    uint64_t lo = 0, hi = n_rows;                    // lower_bound(time, edge)
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (time[mid] < edge) lo = mid + 1; else hi = mid;
+    }
+    row_start[k] = lo;
+}
+
+hipError_t launch_bucket_bounds(hipStream_t s, const int64_t *time, uint64_t n_rows, int64_t t_from, int64_t step, uint64_t n_buckets,
+                                uint64_t *row_start) {
+    KNOX_LAUNCH(bucket_bounds_kernel, (int)((n_buckets + 1 + kBlock - 1) / kBlock), time, n_rows, t_from, step, n_buckets, row_start);
+}
+
+template <int W, unsigned AGG, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_reduce_kernel(const ScanArgs a, const BucketItem *items, uint32_t n_items) {
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint8_t *mask8 = (const uint8_t *)a.mask;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint64_t rb = items[it].begin, re = items[it].end;
+        Acc acc;
+        acc.init();
+        WaveMM wm;
+        wm.init();
+        FirstLast fl;
+        fl.init();
+        uint32_t cnt32 = 0;
+        // aligned middle: whole wave tiles, vector path
+        const uint64_t a0 = (rb + WAVE_ROWS - 1) / WAVE_ROWS, a1 = re / WAVE_ROWS;  // tile indices [a0, a1)
+        for (uint64_t t = a0 + wave; t < a1; t += kWavesPerBlock) {
+            const uint64_t row0 = t * WAVE_ROWS;
+            const u32x4 *p = (const u32x4 *)a.agg_col + row0 / K + lane;
+            u32x4 ra[kUnroll];
+            uint32_t q[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                ra[u] = ld16<true>(p + u * 64);
+                q[u] = a.mask ? a.mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                q[u] = (q[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+                cnt32 += __builtin_popcount(q[u]);
+            }
+            agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
+        }
+        // ragged edges (or the whole item when it holds no aligned tile): one row per lane, rows
+        // ascending per lane, exact per-row update
+        const uint64_t e0 = a0 < a1 ? a0 * WAVE_ROWS : re;  // head edge [rb, e0)
+        const uint64_t e1 = a0 < a1 ? a1 * WAVE_ROWS : re;  // tail edge [e1, re)
+        for (int part = 0; part < 2; part++) {
+            const uint64_t lo = part == 0 ? rb : e1, hi = part == 0 ? e0 : re;
+            for (uint64_t row = lo + threadIdx.x; row < hi; row += blockDim.x) {
+                const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
+                acc.count += hit;
+                acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+            }
+        }
+        acc.count += cnt32;
+        if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
+        block_reduce_store(acc, a.partials + it);
+        __syncthreads();  // block_reduce_store's LDS is reused by the next item
+    }
+}
+
+template <int W> static hipError_t bucket_reduce_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) KNOX_LAUNCH((bucket_reduce_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+    }
+    if (a.agg_flavor == FL_SIGNED) KNOX_LAUNCH((bucket_reduce_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    KNOX_LAUNCH((bucket_reduce_kernel<W, A_ALL, FL_UNSIGNED>), grid, a, items, n_items);
+}
+
+hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    if (n_items == 0 || grid <= 0) return hipSuccess;
+    switch (width) {
+    case 8: return bucket_reduce_w<8>(s, grid, a, items, n_items);
+    case 4: return bucket_reduce_w<4>(s, grid, a, items, n_items);
+    case 2: return bucket_reduce_w<2>(s, grid, a, items, n_items);
+    case 1: return bucket_reduce_w<1>(s, grid, a, items, n_items);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// one thread per window: ordered merge of its work items' partials, fetch adopted values
+template <int W>
+__global__ void __launch_bounds__(kBlock) bucket_finalize_kernel(const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                                                 const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    Acc t;
+    t.init();
+    for (uint32_t i = item_start[k]; i < item_start[k + 1]; i++) {
+        const AggPartial p = partials[i];
+        Acc b;
+        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo;
+        b.minkey = p.minkey; b.minrow = p.minrow; b.maxkey = p.maxkey; b.maxrow = p.maxrow;
+        b.firstrow = p.firstrow; b.lastrow1 = p.lastrow;
+        t.merge(b);
+    }
+    AggStateDev s;
+    s.dtype = dtype;
+    s.flags = 1u;
+    s.count = (int64_t)t.count;
+    s.isum = t.isum;
+    s.fsum_hi = t.hi;
+    s.fsum_lo = t.lo;
+    s.min_row = t.minrow == kNoRow ? -1 : (int64_t)t.minrow;
+    s.max_row = t.maxrow == kNoRow ? -1 : (int64_t)t.maxrow;
+    s.first_row = t.firstrow == kNoRow ? -1 : (int64_t)t.firstrow;
+    s.last_row = t.lastrow1 == 0 ? -1 : (int64_t)(t.lastrow1 - 1);
+    s.min_bits = s.min_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.minrow - row_base) : 0;
+    s.max_bits = s.max_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.maxrow - row_base) : 0;
+    s.first_bits = s.first_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.firstrow - row_base) : 0;
+    s.last_bits = s.last_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.lastrow1 - 1 - row_base) : 0;
+    state_out[k] = s;
+}
+
+hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                  const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out) {
+    if (n_buckets == 0) return hipSuccess;
+    const int grid = (int)((n_buckets + kBlock - 1) / kBlock);
+    switch (width) {
+    case 8: KNOX_LAUNCH((bucket_finalize_kernel<8>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    case 4: KNOX_LAUNCH((bucket_finalize_kernel<4>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    case 2: KNOX_LAUNCH((bucket_finalize_kernel<2>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    case 1: KNOX_LAUNCH((bucket_finalize_kernel<1>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
     default: return hipErrorInvalidValue;
     }
 }

@@ -353,6 +353,13 @@ class Context:
         check(self.L.knox_reduce(self.h, col.h, mask.h if mask is not None else None, row_base, C.byref(st)))
         return st
 
+    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False):
+        """One mergeable state per time window [t_from + k*step, +step): NativeBucket semantics."""
+        states = (AggState * n_buckets)()
+        check(self.L.knox_reduce_buckets(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
+                                         n_buckets, row_base, 1 if assume_sorted else 0, states), "knox_reduce_buckets")
+        return [states[i] for i in range(n_buckets)]
+
     def reduce_sequential(self, col, func, mask=None):
         out = np.zeros(1, dtype=NP_DTYPE[col.dtype])
         seen, row = C.c_int(), C.c_int64()

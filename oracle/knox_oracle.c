@@ -745,6 +745,90 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Time-window aggregation ("next" row f1): pkg/series/series.go:192-246 feeds every selected row
+ * to NativeBucket.Push (internal/reducer/bucket_native.go:104-159) with its timestamp truncated
+ * to the window start (Interval.TruncateRelative, fixed-duration windows here):
+ *     t = from + floor((ts - from) / step) * step
+ * Push keeps one reducer per window that received a row: the typical case appends a reducer when
+ * t >= next, the out-of-order case binary-searches the reducer list by time and inserts a missing
+ * window in place (:120-141).  Output = (window time, Value()) per reducer in list order.
+ * ---------------------------------------------------------------------------------------- */
+#define KO_BUCKET(NAME, T)                                                                      \
+    typedef struct { int64_t t; int seen; T v; int64_t n; double mean, m2; } NAME##_red;        \
+    static void NAME##_reduce(int func, NAME##_red *r, T x, int64_t t) {                        \
+        switch (func) {                                                                         \
+        case KO_R_COUNT: if (!r->seen) r->t = t; r->v = (T)(r->v + 1); break;                   \
+        case KO_R_SUM: if (!r->seen) r->t = t; r->v = (T)(r->v + x); break;                     \
+        case KO_R_FIRST: if (!r->seen) { r->t = t; r->v = x; } break;                           \
+        case KO_R_LAST: r->t = t; r->v = x; break;                                              \
+        case KO_R_MAX: if (!r->seen || r->v < x) { r->t = t; r->v = x; } break;                 \
+        case KO_R_MIN: if (!r->seen || r->v > x) { r->t = t; r->v = x; } break;                 \
+        default: { /* mean (Welford) */                                                         \
+            if (r->n == 0) r->t = t;                                                            \
+            r->n++;                                                                             \
+            double d = (double)x - r->mean;                                                     \
+            r->mean += d / (double)r->n;                                                        \
+            break; }                                                                            \
+        }                                                                                       \
+        r->seen = 1;                                                                            \
+    }                                                                                           \
+    static int64_t NAME##_run(int func, const int64_t *times, const T *vals, int64_t n, const uint8_t *bits, \
+                              int64_t from, int64_t step, int64_t *out_t, T *out_v, int64_t cap) { \
+        NAME##_red *reds = (NAME##_red *)calloc((size_t)cap + 1, sizeof(NAME##_red));           \
+        int64_t nr = 0, last = 0, next = 0;                                                     \
+        int have_next = 0; /* b.next is the zero time until the first row */                    \
+        for (int64_t i = 0; i < n; i++) {                                                       \
+            if (!KO_SELECTED(i)) continue;                                                      \
+            int64_t d = times[i] - from, q = d / step;                                          \
+            if ((d % step != 0) && ((d < 0) != (step < 0))) q--; /* floor division */           \
+            const int64_t t = from + q * step;                                                  \
+            int64_t target = nr - 1;                                                            \
+            if (!have_next || t >= next) { /* typical case: window boundary crossed :113-121 */ \
+                if (nr >= cap) { free(reds); return -1; }                                       \
+                memset(&reds[nr], 0, sizeof(NAME##_red)); nr++;                                 \
+                last = t; next = t + step; have_next = 1; target++;                             \
+            } else if (t < last) { /* out of order :123-141 */                                  \
+                int64_t idx = 0;                                                                \
+                while (idx < nr && !(reds[idx].t > t)) idx++; /* first reducer after t */       \
+                if (idx == 0 || reds[idx - 1].t + step <= t) {                                  \
+                    if (nr >= cap) { free(reds); return -1; }                                   \
+                    memmove(&reds[idx + 1], &reds[idx], (size_t)(nr - idx) * sizeof(NAME##_red)); \
+                    memset(&reds[idx], 0, sizeof(NAME##_red)); nr++;                            \
+                    target = idx;                                                               \
+                } else target = idx - 1;                                                        \
+            }                                                                                   \
+            NAME##_reduce(func, &reds[target], vals[i], t);                                     \
+        }                                                                                       \
+        for (int64_t k = 0; k < nr; k++) {                                                      \
+            out_t[k] = reds[k].t;                                                               \
+            out_v[k] = (func == KO_R_MEAN) ? (T)reds[k].mean : reds[k].v;                       \
+        }                                                                                       \
+        free(reds);                                                                             \
+        return nr;                                                                              \
+    }
+KO_BUCKET(bk_i64, int64_t) KO_BUCKET(bk_i32, int32_t) KO_BUCKET(bk_i16, int16_t) KO_BUCKET(bk_i8, int8_t)
+KO_BUCKET(bk_u64, uint64_t) KO_BUCKET(bk_u32, uint32_t) KO_BUCKET(bk_u16, uint16_t) KO_BUCKET(bk_u8, uint8_t)
+KO_BUCKET(bk_f64, double) KO_BUCKET(bk_f32, float)
+
+KO_EXPORT int64_t ko_buckets(int dtype, int func, const int64_t *times, const void *vals, int64_t n, const uint8_t *bits,
+                             int64_t from, int64_t step, int64_t *out_t, void *out_v, int64_t cap) {
+    if (step <= 0) return -2;
+    switch (dtype) {
+    case KO_I64: return bk_i64_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_I32: return bk_i32_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_I16: return bk_i16_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_I8:  return bk_i8_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_U64: return bk_u64_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_U32: return bk_u32_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_U16: return bk_u16_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_U8:  return bk_u8_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_F64: return bk_f64_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    case KO_F32: return bk_f32_run(func, times, vals, n, bits, from, step, out_t, out_v, cap);
+    default: return -3;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * IN / NOT IN set matchers on materialized blocks:
  *   integers  numInSetMatcher / numNotInSetMatcher.MatchVector  operator/filter/match_num.go:672-690, :789-808
  *             (membership of uint64(v) in a set built from uint64(T(x)), i.e. equality on T)

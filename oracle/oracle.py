@@ -75,6 +75,8 @@ def lib():
         L.ko_bloom_contains.argtypes = [vp, i64, u64]
         L.ko_bytes_match.restype = i64
         L.ko_bytes_match.argtypes = [i32, vp, i64, vp, C.c_char_p, i64, vp, vp]
+        L.ko_buckets.restype = i64
+        L.ko_buckets.argtypes = [i32, i32, vp, vp, i64, vp, i64, i64, vp, vp, i64]
         L.ko_inset.restype = i32
         L.ko_inset.argtypes = [i32, i32, vp, i64, vp, i64, vp, vp]
         L.ko_put_uvarint.restype = i32
@@ -204,6 +206,19 @@ def bytes_match(op, ptr, buf, val, mask=None, bits=None):
     m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
     cnt = lib().ko_bytes_match(op, _p(ptr), n, _p(buf), bytes(val), len(val), _p(out), _p(m))
     return out, cnt
+
+
+def buckets(dtype, func, times, vals, bits, t_from, step, cap=None):
+    """NativeBucket.Push over the selected rows -> (window times, values) per reducer in list order."""
+    times = np.ascontiguousarray(times, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=NP[dtype])
+    cap = cap or (times.size + 1)
+    out_t = np.zeros(cap, dtype=np.int64)
+    out_v = np.zeros(cap, dtype=NP[dtype])
+    b = np.ascontiguousarray(bits, dtype=np.uint8) if bits is not None else None
+    k = lib().ko_buckets(dtype, func, _p(times), _p(vals), times.size, _p(b), t_from, step, _p(out_t), _p(out_v), cap)
+    assert k >= 0, k
+    return out_t[:k].copy(), out_v[:k].copy()
 
 
 def inset(dtype, negate, src, values, mask=None, bits=None):

@@ -53,6 +53,24 @@ elif args.cfg == 3:
         vals = [res.value(i)[0] for i in range(len(aggs))]
         print(json.dumps({"cfg": 3, "aggs": name, "kernel_ms": ms, "rows_per_s": n / ms * 1e3, "achieved_GBs": gbs,
                           "frac_8TBs": gbs / 8000, "count": res.count, "values": [float(v) for v in vals]}))
+elif args.cfg == 6:
+    # time-window aggregation (next row f1): 2^30 rows, time = row id, windows of 2^16 / 2^10 rows
+    tcol = ctx.generate(BlockType.Int64, 3, 0, n, lo=1_000_000, pack_rows=pack)
+    vcol = ctx.generate(BlockType.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=pack)
+    bits = ctx.bits(n)
+    ctx.scan(And(Leaf(0, FilterMode.Range, -(1 << 38), 1 << 38)), [vcol], bits_out=bits)
+    for step in (1 << 16, 1 << 10):
+        nb = n // step
+        for sorted_flag in (False, True):
+            ctx.reduce_buckets(tcol, vcol, 1_000_000, step, nb, mask=bits, assume_sorted=sorted_flag)
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                st = ctx.reduce_buckets(tcol, vcol, 1_000_000, step, nb, mask=bits, assume_sorted=sorted_flag)
+            dt = (time.perf_counter() - t0) / reps
+            byts = n * (8.125 + (0 if sorted_flag else 8))
+            print(json.dumps({"cfg": "buckets", "windows": nb, "rows_per_window": step, "order_check": not sorted_flag, "call_ms": dt * 1e3,
+                              "rows_per_s": n / dt, "GBs_incl_host": byts / dt / 1e9, "count0": st[0].count}))
 elif args.cfg == 4:
     ids = ctx.generate(BlockType.Uint64, 0, 5, n, lo=0, span=0, pack_rows=pack)   # raw 64-bit ids
     bits = ctx.bits(n)

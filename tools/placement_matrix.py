@@ -9,7 +9,11 @@ lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 ncol = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 n = 1 << lg
 ctx = K.Context(0)
-cols = [ctx.generate(BlockType.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=1 << 20) for _ in range(ncol)]
+cols = []
+for i in range(ncol):
+    if len(sys.argv) > 4:   # alternate allocation flags per column: argv[4] = flag for odd columns
+        os.environ["KNOX_COL_MALLOC_FLAGS"] = sys.argv[4] if (i & 1) else "0"
+    cols.append(ctx.generate(BlockType.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=1 << 20))
 bits = ctx.bits(n)
 ctx.L.knox_prof_enable(ctx.h, 1)
 def run(col, steps):
