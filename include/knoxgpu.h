@@ -119,13 +119,14 @@ int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, s
 /* Bytes column in StringPool layout (pkg/stringx/pool.go:45-58): ptr[i] = off<<32 | len.  */
 int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf,
                           size_t buf_len, size_t pack_rows, knox_col **out);
-/* Ingest the ON-DISK raw containers of consecutive packs without a host decode pass ("next"
- * row f2): bufs[i] is the container of pack i as stored by RawContainer.Store /
- * FloatRawContainer.Store (internal/encode/int_raw.go:73-94, float_raw.go:73-89):
- * [7][uvarint n values][LE values] for integer types, [15][uvarint n bytes][LE values] for
- * floats, uvarint = pkg/num/varint.go (SQLite4-style prefix varint).  The payloads are staged
- * straight into one contiguous HBM column.  Any other container type: KNOX_E_UNSUPPORTED (the
- * caller decodes it on the host as today).                                                  */
+/* Ingest the ON-DISK containers of consecutive packs without a host decode pass ("next" row
+ * f2): bufs[i] is the container of pack i exactly as stored by the reference:
+ *   raw ints    [7][uvarint n values][LE values]            internal/encode/int_raw.go:73-94
+ *   raw floats  [15][uvarint n bytes][LE values]            internal/encode/float_raw.go:73-89
+ *   bit-packed  [4][uvarint For][uvarint log2][uvarint N][packed bits]   int_bitpack.go:93-133
+ * (uvarint = pkg/num/varint.go, a SQLite4-style prefix varint).  Raw payloads are staged straight
+ * into the HBM column; bit-packed payloads cross PCIe packed and are decoded ON THE DEVICE
+ * (bitpack/decode.go:56-74).  Any other container type: KNOX_E_UNSUPPORTED (host decode as today). */
 int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens,
                                    size_t n_bufs, size_t pack_rows, knox_col **out);
 /* Borrow memory that already lives on the device (16-byte aligned); never freed by knox.  */

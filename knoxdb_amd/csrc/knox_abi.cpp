@@ -497,29 +497,63 @@ KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint
     const int w = dtype_width(dtype);
     if (w == 0) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
-    const uint8_t want = dtype_is_float(dtype) ? 15 /* TFloatRaw */ : 7 /* TIntRaw */;
-    std::vector<std::pair<const uint8_t *, size_t>> payload(n_bufs);
-    size_t total = 0;
+    const bool isf = dtype_is_float(dtype);
+    struct Part { const uint8_t *payload; size_t n; bool packed; uint32_t log2; uint64_t minv; size_t bytes; };
+    std::vector<Part> parts(n_bufs);
+    size_t total = 0, max_packed = 0;
     for (size_t i = 0; i < n_bufs; i++) {
         if (!bufs[i] || lens[i] < 2) return KNOX_E_INVALID;
-        if (bufs[i][0] != want) return KNOX_E_UNSUPPORTED;  // encoded container: host decode path
+        const uint8_t type = bufs[i][0];
+        size_t o = 1;
         uint64_t v = 0;
-        const int k = knox_uvarint(bufs[i] + 1, lens[i] - 1, &v);
-        if (k == 0) return KNOX_E_INVALID;
-        const uint64_t n = dtype_is_float(dtype) ? v / (uint64_t)w : v;  // floats store the BYTE count (float_raw.go:75)
-        if (1 + (uint64_t)k + n * (uint64_t)w > lens[i]) return KNOX_E_RANGE;
-        payload[i] = {bufs[i] + 1 + k, (size_t)n};
-        total += (size_t)n;
+        if (type == (isf ? 15 /* TFloatRaw */ : 7 /* TIntRaw */)) {
+            const int k = knox_uvarint(bufs[i] + o, lens[i] - o, &v);
+            if (k == 0) return KNOX_E_INVALID;
+            o += (size_t)k;
+            const uint64_t n = isf ? v / (uint64_t)w : v;  // floats store the BYTE count (float_raw.go:75)
+            if (o + n * (uint64_t)w > lens[i]) return KNOX_E_RANGE;
+            parts[i] = {bufs[i] + o, (size_t)n, false, 0, 0, (size_t)n * (size_t)w};
+        } else if (type == 4 /* TIntBitpacked */ && !isf) {
+            uint64_t minv = 0, l2 = 0, n = 0;  // int_bitpack.go:101-126: [4][For][log2][N][packed]
+            int k = knox_uvarint(bufs[i] + o, lens[i] - o, &minv);
+            if (k == 0) return KNOX_E_INVALID;
+            o += (size_t)k;
+            k = knox_uvarint(bufs[i] + o, lens[i] - o, &l2);
+            if (k == 0 || l2 > 64) return KNOX_E_INVALID;
+            o += (size_t)k;
+            k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
+            if (k == 0) return KNOX_E_INVALID;
+            o += (size_t)k;
+            const uint64_t sz = ((l2 * n + 63) & ~63ull) / 8;  // bitpack.EstimateSize
+            if (o + sz > lens[i]) return KNOX_E_RANGE;
+            parts[i] = {bufs[i] + o, (size_t)n, true, (uint32_t)l2, minv, (size_t)sz};
+            max_packed = std::max(max_packed, (size_t)sz);
+        } else {
+            return KNOX_E_UNSUPPORTED;  // any other container type: host decode path
+        }
+        total += parts[i].n;
     }
     int rc = col_new(ctx, dtype, total, pack_rows, true, out);
-    if (rc) return rc;
+    if (!rc && max_packed) rc = ensure(ctx, ctx->tmp_vals, max_packed + 64);
     size_t row = 0;
     for (size_t i = 0; i < n_bufs && !rc; i++) {
-        rc = upload(ctx, (char *)(*out)->dev + row * (size_t)w, payload[i].first, payload[i].second * (size_t)w);
-        row += payload[i].second;
+        char *dst = (char *)(*out)->dev + row * (size_t)w;
+        if (!parts[i].packed) {
+            rc = upload(ctx, dst, parts[i].payload, parts[i].bytes);
+        } else {
+            // packed bits cross PCIe (log2/64 of the decoded size), the decode runs on the device
+            rc = upload(ctx, ctx->tmp_vals.p, parts[i].payload, parts[i].bytes);
+            if (!rc) {
+                hipError_t e = launch_bitpack_decode(ctx->stream, w, (const uint64_t *)ctx->tmp_vals.p, parts[i].bytes / 8, parts[i].log2,
+                                                     parts[i].minv, parts[i].n, dst);
+                if (e != hipSuccess) { ctx->last_hip = (int)e; rc = KNOX_E_HIP; }
+                else if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;  // tmp buffer is reused by the next container
+            }
+        }
+        row += parts[i].n;
     }
     if (rc) {
-        knox_col_free(*out);
+        if (*out) knox_col_free(*out);
         *out = nullptr;
     }
     return rc;

@@ -131,6 +131,10 @@ hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint6
 hipError_t launch_bloom_build_u64(hipStream_t s, const uint64_t *col, uint64_t n_rows, uint64_t pack_rows,
                                   uint8_t *filters, const uint64_t *offsets);
 
+// bit-packed container payload -> materialized values: out[i] = T((stream >> i*log2) & mask) + minv
+hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
+                                 uint64_t n_values, void *dst);
+
 // synthetic columns
 hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint64_t seed, uint64_t first_row,
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);

@@ -1360,6 +1360,47 @@ hipError_t launch_bloom_build_u64(hipStream_t s, const uint64_t *col, uint64_t n
 }
 
 // ---------------------------------------------------------------------------------------------
+// Bit-packed integer container decode (internal/encode/bitpack/decode.go:56-74 DecodeValue):
+// value i = T((word[i*log2 >> 6] >> (i*log2 & 63) | word[+1] << (64 - shift)) & mask) + minv.
+// One lane per value: the packed words are read through L1/L2 (neighbouring lanes share them),
+// the materialized column is written with full-width coalesced stores.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) bitpack_decode_kernel(const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
+                                                                uint64_t n_values, void *dst) {
+    const uint64_t mask = log2 >= 64 ? ~0ull : ((1ull << log2) - 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        if (log2 > 0) {
+            const uint64_t idx = i * log2, pos = idx >> 6;
+            const uint32_t shift = (uint32_t)(idx & 63);
+            uint64_t word = packed[pos] >> shift;
+            if (64 - shift < log2 && pos + 1 < n_words) word |= packed[pos + 1] << (64 - shift);
+            v = word & mask;
+        }
+        v += minv;
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
+                                 uint64_t n_values, void *dst) {
+    if (n_values == 0) return hipSuccess;
+    uint64_t g = (n_values + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    switch (width) {
+    case 8: KNOX_LAUNCH((bitpack_decode_kernel<8>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    case 4: KNOX_LAUNCH((bitpack_decode_kernel<4>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    case 2: KNOX_LAUNCH((bitpack_decode_kernel<2>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    case 1: KNOX_LAUNCH((bitpack_decode_kernel<1>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // synthetic columns (DESIGN.md "synthetic data"): r(i) = mix64(i + mix64(seed))
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {

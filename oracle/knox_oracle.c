@@ -931,6 +931,96 @@ KO_EXPORT int64_t ko_raw_container_load(int dtype, const uint8_t *buf, int64_t l
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Bit-packed integer container (TIntBitpacked = 4): internal/encode/int_bitpack.go:93-133 +
+ * internal/encode/bitpack/encode.go:216-246 (generic horizontal packer), decode.go:24-74.
+ *   [4][uvarint uint64(For)][uvarint log2][uvarint N][packed bits]
+ * For = min value (frame of reference), log2 = bits.Len64(max - min) (types/number.go:163-169),
+ * value i = T((stream >> i*log2) & mask) + For, stream = little-endian 64-bit words,
+ * packed size = ((log2*N + 63) &^ 63) / 8 bytes (bitpack.go:9-11); log2 == 0 packs nothing.
+ * ---------------------------------------------------------------------------------------- */
+static uint64_t ko_raw_bits(int dtype, const void *values, int64_t i) { /* sign/zero extended like uint64(T) */
+    switch (dtype) {
+    case KO_I64: return (uint64_t)((const int64_t *)values)[i];
+    case KO_I32: return (uint64_t)(int64_t)((const int32_t *)values)[i];
+    case KO_I16: return (uint64_t)(int64_t)((const int16_t *)values)[i];
+    case KO_I8:  return (uint64_t)(int64_t)((const int8_t *)values)[i];
+    case KO_U64: return ((const uint64_t *)values)[i];
+    case KO_U32: return ((const uint32_t *)values)[i];
+    case KO_U16: return ((const uint16_t *)values)[i];
+    default:     return ((const uint8_t *)values)[i];
+    }
+}
+static int ko_is_signed(int dtype) { return dtype >= KO_I64 && dtype <= KO_I8; }
+KO_EXPORT int64_t ko_bitpack_container_store(int dtype, const void *values, int64_t n, uint8_t *dst) {
+    int w = ko_width(dtype);
+    if (!w || dtype == KO_F64 || dtype == KO_F32 || n <= 0) return -1;
+    uint64_t minv = ko_raw_bits(dtype, values, 0), maxv = minv;
+    for (int64_t i = 1; i < n; i++) {
+        uint64_t v = ko_raw_bits(dtype, values, i);
+        if (ko_is_signed(dtype) ? ((int64_t)v < (int64_t)minv) : (v < minv)) minv = v;
+        if (ko_is_signed(dtype) ? ((int64_t)v > (int64_t)maxv) : (v > maxv)) maxv = v;
+    }
+    uint64_t range = maxv - minv;
+    int log2 = range ? 64 - __builtin_clzll(range) : 0;      /* bits.Len64 */
+    uint64_t mask = log2 >= 64 ? ~0ull : ((1ull << log2) - 1);
+    int64_t o = 0;
+    dst[o++] = 4;
+    o += ko_put_uvarint(dst + o, minv);                        /* uint64(c.For) */
+    o += ko_put_uvarint(dst + o, (uint64_t)log2);
+    o += ko_put_uvarint(dst + o, (uint64_t)n);
+    int64_t sz = (((int64_t)log2 * n + 63) & ~(int64_t)63) / 8;
+    memset(dst + o, 0, (size_t)sz);
+    if (log2 > 0) { /* encode(): LSB-first stream */
+        uint64_t *out = (uint64_t *)malloc((size_t)sz + 8), word = 0;
+        int offset = 0;
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; i++) {
+            uint64_t x = (ko_raw_bits(dtype, values, i) - minv) & mask;
+            word |= x << offset;
+            offset += log2;
+            if (offset >= 64) {
+                out[k++] = word;
+                offset -= 64;
+                word = offset > 0 ? (x >> (log2 - offset)) : 0;
+            }
+        }
+        if (offset > 0) out[k++] = word;
+        memcpy(dst + o, out, (size_t)k * 8);
+        free(out);
+    }
+    return o + sz;
+}
+KO_EXPORT int64_t ko_bitpack_container_load(int dtype, const uint8_t *buf, int64_t len, void *out, int64_t cap) {
+    int w = ko_width(dtype);
+    if (!w || len < 4 || buf[0] != 4) return -1;
+    uint64_t minv, l2, n;
+    int64_t o = 1;
+    o += ko_uvarint(buf + o, &minv);
+    o += ko_uvarint(buf + o, &l2);
+    o += ko_uvarint(buf + o, &n);
+    int log2 = (int)l2;
+    int64_t sz = (((int64_t)log2 * (int64_t)n + 63) & ~(int64_t)63) / 8;
+    if (o + sz > len || (int64_t)n > cap || log2 > 64) return -2;
+    uint64_t mask = log2 >= 64 ? ~0ull : ((1ull << log2) - 1);
+    int64_t nwords = sz / 8;
+    for (int64_t i = 0; i < (int64_t)n; i++) { /* DecodeValue decode.go:56-74 */
+        uint64_t v = 0;
+        if (log2 > 0) {
+            int64_t idx = i * log2, pos = idx >> 6;
+            int shift = (int)(idx & 63);
+            uint64_t word, nextw = 0;
+            memcpy(&word, buf + o + pos * 8, 8);
+            word >>= shift;
+            if (64 - shift < log2 && pos + 1 < nwords) { memcpy(&nextw, buf + o + (pos + 1) * 8, 8); word |= nextw << (64 - shift); }
+            v = word & mask;
+        }
+        v += minv; /* T(word&mask) + minv wraps in T */
+        memcpy((uint8_t *)out + i * w, &v, (size_t)w);
+    }
+    return (int64_t)n;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic column generator (shared SPEC with the device generator in
  * knoxdb_amd/csrc/knox_kernels.hip: both sides implement DESIGN.md "synthetic data" from the
  * text, neither calls the other).  Counter based so any row can be produced independently:

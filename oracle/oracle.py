@@ -87,6 +87,10 @@ def lib():
         L.ko_raw_container_store.argtypes = [i32, vp, i64, vp]
         L.ko_raw_container_load.restype = i64
         L.ko_raw_container_load.argtypes = [i32, vp, i64, vp, i64]
+        L.ko_bitpack_container_store.restype = i64
+        L.ko_bitpack_container_store.argtypes = [i32, vp, i64, vp]
+        L.ko_bitpack_container_load.restype = i64
+        L.ko_bitpack_container_load.argtypes = [i32, vp, i64, vp, i64]
         L.ko_generate.restype = i32
         L.ko_generate.argtypes = [i32, i32, u64, i64, i64, i64, u64, vp]
         L.ko_scan_i64_bw_sum.restype = i64
@@ -256,6 +260,22 @@ def raw_container_load(dtype, buf):
     b = np.frombuffer(bytes(buf), dtype=np.uint8).copy()
     out = np.zeros(len(buf) // np.dtype(NP[dtype]).itemsize + 1, dtype=NP[dtype])
     n = lib().ko_raw_container_load(dtype, _p(b), b.size, _p(out), out.size)
+    assert n >= 0, n
+    return out[:n].copy()
+
+
+def bitpack_container_store(dtype, values):
+    values = np.ascontiguousarray(values, dtype=NP[dtype])
+    out = np.zeros(values.size * 8 + 64, dtype=np.uint8)
+    n = lib().ko_bitpack_container_store(dtype, _p(values), values.size, _p(out))
+    assert n > 0, n
+    return out[:n].tobytes()
+
+
+def bitpack_container_load(dtype, buf, n_max):
+    b = np.frombuffer(bytes(buf), dtype=np.uint8).copy()
+    out = np.zeros(n_max, dtype=NP[dtype])
+    n = lib().ko_bitpack_container_load(dtype, _p(b), b.size, _p(out), n_max)
     assert n >= 0, n
     return out[:n].copy()
 

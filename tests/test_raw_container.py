@@ -58,5 +58,48 @@ def test_gpu_ingest_of_raw_containers_scans_like_decoded_vectors():
             col.free(); bits.free()
         # an encoded (non-raw) container is refused, not mis-read
         with pytest.raises(K.KnoxError) as e:
-            ctx.upload_raw_containers(BlockType.Int64, [bytes([4, 1, 0, 0])], pack)
+            ctx.upload_raw_containers(BlockType.Int64, [bytes([6, 1, 0, 0])], pack)  # TIntSimple8
         assert e.value.code == -5
+
+
+def _bp_cases(rng):
+    for dt, npdt in ((O.I64, np.int64), (O.U16, np.uint16), (O.I8, np.int8), (O.U64, np.uint64), (O.I32, np.int32), (O.U8, np.uint8)):
+        info = np.iinfo(npdt)
+        for n in (1, 63, 64, 65, 1000):
+            yield dt, npdt, np.full(n, 42 if info.max >= 42 else 1, dtype=npdt)                    # log2 = 0
+            yield dt, npdt, (rng.integers(0, 4, n) + 7).astype(npdt)                                 # 2 bits
+            yield dt, npdt, rng.integers(0, 200, n).astype(np.int64).astype(npdt)                    # 8 bits (wraps for int8)
+            yield dt, npdt, np.array([info.min, info.max] * n, dtype=npdt)[:max(n, 2)]               # full width
+            if npdt in (np.int64, np.int32):
+                yield dt, npdt, (rng.integers(-(1 << 20), 1 << 20, n)).astype(npdt)                  # negative frame of reference
+
+
+def test_bitpack_container_roundtrip_and_framing():
+    rng = np.random.default_rng(8)
+    for dt, npdt, x in _bp_cases(rng):
+        c = O.bitpack_container_store(dt, x)
+        assert c[0] == 4
+        assert (O.bitpack_container_load(dt, c, x.size) == x).all(), (dt, x[:4])
+    # framing by hand: values 7..10 -> For 7, log2 2, N 4, one 64-bit word 0b11_10_01_00
+    c = O.bitpack_container_store(O.U16, np.array([7, 8, 9, 10], dtype=np.uint16))
+    assert c == bytes([4, 7, 2, 4, 0b11100100, 0, 0, 0, 0, 0, 0, 0])
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_bitpacked_containers_on_device():
+    import knoxdb_amd as K
+    from knoxdb_amd.types import BlockType
+    BT = {O.I64: BlockType.Int64, O.U16: BlockType.Uint16, O.I8: BlockType.Int8, O.U64: BlockType.Uint64, O.I32: BlockType.Int32, O.U8: BlockType.Uint8}
+    rng = np.random.default_rng(9)
+    with K.Context(0) as ctx:
+        for dt, npdt, x in _bp_cases(rng):
+            col = ctx.upload_raw_containers(BT[dt], [O.bitpack_container_store(dt, x)], 1024)
+            assert col.rows == x.size and (col.download() == x).all(), (dt, x[:4])
+            col.free()
+        # a run of packs mixing raw and bit-packed containers lands as one column
+        packs = [rng.integers(-500, 500, 4096).astype(np.int64) for _ in range(6)]
+        conts = [O.bitpack_container_store(O.I64, p) if i % 2 else O.raw_container_store(O.I64, p) for i, p in enumerate(packs)]
+        assert sum(len(c) for c in conts[1::2]) < 0.2 * sum(len(c) for c in conts[0::2])   # 10 bits instead of 64
+        col = ctx.upload_raw_containers(BlockType.Int64, conts, 4096)
+        assert (col.download() == np.concatenate(packs)).all()
+        col.free()
