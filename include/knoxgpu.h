@@ -169,6 +169,11 @@ int knox_bits_popcount_segments(knox_ctx *ctx, const knox_bits *b, size_t seg_bi
  * entries available in `rows` (host); *n_out receives the number written (= popcount).     */
 int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t capacity, size_t *n_out);
 
+/* Bool columns are bitsets; their vector matchers (internal/bitset/match.go:14-62 MatchEqual ..
+ * MatchBetween) are copies / negations of the column.  `bits` must be zeroed by the caller; modes
+ * that cannot match leave it untouched, exactly as in the reference.  a / b are 0 or 1.         */
+int knox_bits_match_bool(knox_ctx *ctx, const knox_bits *column, int op, int a, int b, knox_bits *bits);
+
 /* ---- predicate tree + fused scan ---------------------------------------------------- *
  * Replaces filter.Match(node, pkg, stats, bits) (operator/filter/match_core.go:14-215) for
  * every pack of the resident columns in ONE pass, plus the reducers that the reference

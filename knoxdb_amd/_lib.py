@@ -96,6 +96,7 @@ SIGNATURES = {
     "knox_bits_or_flag": (_i, [_vp, _vp, _vp, _pi, _pi]),
     "knox_bits_popcount": (_i, [_vp, _vp, C.POINTER(_i64)]),
     "knox_bits_popcount_segments": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "knox_bits_match_bool": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "knox_bits_indexes": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "knox_scan": (_i, [_vp, C.POINTER(Pred), _i, _pp, _i, C.POINTER(Agg), _i, _u64, _vp, _vp, _vp,
                        C.POINTER(AggState), C.POINTER(ScanOut)]),

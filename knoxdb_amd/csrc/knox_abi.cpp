@@ -714,6 +714,31 @@ KNOX_API int knox_bits_or_flag(knox_ctx *ctx, knox_bits *dst, const knox_bits *s
     return rc;
 }
 
+KNOX_API int knox_bits_match_bool(knox_ctx *ctx, const knox_bits *column, int op, int a, int b, knox_bits *bits) {
+    if (!ctx || !column || !bits || column->size != bits->size) return KNOX_E_INVALID;
+    auto eq = [&](bool val) {  // Bitset.MatchEqual: bits.Copy(s); if !val { bits.Neg() }
+        int rc = bitop(ctx, BIT_COPY, bits, column, nullptr, nullptr);
+        if (!rc && !val) rc = bitop(ctx, BIT_NEG, bits, nullptr, nullptr, nullptr);
+        return rc;
+    };
+    auto one = [&]() { return bitop(ctx, BIT_ONE, bits, nullptr, nullptr, nullptr); };
+    const bool va = a != 0, vb = b != 0;
+    switch (op) {
+    case KNOX_EQ: return eq(va);
+    case KNOX_NE: return eq(!va);
+    case KNOX_LT: return va ? eq(false) : KNOX_OK;
+    case KNOX_LE: return va ? one() : eq(false);
+    case KNOX_GT: return !va ? eq(true) : KNOX_OK;
+    case KNOX_GE: return !va ? one() : eq(true);
+    case KNOX_RANGE:
+        if (va && vb) return eq(true);
+        if (!va && vb) return one();
+        if (!va && !vb) return eq(false);
+        return KNOX_OK;
+    default: return KNOX_E_UNSUPPORTED;
+    }
+}
+
 KNOX_API int knox_bits_popcount(knox_ctx *ctx, const knox_bits *b, int64_t *count) {
     if (!ctx || !b || !count) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);

@@ -151,6 +151,12 @@ class Bits:
     def or_flag(self, o):
         return self._flag("or_flag", o)
 
+    def match_bool(self, mode, a, b=False, out=None):
+        """Bool-column matcher (bitset/match.go:14-62): self is the column, returns the match bitset."""
+        out = out if out is not None else Bits(self.ctx, self.size)
+        check(_lib.lib().knox_bits_match_bool(self.ctx.h, self.h, int(mode), int(bool(a)), int(bool(b)), out.h))
+        return out
+
     def count(self):
         c = C.c_int64()
         check(_lib.lib().knox_bits_popcount(self.ctx.h, self.h, C.byref(c)))

@@ -829,6 +829,33 @@ KO_EXPORT int64_t ko_buckets(int dtype, int func, const int64_t *times, const vo
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Bool columns are bitsets; their matchers are copies / negations: internal/bitset/match.go:14-62
+ * (MatchEqual .. MatchBetween).  `bits` arrives zeroed; a non-matching mode leaves it untouched.
+ * ---------------------------------------------------------------------------------------- */
+static void bool_eq(int val, const uint8_t *src, int64_t size, uint8_t *bits) {
+    int64_t l = (size + 7) >> 3;
+    memcpy(bits, src, (size_t)l);
+    if (size > 0) bits[l - 1] &= bytemask(size);
+    if (!val) ko_bits_neg(bits, size);
+}
+KO_EXPORT int ko_bool_match(int op, int a, int b, const uint8_t *src, int64_t size, uint8_t *bits) {
+    switch (op) {
+    case KO_EQ: bool_eq(a, src, size, bits); return 0;
+    case KO_NE: bool_eq(!a, src, size, bits); return 0;
+    case KO_LT: if (a) bool_eq(0, src, size, bits); return 0;
+    case KO_LE: if (a) ko_bits_one(bits, size); else bool_eq(0, src, size, bits); return 0;
+    case KO_GT: if (!a) bool_eq(1, src, size, bits); return 0;
+    case KO_GE: if (!a) ko_bits_one(bits, size); else bool_eq(1, src, size, bits); return 0;
+    case KO_RG:
+        if (a && b) bool_eq(1, src, size, bits);
+        else if (!a && b) ko_bits_one(bits, size);
+        else if (!a && !b) bool_eq(0, src, size, bits);
+        return 0;
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * IN / NOT IN set matchers on materialized blocks:
  *   integers  numInSetMatcher / numNotInSetMatcher.MatchVector  operator/filter/match_num.go:672-690, :789-808
  *             (membership of uint64(v) in a set built from uint64(T(x)), i.e. equality on T)

@@ -77,6 +77,8 @@ def lib():
         L.ko_bytes_match.argtypes = [i32, vp, i64, vp, C.c_char_p, i64, vp, vp]
         L.ko_buckets.restype = i64
         L.ko_buckets.argtypes = [i32, i32, vp, vp, i64, vp, i64, i64, vp, vp, i64]
+        L.ko_bool_match.restype = i32
+        L.ko_bool_match.argtypes = [i32, i32, i32, vp, i64, vp]
         L.ko_inset.restype = i32
         L.ko_inset.argtypes = [i32, i32, vp, i64, vp, i64, vp, vp]
         L.ko_put_uvarint.restype = i32
@@ -223,6 +225,13 @@ def buckets(dtype, func, times, vals, bits, t_from, step, cap=None):
     k = lib().ko_buckets(dtype, func, _p(times), _p(vals), times.size, _p(b), t_from, step, _p(out_t), _p(out_v), cap)
     assert k >= 0, k
     return out_t[:k].copy(), out_v[:k].copy()
+
+
+def bool_match(op, a, b, src, size):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    out = np.zeros(bitfield_len(size), dtype=np.uint8)
+    assert lib().ko_bool_match(op, int(bool(a)), int(bool(b)), _p(src), size, _p(out)) == 0
+    return out
 
 
 def inset(dtype, negate, src, values, mask=None, bits=None):

@@ -91,3 +91,23 @@ def test_indexes_random_and_segments(ctx):
         want_c = [int(bitsu[i:i + seg].sum()) for i in range(0, sz, seg)]
         assert counts.tolist() == want_c
         d.free()
+
+
+def test_bool_column_matchers(ctx):
+    # internal/bitset/match.go:14-62: bool columns are bitsets, every mode is a copy / negation / fill
+    rng = np.random.default_rng(3)
+    from knoxdb_amd.types import FilterMode as F
+    for sz in (7, 64, 1000, 65536 + 5):
+        col_h = _rand(sz, rng, 0.3)
+        col = ctx.bits(sz).upload(col_h)
+        for mode in (F.Equal, F.NotEqual, F.Lt, F.Le, F.Gt, F.Ge):
+            for a in (False, True):
+                got = col.match_bool(mode, a)
+                assert (got.bytes(poison=8) == O.bool_match(int(mode), a, False, col_h, sz)).all(), (sz, mode, a)
+                got.free()
+        for a in (False, True):
+            for b in (False, True):
+                got = col.match_bool(F.Range, a, b)
+                assert (got.bytes() == O.bool_match(O.RG, a, b, col_h, sz)).all(), (sz, a, b)
+                got.free()
+        col.free()
