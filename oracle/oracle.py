@@ -25,8 +25,8 @@ OPNAME = {"eq": EQ, "ne": NE, "gt": GT, "ge": GE, "lt": LT, "le": LE, "bw": RG}
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "knox_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("knox_oracle.c", "knox_cpu_simd.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -95,6 +95,9 @@ def lib():
         L.ko_bitpack_container_load.argtypes = [i32, vp, i64, vp, i64]
         L.ko_generate.restype = i32
         L.ko_generate.argtypes = [i32, i32, u64, i64, i64, i64, u64, vp]
+        L.ko_simd_scan_i64_bw_sum.restype = i64
+        L.ko_simd_scan_i64_bw_sum.argtypes = [vp, i64, i64, i64, i64, vp, i32, C.POINTER(i64)]
+        L.ko_simd_has_avx2.restype = i32
         L.ko_scan_i64_bw_sum.restype = i64
         L.ko_scan_i64_bw_sum.argtypes = [vp, i64, i64, i64, i64, vp, vp, C.POINTER(i64)]
         _lib = L
@@ -303,4 +306,14 @@ def scan_i64_bw_sum(src, pack_rows, a, b):
     sel = np.zeros(pack_rows + 8, dtype=np.uint32)
     s = C.c_int64()
     cnt = lib().ko_scan_i64_bw_sum(_p(src), n, pack_rows, a, b, _p(bits), _p(sel), C.byref(s))
+    return bits, cnt, s.value
+
+
+def simd_scan_i64_bw_sum(src, pack_rows, a, b, threads, bits=None):
+    """AVX2 pack-parallel CPU baseline (knox_cpu_simd.c): returns (bits, count, sum)."""
+    src = np.ascontiguousarray(src, dtype=np.int64)
+    if bits is None:
+        bits = np.zeros(bitfield_len(src.size), dtype=np.uint8)
+    s = C.c_int64()
+    cnt = lib().ko_simd_scan_i64_bw_sum(_p(src), src.size, pack_rows, a, b, _p(bits), threads, C.byref(s))
     return bits, cnt, s.value

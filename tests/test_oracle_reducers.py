@@ -138,3 +138,11 @@ def test_inset_semantics():
     assert O.inset(O.F64, False, f, [np.nan, 0.0]).tolist() == [0b00011 & 0b11111]
     assert O.inset(O.F64, True, f, [np.nan, 0.0]).tolist() == [0b11100]
     assert O.inset(O.F64, False, f, []).tolist() == [0]
+
+
+def test_simd_cpu_baseline_equals_literal_port():
+    x = O.generate(O.I64, 0, 2, 0, 5 * 4096 + 100, lo=-(1 << 40), span=1 << 41)
+    b0, c0, s0 = O.scan_i64_bw_sum(x, 4096, -(1 << 38), 1 << 38)
+    for threads in (1, 3, 8):
+        b1, c1, s1 = O.simd_scan_i64_bw_sum(x, 4096, -(1 << 38), 1 << 38, threads)
+        assert c1 == c0 and s1 == s0 and (b1 == b0).all()
