@@ -43,7 +43,10 @@ def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts, min_seconds=10.0
         ok = int(gpu_pack_counts[: sample_rows // pack_rows].sum()) == int(cnt)
     rows = sample_rows * passes
     # extra figure: AVX2, pack-parallel over every host core, compare+sum fused (oracle/knox_cpu_simd.c)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
     simd = None
     try:
         sbits = np.zeros((sample_rows + 7) >> 3, dtype=np.uint8)
