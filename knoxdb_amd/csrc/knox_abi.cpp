@@ -1026,7 +1026,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     } else {
         a.pack_shift = 255;
     }
-    a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
+    a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
     // auto occupancy: the pure streaming passes run best at 2 workgroups per CU, VALU-heavier ones at 3
     // (profiles/r01_sweep_blocks_per_cu.txt): 8-byte / 4-byte integer streaming 2 WG/CU; float or min-max

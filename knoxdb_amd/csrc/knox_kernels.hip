@@ -406,7 +406,11 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     const uint32_t m1 = (tt & 2u) ? QMASK : 0u, m0 = (tt & 1u) ? QMASK : 0u;
     const int qshift = K * (lane & (G - 1));
 
-    for (uint64_t vt = blockIdx.x; vt < a.n_tiles; vt += gridDim.x) {
+    // diagnostics (debug bit3): XCD-contiguous mapping -- workgroups are dealt round-robin over the 8
+    // XCDs, so logical block (b%8)*(G/8) + b/8 gives every XCD one contiguous run of tiles per round
+    uint32_t lb = blockIdx.x;
+    if ((a.debug & 8u) && (gridDim.x & 7u) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (uint64_t vt = lb; vt < a.n_tiles; vt += gridDim.x) {
         // packs pruned by the caller's statistics are never touched: with a live-pack list the
         // virtual tile index walks only the surviving packs (their bitset ranges were zeroed by the host)
         uint64_t tile = vt;

@@ -30,6 +30,8 @@ run(cols[0], 60)
 mode = sys.argv[3] if len(sys.argv) > 3 else "iters"
 if mode == "iters":
     configs = [(it, bpc, 1) for bpc in (2, 3) for it in (1, 2, 4, 8, 16)]
+elif mode == "xcd":  # default vs XCD-contiguous tile mapping (variant 5) at iters 1, 2, 4
+    configs = [(it, 2, v) for it in (1, 2, 4) for v in (1, 5)]
 else:  # store flavours at iters=2, 2 WG/CU: nt (1), none (2), plain (3), write-through (4)
     configs = [(2, 2, v) for v in (1, 2, 3, 4)]
 print("col | " + " ".join("i%-2d/b%d/v%d" % c for c in configs))
