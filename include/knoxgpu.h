@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KNOX_ABI_VERSION 1
+#define KNOX_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------------- */
 enum knox_err {
@@ -205,7 +205,7 @@ typedef struct knox_agg {
  * internal/reducer/reducer.go needs, in a form that merges exactly across blocks and GPUs. */
 typedef struct knox_agg_state {
     int32_t dtype;
-    uint32_t flags;     /* bit0: state valid */
+    uint32_t flags;     /* bit0: state valid; bit1: the m_* moments are valid */
     int64_t count;      /* selected rows */
     uint64_t isum;      /* wrapping sum of the raw value bits (integers: SumReducer mod 2^64) */
     double fsum_hi;     /* double-double sum of float64(v): hi + lo */
@@ -214,6 +214,10 @@ typedef struct knox_agg_state {
     uint64_t first_bits, last_bits;  /* value at first_row / last_row */
     int64_t min_row, max_row;        /* global row id of the adopted value, -1 = none       */
     int64_t first_row, last_row;     /* first / last selected global row id, -1 = none      */
+    /* central moments for VarReducer / StdReducer (reducer.go:352-429), second pass:         */
+    double m_shift;                  /* K = the first pass's mean estimate                   */
+    double m_dev_hi, m_dev_lo;       /* double-double sum of (float64(v) - K)                */
+    double m_sq_hi, m_sq_lo;         /* double-double sum of (float64(v) - K)^2              */
 } knox_agg_state;
 
 typedef struct knox_scan_out {
@@ -256,6 +260,11 @@ int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col
 /* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
 int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,
                 uint64_t row_base, knox_agg_state *state);
+/* Var / Std second pass: adds the central moments to a state knox_reduce (or knox_scan) produced
+ * over the SAME column and selection (the pass is centred on that state's mean).  knox_scan runs
+ * it by itself for KNOX_R_VAR / KNOX_R_STD aggregates.                                       */
+int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,
+                        knox_agg_state *state /* in/out */);
 /* Time-window aggregation ("next" row f1): what pkg/series feeds row-at-a-time into
  * NativeBucket.Push (internal/reducer/bucket_native.go:104-159): one reducer per window
  * [t_from + k*step, t_from + (k+1)*step), k < n_buckets, over the rows `mask` selects.

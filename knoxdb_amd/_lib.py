@@ -40,7 +40,9 @@ class AggState(C.Structure):
                 ("min_bits", C.c_uint64), ("max_bits", C.c_uint64),
                 ("first_bits", C.c_uint64), ("last_bits", C.c_uint64),
                 ("min_row", C.c_int64), ("max_row", C.c_int64),
-                ("first_row", C.c_int64), ("last_row", C.c_int64)]
+                ("first_row", C.c_int64), ("last_row", C.c_int64),
+                ("m_shift", C.c_double), ("m_dev_hi", C.c_double), ("m_dev_lo", C.c_double),
+                ("m_sq_hi", C.c_double), ("m_sq_lo", C.c_double)]
 
 
 class ScanOut(C.Structure):
@@ -104,6 +106,7 @@ SIGNATURES = {
     "knox_scan_collect": (_i, [_vp, _vp, C.POINTER(AggState), _i, C.POINTER(ScanOut)]),
     "knox_match_range_vectors": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _vp, _vp]),
     "knox_reduce": (_i, [_vp, _vp, _vp, _u64, C.POINTER(AggState)]),
+    "knox_reduce_moments": (_i, [_vp, _vp, _vp, C.POINTER(AggState)]),
     "knox_reduce_buckets": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(AggState)]),
     "knox_reduce_sequential": (_i, [_vp, _vp, _vp, _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_value": (_i, [C.POINTER(AggState), _i, _vp, _pi, C.POINTER(_i64)]),

@@ -58,6 +58,7 @@ struct knox_ctx {
     DevBuf pack_skip;    // device copy of the caller's pack_skip bytes
     DevBuf pack_counts;  // int64 per pack
     DevBuf misc;         // flags / counters / small outputs
+    DevBuf mom_partials; // var/std second pass: 4 doubles per workgroup
     DevBuf idx_scratch;  // indexes: block offsets
     DevBuf idx_rows;     // indexes: row ids
     DevBuf bytes_val;    // bytes leaf value
@@ -251,7 +252,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
-                      &ctx->misc, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
+                      &ctx->misc, &ctx->mom_partials, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
     for (DevBuf *b : bufs)
         if (b->p) hipFree(b->p);
     for (int i = 0; i < 2; i++) {
@@ -911,18 +912,21 @@ static int make_truth_table(const knox_pred *nodes, int n_nodes, const std::vect
 }
 
 // which aggregate work a reducer needs from the kernels
+constexpr unsigned A_NEED_MOMENTS = 0x100;  // host-only planning bit: var/std second pass wanted
 static int agg_need(int func, int dtype, unsigned &need) {
     switch (func) {
     case KNOX_R_COUNT: break;
     case KNOX_R_SUM: need |= dtype_is_float(dtype) ? A_FSUM : A_ISUM; break;
     case KNOX_R_MEAN: need |= A_FSUM; break;
+    case KNOX_R_VAR: case KNOX_R_STD: need |= A_FSUM | A_NEED_MOMENTS; break;  // + the second pass (run_moments)
     case KNOX_R_MIN: case KNOX_R_MAX: need |= A_MINMAX | (dtype_is_float(dtype) ? A_FIRSTLAST : 0u); break;
     case KNOX_R_FIRST: case KNOX_R_LAST: need |= A_FIRSTLAST; break;
-    default: return KNOX_E_UNSUPPORTED;  // var/std: knox_reduce_sequential
+    default: return KNOX_E_UNSUPPORTED;
     }
     return KNOX_OK;
 }
 static unsigned agg_class(unsigned need) {
+    need &= ~A_NEED_MOMENTS;
     if (need == 0) return 0;
     if (need == A_ISUM) return A_ISUM;
     if ((need & A_ISUM) == 0) return A_FSUM | A_MINMAX | A_FIRSTLAST;
@@ -1071,6 +1075,22 @@ static int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, 
     if (e == hipSuccess)
         e = launch_finalize(ctx->stream, col->width, a.partials, g + 1, col->dev, row_base, col->dtype, (AggStateDev *)ctx->states.p + slot,
                             (int64_t *)((AggStateDev *)ctx->states.p + 16) + slot);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
+// var/std second pass over the rows `mask` selects: centred on the mean of state `slot` (already
+// finalized on the device, same stream), results into that state's moment fields
+static int run_moments(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, size_t n_rows, int slot, int grid) {
+    int rc = ensure(ctx, ctx->mom_partials, (size_t)(grid + 1) * 4 * sizeof(double));
+    if (rc) return rc;
+    AggStateDev *st = (AggStateDev *)ctx->states.p + slot;
+    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * 4;
+    hipError_t e = launch_moments(ctx->stream, col->width, dtype_flavor(col->dtype), std::min(grid, want), col->dev, mask, n_rows, st, 0.0,
+                                  (double *)ctx->mom_partials.p, &st->m_shift, &st->flags);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         return KNOX_E_HIP;
@@ -1257,7 +1277,9 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         else if (width == 0) width = c->width;
         else if (c->width != width) fused = false;
     }
-    const bool need_bits = bits_out != nullptr || want_pack_counts || !fused || n_agg_cols > 1 ||
+    bool any_moments = false;
+    for (int s = 0; s < n_agg_cols; s++) any_moments = any_moments || (agg_needs[s] & A_NEED_MOMENTS) != 0;
+    const bool need_bits = bits_out != nullptr || want_pack_counts || !fused || n_agg_cols > 1 || any_moments ||
                            (n_agg_cols == 1 && fused && cols[agg_cols[0]]->width != width);
     uint64_t *bits = bits_out ? bits_out->dev : nullptr;
     if (need_bits && !bits) {
@@ -1363,6 +1385,13 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     // ---- remaining aggregate columns: masked reduce over the result bitset
     for (int s = first_reduce_slot; s < n_agg_cols; s++) {
         rc = run_reduce(ctx, cols[agg_cols[s]], (const uint32_t *)bits, agg_class(agg_needs[s]) ? agg_class(agg_needs[s]) : A_ISUM, n_rows, row_base, s, grid);
+        if (rc) return rc;
+    }
+
+    // ---- var/std: second pass centred on the mean the first pass just produced (no host round trip)
+    for (int s = 0; s < n_agg_cols; s++) {
+        if (!(agg_needs[s] & A_NEED_MOMENTS)) continue;
+        rc = run_moments(ctx, cols[agg_cols[s]], (const uint32_t *)bits, n_rows, s, grid);
         if (rc) return rc;
     }
 
@@ -1500,6 +1529,28 @@ KNOX_API int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *ma
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(state, ctx->states.p, sizeof(knox_agg_state), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, knox_agg_state *state) {
+    if (!ctx || !col || !state || col->dtype == KNOX_BYTES || state->dtype != col->dtype) return KNOX_E_INVALID;
+    if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 4));
+    int rc = ensure(ctx, ctx->mom_partials, (size_t)(grid + 1) * 4 * sizeof(double) + 64);
+    if (!rc) rc = ensure(ctx, ctx->misc, 256);
+    if (rc) return rc;
+    const double shift = state->count > 0 ? state->fsum_hi / (double)state->count : 0.0;
+    double *d_out = (double *)((char *)ctx->misc.p + 64);
+    hipError_t e = launch_moments(ctx->stream, col->width, dtype_flavor(col->dtype), grid, col->dev, mask ? (const uint32_t *)mask->dev : nullptr,
+                                  col->n_rows, nullptr, shift, (double *)ctx->mom_partials.p, d_out, nullptr);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    double h[5];
+    HIPCHK(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    state->m_shift = h[0]; state->m_dev_hi = h[1]; state->m_dev_lo = h[2]; state->m_sq_hi = h[3]; state->m_sq_lo = h[4];
+    state->flags |= 2u;
     return KNOX_OK;
 }
 
@@ -1674,6 +1725,32 @@ KNOX_API int knox_agg_value(const knox_agg_state *st, int func, void *value_out,
         if (row) *row = mn ? st->min_row : st->max_row;
         break;
     }
+    case KNOX_R_VAR:
+    case KNOX_R_STD: {
+        // VarReducer / StdReducer.Value (reducer.go:376-381,416-421): m2/(n-1), NaN for n < 2.
+        // m2 = Q - D*D/n from the second-pass moments, evaluated in binary128 and rounded once.
+        if (!(st->flags & 2u)) return KNOX_E_INVALID;  // state carries no moments (knox_reduce_moments)
+        double v;
+        if (st->count < 2) {
+            v = NAN;
+        } else {
+            const __float128 n = (__float128)st->count;
+            const __float128 D = (__float128)st->m_dev_hi + (__float128)st->m_dev_lo, Q = (__float128)st->m_sq_hi + (__float128)st->m_sq_lo;
+            __float128 m2 = Q - D * D / n;
+            if (m2 < 0) m2 = 0;  // cannot happen mathematically; guards the last-bit residue
+            v = (double)(m2 / (n - 1));
+            if (!(fabs(st->m_sq_hi) <= 1.7976931348623157e308)) v = st->m_sq_hi + st->m_sq_lo;  // non-finite input: NaN like Welford
+            if (func == KNOX_R_STD) v = sqrt(v);
+        }
+        if (isf) { put_float(v); break; }
+        // T(float64) for integer T: truncation toward zero; NaN / out-of-range results are
+        // implementation-specific in Go (spec: "the behavior is implementation-dependent") -> 0 here
+        const double lim = ldexp(1.0, 8 * w - (dtype_is_signed(dtype) ? 1 : 0));
+        if (!(v == v) || v >= lim || v <= -lim) break;
+        if (dtype_is_signed(dtype)) store_value(dtype, value_out, (uint64_t)(int64_t)v);
+        else if (v > 0) store_value(dtype, value_out, (uint64_t)v);
+        break;
+    }
     default:
         return KNOX_E_UNSUPPORTED;
     }
@@ -1694,10 +1771,25 @@ static uint64_t order_key(int dtype, uint64_t bits) {
 KNOX_API int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out) {
     if (!states || !out || n <= 0) return KNOX_E_INVALID;
     knox_agg_state r = states[0];
+    // central moments: re-centre every part on the first non-empty part's shift K --
+    //   sum (v-K) = D_i + n_i*d,  sum (v-K)^2 = Q_i + 2*d*D_i + n_i*d^2,  d = K_i - K  (binary128)
+    bool mom_ok = true, mom_any = false;
+    double mom_k = 0.0;
+    __float128 mom_d = 0, mom_q = 0;
+    for (int i = 0; i < n; i++) {
+        const knox_agg_state &s = states[i];
+        if (s.count <= 0) continue;
+        if (!(s.flags & 2u)) { mom_ok = false; break; }
+        if (!mom_any) { mom_k = s.m_shift; mom_any = true; }
+        const __float128 d = (__float128)s.m_shift - (__float128)mom_k, ni = (__float128)s.count;
+        const __float128 Di = (__float128)s.m_dev_hi + (__float128)s.m_dev_lo, Qi = (__float128)s.m_sq_hi + (__float128)s.m_sq_lo;
+        mom_d += Di + ni * d;
+        mom_q += Qi + 2 * d * Di + ni * d * d;
+    }
     for (int i = 1; i < n; i++) {
         const knox_agg_state &s = states[i];
         if (s.dtype != r.dtype) return KNOX_E_INVALID;
-        r.flags |= s.flags;
+        r.flags |= s.flags & 1u;
         r.count += s.count;
         r.isum += s.isum;
         {   // double-double add, same form as the device merge
@@ -1719,6 +1811,18 @@ KNOX_API int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_stat
         }
         if (s.first_row >= 0 && (r.first_row < 0 || s.first_row < r.first_row)) { r.first_row = s.first_row; r.first_bits = s.first_bits; }
         if (s.last_row >= 0 && (r.last_row < 0 || s.last_row > r.last_row)) { r.last_row = s.last_row; r.last_bits = s.last_bits; }
+    }
+    r.flags &= ~2u;
+    r.m_shift = r.m_dev_hi = r.m_dev_lo = r.m_sq_hi = r.m_sq_lo = 0.0;
+    if (mom_ok && mom_any) {
+        r.flags |= 2u;
+        r.m_shift = mom_k;
+        r.m_dev_hi = (double)mom_d;
+        r.m_dev_lo = (double)(mom_d - (__float128)r.m_dev_hi);
+        r.m_sq_hi = (double)mom_q;
+        r.m_sq_lo = (double)(mom_q - (__float128)r.m_sq_hi);
+        if (!(fabs(r.m_dev_hi) <= 1.7976931348623157e308)) r.m_dev_lo = 0.0;
+        if (!(fabs(r.m_sq_hi) <= 1.7976931348623157e308)) r.m_sq_lo = 0.0;
     }
     *out = r;
     return KNOX_OK;

@@ -66,6 +66,10 @@ struct AggStateDev {
     double fsum_hi, fsum_lo;
     uint64_t min_bits, max_bits, first_bits, last_bits;
     int64_t min_row, max_row, first_row, last_row;
+    // second-pass central moments (var/std), valid when flags bit1 is set
+    double m_shift;             // K: the first pass's mean estimate
+    double m_dev_hi, m_dev_lo;  // sum of (v - K)
+    double m_sq_hi, m_sq_lo;    // sum of (v - K)^2
 };
 
 int tile_rows(int width);  // rows per workgroup tile of the streaming kernels
@@ -85,6 +89,13 @@ hipError_t launch_reduce(hipStream_t s, int width, unsigned agg, int grid, const
 hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials, int n_partials,
                            const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out,
                            int64_t *count_out);
+
+// Second pass for VarReducer / StdReducer (internal/reducer/reducer.go:352-429): double-double sums
+// of (v - K) and (v - K)^2 over the selected rows, K = state_in->fsum_hi / count (the first pass's
+// mean) or `shift` when state_in == nullptr.  partials: 4 doubles per workgroup.  out5 receives
+// {K, dev_hi, dev_lo, sq_hi, sq_lo}; *flags_out |= 2 when given.
+hipError_t launch_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask, uint64_t n_rows,
+                          const AggStateDev *state_in, double shift, double *partials, double *out5, uint32_t *flags_out);
 
 // ---- time-window (bucket) aggregation over a non-decreasing int64 time column ----------------
 struct BucketItem {        // one work item: a chunk of one window's contiguous row range

@@ -654,6 +654,7 @@ __global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *part
             s.max_bits = (agg_col && s.max_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.maxrow - row_base) : 0;
             s.first_bits = (agg_col && s.first_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.firstrow - row_base) : 0;
             s.last_bits = (agg_col && s.last_row >= 0) ? (uint64_t)load_elem<W>(agg_col, t.lastrow1 - 1 - row_base) : 0;
+            s.m_shift = 0.0; s.m_dev_hi = 0.0; s.m_dev_lo = 0.0; s.m_sq_hi = 0.0; s.m_sq_lo = 0.0;
             *state_out = s;
         }
     }
@@ -775,6 +776,145 @@ hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials,
     case 1: KNOX_LAUNCH((finalize_kernel<1>), 1, partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
     default: return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second pass for VarReducer / StdReducer (internal/reducer/reducer.go:352-429).  The reference
+// runs Welford's recurrence row by row; a parallel scan uses the corrected two-pass form instead:
+//     K = mean estimate of pass 1,  D = sum (v - K),  Q = sum (v - K)^2,
+//     m2 = Q - D*D/n,  var = m2 / (n - 1)
+// v - K is kept exact as a double-double (TwoSum), its square to ~2^-104, both sums double-double,
+// so Q carries no cancellation (all terms >= 0) and the host's final m2 is correctly rounded in
+// practice.  Any non-finite selected value makes Q NaN -- as it makes the reference's m2 NaN.
+// ---------------------------------------------------------------------------------------------
+struct Mom {
+    double qh, ql, dh, dl;
+    __device__ __forceinline__ void init() { qh = ql = dh = dl = 0.0; }
+    __device__ __forceinline__ void add(double v, double k0, bool hit) {
+        double a = v - k0;
+        const double bb = a - v;
+        double b = (v - (a - bb)) + (-k0 - bb);
+        if (!hit) { a = 0.0; b = 0.0; }
+        const double p = a * a;
+        const double e = __builtin_fma(a, a, -p) + 2.0 * a * b;
+        dd_add(qh, ql, p, e);
+        dd_add(dh, dl, a, b);
+    }
+    __device__ __forceinline__ void merge(const Mom &o) {
+        dd_add(qh, ql, o.qh, o.ql);
+        dd_add(dh, dl, o.dh, o.dl);
+    }
+};
+
+__device__ __forceinline__ void mom_block_reduce(Mom &m, Mom *sm) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Mom o;
+        o.qh = shfl_down_f64(m.qh, off); o.ql = shfl_down_f64(m.ql, off);
+        o.dh = shfl_down_f64(m.dh, off); o.dl = shfl_down_f64(m.dl, off);
+        m.merge(o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < kBlock / 64; w++) m.merge(sm[w]);
+}
+
+__device__ __forceinline__ double moments_shift(const AggStateDev *st, double shift) {
+    if (st == nullptr) return shift;
+    return st->count > 0 ? st->fsum_hi / (double)st->count : 0.0;
+}
+
+template <int W, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) moments_kernel(const void *col, const uint32_t *mask, uint64_t n_tiles, uint64_t n_rows,
+                                                         const AggStateDev *st, double shift, double *partials) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr int WAVE_ROWS = RPL * kUnroll;
+    __shared__ Mom sm[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const double k0 = moments_shift(st, shift);
+    Mom m;
+    m.init();
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t row0 = (tile * kWavesPerBlock + (uint64_t)wave) * WAVE_ROWS;
+        const u32x4 *p = (const u32x4 *)col + row0 / K + lane;
+        u32x4 r[kUnroll];
+        uint32_t q[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            r[u] = ld16<true>(p + u * 64);
+            q[u] = mask ? mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t qq = (q[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+#pragma unroll
+            for (int j = 0; j < K; j++) m.add(to_f64_c<W, FLV>(elem<W>(r[u], j)), k0, ((qq >> j) & 1u) != 0);
+        }
+    }
+    // ragged tail: rows the full tiles do not cover, by workgroup 0
+    if (blockIdx.x == 0) {
+        const uint8_t *mask8 = (const uint8_t *)mask;
+        for (uint64_t row = n_tiles * (uint64_t)(kWavesPerBlock * WAVE_ROWS) + threadIdx.x; row < n_rows; row += kBlock) {
+            const bool hit = mask8 ? ((mask8[row >> 3] >> (row & 7)) & 1u) != 0 : true;
+            m.add(to_f64_c<W, FLV>((U)load_elem<W>(col, row)), k0, hit);
+        }
+    }
+    mom_block_reduce(m, sm);
+    if (threadIdx.x == 0) {
+        double *o = partials + 4 * (size_t)blockIdx.x;
+        o[0] = m.qh; o[1] = m.ql; o[2] = m.dh; o[3] = m.dl;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) moments_finalize_kernel(const double *partials, int n_partials, const AggStateDev *st, double shift,
+                                                                  double *out5, uint32_t *flags_out) {
+    __shared__ Mom sm[kBlock / 64];
+    Mom m;
+    m.init();
+    for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
+        Mom o;
+        o.qh = partials[4 * i]; o.ql = partials[4 * i + 1]; o.dh = partials[4 * i + 2]; o.dl = partials[4 * i + 3];
+        m.merge(o);
+    }
+    mom_block_reduce(m, sm);
+    if (threadIdx.x == 0) {
+        out5[0] = moments_shift(st, shift);
+        out5[1] = m.dh; out5[2] = m.dl; out5[3] = m.qh; out5[4] = m.ql;
+        if (flags_out) *flags_out |= 2u;
+    }
+}
+
+template <int W>
+static hipError_t moments_w(hipStream_t s, uint32_t flavor, int grid, const void *col, const uint32_t *mask, uint64_t n_tiles,
+                            uint64_t n_rows, const AggStateDev *st, double shift, double *partials) {
+    if constexpr (W >= 4) {
+        if (flavor == FL_FLOAT) KNOX_LAUNCH((moments_kernel<W, FL_FLOAT>), grid, col, mask, n_tiles, n_rows, st, shift, partials);
+    }
+    if (flavor == FL_SIGNED) KNOX_LAUNCH((moments_kernel<W, FL_SIGNED>), grid, col, mask, n_tiles, n_rows, st, shift, partials);
+    KNOX_LAUNCH((moments_kernel<W, FL_UNSIGNED>), grid, col, mask, n_tiles, n_rows, st, shift, partials);
+}
+
+hipError_t launch_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask, uint64_t n_rows,
+                          const AggStateDev *state_in, double shift, double *partials, double *out5, uint32_t *flags_out) {
+    const uint64_t n_tiles = n_rows / (uint64_t)tile_rows(width);
+    grid = (int)(n_tiles < (uint64_t)grid ? (n_tiles ? n_tiles : 1) : (uint64_t)grid);
+    hipError_t e;
+    switch (width) {
+    case 8: e = moments_w<8>(s, flavor, grid, col, mask, n_tiles, n_rows, state_in, shift, partials); break;
+    case 4: e = moments_w<4>(s, flavor, grid, col, mask, n_tiles, n_rows, state_in, shift, partials); break;
+    case 2: e = moments_w<2>(s, flavor, grid, col, mask, n_tiles, n_rows, state_in, shift, partials); break;
+    case 1: e = moments_w<1>(s, flavor, grid, col, mask, n_tiles, n_rows, state_in, shift, partials); break;
+    default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(kBlock), 0, s, (const double *)partials, grid, state_in, shift, out5, flags_out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -939,6 +1079,7 @@ __global__ void __launch_bounds__(kBlock) bucket_finalize_kernel(const AggPartia
     s.max_bits = s.max_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.maxrow - row_base) : 0;
     s.first_bits = s.first_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.firstrow - row_base) : 0;
     s.last_bits = s.last_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.lastrow1 - 1 - row_base) : 0;
+    s.m_shift = 0.0; s.m_dev_hi = 0.0; s.m_dev_lo = 0.0; s.m_sq_hi = 0.0; s.m_sq_lo = 0.0;
     state_out[k] = s;
 }
 

@@ -354,9 +354,12 @@ class Context:
               "knox_match_range_vectors")
         return out
 
-    def reduce(self, col, mask=None, row_base=0):
+    def reduce(self, col, mask=None, row_base=0, moments=False):
+        """Masked reduction of one column; moments=True adds the var/std second pass."""
         st = AggState()
         check(self.L.knox_reduce(self.h, col.h, mask.h if mask is not None else None, row_base, C.byref(st)))
+        if moments:
+            check(self.L.knox_reduce_moments(self.h, col.h, mask.h if mask is not None else None, C.byref(st)), "knox_reduce_moments")
         return st
 
     def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False):
