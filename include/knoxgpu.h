@@ -273,7 +273,8 @@ int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mas
  * result equals the reference's for any reducer; out-of-order timestamps (which the reference
  * handles by inserting reducers) return KNOX_E_UNSUPPORTED so the caller keeps the host path.
  * states[k] is the window's mergeable state (count == 0: the reference created no reducer).
- * flags bit0: the caller guarantees the order, skip the verification pass.                   */
+ * flags bit0: the caller guarantees the order, skip the verification pass.
+ * flags bit1: also run the var/std second pass per window (states carry the m_* moments).    */
 int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                         const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                         size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states);

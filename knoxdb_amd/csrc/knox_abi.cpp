@@ -1624,6 +1624,14 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
     if (e == hipSuccess)
         e = launch_bucket_finalize(ctx->stream, value_col->width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, value_col->dev,
                                    row_base, value_col->dtype, (AggStateDev *)(base + off_states));
+    if (e == hipSuccess && (flags & 2)) {
+        // var/std: second pass over the same work items, each centred on its window's mean
+        rc = ensure(ctx, ctx->mom_partials, (n_items + 1) * 4 * sizeof(double));
+        if (rc) return rc;
+        e = launch_bucket_moments(ctx->stream, value_col->width, a.agg_flavor, grid, value_col->dev, a.mask, (const BucketItem *)(base + off_items),
+                                  (uint32_t)n_items, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, (AggStateDev *)(base + off_states),
+                                  (double *)ctx->mom_partials.p);
+    }
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     return download(ctx, states, base + off_states, n_buckets * sizeof(AggStateDev));
 }

@@ -114,6 +114,11 @@ hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanAr
 hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
                                   const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out);
 
+// var/std per window (second pass over the same work items); partials: 4 doubles per work item
+hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask,
+                                 const BucketItem *items, uint32_t n_items, const uint32_t *item_start, uint32_t n_buckets,
+                                 AggStateDev *states, double *partials);
+
 // bitset combinators on 64-bit words (buffers padded to a multiple of 8 bytes)
 enum BitOp { BIT_AND = 0, BIT_ANDNOT = 1, BIT_OR = 2, BIT_XOR = 3, BIT_NEG = 4, BIT_COPY = 5, BIT_ONE = 6 };
 hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *src, uint64_t size_bits,

@@ -1096,6 +1096,108 @@ hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *pa
     }
 }
 
+// var/std per window: the same work items again, each centred on ITS window's mean (already in
+// states[bucket]); 4 doubles per work item, merged per window in row order
+template <int W, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_moments_kernel(const void *col, const uint32_t *mask, const BucketItem *items, uint32_t n_items,
+                                                                const AggStateDev *states, double *partials) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
+    __shared__ Mom sm[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint8_t *mask8 = (const uint8_t *)mask;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint64_t rb = items[it].begin, re = items[it].end;
+        const double k0 = moments_shift(states + items[it].bucket, 0.0);
+        Mom m;
+        m.init();
+        const uint64_t a0 = (rb + WAVE_ROWS - 1) / WAVE_ROWS, a1 = re / WAVE_ROWS;
+        for (uint64_t t = a0 + wave; t < a1; t += kWavesPerBlock) {
+            const uint64_t row0 = t * WAVE_ROWS;
+            const u32x4 *p = (const u32x4 *)col + row0 / K + lane;
+            u32x4 r[kUnroll];
+            uint32_t q[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                r[u] = ld16<true>(p + u * 64);
+                q[u] = mask ? mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t qq = (q[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+#pragma unroll
+                for (int j = 0; j < K; j++) m.add(to_f64_c<W, FLV>(elem<W>(r[u], j)), k0, ((qq >> j) & 1u) != 0);
+            }
+        }
+        const uint64_t e0 = a0 < a1 ? a0 * WAVE_ROWS : re;
+        const uint64_t e1 = a0 < a1 ? a1 * WAVE_ROWS : re;
+        for (int part = 0; part < 2; part++) {
+            const uint64_t lo = part == 0 ? rb : e1, hi = part == 0 ? e0 : re;
+            for (uint64_t row = lo + threadIdx.x; row < hi; row += blockDim.x) {
+                const bool hit = mask8 ? ((mask8[row >> 3] >> (row & 7)) & 1u) != 0 : true;
+                m.add(to_f64_c<W, FLV>((U)load_elem<W>(col, row)), k0, hit);
+            }
+        }
+        mom_block_reduce(m, sm);
+        if (threadIdx.x == 0) {
+            double *o = partials + 4 * (size_t)it;
+            o[0] = m.qh; o[1] = m.ql; o[2] = m.dh; o[3] = m.dl;
+        }
+        __syncthreads();  // sm is reused by the next item
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bucket_moments_finalize_kernel(const double *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                                                         AggStateDev *states) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    Mom m;
+    m.init();
+    for (uint32_t i = item_start[k]; i < item_start[k + 1]; i++) {
+        Mom o;
+        o.qh = partials[4 * (size_t)i]; o.ql = partials[4 * (size_t)i + 1]; o.dh = partials[4 * (size_t)i + 2]; o.dl = partials[4 * (size_t)i + 3];
+        m.merge(o);
+    }
+    AggStateDev *s = states + k;
+    s->m_shift = moments_shift(s, 0.0);
+    s->m_dev_hi = m.dh; s->m_dev_lo = m.dl; s->m_sq_hi = m.qh; s->m_sq_lo = m.ql;
+    s->flags |= 2u;
+}
+
+template <int W>
+static hipError_t bucket_moments_w(hipStream_t s, uint32_t flavor, int grid, const void *col, const uint32_t *mask, const BucketItem *items,
+                                   uint32_t n_items, const AggStateDev *states, double *partials) {
+    if constexpr (W >= 4) {
+        if (flavor == FL_FLOAT) KNOX_LAUNCH((bucket_moments_kernel<W, FL_FLOAT>), grid, col, mask, items, n_items, states, partials);
+    }
+    if (flavor == FL_SIGNED) KNOX_LAUNCH((bucket_moments_kernel<W, FL_SIGNED>), grid, col, mask, items, n_items, states, partials);
+    KNOX_LAUNCH((bucket_moments_kernel<W, FL_UNSIGNED>), grid, col, mask, items, n_items, states, partials);
+}
+
+hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask,
+                                 const BucketItem *items, uint32_t n_items, const uint32_t *item_start, uint32_t n_buckets,
+                                 AggStateDev *states, double *partials) {
+    if (n_buckets == 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (n_items != 0 && grid > 0) {
+        switch (width) {
+        case 8: e = bucket_moments_w<8>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 4: e = bucket_moments_w<4>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 2: e = bucket_moments_w<2>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 1: e = bucket_moments_w<1>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        default: return hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(bucket_moments_finalize_kernel, dim3((n_buckets + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const double *)partials,
+                       item_start, n_buckets, states);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // bitset combinators (internal/bitset/generic/bitset.go:13-330) on 64-bit words.
 // The last word is masked to `size` bits (bytemask semantics extended to the padded word).

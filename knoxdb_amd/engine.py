@@ -362,11 +362,12 @@ class Context:
             check(self.L.knox_reduce_moments(self.h, col.h, mask.h if mask is not None else None, C.byref(st)), "knox_reduce_moments")
         return st
 
-    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False):
-        """One mergeable state per time window [t_from + k*step, +step): NativeBucket semantics."""
+    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False):
+        """One mergeable state per time window [t_from + k*step, +step): NativeBucket semantics.
+        moments=True adds the var/std second pass per window."""
         states = (AggState * n_buckets)()
         check(self.L.knox_reduce_buckets(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
-                                         n_buckets, row_base, 1 if assume_sorted else 0, states), "knox_reduce_buckets")
+                                         n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), states), "knox_reduce_buckets")
         return [states[i] for i in range(n_buckets)]
 
     def reduce_sequential(self, col, func, mask=None):

@@ -204,3 +204,59 @@ def test_var_two_columns_and_multipass(ctx):
     assert abs(int(res.value(2)[0]) - int(math.sqrt(exact_var(a[sel].astype(np.float64))))) <= 1
     ca.free()
     cb.free()
+
+
+def test_var_per_time_window(ctx):
+    """var/std per window (knox_reduce_buckets flags bit1): every window centred on its own mean;
+    windows spanning several work items (> 65536 rows), tiny windows and empty windows."""
+    rng = np.random.default_rng(17)
+    n = 400000
+    dt = rng.integers(0, 3, size=n)
+    dt[100000:300000] = 0  # one window holding 200k rows -> several work items
+    dt[rng.integers(0, n, size=50)] += 5000  # empty windows
+    t = (1_700_000_000 + np.cumsum(dt)).astype(np.int64)
+    step = 1000
+    t_from = int(t[0])
+    nb = int((t[-1] - t_from) // step) + 1
+    tcol = ctx.upload(t, 4096)
+    sel = rng.random(n) < 0.7
+    mask = ctx.bits(n).upload(np.packbits(sel, bitorder="little"))
+    for npdt in (np.float64, np.int32, np.uint8):
+        if npdt == np.float64:
+            v = (rng.standard_normal(n) * 5 + 1e7 + np.arange(n) * 0.01).astype(npdt)
+        else:
+            info = np.iinfo(npdt)
+            v = rng.integers(info.min, int(info.max) + 1, size=n).astype(npdt)
+        vcol = ctx.upload(v, 4096)
+        states = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=mask, moments=True)
+        win = (t - t_from) // step
+        checked = 0
+        for k in list(range(0, nb, max(1, nb // 40))) + [int(win[150000])]:
+            xs = v[(win == k) & sel].astype(np.float64)
+            st = states[k]
+            assert st.count == xs.size
+            if xs.size == 0:
+                continue
+            assert st.flags & 2
+            gv, seen, _ = K.agg_value(st, R.Var)
+            assert seen
+            if xs.size < 2:
+                if npdt == np.float64:
+                    assert math.isnan(gv)
+                continue
+            want = exact_var(xs)
+            if npdt == np.float64:
+                assert ulps(float(gv), want) <= 1, k
+                assert ulps(float(K.agg_value(st, R.Std)[0]), math.sqrt(want)) <= 1
+            elif want < float(np.iinfo(npdt).max):
+                assert abs(int(gv) - int(want)) <= 1
+            checked += 1
+        assert checked > 10
+        # windows merge like row ranges: all windows combined == the global variance
+        allst = K.agg_combine([s for s in states])
+        wantall = exact_var(v[sel & (win >= 0) & (win < nb)].astype(np.float64))
+        if npdt == np.float64:
+            assert ulps(float(K.agg_value(allst, R.Var)[0]), wantall) <= 1
+        vcol.free()
+    tcol.free()
+    mask.free()
