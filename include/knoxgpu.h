@@ -247,6 +247,18 @@ int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_col
 int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_state *states, int n_aggs,
                       knox_scan_out *out);
 
+/* Int128 / Int256 matchers ("next" row f4): cmp_i128_eq..bw / cmp_i256_eq..bw
+ * (internal/cmp/int128.go:14-471, int256.go:14-270) over the reference's stride layout
+ * num.Int128Stride{X0 []int64, X1 []uint64} / Int256Stride{X0..X3} (pkg/num/int128_stride.go:19-22,
+ * int256_stride.go:22-27): limbs[l] is the resident 8-byte integer column of limb l, MOST
+ * significant first; a / b hold n_limbs uint64, most significant first (num.Int128 = [2]uint64).
+ * op = KNOX_EQ..KNOX_LE or KNOX_RANGE (a <= v && v <= b, signed).  bits = hits & mask (mask
+ * nullable; bits is pre-zeroed by the caller per the Matcher contract).  *count (nullable) =
+ * popcount of the result -- NOT the reference's return value when a mask is given: its unrolled
+ * i128 loops add the popcount of the unmasked byte (int128.go:40-41), documented in DESIGN.md. */
+int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 | 4 */, int op, const uint64_t *a,
+                    const uint64_t *b /* RANGE only */, const knox_bits *mask, knox_bits *bits, int64_t *count);
+
 /* Matcher.MatchRangeVectors (operator/filter/match.go:66-71; numeric forms match_num.go:357-371,
  * 396-403, 429-434, 460-465, 491-496, 522-527, 573-588): vectorized zone-map test over the
  * per-pack min / max statistics columns (one row per pack) -- which packs MAY contain a match.

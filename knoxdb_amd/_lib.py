@@ -106,6 +106,7 @@ SIGNATURES = {
     "knox_scan_collect": (_i, [_vp, _vp, C.POINTER(AggState), _i, C.POINTER(ScanOut)]),
     "knox_match_range_vectors": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _vp, _vp]),
     "knox_reduce": (_i, [_vp, _vp, _vp, _u64, C.POINTER(AggState)]),
+    "knox_match_wide": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, C.POINTER(_i64)]),
     "knox_reduce_moments": (_i, [_vp, _vp, _vp, C.POINTER(AggState)]),
     "knox_reduce_buckets": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(AggState)]),
     "knox_reduce_sequential": (_i, [_vp, _vp, _vp, _i, _vp, _pi, C.POINTER(_i64)]),

@@ -740,6 +740,51 @@ KNOX_API int knox_bits_match_bool(knox_ctx *ctx, const knox_bits *column, int op
     }
 }
 
+// Int128 / Int256 matchers over limb columns (cmp_i128_* / cmp_i256_*)
+KNOX_API int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs, int op, const uint64_t *a, const uint64_t *b,
+                             const knox_bits *mask, knox_bits *bits, int64_t *count) {
+    if (!ctx || !limbs || !a || !bits || (n_limbs != 2 && n_limbs != 4)) return KNOX_E_INVALID;
+    if (op == KNOX_RANGE && !b) return KNOX_E_INVALID;
+    if (!(op == KNOX_EQ || op == KNOX_NE || op == KNOX_LT || op == KNOX_LE || op == KNOX_GT || op == KNOX_GE || op == KNOX_RANGE)) return KNOX_E_UNSUPPORTED;
+    const size_t n_rows = limbs[0] ? limbs[0]->n_rows : 0;
+    for (int l = 0; l < n_limbs; l++) {
+        // X0 is []int64, X1.. are []uint64 (num.Int128Stride); any 8-byte integer column is accepted
+        if (!limbs[l] || limbs[l]->ctx != ctx || limbs[l]->n_rows != n_rows || limbs[l]->width != 8 || dtype_is_float(limbs[l]->dtype)) return KNOX_E_INVALID;
+    }
+    if (bits->size != n_rows || (mask && mask->size != n_rows)) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    int rc = ensure(ctx, ctx->misc, 256);
+    if (rc) return rc;
+    unsigned long long *d_cnt = (unsigned long long *)((char *)ctx->misc.p + 64);
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    WideArgs w;
+    memset(&w, 0, sizeof w);
+    for (int l = 0; l < n_limbs; l++) {
+        w.limb[l] = (const uint64_t *)limbs[l]->dev;
+        w.a[l] = a[l];
+        w.b[l] = b ? b[l] : a[l];
+    }
+    w.a[0] ^= 1ull << 63;  // signed top limb -> unsigned order
+    w.b[0] ^= 1ull << 63;
+    w.op = (uint32_t)op;
+    w.mask = mask ? (const uint32_t *)mask->dev : nullptr;
+    w.bits = (uint32_t *)bits->dev;
+    w.n_tiles = n_rows / (uint64_t)tile_rows(8);
+    w.n_rows = n_rows;
+    w.count = d_cnt;
+    const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(w.n_tiles, 1), (uint64_t)ctx->n_cus * 4);
+    hipError_t e = launch_wide_cmp(ctx->stream, n_limbs, grid, w);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    if (count) {
+        unsigned long long h = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&h, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *count = (int64_t)h;
+    }
+    return KNOX_OK;
+}
+
 KNOX_API int knox_bits_popcount(knox_ctx *ctx, const knox_bits *b, int64_t *count) {
     if (!ctx || !b || !count) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);

@@ -119,6 +119,20 @@ hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int 
                                  const BucketItem *items, uint32_t n_items, const uint32_t *item_start, uint32_t n_buckets,
                                  AggStateDev *states, double *partials);
 
+// Int128 / Int256 compare over limb columns (most significant first; a / b already sign-flipped in limb 0)
+struct WideArgs {
+    const uint64_t *limb[4];
+    uint64_t a[4], b[4];
+    uint32_t op;             // FilterMode: 1 eq 2 ne 3 gt 4 ge 5 lt 6 le 9 range
+    uint32_t _pad;
+    const uint32_t *mask;    // nullable
+    uint32_t *bits;
+    uint64_t n_tiles;        // full tiles of tile_rows(8) rows
+    uint64_t n_rows;
+    unsigned long long *count;  // pre-zeroed, nullable
+};
+hipError_t launch_wide_cmp(hipStream_t s, int n_limbs, int grid, const WideArgs &w);
+
 // bitset combinators on 64-bit words (buffers padded to a multiple of 8 bytes)
 enum BitOp { BIT_AND = 0, BIT_ANDNOT = 1, BIT_OR = 2, BIT_XOR = 3, BIT_NEG = 4, BIT_COPY = 5, BIT_ONE = 6 };
 hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *src, uint64_t size_bits,

@@ -1199,6 +1199,118 @@ hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Int128 / Int256 compares over the stride layout (internal/cmp/int128.go:14-471, int256.go:14-270;
+// num.Int128Stride{X0 []int64, X1 []uint64}, Int256Stride{X0..X3}): one 8-byte limb column per
+// limb, most significant first.  The order is lexicographic with a signed top limb
+// (pkg/num/int128.go:541-555, int256.go:701-713): the host flips the sign bit of a[0] / b[0], the
+// kernel flips it on the loaded top limb, and every limb compares unsigned.  A lane owns 2 adjacent
+// rows per 16-byte load of every limb column (the W = 8 layout), words are assembled with the same
+// DPP butterfly as the scan kernel.  result = hits & mask (bits pre-zeroed per the Matcher
+// contract); rows past the last full tile are written byte-granular (poison-tail rule).
+// ---------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ bool wide_hit(uint32_t op, const uint64_t (&x)[L], const uint64_t (&a)[L], const uint64_t (&b)[L]) {
+    bool lt = false, eq = true;  // row <=> a
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        lt = lt || (eq && x[l] < a[l]);
+        eq = eq && x[l] == a[l];
+    }
+    switch (op) {
+    case 1: return eq;            // FilterModeEqual
+    case 2: return !eq;           // NotEqual
+    case 3: return !lt && !eq;    // Gt
+    case 4: return !lt;           // Ge
+    case 5: return lt;            // Lt
+    case 6: return lt || eq;      // Le
+    default: {                    // Range: a <= x && x <= b
+        bool gt = false, e2 = true;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            gt = gt || (e2 && x[l] > b[l]);
+            e2 = e2 && x[l] == b[l];
+        }
+        return !lt && !gt;
+    }
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(kBlock) wide_cmp_kernel(const WideArgs w) {
+    constexpr int RPL = 128;               // rows per wave-load (64 lanes x 2)
+    constexpr int WAVE_ROWS = RPL * kUnroll;
+    constexpr uint64_t SIGN = 1ull << 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint64_t a[L], b[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) { a[l] = w.a[l]; b[l] = w.b[l]; }
+    uint32_t cnt = 0;
+    for (uint64_t tile = blockIdx.x; tile < w.n_tiles; tile += gridDim.x) {
+        const uint64_t row0 = (tile * kWavesPerBlock + (uint64_t)wave) * WAVE_ROWS;
+        u32x4 r[L][kUnroll];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const u32x4 *p = (const u32x4 *)w.limb[l] + row0 / 2 + lane;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<true>(p + u * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            uint32_t q = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                uint64_t x[L];
+#pragma unroll
+                for (int l = 0; l < L; l++) x[l] = elem<8>(r[l][u], j);
+                x[0] ^= SIGN;
+                q |= (wide_hit<L>(w.op, x, a, b) ? 1u : 0u) << j;
+            }
+            uint32_t word = pack_word<2>(q, lane);  // complete in every lane of the 16-lane group
+            const uint64_t wi = ((row0 + (uint64_t)u * RPL) >> 5) + (lane >> 4);
+            if ((lane & 15) == 0) {
+                if (w.mask) word &= w.mask[wi];
+                w.bits[wi] = word;
+                cnt += __builtin_popcount(word);
+            }
+        }
+    }
+    // ragged tail by workgroup 0: thread t owns output bytes t, t + 256, ...
+    if (blockIdx.x == 0) {
+        const uint64_t start = w.n_tiles * (uint64_t)(kWavesPerBlock * WAVE_ROWS);
+        if (start < w.n_rows) {
+            const uint64_t nbytes = (w.n_rows - start + 7) >> 3;
+            const uint8_t *mask8 = (const uint8_t *)w.mask;
+            for (uint64_t bi = threadIdx.x; bi < nbytes; bi += blockDim.x) {
+                uint32_t out = 0;
+                for (int k = 0; k < 8; k++) {
+                    const uint64_t row = start + 8 * bi + k;
+                    if (row >= w.n_rows) break;
+                    uint64_t x[L];
+#pragma unroll
+                    for (int l = 0; l < L; l++) x[l] = w.limb[l][row];
+                    x[0] ^= SIGN;
+                    out |= (wide_hit<L>(w.op, x, a, b) ? 1u : 0u) << k;
+                }
+                if (mask8) out &= mask8[(start >> 3) + bi];
+                ((uint8_t *)w.bits)[(start >> 3) + bi] = (uint8_t)out;
+                cnt += __builtin_popcount(out);
+            }
+        }
+    }
+    // count: wave reduce, one atomic per wave
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0 && cnt && w.count) atomicAdd(w.count, (unsigned long long)cnt);
+}
+
+hipError_t launch_wide_cmp(hipStream_t s, int n_limbs, int grid, const WideArgs &w) {
+    if (grid < 1) grid = 1;
+    if (n_limbs == 2) KNOX_LAUNCH((wide_cmp_kernel<2>), grid, w);
+    if (n_limbs == 4) KNOX_LAUNCH((wide_cmp_kernel<4>), grid, w);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
 // bitset combinators (internal/bitset/generic/bitset.go:13-330) on 64-bit words.
 // The last word is masked to `size` bits (bytemask semantics extended to the padded word).
 // flags[0] |= any set bit, flags[1] |= any valid bit clear (all == !flags[1]).

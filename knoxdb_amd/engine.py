@@ -354,6 +354,18 @@ class Context:
               "knox_match_range_vectors")
         return out
 
+    def match_wide(self, limbs, mode, a, b=None, mask=None, bits=None):
+        """Int128 / Int256 matcher over limb columns (most significant first) -> (Bits, count)."""
+        n = len(limbs)
+        arr = (C.c_void_p * n)(*[c.h for c in limbs])
+        av = (C.c_uint64 * n)(*[int(v) & (2**64 - 1) for v in a])
+        bv = (C.c_uint64 * n)(*[int(v) & (2**64 - 1) for v in b]) if b is not None else None
+        out = bits if bits is not None else self.bits(limbs[0].rows)
+        cnt = C.c_int64()
+        check(self.L.knox_match_wide(self.h, arr, n, int(mode), av, bv, mask.h if mask is not None else None, out.h, C.byref(cnt)),
+              "knox_match_wide")
+        return out, cnt.value
+
     def reduce(self, col, mask=None, row_base=0, moments=False):
         """Masked reduction of one column; moments=True adds the var/std second pass."""
         st = AggState()

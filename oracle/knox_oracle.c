@@ -856,6 +856,67 @@ KO_EXPORT int ko_bool_match(int op, int a, int b, const uint8_t *src, int64_t si
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Int128 / Int256 compare kernels over the stride layout (one limb slice per 64-bit limb,
+ * X0 = most significant, signed):  internal/cmp/int128.go:14-471, int256.go:14-270;
+ * ordering num.Int128.Lt/Le/Gt/Ge pkg/num/int128.go:541-555 (signed top limb, then unsigned
+ * limbs), num.Int256.Lt pkg/num/int256.go:701-713 (sign test, then unsigned compare) -- the
+ * same lexicographic order.  limbs[l][i] = limb l of row i; a / b most significant limb first.
+ *
+ * Mask handling restated as written: the unrolled i128 eq..ge loops store `b & m` per full byte
+ * but add popcount(b) -- the UNMASKED byte -- to the returned count (int128.go:40-41 and
+ * siblings); their tails, cmp_i128_bw and all cmp_i256_* count only mask-selected hits.
+ * `quirk_count` selects the former so the returned count is the reference's in both families.
+ * ---------------------------------------------------------------------------------------- */
+static int wide_cmp3(const uint64_t *const *limbs, int nl, int64_t i, const uint64_t *v) {
+    /* -1 / 0 / +1 : row i <=> v */
+    int64_t x0 = (int64_t)limbs[0][i], v0 = (int64_t)v[0];
+    if (x0 != v0) return x0 < v0 ? -1 : 1;
+    for (int l = 1; l < nl; l++) {
+        if (limbs[l][i] != v[l]) return limbs[l][i] < v[l] ? -1 : 1;
+    }
+    return 0;
+}
+static int wide_hit(int op, const uint64_t *const *limbs, int nl, int64_t i, const uint64_t *a, const uint64_t *b) {
+    int c = wide_cmp3(limbs, nl, i, a);
+    switch (op) {
+    case KO_EQ: return c == 0;
+    case KO_NE: return c != 0;
+    case KO_LT: return c < 0;
+    case KO_LE: return c <= 0;
+    case KO_GT: return c > 0;
+    case KO_GE: return c >= 0;
+    default: return c >= 0 && wide_cmp3(limbs, nl, i, b) <= 0; /* a.Le(v) && b.Ge(v) */
+    }
+}
+KO_EXPORT int64_t ko_cmp_wide(int n_limbs, int op, const uint64_t *const *limbs, int64_t n, const uint64_t *a, const uint64_t *b,
+                              uint8_t *bits, const uint8_t *mask) {
+    if ((n_limbs != 2 && n_limbs != 4) || !(op == KO_EQ || op == KO_NE || op == KO_LT || op == KO_LE || op == KO_GT || op == KO_GE || op == KO_RG))
+        return -1;
+    int64_t cnt = 0;
+    const int unrolled = n_limbs == 2 && op != KO_RG; /* the byte-at-a-time i128 loops */
+    if (unrolled) {
+        int64_t nb = n / 8;
+        for (int64_t i = 0; i < nb; i++) {
+            if (mask && mask[i] == 0) continue;
+            uint8_t byte = 0;
+            for (int k = 0; k < 8; k++) byte |= (uint8_t)(wide_hit(op, limbs, n_limbs, i * 8 + k, a, b) << k);
+            bits[i] = mask ? (uint8_t)(byte & mask[i]) : byte;
+            cnt += __builtin_popcount(byte); /* unmasked, as written */
+        }
+        for (int64_t i = nb * 8; i < n; i++) {
+            if (mask && !((mask[nb] >> (i & 7)) & 1)) continue;
+            if (wide_hit(op, limbs, n_limbs, i, a, b)) { bits[nb] |= (uint8_t)(1u << (i & 7)); cnt++; }
+        }
+        return cnt;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        if (mask && !((mask[i >> 3] >> (i & 7)) & 1)) continue;
+        if (wide_hit(op, limbs, n_limbs, i, a, b)) { bits[i >> 3] |= (uint8_t)(1u << (i & 7)); cnt++; }
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
  * IN / NOT IN set matchers on materialized blocks:
  *   integers  numInSetMatcher / numNotInSetMatcher.MatchVector  operator/filter/match_num.go:672-690, :789-808
  *             (membership of uint64(v) in a set built from uint64(T(x)), i.e. equality on T)

@@ -237,6 +237,24 @@ def bool_match(op, a, b, src, size):
     return out
 
 
+def cmp_wide(op, limbs, a, b=None, mask=None):
+    """Int128 / Int256 compare over limb slices (most significant first) -> (bits, count)."""
+    limbs = [np.ascontiguousarray(x).view(np.uint64) for x in limbs]
+    n = limbs[0].size
+    arr = (C.c_void_p * len(limbs))(*[x.ctypes.data for x in limbs])
+    av = np.array([int(v) & (2**64 - 1) for v in a], dtype=np.uint64)
+    bv = np.array([int(v) & (2**64 - 1) for v in (b if b is not None else a)], dtype=np.uint64)
+    out = np.zeros(bitfield_len(n) + 32, dtype=np.uint8)
+    out[bitfield_len(n):] = 0xFA  # poison tail (internal/cmp/tests/tests.go:24-48)
+    m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+    f = lib().ko_cmp_wide
+    f.restype = C.c_int64
+    cnt = f(len(limbs), int(op), arr, C.c_int64(n), _p(av), _p(bv), _p(out), _p(m))
+    assert cnt >= 0
+    assert (out[bitfield_len(n):] == 0xFA).all(), "oracle wrote past the bitset"
+    return out[:bitfield_len(n)].copy(), int(cnt)
+
+
 def inset(dtype, negate, src, values, mask=None, bits=None):
     src = np.ascontiguousarray(src, dtype=NP[dtype])
     vals = np.ascontiguousarray(values, dtype=NP[dtype])

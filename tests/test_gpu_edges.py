@@ -81,8 +81,10 @@ def test_error_codes_instead_of_crashes(ctx):
     with pytest.raises(K.KnoxError) as e:     # bitset of the wrong size
         ctx.scan(And(Leaf(0, FilterMode.Lt, 5)), [x], bits_out=ctx.bits(999))
     assert e.value.code == -1
-    with pytest.raises(K.KnoxError) as e:     # unknown reducer function
-        ctx.scan(And(Leaf(0, FilterMode.Lt, 5)), [x], aggs=[(42, 0)])
+    plan = ctx.plan(And(Leaf(0, FilterMode.Lt, 5)), [x], aggs=[(R.Sum, 0)])
+    plan[4][0].func = 42                      # unknown reducer function
+    with pytest.raises(K.KnoxError) as e:
+        ctx.scan_async(plan)
     assert e.value.code == -5
     a, b = ctx.bits(100), ctx.bits(101)
     with pytest.raises(K.KnoxError):          # size mismatch: error here, silent no-op in Go

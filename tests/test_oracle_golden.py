@@ -155,3 +155,47 @@ def test_bloom_no_false_negatives():
     other = rng.integers(2**63, 2**64 - 1, size=20000, dtype=np.uint64)
     fp = sum(O.bloom_contains(f, O.lib().ko_xxh3_u64(int(k))) for k in other) / other.size
     assert fp < 10 * 0.002394  # design p for factor 2, pack/stats/filter.go:303-311
+
+
+WIDE = json.load(open(os.path.join(G, "cmp_wide_cases.json")))["cases"]
+
+
+def wide_limbs(c):
+    """stride layout (num.Int128Stride / Int256Stride): one uint64 array per limb, X0 first"""
+    nl = 2 if c["dtype"] == "i128" else 4
+    src = np.array(c["src"], dtype=np.uint64).reshape(-1, nl)
+    return [np.ascontiguousarray(src[:, l]) for l in range(nl)]
+
+
+@pytest.mark.parametrize("dtype", ["i128", "i256"])
+def test_cmp_wide_golden(dtype):
+    """internal/cmp/tests/int128.go, int256.go: count, exact bytes, poison tail"""
+    cases = [c for c in WIDE if c["dtype"] == dtype]
+    assert len(cases) == 119
+    for c in cases:
+        bits, cnt = O.cmp_wide(O.OPNAME[c["op"]], wide_limbs(c), c["a"], c["b"])
+        assert bits.tobytes().hex() == c["result"], (dtype, c["op"], c["name"])
+        assert cnt == c["count"], (dtype, c["op"], c["name"])
+
+
+def test_cmp_wide_mask_semantics():
+    """mask restatement: bits = hits & mask everywhere; the unrolled i128 loops count the
+    UNMASKED byte (int128.go:40-41), the per-row loops count masked hits only"""
+    rng = np.random.default_rng(5)
+    n = 77
+    for nl in (2, 4):
+        limbs = [rng.integers(0, 4, size=n).astype(np.uint64) for _ in range(nl)]
+        a = [1] * nl
+        mask = rng.integers(0, 256, size=O.bitfield_len(n)).astype(np.uint8)
+        mask[3] = 0
+        full, full_cnt = O.cmp_wide(O.OPNAME["ge"], limbs, a)
+        got, cnt = O.cmp_wide(O.OPNAME["ge"], limbs, a, mask=mask)
+        want = full & mask
+        want[-1] &= 0xFF >> (8 - n % 8)
+        assert (got == want).all()
+        if nl == 4:
+            assert cnt == O.popcount(want, n)
+        else:
+            nb = n // 8
+            unmasked_full_bytes = sum(bin(int(full[i])).count("1") for i in range(nb) if mask[i])
+            assert cnt == unmasked_full_bytes + bin(int(want[nb])).count("1")
