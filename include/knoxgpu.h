@@ -182,7 +182,9 @@ int knox_bits_match_bool(knox_ctx *ctx, const knox_bits *column, int op, int a, 
  * The tree is flattened to postfix: leaves push, AND/OR pop `nchild` operands.
  * Leaf = filter.Filter{Type, Mode, Index, Value} (operator/filter/filter.go:22-30):
  * `col` indexes the cols[] array, a/b hold the value bits of the column type (little-endian,
- * zero-extended to 64 bit; b only for KNOX_RANGE).  Bytes leaves (EQ/NE) pass val/val_len;
+ * zero-extended to 64 bit; b only for KNOX_RANGE).  Bytes leaves pass val/val_len -- EQ/NE
+ * (StringPool.MatchEqual/NotEqual, pkg/stringx/match.go:20-84) and the bytes.Compare ordered modes
+ * LT/LE/GT/GE/RANGE (:86-251, RANGE = [val, val2] inclusive);
  * KNOX_IN / KNOX_NOTIN leaves pass the set as val = array of column-type values, val_len =
  * its length in BYTES (numInSetMatcher / floatInSetMatcher, match_num.go:593-808).           */
 enum knox_node_kind { KNOX_NODE_LEAF = 0, KNOX_NODE_AND = 1, KNOX_NODE_OR = 2 };
@@ -192,8 +194,10 @@ typedef struct knox_pred {
     int32_t col;    /* leaf: index into cols[] */
     int32_t op;     /* leaf: knox_op */
     uint64_t a, b;  /* leaf: value bits */
-    const uint8_t *val; /* bytes leaf: value */
+    const uint8_t *val; /* bytes leaf: value (RANGE: lower bound); IN / NOT IN: the set */
     uint64_t val_len;
+    const uint8_t *val2; /* bytes leaf, KNOX_RANGE: upper bound (inclusive) */
+    uint64_t val2_len;
 } knox_pred;
 
 typedef struct knox_agg {

@@ -26,7 +26,8 @@ class KnoxError(RuntimeError):
 class Pred(C.Structure):
     """knox_pred (include/knoxgpu.h) -- one postfix node of a filter.Node tree."""
     _fields_ = [("kind", C.c_int32), ("nchild", C.c_int32), ("col", C.c_int32), ("op", C.c_int32),
-                ("a", C.c_uint64), ("b", C.c_uint64), ("val", C.c_char_p), ("val_len", C.c_uint64)]
+                ("a", C.c_uint64), ("b", C.c_uint64), ("val", C.c_char_p), ("val_len", C.c_uint64),
+                ("val2", C.c_char_p), ("val2_len", C.c_uint64)]
 
 
 class Agg(C.Structure):

@@ -1148,16 +1148,20 @@ static uint64_t order_key(int dtype, uint64_t bits);
 
 static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *col, size_t n_rows, uint64_t *bits, int grid) {
     if (col->dtype == KNOX_BYTES) {
-        if (p.op != KNOX_EQ && p.op != KNOX_NE) return KNOX_E_UNSUPPORTED;
+        const bool ordered = p.op == KNOX_LT || p.op == KNOX_LE || p.op == KNOX_GT || p.op == KNOX_GE || p.op == KNOX_RANGE;
+        if (p.op != KNOX_EQ && p.op != KNOX_NE && !ordered) return KNOX_E_UNSUPPORTED;  // IN / regexp: host path
         if (p.val_len > 0xffffffffull || (p.val_len && !p.val)) return KNOX_E_INVALID;
-        int rc = ensure(ctx, ctx->bytes_val, (size_t)p.val_len + 16);
+        const size_t len2 = p.op == KNOX_RANGE ? (size_t)p.val2_len : 0;
+        if (len2 > 0xffffffffull || (len2 && !p.val2)) return KNOX_E_INVALID;
+        const size_t off2 = ((size_t)p.val_len + 15) & ~(size_t)15;
+        int rc = ensure(ctx, ctx->bytes_val, off2 + len2 + 16);
         if (rc) return rc;
-        if (p.val_len) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, p.val, (size_t)p.val_len, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host value not retained
-        }
-        hipError_t e = launch_bytes_match(ctx->stream, p.op == KNOX_EQ, (const uint64_t *)col->dev, n_rows, col->buf,
-                                          (const uint8_t *)ctx->bytes_val.p, (uint32_t)p.val_len, (uint8_t *)bits, nullptr, nullptr);
+        if (p.val_len) HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, p.val, (size_t)p.val_len, hipMemcpyHostToDevice, ctx->stream));
+        if (len2) HIPCHK(ctx, hipMemcpyAsync((char *)ctx->bytes_val.p + off2, p.val2, len2, hipMemcpyHostToDevice, ctx->stream));
+        if (p.val_len || len2) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host values not retained
+        hipError_t e = launch_bytes_match(ctx->stream, p.op, (const uint64_t *)col->dev, n_rows, col->buf, (const uint8_t *)ctx->bytes_val.p,
+                                          (uint32_t)p.val_len, (const uint8_t *)ctx->bytes_val.p + off2, (uint32_t)len2, (uint8_t *)bits, nullptr,
+                                          nullptr);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return KNOX_E_HIP;

@@ -145,9 +145,9 @@ hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_
 hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
                           uint32_t *rows_out, uint64_t capacity, unsigned long long *n_out);
 
-// bytes column EQ / NE (StringPool layout)
-hipError_t launch_bytes_match(hipStream_t s, bool want_eq, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                              const uint8_t *val, uint32_t vlen, uint8_t *bits, const uint8_t *mask,
+// bytes column matchers (StringPool layout): mode = FilterMode 1 eq 2 ne 3 gt 4 ge 5 lt 6 le 9 range [val, val2]
+hipError_t launch_bytes_match(hipStream_t s, int mode, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                              const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2, uint8_t *bits, const uint8_t *mask,
                               unsigned long long *count_out /* pre-zeroed */);
 
 // IN / NOT IN: membership of the value's canonical order key in a sorted key set (binary search);

@@ -1532,9 +1532,26 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t *p, const uint8_t *v, 
     return true;
 }
 
-__global__ void __launch_bounds__(kBlock) bytes_match_kernel(int want_eq, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                                                             const uint8_t *val, uint32_t vlen, uint8_t *bits,
-                                                             const uint8_t *mask, unsigned long long *count_out) {
+// bytes.Compare(p[:n], v[:m]): -1 / 0 / +1, byte-lexicographic, a proper prefix sorts first
+__device__ __forceinline__ int bytes_cmp3(const uint8_t *p, uint32_t n, const uint8_t *v, uint32_t m) {
+    const uint32_t c = n < m ? n : m;
+    uint32_t i = 0;
+    for (; i + 8 <= c; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, p + i, 8);
+        __builtin_memcpy(&y, v + i, 8);
+        if (x != y) return __builtin_bswap64(x) < __builtin_bswap64(y) ? -1 : 1;  // first differing byte decides
+    }
+    for (; i < c; i++)
+        if (p[i] != v[i]) return p[i] < v[i] ? -1 : 1;
+    return n == m ? 0 : (n < m ? -1 : 1);
+}
+
+// mode = FilterMode: 1 eq, 2 ne (MatchEqual / MatchNotEqual stringx/match.go:20-84), 3 gt, 4 ge, 5 lt,
+// 6 le, 9 range [val, val2] (MatchGreater.. / MatchBetween :86-251)
+__global__ void __launch_bounds__(kBlock) bytes_match_kernel(int mode, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                                                             const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2,
+                                                             uint8_t *bits, const uint8_t *mask, unsigned long long *count_out) {
     const int lane = threadIdx.x & 63;
     const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint64_t ngroups = (n_rows + 63) >> 6;
@@ -1545,8 +1562,19 @@ __global__ void __launch_bounds__(kBlock) bytes_match_kernel(int want_eq, const 
         if (row < n_rows) {
             const uint64_t p = ptr[row];
             const uint32_t ofs = (uint32_t)(p >> 32), len = (uint32_t)p;
-            const bool eq = (len == vlen) && bytes_equal(buf + ofs, val, len);
-            m = want_eq ? eq : !eq;
+            if (mode <= 2) {
+                const bool eq = (len == vlen) && bytes_equal(buf + ofs, val, len);
+                m = mode == 1 ? eq : !eq;
+            } else {
+                const int c = bytes_cmp3(buf + ofs, len, val, vlen);
+                switch (mode) {
+                case 3: m = c > 0; break;
+                case 4: m = c >= 0; break;
+                case 5: m = c < 0; break;
+                case 6: m = c <= 0; break;
+                default: m = c >= 0 && bytes_cmp3(buf + ofs, len, val2, vlen2) <= 0; break;
+                }
+            }
         }
         const uint64_t ballot = __ballot(m);
         if (lane < 8) {
@@ -1563,13 +1591,13 @@ __global__ void __launch_bounds__(kBlock) bytes_match_kernel(int want_eq, const 
     if (lane == 0 && cnt && count_out) atomicAdd(count_out, (unsigned long long)cnt);
 }
 
-hipError_t launch_bytes_match(hipStream_t s, bool want_eq, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                              const uint8_t *val, uint32_t vlen, uint8_t *bits, const uint8_t *mask,
+hipError_t launch_bytes_match(hipStream_t s, int mode, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                              const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2, uint8_t *bits, const uint8_t *mask,
                               unsigned long long *count_out) {
     if (n_rows == 0) return hipSuccess;
     uint64_t g = (n_rows + kBlock - 1) / kBlock;
     if (g > 2048 * 4) g = 2048 * 4;
-    KNOX_LAUNCH(bytes_match_kernel, (int)g, want_eq ? 1 : 0, ptr, n_rows, buf, val, vlen, bits, mask, count_out);
+    KNOX_LAUNCH(bytes_match_kernel, (int)g, mode, ptr, n_rows, buf, val, vlen, val2, vlen2, bits, mask, count_out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -44,6 +44,10 @@ def _flatten(node, cols, out, keep):
             val = bytes(node.a)
             keep.append(val)
             p.val, p.val_len = val, len(val)
+            if node.b is not None:
+                val2 = bytes(node.b)
+                keep.append(val2)
+                p.val2, p.val2_len = val2, len(val2)
         elif node.mode in (FilterMode.In, FilterMode.NotIn):
             val = np.ascontiguousarray(node.a, dtype=NP_DTYPE[c.dtype]).tobytes()
             keep.append(val)

@@ -712,20 +712,38 @@ KO_EXPORT int ko_bloom_contains(const uint8_t *buf, int64_t buf_len, uint64_t h)
 }
 
 /* ------------------------------------------------------------------------------------------
- * bytes column: pkg/stringx/pool.go:45-58 (ptr = off<<32 | len), match.go:20-84
+ * bytes column: pkg/stringx/pool.go:45-58 (ptr = off<<32 | len), match.go:20-251
  * mask == NULL: every byte of bits (incl. partial last byte) is overwritten, returns count.
  * mask != NULL: only bits.Set(i) for mask-selected matching rows, returns -1 (count unknown).
  * ---------------------------------------------------------------------------------------- */
-KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const uint8_t *buf, const uint8_t *val,
-                                 int64_t vlen, uint8_t *bits, const uint8_t *mask) {
-    int want_eq = (op == KO_EQ);
-    if (op != KO_EQ && op != KO_NE) return -2;
+/* bytes.Compare */
+static int bytes_compare(const uint8_t *p, uint32_t n, const uint8_t *v, uint32_t m) {
+    uint32_t c = n < m ? n : m;
+    int r = c ? memcmp(p, v, c) : 0;
+    if (r) return r < 0 ? -1 : 1;
+    return n == m ? 0 : (n < m ? -1 : 1);
+}
+/* one row of MatchEqual / NotEqual / Less / LessEqual / Greater / GreaterEqual / Between
+ * (pkg/stringx/match.go:20-251) */
+static int bytes_row_hit(int op, const uint8_t *p, uint32_t len, const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2) {
+    switch (op) {
+    case KO_EQ: return len == vlen && (len == 0 || memcmp(p, val, len) == 0);
+    case KO_NE: return !(len == vlen && (len == 0 || memcmp(p, val, len) == 0));
+    case KO_LT: return bytes_compare(p, len, val, vlen) < 0;
+    case KO_LE: return bytes_compare(p, len, val, vlen) <= 0;
+    case KO_GT: return bytes_compare(p, len, val, vlen) > 0;
+    case KO_GE: return bytes_compare(p, len, val, vlen) >= 0;
+    default: return bytes_compare(p, len, val, vlen) >= 0 && bytes_compare(p, len, val2, vlen2) <= 0;
+    }
+}
+KO_EXPORT int64_t ko_bytes_match2(int op, const uint64_t *ptr, int64_t n, const uint8_t *buf, const uint8_t *val, int64_t vlen,
+                                  const uint8_t *val2, int64_t vlen2, uint8_t *bits, const uint8_t *mask) {
+    if (!(op == KO_EQ || op == KO_NE || op == KO_LT || op == KO_LE || op == KO_GT || op == KO_GE || op == KO_RG)) return -2;
     if (mask) {
         for (int64_t i = 0; i < n; i++) {
             if (!((mask[i >> 3] >> (i & 7)) & 1)) continue;
             uint32_t ofs = (uint32_t)(ptr[i] >> 32), len = (uint32_t)ptr[i];
-            int eq = (len == (uint32_t)vlen) && (len == 0 || memcmp(buf + ofs, val, len) == 0);
-            if (eq == want_eq) bits[i >> 3] |= (uint8_t)(1 << (i & 7));
+            if (bytes_row_hit(op, buf + ofs, len, val, (uint32_t)vlen, val2, (uint32_t)vlen2)) bits[i >> 3] |= (uint8_t)(1 << (i & 7));
         }
         return -1;
     }
@@ -734,14 +752,18 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
     for (int64_t i = 0; i < n; i++) {
         uint32_t ofs = (uint32_t)(ptr[i] >> 32), len = (uint32_t)ptr[i];
         int k = (int)(i & 7);
-        int eq = (len == (uint32_t)vlen) && (len == 0 || memcmp(buf + ofs, val, len) == 0);
-        uint8_t bit = (uint8_t)(eq == want_eq);
+        uint8_t bit = (uint8_t)bytes_row_hit(op, buf + ofs, len, val, (uint32_t)vlen, val2, (uint32_t)vlen2);
         b |= (uint8_t)(bit << k);
         cnt += bit;
         if (k == 7) { bits[i >> 3] = b; b = 0; }
     }
     if ((n & 7) > 0) bits[n >> 3] = b;
     return cnt;
+}
+KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const uint8_t *buf, const uint8_t *val,
+                                 int64_t vlen, uint8_t *bits, const uint8_t *mask) {
+    if (op != KO_EQ && op != KO_NE) return -2;
+    return ko_bytes_match2(op, ptr, n, buf, val, vlen, NULL, 0, bits, mask);
 }
 
 /* ------------------------------------------------------------------------------------------

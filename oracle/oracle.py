@@ -207,13 +207,18 @@ def bloom_contains(buf, h):
     return bool(lib().ko_bloom_contains(_p(buf), buf.size, h))
 
 
-def bytes_match(op, ptr, buf, val, mask=None, bits=None):
+def bytes_match(op, ptr, buf, val, mask=None, bits=None, val2=None):
+    """StringPool.Match* (EQ/NE/LT/LE/GT/GE, RANGE = [val, val2])"""
     ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
     n = ptr.size
     out = np.zeros(bitfield_len(n), dtype=np.uint8) if bits is None else np.array(bits, dtype=np.uint8, copy=True)
     m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
-    cnt = lib().ko_bytes_match(op, _p(ptr), n, _p(buf), bytes(val), len(val), _p(out), _p(m))
+    v2 = bytes(val2) if val2 is not None else b""
+    f = lib().ko_bytes_match2
+    f.restype = C.c_int64
+    cnt = f(int(op), _p(ptr), C.c_int64(n), _p(buf), bytes(val), C.c_int64(len(val)), v2, C.c_int64(len(v2)), _p(out), _p(m))
+    assert cnt != -2, "unsupported bytes mode"
     return out, cnt
 
 

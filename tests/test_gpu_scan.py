@@ -194,6 +194,34 @@ def test_bytes_column_eq_ne_and_mixed_tree(ctx):
     check_scan(ctx, And(Leaf(0, FilterMode.Equal, keys[3]), Leaf(1, FilterMode.Lt, 10000)), [(ptr, buf), ids], [(R.Max, 1)], 1024, n)
 
 
+def test_bytes_column_ordered_modes(ctx):
+    """StringPool.MatchLess / LessEqual / Greater / GreaterEqual / Between (pkg/stringx/match.go:86-251):
+    bytes.Compare order -- byte-lexicographic, a proper prefix sorts first, empty string lowest."""
+    rng = np.random.default_rng(29)
+    n = 9000 + 5
+    keys = [b"", b"a", b"ab", b"abc", b"abd", b"b", b"\x00", b"\x00\x00", b"\xff", b"\xff\x00", b"abcdefgh", b"abcdefgi", b"abcdefghi",
+            b"abcdefghabcdefgh", b"abcdefghabcdefgi", b"abcdefgh\x80", b"abcdefgh\x7f"]
+    keys += [bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8)) for _ in range(60)]
+    pick = rng.integers(0, len(keys), size=n)
+    vals = [keys[i] for i in pick]
+    buf = np.frombuffer(b"".join(vals) + b"\x00" * 8, dtype=np.uint8)
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    ids = np.arange(n, dtype=np.uint64)
+    # python bytes order == bytes.Compare order: cross-check the oracle once, independently
+    want_lt = np.packbits(np.array([v < b"abcdefgh" for v in vals]), bitorder="little")
+    assert (O.bytes_match(O.LT, ptr, buf, b"abcdefgh")[0] == want_lt).all()
+    for key in (b"", b"abc", b"abcdefgh", b"abcdefgh\x80", b"\xff", keys[20], b"zzzz-absent"):
+        for op in (FilterMode.Lt, FilterMode.Le, FilterMode.Gt, FilterMode.Ge):
+            check_scan(ctx, And(Leaf(0, op, key)), [(ptr, buf), ids], [(R.Count, 1)], 1024, n)
+    for lo, hi in ((b"a", b"abd"), (b"", b"\x00\x00"), (b"abcdefgh", b"abcdefghi"), (b"b", b"a"), (keys[25], keys[25])):
+        check_scan(ctx, And(Leaf(0, FilterMode.Range, lo, hi)), [(ptr, buf), ids], [(R.Sum, 1)], 1024, n)
+    # inside a mixed tree (multi-pass plan)
+    check_scan(ctx, Or(Leaf(0, FilterMode.Lt, b"abc"), And(Leaf(0, FilterMode.Ge, b"\xff"), Leaf(1, FilterMode.Lt, 5000))),
+               [(ptr, buf), ids], [(R.Max, 1)], 1024, n)
+
+
 def test_pack_skip_is_an_optimisation_only(ctx):
     # packs pruned by a bloom / zone map (no false negatives) produce the same bitset, fewer rows read
     n, pack = 8 * 4096, 4096

@@ -199,3 +199,29 @@ def test_cmp_wide_mask_semantics():
             nb = n // 8
             unmasked_full_bytes = sum(bin(int(full[i])).count("1") for i in range(nb) if mask[i])
             assert cnt == unmasked_full_bytes + bin(int(want[nb])).count("1")
+
+
+def test_bytes_ordered_modes_vs_python_bytes_order():
+    """StringPool.MatchLess.. / MatchBetween (pkg/stringx/match.go:86-251) use bytes.Compare, whose
+    order is Python's bytes order: an independent check of the restatement, mask path included."""
+    rng = np.random.default_rng(3)
+    keys = [b"", b"a", b"ab", b"abc", b"b", b"\x00", b"\xff", b"abcdefgh", b"abcdefghi", b"abcdefgh\x80"]
+    keys += [bytes(rng.integers(0, 256, size=int(rng.integers(0, 20)), dtype=np.uint8)) for _ in range(40)]
+    n = 1003
+    vals = [keys[i] for i in rng.integers(0, len(keys), size=n)]
+    buf = np.frombuffer(b"".join(vals) + b"\x00", dtype=np.uint8)
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    mask = rng.integers(0, 256, size=O.bitfield_len(n)).astype(np.uint8)
+    pred = {O.LT: lambda v, a, b: v < a, O.LE: lambda v, a, b: v <= a, O.GT: lambda v, a, b: v > a, O.GE: lambda v, a, b: v >= a,
+            O.RG: lambda v, a, b: a <= v <= b, O.EQ: lambda v, a, b: v == a, O.NE: lambda v, a, b: v != a}
+    for a, b in ((b"abc", b"abcdefghi"), (b"", b"\xff"), (keys[15], keys[30]), (b"b", b"a")):
+        for op, fn in pred.items():
+            want = np.packbits(np.array([fn(v, a, b) for v in vals]), bitorder="little")
+            got, cnt = O.bytes_match(op, ptr, buf, a, val2=b)
+            assert (got == want).all() and cnt == int(np.unpackbits(want, bitorder="little")[:n].sum()), (op, a, b)
+            gm, _ = O.bytes_match(op, ptr, buf, a, mask=mask, val2=b)
+            wm = want & mask
+            wm[-1] &= 0xFF >> (8 - n % 8)
+            assert (gm == wm).all()
