@@ -59,6 +59,7 @@ struct knox_ctx {
     DevBuf pack_counts;  // int64 per pack
     DevBuf misc;         // flags / counters / small outputs
     DevBuf mom_partials; // var/std second pass: 4 doubles per workgroup
+    DevBuf tile_counts;  // fused scan: popcount per wave tile -> per-pack counts
     DevBuf idx_scratch;  // indexes: block offsets
     DevBuf idx_rows;     // indexes: row ids
     DevBuf bytes_val;    // bytes leaf value
@@ -252,7 +253,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
-                      &ctx->misc, &ctx->mom_partials, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
+                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
     for (DevBuf *b : bufs)
         if (b->p) hipFree(b->p);
     for (int i = 0; i < 2; i++) {
@@ -1018,9 +1019,10 @@ struct SkipPlan {
 // single fused pass: leaves (same width) + optional aggregate column, into partial slot `slot`
 static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_col *const *lcols, int n_leaves, uint64_t tt,
                      const knox_col *agg_col, unsigned agg, size_t n_rows, size_t pack_rows, uint64_t row_base,
-                     SkipPlan *skip, uint32_t *bits, int slot, int grid, int dtype_for_state) {
+                     SkipPlan *skip, uint32_t *bits, int slot, int grid, int dtype_for_state, uint32_t *per_pack_tiles = nullptr) {
     ScanArgs a;
     memset(&a, 0, sizeof a);
+    if (per_pack_tiles) *per_pack_tiles = 0;
     for (int l = 0; l < n_leaves; l++) {
         a.leaf[l].col = lcols[l]->dev;
         a.leaf[l].lo = lh[l].lo;
@@ -1074,6 +1076,16 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
         }
     } else {
         a.pack_shift = 255;
+    }
+    // per-pack counts for free: when packs are whole numbers of wave tiles and nothing is left for the
+    // tail kernel, every wave records the popcount of its burst (4 B per wave tile)
+    if (per_pack_tiles && bits && ctx->variant != 2 && pack_rows) {
+        const uint64_t wave_tile = tr / kWavesPerBlock;
+        if (a.tail_first_row == n_rows && n_rows % pack_rows == 0 && pack_rows % wave_tile == 0 && pack_rows / wave_tile <= 0xffffffffull &&
+            ensure(ctx, ctx->tile_counts, (n_rows / wave_tile) * 4 + 64) == KNOX_OK) {
+            a.tile_counts = (uint32_t *)ctx->tile_counts.p;
+            *per_pack_tiles = (uint32_t)(pack_rows / wave_tile);
+        }
     }
     a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
@@ -1339,6 +1351,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     }
 
     int first_reduce_slot = 0;
+    uint32_t per_pack_tiles = 0;  // != 0: the fused kernel left per-wave-tile counts
     if (fused) {
         LeafHost lh[kMaxLeaves];
         const knox_col *lc[kMaxLeaves];
@@ -1378,7 +1391,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         rc = make_truth_table(nodes, n_nodes, lof, neg, n_leaves, tt);
         if (rc) return rc;
         rc = run_fused(ctx, width, lh, lc, n_leaves, tt, ac, acls, n_rows, pack_rows, row_base, pack_skip ? &skip : nullptr, (uint32_t *)bits, 0,
-                       grid, ac ? ac->dtype : lc[0]->dtype);
+                       grid, ac ? ac->dtype : lc[0]->dtype, want_pack_counts ? &per_pack_tiles : nullptr);
         if (rc) return rc;
         if (skip.used) slot.rows_scanned = n_rows - rows_pruned;
     } else {
@@ -1448,7 +1461,10 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     slot.has_pack_counts = false;
     slot.n_packs = n_packs;
     if (want_pack_counts && n_packs) {
-        hipError_t e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)((char *)ctx->states.p + res_base), n_packs);
+        hipError_t e = per_pack_tiles
+                           ? launch_pack_counts(ctx->stream, (const uint32_t *)ctx->tile_counts.p, per_pack_tiles, n_packs,
+                                                skip.used ? skip.d_skip : nullptr, (int64_t *)((char *)ctx->states.p + res_base))
+                           : launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)((char *)ctx->states.p + res_base), n_packs);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         slot.has_pack_counts = true;
     }

@@ -497,12 +497,21 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             // 16 iterations): whole 128-B lines, 16-byte-per-lane streaming (nt) stores.
             const uint32_t nv = iters * (WAVE_ROWS / 128);  // 16-byte vectors
             u32x4 *dst = (u32x4 *)(a.bits + (wrow0 >> 5));
+            uint32_t tc = 0;
             for (uint32_t v = lane; v < nv; v += 64) {
                 const u32x4 x = ((const u32x4 *)stage[wave])[v];
+                tc += __builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w);
                 // debug bit0 = diagnostics: words are assembled but never leave the CU
                 if (a.debug & 2u) dst[v] = x;  // diagnostics: plain (L2 write-back) store
                 else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
                 else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
+            }
+            if (a.tile_counts != nullptr) {
+                // popcount of this wave tile's burst, once per tile: the per-pack counts
+                // (Bitset.ResetCount) then come from 4 B per 1024+ rows instead of re-reading the bitset
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) tc += __shfl_down(tc, off, 64);
+                if (lane == 0) a.tile_counts[tile * kWavesPerBlock + (uint64_t)wave] = tc;
             }
         }
     }
@@ -1416,6 +1425,27 @@ __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bi
         if (threadIdx.x == 0) counts[seg] = (int64_t)(sm[0] + sm[1] + sm[2] + sm[3]);
         __syncthreads();
     }
+}
+
+// per-pack counts from the scan kernel's per-wave-tile counts: one wave per pack
+__global__ void __launch_bounds__(kBlock) pack_counts_kernel(const uint32_t *tile_counts, uint32_t per_pack, uint64_t n_packs,
+                                                             const uint8_t *skip, int64_t *counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t p = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (p >= n_packs) return;
+    uint64_t c = 0;
+    if (skip == nullptr || skip[p] == 0) {
+        const uint32_t *t = tile_counts + p * (uint64_t)per_pack;
+        for (uint32_t i = lane; i < per_pack; i += 64) c += t[i];
+    }
+    for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
+    if (lane == 0) counts[p] = (int64_t)c;
+}
+
+hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t per_pack, uint64_t n_packs, const uint8_t *skip,
+                              int64_t *counts) {
+    if (n_packs == 0) return hipSuccess;
+    KNOX_LAUNCH(pack_counts_kernel, (int)((n_packs + kBlock / 64 - 1) / (kBlock / 64)), tile_counts, per_pack, n_packs, skip, counts);
 }
 
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,

@@ -222,6 +222,50 @@ def test_bytes_column_ordered_modes(ctx):
                [(ptr, buf), ids], [(R.Max, 1)], 1024, n)
 
 
+@pytest.mark.parametrize("bt", [BlockType.Int64, BlockType.Float64, BlockType.Int32, BlockType.Uint16, BlockType.Int8])
+def test_pack_counts_from_the_scan_kernel(ctx, bt):
+    """whole packs, no ragged tail: the per-pack counts come from the scan kernel's per-wave-tile
+    popcounts (no second pass over the bitset) -- must equal the popcount of every pack's slice,
+    also with pruned packs (compact live-pack walk) and for a multi-leaf tree"""
+    rng = np.random.default_rng(300 + int(bt))
+    pack, n_packs = 16384, 24
+    n = pack * n_packs
+    x = rand_col(bt, n, rng)
+    y = rand_col(bt, n, rng)
+    cx, cy = ctx.upload(x, pack), ctx.upload(y, pack)
+    skip = np.zeros(n_packs, dtype=np.uint8)
+    for tree, cols, hcols in ((And(Leaf(0, FilterMode.Ge, 3)), [cx], [x]),
+                              (Or(Leaf(0, FilterMode.Lt, 2), And(Leaf(1, FilterMode.Ge, 1), Leaf(0, FilterMode.NotEqual, 5))), [cx, cy], [x, y])):
+        want = oracle_match(tree, hcols, n)
+        per_pack = [O.popcount(want[p * pack // 8:(p + 1) * pack // 8], pack) for p in range(n_packs)]
+        bits = ctx.bits(n)
+        res = ctx.scan(tree, cols, aggs=[(R.Count, 0)], bits_out=bits, pack_counts=True)
+        assert (bits.bytes() == want).all()
+        assert res.pack_counts.tolist() == per_pack and res.count == sum(per_pack)
+        # prune the packs that hold no match (what a zone map / bloom may do) plus nothing else
+        skip[:] = [1 if c == 0 else 0 for c in per_pack]
+        skip[5] = 1 if per_pack[5] == 0 else skip[5]
+        res2 = ctx.scan(tree, cols, aggs=[(R.Count, 0)], bits_out=bits, pack_counts=True, pack_skip=skip)
+        assert (bits.bytes() == want).all() and res2.pack_counts.tolist() == per_pack
+        bits.free()
+    # all-zero packs in the data so that pruning really skips something
+    z = x.copy()
+    z[3 * pack:7 * pack] = 0
+    cz = ctx.upload(z, pack)
+    tree = And(Leaf(0, FilterMode.Gt, 0) if z.dtype.kind != "f" else Leaf(0, FilterMode.Gt, 0.0))
+    want = oracle_match(tree, [z], n)
+    per_pack = [O.popcount(want[p * pack // 8:(p + 1) * pack // 8], pack) for p in range(n_packs)]
+    assert per_pack[3:7] == [0, 0, 0, 0]
+    skip[:] = 0
+    skip[3:7] = 1
+    bits = ctx.bits(n)
+    bits.one()  # stale ones in the pruned range must be cleared by the scan
+    res3 = ctx.scan(tree, [cz], aggs=[(R.Count, 0)], bits_out=bits, pack_counts=True, pack_skip=skip)
+    assert (bits.bytes() == want).all() and res3.pack_counts.tolist() == per_pack and res3.rows_scanned == n - 4 * pack
+    for o in (cx, cy, cz, bits):
+        o.free()
+
+
 def test_pack_skip_is_an_optimisation_only(ctx):
     # packs pruned by a bloom / zone map (no false negatives) produce the same bitset, fewer rows read
     n, pack = 8 * 4096, 4096
