@@ -1,0 +1,105 @@
+"""BASELINE.json's full sizes (2^30 rows per GPU, 1024 packs of 2^20) on the device, checked through
+size-independent properties plus sampled packs against the oracle (the device generator and the
+oracle's generator share one counter-based spec, DESIGN.md 9, so any pack can be regenerated on
+the host without holding 8 GiB):
+
+  cfg 2  int64 Between[-2^38, 2^38] + sum + count + bitset + per-pack counts
+  cfg 3  A >= 256.0 AND B < 0.5 over two float64 columns, min / max / mean(A) + count
+"""
+import numpy as np
+import pytest
+
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf
+from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc as R
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+N, PACK = 1 << 30, 1 << 20
+SAMPLE = (0, 1, 511, 777, 1023)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def test_cfg2_full_size_properties(ctx):
+    a, b = -(1 << 38), 1 << 38
+    col = ctx.generate(BlockType.Int64, 0, 2, N, lo=-(1 << 40), span=1 << 41, pack_rows=PACK)
+    bits = ctx.bits(N)
+    tree = And(Leaf(0, FilterMode.Range, a, b))
+    res = ctx.scan(tree, [col], aggs=[(R.Sum, 0), (R.Count, 0), (R.Min, 0), (R.Max, 0), (R.First, 0), (R.Last, 0)], bits_out=bits, pack_counts=True)
+    # checksum of checksums: per-pack counts, total, popcount kernel and the count reducer agree
+    assert int(res.pack_counts.sum()) == res.count == bits.count() == int(res.value(1)[0])
+    assert abs(res.count / N - 0.25) < 2e-4
+    assert a <= res.value(2)[0] <= res.value(3)[0] <= b
+    # idempotence: a second scan into a fresh bitset gives the same bytes
+    bits2 = ctx.bits(N)
+    res2 = ctx.scan(tree, [col], aggs=[(R.Sum, 0)], bits_out=bits2, pack_counts=True)
+    assert res2.count == res.count and (res2.pack_counts == res.pack_counts).all() and res2.value(0)[0] == res.value(0)[0]
+    bits2.xor(bits)
+    assert bits2.count() == 0
+    # partition: the complement's count and wrapping sum add up to the whole column
+    bits2.copy_from(bits).neg()
+    st = ctx.reduce(col, bits2)
+    whole = ctx.reduce(col)
+    assert K.agg_value(st, R.Count)[0] + res.count == N == K.agg_value(whole, R.Count)[0]
+    assert (int(K.agg_value(st, R.Sum)[0]) + int(res.value(0)[0])) % (1 << 64) == int(K.agg_value(whole, R.Sum)[0]) % (1 << 64)
+    # pruning every second pack by hand: counts of the kept packs are unchanged, the others 0
+    skip = np.zeros(N // PACK, dtype=np.uint8)
+    skip[1::2] = 1
+    res3 = ctx.scan(tree, [col], aggs=[(R.Count, 0)], bits_out=bits2, pack_counts=True, pack_skip=skip)
+    assert (res3.pack_counts[0::2] == res.pack_counts[0::2]).all() and int(res3.pack_counts[1::2].sum()) == 0
+    assert res3.rows_scanned == N // 2
+    # sampled packs bit-exact against the oracle: bitset bytes, count, wrapping sum, min, max
+    got = bits.bytes()
+    for p in SAMPLE:
+        x = O.generate(O.I64, 0, 2, p * PACK, PACK, lo=-(1 << 40), span=1 << 41)
+        wb, wc = O.cmp(O.I64, O.RG, x, a, b)
+        assert (got[p * PACK // 8:(p + 1) * PACK // 8] == wb).all() and res.pack_counts[p] == wc, p
+    x0 = O.generate(O.I64, 0, 2, 0, PACK, lo=-(1 << 40), span=1 << 41)
+    wb0, _ = O.cmp(O.I64, O.RG, x0, a, b)
+    first = O.reduce(O.I64, O.R_FIRST, x0, wb0)
+    assert res.value(4)[0] == first[0] and res.value(4)[2] == first[2]
+    xl = O.generate(O.I64, 0, 2, N - PACK, PACK, lo=-(1 << 40), span=1 << 41)
+    wbl, _ = O.cmp(O.I64, O.RG, xl, a, b)
+    last = O.reduce(O.I64, O.R_LAST, xl, wbl)
+    assert res.value(5)[0] == last[0] and res.value(5)[2] == last[2] + (N - PACK)
+    for o in (col, bits, bits2):
+        o.free()
+
+
+def test_cfg3_full_size_properties(ctx):
+    A = ctx.generate(BlockType.Float64, 1, 3, N, pack_rows=PACK)   # k * 2^-10, k < 2^20: every sum order is exact
+    B = ctx.generate(BlockType.Float64, 2, 4, N, pack_rows=PACK)   # uniform [0, 1)
+    bits = ctx.bits(N)
+    tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
+    res = ctx.scan(tree, [A, B], aggs=[(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Count, 0), (R.Sum, 0)], bits_out=bits, pack_counts=True)
+    assert int(res.pack_counts.sum()) == res.count == bits.count()
+    assert abs(res.count / N - 0.75 * 0.5) < 2e-4
+    mn, mx, mean, s = (float(res.value(i)[0]) for i in (0, 1, 2, 4))
+    assert 256.0 <= mn <= mean <= mx < 1024.0
+    # exact-sum grid: sum is an exact multiple of 2^-10 below 2^53 * 2^-10, and mean == sum / count rounded once
+    assert (s * 1024.0).is_integer() and s * 1024.0 < 2.0**53
+    assert mean == s / res.count
+    # AND == intersection of the two single-leaf scans (bitset combinators)
+    ba, bb = ctx.bits(N), ctx.bits(N)
+    ra = ctx.scan(And(Leaf(0, FilterMode.Ge, 256.0)), [A, B], bits_out=ba)
+    rb = ctx.scan(And(Leaf(1, FilterMode.Lt, 0.5)), [A, B], bits_out=bb)
+    ba.and_(bb)
+    ba.xor(bits)
+    assert ba.count() == 0 and ra.count >= res.count <= rb.count
+    # sampled packs against the oracle: bitset bytes, count, and the per-pack exact sum adds up
+    got = bits.bytes()
+    for p in SAMPLE:
+        a = O.generate(O.F64, 1, 3, p * PACK, PACK)
+        b = O.generate(O.F64, 2, 4, p * PACK, PACK)
+        wa, _ = O.cmp(O.F64, O.GE, a, 256.0, 0.0)
+        wb, _ = O.cmp(O.F64, O.LT, b, 0.5, 0.0)
+        want = O.bits_op("and", wa, wb, PACK)
+        assert (got[p * PACK // 8:(p + 1) * PACK // 8] == want).all() and res.pack_counts[p] == O.popcount(want, PACK), p
+    for o in (A, B, bits, ba, bb):
+        o.free()
