@@ -145,7 +145,7 @@ hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32
                               int64_t *counts);
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
                                     int64_t *counts, uint64_t n_seg);
-// bitset -> ascending uint32 row ids; scratch holds ceil(size/8192)+1 uint32 block offsets
+// bitset -> ascending uint32 row ids; scratch holds ceil(size/16384)+1 uint32 block offsets
 hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
                           uint32_t *rows_out, uint64_t capacity, unsigned long long *n_out);
 

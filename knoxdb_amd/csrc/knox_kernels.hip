@@ -1458,16 +1458,16 @@ hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_
 
 // ---------------------------------------------------------------------------------------------
 // Indexes (generic/bitset.go:355-396): bitset -> ascending uint32 row ids.
-// chunk = 8192 bits = 128 words per workgroup; counts -> exclusive scan -> ordered write.
+// chunk = 16384 bits = 256 words per workgroup; counts -> exclusive scan -> ordered write.
 // ---------------------------------------------------------------------------------------------
-constexpr int kIdxWords = 128;
+constexpr int kIdxWords = kBlock;  // one 64-bit word per thread: 16384 bits per workgroup
 
 __global__ void __launch_bounds__(kBlock) idx_count_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
                                                            uint32_t *block_counts) {
     __shared__ uint32_t sm[kBlock / 64];
     const uint64_t i = (uint64_t)blockIdx.x * kIdxWords + threadIdx.x;
     uint32_t c = 0;
-    if (threadIdx.x < kIdxWords && i < nwords) c = __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+    if (i < nwords) c = __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
@@ -1475,28 +1475,46 @@ __global__ void __launch_bounds__(kBlock) idx_count_kernel(const uint64_t *bits,
     if (threadIdx.x == 0) block_counts[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-// single workgroup exclusive scan in place; total written to counts[n] and *n_out
+// inclusive scan of one value per thread over a 64-lane wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// single workgroup exclusive scan in place, 4 entries per thread per round (4096 per round);
+// total written to counts[n] and *n_out
 __global__ void __launch_bounds__(1024) idx_scan_kernel(uint32_t *counts, uint64_t n, unsigned long long *n_out) {
-    __shared__ uint32_t sm[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? counts[i] : 0;
-        sm[threadIdx.x] = v;
+    __shared__ uint32_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;  // identical in every thread
+    for (uint64_t base = 0; base < n; base += 4096) {
+        const uint64_t i = base + 4 * (uint64_t)threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + k < n ? counts[i + k] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t incl = wave_incl_scan(mine, lane);
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t t = threadIdx.x >= (unsigned)off ? sm[threadIdx.x - off] : 0;
-            __syncthreads();
-            sm[threadIdx.x] += t;
-            __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wsum[w];
+            before += w < wave ? t : 0;
+            total += t;
         }
-        const uint32_t incl = sm[threadIdx.x];
-        if (i < n) counts[i] = carry + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
-        __syncthreads();
+        uint32_t o = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < n) counts[i + k] = o;
+            o += v[k];
+        }
+        carry += total;
+        __syncthreads();  // wsum is rewritten next round
     }
     if (threadIdx.x == 0) {
         counts[n] = carry;
@@ -1506,23 +1524,20 @@ __global__ void __launch_bounds__(1024) idx_scan_kernel(uint32_t *counts, uint64
 
 __global__ void __launch_bounds__(kBlock) idx_write_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
                                                            const uint32_t *block_offsets, uint32_t *rows_out, uint64_t capacity) {
-    __shared__ uint32_t sm[kIdxWords];
+    __shared__ uint32_t wsum[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t i = (uint64_t)blockIdx.x * kIdxWords + threadIdx.x;
     uint64_t w = 0;
-    if (threadIdx.x < kIdxWords && i < nwords) w = bits[i] & valid_mask(i, nwords, size_bits);
+    if (i < nwords) w = bits[i] & valid_mask(i, nwords, size_bits);
     const uint32_t c = __builtin_popcountll(w);
-    if (threadIdx.x < kIdxWords) sm[threadIdx.x] = c;
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    // inclusive scan over 128 entries
-    for (int off = 1; off < kIdxWords; off <<= 1) {
-        uint32_t t = 0;
-        if (threadIdx.x < kIdxWords && threadIdx.x >= (unsigned)off) t = sm[threadIdx.x - off];
-        __syncthreads();
-        if (threadIdx.x < kIdxWords) sm[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (threadIdx.x < kIdxWords && c) {
-        uint64_t o = (uint64_t)block_offsets[blockIdx.x] + sm[threadIdx.x] - c;
+    uint32_t before = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; k++) before += k < wave ? wsum[k] : 0;
+    if (c) {
+        uint64_t o = (uint64_t)block_offsets[blockIdx.x] + before + incl - c;
         const uint32_t row0 = (uint32_t)(i << 6);
         while (w) {
             const int k = __builtin_ctzll(w);

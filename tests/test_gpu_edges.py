@@ -170,3 +170,41 @@ def test_four_leaf_mixed_float_int_tree_all_widths(ctx):
         for d in dev:
             d.free()
         bits.free()
+
+
+def test_two_threads_two_contexts_scan_concurrently():
+    """(b) Threading: one knox_ctx per host thread, no shared mutable state in the library --
+    many queries in flight like the reference's b.RunParallel (benchmark3_test.go:112-127)."""
+    import threading
+    rng = np.random.default_rng(77)
+    n = 300000 + 7
+    data = [rng.integers(-1000, 1000, size=n).astype(np.int64) for _ in range(4)]
+    errors, results = [], [None] * 4
+
+    def worker(i):
+        try:
+            with K.Context(0) as c:
+                col = c.upload(data[i], 4096)
+                out = []
+                for rep in range(20):
+                    lo = -500 + 10 * rep + i
+                    bits = c.bits(n)
+                    r = c.scan(And(Leaf(0, FilterMode.Range, lo, lo + 300)), [col], aggs=[(R.Sum, 0)], bits_out=bits, pack_counts=True)
+                    out.append((r.count, int(r.value(0)[0]), int(r.pack_counts.sum()), bits.count()))
+                    bits.free()
+                col.free()
+                results[i] = out
+        except Exception as e:  # surfaced below: an exception in a thread must fail the test
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        for rep, (cnt, s, pc, bc) in enumerate(results[i]):
+            lo = -500 + 10 * rep + i
+            m = (data[i] >= lo) & (data[i] <= lo + 300)
+            assert cnt == pc == bc == int(m.sum()) and s == int(data[i][m].sum()), (i, rep)
