@@ -4,6 +4,7 @@
 // operator pipeline's PhysicalFilter (operator/filter.go:29-37).  Expected values are the
 // reference's golden vector i64_s0 with its results (internal/cmp/tests/int64.go:14-45).
 // Runs on the GPU box: g++ tests/cpp/test_host.cpp -Iknoxdb_amd/csrc/host -Lknoxdb_amd -lknoxgpu
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -78,6 +79,18 @@ int main() {
         EXPECT(sum.seen && sum.value == wsum);
         auto mx = reducer::Aggregate<double>(ctx, *root, pkg, KNOX_R_MAX, 1);
         EXPECT(mx.seen && mx.value == 42.0 && mx.row == 28);
+        // VarReducer / StdReducer (reducer.go:352-429): m2 / (n - 1) over the selected rows
+        double m = 0, m2 = 0;
+        for (uint32_t r : pkg.Selected()) m += f0[r];
+        m /= (double)pkg.Selected().size();
+        for (uint32_t r : pkg.Selected()) m2 += (f0[r] - m) * (f0[r] - m);
+        const double wvar = m2 / (double)(pkg.Selected().size() - 1);
+        auto var = reducer::Aggregate<double>(ctx, *root, pkg, KNOX_R_VAR, 1);
+        auto sd = reducer::Aggregate<double>(ctx, *root, pkg, KNOX_R_STD, 1);
+        EXPECT(var.seen && std::fabs(var.value - wvar) <= 1e-12 * wvar);
+        EXPECT(sd.seen && std::fabs(sd.value - std::sqrt(wvar)) <= 1e-12 * std::sqrt(wvar));
+        auto ivar = reducer::Aggregate<int64_t>(ctx, *root, pkg, KNOX_R_VAR, 0);
+        EXPECT(ivar.seen && ivar.value == (int64_t)wvar);  // T(m2/(n-1)) truncates
     }
     // --- Bitset method semantics (bitset.go:400-540): cnt short-cuts, flags, size mismatch no-op
     {
