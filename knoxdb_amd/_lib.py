@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libknoxgpu.so")
+# KNOXGPU_SO: diagnostics builds only (knoxdb_amd/diag/, `make diag`); the product is the in-tree library
+SO_PATH = os.environ.get("KNOXGPU_SO") or os.path.join(_HERE, "libknoxgpu.so")
 
 COMM_ID_BYTES = 128
 

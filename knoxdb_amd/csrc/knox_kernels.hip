@@ -78,6 +78,35 @@ template <bool NT> __device__ __forceinline__ u32x4 ld16(const u32x4 *p) {
     }
 }
 
+// Diagnostics builds only (make diag): the scan kernel's column loads with an explicit gfx950 cache
+// policy (sc0 / sc1 / nt bits), to separate kernel effects from HBM placement effects.
+// The product build (KNOX_LOAD_POLICY undefined) uses the nontemporal builtin above.
+#ifdef KNOX_LOAD_POLICY
+#if KNOX_LOAD_POLICY == 1
+#define KNOX_LD_BITS ""
+#elif KNOX_LOAD_POLICY == 2
+#define KNOX_LD_BITS " sc0 sc1"
+#elif KNOX_LOAD_POLICY == 3
+#define KNOX_LD_BITS " sc0 sc1 nt"
+#elif KNOX_LOAD_POLICY == 4
+#define KNOX_LD_BITS " sc1"
+#elif KNOX_LOAD_POLICY == 5
+#define KNOX_LD_BITS " sc1 nt"
+#elif KNOX_LOAD_POLICY == 6
+#define KNOX_LD_BITS " sc0"
+#else
+#define KNOX_LD_BITS " nt"
+#endif
+__device__ __forceinline__ u32x4 ld16_policy(const u32x4 *p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" KNOX_LD_BITS : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ void ld_fence(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // bitset word assembly: lane holds q (K bits, rows K*lane .. K*lane+K-1 of the wave-load);
 // the G = 32/K lanes sharing a 32-bit word OR their shifted pieces with a DPP butterfly.
@@ -426,8 +455,17 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
         for (int l = 0; l < NL; l++) {
             const u32x4 *p = (const u32x4 *)a.leaf[l].col + vec0;
 #pragma unroll
+#ifdef KNOX_LOAD_POLICY
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16_policy(p + u * 64);
+#else
             for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<true>(p + u * 64);
+#endif
         }
+#ifdef KNOX_LOAD_POLICY
+        static_assert(kUnroll == 4, "ld_fence takes 4 registers");
+#pragma unroll
+        for (int l = 0; l < NL; l++) ld_fence(r[l][0], r[l][1], r[l][2], r[l][3]);
+#endif
         u32x4 ra[kUnroll];
         if constexpr (SEP && AGG != 0) {
             const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
