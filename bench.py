@@ -186,6 +186,10 @@ def main():
                      "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": kernel_ms,
                      "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW},
         "whole_step_gb_per_s": n_rows * BYTES_PER_ROW / (elapsed / args.steps) / 1e9,
+        # placement-aware allocation (include/knoxgpu.h knox_ctx_set_placement; KNOX_PLACEMENT=0 turns it off):
+        # the allocator's own probe of the column buffer and how many candidates it tried
+        "placement": {"enabled": os.environ.get("KNOX_PLACEMENT", "1") != "0", "probe_gb_per_s": col.placement[0],
+                      "candidates_tried": col.placement[1], "held_gib": ctx.placement_info()["held_bytes"] / 2**30},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr) and args.rows_log2 == 30:

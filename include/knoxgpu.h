@@ -91,6 +91,17 @@ int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms); /* records, syncs, return
 /* Tuning knobs: workgroups per CU of the streaming kernels (0 = auto, <0 keeps the current
  * value); variant: 1 = default, 2 = diagnostics (bitset assembled, never stored), <0 keeps.  */
 int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
+/* Placement-aware column allocation (default on; env KNOX_PLACEMENT=0 or mode 0 turns it off).
+ * On MI355X a physical HBM region runs the scan's read+write mix either at ~6.9 TB/s or at
+ * ~6.0 TB/s.  Owned column buffers >= 256 MiB are probed with the scan kernel right
+ * after allocation; a candidate clearly slower than the best class seen is held back (so the
+ * driver cannot return the same region) and another one is tried, at most 6.  Held regions are
+ * returned to the driver when an allocation would otherwise fail, when placement is switched
+ * off, and at knox_ctx_close.  Results never depend on it.                                  */
+int knox_ctx_set_placement(knox_ctx *ctx, int mode /* 0 off, 1 on */);
+int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *held_regions);
+/* probe rate (GB/s of the 8.125 B/row mix; 0 = not probed) and candidates tried for this column */
+int knox_col_placement(const knox_col *col, double *probe_gbs, int *candidates);
 /* Per-kernel stopwatch: while enabled, every launch of the dominant streaming kernel
  * (scan / reduce) is bracketed by HIP events on the ctx stream; knox_prof_read syncs, returns
  * the summed kernel time and launch count since the last read, and resets.                */

@@ -85,6 +85,15 @@ struct knox_ctx {
     static constexpr int kProfRing = 512;
     hipEvent_t prof_ev[2 * kProfRing] = {};
     int prof_n = 0;
+    // placement-aware column allocation: candidates that probed slow are held so the
+    // driver cannot hand the same physical region out again; released under memory pressure
+    struct Held { void *p; size_t bytes; };
+    std::vector<Held> held;
+    size_t held_bytes = 0;
+    int placement = 1;             // 0 = plain hipMalloc
+    double best_probe[48] = {};    // best probe rate seen, per log2(probe rows)
+    DevBuf probe_bits;
+    hipEvent_t pev0 = nullptr, pev1 = nullptr;
     // RCCL
     void *rccl = nullptr;
     ncclComm_t comm = nullptr;
@@ -102,6 +111,8 @@ struct knox_col {
     uint8_t *buf;   // bytes column payload
     size_t buf_len;
     bool owned;
+    double probe_gbs = 0.0;  // placement probe of the accepted buffer (0 = not probed)
+    int probe_candidates = 0;
 };
 
 struct knox_bits {
@@ -136,6 +147,23 @@ static bool dtype_is_float(int dtype) { return dtype == KNOX_FLOAT64 || dtype ==
 static bool dtype_is_signed(int dtype) { return dtype >= KNOX_INT64 && dtype <= KNOX_INT8; }
 static uint32_t dtype_flavor(int dtype) { return dtype_is_float(dtype) ? FL_FLOAT : dtype_is_signed(dtype) ? FL_SIGNED : FL_UNSIGNED; }
 
+static void release_held(knox_ctx *ctx) {
+    for (auto &h : ctx->held) hipFree(h.p);
+    ctx->held.clear();
+    ctx->held_bytes = 0;
+}
+// hipMalloc that gives the held (slow-probed) regions back to the driver before reporting OOM
+static hipError_t dev_malloc(knox_ctx *ctx, void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && ctx && !ctx->held.empty()) {
+        (void)hipGetLastError();
+        hipStreamSynchronize(ctx->stream);
+        release_held(ctx);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
 static int ensure(knox_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.cap >= bytes) return KNOX_OK;
     if (b.p) {
@@ -147,7 +175,7 @@ static int ensure(knox_ctx *ctx, DevBuf &b, size_t bytes) {
     }
     size_t cap = std::max<size_t>(bytes, 4096);
     cap = (cap + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(&b.p, cap);
+    hipError_t e = dev_malloc(ctx, &b.p, cap);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         b.p = nullptr;
@@ -240,6 +268,8 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
     if (env && atoi(env) > 0) c->blocks_per_cu = atoi(env);
     env = getenv("KNOX_VARIANT");
     if (env) c->variant = atoi(env);
+    env = getenv("KNOX_PLACEMENT");
+    if (env) c->placement = atoi(env);
     *out = c;
     return KNOX_OK;
 }
@@ -256,6 +286,10 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
                       &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
     for (DevBuf *b : bufs)
         if (b->p) hipFree(b->p);
+    if (ctx->probe_bits.p) hipFree(ctx->probe_bits.p);
+    release_held(ctx);
+    if (ctx->pev0) hipEventDestroy(ctx->pev0);
+    if (ctx->pev1) hipEventDestroy(ctx->pev1);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) hipHostFree(ctx->stage[i]);
         if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
@@ -300,6 +334,31 @@ KNOX_API int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant) 
     if (!ctx) return KNOX_E_INVALID;
     if (blocks_per_cu >= 0) ctx->blocks_per_cu = blocks_per_cu;
     if (variant >= 0) ctx->variant = variant;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_set_placement(knox_ctx *ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 1) return KNOX_E_INVALID;
+    ctx->placement = mode;
+    if (mode == 0) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        release_held(ctx);
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *held_regions) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (held_bytes) *held_bytes = (int64_t)ctx->held_bytes;
+    if (held_regions) *held_regions = (int)ctx->held.size();
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_placement(const knox_col *col, double *probe_gbs, int *candidates) {
+    if (!col) return KNOX_E_INVALID;
+    if (probe_gbs) *probe_gbs = col->probe_gbs;
+    if (candidates) *candidates = col->probe_candidates;
     return KNOX_OK;
 }
 
@@ -403,6 +462,139 @@ static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // columns
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Placement-aware column allocation.  Measured on MI355X (profiles/r01_placement_*):
+// for the read+write mix of the scan (8 B read, 1/8 B written per row) a physical region of HBM is
+// either "fast" (~6.9 TB/s) or "slow" (~6.0 TB/s); the class is a property of the region (uniform
+// over an 8 GiB allocation, stable for the life of the process), read-only passes do not see it.
+// Large column buffers are therefore probed with the real scan kernel right after hipMalloc; a
+// candidate that is clearly slower than the best class seen is HELD (freeing it would make the
+// driver hand the same region out again) and another one is tried.  Held regions go back to the
+// driver when an allocation would otherwise fail, and at knox_ctx_close.
+// ------------------------------------------------------------------------------------------------
+static constexpr size_t kProbeMinBytes = (size_t)256 << 20;
+static constexpr size_t kProbeMaxRows = (size_t)1 << 33;  // the whole buffer: an allocation can mix regions of both classes
+static constexpr int kProbeCandidates = 6;
+static constexpr size_t kHeldCapBytes = (size_t)96 << 30;
+static constexpr size_t kSearchBytes = (size_t)72 << 30;  // first large column: candidates alive at once
+
+static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, int *size_class) {
+    const uint32_t iters = 2;
+    const uint64_t tr = (uint64_t)tile_rows(8) * iters;
+    uint64_t rows = std::min<uint64_t>(bytes / 8, kProbeMaxRows);
+    rows -= rows % tr;
+    if (rows == 0) return 0.0;
+    int lg = 0;
+    while (((uint64_t)2 << lg) <= rows) lg++;
+    *size_class = lg;
+    const int grid = ctx->n_cus * 2;
+    if (ensure(ctx, ctx->probe_bits, rows / 8 + 256) || ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(ctx->n_cus * 8 + 1) * 16)) return 0.0;
+    if (!ctx->pev0 && (hipEventCreate(&ctx->pev0) != hipSuccess || hipEventCreate(&ctx->pev1) != hipSuccess)) return 0.0;
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaf[0].col = p;
+    a.leaf[0].lo = 0;
+    a.leaf[0].diff = ~0ull >> 2;  // contents are whatever the region held: any predicate will do
+    a.tt = 2;
+    a.agg_col = p;
+    a.agg_flavor = FL_SIGNED;
+    a.iters = iters;
+    a.n_tiles = rows / tr;
+    a.n_rows = rows;
+    a.tail_first_row = rows;
+    a.pack_shift = 255;
+    a.bits = (uint32_t *)ctx->probe_bits.p;
+    a.partials = (AggPartial *)ctx->partials.p;
+    // batches of 4 launches until two consecutive batches agree within 1 % (the clock ramps over the
+    // first launches after idle); at least 3 batches
+    double prev = 0.0, cur = 0.0;
+    for (int batch = 0; batch < 16; batch++) {
+        if (hipEventRecord(ctx->pev0, ctx->stream) != hipSuccess) return 0.0;
+        for (int i = 0; i < 4; i++)
+            if (launch_scan(ctx->stream, 8, 1, A_ISUM, false, (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid), 1, a) != hipSuccess) return 0.0;
+        float ms = 0.f;
+        if (hipEventRecord(ctx->pev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->pev1) != hipSuccess ||
+            hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1) != hipSuccess || ms <= 0.f)
+            return 0.0;
+        const double r = (double)rows * 8.125 * 4 / ((double)ms * 1e6);  // GB/s
+        const bool stable = batch >= 2 && fabs(r - cur) <= 0.01 * r;
+        prev = cur;
+        cur = r;
+        if (stable) break;
+    }
+    return std::max(cur, prev);
+}
+
+static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
+    const char *fl = getenv("KNOX_COL_MALLOC_FLAGS");  // diagnostics: hipExtMallocWithFlags flag (e.g. 4 = contiguous)
+    if (fl && atoi(fl) > 0) return hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl));
+    if (!ctx->placement || bytes < kProbeMinBytes) return dev_malloc(ctx, &c->dev, bytes);
+    hipStreamSynchronize(ctx->stream);
+    struct Cand { void *p; double r; };
+    std::vector<Cand> cands;
+    int accept = -1, cls = 0;
+    hipError_t err = hipSuccess;
+    // The two classes are ~13 % apart and each spreads < 5 %: 6 % separates them.  Until both have
+    // been seen in this context nothing says which one a probe belongs to (7 % separates them), so the FIRST large column
+    // searches wide (slow regions come in runs of tens of GiB); afterwards every candidate is judged on
+    // its own against the best rate seen.
+    const bool first = ctx->best_probe[0] == 0.0;  // [0]: any probe done yet (size classes are >= 25)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    // first large column: up to 70 % of what is free may be alive at once while searching
+    const size_t budget_bytes = first ? std::max(kSearchBytes, (size_t)(0.7 * (double)free_b)) : (size_t)kProbeCandidates * bytes;
+    const int budget_n = first ? 48 : kProbeCandidates;
+    size_t spent = 0;
+    while ((int)cands.size() < budget_n && spent + bytes <= std::max(budget_bytes, bytes)) {
+        void *p = nullptr;
+        // while other candidates are being held, an OOM only ends the search
+        err = cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        spent += bytes;
+        const double r = probe_rate(ctx, p, bytes, &cls);
+        cands.push_back({p, r});
+        const int me = (int)cands.size() - 1;
+        if (r <= 0.0) { accept = me; break; }  // probe unavailable: take it as it is
+        const double ref = ctx->best_probe[cls];
+        if (ref > 0.0) {
+            if (r >= 0.94 * ref) { accept = me; break; }  // as good as the best seen (or better)
+            continue;                                      // slower class: hold it, try another
+        }
+        double lo = r, hi = r;
+        int arg = me;
+        for (int i = 0; i < me; i++) {
+            lo = std::min(lo, cands[i].r);
+            if (cands[i].r > hi) { hi = cands[i].r; arg = i; }
+        }
+        if (hi >= 1.07 * lo) { accept = arg; break; }  // both classes seen: keep a fast one
+    }
+    if (cands.empty()) return err != hipSuccess ? err : hipErrorOutOfMemory;
+    if (accept < 0) {
+        accept = 0;
+        for (size_t i = 1; i < cands.size(); i++)
+            if (cands[i].r > cands[accept].r) accept = (int)i;
+    }
+    const double best = cands[accept].r;
+    ctx->best_probe[cls] = std::max(ctx->best_probe[cls], best);
+    ctx->best_probe[0] = 1.0;
+    for (size_t i = 0; i < cands.size(); i++) {
+        if ((int)i == accept) continue;
+        if (cands[i].r < 0.94 * ctx->best_probe[cls] && ctx->held_bytes + bytes <= kHeldCapBytes) {
+            ctx->held.push_back({cands[i].p, bytes});  // slower class: keep it away from the driver's free list
+            ctx->held_bytes += bytes;
+        } else {
+            hipFree(cands[i].p);  // same class as the accepted one: nothing to avoid
+        }
+    }
+    c->dev = cands[accept].p;
+    c->probe_gbs = best;
+    c->probe_candidates = (int)cands.size();
+    return hipSuccess;
+}
+
 static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bool alloc, knox_col **out) {
     if (!ctx || !out) return KNOX_E_INVALID;
     *out = nullptr;
@@ -423,8 +615,7 @@ static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bo
     if (alloc) {
         // pad to a whole 16-byte vector so the streaming kernels never read past the allocation
         size_t bytes = ((n_rows * (size_t)w + 255) & ~(size_t)255) + 256;
-        const char *fl = getenv("KNOX_COL_MALLOC_FLAGS");  // diagnostics: hipExtMallocWithFlags flag (e.g. 4 = contiguous)
-        hipError_t e = (fl && atoi(fl) > 0) ? hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl)) : hipMalloc(&c->dev, bytes);
+        hipError_t e = col_alloc_placed(ctx, c, bytes);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             delete c;
@@ -460,7 +651,7 @@ KNOX_API int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_
     int rc = col_new(ctx, KNOX_BYTES, n_rows, pack_rows, true, out);
     if (rc) return rc;
     knox_col *c = *out;
-    hipError_t e = hipMalloc((void **)&c->buf, buf_len + 256);
+    hipError_t e = dev_malloc(ctx, (void **)&c->buf, buf_len + 256);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         knox_col_free(c);
@@ -619,7 +810,7 @@ KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) {
     b->ctx = ctx;
     b->size = size_bits;
     b->cap_bytes = bits_padded(size_bits) + 64;
-    hipError_t e = hipMalloc((void **)&b->dev, b->cap_bytes);
+    hipError_t e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         delete b;
@@ -1079,7 +1270,10 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     }
     // per-pack counts for free: when packs are whole numbers of wave tiles and nothing is left for the
     // tail kernel, every wave records the popcount of its burst (4 B per wave tile)
-    if (per_pack_tiles && bits && ctx->variant != 2 && pack_rows) {
+    // measured (bench A/B, same box): the 4-byte-per-wave-tile stores are partial HBM writes and cost the
+    // scan kernel 5 % (0.866 -> 0.82 of peak) -- more than the popcount pass they save; off unless asked for
+    static const bool tile_counts_on = getenv("KNOX_TILE_COUNTS") && atoi(getenv("KNOX_TILE_COUNTS")) == 1;
+    if (per_pack_tiles && bits && ctx->variant != 2 && pack_rows && tile_counts_on) {
         const uint64_t wave_tile = tr / kWavesPerBlock;
         if (a.tail_first_row == n_rows && n_rows % pack_rows == 0 && pack_rows % wave_tile == 0 && pack_rows / wave_tile <= 0xffffffffull &&
             ensure(ctx, ctx->tile_counts, (n_rows / wave_tile) * 4 + 64) == KNOX_OK) {

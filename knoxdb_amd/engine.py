@@ -78,6 +78,13 @@ class Column:
     def device_ptr(self):
         return _lib.lib().knox_col_device_ptr(self.h)
 
+    @property
+    def placement(self):
+        """(probe GB/s of the scan's read+write mix, candidates tried); (0, 0) = not probed"""
+        g, k = C.c_double(), C.c_int()
+        check(_lib.lib().knox_col_placement(self.h, C.byref(g), C.byref(k)))
+        return g.value, k.value
+
     def download(self, first=0, n=None):
         n = self.rows - first if n is None else n
         out = np.empty(n, dtype=NP_DTYPE[self.dtype])
@@ -237,6 +244,15 @@ class Context:
 
     def set_tuning(self, blocks_per_cu=0, variant=-1):
         check(self.L.knox_ctx_set_tuning(self.h, blocks_per_cu, variant))
+
+    def set_placement(self, on=True):
+        """placement-aware column allocation (include/knoxgpu.h: knox_ctx_set_placement)"""
+        check(self.L.knox_ctx_set_placement(self.h, 1 if on else 0))
+
+    def placement_info(self):
+        b, r = C.c_int64(), C.c_int()
+        check(self.L.knox_ctx_placement_info(self.h, C.byref(b), C.byref(r)))
+        return {"held_bytes": b.value, "held_regions": r.value}
 
     def timer_start(self):
         check(self.L.knox_timer_start(self.h))

@@ -208,3 +208,28 @@ def test_two_threads_two_contexts_scan_concurrently():
             lo = -500 + 10 * rep + i
             m = (data[i] >= lo) & (data[i] <= lo + 300)
             assert cnt == pc == bc == int(m.sum()) and s == int(data[i][m].sum()), (i, rep)
+
+
+def test_placement_aware_allocation_is_transparent():
+    """Large owned columns are probed at allocation (knox_ctx_set_placement): results are the same
+    with it on or off, slow candidates are held and come back when it is switched off / at close."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free0, tot = C.c_size_t(), C.c_size_t()
+    n = (1 << 25) + 4096 * 3 + 17  # > 256 MiB of int64 -> probed
+    x = (np.arange(n, dtype=np.int64) * 2654435761) % 1000003
+    want = int(((x >= 1000) & (x <= 500000)).sum())
+    for on in (True, False):
+        with K.Context(0) as c:
+            c.set_placement(on)
+            hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
+            col = c.upload(x, 1 << 20)
+            gbs, tried = col.placement
+            assert (gbs > 1000.0 and 1 <= tried <= 48) if on else (gbs == 0.0 and tried == 0)
+            r = c.scan(And(Leaf(0, FilterMode.Range, 1000, 500000)), [col], aggs=[(R.Sum, 0)])
+            assert r.count == want and int(r.value(0)[0]) == int(x[(x >= 1000) & (x <= 500000)].sum())
+            info = c.placement_info()
+            assert info["held_bytes"] >= 0 and (on or info["held_regions"] == 0)
+            c.set_placement(False)  # gives every held region back
+            assert c.placement_info() == {"held_bytes": 0, "held_regions": 0}
+            col.free()
