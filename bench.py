@@ -119,7 +119,7 @@ def main():
     first_pack, _ = kdist.shard_range(n_packs * world, rank, world)
     row_base = first_pack * pack_rows
     col = ctx.generate(BlockType.Int64, 0, seed, n_rows, first_row=0, lo=-(1 << 40), span=1 << 41, pack_rows=pack_rows)
-    bits = ctx.bits(n_rows)
+    bits = ctx.bits(n_rows, for_col=col)  # selection bitset of the placement class that matches the column
     plan = ctx.plan(And(Leaf(0, FilterMode.Range, a, b)), [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
     ctx.sync()
 
@@ -189,7 +189,8 @@ def main():
         # placement-aware allocation (include/knoxgpu.h knox_ctx_set_placement; KNOX_PLACEMENT=0 turns it off):
         # the allocator's own probe of the column buffer and how many candidates it tried
         "placement": {"enabled": os.environ.get("KNOX_PLACEMENT", "1") != "0", "probe_gb_per_s": col.placement[0],
-                      "candidates_tried": col.placement[1], "held_gib": ctx.placement_info()["held_bytes"] / 2**30},
+                      "candidates_tried": col.placement[1], "held_gib": ctx.placement_info()["held_bytes"] / 2**30,
+                      "bitset_probe_gb_per_s": bits.placement[0], "bitset_candidates_tried": bits.placement[1]},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr) and args.rows_log2 == 30:

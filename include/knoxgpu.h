@@ -91,17 +91,22 @@ int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms); /* records, syncs, return
 /* Tuning knobs: workgroups per CU of the streaming kernels (0 = auto, <0 keeps the current
  * value); variant: 1 = default, 2 = diagnostics (bitset assembled, never stored), <0 keeps.  */
 int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
-/* Placement-aware column allocation (default on; env KNOX_PLACEMENT=0 or mode 0 turns it off).
- * On MI355X a physical HBM region runs the scan's read+write mix either at ~6.9 TB/s or at
- * ~6.0 TB/s.  Owned column buffers >= 256 MiB are probed with the scan kernel right
- * after allocation; a candidate clearly slower than the best class seen is held back (so the
- * driver cannot return the same region) and another one is tried, at most 6.  Held regions are
- * returned to the driver when an allocation would otherwise fail, when placement is switched
- * off, and at knox_ctx_close.  Results never depend on it.                                  */
+/* Placement-aware allocation (default on; env KNOX_PLACEMENT=0 or mode 0 turns it off).
+ * Measured on MI355X: every device buffer carries a binary placement class, and the
+ * scan's read+write mix (8 B read / 0.125 B written per row) runs at ~6.9 TB/s when the column and
+ * the bitset it writes are of the SAME class and at ~6.0 TB/s when they differ; read-only passes do
+ * not see it.  The library therefore (1) keeps one fixed reference bitset window per context and
+ * probes every owned column buffer >= 256 MiB against it with the scan kernel right after
+ * allocation -- a candidate of the other class is held back (so the driver cannot return the same
+ * region) and another one is tried; (2) offers knox_bits_alloc_for, which returns a bitset of the
+ * class that matches a given column.  Held regions go back to the driver when an allocation would
+ * otherwise fail, when placement is switched off, and at knox_ctx_close.  Results never depend
+ * on any of this.                                                                           */
 int knox_ctx_set_placement(knox_ctx *ctx, int mode /* 0 off, 1 on */);
 int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *held_regions);
 /* probe rate (GB/s of the 8.125 B/row mix; 0 = not probed) and candidates tried for this column */
 int knox_col_placement(const knox_col *col, double *probe_gbs, int *candidates);
+int knox_bits_placement(const knox_bits *bits, double *probe_gbs, int *candidates);
 /* Per-kernel stopwatch: while enabled, every launch of the dominant streaming kernel
  * (scan / reduce) is bracketed by HIP events on the ctx stream; knox_prof_read syncs, returns
  * the summed kernel time and launch count since the last read, and resets.                */
@@ -155,7 +160,11 @@ int knox_col_dtype(const knox_col *col);
 void *knox_col_device_ptr(const knox_col *col);
 
 /* ---- device bitsets: internal/bitset/bitset.go:30-35 + generic/bitset.go:13-435 ------ */
-int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out); /* zeroed           */
+int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out);
+/* As knox_bits_alloc, but the buffer is chosen to be of the placement class that is fast with
+ * scans of `col` (pair probe with the scan kernel, <= 12 small candidates).  Use it for the
+ * selection bitset (bits_out) of scans over that column / over columns placed by this context. */
+int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, knox_bits **out); /* zeroed           */
 int knox_bits_free(knox_bits *b);
 size_t knox_bits_size(const knox_bits *b);
 void *knox_bits_device_ptr(const knox_bits *b);

@@ -60,6 +60,7 @@ struct knox_ctx {
     DevBuf misc;         // flags / counters / small outputs
     DevBuf mom_partials; // var/std second pass: 4 doubles per workgroup
     DevBuf tile_counts;  // fused scan: popcount per wave tile -> per-pack counts
+    uint32_t tc_grid = 0, tc_rounds = 0;  // layout of tile_counts as the last scan wrote it
     DevBuf idx_scratch;  // indexes: block offsets
     DevBuf idx_rows;     // indexes: row ids
     DevBuf bytes_val;    // bytes leaf value
@@ -92,7 +93,9 @@ struct knox_ctx {
     size_t held_bytes = 0;
     int placement = 1;             // 0 = plain hipMalloc
     double best_probe[48] = {};    // best probe rate seen, per log2(probe rows)
-    DevBuf probe_bits;
+    DevBuf probe_bits;             // reference bitset window (fixed size): defines the class placed buffers match
+    const void *ref_col = nullptr; // a placed column (still alive) that write buffers are matched against
+    uint64_t ref_rows = 0;
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
     // RCCL
     void *rccl = nullptr;
@@ -120,6 +123,8 @@ struct knox_bits {
     size_t size;
     uint64_t *dev;
     size_t cap_bytes;
+    double probe_gbs = 0.0;  // pair probe of the accepted buffer (knox_bits_alloc_for), 0 = not probed
+    int probe_candidates = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -473,22 +478,19 @@ static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
 // driver when an allocation would otherwise fail, and at knox_ctx_close.
 // ------------------------------------------------------------------------------------------------
 static constexpr size_t kProbeMinBytes = (size_t)256 << 20;
-static constexpr size_t kProbeMaxRows = (size_t)1 << 33;  // the whole buffer: an allocation can mix regions of both classes
+static constexpr uint64_t kProbeChunkRows = (uint64_t)1 << 28;  // probe granularity: 2 GiB of int64 against a 32 MiB bitset window
 static constexpr int kProbeCandidates = 6;
 static constexpr size_t kHeldCapBytes = (size_t)96 << 30;
 static constexpr size_t kSearchBytes = (size_t)72 << 30;  // first large column: candidates alive at once
 
-static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, int *size_class) {
+// Steady-state GB/s of the scan's read+write mix for ONE (column region, bitset buffer) pair:
+// `rows` int64 rows at `p` scanned into `bits` (rows/8 bytes).
+static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits) {
     const uint32_t iters = 2;
     const uint64_t tr = (uint64_t)tile_rows(8) * iters;
-    uint64_t rows = std::min<uint64_t>(bytes / 8, kProbeMaxRows);
-    rows -= rows % tr;
-    if (rows == 0) return 0.0;
-    int lg = 0;
-    while (((uint64_t)2 << lg) <= rows) lg++;
-    *size_class = lg;
+    if (rows < tr || rows % tr) return 0.0;
     const int grid = ctx->n_cus * 2;
-    if (ensure(ctx, ctx->probe_bits, rows / 8 + 256) || ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(ctx->n_cus * 8 + 1) * 16)) return 0.0;
+    if (ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(ctx->n_cus * 8 + 1) * 16)) return 0.0;
     if (!ctx->pev0 && (hipEventCreate(&ctx->pev0) != hipSuccess || hipEventCreate(&ctx->pev1) != hipSuccess)) return 0.0;
     ScanArgs a;
     memset(&a, 0, sizeof a);
@@ -503,7 +505,7 @@ static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, int *size_class) 
     a.n_rows = rows;
     a.tail_first_row = rows;
     a.pack_shift = 255;
-    a.bits = (uint32_t *)ctx->probe_bits.p;
+    a.bits = (uint32_t *)bits;
     a.partials = (AggPartial *)ctx->partials.p;
     // batches of 4 launches until two consecutive batches agree within 1 % (the clock ramps over the
     // first launches after idle); at least 3 batches
@@ -523,6 +525,33 @@ static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, int *size_class) 
         if (stable) break;
     }
     return std::max(cur, prev);
+}
+
+// A column buffer against the context's reference bitset window (fixed size, allocated once: it
+// DEFINES the class every placed buffer of this context matches).  The buffer is probed chunk by
+// chunk -- a large allocation can straddle both classes -- and the slowest chunk counts.
+static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, int *size_class) {
+    const uint64_t tr = (uint64_t)tile_rows(8) * 2;
+    const uint64_t total = (bytes / 8) - (bytes / 8) % tr;
+    if (total == 0) return 0.0;
+    if (ensure(ctx, ctx->probe_bits, (kProbeChunkRows >> 3) + 256)) return 0.0;
+    const uint64_t first = std::min<uint64_t>(total, kProbeChunkRows);
+    int lg = 0;
+    while (((uint64_t)2 << lg) <= first) lg++;
+    *size_class = lg;
+    double worst = 0.0;
+    for (uint64_t off = 0; off < total; off += kProbeChunkRows) {
+        uint64_t rows = std::min<uint64_t>(kProbeChunkRows, total - off);
+        if (rows < first) {  // ragged last chunk: re-probe the last `first` rows so every chunk has the same size class
+            off = total - first;
+            rows = first;
+        }
+        const double r = probe_pair(ctx, (const char *)p + off * 8, rows, ctx->probe_bits.p);
+        if (r <= 0.0) return 0.0;
+        worst = worst == 0.0 ? r : std::min(worst, r);
+        if (off + rows >= total) break;
+    }
+    return worst;
 }
 
 static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
@@ -592,6 +621,10 @@ static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
     c->dev = cands[accept].p;
     c->probe_gbs = best;
     c->probe_candidates = (int)cands.size();
+    if (!ctx->ref_col) {  // a placed column future bitset / scratch allocations are matched against
+        ctx->ref_col = c->dev;
+        ctx->ref_rows = bytes / 8;
+    }
     return hipSuccess;
 }
 
@@ -788,7 +821,10 @@ KNOX_API int knox_col_free(knox_col *col) {
     if (!col) return KNOX_E_INVALID;
     hipSetDevice(col->ctx->device);
     hipStreamSynchronize(col->ctx->stream);
-    if (col->owned && col->dev) hipFree(col->dev);
+    if (col->owned && col->dev) {
+        if (col->ctx->ref_col == col->dev) col->ctx->ref_col = nullptr;
+        hipFree(col->dev);
+    }
     if (col->buf) hipFree(col->buf);
     delete col;
     return KNOX_OK;
@@ -801,7 +837,82 @@ KNOX_API void *knox_col_device_ptr(const knox_col *col) { return col ? col->dev 
 // ------------------------------------------------------------------------------------------------
 // device bitsets
 // ------------------------------------------------------------------------------------------------
-KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) {
+// A write buffer (bitset, scratch) of the class that is fast with column region `col` (`rows` int64 rows,
+// rows/8 <= bytes): candidates are probed as a pair with the scan kernel; mismatches are only held while
+// the search runs (they are small).  Falls back to a plain allocation when nothing can be probed.
+static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t bytes, const void *col, uint64_t col_rows, double *rate, int *tried) {
+    if (rate) *rate = 0.0;
+    if (tried) *tried = 0;
+    const uint64_t tr = (uint64_t)tile_rows(8) * 2;
+    uint64_t rows = std::min<uint64_t>(std::min<uint64_t>(col_rows, kProbeChunkRows), (uint64_t)bytes * 8);
+    rows -= rows % tr;
+    if (!ctx->placement || !col || rows < ((uint64_t)1 << 24)) return dev_malloc(ctx, out, bytes);
+    hipStreamSynchronize(ctx->stream);
+    int lg = 0;
+    while (((uint64_t)2 << lg) <= rows) lg++;
+    std::vector<std::pair<void *, double>> cands;
+    int accept = -1;
+    for (int k = 0; k < 12; k++) {
+        void *p = nullptr;
+        if ((cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes)) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        const double r = probe_pair(ctx, col, rows, p);
+        cands.push_back({p, r});
+        const int me = (int)cands.size() - 1;
+        if (r <= 0.0) { accept = me; break; }
+        if (ctx->best_probe[lg] > 0.0) {
+            if (r >= 0.94 * ctx->best_probe[lg]) { accept = me; break; }
+            continue;
+        }
+        double lo = r, hi = r;
+        int arg = me;
+        for (int i = 0; i < me; i++) {
+            lo = std::min(lo, cands[i].second);
+            if (cands[i].second > hi) { hi = cands[i].second; arg = i; }
+        }
+        if (hi >= 1.07 * lo) { accept = arg; break; }
+    }
+    if (cands.empty()) return hipErrorOutOfMemory;
+    if (accept < 0) {
+        accept = 0;
+        for (size_t i = 1; i < cands.size(); i++)
+            if (cands[i].second > cands[accept].second) accept = (int)i;
+    }
+    ctx->best_probe[lg] = std::max(ctx->best_probe[lg], cands[accept].second);
+    for (size_t i = 0; i < cands.size(); i++)
+        if ((int)i != accept) hipFree(cands[i].first);
+    *out = cands[accept].first;
+    if (rate) *rate = cands[accept].second;
+    if (tried) *tried = (int)cands.size();
+    return hipSuccess;
+}
+
+// grow-only scratch that the scan WRITES next to its bitset: same placement class as the column it is
+// written for (at least one probe window large so that the class can be measured)
+static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col) {
+    if (b.cap >= bytes) return KNOX_OK;
+    if (!ctx->placement || !col || col->width != 8 || col->dtype == KNOX_BYTES || col->n_rows < ((uint64_t)1 << 24)) return ensure(ctx, b, bytes);
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = std::max<size_t>(bytes, (size_t)(kProbeChunkRows >> 3) + 256);
+    cap = (cap + 255) & ~(size_t)255;
+    hipError_t e = write_buf_alloc_matched(ctx, &b.p, cap, col->dev, col->n_rows, nullptr, nullptr);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        b.p = nullptr;
+        return KNOX_E_NOMEM;
+    }
+    b.cap = cap;
+    return KNOX_OK;
+}
+
+static int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, knox_bits **out) {
     if (!ctx || !out) return KNOX_E_INVALID;
     *out = nullptr;
     hipSetDevice(ctx->device);
@@ -810,7 +921,13 @@ KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) {
     b->ctx = ctx;
     b->size = size_bits;
     b->cap_bytes = bits_padded(size_bits) + 64;
-    hipError_t e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
+    hipError_t e;
+    if (for_col && for_col->width == 8 && for_col->dtype != KNOX_BYTES)
+        e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, for_col->dev, for_col->n_rows, &b->probe_gbs, &b->probe_candidates);
+    else if (for_col && ctx->ref_col)  // narrower column: match the context's reference column (all placed columns share its class)
+        e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, ctx->ref_col, ctx->ref_rows, &b->probe_gbs, &b->probe_candidates);
+    else
+        e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         delete b;
@@ -824,6 +941,20 @@ KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) {
         return KNOX_E_HIP;
     }
     *out = b;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) { return bits_alloc(ctx, size_bits, nullptr, out); }
+
+KNOX_API int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, knox_bits **out) {
+    if (!col || col->ctx != ctx) return KNOX_E_INVALID;
+    return bits_alloc(ctx, size_bits, col, out);
+}
+
+KNOX_API int knox_bits_placement(const knox_bits *b, double *probe_gbs, int *candidates) {
+    if (!b) return KNOX_E_INVALID;
+    if (probe_gbs) *probe_gbs = b->probe_gbs;
+    if (candidates) *candidates = b->probe_candidates;
     return KNOX_OK;
 }
 
@@ -1268,21 +1399,6 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     } else {
         a.pack_shift = 255;
     }
-    // per-pack counts for free: when packs are whole numbers of wave tiles and nothing is left for the
-    // tail kernel, every wave records the popcount of its burst (4 B per wave tile)
-    // measured (bench A/B, same box): the 4-byte-per-wave-tile stores are partial HBM writes and cost the
-    // scan kernel 5 % (0.866 -> 0.82 of peak) -- more than the popcount pass they save; off unless asked for
-    static const bool tile_counts_on = getenv("KNOX_TILE_COUNTS") && atoi(getenv("KNOX_TILE_COUNTS")) == 1;
-    if (per_pack_tiles && bits && ctx->variant != 2 && pack_rows && tile_counts_on) {
-        const uint64_t wave_tile = tr / kWavesPerBlock;
-        if (a.tail_first_row == n_rows && n_rows % pack_rows == 0 && pack_rows % wave_tile == 0 && pack_rows / wave_tile <= 0xffffffffull &&
-            ensure(ctx, ctx->tile_counts, (n_rows / wave_tile) * 4 + 64) == KNOX_OK) {
-            a.tile_counts = (uint32_t *)ctx->tile_counts.p;
-            *per_pack_tiles = (uint32_t)(pack_rows / wave_tile);
-        }
-    }
-    a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
-    a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
     // auto occupancy: the pure streaming passes run best at 2 workgroups per CU, VALU-heavier ones at 3
     // (profiles/r01_sweep_blocks_per_cu.txt): 8-byte / 4-byte integer streaming 2 WG/CU; float or min-max
     // aggregates, several leaves, 2-byte types 3; 1-byte types and float32 sums (VALU bound) 8
@@ -1290,6 +1406,22 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     const bool very_heavy = width == 1 || (width == 4 && agg_col && (agg & A_FSUM) != 0);
     const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (very_heavy ? 8 : heavy ? 3 : 2);
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
+    // per-pack counts for free: when packs are whole numbers of tiles, nothing is pruned and nothing is
+    // left for the tail kernel, every wave records the popcount of its bursts (one 128-byte line per 32 tiles)
+    static const bool tile_counts_on = !(getenv("KNOX_TILE_COUNTS") && atoi(getenv("KNOX_TILE_COUNTS")) == 0);  // 0: diagnostics
+    if (per_pack_tiles && bits && ctx->variant != 2 && ctx->variant != 5 && pack_rows && tile_counts_on && a.live_packs == nullptr && g > 0) {
+        const uint64_t rounds = ((a.n_tiles + (uint64_t)g - 1) / (uint64_t)g + 31) & ~(uint64_t)31;
+        if (a.tail_first_row == n_rows && n_rows % pack_rows == 0 && pack_rows % tr == 0 && pack_rows / tr <= 0xffffffffull &&
+            rounds <= 0xffffffffull && ensure_matched(ctx, ctx->tile_counts, (size_t)g * kWavesPerBlock * rounds * 4 + 256, lcols[0]) == KNOX_OK) {
+            a.tile_counts = (uint32_t *)ctx->tile_counts.p;
+            a.tc_rounds = (uint32_t)rounds;
+            *per_pack_tiles = (uint32_t)(pack_rows / tr);
+            ctx->tc_grid = (uint32_t)g;
+            ctx->tc_rounds = (uint32_t)rounds;
+        }
+    }
+    a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // diagnostics: 2 no store, 3 plain store, 4 write-through store
+    a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
     if (slot != 15) prof_mark(ctx, 0);
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, ctx->variant, a);
     if (slot != 15) prof_mark(ctx, 1);
@@ -1656,8 +1788,8 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     slot.n_packs = n_packs;
     if (want_pack_counts && n_packs) {
         hipError_t e = per_pack_tiles
-                           ? launch_pack_counts(ctx->stream, (const uint32_t *)ctx->tile_counts.p, per_pack_tiles, n_packs,
-                                                skip.used ? skip.d_skip : nullptr, (int64_t *)((char *)ctx->states.p + res_base))
+                           ? launch_pack_counts(ctx->stream, (const uint32_t *)ctx->tile_counts.p, ctx->tc_grid, ctx->tc_rounds, per_pack_tiles,
+                                                n_packs, (int64_t *)((char *)ctx->states.p + res_base))
                            : launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)((char *)ctx->states.p + res_base), n_packs);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         slot.has_pack_counts = true;

@@ -54,7 +54,8 @@ struct ScanArgs {
     const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)
     uint32_t debug;         // diagnostics: bit0 = compute the bitset words but skip the global store
     uint32_t iters;         // wave iterations per tile (1..kMaxIters): tile = iters * tile_rows(width)
-    uint32_t *tile_counts;  // nullable: [tile * kWavesPerBlock + wave] = popcount of that wave tile's bitset burst
+    uint32_t *tile_counts;  // nullable: [(workgroup * kWavesPerBlock + wave) * tc_rounds + round] = popcount of that wave tile's burst
+    uint32_t tc_rounds;     // rounds per workgroup, padded to a multiple of 32 (one 128-byte line of counts)
     AggPartial *partials;   // [grid] (+1 slot for the tail at index grid)
 };
 
@@ -140,9 +141,9 @@ hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *sr
                         uint32_t *flags_any_all /* nullable: [0]=any (or), [1]=not-all (or) */);
 hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bits,
                            unsigned long long *count_out /* pre-zeroed */);
-// counts[p] = sum of the per_pack wave-tile counts of pack p (0 for skipped packs)
-hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t per_pack, uint64_t n_packs, const uint8_t *skip,
-                              int64_t *counts);
+// counts[p] = sum of the wave-tile counts of pack p's tiles_per_pack tiles (scan launched with `grid` workgroups)
+hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
+                              uint64_t n_packs, int64_t *counts);
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
                                     int64_t *counts, uint64_t n_seg);
 // bitset -> ascending uint32 row ids; scratch holds ceil(size/16384)+1 uint32 block offsets

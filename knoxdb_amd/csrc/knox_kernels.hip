@@ -439,6 +439,9 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // XCDs, so logical block (b%8)*(G/8) + b/8 gives every XCD one contiguous run of tiles per round
     uint32_t lb = blockIdx.x;
     if ((a.debug & 8u) && (gridDim.x & 7u) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // per-wave-tile popcounts, laid out [workgroup][wave][round] so that a wave's counts are contiguous
+    uint32_t *tcbase = a.tile_counts ? a.tile_counts + ((uint64_t)lb * kWavesPerBlock + (uint64_t)wave) * a.tc_rounds : nullptr;
+    uint32_t tcreg = 0, round = 0;
     for (uint64_t vt = lb; vt < a.n_tiles; vt += gridDim.x) {
         // packs pruned by the caller's statistics are never touched: with a live-pack list the
         // virtual tile index walks only the surviving packs (their bitset ranges were zeroed by the host)
@@ -544,15 +547,24 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
                 else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
                 else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
             }
-            if (a.tile_counts != nullptr) {
-                // popcount of this wave tile's burst, once per tile: the per-pack counts
-                // (Bitset.ResetCount) then come from 4 B per 1024+ rows instead of re-reading the bitset
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) tc += __shfl_down(tc, off, 64);
-                if (lane == 0) a.tile_counts[tile * kWavesPerBlock + (uint64_t)wave] = tc;
+            if (tcbase != nullptr) {
+                // popcount of this wave tile's burst, once per tile.  The counts of 32 consecutive
+                // rounds are parked one per lane and leave as ONE full 128-byte line (no partial writes).
+                // (DPP row butterfly + 4 readlanes: a ds_bpermute shuffle chain here costs ~700 cycles of
+                // exposed latency per tile, 5 % of the kernel at 2 workgroups/CU)
+                tc += dpp_mov<0xB1>(tc);
+                tc += dpp_mov<0x4E>(tc);
+                tc += dpp_mov<0x141>(tc);
+                tc += dpp_mov<0x140>(tc);
+                const uint32_t total = (uint32_t)(__builtin_amdgcn_readlane((int)tc, 0) + __builtin_amdgcn_readlane((int)tc, 16) +
+                                                  __builtin_amdgcn_readlane((int)tc, 32) + __builtin_amdgcn_readlane((int)tc, 48));
+                tcreg = lane == (int)(round & 31u) ? total : tcreg;
+                if ((round & 31u) == 31u && lane < 32) tcbase[(round & ~31u) + lane] = tcreg;
+                round++;
             }
         }
     }
+    if (tcbase != nullptr && (round & 31u) != 0 && lane < (int)(round & 31u)) tcbase[(round & ~31u) + lane] = tcreg;
     acc.count = cnt32;
     if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
     block_reduce_store(acc, a.partials + blockIdx.x);
@@ -1465,25 +1477,27 @@ __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bi
     }
 }
 
-// per-pack counts from the scan kernel's per-wave-tile counts: one wave per pack
-__global__ void __launch_bounds__(kBlock) pack_counts_kernel(const uint32_t *tile_counts, uint32_t per_pack, uint64_t n_packs,
-                                                             const uint8_t *skip, int64_t *counts) {
+// per-pack counts from the scan kernel's per-wave-tile counts ([workgroup][wave][round], tile t was
+// round t / grid of workgroup t % grid): one wave per pack
+__global__ void __launch_bounds__(kBlock) pack_counts_kernel(const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
+                                                             uint64_t n_packs, int64_t *counts) {
     const int lane = threadIdx.x & 63;
     const uint64_t p = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (p >= n_packs) return;
     uint64_t c = 0;
-    if (skip == nullptr || skip[p] == 0) {
-        const uint32_t *t = tile_counts + p * (uint64_t)per_pack;
-        for (uint32_t i = lane; i < per_pack; i += 64) c += t[i];
+    for (uint32_t i = lane; i < tiles_per_pack * kWavesPerBlock; i += 64) {
+        const uint64_t tile = p * tiles_per_pack + i / kWavesPerBlock;
+        const uint32_t wave = i % kWavesPerBlock;
+        c += tile_counts[((tile % grid) * kWavesPerBlock + wave) * (uint64_t)rounds + tile / grid];
     }
     for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
     if (lane == 0) counts[p] = (int64_t)c;
 }
 
-hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t per_pack, uint64_t n_packs, const uint8_t *skip,
-                              int64_t *counts) {
+hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
+                              uint64_t n_packs, int64_t *counts) {
     if (n_packs == 0) return hipSuccess;
-    KNOX_LAUNCH(pack_counts_kernel, (int)((n_packs + kBlock / 64 - 1) / (kBlock / 64)), tile_counts, per_pack, n_packs, skip, counts);
+    KNOX_LAUNCH(pack_counts_kernel, (int)((n_packs + kBlock / 64 - 1) / (kBlock / 64)), tile_counts, grid, rounds, tiles_per_pack, n_packs, counts);
 }
 
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,

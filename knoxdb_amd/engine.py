@@ -100,11 +100,20 @@ class Column:
 class Bits:
     """bitset.Bitset resident on the device (internal/bitset/bitset.go:30-35)."""
 
-    def __init__(self, ctx, size):
+    def __init__(self, ctx, size, for_col=None):
         self.ctx, self.size = ctx, size
         h = C.c_void_p()
-        check(_lib.lib().knox_bits_alloc(ctx.h, size, C.byref(h)))
+        if for_col is None:
+            check(_lib.lib().knox_bits_alloc(ctx.h, size, C.byref(h)))
+        else:  # placement class matched to scans of that column (include/knoxgpu.h knox_bits_alloc_for)
+            check(_lib.lib().knox_bits_alloc_for(ctx.h, size, for_col.h, C.byref(h)), "knox_bits_alloc_for")
         self.h = h
+
+    @property
+    def placement(self):
+        g, k = C.c_double(), C.c_int()
+        check(_lib.lib().knox_bits_placement(self.h, C.byref(g), C.byref(k)))
+        return g.value, k.value
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=np.uint8)
@@ -314,8 +323,8 @@ class Context:
         check(self.L.knox_col_generate(self.h, int(dtype), kind, seed, first_row, n_rows, lo, span, pack_rows, C.byref(h)))
         return Column(self, h, dtype, pack_rows=pack_rows)
 
-    def bits(self, size):
-        return Bits(self, size)
+    def bits(self, size, for_col=None):
+        return Bits(self, size, for_col)
 
     # -- filter.Match over every resident pack + reducers
     def _plan(self, tree, cols, aggs):

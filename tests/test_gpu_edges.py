@@ -226,8 +226,13 @@ def test_placement_aware_allocation_is_transparent():
             col = c.upload(x, 1 << 20)
             gbs, tried = col.placement
             assert (gbs > 1000.0 and 1 <= tried <= 48) if on else (gbs == 0.0 and tried == 0)
-            r = c.scan(And(Leaf(0, FilterMode.Range, 1000, 500000)), [col], aggs=[(R.Sum, 0)])
-            assert r.count == want and int(r.value(0)[0]) == int(x[(x >= 1000) & (x <= 500000)].sum())
+            bits = c.bits(n, for_col=col)  # knox_bits_alloc_for: the class that is fast with this column
+            bg, btried = bits.placement
+            assert (bg > 1000.0 and 1 <= btried <= 12) if on else (bg == 0.0 and btried == 0)
+            r = c.scan(And(Leaf(0, FilterMode.Range, 1000, 500000)), [col], aggs=[(R.Sum, 0)], bits_out=bits, pack_counts=True)
+            assert r.count == want == bits.count() == int(r.pack_counts.sum())
+            assert int(r.value(0)[0]) == int(x[(x >= 1000) & (x <= 500000)].sum())
+            bits.free()
             info = c.placement_info()
             assert info["held_bytes"] >= 0 and (on or info["held_regions"] == 0)
             c.set_placement(False)  # gives every held region back

@@ -33,7 +33,7 @@ for on in (True, False):
     ctx.set_placement(on)
     ctx.L.knox_prof_enable(ctx.h, 1)
     cols = [ctx.generate(BlockType.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=1 << 20) for _ in range(ncol)]
-    bits = ctx.bits(n)
+    bits = ctx.bits(n, for_col=cols[0]) if on else ctx.bits(n)
     rate(ctx, cols[0], bits, 60)
     rates = [rate(ctx, c, bits) for c in cols]
     print("placement %s: held %s" % ("on " if on else "off", ctx.placement_info()))
