@@ -96,6 +96,7 @@ struct knox_ctx {
     DevBuf probe_bits;             // reference bitset window (fixed size): defines the class placed buffers match
     const void *ref_col = nullptr; // a placed column (still alive) that write buffers are matched against
     uint64_t ref_rows = 0;
+    void *ref_scratch = nullptr;   // 2 GiB placed stand-in, created on demand when no placed column is alive
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
     // RCCL
     void *rccl = nullptr;
@@ -292,6 +293,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->probe_bits.p) hipFree(ctx->probe_bits.p);
+    if (ctx->ref_scratch) hipFree(ctx->ref_scratch);
     release_held(ctx);
     if (ctx->pev0) hipEventDestroy(ctx->pev0);
     if (ctx->pev1) hipEventDestroy(ctx->pev1);
@@ -628,6 +630,29 @@ static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
     return hipSuccess;
 }
 
+// A placed column region of this context to match write buffers against: a live placed column, or a
+// 2 GiB stand-in allocated (and placed) on demand and kept until the context closes.
+static const void *get_ref_col(knox_ctx *ctx, uint64_t *rows) {
+    if (ctx->ref_col) {
+        *rows = ctx->ref_rows;
+        return ctx->ref_col;
+    }
+    if (!ctx->placement) return nullptr;
+    if (!ctx->ref_scratch) {
+        knox_col tmp;
+        memset((void *)&tmp, 0, sizeof tmp);
+        const void *keep_ref = ctx->ref_col;
+        if (col_alloc_placed(ctx, &tmp, (size_t)kProbeChunkRows * 8 + 512) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ctx->ref_col = keep_ref;  // the stand-in is not a user column: knox_col_free never sees it
+        ctx->ref_scratch = tmp.dev;
+    }
+    *rows = kProbeChunkRows;
+    return ctx->ref_scratch;
+}
+
 static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bool alloc, knox_col **out) {
     if (!ctx || !out) return KNOX_E_INVALID;
     *out = nullptr;
@@ -893,7 +918,11 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
 // written for (at least one probe window large so that the class can be measured)
 static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col) {
     if (b.cap >= bytes) return KNOX_OK;
-    if (!ctx->placement || !col || col->width != 8 || col->dtype == KNOX_BYTES || col->n_rows < ((uint64_t)1 << 24)) return ensure(ctx, b, bytes);
+    if (!ctx->placement || !col || col->n_rows < ((uint64_t)1 << 24)) return ensure(ctx, b, bytes);
+    const void *rc = col->dev;
+    uint64_t rr = col->n_rows;
+    if (col->width != 8 || col->dtype == KNOX_BYTES) rc = get_ref_col(ctx, &rr);
+    if (!rc) return ensure(ctx, b, bytes);
     if (b.p) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(b.p));
@@ -902,7 +931,7 @@ static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col
     }
     size_t cap = std::max<size_t>(bytes, (size_t)(kProbeChunkRows >> 3) + 256);
     cap = (cap + 255) & ~(size_t)255;
-    hipError_t e = write_buf_alloc_matched(ctx, &b.p, cap, col->dev, col->n_rows, nullptr, nullptr);
+    hipError_t e = write_buf_alloc_matched(ctx, &b.p, cap, rc, rr, nullptr, nullptr);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         b.p = nullptr;
@@ -924,9 +953,13 @@ static int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, 
     hipError_t e;
     if (for_col && for_col->width == 8 && for_col->dtype != KNOX_BYTES)
         e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, for_col->dev, for_col->n_rows, &b->probe_gbs, &b->probe_candidates);
-    else if (for_col && ctx->ref_col)  // narrower column: match the context's reference column (all placed columns share its class)
-        e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, ctx->ref_col, ctx->ref_rows, &b->probe_gbs, &b->probe_candidates);
-    else
+    else if (ctx->placement && (for_col || size_bits >= ((size_t)1 << 27))) {
+        // any other large bitset: the class of this context's placed columns (they all share one)
+        uint64_t rr = 0;
+        const void *rc = get_ref_col(ctx, &rr);
+        e = rc ? write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, rc, rr, &b->probe_gbs, &b->probe_candidates)
+               : dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
+    } else
         e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
@@ -1670,7 +1703,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                            (n_agg_cols == 1 && fused && cols[agg_cols[0]]->width != width);
     uint64_t *bits = bits_out ? bits_out->dev : nullptr;
     if (need_bits && !bits) {
-        rc = ensure(ctx, ctx->tmp_bits, (bits_padded(n_rows) + 64) * 8);  // result + up to 7 stack temporaries
+        rc = ensure_matched(ctx, ctx->tmp_bits, (bits_padded(n_rows) + 64) * 8, cols[0]);  // result + up to 7 stack temporaries
         if (rc) return rc;
         bits = (uint64_t *)ctx->tmp_bits.p;
         HIPCHK(ctx, hipMemsetAsync(bits, 0, bits_padded(n_rows) + 64, ctx->stream));
@@ -1725,7 +1758,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         // kernels (exactly the reference's MatchAnd / MatchOr data flow, match_core.go:45-215)
         if (bits_out == nullptr && bits == nullptr) return KNOX_E_INVALID;
         const size_t stride = (bits_padded(n_rows) + 64) / 8;  // uint64 words per scratch bitset
-        rc = ensure(ctx, ctx->tmp_bits, stride * 8 * 8);
+        rc = ensure_matched(ctx, ctx->tmp_bits, stride * 8 * 8, cols[0]);
         if (rc) return rc;
         if (!bits_out) bits = (uint64_t *)ctx->tmp_bits.p;
         uint64_t *pool = (uint64_t *)ctx->tmp_bits.p;
