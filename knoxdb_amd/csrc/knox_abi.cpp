@@ -515,7 +515,7 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
     for (int batch = 0; batch < 16; batch++) {
         if (hipEventRecord(ctx->pev0, ctx->stream) != hipSuccess) return 0.0;
         for (int i = 0; i < 4; i++)
-            if (launch_scan(ctx->stream, 8, 1, A_ISUM, false, (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid), 1, a) != hipSuccess) return 0.0;
+            if (launch_probe_scan(ctx->stream, (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid), a) != hipSuccess) return 0.0;
         float ms = 0.f;
         if (hipEventRecord(ctx->pev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->pev1) != hipSuccess ||
             hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1) != hipSuccess || ms <= 0.f)

@@ -80,6 +80,8 @@ int tile_rows(int width);  // rows per workgroup tile of the streaming kernels
 // words, accumulates count + aggregates into partials[0..grid).  width = bytes per value.
 hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, bool agg_separate,
                        int grid, int variant, const ScanArgs &a);
+// placement probe: scan_kernel<8,1,ISUM> under a separate symbol
+hipError_t launch_probe_scan(hipStream_t s, int grid, const ScanArgs &a);
 // Tail / small-n path: rows [n_tiles*tile_rows, n_rows), byte-granular stores, one workgroup,
 // partial written to partials[tail_slot].
 hipError_t launch_scan_tail(hipStream_t s, int width, int n_leaves, unsigned agg, int tail_slot,

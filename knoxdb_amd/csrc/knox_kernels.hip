@@ -782,6 +782,13 @@ hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, boo
     }
 }
 
+// The allocator's placement probe (knox_abi.cpp): the headline code path under its own symbol
+// (FLV is irrelevant to an integer sum), so that profiles keep probe launches and real scans apart.
+hipError_t launch_probe_scan(hipStream_t s, int grid, const ScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+    KNOX_LAUNCH((scan_kernel<8, 1, A_ISUM, false, false, FL_UNSIGNED>), grid, a);
+}
+
 hipError_t launch_scan_tail(hipStream_t s, int width, int n_leaves, unsigned agg, int tail_slot, const ScanArgs &a) {
     (void)agg;
     switch (width) {

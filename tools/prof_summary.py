@@ -15,7 +15,8 @@ def short(name):
     return name[:90]
 
 
-print("# rocprofv3 summary of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (%s)" % os.path.basename(root))
+print("# rocprofv3 summary of `python3 bench.py --no-cpu-baseline` = the default run, 20 steps + 3 warmup (%s)" % os.path.basename(root))
+print("# scan_kernel<8, 1, 1u, false, false, 0u> = the timed scans; <..., 1u> (FLV 1) = the allocator's placement probes")
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("\n## kernel stats (--kernel-trace --stats)")
     print("%-92s %7s %12s %12s %8s" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
@@ -39,7 +40,7 @@ for sub in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             print(k)
             for c, vals in sorted(ctrs.items()):
                 print("    %-24s n=%-4d mean=%.6g" % (c, len(vals), sum(vals) / len(vals)))
-                if "scan_kernel" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+                if "scan_kernel<8, 1, 1u, false, false, 0u>" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
                     traffic[c] = sum(vals) / len(vals)
 
 if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
