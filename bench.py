@@ -166,6 +166,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # empirical ceiling: the same column through the read-only form of the kernel (count + sum,
+    # no bitset, no pack counts), outside the timed region
+    ro_plan = ctx.plan(And(Leaf(0, FilterMode.Range, a, b)), [col], aggs=[(ReducerFunc.Sum, 0)])
+    ctx.L.knox_prof_enable(ctx.h, 1)
+    ctx.scan_async(ro_plan)
+    for _ in range(9):
+        ctx.scan_async(ro_plan)
+        ctx.scan_collect(ro_plan, 0)
+    ro_res = ctx.scan_collect(ro_plan, 0)
+    ro_ms, ro_n = C.c_double(), C.c_int()
+    ctx.L.knox_prof_read(ctx.h, C.byref(ro_ms), C.byref(ro_n))
+    ctx.L.knox_prof_enable(ctx.h, 0)
+    read_only_gbs = n_rows * 8.0 * ro_n.value / (ro_ms.value * 1e6) if ro_ms.value > 0 else 0.0
+    assert ro_res.count == res.count
+
     kernel_ms = kms.value / max(1, kn.value)
     achieved = n_rows * BYTES_PER_ROW / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     total_rows = n_rows * world * args.steps
@@ -184,7 +199,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": kernel_ms,
-                     "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW},
+                     "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW,
+                     "read_only_ceiling_gb_per_s": read_only_gbs,
+                     "frac_of_read_only_ceiling": achieved / read_only_gbs if read_only_gbs > 0 else None},
         "whole_step_gb_per_s": n_rows * BYTES_PER_ROW / (elapsed / args.steps) / 1e9,
         # placement-aware allocation (include/knoxgpu.h knox_ctx_set_placement; KNOX_PLACEMENT=0 turns it off):
         # the allocator's own probe of the column buffer and how many candidates it tried
