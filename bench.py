@@ -206,7 +206,7 @@ def main():
         # placement-aware allocation (include/knoxgpu.h knox_ctx_set_placement; KNOX_PLACEMENT=0 turns it off):
         # the allocator's own probe of the column buffer and how many candidates it tried
         "placement": {"enabled": os.environ.get("KNOX_PLACEMENT", "1") != "0", "probe_gb_per_s": col.placement[0],
-                      "candidates_tried": col.placement[1], "held_gib": ctx.placement_info()["held_bytes"] / 2**30,
+                      "probe_mix_over_read_only": col.placement[2], "candidates_tried": col.placement[1], "held_gib": ctx.placement_info()["held_bytes"] / 2**30,
                       "bitset_probe_gb_per_s": bits.placement[0], "bitset_candidates_tried": bits.placement[1]},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")

@@ -92,7 +92,6 @@ struct knox_ctx {
     std::vector<Held> held;
     size_t held_bytes = 0;
     int placement = 1;             // 0 = plain hipMalloc
-    double best_probe[48] = {};    // best probe rate seen, per log2(probe rows)
     DevBuf probe_bits;             // reference bitset window (fixed size): defines the class placed buffers match
     const void *ref_col = nullptr; // a placed column (still alive) that write buffers are matched against
     uint64_t ref_rows = 0;
@@ -115,7 +114,8 @@ struct knox_col {
     uint8_t *buf;   // bytes column payload
     size_t buf_len;
     bool owned;
-    double probe_gbs = 0.0;  // placement probe of the accepted buffer (0 = not probed)
+    double probe_gbs = 0.0;    // placement probe of the accepted buffer: mix rate of its worst chunk (0 = not probed)
+    double probe_ratio = 0.0;  // mix / read-only of that chunk (>= 0.90: same class as the context's reference)
     int probe_candidates = 0;
 };
 
@@ -362,9 +362,10 @@ KNOX_API int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *he
     return KNOX_OK;
 }
 
-KNOX_API int knox_col_placement(const knox_col *col, double *probe_gbs, int *candidates) {
+KNOX_API int knox_col_placement(const knox_col *col, double *probe_gbs, double *probe_ratio, int *candidates) {
     if (!col) return KNOX_E_INVALID;
     if (probe_gbs) *probe_gbs = col->probe_gbs;
+    if (probe_ratio) *probe_ratio = col->probe_ratio;
     if (candidates) *candidates = col->probe_candidates;
     return KNOX_OK;
 }
@@ -482,11 +483,12 @@ static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
 static constexpr size_t kProbeMinBytes = (size_t)256 << 20;
 static constexpr uint64_t kProbeChunkRows = (uint64_t)1 << 28;  // probe granularity: 2 GiB of int64 against a 32 MiB bitset window
 static constexpr int kProbeCandidates = 6;
+static constexpr int kMaxCandidates = 40;
+static constexpr double kMatchRatio = 0.90;  // mix / read-only: ~0.95 like classes, ~0.84 unlike
 static constexpr size_t kHeldCapBytes = (size_t)96 << 30;
-static constexpr size_t kSearchBytes = (size_t)72 << 30;  // first large column: candidates alive at once
 
-// Steady-state GB/s of the scan's read+write mix for ONE (column region, bitset buffer) pair:
-// `rows` int64 rows at `p` scanned into `bits` (rows/8 bytes).
+// Steady-state GB/s of the scan for ONE (column region, bitset buffer) pair: `rows` int64 rows at `p`
+// scanned into `bits` (rows/8 bytes, the read+write mix), or read-only when bits == nullptr.
 static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits) {
     const uint32_t iters = 2;
     const uint64_t tr = (uint64_t)tile_rows(8) * iters;
@@ -520,7 +522,7 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
         if (hipEventRecord(ctx->pev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->pev1) != hipSuccess ||
             hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1) != hipSuccess || ms <= 0.f)
             return 0.0;
-        const double r = (double)rows * 8.125 * 4 / ((double)ms * 1e6);  // GB/s
+        const double r = (double)rows * (bits ? 8.125 : 8.0) * 4 / ((double)ms * 1e6);  // GB/s
         const bool stable = batch >= 2 && fabs(r - cur) <= 0.01 * r;
         prev = cur;
         cur = r;
@@ -531,28 +533,35 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
 
 // A column buffer against the context's reference bitset window (fixed size, allocated once: it
 // DEFINES the class every placed buffer of this context matches).  The buffer is probed chunk by
-// chunk -- a large allocation can straddle both classes -- and the slowest chunk counts.
-static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, int *size_class) {
+// chunk -- a large allocation can straddle both classes.  The class test is self-normalising:
+// mix rate / read-only rate of the SAME chunk is ~0.95 for like classes and ~0.84 for unlike ones
+// at every probe size, so one threshold (kMatchRatio) serves all sizes and needs no history.
+// Returns the worst chunk's mix rate, *ratio = the worst chunk's ratio (0 = probe unavailable).
+static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, double *ratio) {
+    *ratio = 0.0;
     const uint64_t tr = (uint64_t)tile_rows(8) * 2;
     const uint64_t total = (bytes / 8) - (bytes / 8) % tr;
     if (total == 0) return 0.0;
     if (ensure(ctx, ctx->probe_bits, (kProbeChunkRows >> 3) + 256)) return 0.0;
     const uint64_t first = std::min<uint64_t>(total, kProbeChunkRows);
-    int lg = 0;
-    while (((uint64_t)2 << lg) <= first) lg++;
-    *size_class = lg;
-    double worst = 0.0;
+    double worst = 0.0, worst_ratio = 0.0;
     for (uint64_t off = 0; off < total; off += kProbeChunkRows) {
         uint64_t rows = std::min<uint64_t>(kProbeChunkRows, total - off);
-        if (rows < first) {  // ragged last chunk: re-probe the last `first` rows so every chunk has the same size class
+        if (rows < first) {  // ragged last chunk: re-probe the last `first` rows
             off = total - first;
             rows = first;
         }
-        const double r = probe_pair(ctx, (const char *)p + off * 8, rows, ctx->probe_bits.p);
-        if (r <= 0.0) return 0.0;
-        worst = worst == 0.0 ? r : std::min(worst, r);
+        const char *q = (const char *)p + off * 8;
+        const double ro = probe_pair(ctx, q, rows, nullptr);
+        const double mix = probe_pair(ctx, q, rows, ctx->probe_bits.p);
+        if (ro <= 0.0 || mix <= 0.0) return 0.0;
+        if (worst_ratio == 0.0 || mix / ro < worst_ratio) {
+            worst_ratio = mix / ro;
+            worst = mix;
+        }
         if (off + rows >= total) break;
     }
+    *ratio = worst_ratio;
     return worst;
 }
 
@@ -561,22 +570,16 @@ static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
     if (fl && atoi(fl) > 0) return hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl));
     if (!ctx->placement || bytes < kProbeMinBytes) return dev_malloc(ctx, &c->dev, bytes);
     hipStreamSynchronize(ctx->stream);
-    struct Cand { void *p; double r; };
+    struct Cand { void *p; double mix, ratio; };
     std::vector<Cand> cands;
-    int accept = -1, cls = 0;
+    int accept = -1;
     hipError_t err = hipSuccess;
-    // The two classes are ~13 % apart and each spreads < 5 %: 6 % separates them.  Until both have
-    // been seen in this context nothing says which one a probe belongs to (7 % separates them), so the FIRST large column
-    // searches wide (slow regions come in runs of tens of GiB); afterwards every candidate is judged on
-    // its own against the best rate seen.
-    const bool first = ctx->best_probe[0] == 0.0;  // [0]: any probe done yet (size classes are >= 25)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    // first large column: up to 70 % of what is free may be alive at once while searching
-    const size_t budget_bytes = first ? std::max(kSearchBytes, (size_t)(0.7 * (double)free_b)) : (size_t)kProbeCandidates * bytes;
-    const int budget_n = first ? 48 : kProbeCandidates;
+    // regions of one class come in runs of tens of GiB: up to half of what is free may be alive at once
+    const size_t budget_bytes = std::max((size_t)kProbeCandidates * bytes, (size_t)(0.5 * (double)free_b));
     size_t spent = 0;
-    while ((int)cands.size() < budget_n && spent + bytes <= std::max(budget_bytes, bytes)) {
+    while ((int)cands.size() < kMaxCandidates && spent + bytes <= std::max(budget_bytes, bytes)) {
         void *p = nullptr;
         // while other candidates are being held, an OOM only ends the search
         err = cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
@@ -585,45 +588,36 @@ static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
             break;
         }
         spent += bytes;
-        const double r = probe_rate(ctx, p, bytes, &cls);
-        cands.push_back({p, r});
-        const int me = (int)cands.size() - 1;
-        if (r <= 0.0) { accept = me; break; }  // probe unavailable: take it as it is
-        const double ref = ctx->best_probe[cls];
-        if (ref > 0.0) {
-            if (r >= 0.94 * ref) { accept = me; break; }  // as good as the best seen (or better)
-            continue;                                      // slower class: hold it, try another
+        double ratio = 0.0;
+        const double mix = probe_rate(ctx, p, bytes, &ratio);
+        cands.push_back({p, mix, ratio});
+        if (mix <= 0.0 || ratio >= kMatchRatio) {  // probe unavailable: take it as it is
+            accept = (int)cands.size() - 1;
+            break;
         }
-        double lo = r, hi = r;
-        int arg = me;
-        for (int i = 0; i < me; i++) {
-            lo = std::min(lo, cands[i].r);
-            if (cands[i].r > hi) { hi = cands[i].r; arg = i; }
-        }
-        if (hi >= 1.07 * lo) { accept = arg; break; }  // both classes seen: keep a fast one
     }
     if (cands.empty()) return err != hipSuccess ? err : hipErrorOutOfMemory;
-    if (accept < 0) {
+    if (accept < 0) {  // nothing of the reference's class within the budget: the best there is
         accept = 0;
         for (size_t i = 1; i < cands.size(); i++)
-            if (cands[i].r > cands[accept].r) accept = (int)i;
+            if (cands[i].ratio > cands[accept].ratio) accept = (int)i;
     }
-    const double best = cands[accept].r;
-    ctx->best_probe[cls] = std::max(ctx->best_probe[cls], best);
-    ctx->best_probe[0] = 1.0;
+    const bool matched = cands[accept].ratio >= kMatchRatio;
     for (size_t i = 0; i < cands.size(); i++) {
         if ((int)i == accept) continue;
-        if (cands[i].r < 0.94 * ctx->best_probe[cls] && ctx->held_bytes + bytes <= kHeldCapBytes) {
-            ctx->held.push_back({cands[i].p, bytes});  // slower class: keep it away from the driver's free list
+        // unlike regions are kept away from the driver's free list while like ones can still be found
+        if (matched && ctx->held_bytes + bytes <= kHeldCapBytes) {
+            ctx->held.push_back({cands[i].p, bytes});
             ctx->held_bytes += bytes;
         } else {
-            hipFree(cands[i].p);  // same class as the accepted one: nothing to avoid
+            hipFree(cands[i].p);
         }
     }
     c->dev = cands[accept].p;
-    c->probe_gbs = best;
+    c->probe_gbs = cands[accept].mix;
+    c->probe_ratio = cands[accept].ratio;
     c->probe_candidates = (int)cands.size();
-    if (!ctx->ref_col) {  // a placed column future bitset / scratch allocations are matched against
+    if (!ctx->ref_col && matched) {  // a placed column future bitset / scratch allocations are matched against
         ctx->ref_col = c->dev;
         ctx->ref_rows = bytes / 8;
     }
@@ -873,11 +867,11 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     rows -= rows % tr;
     if (!ctx->placement || !col || rows < ((uint64_t)1 << 24)) return dev_malloc(ctx, out, bytes);
     hipStreamSynchronize(ctx->stream);
-    int lg = 0;
-    while (((uint64_t)2 << lg) <= rows) lg++;
+    const double ro = probe_pair(ctx, col, rows, nullptr);
+    if (ro <= 0.0) return dev_malloc(ctx, out, bytes);
     std::vector<std::pair<void *, double>> cands;
     int accept = -1;
-    for (int k = 0; k < 12; k++) {
+    for (int k = 0; k < 16; k++) {
         void *p = nullptr;
         if ((cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes)) != hipSuccess) {
             (void)hipGetLastError();
@@ -885,19 +879,10 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
         }
         const double r = probe_pair(ctx, col, rows, p);
         cands.push_back({p, r});
-        const int me = (int)cands.size() - 1;
-        if (r <= 0.0) { accept = me; break; }
-        if (ctx->best_probe[lg] > 0.0) {
-            if (r >= 0.94 * ctx->best_probe[lg]) { accept = me; break; }
-            continue;
+        if (r <= 0.0 || r / ro >= kMatchRatio) {
+            accept = (int)cands.size() - 1;
+            break;
         }
-        double lo = r, hi = r;
-        int arg = me;
-        for (int i = 0; i < me; i++) {
-            lo = std::min(lo, cands[i].second);
-            if (cands[i].second > hi) { hi = cands[i].second; arg = i; }
-        }
-        if (hi >= 1.07 * lo) { accept = arg; break; }
     }
     if (cands.empty()) return hipErrorOutOfMemory;
     if (accept < 0) {
@@ -905,7 +890,6 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
         for (size_t i = 1; i < cands.size(); i++)
             if (cands[i].second > cands[accept].second) accept = (int)i;
     }
-    ctx->best_probe[lg] = std::max(ctx->best_probe[lg], cands[accept].second);
     for (size_t i = 0; i < cands.size(); i++)
         if ((int)i != accept) hipFree(cands[i].first);
     *out = cands[accept].first;

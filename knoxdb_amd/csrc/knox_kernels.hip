@@ -45,10 +45,18 @@ template <> struct WT<1> { using U = uint32_t; static constexpr int K = 16; stat
 
 int tile_rows(int width) { return 64 * (16 / width) * kUnroll * kWavesPerBlock; }
 
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
 template <int W> __device__ __forceinline__ typename WT<W>::U elem(const u32x4 &r, int j) {
     const uint32_t d[4] = {r.x, r.y, r.z, r.w};
     if constexpr (W == 8) {
+        // the loaded register pair as it is (composing (hi << 32) | lo makes the compiler split 64-bit
+        // arithmetic into a zero-extended low part plus a shifted high part)
+#ifdef KNOX_ELEM_COMPOSE  // diagnostics: the old form, for A/B runs
         return ((uint64_t)d[2 * j + 1] << 32) | d[2 * j];
+#else
+        return __builtin_bit_cast(u64x2, r)[j];
+#endif
     } else if constexpr (W == 4) {
         return d[j];
     } else if constexpr (W == 2) {

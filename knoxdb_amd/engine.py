@@ -80,10 +80,10 @@ class Column:
 
     @property
     def placement(self):
-        """(probe GB/s of the scan's read+write mix, candidates tried); (0, 0) = not probed"""
-        g, k = C.c_double(), C.c_int()
-        check(_lib.lib().knox_col_placement(self.h, C.byref(g), C.byref(k)))
-        return g.value, k.value
+        """(probe GB/s of the scan's read+write mix, candidates tried, mix / read-only ratio); zeros = not probed"""
+        g, r, k = C.c_double(), C.c_double(), C.c_int()
+        check(_lib.lib().knox_col_placement(self.h, C.byref(g), C.byref(r), C.byref(k)))
+        return g.value, k.value, r.value
 
     def download(self, first=0, n=None):
         n = self.rows - first if n is None else n

@@ -39,6 +39,7 @@ for on in (True, False):
     print("placement %s: held %s" % ("on " if on else "off", ctx.placement_info()))
     print("  probe GB/s : " + " ".join("%5.0f" % c.placement[0] for c in cols))
     print("  candidates : " + " ".join("%5d" % c.placement[1] for c in cols))
+    print("  mix/ro     : " + " ".join("%5.3f" % c.placement[2] for c in cols))
     print("  scan GB/s  : " + " ".join("%5.0f" % r for r in rates))
     print("  min %.0f  median %.0f  max %.0f" % (min(rates), statistics.median(rates), max(rates)))
     for c in cols:
