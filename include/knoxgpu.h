@@ -91,6 +91,14 @@ int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms); /* records, syncs, return
 /* Tuning knobs: workgroups per CU of the streaming kernels (0 = auto, <0 keeps the current
  * value); variant: 1 = default, 2 = diagnostics (bitset assembled, never stored), <0 keeps.  */
 int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
+/* Page-locked host memory owned by the library (hipHostMalloc): the one kind of host memory the
+ * library may be handed repeatedly without staging.  A Go host builds its block vectors in it
+ * (unsafe.Slice over the pointer; arena hook, SURVEY.md 8b "Ownership") and knox_col_upload /
+ * knox_bits_upload / the download calls then DMA straight from / into it at PCIe rate; any other
+ * host pointer goes through the library's pinned staging ring.  Never retained after a call.  */
+int knox_host_alloc(knox_ctx *ctx, size_t bytes, void **out);
+int knox_host_free(knox_ctx *ctx, void *p);
+
 /* Placement-aware allocation (default on; env KNOX_PLACEMENT=0 or mode 0 turns it off).
  * Measured on MI355X: every device buffer carries a binary placement class, and the
  * scan's read+write mix (8 B read / 0.125 B written per row) runs at ~6.9 TB/s when the column and

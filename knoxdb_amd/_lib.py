@@ -108,6 +108,8 @@ SIGNATURES = {
     "knox_scan_collect": (_i, [_vp, _vp, C.POINTER(AggState), _i, C.POINTER(ScanOut)]),
     "knox_match_range_vectors": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _vp, _vp]),
     "knox_reduce": (_i, [_vp, _vp, _vp, _u64, C.POINTER(AggState)]),
+    "knox_host_alloc": (_i, [_vp, _sz, _pp]),
+    "knox_host_free": (_i, [_vp, _vp]),
     "knox_ctx_set_placement": (_i, [_vp, _i]),
     "knox_ctx_placement_info": (_i, [_vp, C.POINTER(_i64), _pi]),
     "knox_col_placement": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pi]),

@@ -344,6 +344,29 @@ KNOX_API int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant) 
     return KNOX_OK;
 }
 
+KNOX_API int knox_host_alloc(knox_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return KNOX_E_INVALID;
+    *out = nullptr;
+    if (bytes == 0) return KNOX_OK;
+    hipSetDevice(ctx->device);
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        *out = nullptr;
+        return KNOX_E_NOMEM;
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_host_free(knox_ctx *ctx, void *p) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (!p) return KNOX_OK;
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipHostFree(p));
+    return KNOX_OK;
+}
+
 KNOX_API int knox_ctx_set_placement(knox_ctx *ctx, int mode) {
     if (!ctx || mode < 0 || mode > 1) return KNOX_E_INVALID;
     ctx->placement = mode;
@@ -429,8 +452,25 @@ static int stage_init(knox_ctx *ctx) {
     return KNOX_OK;
 }
 
+// is `p` page-locked host memory HIP can DMA from directly (knox_host_alloc, hipHostMalloc, hipHostRegister)?
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain pageable memory is "invalid value" to this query
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 static int upload(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return KNOX_OK;
+    if (is_pinned_host(src)) {
+        // page-locked source: the DMA engine reads it in place, no staging copy (PCIe rate)
+        HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the caller's memory is not referenced after return
+        return KNOX_OK;
+    }
     int rc = stage_init(ctx);
     if (rc) return rc;
     size_t off = 0;
@@ -454,6 +494,11 @@ static int upload(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return KNOX_OK;
+    if (is_pinned_host(dst)) {
+        HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return KNOX_OK;
+    }
     int rc = stage_init(ctx);
     if (rc) return rc;
     size_t off = 0;

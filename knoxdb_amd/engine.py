@@ -254,6 +254,21 @@ class Context:
     def set_tuning(self, blocks_per_cu=0, variant=-1):
         check(self.L.knox_ctx_set_tuning(self.h, blocks_per_cu, variant))
 
+    def host_array(self, n, dtype):
+        """numpy array over page-locked memory from knox_host_alloc (freed with .base_free())"""
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        check(self.L.knox_host_alloc(self.h, n * dt.itemsize, C.byref(p)), "knox_host_alloc")
+        buf = (C.c_char * (n * dt.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=n)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        check(self.L.knox_host_free(self.h, p), "knox_host_free")
+
     def set_placement(self, on=True):
         """placement-aware column allocation (include/knoxgpu.h: knox_ctx_set_placement)"""
         check(self.L.knox_ctx_set_placement(self.h, 1 if on else 0))

@@ -238,3 +238,27 @@ def test_placement_aware_allocation_is_transparent():
             c.set_placement(False)  # gives every held region back
             assert c.placement_info() == {"held_bytes": 0, "held_regions": 0}
             col.free()
+
+
+def test_pinned_host_memory_round_trip(ctx):
+    """knox_host_alloc: page-locked memory is DMA'd from / into directly (no staging ring); results
+    are the same as with pageable memory"""
+    n = 3 * (1 << 20) + 11
+    pinned = ctx.host_array(n, np.int64)
+    pinned[:] = (np.arange(n, dtype=np.int64) * 7919) % 100003
+    pageable = np.array(pinned)  # ordinary copy
+    c1, c2 = ctx.upload(pinned, 1 << 16), ctx.upload(pageable, 1 << 16)
+    tree = And(Leaf(0, FilterMode.Range, 500, 40000))
+    b1, b2 = ctx.bits(n), ctx.bits(n)
+    r1 = ctx.scan(tree, [c1], aggs=[(R.Sum, 0)], bits_out=b1)
+    r2 = ctx.scan(tree, [c2], aggs=[(R.Sum, 0)], bits_out=b2)
+    m = (pageable >= 500) & (pageable <= 40000)
+    assert r1.count == r2.count == int(m.sum()) and r1.value(0)[0] == r2.value(0)[0] == int(pageable[m].sum())
+    assert (b1.bytes() == b2.bytes()).all()
+    back = ctx.host_array(n, np.int64)
+    assert ctx.L.knox_col_download(ctx.h, c1.h, 0, n, back.ctypes.data_as(C.c_void_p)) == 0
+    assert (back == pageable).all()
+    for o in (c1, c2, b1, b2):
+        o.free()
+    ctx.host_free(pinned)
+    ctx.host_free(back)

@@ -39,6 +39,11 @@ if args.cfg == 0:
     plan = ctx.plan(And(Leaf(0, FilterMode.Range, 5, m // 4)), [col], aggs=[(R.Sum, 0)])
     t0 = time.perf_counter(); ctx.scan_async(plan, bits_out=bits); res = ctx.scan_collect(plan, 0); t_scan = time.perf_counter() - t0
     t0 = time.perf_counter(); b, c = ctx.cmp(BlockType.Int64, FilterMode.Lt, host[:1 << 16], 127); t_cmp = time.perf_counter() - t0
+    pin = ctx.host_array(m, np.int64)
+    pin[:] = host
+    t0 = time.perf_counter(); colp = ctx.upload(pin, pack); ctx.sync(); t_pin = time.perf_counter() - t0
+    print(json.dumps({"cfg": "pcie-pinned (knox_host_alloc)", "rows": m, "upload_s": t_pin, "upload_GBs": m * 8 / t_pin / 1e9,
+                      "placement": colp.placement}))
     print(json.dumps({"cfg": "pcie", "rows": m, "upload_s": t_up, "upload_GBs": m * 8 / t_up / 1e9, "first_scan_s": t_scan,
                       "pcie_inclusive_rows_per_s": m / (t_up + t_scan), "knox_cmp_2^16_rows_s": t_cmp}))
 elif args.cfg == 3:
