@@ -915,8 +915,14 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     const double ro = probe_pair(ctx, col, rows, nullptr);
     if (ro <= 0.0) return dev_malloc(ctx, out, bytes);
     std::vector<std::pair<void *, double>> cands;
+    std::vector<void *> spacers;
     int accept = -1;
-    for (int k = 0; k < 16; k++) {
+    const char *fm = getenv("KNOX_PLACEMENT_FORCE_MISS");  // tests: treat the first N candidates as misses
+    const int force_miss = fm ? atoi(fm) : 0;
+    // Regions of one class come in runs of tens of GiB in the driver's allocation order, and a small
+    // buffer moves through that order slowly: after every second miss a 4 GiB spacer is parked (and
+    // given back at the end) so that the search reaches the next run.
+    for (int k = 0; k < 40; k++) {
         void *p = nullptr;
         if ((cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes)) != hipSuccess) {
             (void)hipGetLastError();
@@ -924,11 +930,17 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
         }
         const double r = probe_pair(ctx, col, rows, p);
         cands.push_back({p, r});
-        if (r <= 0.0 || r / ro >= kMatchRatio) {
+        if ((r <= 0.0 || r / ro >= kMatchRatio) && k >= force_miss) {
             accept = (int)cands.size() - 1;
             break;
         }
+        if ((k & 1) == 1 && spacers.size() < 32) {
+            void *sp = nullptr;
+            if (hipMalloc(&sp, (size_t)4 << 30) == hipSuccess) spacers.push_back(sp);
+            else (void)hipGetLastError();
+        }
     }
+    for (void *sp : spacers) hipFree(sp);
     if (cands.empty()) return hipErrorOutOfMemory;
     if (accept < 0) {
         accept = 0;

@@ -262,3 +262,29 @@ def test_pinned_host_memory_round_trip(ctx):
         o.free()
     ctx.host_free(pinned)
     ctx.host_free(back)
+
+
+def test_placement_search_with_spacers_returns_everything(monkeypatch):
+    """the write-buffer search parks 4 GiB spacers after every second miss and must give all of them
+    (and every rejected candidate) back; KNOX_PLACEMENT_FORCE_MISS drives it through that path"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free0, free1, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    n = 1 << 25
+    x = np.arange(n, dtype=np.int64)
+    with K.Context(0) as c:
+        col = c.upload(x, 1 << 20)
+        c.sync()
+        hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
+        monkeypatch.setenv("KNOX_PLACEMENT_FORCE_MISS", "7")
+        bits = c.bits(n, for_col=col)
+        monkeypatch.delenv("KNOX_PLACEMENT_FORCE_MISS")
+        assert bits.placement[1] >= 8  # 7 forced misses (3 spacers parked on the way) + the one taken
+        c.sync()
+        hip.hipMemGetInfo(C.byref(free1), C.byref(tot))
+        # only the accepted 4 MiB bitset (+ allocator granularity) stays allocated
+        assert free0.value - free1.value < (64 << 20), (free0.value, free1.value)
+        r = c.scan(And(Leaf(0, FilterMode.Lt, 1000)), [col], bits_out=bits)
+        assert r.count == 1000 == bits.count()
+        bits.free()
+        col.free()
