@@ -912,8 +912,31 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     rows -= rows % tr;
     if (!ctx->placement || !col || rows < ((uint64_t)1 << 24)) return dev_malloc(ctx, out, bytes);
     hipStreamSynchronize(ctx->stream);
-    const double ro = probe_pair(ctx, col, rows, nullptr);
-    if (ro <= 0.0) return dev_malloc(ctx, out, bytes);
+    // every (column chunk, the part of the write buffer that chunk's bits go to) pair the scan will
+    // really use is probed: either buffer may straddle a class boundary
+    const uint64_t span = std::min<uint64_t>(col_rows - col_rows % tr, (uint64_t)bytes * 8 - ((uint64_t)bytes * 8) % tr);
+    std::vector<uint64_t> chunk_off;
+    std::vector<double> chunk_ro;
+    for (uint64_t off = 0; off + rows <= span; off += kProbeChunkRows) {
+        const double ro_c = probe_pair(ctx, (const char *)col + off * 8, rows, nullptr);
+        if (ro_c <= 0.0) return dev_malloc(ctx, out, bytes);
+        chunk_off.push_back(off);
+        chunk_ro.push_back(ro_c);
+        if (rows < kProbeChunkRows) break;
+    }
+    if (chunk_off.empty()) return dev_malloc(ctx, out, bytes);
+    const double ro = chunk_ro[0];
+    auto probe_all = [&](void *p) {  // mix rate of the worst pair, scaled to chunk 0's read-only rate
+        double worst = 0.0;
+        for (size_t i = 0; i < chunk_off.size(); i++) {
+            const double r = probe_pair(ctx, (const char *)col + chunk_off[i] * 8, rows, (char *)p + (chunk_off[i] >> 3));
+            if (r <= 0.0) return 0.0;
+            const double scaled = r / chunk_ro[i] * ro;
+            if (worst == 0.0 || scaled < worst) worst = scaled;
+            if (r / chunk_ro[i] < kMatchRatio) break;  // already a miss
+        }
+        return worst;
+    };
     std::vector<std::pair<void *, double>> cands;
     std::vector<void *> spacers;
     int accept = -1;
@@ -928,7 +951,7 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
             (void)hipGetLastError();
             break;
         }
-        const double r = probe_pair(ctx, col, rows, p);
+        const double r = probe_all(p);
         cands.push_back({p, r});
         if ((r <= 0.0 || r / ro >= kMatchRatio) && k >= force_miss) {
             accept = (int)cands.size() - 1;
