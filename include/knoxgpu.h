@@ -171,6 +171,10 @@ void *knox_col_device_ptr(const knox_col *col);
 
 /* ---- device bitsets: internal/bitset/bitset.go:30-35 + generic/bitset.go:13-435 ------ */
 int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out);
+/* Borrowed device memory as a bitset (counterpart of knox_col_wrap): device_ptr is 128-byte aligned
+ * and at least ((size_bits + 63) / 64) * 8 + 64 bytes long; tail bits must be zero; never freed
+ * by the library.                                                                            */
+int knox_bits_wrap(knox_ctx *ctx, void *device_ptr, size_t size_bits, knox_bits **out);
 /* As knox_bits_alloc, but the buffer is chosen to be of the placement class that is fast with
  * scans of `col` (pair probe with the scan kernel, <= 12 small candidates).  Use it for the
  * selection bitset (bits_out) of scans over that column / over columns placed by this context. */

@@ -114,6 +114,7 @@ SIGNATURES = {
     "knox_ctx_placement_info": (_i, [_vp, C.POINTER(_i64), _pi]),
     "knox_col_placement": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pi]),
     "knox_bits_placement": (_i, [_vp, C.POINTER(C.c_double), _pi]),
+    "knox_bits_wrap": (_i, [_vp, _vp, _sz, _pp]),
     "knox_bits_alloc_for": (_i, [_vp, _sz, _vp, _pp]),
     "knox_match_wide": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, C.POINTER(_i64)]),
     "knox_reduce_moments": (_i, [_vp, _vp, _vp, C.POINTER(AggState)]),

@@ -124,6 +124,7 @@ struct knox_bits {
     size_t size;
     uint64_t *dev;
     size_t cap_bytes;
+    bool owned = true;
     double probe_gbs = 0.0;  // pair probe of the accepted buffer (knox_bits_alloc_for), 0 = not probed
     int probe_candidates = 0;
 };
@@ -1055,11 +1056,25 @@ KNOX_API int knox_bits_placement(const knox_bits *b, double *probe_gbs, int *can
     return KNOX_OK;
 }
 
+// Borrowed bitset memory (the counterpart of knox_col_wrap): bits_padded(size) + 64 bytes at device_ptr
+KNOX_API int knox_bits_wrap(knox_ctx *ctx, void *device_ptr, size_t size_bits, knox_bits **out) {
+    if (!ctx || !out || !device_ptr || ((uintptr_t)device_ptr & 127) != 0) return KNOX_E_INVALID;
+    knox_bits *b = new (std::nothrow) knox_bits();
+    if (!b) return KNOX_E_NOMEM;
+    b->ctx = ctx;
+    b->size = size_bits;
+    b->dev = (uint64_t *)device_ptr;
+    b->cap_bytes = bits_padded(size_bits) + 64;
+    b->owned = false;
+    *out = b;
+    return KNOX_OK;
+}
+
 KNOX_API int knox_bits_free(knox_bits *b) {
     if (!b) return KNOX_E_INVALID;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    if (b->dev) hipFree(b->dev);
+    if (b->dev && b->owned) hipFree(b->dev);
     delete b;
     return KNOX_OK;
 }

@@ -100,10 +100,12 @@ class Column:
 class Bits:
     """bitset.Bitset resident on the device (internal/bitset/bitset.go:30-35)."""
 
-    def __init__(self, ctx, size, for_col=None):
+    def __init__(self, ctx, size, for_col=None, wrap_ptr=None):
         self.ctx, self.size = ctx, size
         h = C.c_void_p()
-        if for_col is None:
+        if wrap_ptr is not None:  # borrowed device memory (knox_bits_wrap)
+            check(_lib.lib().knox_bits_wrap(ctx.h, C.c_void_p(wrap_ptr), size, C.byref(h)), "knox_bits_wrap")
+        elif for_col is None:
             check(_lib.lib().knox_bits_alloc(ctx.h, size, C.byref(h)))
         else:  # placement class matched to scans of that column (include/knoxgpu.h knox_bits_alloc_for)
             check(_lib.lib().knox_bits_alloc_for(ctx.h, size, for_col.h, C.byref(h)), "knox_bits_alloc_for")
@@ -114,6 +116,12 @@ class Bits:
         g, k = C.c_double(), C.c_int()
         check(_lib.lib().knox_bits_placement(self.h, C.byref(g), C.byref(k)))
         return g.value, k.value
+
+    @property
+    def device_ptr(self):
+        f = _lib.lib().knox_bits_device_ptr
+        f.restype = C.c_void_p
+        return f(self.h)
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=np.uint8)
