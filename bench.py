@@ -7,7 +7,7 @@ evaluates `Between(-2^38, 2^38)` on 2^30 int64 rows (1024 packs of 2^20), writes
 selection bitset, the per-pack popcounts and the wrapping int64 sum + count.  Inputs are
 generated on the device (counter-based generator) and are resident in HBM when the
 timed region starts.  For N > 1 each rank owns a contiguous pack range (no data-path
-collective); only the 100-byte partial aggregate crosses xGMI (RCCL all-gather) each step.
+collective); only the 144-byte partial aggregate state crosses xGMI (RCCL all-gather) each step.
 
 Prints ONE JSON line (rank 0).
 """
