@@ -78,6 +78,14 @@ func NewBits(c *Ctx, size int) (*Bits, error) {
 	return &Bits{b}, errOf(rc)
 }
 
+// NewBitsFor allocates the selection bitset for scans over col: same HBM placement class as the
+// column (knox_bits_alloc_for; a bitset of the other class costs the scan ~13 %, DESIGN.md 7).
+func NewBitsFor(c *Ctx, size int, col *Column) (*Bits, error) {
+	var b *C.knox_bits
+	rc := C.knox_bits_alloc_for(c.p, C.size_t(size), col.p, &b)
+	return &Bits{b}, errOf(rc)
+}
+
 func (b *Bits) Free() { C.knox_bits_free(b.p) }
 
 // Download copies the bitset into a Go slice of (size+7)/8 bytes (bitset.Bitset.Bytes()).
