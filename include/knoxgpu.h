@@ -307,6 +307,12 @@ int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 | 4 
 int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op, uint64_t a,
                              uint64_t b, const knox_bits *mask /* nullable */, knox_bits *bits);
 
+/* The same for bytes statistics columns (match_bytes.go:97-117, 138-145, 165-170, 190-195, 215-220,
+ * 240-245, 282-299): bytes.Compare order; RANGE tests min <= val2 && max >= val.           */
+int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op,
+                                   const uint8_t *val, uint64_t val_len, const uint8_t *val2, uint64_t val2_len,
+                                   const knox_bits *mask /* nullable */, knox_bits *bits);
+
 /* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
 int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,
                 uint64_t row_base, knox_agg_state *state);

@@ -1980,6 +1980,44 @@ KNOX_API int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const
     return rc;
 }
 
+// the bytes forms (bytesEqualMatcher.. bytesRangeMatcher.MatchRangeVectors, match_bytes.go:97-299): same
+// shapes over StringPool statistics columns, bytes.Compare order
+KNOX_API int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op, const uint8_t *val, uint64_t val_len,
+                                            const uint8_t *val2, uint64_t val2_len, const knox_bits *mask, knox_bits *bits) {
+    if (!ctx || !mins || !maxs || !bits || mins->n_rows != maxs->n_rows || mins->dtype != KNOX_BYTES || maxs->dtype != KNOX_BYTES ||
+        bits->size != mins->n_rows)
+        return KNOX_E_INVALID;
+    if (mask && mask->size != bits->size) return KNOX_E_INVALID;
+    if ((val_len && !val) || (op == KNOX_RANGE && val2_len && !val2)) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    knox_col *cols[2] = {const_cast<knox_col *>(mins), const_cast<knox_col *>(maxs)};
+    knox_pred p[3];
+    memset(p, 0, sizeof p);
+    int n = 0;
+    bool and_mask = false;
+    auto leaf = [&](int i, int mode, int col, const uint8_t *v, uint64_t len) {
+        p[i].op = mode; p[i].col = col; p[i].val = v; p[i].val_len = len;
+    };
+    switch (op) {
+    case KNOX_EQ:     // min <= v && max >= v
+        leaf(0, KNOX_LE, 0, val, val_len); leaf(1, KNOX_GE, 1, val, val_len); p[2].kind = KNOX_NODE_AND; p[2].nchild = 2; n = 3; and_mask = true; break;
+    case KNOX_RANGE:  // min <= to && max >= from
+        leaf(0, KNOX_LE, 0, val2, val2_len); leaf(1, KNOX_GE, 1, val, val_len); p[2].kind = KNOX_NODE_AND; p[2].nchild = 2; n = 3; and_mask = true; break;
+    case KNOX_GT: leaf(0, KNOX_GT, 1, val, val_len); n = 1; break;  // max > v
+    case KNOX_GE: leaf(0, KNOX_GE, 1, val, val_len); n = 1; break;  // max >= v
+    case KNOX_LT: leaf(0, KNOX_LT, 0, val, val_len); n = 1; break;  // min < v
+    case KNOX_LE: leaf(0, KNOX_LE, 0, val, val_len); n = 1; break;  // min <= v
+    case KNOX_NE: case KNOX_NOTIN:  // undecided, always true
+        return mask ? knox_bits_copy(ctx, bits, mask) : knox_bits_one(ctx, bits);
+    default: return KNOX_E_UNSUPPORTED;
+    }
+    knox_scan_out out;
+    int rc = knox_scan(ctx, p, n, cols, 2, nullptr, 0, 0, nullptr, bits, nullptr, nullptr, &out);
+    if (rc) return rc;
+    if (and_mask && mask) rc = knox_bits_and(ctx, bits, mask);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // knox_cmp: the finest boundary (host slices in, host bitset out)
 // ------------------------------------------------------------------------------------------------

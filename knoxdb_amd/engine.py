@@ -406,6 +406,14 @@ class Context:
               "knox_match_range_vectors")
         return out
 
+    def match_range_vectors_bytes(self, mins, maxs, mode, val, val2=None, mask=None, bits=None):
+        """MatchRangeVectors over bytes (StringPool) min / max statistics columns."""
+        out = bits if bits is not None else self.bits(mins.rows)
+        v, v2 = bytes(val), bytes(val2) if val2 is not None else b""
+        check(self.L.knox_match_range_vectors_bytes(self.h, mins.h, maxs.h, int(mode), v, len(v), v2, len(v2),
+                                                    mask.h if mask is not None else None, out.h), "knox_match_range_vectors_bytes")
+        return out
+
     def match_wide(self, limbs, mode, a, b=None, mask=None, bits=None):
         """Int128 / Int256 matcher over limb columns (most significant first) -> (Bits, count)."""
         n = len(limbs)

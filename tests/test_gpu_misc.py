@@ -154,3 +154,37 @@ def test_zone_map_pruning_match_range_vectors(ctx):
     assert r1.rows_scanned == int((1 - skip).sum()) * pack < x.size
     for h in (col, mins, maxs, mask, maybe, bits):
         h.free()
+
+
+def test_zone_map_match_range_vectors_bytes(ctx):
+    """the bytes forms of MatchRangeVectors (match_bytes.go:97-299) over StringPool min / max statistics
+    columns: expected values from Python's bytes order (= bytes.Compare)"""
+    rng = np.random.default_rng(53)
+    n_packs = 200
+    def pool(vals):
+        buf = np.frombuffer(b"".join(vals) + b"\x00" * 8, dtype=np.uint8)
+        lens = np.array([len(v) for v in vals], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+        return (offs << np.uint64(32)) | lens, buf
+    keys = sorted({bytes(rng.integers(97, 123, size=int(rng.integers(1, 12)), dtype=np.uint8)) for _ in range(3 * n_packs)})
+    los = [keys[i] for i in sorted(rng.integers(0, len(keys) - 40, size=n_packs))]
+    his = [max(lo, keys[min(len(keys) - 1, keys.index(lo) + int(rng.integers(0, 40)))]) for lo in los]
+    mins, maxs = ctx.upload_bytes(*pool(los)), ctx.upload_bytes(*pool(his))
+    mask_h = np.packbits(rng.random(n_packs) < 0.6, bitorder="little")
+    mask = ctx.bits(n_packs).upload(mask_h)
+    maskb = np.unpackbits(mask_h, bitorder="little")[:n_packs].astype(bool)
+    v, frm, to = keys[len(keys) // 2], keys[len(keys) // 3], keys[len(keys) // 3 + 25]
+    A = lambda f: np.array([f(lo, hi) for lo, hi in zip(los, his)])
+    cases = [(FilterMode.Equal, v, None, A(lambda lo, hi: lo <= v <= hi), True),
+             (FilterMode.Range, frm, to, A(lambda lo, hi: lo <= to and hi >= frm), True),
+             (FilterMode.Gt, v, None, A(lambda lo, hi: hi > v), False), (FilterMode.Ge, v, None, A(lambda lo, hi: hi >= v), False),
+             (FilterMode.Lt, v, None, A(lambda lo, hi: lo < v), False), (FilterMode.Le, v, None, A(lambda lo, hi: lo <= v), False),
+             (FilterMode.NotEqual, v, None, np.ones(n_packs, bool), True)]
+    for mode, a, b, want, masked in cases:
+        for m in (None, mask):
+            got = ctx.match_range_vectors_bytes(mins, maxs, mode, a, b, mask=m)
+            w = want & maskb if (m is not None and masked) else want
+            assert (np.unpackbits(got.bytes(), bitorder="little")[:n_packs].astype(bool) == w).all(), (mode, m is not None)
+            got.free()
+    for h in (mins, maxs, mask):
+        h.free()
