@@ -354,9 +354,11 @@ int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out);
 typedef struct knox_bloom knox_bloom;
 int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs,
                       knox_bloom **out);
-/* Build the per-pack filters on the device for an 8-byte column: xxh3_u64 of the raw value
- * bits, k = 4, m = pow2(pack_rows * factor * 8) bits (pack/stats/filter.go:296-360; factor =
- * FilterType.Factor(), bytes per value).  Sets up config 4.                                 */
+/* Build the per-pack filters on the device for a numeric column of any width: the fixed-width
+ * xxh3 of the raw value bits (hash.HashT, internal/hash/hash.go:67-92, xxh3.go:22-58), k = 4,
+ * m = pow2(pack_rows * factor * 8) bits (pack/stats/filter.go:296-360; factor =
+ * FilterType.Factor(), bytes per value).  knox_bloom_build_u64 is the 8-byte form (config 4). */
+int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out);
 int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out);
 size_t knox_bloom_packs(const knox_bloom *b);
 size_t knox_bloom_bytes(const knox_bloom *b);

@@ -124,6 +124,7 @@ SIGNATURES = {
     "knox_agg_value": (_i, [C.POINTER(AggState), _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_combine": (_i, [C.POINTER(AggState), _i, C.POINTER(AggState)]),
     "knox_bloom_upload": (_i, [_vp, _vp, _vp, _sz, _pp]),
+    "knox_bloom_build": (_i, [_vp, _vp, _i, _pp]),
     "knox_bloom_build_u64": (_i, [_vp, _vp, _i, _pp]),
     "knox_bloom_packs": (_sz, [_vp]),
     "knox_bloom_bytes": (_sz, [_vp]),

@@ -2458,8 +2458,8 @@ KNOX_API int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint
     return rc;
 }
 
-KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out) {
-    if (!ctx || !col || !out || col->width != 8 || col->dtype == KNOX_BYTES || factor <= 0 || col->pack_rows == 0) return KNOX_E_INVALID;
+KNOX_API int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out) {
+    if (!ctx || !col || !out || col->dtype == KNOX_BYTES || factor <= 0 || col->pack_rows == 0) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
     const size_t n_packs = (col->n_rows + col->pack_rows - 1) / col->pack_rows;
     std::vector<uint64_t> offsets(n_packs + 1);
@@ -2476,7 +2476,7 @@ KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor
     if (rc) return rc;
     knox_bloom *b = *out;
     hipError_t e = hipMemsetAsync(b->d_filters, 0, b->bytes, ctx->stream);
-    if (e == hipSuccess) e = launch_bloom_build_u64(ctx->stream, (const uint64_t *)col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
+    if (e == hipSuccess) e = launch_bloom_build(ctx->stream, col->width, col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         knox_bloom_free(b);
@@ -2484,6 +2484,11 @@ KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor
         return KNOX_E_HIP;
     }
     return KNOX_OK;
+}
+
+KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out) {
+    if (!col || col->width != 8) return KNOX_E_INVALID;
+    return knox_bloom_build(ctx, col, factor, out);
 }
 
 KNOX_API size_t knox_bloom_packs(const knox_bloom *b) { return b ? b->n_packs : 0; }

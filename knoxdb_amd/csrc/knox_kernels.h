@@ -165,8 +165,8 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
 // bloom probe / build
 hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,
                               uint64_t h, uint8_t *maybe_out);
-hipError_t launch_bloom_build_u64(hipStream_t s, const uint64_t *col, uint64_t n_rows, uint64_t pack_rows,
-                                  uint8_t *filters, const uint64_t *offsets);
+hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows,
+                              uint8_t *filters, const uint64_t *offsets);
 
 // bit-packed container payload -> materialized values: out[i] = T((stream >> i*log2) & mask) + minv
 hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,

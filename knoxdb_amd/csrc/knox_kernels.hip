@@ -1892,7 +1892,31 @@ hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint6
 }
 
 // one workgroup per pack; filters pre-zeroed by the host; k byte = 4 (bloom.go:48-60)
-__global__ void __launch_bounds__(kBlock) bloom_build_kernel(const uint64_t *col, uint64_t n_rows, uint64_t pack_rows,
+// fixed-width value hashes (internal/hash/xxh3.go:35-58, hash.go:67-92): u32 = the 4..8 byte XXH3 branch,
+// u16 / u8 = the 1..3 byte branch; floats hash their IEEE bits like the same-width integer
+__device__ __forceinline__ uint64_t xxh3_rrmxmx(uint64_t h, uint64_t len) {
+    h ^= rol64(h, 49) ^ rol64(h, 24);
+    h *= 0x9fb21c651e98df25ull;
+    h ^= (h >> 35) + len;
+    h *= 0x9fb21c651e98df25ull;
+    return h ^ (h >> 28);
+}
+__device__ __forceinline__ uint64_t xxh3_avalanche_small(uint64_t x) {
+    x ^= x >> 33;
+    x *= 14029467366897019727ull;
+    x ^= x >> 29;
+    x *= 1609587929392839161ull;
+    return x ^ (x >> 32);
+}
+template <int W> __device__ __forceinline__ uint64_t xxh3_value(uint64_t v) {
+    if constexpr (W == 8) return xxh3_u64(v);
+    else if constexpr (W == 4) return xxh3_rrmxmx((v + (v << 32)) ^ (0x1cad21f72c81017cull ^ 0xdb979083e96dd4deull), 4);
+    else if constexpr (W == 2) return xxh3_avalanche_small((((v * ((1ull << 24) + 1)) >> 8) + (2ull << 8)) ^ (0xbe4ba423ull ^ 0x396cfeb8ull));
+    else return xxh3_avalanche_small(((v * ((1ull << 24) + (1ull << 16) + 1)) + (1ull << 8)) ^ (0xbe4ba423ull ^ 0x396cfeb8ull));
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) bloom_build_kernel(const void *col, uint64_t n_rows, uint64_t pack_rows,
                                                              uint8_t *filters, const uint64_t *offsets) {
     const uint64_t p = blockIdx.x;
     const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
@@ -1904,7 +1928,7 @@ __global__ void __launch_bounds__(kBlock) bloom_build_kernel(const uint64_t *col
     uint64_t r0 = p * pack_rows, r1 = r0 + pack_rows;
     if (r1 > n_rows) r1 = n_rows;
     for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const uint64_t h = xxh3_u64(col[r]);
+        const uint64_t h = xxh3_value<W>((uint64_t)load_elem<W>(col, r));
         uint32_t h0 = (uint32_t)h;
         const uint32_t h1 = (uint32_t)(h >> 32);
 #pragma unroll
@@ -1919,11 +1943,17 @@ __global__ void __launch_bounds__(kBlock) bloom_build_kernel(const uint64_t *col
     }
 }
 
-hipError_t launch_bloom_build_u64(hipStream_t s, const uint64_t *col, uint64_t n_rows, uint64_t pack_rows, uint8_t *filters,
-                                  const uint64_t *offsets) {
+hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows, uint8_t *filters,
+                              const uint64_t *offsets) {
     const uint64_t n_packs = (n_rows + pack_rows - 1) / pack_rows;
     if (n_packs == 0) return hipSuccess;
-    KNOX_LAUNCH(bloom_build_kernel, (int)n_packs, col, n_rows, pack_rows, filters, offsets);
+    switch (width) {
+    case 8: KNOX_LAUNCH(bloom_build_kernel<8>, (int)n_packs, col, n_rows, pack_rows, filters, offsets);
+    case 4: KNOX_LAUNCH(bloom_build_kernel<4>, (int)n_packs, col, n_rows, pack_rows, filters, offsets);
+    case 2: KNOX_LAUNCH(bloom_build_kernel<2>, (int)n_packs, col, n_rows, pack_rows, filters, offsets);
+    case 1: KNOX_LAUNCH(bloom_build_kernel<1>, (int)n_packs, col, n_rows, pack_rows, filters, offsets);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -457,6 +457,12 @@ class Context:
         check(self.L.knox_bloom_upload(self.h, _ptr(filters) if filters.size else None, _ptr(offsets), offsets.size - 1, C.byref(h)))
         return Bloom(self, h)
 
+    def bloom_build(self, col, factor):
+        """per-pack bloom filters of a numeric column of any width, built on the device"""
+        h = C.c_void_p()
+        check(self.L.knox_bloom_build(self.h, col.h, factor, C.byref(h)), "knox_bloom_build")
+        return Bloom(self, h)
+
     def bloom_build_u64(self, col, factor):
         h = C.c_void_p()
         check(self.L.knox_bloom_build_u64(self.h, col.h, factor, C.byref(h)))

@@ -68,6 +68,34 @@ def test_bloom_build_and_probe(ctx):
     col.free(); bits.free(); bloom.free()
 
 
+@pytest.mark.parametrize("bt", [BlockType.Int32, BlockType.Uint32, BlockType.Float32, BlockType.Float64, BlockType.Int16, BlockType.Uint16,
+                                BlockType.Int8, BlockType.Uint8, BlockType.Int64])
+def test_bloom_build_every_width_matches_reference_hashes(ctx, bt):
+    """device bloom build for every numeric width: byte-identical to filters built with the oracle's
+    hash.HashT restatement (xxh3 u64 / u32 / u16 / u8; floats hash their IEEE bits) and bloom.Add"""
+    from helpers import rand_col
+    rng = np.random.default_rng(70 + int(bt))
+    pack, n_packs = 512, 5
+    n = pack * n_packs - 37  # short last pack
+    x = rand_col(bt, n, rng)
+    col = ctx.upload(x, pack)
+    bloom = ctx.bloom_build(col, 2)
+    filters, offsets = bloom.download()
+    dt = int(bt)
+    for p in range(n_packs):
+        vals = x[p * pack:(p + 1) * pack]
+        f = O.bloom_new(len(vals), 2)
+        for v in vals:
+            O.bloom_add(f, O.hash_value(dt, v))
+        assert (filters[int(offsets[p]):int(offsets[p + 1])] == f).all(), (bt, p)
+    # every stored value probes positive in its own pack through the public hash
+    for p in (0, n_packs - 1):
+        v = x[p * pack]
+        assert bloom.probe(K.hash_value(bt, v))[p] == 1
+    col.free()
+    bloom.free()
+
+
 def test_large_scan_properties(ctx):
     """2^26 rows (512 MiB): size-independent properties + sampled packs against the oracle."""
     n, pack = 1 << 26, 1 << 20
