@@ -354,8 +354,9 @@ int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out);
 typedef struct knox_bloom knox_bloom;
 int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint64_t *offsets, size_t n_packs,
                       knox_bloom **out);
-/* Build the per-pack filters on the device for a numeric column of any width: the fixed-width
- * xxh3 of the raw value bits (hash.HashT, internal/hash/hash.go:67-92, xxh3.go:22-58), k = 4,
+/* Build the per-pack filters on the device: numeric columns of any width hash the fixed-width
+ * xxh3 of the raw value bits (hash.HashT, internal/hash/hash.go:67-92, xxh3.go:22-58), bytes columns
+ * the XXH3-64 of every row's bytes (hash.Hash; pack/stats/filter.go:352-354); k = 4,
  * m = pow2(pack_rows * factor * 8) bits (pack/stats/filter.go:296-360; factor =
  * FilterType.Factor(), bytes per value).  knox_bloom_build_u64 is the 8-byte form (config 4). */
 int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out);
@@ -370,6 +371,9 @@ int knox_bloom_free(knox_bloom *b);
 /* hash.HashT for fixed-width values (internal/hash/hash.go:67-92, xxh3.go:22-58): the hash a
  * numeric Equal matcher probes with (match_num.go:339-346).  Float types hash their bytes.   */
 uint64_t knox_hash_value(int dtype, const void *val);
+/* hash.Hash (internal/hash/hash.go:26 = zeebo/xxh3.Hash): XXH3-64, seed 0, of a byte string -- the
+ * probe value for filters built over bytes columns (bytesMatcher.WithValue, match_bytes.go:56-59). */
+uint64_t knox_hash_bytes(const uint8_t *val, size_t len);
 
 /* ---- multi-GPU: final aggregate only ------------------------------------------------- *
  * One process per GPU.  Rank 0 creates an id, every rank receives it out of band (the host's

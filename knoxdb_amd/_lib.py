@@ -131,6 +131,7 @@ SIGNATURES = {
     "knox_bloom_download": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "knox_bloom_probe": (_i, [_vp, _vp, _u64, _vp]),
     "knox_bloom_free": (_i, [_vp]),
+    "knox_hash_bytes": (_u64, [C.c_char_p, _sz]),
     "knox_hash_value": (_u64, [_i, _vp]),
     "knox_comm_unique_id": (_i, [_vp]),
     "knox_comm_init": (_i, [_vp, _i, _i, _vp]),

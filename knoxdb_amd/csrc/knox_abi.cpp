@@ -21,6 +21,7 @@
 
 #include "../../include/knoxgpu.h"
 #include "knox_kernels.h"
+#include "knox_xxh3.h"  // host flavour: KNOX_HD / KNOX_XXH3_CONST empty
 
 using namespace knox;
 
@@ -2395,6 +2396,12 @@ static uint64_t h_avalanche_small(uint64_t x) {
 
 // internal/hash/hash.go:67-92 + xxh3.go:22-58.  float32/float64 hash their IEEE bytes with the
 // []byte hash, which for 4 and 8 byte inputs is the same 4..8 byte XXH3 branch as u32 / u64.
+// hash.Hash (internal/hash/hash.go:26): XXH3-64 of a byte string -- the probe value of bytes filters
+KNOX_API uint64_t knox_hash_bytes(const uint8_t *val, size_t len) {
+    if (len && !val) return 0;
+    return knox_xxh3::hash(val, (uint64_t)len);
+}
+
 KNOX_API uint64_t knox_hash_value(int dtype, const void *val) {
     if (!val) return 0;
     const uint64_t K = 0x1cad21f72c81017cull ^ 0xdb979083e96dd4deull;
@@ -2459,7 +2466,7 @@ KNOX_API int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint
 }
 
 KNOX_API int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out) {
-    if (!ctx || !col || !out || col->dtype == KNOX_BYTES || factor <= 0 || col->pack_rows == 0) return KNOX_E_INVALID;
+    if (!ctx || !col || !out || factor <= 0 || col->pack_rows == 0) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
     const size_t n_packs = (col->n_rows + col->pack_rows - 1) / col->pack_rows;
     std::vector<uint64_t> offsets(n_packs + 1);
@@ -2476,7 +2483,10 @@ KNOX_API int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, kn
     if (rc) return rc;
     knox_bloom *b = *out;
     hipError_t e = hipMemsetAsync(b->d_filters, 0, b->bytes, ctx->stream);
-    if (e == hipSuccess) e = launch_bloom_build(ctx->stream, col->width, col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
+    if (e == hipSuccess)
+        e = col->dtype == KNOX_BYTES
+                ? launch_bloom_build_bytes(ctx->stream, (const uint64_t *)col->dev, col->buf, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets)
+                : launch_bloom_build(ctx->stream, col->width, col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         knox_bloom_free(b);

@@ -165,6 +165,8 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
 // bloom probe / build
 hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,
                               uint64_t h, uint8_t *maybe_out);
+hipError_t launch_bloom_build_bytes(hipStream_t s, const uint64_t *ptr, const uint8_t *pool, uint64_t n_rows, uint64_t pack_rows,
+                                    uint8_t *filters, const uint64_t *offsets);
 hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows,
                               uint8_t *filters, const uint64_t *offsets);
 

@@ -30,6 +30,10 @@
 //     sum rounded once; integer sums wrap mod 2^64 exactly like Go.
 #include "knox_kernels.h"
 
+#define KNOX_HD __host__ __device__
+#define KNOX_XXH3_CONST __constant__
+#include "knox_xxh3.h"
+
 namespace knox {
 
 // ---------------------------------------------------------------------------------------------
@@ -1941,6 +1945,39 @@ __global__ void __launch_bounds__(kBlock) bloom_build_kernel(const void *col, ui
             h0 += h1;
         }
     }
+}
+
+// bytes column (StringPool): hash.Hash = XXH3-64 of every row's bytes (pack/stats/filter.go:352-354), one lane per row
+__global__ void __launch_bounds__(kBlock) bloom_build_bytes_kernel(const uint64_t *ptr, const uint8_t *pool, uint64_t n_rows, uint64_t pack_rows,
+                                                                   uint8_t *filters, const uint64_t *offsets) {
+    const uint64_t p = blockIdx.x;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    if (threadIdx.x == 0) filters[o0] = 4;
+    const uint64_t bits_off = o0 + 1;
+    const uint32_t mask = (uint32_t)((o1 - o0 - 1) * 8 - 1);
+    uint64_t r0 = p * pack_rows, r1 = r0 + pack_rows;
+    if (r1 > n_rows) r1 = n_rows;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const uint64_t pr = ptr[r];
+        const uint64_t h = knox_xxh3::hash(pool + (uint32_t)(pr >> 32), (uint64_t)(uint32_t)pr);
+        uint32_t h0 = (uint32_t)h;
+        const uint32_t h1 = (uint32_t)(h >> 32);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t byte_addr = bits_off + ((h0 & mask) >> 3);
+            uint32_t *word = (uint32_t *)(filters + (byte_addr & ~3ull));
+            atomicOr(word, (1u << (h0 & 7)) << (8 * (byte_addr & 3)));
+            h0 += h1;
+        }
+    }
+}
+
+hipError_t launch_bloom_build_bytes(hipStream_t s, const uint64_t *ptr, const uint8_t *pool, uint64_t n_rows, uint64_t pack_rows,
+                                    uint8_t *filters, const uint64_t *offsets) {
+    const uint64_t n_packs = (n_rows + pack_rows - 1) / pack_rows;
+    if (n_packs == 0) return hipSuccess;
+    KNOX_LAUNCH(bloom_build_bytes_kernel, (int)n_packs, ptr, pool, n_rows, pack_rows, filters, offsets);
 }
 
 hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows, uint8_t *filters,

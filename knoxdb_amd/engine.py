@@ -497,6 +497,12 @@ class Bloom:
             self.h = None
 
 
+def hash_bytes(val):
+    """hash.Hash: XXH3-64 of a byte string (knox_hash_bytes)"""
+    v = bytes(val)
+    return _lib.lib().knox_hash_bytes(v, len(v))
+
+
 def hash_value(dtype, v):
     a = np.array([v], dtype=NP_DTYPE[BlockType(dtype)])
     return _lib.lib().knox_hash_value(int(dtype), _ptr(a))

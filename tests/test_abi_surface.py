@@ -123,3 +123,19 @@ def test_min_max_first_value_nan_is_sticky():
     for f_k, f_o in ((K.ReducerFunc.Min, O.R_MIN), (K.ReducerFunc.Max, O.R_MAX)):
         got, want = K.agg_value(st, f_k), O.reduce(O.F64, f_o, x)
         assert np.isnan(got[0]) and np.isnan(want[0]) and got[2] == want[2] == 0
+
+
+def test_host_hash_bytes_matches_xxh3_golden_vectors():
+    """knox_hash_bytes (host side of the library: pure C++, no device needed) against the 271
+    python-xxhash digests in tests/golden/xxh3_bytes.json (lengths 0..1040: every XXH3 branch) and
+    the reference's own fixed-width KATs (internal/hash/xxh3_test.go:14-31 via xxh3_kat.json)"""
+    import json
+    import knoxdb_amd as K
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxh3_bytes.json")))
+    for n, want in g["digests"].items():
+        data = bytes((i * 131 + 7) & 0xFF for i in range(int(n)))
+        assert K.hash_bytes(data) == want, n
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxh3_kat.json")))
+    for i in range(8):
+        data = bytes(range(i, i + 8))
+        assert K.hash_bytes(data) == kat["u64"][i] and K.hash_bytes(data[:4]) == kat["u32"][i]

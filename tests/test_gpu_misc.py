@@ -96,6 +96,36 @@ def test_bloom_build_every_width_matches_reference_hashes(ctx, bt):
     bloom.free()
 
 
+def test_bloom_build_bytes_column(ctx):
+    """device bloom build over a bytes (StringPool) column: XXH3-64 of every row on the device, filters
+    byte-identical to the oracle's construction; lengths 0..300 cover every branch of the hash"""
+    rng = np.random.default_rng(91)
+    pack, n_packs = 256, 4
+    n = pack * n_packs - 9
+    lens = np.concatenate([np.arange(0, 130), [136, 144, 159, 160, 161, 200, 239, 240, 241, 255, 256, 257, 300],
+                           rng.integers(0, 48, size=n - 143)])[:n]
+    rng.shuffle(lens)
+    vals = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in lens]
+    buf = np.frombuffer(b"".join(vals) + b"\x00" * 8, dtype=np.uint8)
+    ln = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.uint64)
+    col = ctx.upload_bytes((offs << np.uint64(32)) | ln, buf, pack)
+    bloom = ctx.bloom_build(col, 2)
+    filters, offsets = bloom.download()
+    for p in range(n_packs):
+        vs = vals[p * pack:(p + 1) * pack]
+        f = O.bloom_new(len(vs), 2)
+        for v in vs:
+            O.bloom_add(f, O.xxh3_bytes(v))
+        assert (filters[int(offsets[p]):int(offsets[p + 1])] == f).all(), p
+    # probe through the library's own host hash (knox_hash_bytes)
+    for i in (0, 17, n - 1):
+        assert K.hash_bytes(vals[i]) == O.xxh3_bytes(vals[i])
+        assert bloom.probe(K.hash_bytes(vals[i]))[i // pack] == 1
+    col.free()
+    bloom.free()
+
+
 def test_large_scan_properties(ctx):
     """2^26 rows (512 MiB): size-independent properties + sampled packs against the oracle."""
     n, pack = 1 << 26, 1 << 20
