@@ -220,7 +220,9 @@ int knox_bits_match_bool(knox_ctx *ctx, const knox_bits *column, int op, int a, 
  * (StringPool.MatchEqual/NotEqual, pkg/stringx/match.go:20-84) and the bytes.Compare ordered modes
  * LT/LE/GT/GE/RANGE (:86-251, RANGE = [val, val2] inclusive);
  * KNOX_IN / KNOX_NOTIN leaves pass the set as val = array of column-type values, val_len =
- * its length in BYTES (numInSetMatcher / floatInSetMatcher, match_num.go:593-808).           */
+ * its length in BYTES (numInSetMatcher / floatInSetMatcher, match_num.go:593-808); on a bytes
+ * column the set is a packed list of [uint32 little-endian length][bytes] entries (any order,
+ * duplicates allowed: bytesInSetMatcher / bytesNotInSetMatcher, match_bytes.go:300-540).       */
 enum knox_node_kind { KNOX_NODE_LEAF = 0, KNOX_NODE_AND = 1, KNOX_NODE_OR = 2 };
 typedef struct knox_pred {
     int32_t kind;   /* knox_node_kind */

@@ -1598,9 +1598,52 @@ static int run_moments(knox_ctx *ctx, const knox_col *col, const uint32_t *mask,
 static uint64_t order_key(int dtype, uint64_t bits);
 
 static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *col, size_t n_rows, uint64_t *bits, int grid) {
+    if (col->dtype == KNOX_BYTES && (p.op == KNOX_IN || p.op == KNOX_NOTIN)) {
+        // the set: val = packed list of [uint32 little-endian length][bytes]; sorted (bytes.Compare) + unique here
+        if (p.val_len && !p.val) return KNOX_E_INVALID;
+        std::vector<std::pair<const uint8_t *, uint32_t>> items;
+        for (uint64_t off = 0; off < p.val_len;) {
+            if (off + 4 > p.val_len) return KNOX_E_INVALID;
+            uint32_t len;
+            memcpy(&len, p.val + off, 4);
+            off += 4;
+            if (off + len > p.val_len) return KNOX_E_INVALID;
+            items.push_back({p.val + off, len});
+            off += len;
+        }
+        auto less = [](const std::pair<const uint8_t *, uint32_t> &x, const std::pair<const uint8_t *, uint32_t> &y) {
+            const uint32_t c = std::min(x.second, y.second);
+            const int r = c ? memcmp(x.first, y.first, c) : 0;
+            return r != 0 ? r < 0 : x.second < y.second;
+        };
+        std::sort(items.begin(), items.end(), less);
+        items.erase(std::unique(items.begin(), items.end(), [&](const auto &x, const auto &y) { return !less(x, y) && !less(y, x); }), items.end());
+        if (items.size() > 0xffffffffull) return KNOX_E_RANGE;
+        std::vector<uint64_t> sp(items.size());
+        std::vector<uint8_t> pool;
+        for (size_t i = 0; i < items.size(); i++) {
+            if (pool.size() > 0xffffffffull) return KNOX_E_RANGE;
+            sp[i] = ((uint64_t)pool.size() << 32) | items[i].second;
+            pool.insert(pool.end(), items[i].first, items[i].first + items[i].second);
+        }
+        pool.resize(pool.size() + 8);  // 8-byte compare loads may touch the padding
+        const size_t pool_off = (sp.size() * 8 + 63) & ~(size_t)63;
+        int rc = ensure(ctx, ctx->bytes_val, pool_off + pool.size() + 64);
+        if (rc) return rc;
+        if (!sp.empty()) HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, sp.data(), sp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->bytes_val.p + pool_off, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors not retained
+        hipError_t e = launch_bytes_inset(ctx->stream, p.op == KNOX_NOTIN, (const uint64_t *)col->dev, n_rows, col->buf, (const uint64_t *)ctx->bytes_val.p,
+                                          (uint32_t)sp.size(), (const uint8_t *)ctx->bytes_val.p + pool_off, (uint8_t *)bits, nullptr);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return KNOX_E_HIP;
+        }
+        return KNOX_OK;
+    }
     if (col->dtype == KNOX_BYTES) {
         const bool ordered = p.op == KNOX_LT || p.op == KNOX_LE || p.op == KNOX_GT || p.op == KNOX_GE || p.op == KNOX_RANGE;
-        if (p.op != KNOX_EQ && p.op != KNOX_NE && !ordered) return KNOX_E_UNSUPPORTED;  // IN / regexp: host path
+        if (p.op != KNOX_EQ && p.op != KNOX_NE && !ordered) return KNOX_E_UNSUPPORTED;  // regexp: host path
         if (p.val_len > 0xffffffffull || (p.val_len && !p.val)) return KNOX_E_INVALID;
         const size_t len2 = p.op == KNOX_RANGE ? (size_t)p.val2_len : 0;
         if (len2 > 0xffffffffull || (len2 && !p.val2)) return KNOX_E_INVALID;

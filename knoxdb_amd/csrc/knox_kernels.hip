@@ -1851,6 +1851,55 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
     }
 }
 
+// bytes IN / NOT IN (bytesInSetMatcher / bytesNotInSetMatcher.MatchVector, match_bytes.go:408-470):
+// membership of the row's bytes in the set.  The reference consults a hash map and confirms with
+// bytes.Equal, i.e. plain equality; here the set arrives sorted (bytes.Compare order) and unique in
+// StringPool form and every lane binary-searches it.  Matching rows are OR-ed into bits (bits.Set).
+__global__ void __launch_bounds__(kBlock) bytes_inset_kernel(int negate, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                                                             const uint64_t *set_ptr, uint32_t n_set, const uint8_t *set_buf, uint8_t *bits,
+                                                             const uint8_t *mask) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            const uint64_t p = ptr[row];
+            const uint8_t *v = buf + (uint32_t)(p >> 32);
+            const uint32_t len = (uint32_t)p;
+            uint32_t lo = 0, hi = n_set;
+            bool found = false;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t sp = set_ptr[mid];
+                const int c = bytes_cmp3(set_buf + (uint32_t)(sp >> 32), (uint32_t)sp, v, len);
+                if (c == 0) { found = true; break; }
+                if (c < 0) lo = mid + 1; else hi = mid;
+            }
+            m = negate ? !found : found;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) byte &= mask[bi];
+                if (byte) bits[bi] |= byte;
+            }
+        }
+    }
+}
+
+hipError_t launch_bytes_inset(hipStream_t s, bool negate, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf, const uint64_t *set_ptr,
+                              uint32_t n_set, const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    KNOX_LAUNCH(bytes_inset_kernel, (int)g, negate ? 1 : 0, ptr, n_rows, buf, set_ptr, n_set, set_buf, bits, mask);
+}
+
 // ---------------------------------------------------------------------------------------------
 // bloom filter: internal/filter/bloom/bloom.go:136-150 (probe), :162-169 (add), xxh3.go:22-33
 // ---------------------------------------------------------------------------------------------

@@ -40,7 +40,12 @@ def _flatten(node, cols, out, keep):
         c = cols[node.col]
         p = Pred()
         p.kind, p.nchild, p.col, p.op = 0, 0, node.col, int(node.mode)
-        if c.dtype == BlockType.Bytes:
+        if c.dtype == BlockType.Bytes and node.mode in (FilterMode.In, FilterMode.NotIn):
+            # the set as a packed list of [uint32 little-endian length][bytes] (include/knoxgpu.h)
+            val = b"".join(len(bytes(v)).to_bytes(4, "little") + bytes(v) for v in node.a)
+            keep.append(val)
+            p.val, p.val_len = val, len(val)
+        elif c.dtype == BlockType.Bytes:
             val = bytes(node.a)
             keep.append(val)
             p.val, p.val_len = val, len(val)

@@ -760,6 +760,24 @@ KO_EXPORT int64_t ko_bytes_match2(int op, const uint64_t *ptr, int64_t n, const 
     if ((n & 7) > 0) bits[n >> 3] = b;
     return cnt;
 }
+/* bytesInSetMatcher / bytesNotInSetMatcher.MatchVector (operator/filter/match_bytes.go:408-470, :480-540):
+ * a row matches when its bytes equal one of the set's values (the hash map and the ordered slice are
+ * two lookup structures for the same equality); matching rows are bits.Set, only mask-selected rows
+ * are tested when a mask is given.  The set: set_ptr[i] = off << 32 | len into set_buf. */
+KO_EXPORT int ko_bytes_inset(int negate, const uint64_t *ptr, int64_t n, const uint8_t *buf, const uint64_t *set_ptr, int64_t n_set,
+                             const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask) {
+    for (int64_t i = 0; i < n; i++) {
+        if (mask && !((mask[i >> 3] >> (i & 7)) & 1)) continue;
+        uint32_t ofs = (uint32_t)(ptr[i] >> 32), len = (uint32_t)ptr[i];
+        int found = 0;
+        for (int64_t k = 0; k < n_set && !found; k++) {
+            uint32_t so = (uint32_t)(set_ptr[k] >> 32), sl = (uint32_t)set_ptr[k];
+            found = sl == len && (len == 0 || memcmp(buf + ofs, set_buf + so, len) == 0);
+        }
+        if (found != (negate != 0)) bits[i >> 3] |= (uint8_t)(1 << (i & 7));
+    }
+    return 0;
+}
 KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const uint8_t *buf, const uint8_t *val,
                                  int64_t vlen, uint8_t *bits, const uint8_t *mask) {
     if (op != KO_EQ && op != KO_NE) return -2;

@@ -222,6 +222,23 @@ def bytes_match(op, ptr, buf, val, mask=None, bits=None, val2=None):
     return out, cnt
 
 
+def bytes_inset(negate, ptr, buf, values, mask=None, bits=None):
+    """bytes IN / NOT IN: membership of each row in `values` (list of bytes)"""
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    n = ptr.size
+    vals = [bytes(v) for v in values]
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if vals else np.zeros(0, np.uint64)
+    sp = (offs << np.uint64(32)) | lens
+    sb = np.frombuffer(b"".join(vals) + b"\x00", dtype=np.uint8)
+    out = np.zeros(bitfield_len(n), dtype=np.uint8) if bits is None else np.array(bits, dtype=np.uint8, copy=True)
+    m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+    assert lib().ko_bytes_inset(int(bool(negate)), _p(ptr), C.c_int64(n), _p(buf), _p(sp) if len(vals) else None, C.c_int64(len(vals)), _p(sb),
+                                _p(out), _p(m)) == 0
+    return out
+
+
 def buckets(dtype, func, times, vals, bits, t_from, step, cap=None):
     """NativeBucket.Push over the selected rows -> (window times, values) per reducer in list order."""
     times = np.ascontiguousarray(times, dtype=np.int64)

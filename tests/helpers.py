@@ -9,6 +9,8 @@ from knoxdb_amd.types import NP_DTYPE, BlockType, FilterMode
 
 def oracle_leaf(leaf, host_cols):
     col = host_cols[leaf.col]
+    if isinstance(col, tuple) and leaf.mode in (FilterMode.In, FilterMode.NotIn):
+        return O.bytes_inset(leaf.mode == FilterMode.NotIn, col[0], col[1], list(leaf.a))
     if isinstance(col, tuple):  # bytes column: (ptr, buf)
         bits, _ = O.bytes_match(int(leaf.mode), col[0], col[1], bytes(leaf.a), val2=bytes(leaf.b) if leaf.b is not None else None)
         return bits

@@ -222,6 +222,30 @@ def test_bytes_column_ordered_modes(ctx):
                [(ptr, buf), ids], [(R.Max, 1)], 1024, n)
 
 
+def test_bytes_column_in_not_in(ctx):
+    """bytesInSetMatcher / bytesNotInSetMatcher (match_bytes.go:300-540): equality membership, incl. the
+    empty string, duplicates in the set, an empty set, values that share long prefixes"""
+    rng = np.random.default_rng(31)
+    n = 7000 + 3
+    keys = [b"", b"a", b"ab", b"abcdefgh", b"abcdefghi", b"abcdefgh\x00", b"\xff" * 9] + \
+           [bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8)) for _ in range(80)]
+    vals = [keys[i] for i in rng.integers(0, len(keys), size=n)]
+    buf = np.frombuffer(b"".join(vals) + b"\x00" * 8, dtype=np.uint8)
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    ids = np.arange(n, dtype=np.uint64)
+    sets = [[keys[3], keys[10], b"absent", keys[3], b""], [b"ab"], [], keys[:50], [b"zz-absent-1", b"zz-absent-2"]]
+    for st in sets:
+        for mode in (FilterMode.In, FilterMode.NotIn):
+            check_scan(ctx, And(Leaf(0, mode, st)), [(ptr, buf), ids], [(R.Count, 1)], 1024, n)
+    # independent check of the oracle against Python set membership
+    want = np.packbits(np.array([v in set(sets[0]) for v in vals]), bitorder="little")
+    assert (O.bytes_inset(False, ptr, buf, sets[0]) == want).all()
+    # inside a mixed tree
+    check_scan(ctx, And(Leaf(0, FilterMode.In, keys[:30]), Leaf(1, FilterMode.Ge, 1000)), [(ptr, buf), ids], [(R.Sum, 1)], 1024, n)
+
+
 @pytest.mark.parametrize("bt", [BlockType.Int64, BlockType.Float64, BlockType.Int32, BlockType.Uint16, BlockType.Int8])
 def test_pack_counts_from_the_scan_kernel(ctx, bt):
     """whole packs, no ragged tail: the per-pack counts come from the scan kernel's per-wave-tile
