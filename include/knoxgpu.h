@@ -150,6 +150,8 @@ int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, con
  *   raw ints    [7][uvarint n values][LE values]            internal/encode/int_raw.go:73-94
  *   raw floats  [15][uvarint n bytes][LE values]            internal/encode/float_raw.go:73-89
  *   bit-packed  [4][uvarint For][uvarint log2][uvarint N][packed bits]   int_bitpack.go:93-133
+ *   constant    [1][uvarint Val][uvarint N]                 int_const.go:67-71   (floats: [10][LE bits][N])
+ *   delta       [2][uvarint For][uvarint Delta][uvarint N]  int_delta.go:70-75   value i = T(i)*Delta + For
  * (uvarint = pkg/num/varint.go, a SQLite4-style prefix varint).  Raw payloads are staged straight
  * into the HBM column; bit-packed payloads cross PCIe packed and are decoded ON THE DEVICE
  * (bitpack/decode.go:56-74).  Any other container type: KNOX_E_UNSUPPORTED (host decode as today). */

@@ -790,7 +790,7 @@ KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint
     if (w == 0) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
     const bool isf = dtype_is_float(dtype);
-    struct Part { const uint8_t *payload; size_t n; bool packed; uint32_t log2; uint64_t minv; size_t bytes; };
+    struct Part { const uint8_t *payload; size_t n; bool packed; uint32_t log2; uint64_t minv; size_t bytes; bool affine = false; uint64_t delta = 0; };
     std::vector<Part> parts(n_bufs);
     size_t total = 0, max_packed = 0;
     for (size_t i = 0; i < n_bufs; i++) {
@@ -820,6 +820,32 @@ KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint
             if (o + sz > lens[i]) return KNOX_E_RANGE;
             parts[i] = {bufs[i] + o, (size_t)n, true, (uint32_t)l2, minv, (size_t)sz};
             max_packed = std::max(max_packed, (size_t)sz);
+        } else if ((type == 1 /* TIntConstant */ || type == 2 /* TIntDelta */) && !isf) {
+            // int_const.go:67-71 [1][Val][N]; int_delta.go:70-75 [2][For][Delta][N]: value i = T(i)*Delta + For
+            uint64_t base = 0, delta = 0, n = 0;
+            int k = knox_uvarint(bufs[i] + o, lens[i] - o, &base);
+            if (k == 0) return KNOX_E_INVALID;
+            o += (size_t)k;
+            if (type == 2) {
+                k = knox_uvarint(bufs[i] + o, lens[i] - o, &delta);
+                if (k == 0) return KNOX_E_INVALID;
+                o += (size_t)k;
+            }
+            k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
+            if (k == 0) return KNOX_E_INVALID;
+            parts[i] = {nullptr, (size_t)n, false, 0, base, 0};
+            parts[i].affine = true;
+            parts[i].delta = delta;
+        } else if (type == 10 /* TFloatConstant */ && isf) {
+            // float_const.go:67-71 [10][LE float bits][N]
+            if (o + (size_t)w >= lens[i]) return KNOX_E_RANGE;
+            uint64_t bitsv = 0, n = 0;
+            memcpy(&bitsv, bufs[i] + o, (size_t)w);
+            o += (size_t)w;
+            const int k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
+            if (k == 0) return KNOX_E_INVALID;
+            parts[i] = {nullptr, (size_t)n, false, 0, bitsv, 0};
+            parts[i].affine = true;
         } else {
             return KNOX_E_UNSUPPORTED;  // any other container type: host decode path
         }
@@ -830,7 +856,10 @@ KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint
     size_t row = 0;
     for (size_t i = 0; i < n_bufs && !rc; i++) {
         char *dst = (char *)(*out)->dev + row * (size_t)w;
-        if (!parts[i].packed) {
+        if (parts[i].affine) {
+            hipError_t e = launch_affine_fill(ctx->stream, w, parts[i].minv, parts[i].delta, parts[i].n, dst);
+            if (e != hipSuccess) { ctx->last_hip = (int)e; rc = KNOX_E_HIP; }
+        } else if (!parts[i].packed) {
             rc = upload(ctx, dst, parts[i].payload, parts[i].bytes);
         } else {
             // packed bits cross PCIe (log2/64 of the decoded size), the decode runs on the device

@@ -178,6 +178,9 @@ hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_
 hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
                                  uint64_t n_values, void *dst);
 
+// constant / delta containers: dst[i] = T(i) * delta + base
+hipError_t launch_affine_fill(hipStream_t s, int width, uint64_t base, uint64_t delta, uint64_t n, void *dst);
+
 // synthetic columns
 hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint64_t seed, uint64_t first_row,
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);

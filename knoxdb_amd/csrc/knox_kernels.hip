@@ -2084,6 +2084,35 @@ hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packe
 }
 
 // ---------------------------------------------------------------------------------------------
+// Constant and delta containers (internal/encode/int_const.go:67-88, int_delta.go:70-95, float_const.go:67-86):
+// value i = T(i) * delta + base, wrapping in T (delta = 0: constant; floats: base = the IEEE bits).
+// Nothing but three varints crosses PCIe; the column is written at HBM rate.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) affine_fill_kernel(uint64_t base, uint64_t delta, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = i * delta + base;  // low W bytes = T(i) * delta + base in T's arithmetic
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_affine_fill(hipStream_t s, int width, uint64_t base, uint64_t delta, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    switch (width) {
+    case 8: KNOX_LAUNCH(affine_fill_kernel<8>, (int)g, base, delta, n, dst);
+    case 4: KNOX_LAUNCH(affine_fill_kernel<4>, (int)g, base, delta, n, dst);
+    case 2: KNOX_LAUNCH(affine_fill_kernel<2>, (int)g, base, delta, n, dst);
+    case 1: KNOX_LAUNCH(affine_fill_kernel<1>, (int)g, base, delta, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // synthetic columns (DESIGN.md "synthetic data"): r(i) = mix64(i + mix64(seed))
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {

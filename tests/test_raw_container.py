@@ -103,3 +103,45 @@ def test_gpu_decodes_bitpacked_containers_on_device():
         col = ctx.upload_raw_containers(BlockType.Int64, conts, 4096)
         assert (col.download() == np.concatenate(packs)).all()
         col.free()
+
+
+def _const(val, n, w_mask):
+    return bytes([1]) + O.put_uvarint(val & w_mask) + O.put_uvarint(n)
+
+
+def _delta(base, delta, n, w_mask):
+    return bytes([2]) + O.put_uvarint(base & w_mask) + O.put_uvarint(delta & w_mask) + O.put_uvarint(n)
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_of_const_and_delta_containers():
+    """[1][Val][N] (int_const.go:67-71), [2][For][Delta][N] with value i = T(i)*Delta + For wrapping in T
+    (int_delta.go:70-95), [10][LE bits][N] (float_const.go:67-71) -- filled on the device, mixed with raw
+    containers inside one column"""
+    import knoxdb_amd as K
+    from knoxdb_amd.types import BlockType
+    with K.Context(0) as ctx:
+        for bt, dt, npdt in ((BlockType.Int64, O.I64, np.int64), (BlockType.Uint32, O.U32, np.uint32), (BlockType.Int16, O.I16, np.int16),
+                             (BlockType.Uint8, O.U8, np.uint8)):
+            bits_w = np.dtype(npdt).itemsize * 8
+            m = (1 << bits_w) - 1
+            n = 5000
+            i = np.arange(n, dtype=np.uint64)
+            def T(v):  # wrap into the column type like Go's T(...)
+                return (np.asarray(v, dtype=np.uint64) & np.uint64(m)).astype(np.dtype("u%d" % (bits_w // 8))).view(npdt) if bits_w < 64 else np.asarray(v, dtype=np.uint64).view(np.int64).astype(npdt)
+            parts = [(_const(-7 if np.dtype(npdt).kind == "i" else 200, n, m), T(np.full(n, (-7 if np.dtype(npdt).kind == "i" else 200) & m, dtype=np.uint64))),
+                     (_delta(1000, 3, n, m), T((i * np.uint64(3) + np.uint64(1000)))),
+                     (_delta(5, -2 & m, n, m), T(i * np.uint64((-2) & m) + np.uint64(5))),   # negative step, wraps in T
+                     (O.raw_container_store(dt, T(i * np.uint64(7))), T(i * np.uint64(7)))]
+            col = ctx.upload_raw_containers(bt, [p for p, _ in parts], n)
+            want = np.concatenate([w for _, w in parts])
+            got = col.download()
+            assert got.dtype == want.dtype and (got == want).all(), bt
+            col.free()
+        for bt, npdt, code in ((BlockType.Float64, np.float64, "<d"), (BlockType.Float32, np.float32, "<f")):
+            import struct
+            c = bytes([10]) + struct.pack(code, -2.5) + O.put_uvarint(3000)
+            col = ctx.upload_raw_containers(bt, [c, O.raw_container_store(O.F64 if npdt == np.float64 else O.F32, np.arange(10, dtype=npdt))], 3000)
+            got = col.download()
+            assert (got[:3000] == npdt(-2.5)).all() and (got[3000:] == np.arange(10, dtype=npdt)).all()
+            col.free()
