@@ -152,6 +152,8 @@ int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, con
  *   bit-packed  [4][uvarint For][uvarint log2][uvarint N][packed bits]   int_bitpack.go:93-133
  *   constant    [1][uvarint Val][uvarint N]                 int_const.go:67-71   (floats: [10][LE bits][N])
  *   delta       [2][uvarint For][uvarint Delta][uvarint N]  int_delta.go:70-75   value i = T(i)*Delta + For
+ *   dictionary  [5|12][container of T][container of uint16 codes]         int_dict.go:76-103, float_dict.go:75-102
+ *   run-end     [3|11][container of T][container of uint32 inclusive ends] int_runend.go:84-112, float_runend.go:80-110
  * (uvarint = pkg/num/varint.go, a SQLite4-style prefix varint).  Raw payloads are staged straight
  * into the HBM column; bit-packed payloads cross PCIe packed and are decoded ON THE DEVICE
  * (bitpack/decode.go:56-74).  Any other container type: KNOX_E_UNSUPPORTED (host decode as today). */

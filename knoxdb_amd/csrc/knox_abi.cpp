@@ -783,95 +783,197 @@ static int knox_uvarint(const uint8_t *b, size_t len, uint64_t *out) {
     return need;
 }
 
+// ---- on-disk containers -> device vectors ------------------------------------------------------------
+// Container headers are parsed on the host (a few varints); payloads go to the device as they are and
+// are expanded there.  Nested containers (dictionary, run-end) decode their children first.
+//   [7]/[15] raw            internal/encode/int_raw.go:73-94, float_raw.go:73-89
+//   [4]  bit-packed         int_bitpack.go:93-133
+//   [1]/[10] constant       int_const.go:67-84, float_const.go:67-82
+//   [2]  delta              int_delta.go:70-95
+//   [5]/[12] dictionary     int_dict.go:76-103, float_dict.go:75-102     (T dict, uint16 codes)
+//   [3]/[11] run-end        int_runend.go:84-112, float_runend.go:80-110 (T values, uint32 inclusive ends)
+static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size_t *n_out, size_t *consumed, int depth = 0) {
+    if (!b || len < 2 || depth > 4) return KNOX_E_INVALID;
+    const uint8_t type = b[0];
+    size_t o = 1;
+    uint64_t v = 0;
+    auto uv = [&](uint64_t *x) {
+        const int k = knox_uvarint(b + o, len - o, x);
+        if (k == 0) return false;
+        o += (size_t)k;
+        return true;
+    };
+    if (type == (isf ? 15 : 7)) {
+        if (!uv(&v)) return KNOX_E_INVALID;
+        const uint64_t n = isf ? v / (uint64_t)w : v;  // floats store the BYTE count (float_raw.go:75)
+        if (o + n * (uint64_t)w > len) return KNOX_E_RANGE;
+        *n_out = (size_t)n;
+        *consumed = o + (size_t)n * (size_t)w;
+        return KNOX_OK;
+    }
+    if (type == 4 && !isf) {
+        uint64_t minv, l2, n;
+        if (!uv(&minv) || !uv(&l2) || l2 > 64 || !uv(&n)) return KNOX_E_INVALID;
+        const uint64_t sz = ((l2 * n + 63) & ~63ull) / 8;  // bitpack.EstimateSize
+        if (o + sz > len) return KNOX_E_RANGE;
+        *n_out = (size_t)n;
+        *consumed = o + (size_t)sz;
+        return KNOX_OK;
+    }
+    if ((type == 1 || type == 2) && !isf) {
+        uint64_t base, delta = 0, n;
+        if (!uv(&base) || (type == 2 && !uv(&delta)) || !uv(&n)) return KNOX_E_INVALID;
+        *n_out = (size_t)n;
+        *consumed = o;
+        return KNOX_OK;
+    }
+    if (type == 10 && isf) {
+        if (o + (size_t)w >= len) return KNOX_E_RANGE;
+        o += (size_t)w;
+        uint64_t n;
+        if (!uv(&n)) return KNOX_E_INVALID;
+        *n_out = (size_t)n;
+        *consumed = o;
+        return KNOX_OK;
+    }
+    if (type == (isf ? 12 : 5) || type == (isf ? 11 : 3)) {
+        // [type][child of T][child of uint16 codes / uint32 ends]
+        const bool dict = type == (isf ? 12 : 5);
+        size_t n1 = 0, c1 = 0, n2 = 0, c2 = 0;
+        int rc = container_measure(b + o, len - o, w, isf, &n1, &c1, depth + 1);
+        if (rc) return rc;
+        o += c1;
+        if (o >= len) return KNOX_E_RANGE;
+        rc = container_measure(b + o, len - o, dict ? 2 : 4, false, &n2, &c2, depth + 1);
+        if (rc) return rc;
+        o += c2;
+        if (dict) {
+            if (n1 == 0 && n2 != 0) return KNOX_E_INVALID;
+            *n_out = n2;
+        } else {
+            if (n1 != n2) return KNOX_E_INVALID;
+            *n_out = 0;  // = ends[last] + 1, known after the ends are decoded: reported by container_rows()
+            if (n2 == 0) return KNOX_E_INVALID;
+        }
+        *consumed = o;
+        return KNOX_OK;
+    }
+    return KNOX_E_UNSUPPORTED;  // simple8, ALP, 128/256-bit: host decode path
+}
+
+static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, void *dst, size_t n, int depth = 0);
+
+// run-end containers carry their length in the last end: decode the ends child to learn it
+static int runend_rows(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, size_t *rows) {
+    size_t n1 = 0, c1 = 0, n2 = 0, c2 = 0;
+    int rc = container_measure(b + 1, len - 1, w, isf, &n1, &c1, 1);
+    if (!rc) rc = container_measure(b + 1 + c1, len - 1 - c1, 4, false, &n2, &c2, 1);
+    if (rc) return rc;
+    void *d_ends = nullptr;
+    if (dev_malloc(ctx, &d_ends, n2 * 4 + 64) != hipSuccess) return KNOX_E_NOMEM;
+    rc = container_decode(ctx, b + 1 + c1, len - 1 - c1, 4, false, d_ends, n2, 1);
+    uint32_t last = 0;
+    if (!rc && (hipMemcpyAsync(&last, (const uint32_t *)d_ends + (n2 - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = KNOX_E_HIP;
+    hipFree(d_ends);
+    *rows = (size_t)last + 1;
+    return rc;
+}
+
+static int container_rows(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, size_t *rows) {
+    size_t consumed = 0;
+    int rc = container_measure(b, len, w, isf, rows, &consumed);
+    if (rc) return rc;
+    if (b[0] == (isf ? 11 : 3)) rc = runend_rows(ctx, b, len, w, isf, rows);
+    return rc;
+}
+
+static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, void *dst, size_t n, int depth) {
+    if (n == 0) return KNOX_OK;
+    const uint8_t type = b[0];
+    size_t o = 1;
+    uint64_t v = 0;
+    auto uv = [&](uint64_t *x) { o += (size_t)knox_uvarint(b + o, len - o, x); };  // lengths were validated by container_measure
+    hipError_t e = hipSuccess;
+    if (type == (isf ? 15 : 7)) {
+        uv(&v);
+        return upload(ctx, dst, b + o, n * (size_t)w);
+    }
+    if (type == 4) {
+        uint64_t minv, l2, nn;
+        uv(&minv); uv(&l2); uv(&nn);
+        const size_t sz = (size_t)(((l2 * nn + 63) & ~63ull) / 8);
+        void *d_packed = nullptr;  // packed bits cross PCIe (log2/64 of the decoded size), the decode runs on the device
+        if (dev_malloc(ctx, &d_packed, sz + 64) != hipSuccess) return KNOX_E_NOMEM;
+        int rc = upload(ctx, d_packed, b + o, sz);
+        if (!rc) {
+            e = launch_bitpack_decode(ctx->stream, w, (const uint64_t *)d_packed, sz / 8, (uint32_t)l2, minv, nn, dst);
+            if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
+        }
+        hipFree(d_packed);
+        return rc;
+    }
+    if (type == 1 || type == 2) {
+        uint64_t base, delta = 0, nn;
+        uv(&base);
+        if (type == 2) uv(&delta);
+        uv(&nn);
+        e = launch_affine_fill(ctx->stream, w, base, delta, nn, dst);
+    } else if (type == 10) {
+        uint64_t bitsv = 0;
+        memcpy(&bitsv, b + o, (size_t)w);
+        e = launch_affine_fill(ctx->stream, w, bitsv, 0, n, dst);
+    } else {
+        const bool dict = type == (isf ? 12 : 5);
+        size_t n1 = 0, c1 = 0, n2 = 0, c2 = 0;
+        int rc = container_measure(b + o, len - o, w, isf, &n1, &c1, depth + 1);
+        if (!rc) rc = container_measure(b + o + c1, len - o - c1, dict ? 2 : 4, false, &n2, &c2, depth + 1);
+        if (rc) return rc;
+        if (b[o] == (isf ? 11 : 3)) rc = runend_rows(ctx, b + o, len - o, w, isf, &n1);  // a run-end child reports its rows late
+        if (rc) return rc;
+        void *d1 = nullptr, *d2 = nullptr;
+        if (dev_malloc(ctx, &d1, n1 * (size_t)w + 64) != hipSuccess) return KNOX_E_NOMEM;
+        if (dev_malloc(ctx, &d2, n2 * (dict ? 2 : 4) + 64) != hipSuccess) { hipFree(d1); return KNOX_E_NOMEM; }
+        rc = container_decode(ctx, b + o, len - o, w, isf, d1, n1, depth + 1);
+        if (!rc) rc = container_decode(ctx, b + o + c1, len - o - c1, dict ? 2 : 4, false, d2, n2, depth + 1);
+        if (!rc) {
+            e = dict ? launch_dict_gather(ctx->stream, w, d1, n1, (const uint16_t *)d2, n, dst)
+                     : launch_runend_expand(ctx->stream, w, d1, (const uint32_t *)d2, n2, n, dst);
+            if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
+        }
+        hipFree(d1);
+        hipFree(d2);
+        if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
+        return rc;
+    }
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
 KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
                                             size_t pack_rows, knox_col **out) {
     if (!ctx || !out || (n_bufs && (!bufs || !lens))) return KNOX_E_INVALID;
     const int w = dtype_width(dtype);
-    if (w == 0) return KNOX_E_INVALID;
+    if (w == 0 || dtype == KNOX_BYTES) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
     const bool isf = dtype_is_float(dtype);
-    struct Part { const uint8_t *payload; size_t n; bool packed; uint32_t log2; uint64_t minv; size_t bytes; bool affine = false; uint64_t delta = 0; };
-    std::vector<Part> parts(n_bufs);
-    size_t total = 0, max_packed = 0;
+    std::vector<size_t> rows(n_bufs);
+    size_t total = 0;
     for (size_t i = 0; i < n_bufs; i++) {
         if (!bufs[i] || lens[i] < 2) return KNOX_E_INVALID;
-        const uint8_t type = bufs[i][0];
-        size_t o = 1;
-        uint64_t v = 0;
-        if (type == (isf ? 15 /* TFloatRaw */ : 7 /* TIntRaw */)) {
-            const int k = knox_uvarint(bufs[i] + o, lens[i] - o, &v);
-            if (k == 0) return KNOX_E_INVALID;
-            o += (size_t)k;
-            const uint64_t n = isf ? v / (uint64_t)w : v;  // floats store the BYTE count (float_raw.go:75)
-            if (o + n * (uint64_t)w > lens[i]) return KNOX_E_RANGE;
-            parts[i] = {bufs[i] + o, (size_t)n, false, 0, 0, (size_t)n * (size_t)w};
-        } else if (type == 4 /* TIntBitpacked */ && !isf) {
-            uint64_t minv = 0, l2 = 0, n = 0;  // int_bitpack.go:101-126: [4][For][log2][N][packed]
-            int k = knox_uvarint(bufs[i] + o, lens[i] - o, &minv);
-            if (k == 0) return KNOX_E_INVALID;
-            o += (size_t)k;
-            k = knox_uvarint(bufs[i] + o, lens[i] - o, &l2);
-            if (k == 0 || l2 > 64) return KNOX_E_INVALID;
-            o += (size_t)k;
-            k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
-            if (k == 0) return KNOX_E_INVALID;
-            o += (size_t)k;
-            const uint64_t sz = ((l2 * n + 63) & ~63ull) / 8;  // bitpack.EstimateSize
-            if (o + sz > lens[i]) return KNOX_E_RANGE;
-            parts[i] = {bufs[i] + o, (size_t)n, true, (uint32_t)l2, minv, (size_t)sz};
-            max_packed = std::max(max_packed, (size_t)sz);
-        } else if ((type == 1 /* TIntConstant */ || type == 2 /* TIntDelta */) && !isf) {
-            // int_const.go:67-71 [1][Val][N]; int_delta.go:70-75 [2][For][Delta][N]: value i = T(i)*Delta + For
-            uint64_t base = 0, delta = 0, n = 0;
-            int k = knox_uvarint(bufs[i] + o, lens[i] - o, &base);
-            if (k == 0) return KNOX_E_INVALID;
-            o += (size_t)k;
-            if (type == 2) {
-                k = knox_uvarint(bufs[i] + o, lens[i] - o, &delta);
-                if (k == 0) return KNOX_E_INVALID;
-                o += (size_t)k;
-            }
-            k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
-            if (k == 0) return KNOX_E_INVALID;
-            parts[i] = {nullptr, (size_t)n, false, 0, base, 0};
-            parts[i].affine = true;
-            parts[i].delta = delta;
-        } else if (type == 10 /* TFloatConstant */ && isf) {
-            // float_const.go:67-71 [10][LE float bits][N]
-            if (o + (size_t)w >= lens[i]) return KNOX_E_RANGE;
-            uint64_t bitsv = 0, n = 0;
-            memcpy(&bitsv, bufs[i] + o, (size_t)w);
-            o += (size_t)w;
-            const int k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
-            if (k == 0) return KNOX_E_INVALID;
-            parts[i] = {nullptr, (size_t)n, false, 0, bitsv, 0};
-            parts[i].affine = true;
-        } else {
-            return KNOX_E_UNSUPPORTED;  // any other container type: host decode path
-        }
-        total += parts[i].n;
+        const int rc = container_rows(ctx, bufs[i], lens[i], w, isf, &rows[i]);
+        if (rc) return rc;
+        total += rows[i];
     }
     int rc = col_new(ctx, dtype, total, pack_rows, true, out);
-    if (!rc && max_packed) rc = ensure(ctx, ctx->tmp_vals, max_packed + 64);
     size_t row = 0;
     for (size_t i = 0; i < n_bufs && !rc; i++) {
-        char *dst = (char *)(*out)->dev + row * (size_t)w;
-        if (parts[i].affine) {
-            hipError_t e = launch_affine_fill(ctx->stream, w, parts[i].minv, parts[i].delta, parts[i].n, dst);
-            if (e != hipSuccess) { ctx->last_hip = (int)e; rc = KNOX_E_HIP; }
-        } else if (!parts[i].packed) {
-            rc = upload(ctx, dst, parts[i].payload, parts[i].bytes);
-        } else {
-            // packed bits cross PCIe (log2/64 of the decoded size), the decode runs on the device
-            rc = upload(ctx, ctx->tmp_vals.p, parts[i].payload, parts[i].bytes);
-            if (!rc) {
-                hipError_t e = launch_bitpack_decode(ctx->stream, w, (const uint64_t *)ctx->tmp_vals.p, parts[i].bytes / 8, parts[i].log2,
-                                                     parts[i].minv, parts[i].n, dst);
-                if (e != hipSuccess) { ctx->last_hip = (int)e; rc = KNOX_E_HIP; }
-                else if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;  // tmp buffer is reused by the next container
-            }
-        }
-        row += parts[i].n;
+        rc = container_decode(ctx, bufs[i], lens[i], w, isf, (char *)(*out)->dev + row * (size_t)w, rows[i]);
+        row += rows[i];
     }
     if (rc) {
         if (*out) knox_col_free(*out);

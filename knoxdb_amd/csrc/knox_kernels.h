@@ -181,6 +181,10 @@ hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packe
 // constant / delta containers: dst[i] = T(i) * delta + base
 hipError_t launch_affine_fill(hipStream_t s, int width, uint64_t base, uint64_t delta, uint64_t n, void *dst);
 
+// dictionary / run-end containers over already decoded children
+hipError_t launch_dict_gather(hipStream_t s, int width, const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst);
+hipError_t launch_runend_expand(hipStream_t s, int width, const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst);
+
 // synthetic columns
 hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint64_t seed, uint64_t first_row,
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);

@@ -2084,6 +2084,70 @@ hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packe
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dictionary and run-end containers (internal/encode/int_dict.go:76-103, int_runend.go:84-120 and the
+// float twins float_dict.go:75-102, float_runend.go:80-110), children already decoded on the device:
+//   dictionary  value i = dict[codes[i]]           (codes: uint16)
+//   run-end     value i = values[k], k = first run with ends[k] >= i   (ends: uint32, inclusive)
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) dict_gather_kernel(const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c = codes[i];
+        if (c >= n_dict) c = n_dict - 1;  // corrupt input: stay inside the dictionary
+        const auto v = load_elem<W>(dict, c);
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) runend_expand_kernel(const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n_runs;  // first k with ends[k] >= i (sort.Search)
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)ends[mid] >= i) hi = mid; else lo = mid + 1;
+        }
+        if (lo >= n_runs) lo = n_runs - 1;
+        const auto v = load_elem<W>(values, lo);
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_dict_gather(hipStream_t s, int width, const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    if (n_dict == 0) return hipErrorInvalidValue;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    switch (width) {
+    case 8: KNOX_LAUNCH(dict_gather_kernel<8>, (int)g, dict, n_dict, codes, n, dst);
+    case 4: KNOX_LAUNCH(dict_gather_kernel<4>, (int)g, dict, n_dict, codes, n, dst);
+    case 2: KNOX_LAUNCH(dict_gather_kernel<2>, (int)g, dict, n_dict, codes, n, dst);
+    case 1: KNOX_LAUNCH(dict_gather_kernel<1>, (int)g, dict, n_dict, codes, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_runend_expand(hipStream_t s, int width, const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    if (n_runs == 0) return hipErrorInvalidValue;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    switch (width) {
+    case 8: KNOX_LAUNCH(runend_expand_kernel<8>, (int)g, values, ends, n_runs, n, dst);
+    case 4: KNOX_LAUNCH(runend_expand_kernel<4>, (int)g, values, ends, n_runs, n, dst);
+    case 2: KNOX_LAUNCH(runend_expand_kernel<2>, (int)g, values, ends, n_runs, n, dst);
+    case 1: KNOX_LAUNCH(runend_expand_kernel<1>, (int)g, values, ends, n_runs, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Constant and delta containers (internal/encode/int_const.go:67-88, int_delta.go:70-95, float_const.go:67-86):
 // value i = T(i) * delta + base, wrapping in T (delta = 0: constant; floats: base = the IEEE bits).
 // Nothing but three varints crosses PCIe; the column is written at HBM rate.

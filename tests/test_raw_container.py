@@ -145,3 +145,51 @@ def test_gpu_ingest_of_const_and_delta_containers():
             got = col.download()
             assert (got[:3000] == npdt(-2.5)).all() and (got[3000:] == np.arange(10, dtype=npdt)).all()
             col.free()
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_of_dictionary_and_runend_containers():
+    """nested containers: [5]/[12][dict of T][uint16 codes] (int_dict.go:76-103, float_dict.go:75-102) and
+    [3]/[11][values of T][uint32 inclusive ends] (int_runend.go:84-112, float_runend.go:80-110), children
+    raw / bit-packed / delta; expected vectors built here with numpy"""
+    import knoxdb_amd as K
+    from knoxdb_amd.types import BlockType
+    rng = np.random.default_rng(9)
+    with K.Context(0) as ctx:
+        for bt, dt, npdt, isf in ((BlockType.Int64, O.I64, np.int64, False), (BlockType.Uint16, O.U16, np.uint16, False),
+                                  (BlockType.Float64, O.F64, np.float64, True), (BlockType.Int32, O.I32, np.int32, False)):
+            # dictionary: 300 distinct values, 20000 rows
+            if isf:
+                dvals = (rng.standard_normal(300) * 1e3).astype(npdt)
+            else:
+                info = np.iinfo(npdt)
+                dvals = rng.integers(info.min // 2, info.max // 2, size=300).astype(npdt)
+            codes = rng.integers(0, 300, size=20000).astype(np.uint16)
+            child_dict = O.raw_container_store(dt, dvals) if isf else O.bitpack_container_store(dt, dvals)
+            child_codes = O.bitpack_container_store(O.U16, codes)
+            dict_c = bytes([12 if isf else 5]) + bytes(child_dict) + bytes(child_codes)
+            # run-end: 500 runs of random lengths
+            runs = rng.integers(1, 90, size=500)
+            ends = (np.cumsum(runs) - 1).astype(np.uint32)
+            rvals = dvals[rng.integers(0, 300, size=500)]
+            child_vals = O.raw_container_store(dt, rvals)
+            child_ends = O.bitpack_container_store(O.U32, ends)
+            run_c = bytes([11 if isf else 3]) + bytes(child_vals) + bytes(child_ends)
+            raw_c = O.raw_container_store(dt, dvals[:100])
+            col = ctx.upload_raw_containers(bt, [dict_c, run_c, raw_c], 20000)
+            want = np.concatenate([dvals[codes], np.repeat(rvals, runs), dvals[:100]])
+            got = col.download()
+            assert got.size == want.size and (got == want).all(), bt
+            col.free()
+        # run-end whose values child is a delta container, inside a column of int64
+        runs = np.array([3, 1, 10, 6])
+        ends = (np.cumsum(runs) - 1).astype(np.uint32)
+        delta_child = bytes([2]) + O.put_uvarint(100) + O.put_uvarint(7) + O.put_uvarint(4)  # 100, 107, 114, 121
+        run_c = bytes([3]) + delta_child + bytes(O.raw_container_store(O.U32, ends))
+        col = ctx.upload_raw_containers(BlockType.Int64, [run_c], 64)
+        assert (col.download() == np.repeat(np.array([100, 107, 114, 121], dtype=np.int64), runs)).all()
+        col.free()
+        # simple8 ([6]) is refused, not mis-read
+        with pytest.raises(K.KnoxError) as e:
+            ctx.upload_raw_containers(BlockType.Int64, [bytes([6, 1, 2, 3])], 64)
+        assert e.value.code == -5
