@@ -792,6 +792,7 @@ static int knox_uvarint(const uint8_t *b, size_t len, uint64_t *out) {
 //   [2]  delta              int_delta.go:70-95
 //   [5]/[12] dictionary     int_dict.go:76-103, float_dict.go:75-102     (T dict, uint16 codes)
 //   [3]/[11] run-end        int_runend.go:84-112, float_runend.go:80-110 (T values, uint32 inclusive ends)
+//   [6]  simple8            int_s8b.go:87-115, s8b/generic/decode.go:15-80
 static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size_t *n_out, size_t *consumed, int depth = 0) {
     if (!b || len < 2 || depth > 4) return KNOX_E_INVALID;
     const uint8_t type = b[0];
@@ -827,6 +828,15 @@ static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size
         *consumed = o;
         return KNOX_OK;
     }
+    if (type == 6 && !isf) {  // int_s8b.go:87-93 [6][For][N][len(Packed)][Packed]
+        uint64_t minv, n, plen;
+        if (!uv(&minv) || !uv(&n) || !uv(&plen) || (plen & 7)) return KNOX_E_INVALID;
+        if (o + plen > len) return KNOX_E_RANGE;
+        if (n > plen / 8 * 128) return KNOX_E_INVALID;  // more values than the words can hold
+        *n_out = (size_t)n;
+        *consumed = o + (size_t)plen;
+        return KNOX_OK;
+    }
     if (type == 10 && isf) {
         if (o + (size_t)w >= len) return KNOX_E_RANGE;
         o += (size_t)w;
@@ -858,7 +868,7 @@ static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size
         *consumed = o;
         return KNOX_OK;
     }
-    return KNOX_E_UNSUPPORTED;  // simple8, ALP, 128/256-bit: host decode path
+    return KNOX_E_UNSUPPORTED;  // ALP, 128/256-bit, strings, bitmaps: host decode path
 }
 
 static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, void *dst, size_t n, int depth = 0);
@@ -912,6 +922,29 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
             if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
         }
         hipFree(d_packed);
+        return rc;
+    }
+    if (type == 6) {
+        uint64_t minv, nn, plen;
+        uv(&minv); uv(&nn); uv(&plen);
+        const size_t n_words = (size_t)plen / 8;
+        void *d_packed = nullptr, *d_scr = nullptr;
+        if (dev_malloc(ctx, &d_packed, (size_t)plen + 64) != hipSuccess) return KNOX_E_NOMEM;
+        if (dev_malloc(ctx, &d_scr, (n_words + 2) * 4 + 64) != hipSuccess) { hipFree(d_packed); return KNOX_E_NOMEM; }
+        int rc = ensure(ctx, ctx->misc, 256);
+        if (!rc) rc = upload(ctx, d_packed, b + o, (size_t)plen);
+        if (!rc) {
+            unsigned long long *d_tot = (unsigned long long *)((char *)ctx->misc.p + 128);
+            e = launch_s8b_decode(ctx->stream, w, (const uint64_t *)d_packed, n_words, minv, nn, (uint32_t *)d_scr, d_tot, dst);
+            unsigned long long tot = 0;
+            if (e != hipSuccess || hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = KNOX_E_HIP;
+            else if (tot < nn) rc = KNOX_E_INVALID;  // the words hold fewer values than the header claims
+        }
+        hipFree(d_packed);
+        hipFree(d_scr);
+        if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }
     if (type == 1 || type == 2) {

@@ -2084,6 +2084,56 @@ hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packe
 }
 
 // ---------------------------------------------------------------------------------------------
+// Simple8 containers (internal/encode/int_s8b.go:87-115, s8b/generic/decode.go:15-80, unpack_for.go):
+// every 64-bit word carries a 4-bit selector (bits 60..63) and n values of b bits, LSB first;
+// selectors 0 / 1 are runs of 128 zeros / ones.  value = field + minv.  A word's position in the
+// output is the prefix sum of the counts before it: count -> exclusive scan -> unpack, one lane per word.
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ uint8_t kS8bN[16] = {128, 128, 60, 30, 20, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1};
+__device__ __constant__ uint8_t kS8bBits[16] = {0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 15, 20, 30, 60};
+
+__global__ void __launch_bounds__(kBlock) s8b_count_kernel(const uint64_t *words, uint64_t n_words, uint32_t *counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) counts[i] = kS8bN[words[i] >> 60];
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) s8b_unpack_kernel(const uint64_t *words, uint64_t n_words, const uint32_t *offsets, uint64_t minv,
+                                                            uint64_t n, void *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const uint64_t v = words[i];
+    const uint32_t sel = (uint32_t)(v >> 60);
+    const uint32_t cnt = kS8bN[sel], b = kS8bBits[sel];
+    const uint64_t mask = b == 60 ? 0xFFFFFFFFFFFFFFFull : ((1ull << b) - 1);
+    const uint64_t pos = offsets[i];
+    for (uint32_t j = 0; j < cnt && pos + j < n; j++) {
+        const uint64_t field = sel < 2 ? (uint64_t)sel : ((v >> (j * b)) & mask);
+        const uint64_t x = field + minv;
+        if constexpr (W == 8) ((uint64_t *)dst)[pos + j] = x;
+        else if constexpr (W == 4) ((uint32_t *)dst)[pos + j] = (uint32_t)x;
+        else if constexpr (W == 2) ((uint16_t *)dst)[pos + j] = (uint16_t)x;
+        else ((uint8_t *)dst)[pos + j] = (uint8_t)x;
+    }
+}
+
+// scratch: n_words + 1 uint32 (counts -> offsets, total at [n_words]); n_out: device counter
+hipError_t launch_s8b_decode(hipStream_t s, int width, const uint64_t *words, uint64_t n_words, uint64_t minv, uint64_t n, uint32_t *scratch,
+                             unsigned long long *n_out, void *dst) {
+    if (n_words == 0 || n == 0) return hipSuccess;
+    const int g = (int)((n_words + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(s8b_count_kernel, dim3(g), dim3(kBlock), 0, s, words, n_words, scratch);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, n_words, n_out);
+    switch (width) {
+    case 8: KNOX_LAUNCH(s8b_unpack_kernel<8>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    case 4: KNOX_LAUNCH(s8b_unpack_kernel<4>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    case 2: KNOX_LAUNCH(s8b_unpack_kernel<2>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    case 1: KNOX_LAUNCH(s8b_unpack_kernel<1>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dictionary and run-end containers (internal/encode/int_dict.go:76-103, int_runend.go:84-120 and the
 // float twins float_dict.go:75-102, float_runend.go:80-110), children already decoded on the device:
 //   dictionary  value i = dict[codes[i]]           (codes: uint16)

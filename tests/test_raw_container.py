@@ -58,7 +58,7 @@ def test_gpu_ingest_of_raw_containers_scans_like_decoded_vectors():
             col.free(); bits.free()
         # an encoded (non-raw) container is refused, not mis-read
         with pytest.raises(K.KnoxError) as e:
-            ctx.upload_raw_containers(BlockType.Int64, [bytes([6, 1, 0, 0])], pack)  # TIntSimple8
+            ctx.upload_raw_containers(BlockType.Int64, [bytes([8, 1, 0, 0])], pack)  # TInt128: not a 64-bit column container
         assert e.value.code == -5
 
 
@@ -189,7 +189,69 @@ def test_gpu_ingest_of_dictionary_and_runend_containers():
         col = ctx.upload_raw_containers(BlockType.Int64, [run_c], 64)
         assert (col.download() == np.repeat(np.array([100, 107, 114, 121], dtype=np.int64), runs)).all()
         col.free()
-        # simple8 ([6]) is refused, not mis-read
+        # ALP ([13]) is refused, not mis-read
         with pytest.raises(K.KnoxError) as e:
-            ctx.upload_raw_containers(BlockType.Int64, [bytes([6, 1, 2, 3])], 64)
+            ctx.upload_raw_containers(BlockType.Float64, [bytes([13, 1, 2, 3])], 64)
         assert e.value.code == -5
+
+
+S8_N = [128, 128, 60, 30, 20, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1]
+S8_BITS = [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 15, 20, 30, 60]
+
+
+def s8b_encode(vals):
+    """a valid Simple8 stream for `vals` (each < 2^60): greedy, densest selector whose next n values
+    fit; selectors 0 / 1 for runs of 128 zeros / ones; the last word may be partly filled.  (The
+    reference encoder may choose other words: decoding is what the format fixes.)"""
+    words, i, n = [], 0, len(vals)
+    while i < n:
+        if i + 128 <= n and all(v == vals[i] for v in vals[i:i + 128]) and vals[i] in (0, 1):
+            words.append(int(vals[i]) << 60)
+            i += 128
+            continue
+        for sel in range(2, 16):
+            k, b = S8_N[sel], S8_BITS[sel]
+            chunk = vals[i:i + k]
+            if all(int(v) < (1 << b) for v in chunk):
+                w = sel << 60
+                for j, v in enumerate(chunk):
+                    w |= int(v) << (j * b)
+                words.append(w)
+                i += len(chunk)
+                break
+        else:
+            raise ValueError("value too large for simple8")
+    return np.array(words, dtype=np.uint64).tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_of_simple8_containers():
+    """[6][For][N][len][words] (int_s8b.go:87-115): selector / count table and LSB-first fields of
+    s8b/generic/decode.go + unpack_for.go; value = field + For, wrapping in T"""
+    import knoxdb_amd as K
+    from knoxdb_amd.types import BlockType
+    rng = np.random.default_rng(19)
+    with K.Context(0) as ctx:
+        for bt, npdt in ((BlockType.Int64, np.int64), (BlockType.Uint32, np.uint32), (BlockType.Int16, np.int16), (BlockType.Uint8, np.uint8)):
+            wbits = np.dtype(npdt).itemsize * 8
+            cap = min(wbits, 40)
+            # mixed magnitudes so that many selectors occur, runs of zeros / ones, a ragged tail
+            mags = rng.integers(0, cap + 1, size=30000)
+            fields = np.array([int(rng.integers(0, 1 << int(m))) if m else 0 for m in mags], dtype=np.uint64)
+            fields[1000:1000 + 300] = 0
+            fields[5000:5000 + 200] = 1
+            fields = fields[:29987]
+            minv = -1234 if np.dtype(npdt).kind == "i" else 77
+            packed = s8b_encode(fields.tolist())
+            c = bytes([6]) + O.put_uvarint(minv & ((1 << wbits) - 1)) + O.put_uvarint(fields.size) + O.put_uvarint(len(packed)) + packed
+            col = ctx.upload_raw_containers(bt, [c, c], fields.size)
+            want64 = (fields + np.uint64(minv & ((1 << 64) - 1)))  # wraps mod 2^64, then truncates to T
+            want = (want64 & np.uint64((1 << wbits) - 1)).astype(np.dtype("u%d" % (wbits // 8))).view(npdt) if wbits < 64 else want64.view(np.int64).astype(npdt)
+            got = col.download()
+            assert got.size == 2 * fields.size and (got[:fields.size] == want).all() and (got[fields.size:] == want).all(), bt
+            col.free()
+        # a header that claims more values than the words hold is refused
+        packed = s8b_encode([1, 2, 3])
+        bad = bytes([6]) + O.put_uvarint(0) + O.put_uvarint(100) + O.put_uvarint(len(packed)) + packed
+        with pytest.raises(K.KnoxError):
+            ctx.upload_raw_containers(BlockType.Int64, [bad], 64)
