@@ -793,6 +793,7 @@ static int knox_uvarint(const uint8_t *b, size_t len, uint64_t *out) {
 //   [5]/[12] dictionary     int_dict.go:76-103, float_dict.go:75-102     (T dict, uint16 codes)
 //   [3]/[11] run-end        int_runend.go:84-112, float_runend.go:80-110 (T values, uint32 inclusive ends)
 //   [6]  simple8            int_s8b.go:87-115, s8b/generic/decode.go:15-80
+//   [13] ALP                float_alp.go:109-165, alp/decoder.go:40-130 (values of int64 / int32, patches, positions)
 static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size_t *n_out, size_t *consumed, int depth = 0) {
     if (!b || len < 2 || depth > 4) return KNOX_E_INVALID;
     const uint8_t type = b[0];
@@ -868,7 +869,33 @@ static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size
         *consumed = o;
         return KNOX_OK;
     }
-    return KNOX_E_UNSUPPORTED;  // ALP, 128/256-bit, strings, bitmaps: host decode path
+    if (type == 13 && isf) {  // float_alp.go:109-120 [13][Exponent][Factor][flags][Values of E][Patches of T][Positions of uint32]
+        uint64_t ex, fa;
+        if (!uv(&ex) || !uv(&fa) || o >= len) return KNOX_E_INVALID;
+        if (ex > (w == 8 ? 20u : 10u) || fa > (w == 8 ? 23u : 10u)) return KNOX_E_INVALID;  // alp/constants.go:47-130 table sizes
+        const uint8_t flags = b[o++];
+        size_t nv = 0, cv = 0;
+        int rc = container_measure(b + o, len - o, w, false, &nv, &cv, depth + 1);  // E = int64 / int32
+        if (rc) return rc;
+        if (b[o] == 3) return KNOX_E_UNSUPPORTED;  // run-end values child: length known only after decode (not produced for ALP)
+        o += cv;
+        if (flags & 1) {  // FlagPatched
+            size_t np = 0, cp = 0, nq = 0, cq = 0;
+            if (o >= len) return KNOX_E_RANGE;
+            rc = container_measure(b + o, len - o, w, true, &np, &cp, depth + 1);
+            if (rc) return rc;
+            o += cp;
+            if (o >= len) return KNOX_E_RANGE;
+            rc = container_measure(b + o, len - o, 4, false, &nq, &cq, depth + 1);
+            if (rc) return rc;
+            o += cq;
+            if (np != nq || b[o - cq] == 3 || b[o - cq - cp] == 11) return np != nq ? KNOX_E_INVALID : KNOX_E_UNSUPPORTED;
+        }
+        *n_out = nv;
+        *consumed = o;
+        return KNOX_OK;
+    }
+    return KNOX_E_UNSUPPORTED;  // ALP-RD, 128/256-bit, strings, bitmaps: host decode path
 }
 
 static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, void *dst, size_t n, int depth = 0);
@@ -944,6 +971,53 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
         }
         hipFree(d_packed);
         hipFree(d_scr);
+        if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
+        return rc;
+    }
+    if (type == 13) {
+        static const double kF10[24] = {1.0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                        1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22, 1e23};
+        static const double kIF10[21] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001, 0.00000001, 0.000000001, 0.0000000001,
+                                         0.00000000001, 0.000000000001, 0.0000000000001, 0.00000000000001, 0.000000000000001,
+                                         0.0000000000000001, 0.00000000000000001, 0.000000000000000001, 0.0000000000000000001,
+                                         0.00000000000000000001};
+        static const float kF10f[11] = {1.0f, 10.0f, 100.0f, 1000.0f, 10000.0f, 100000.0f, 1000000.0f, 10000000.0f, 100000000.0f,
+                                        1000000000.0f, 10000000000.0f};
+        static const float kIF10f[11] = {1.0f, 0.1f, 0.01f, 0.001f, 0.0001f, 0.00001f, 0.000001f, 0.0000001f, 0.00000001f, 0.000000001f,
+                                         0.0000000001f};
+        uint64_t ex, fa;
+        uv(&ex); uv(&fa);
+        const uint8_t flags = b[o++];
+        uint64_t f_bits = 0, e_bits = 0;
+        if (w == 8) { memcpy(&f_bits, &kF10[fa], 8); memcpy(&e_bits, &kIF10[ex], 8); }
+        else { memcpy(&f_bits, &kF10f[fa], 4); memcpy(&e_bits, &kIF10f[ex], 4); }
+        size_t nv = 0, cv = 0, np = 0, cp = 0, nq = 0, cq = 0;
+        int rc = container_measure(b + o, len - o, w, false, &nv, &cv, depth + 1);
+        if (!rc && (flags & 1)) {
+            rc = container_measure(b + o + cv, len - o - cv, w, true, &np, &cp, depth + 1);
+            if (!rc) rc = container_measure(b + o + cv + cp, len - o - cv - cp, 4, false, &nq, &cq, depth + 1);
+        }
+        if (rc) return rc;
+        void *d_enc = nullptr, *d_pat = nullptr, *d_pos = nullptr;
+        if (dev_malloc(ctx, &d_enc, nv * (size_t)w + 64) != hipSuccess) return KNOX_E_NOMEM;
+        rc = container_decode(ctx, b + o, len - o, w, false, d_enc, nv, depth + 1);
+        if (!rc) {
+            e = launch_alp_decode(ctx->stream, w, d_enc, f_bits, e_bits, nv, dst);
+            if (e != hipSuccess) rc = KNOX_E_HIP;
+        }
+        if (!rc && np) {
+            if (dev_malloc(ctx, &d_pat, np * (size_t)w + 64) != hipSuccess || dev_malloc(ctx, &d_pos, nq * 4 + 64) != hipSuccess) rc = KNOX_E_NOMEM;
+            if (!rc) rc = container_decode(ctx, b + o + cv, len - o - cv, w, true, d_pat, np, depth + 1);
+            if (!rc) rc = container_decode(ctx, b + o + cv + cp, len - o - cv - cp, 4, false, d_pos, nq, depth + 1);
+            if (!rc) {
+                e = launch_patch_scatter(ctx->stream, w, d_pat, (const uint32_t *)d_pos, np, nv, dst);
+                if (e != hipSuccess) rc = KNOX_E_HIP;
+            }
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = KNOX_E_HIP;
+        if (d_enc) hipFree(d_enc);
+        if (d_pat) hipFree(d_pat);
+        if (d_pos) hipFree(d_pos);
         if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }

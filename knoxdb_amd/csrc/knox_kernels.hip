@@ -2134,6 +2134,57 @@ hipError_t launch_s8b_decode(hipStream_t s, int width, const uint64_t *words, ui
 }
 
 // ---------------------------------------------------------------------------------------------
+// ALP float containers (internal/encode/float_alp.go:109-165, alp/decoder.go:40-130): value i =
+// T(enc[i]) * F10[factor] * IF10[exponent] -- two separate multiplications in T's arithmetic, left
+// to right (this file is compiled with -ffp-contract=off) -- then the exceptions are patched in.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) alp_decode_kernel(const void *enc, uint64_t f_bits, uint64_t e_bits, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if constexpr (W == 8) {
+            const double f = __longlong_as_double((long long)f_bits), e = __longlong_as_double((long long)e_bits);
+            double v = (double)((const int64_t *)enc)[i];
+            v = v * f;
+            v = v * e;
+            ((double *)dst)[i] = v;
+        } else {
+            const float f = __uint_as_float((uint32_t)f_bits), e = __uint_as_float((uint32_t)e_bits);
+            float v = (float)((const int32_t *)enc)[i];
+            v = v * f;
+            v = v * e;
+            ((float *)dst)[i] = v;
+        }
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) patch_scatter_kernel(const void *patches, const uint32_t *pos, uint64_t n_patch, uint64_t n, void *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_patch) return;
+    const uint64_t p = pos[i];
+    if (p >= n) return;
+    if constexpr (W == 8) ((uint64_t *)dst)[p] = ((const uint64_t *)patches)[i];
+    else ((uint32_t *)dst)[p] = ((const uint32_t *)patches)[i];
+}
+
+hipError_t launch_alp_decode(hipStream_t s, int width, const void *enc, uint64_t f_bits, uint64_t e_bits, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (width == 8) KNOX_LAUNCH(alp_decode_kernel<8>, (int)g, enc, f_bits, e_bits, n, dst);
+    if (width == 4) KNOX_LAUNCH(alp_decode_kernel<4>, (int)g, enc, f_bits, e_bits, n, dst);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_patch_scatter(hipStream_t s, int width, const void *patches, const uint32_t *pos, uint64_t n_patch, uint64_t n, void *dst) {
+    if (n_patch == 0) return hipSuccess;
+    const int g = (int)((n_patch + kBlock - 1) / kBlock);
+    if (width == 8) KNOX_LAUNCH(patch_scatter_kernel<8>, g, patches, pos, n_patch, n, dst);
+    if (width == 4) KNOX_LAUNCH(patch_scatter_kernel<4>, g, patches, pos, n_patch, n, dst);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dictionary and run-end containers (internal/encode/int_dict.go:76-103, int_runend.go:84-120 and the
 // float twins float_dict.go:75-102, float_runend.go:80-110), children already decoded on the device:
 //   dictionary  value i = dict[codes[i]]           (codes: uint16)

@@ -189,9 +189,9 @@ def test_gpu_ingest_of_dictionary_and_runend_containers():
         col = ctx.upload_raw_containers(BlockType.Int64, [run_c], 64)
         assert (col.download() == np.repeat(np.array([100, 107, 114, 121], dtype=np.int64), runs)).all()
         col.free()
-        # ALP ([13]) is refused, not mis-read
+        # ALP-RD ([14]) is refused, not mis-read
         with pytest.raises(K.KnoxError) as e:
-            ctx.upload_raw_containers(BlockType.Float64, [bytes([13, 1, 2, 3])], 64)
+            ctx.upload_raw_containers(BlockType.Float64, [bytes([14, 1, 2, 3])], 64)
         assert e.value.code == -5
 
 
@@ -255,3 +255,44 @@ def test_gpu_ingest_of_simple8_containers():
         bad = bytes([6]) + O.put_uvarint(0) + O.put_uvarint(100) + O.put_uvarint(len(packed)) + packed
         with pytest.raises(K.KnoxError):
             ctx.upload_raw_containers(BlockType.Int64, [bad], 64)
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_of_alp_containers():
+    """[13][Exponent][Factor][flags][Values][Patches][Positions] (float_alp.go:109-165): value =
+    T(enc) * F10[factor] * IF10[exponent], two separate multiplications in T (alp/decoder.go:114-116),
+    then the exceptions overwrite their positions"""
+    import knoxdb_amd as K
+    from knoxdb_amd.types import BlockType
+    rng = np.random.default_rng(23)
+    F10 = [10.0 ** k for k in range(24)]
+    IF10 = [float("1e-%d" % k) if k else 1.0 for k in range(21)]
+    with K.Context(0) as ctx:
+        n = 20000
+        for ex, fa in ((2, 0), (5, 1), (14, 3), (0, 0)):
+            enc = rng.integers(-10**9, 10**9, size=n).astype(np.int64)
+            want = (enc.astype(np.float64) * np.float64(F10[fa])) * np.float64(IF10[ex])
+            pos = np.sort(rng.choice(n, size=37, replace=False)).astype(np.uint32)
+            pat = rng.standard_normal(37) * 1e300
+            pat[:3] = [np.nan, np.inf, -0.0]
+            want_p = want.copy()
+            want_p[pos] = pat
+            vals_c = bytes(O.bitpack_container_store(O.I64, enc))
+            plain = bytes([13]) + O.put_uvarint(ex) + O.put_uvarint(fa) + bytes([0]) + vals_c
+            patched = bytes([13]) + O.put_uvarint(ex) + O.put_uvarint(fa) + bytes([1]) + vals_c + bytes(O.raw_container_store(O.F64, pat)) + bytes(O.raw_container_store(O.U32, pos))
+            col = ctx.upload_raw_containers(BlockType.Float64, [plain, patched], n)
+            got = col.download()
+            assert (got[:n].view(np.uint64) == want.view(np.uint64)).all(), (ex, fa)
+            assert (got[n:].view(np.uint64) == want_p.view(np.uint64)).all(), (ex, fa, "patched")
+            col.free()
+        # float32: E = int32, arithmetic in float32
+        enc = rng.integers(-10**6, 10**6, size=n).astype(np.int32)
+        want = (enc.astype(np.float32) * np.float32(10.0)) * np.float32(0.001)
+        c = bytes([13]) + O.put_uvarint(3) + O.put_uvarint(1) + bytes([0]) + bytes(O.raw_container_store(O.I32, enc))
+        col = ctx.upload_raw_containers(BlockType.Float32, [c], n)
+        assert (col.download().view(np.uint32) == want.view(np.uint32)).all()
+        col.free()
+        # ALP-RD ([14]) is refused
+        with pytest.raises(K.KnoxError) as e:
+            ctx.upload_raw_containers(BlockType.Float64, [bytes([14, 1, 2, 3])], 64)
+        assert e.value.code == -5
