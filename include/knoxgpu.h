@@ -154,11 +154,12 @@ int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, con
  *   delta       [2][uvarint For][uvarint Delta][uvarint N]  int_delta.go:70-75   value i = T(i)*Delta + For
  *   simple8     [6][uvarint For][uvarint N][uvarint len][64-bit words]    int_s8b.go:87-115, s8b/generic/decode.go
  *   ALP         [13][uvarint Exponent][uvarint Factor][flags][int64|int32 values][patches][positions]  float_alp.go:109-165
+ *   ALP-RD      [14][container of uint16 left parts][container of uint64|uint32 right parts][uvarint Shift]  float_alprd.go:80-110
  *   dictionary  [5|12][container of T][container of uint16 codes]         int_dict.go:76-103, float_dict.go:75-102
  *   run-end     [3|11][container of T][container of uint32 inclusive ends] int_runend.go:84-112, float_runend.go:80-110
  * (uvarint = pkg/num/varint.go, a SQLite4-style prefix varint).  Raw payloads are staged straight
  * into the HBM column; bit-packed payloads cross PCIe packed and are decoded ON THE DEVICE
- * (bitpack/decode.go:56-74).  Any other container type (ALP-RD, 128/256-bit, strings, bitmaps): KNOX_E_UNSUPPORTED (host decode as today). */
+ * (bitpack/decode.go:56-74).  Any other container type (128/256-bit, strings, bitmaps): KNOX_E_UNSUPPORTED (host decode as today). */
 int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens,
                                    size_t n_bufs, size_t pack_rows, knox_col **out);
 /* Borrow memory that already lives on the device (16-byte aligned); never freed by knox.  */

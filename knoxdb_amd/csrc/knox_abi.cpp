@@ -793,6 +793,7 @@ static int knox_uvarint(const uint8_t *b, size_t len, uint64_t *out) {
 //   [5]/[12] dictionary     int_dict.go:76-103, float_dict.go:75-102     (T dict, uint16 codes)
 //   [3]/[11] run-end        int_runend.go:84-112, float_runend.go:80-110 (T values, uint32 inclusive ends)
 //   [6]  simple8            int_s8b.go:87-115, s8b/generic/decode.go:15-80
+//   [14] ALP-RD             float_alprd.go:80-110, alp/rd.go:200-225 (uint16 left parts, right parts, shift)
 //   [13] ALP                float_alp.go:109-165, alp/decoder.go:40-130 (values of int64 / int32, patches, positions)
 static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size_t *n_out, size_t *consumed, int depth = 0) {
     if (!b || len < 2 || depth > 4) return KNOX_E_INVALID;
@@ -895,7 +896,22 @@ static int container_measure(const uint8_t *b, size_t len, int w, bool isf, size
         *consumed = o;
         return KNOX_OK;
     }
-    return KNOX_E_UNSUPPORTED;  // ALP-RD, 128/256-bit, strings, bitmaps: host decode path
+    if (type == 14 && isf) {  // float_alprd.go:80-86 [14][Left of uint16][Right of uint64|uint32][Shift]
+        size_t nl = 0, cl = 0, nr = 0, cr = 0;
+        int rc = container_measure(b + o, len - o, 2, false, &nl, &cl, depth + 1);
+        if (rc) return rc;
+        if (b[o] == 3 || o + cl >= len) return b[o] == 3 ? KNOX_E_UNSUPPORTED : KNOX_E_RANGE;
+        rc = container_measure(b + o + cl, len - o - cl, w, false, &nr, &cr, depth + 1);
+        if (rc) return rc;
+        if (b[o + cl] == 3) return KNOX_E_UNSUPPORTED;
+        o += cl + cr;
+        uint64_t shift;
+        if (nl != nr || !uv(&shift) || shift >= (uint64_t)(8 * w)) return KNOX_E_INVALID;
+        *n_out = nl;
+        *consumed = o;
+        return KNOX_OK;
+    }
+    return KNOX_E_UNSUPPORTED;  // 128/256-bit, strings, bitmaps: host decode path
 }
 
 static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool isf, void *dst, size_t n, int depth = 0);
@@ -971,6 +987,27 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
         }
         hipFree(d_packed);
         hipFree(d_scr);
+        if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
+        return rc;
+    }
+    if (type == 14) {
+        size_t nl = 0, cl = 0, nr = 0, cr = 0;
+        int rc = container_measure(b + o, len - o, 2, false, &nl, &cl, depth + 1);
+        if (!rc) rc = container_measure(b + o + cl, len - o - cl, w, false, &nr, &cr, depth + 1);
+        if (rc) return rc;
+        uint64_t shift = 0;
+        knox_uvarint(b + o + cl + cr, len - o - cl - cr, &shift);
+        void *d_l = nullptr, *d_r = nullptr;
+        if (dev_malloc(ctx, &d_l, nl * 2 + 64) != hipSuccess) return KNOX_E_NOMEM;
+        if (dev_malloc(ctx, &d_r, nr * (size_t)w + 64) != hipSuccess) { hipFree(d_l); return KNOX_E_NOMEM; }
+        rc = container_decode(ctx, b + o, len - o, 2, false, d_l, nl, depth + 1);
+        if (!rc) rc = container_decode(ctx, b + o + cl, len - o - cl, w, false, d_r, nr, depth + 1);
+        if (!rc) {
+            e = launch_alprd_merge(ctx->stream, w, (const uint16_t *)d_l, d_r, (uint32_t)shift, nl, dst);
+            if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
+        }
+        hipFree(d_l);
+        hipFree(d_r);
         if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }

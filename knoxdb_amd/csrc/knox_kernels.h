@@ -187,6 +187,8 @@ hipError_t launch_s8b_decode(hipStream_t s, int width, const uint64_t *words, ui
 // ALP: dst[i] = T(enc[i]) * f * e (f, e as IEEE bits of T), then dst[pos[k]] = patches[k]
 hipError_t launch_alp_decode(hipStream_t s, int width, const void *enc, uint64_t f_bits, uint64_t e_bits, uint64_t n, void *dst);
 hipError_t launch_patch_scatter(hipStream_t s, int width, const void *patches, const uint32_t *pos, uint64_t n_patch, uint64_t n, void *dst);
+// ALP-RD: bits = uint(left[i]) << shift | right[i]
+hipError_t launch_alprd_merge(hipStream_t s, int width, const uint16_t *left, const void *right, uint32_t shift, uint64_t n, void *dst);
 // dictionary / run-end containers over already decoded children
 hipError_t launch_dict_gather(hipStream_t s, int width, const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst);
 hipError_t launch_runend_expand(hipStream_t s, int width, const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst);

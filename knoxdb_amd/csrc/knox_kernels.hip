@@ -2167,6 +2167,24 @@ __global__ void __launch_bounds__(kBlock) patch_scatter_kernel(const void *patch
     else ((uint32_t *)dst)[p] = ((const uint32_t *)patches)[i];
 }
 
+// ALP-RD (float_alprd.go:80-110, alp/rd.go:200-225): IEEE bits = uint(left) << shift | right
+template <int W>
+__global__ void __launch_bounds__(kBlock) alprd_merge_kernel(const uint16_t *left, const void *right, uint32_t shift, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = ((uint64_t)left[i] << shift) | ((const uint64_t *)right)[i];
+        else ((uint32_t *)dst)[i] = ((uint32_t)left[i] << shift) | ((const uint32_t *)right)[i];
+    }
+}
+
+hipError_t launch_alprd_merge(hipStream_t s, int width, const uint16_t *left, const void *right, uint32_t shift, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (width == 8) KNOX_LAUNCH(alprd_merge_kernel<8>, (int)g, left, right, shift, n, dst);
+    if (width == 4) KNOX_LAUNCH(alprd_merge_kernel<4>, (int)g, left, right, shift, n, dst);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_alp_decode(hipStream_t s, int width, const void *enc, uint64_t f_bits, uint64_t e_bits, uint64_t n, void *dst) {
     if (n == 0) return hipSuccess;
     uint64_t g = (n + kBlock - 1) / kBlock;

@@ -189,9 +189,9 @@ def test_gpu_ingest_of_dictionary_and_runend_containers():
         col = ctx.upload_raw_containers(BlockType.Int64, [run_c], 64)
         assert (col.download() == np.repeat(np.array([100, 107, 114, 121], dtype=np.int64), runs)).all()
         col.free()
-        # ALP-RD ([14]) is refused, not mis-read
+        # string containers ([16]) are refused, not mis-read
         with pytest.raises(K.KnoxError) as e:
-            ctx.upload_raw_containers(BlockType.Float64, [bytes([14, 1, 2, 3])], 64)
+            ctx.upload_raw_containers(BlockType.Float64, [bytes([16, 1, 2, 3])], 64)
         assert e.value.code == -5
 
 
@@ -292,7 +292,24 @@ def test_gpu_ingest_of_alp_containers():
         col = ctx.upload_raw_containers(BlockType.Float32, [c], n)
         assert (col.download().view(np.uint32) == want.view(np.uint32)).all()
         col.free()
-        # ALP-RD ([14]) is refused
+        # ALP-RD: IEEE bits = uint(left) << shift | right (float_alprd.go:80-110, alp/rd.go:200-225)
+        x = rng.standard_normal(n) * 1e-3 + 97.25
+        bits64 = x.view(np.uint64)
+        shift = 48
+        left = (bits64 >> np.uint64(shift)).astype(np.uint16)
+        right = bits64 & np.uint64((1 << shift) - 1)
+        c = bytes([14]) + bytes(O.bitpack_container_store(O.U16, left)) + bytes(O.bitpack_container_store(O.U64, right)) + O.put_uvarint(shift)
+        col = ctx.upload_raw_containers(BlockType.Float64, [c], n)
+        assert (col.download().view(np.uint64) == bits64).all()
+        col.free()
+        xf = (rng.standard_normal(n) * 3).astype(np.float32)
+        b32 = xf.view(np.uint32)
+        c = bytes([14]) + bytes(O.raw_container_store(O.U16, (b32 >> np.uint32(20)).astype(np.uint16))) + \
+            bytes(O.raw_container_store(O.U32, b32 & np.uint32((1 << 20) - 1))) + O.put_uvarint(20)
+        col = ctx.upload_raw_containers(BlockType.Float32, [c], n)
+        assert (col.download().view(np.uint32) == b32).all()
+        col.free()
+        # 128-bit containers are not column containers of this path
         with pytest.raises(K.KnoxError) as e:
-            ctx.upload_raw_containers(BlockType.Float64, [bytes([14, 1, 2, 3])], 64)
+            ctx.upload_raw_containers(BlockType.Float64, [bytes([8, 1, 2, 3])], 64)
         assert e.value.code == -5
