@@ -162,6 +162,16 @@ int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, con
  * (bitpack/decode.go:56-74).  Any other container type (128/256-bit, strings, bitmaps): KNOX_E_UNSUPPORTED (host decode as today). */
 int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens,
                                    size_t n_bufs, size_t pack_rows, knox_col **out);
+/* The same for bytes columns: one string container per pack -> one StringPool column.  Payloads are
+ * uploaded as they are, the row pointers are built on the device from the decoded children:
+ *   constant    [16][uvarint n][uvarint len][val]                          string_const.go:51-70
+ *   fixed       [17][uvarint n][uvarint sz][n*sz bytes]                    string_fixed.go:59-82
+ *   compact     [18][uint32 container ofs][uint32 container len][uvarint buflen][buf]   string_compact.go:64-97
+ *   dictionary  [19][ofs][len][uint32 container code][uvarint dictlen][dict]            string_dict.go:70-108
+ * A row that would leave its payload returns KNOX_E_RANGE (nothing on the device ever reads out of
+ * bounds).  The pool of one column is limited to 4 GiB (32-bit StringPool offsets).            */
+int knox_col_upload_string_containers(knox_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
+                                      size_t pack_rows, knox_col **out);
 /* Borrow memory that already lives on the device (16-byte aligned); never freed by knox.  */
 int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows,
                   knox_col **out);

@@ -1126,6 +1126,146 @@ KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint
     return rc;
 }
 
+// String containers -> one bytes (StringPool) column: payloads are uploaded as they are, the row
+// pointers are built on the device.
+//   [16] constant    string_const.go:51-70      [n][len][val]
+//   [17] fixed       string_fixed.go:59-82      [n][sz][n*sz bytes]
+//   [18] compact     string_compact.go:64-97    [ofs: uint32 container][len: uint32 container][buflen][buf]
+//   [19] dictionary  string_dict.go:70-108      [ofs][len][code: uint32 container][dictlen][dict]
+KNOX_API int knox_col_upload_string_containers(knox_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs, size_t pack_rows,
+                                               knox_col **out) {
+    if (!ctx || !out || (n_bufs && (!bufs || !lens))) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    struct Part {
+        uint8_t type;
+        size_t rows, n_entries;
+        const uint8_t *payload;
+        size_t payload_len;
+        uint64_t sz;                      // const: value length, fixed: element size
+        const uint8_t *c_ofs, *c_len, *c_code;
+        size_t l_ofs, l_len, l_code;
+    };
+    std::vector<Part> parts(n_bufs);
+    size_t total_rows = 0, total_pool = 0;
+    for (size_t i = 0; i < n_bufs; i++) {
+        const uint8_t *b = bufs[i];
+        const size_t len = lens[i];
+        if (!b || len < 2) return KNOX_E_INVALID;
+        Part &p = parts[i];
+        memset(&p, 0, sizeof p);
+        p.type = b[0];
+        size_t o = 1;
+        auto uv = [&](uint64_t *x) {
+            const int k = knox_uvarint(b + o, len - o, x);
+            if (k == 0) return false;
+            o += (size_t)k;
+            return true;
+        };
+        uint64_t n = 0, v = 0;
+        if (p.type == 16 || p.type == 17) {
+            if (!uv(&n) || !uv(&v)) return KNOX_E_INVALID;
+            const uint64_t bytes = p.type == 16 ? v : n * v;
+            if (v > 0xffffffffull || o + bytes > len) return KNOX_E_RANGE;
+            p.rows = (size_t)n;
+            p.sz = v;
+            p.payload = b + o;
+            p.payload_len = (size_t)bytes;
+        } else if (p.type == 18 || p.type == 19) {
+            size_t consumed = 0, rows = 0;
+            auto child = [&](const uint8_t **cp, size_t *cl, size_t *rows_out) {
+                if (o >= len) return (int)KNOX_E_RANGE;
+                int rc = container_measure(b + o, len - o, 4, false, rows_out, &consumed);
+                if (!rc && b[o] == 3) rc = runend_rows(ctx, b + o, len - o, 4, false, rows_out);
+                *cp = b + o;
+                *cl = consumed;
+                o += consumed;
+                return rc;
+            };
+            size_t n_ofs = 0, n_len = 0;
+            int rc = child(&p.c_ofs, &p.l_ofs, &n_ofs);
+            if (!rc) rc = child(&p.c_len, &p.l_len, &n_len);
+            if (rc) return rc;
+            if (n_ofs != n_len) return KNOX_E_INVALID;
+            p.n_entries = n_ofs;
+            rows = n_ofs;
+            if (p.type == 19) {
+                rc = child(&p.c_code, &p.l_code, &rows);
+                if (rc) return rc;
+                if (rows && p.n_entries == 0) return KNOX_E_INVALID;
+            }
+            if (!uv(&v) || o + v > len) return KNOX_E_RANGE;
+            p.rows = rows;
+            p.payload = b + o;
+            p.payload_len = (size_t)v;
+        } else {
+            return KNOX_E_UNSUPPORTED;
+        }
+        total_rows += p.rows;
+        total_pool += p.payload_len;
+    }
+    if (total_pool > 0xffffffffull) return KNOX_E_RANGE;  // StringPool offsets are 32 bit (pkg/stringx/pool.go:45-58)
+    int rc = col_new(ctx, KNOX_BYTES, total_rows, pack_rows, true, out);
+    if (rc) return rc;
+    knox_col *c = *out;
+    auto fail = [&](int code) {
+        knox_col_free(c);
+        *out = nullptr;
+        return code;
+    };
+    if (dev_malloc(ctx, (void **)&c->buf, total_pool + 256) != hipSuccess) return fail(KNOX_E_NOMEM);
+    c->buf_len = total_pool;
+    size_t row = 0, pool = 0;
+    for (size_t i = 0; i < n_bufs; i++) {
+        const Part &p = parts[i];
+        uint64_t *dst = (uint64_t *)c->dev + row;
+        rc = upload(ctx, c->buf + pool, p.payload, p.payload_len);
+        if (rc) return fail(rc);
+        hipError_t e = hipSuccess;
+        if (p.type == 16) {
+            e = launch_affine_fill(ctx->stream, 8, ((uint64_t)pool << 32) | p.sz, 0, p.rows, dst);
+        } else if (p.type == 17) {
+            e = launch_affine_fill(ctx->stream, 8, ((uint64_t)pool << 32) | p.sz, p.sz << 32, p.rows, dst);
+        } else {
+            void *d_ofs = nullptr, *d_len = nullptr, *d_code = nullptr;
+            if (dev_malloc(ctx, &d_ofs, p.n_entries * 4 + 64) != hipSuccess || dev_malloc(ctx, &d_len, p.n_entries * 4 + 64) != hipSuccess ||
+                (p.type == 19 && dev_malloc(ctx, &d_code, p.rows * 4 + 64) != hipSuccess))
+                rc = KNOX_E_NOMEM;
+            if (!rc) rc = container_decode(ctx, p.c_ofs, p.l_ofs, 4, false, d_ofs, p.n_entries);
+            if (!rc) rc = container_decode(ctx, p.c_len, p.l_len, 4, false, d_len, p.n_entries);
+            if (!rc && p.type == 19) rc = container_decode(ctx, p.c_code, p.l_code, 4, false, d_code, p.rows);
+            if (!rc) {
+                e = launch_str_ptr(ctx->stream, (const uint32_t *)d_ofs, (const uint32_t *)d_len, p.n_entries, (const uint32_t *)d_code, p.rows,
+                                   (uint64_t)pool, dst);
+                if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
+            }
+            if (d_ofs) hipFree(d_ofs);
+            if (d_len) hipFree(d_len);
+            if (d_code) hipFree(d_code);
+            if (rc) {
+                if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
+                return fail(rc);
+            }
+        }
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return fail(KNOX_E_HIP);
+        }
+        row += p.rows;
+        pool += p.payload_len;
+    }
+    // every (off, len) must lie inside the payload buffer: the match kernels never read out of bounds
+    rc = ensure(ctx, ctx->misc, 256);
+    if (rc) return fail(rc);
+    uint32_t *d_flag = (uint32_t *)((char *)ctx->misc.p + 32);
+    uint32_t bad = 0;
+    if (hipMemsetAsync(d_flag, 0, 4, ctx->stream) != hipSuccess ||
+        launch_ptr_check(ctx->stream, (const uint64_t *)c->dev, total_rows, total_pool, d_flag) != hipSuccess ||
+        hipMemcpyAsync(&bad, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(KNOX_E_HIP);
+    if (bad) return fail(KNOX_E_RANGE);
+    return KNOX_OK;
+}
+
 KNOX_API int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows, knox_col **out) {
     if (!ctx || !out || (n_rows && !device_ptr) || dtype == KNOX_BYTES) return KNOX_E_INVALID;
     if (((uintptr_t)device_ptr & 15) != 0) return KNOX_E_INVALID;

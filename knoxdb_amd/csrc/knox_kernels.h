@@ -189,6 +189,10 @@ hipError_t launch_alp_decode(hipStream_t s, int width, const void *enc, uint64_t
 hipError_t launch_patch_scatter(hipStream_t s, int width, const void *patches, const uint32_t *pos, uint64_t n_patch, uint64_t n, void *dst);
 // ALP-RD: bits = uint(left[i]) << shift | right[i]
 hipError_t launch_alprd_merge(hipStream_t s, int width, const uint16_t *left, const void *right, uint32_t shift, uint64_t n, void *dst);
+// string containers: StringPool rows from decoded (ofs, len[, code]) children; bounds check of a ptr vector
+hipError_t launch_str_ptr(hipStream_t s, const uint32_t *ofs, const uint32_t *len, uint64_t n_entries, const uint32_t *code, uint64_t n,
+                          uint64_t base, uint64_t *dst);
+hipError_t launch_ptr_check(hipStream_t s, const uint64_t *ptr, uint64_t n, uint64_t pool_len, uint32_t *flag /* pre-zeroed */);
 // dictionary / run-end containers over already decoded children
 hipError_t launch_dict_gather(hipStream_t s, int width, const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst);
 hipError_t launch_runend_expand(hipStream_t s, int width, const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst);

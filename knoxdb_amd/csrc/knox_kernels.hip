@@ -2203,6 +2203,44 @@ hipError_t launch_patch_scatter(hipStream_t s, int width, const void *patches, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// String containers -> StringPool rows (ptr = off << 32 | len into the column's payload buffer):
+// compact (string_compact.go:64-105) row i = buf[ofs[i] : ofs[i] + len[i]], dictionary
+// (string_dict.go:70-120) row i = dict[ofs[code[i]] : + len[code[i]]]; `base` = where this container's
+// payload starts inside the column's buffer.  ptr_check flags any row that leaves the buffer.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) str_ptr_kernel(const uint32_t *ofs, const uint32_t *len, uint64_t n_entries, const uint32_t *code,
+                                                         uint64_t n, uint64_t base, uint64_t *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = code ? (uint64_t)code[i] : i;
+        if (k >= n_entries) k = n_entries - 1;  // corrupt code: stay inside the entry table (ptr_check sees the rest)
+        dst[i] = ((base + ofs[k]) << 32) | (uint64_t)len[k];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) ptr_check_kernel(const uint64_t *ptr, uint64_t n, uint64_t pool_len, uint32_t *flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = ptr[i];
+        if ((p >> 32) + (p & 0xffffffffull) > pool_len) atomicOr(flag, 1u);
+    }
+}
+
+hipError_t launch_str_ptr(hipStream_t s, const uint32_t *ofs, const uint32_t *len, uint64_t n_entries, const uint32_t *code, uint64_t n,
+                          uint64_t base, uint64_t *dst) {
+    if (n == 0) return hipSuccess;
+    if (n_entries == 0) return hipErrorInvalidValue;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    KNOX_LAUNCH(str_ptr_kernel, (int)g, ofs, len, n_entries, code, n, base, dst);
+}
+
+hipError_t launch_ptr_check(hipStream_t s, const uint64_t *ptr, uint64_t n, uint64_t pool_len, uint32_t *flag) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    KNOX_LAUNCH(ptr_check_kernel, (int)g, ptr, n, pool_len, flag);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dictionary and run-end containers (internal/encode/int_dict.go:76-103, int_runend.go:84-120 and the
 // float twins float_dict.go:75-102, float_runend.go:80-110), children already decoded on the device:
 //   dictionary  value i = dict[codes[i]]           (codes: uint16)

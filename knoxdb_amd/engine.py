@@ -341,6 +341,16 @@ class Context:
               "knox_col_upload_raw_containers")
         return Column(self, h, dtype, keep=bufs, pack_rows=pack_rows)
 
+    def upload_string_containers(self, containers, pack_rows=0):
+        """One on-disk string container (bytes) per pack -> one bytes (StringPool) column."""
+        bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(1, len(bufs)))(*[b.size for b in bufs])
+        h = C.c_void_p()
+        check(self.L.knox_col_upload_string_containers(self.h, ptrs, lens, len(bufs), pack_rows, C.byref(h)),
+              "knox_col_upload_string_containers")
+        return Column(self, h, BlockType.Bytes, keep=bufs, pack_rows=pack_rows)
+
     def wrap(self, dtype, device_ptr, n_rows, pack_rows=0, keep=None):
         h = C.c_void_p()
         check(self.L.knox_col_wrap(self.h, int(dtype), C.c_void_p(device_ptr), n_rows, pack_rows, C.byref(h)))

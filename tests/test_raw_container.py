@@ -313,3 +313,59 @@ def test_gpu_ingest_of_alp_containers():
         with pytest.raises(K.KnoxError) as e:
             ctx.upload_raw_containers(BlockType.Float64, [bytes([8, 1, 2, 3])], 64)
         assert e.value.code == -5
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_of_string_containers():
+    """[16] constant, [17] fixed, [18] compact, [19] dictionary string containers (string_*.go) become one
+    StringPool column; checked through the bytes matchers against the oracle on the expected rows"""
+    import knoxdb_amd as K
+    from knoxdb_amd import And, Leaf
+    from knoxdb_amd.types import FilterMode
+    rng = np.random.default_rng(29)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(0, 14)), dtype=np.uint8)) for _ in range(40)] + [b"", b"zz"]
+    u32 = lambda a: bytes(O.raw_container_store(O.U32, np.asarray(a, dtype=np.uint32)))
+    bp32 = lambda a: bytes(O.bitpack_container_store(O.U32, np.asarray(a, dtype=np.uint32)))
+    # constant
+    c_const = bytes([16]) + O.put_uvarint(500) + O.put_uvarint(5) + b"hello"
+    rows_const = [b"hello"] * 500
+    # fixed
+    fx = [bytes(rng.integers(97, 100, size=4, dtype=np.uint8)) for _ in range(700)]
+    c_fixed = bytes([17]) + O.put_uvarint(700) + O.put_uvarint(4) + b"".join(fx)
+    # compact: rows reference slices of one buffer (shared / overlapping slices are allowed)
+    buf = b"".join(words)
+    starts = np.cumsum([0] + [len(w) for w in words])[:-1]
+    pick = rng.integers(0, len(words), size=900)
+    c_compact = bytes([18]) + bp32(starts[pick]) + u32([len(words[i]) for i in pick]) + O.put_uvarint(len(buf)) + buf
+    rows_compact = [words[i] for i in pick]
+    # dictionary: entries (ofs, len) + codes
+    codes = rng.integers(0, len(words), size=1100)
+    c_dict = bytes([19]) + u32(starts) + bp32([len(w) for w in words]) + bp32(codes) + O.put_uvarint(len(buf)) + buf
+    rows_dict = [words[i] for i in codes]
+    rows = rows_const + fx + rows_compact + rows_dict
+    n = len(rows)
+    with K.Context(0) as ctx:
+        col = ctx.upload_string_containers([c_const, c_fixed, c_compact, c_dict], 512)
+        assert col.rows == n
+        pool = np.frombuffer(b"".join(rows) + b"\\x00" * 8, dtype=np.uint8)
+        lens = np.array([len(r) for r in rows], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+        ptr = (offs << np.uint64(32)) | lens
+        for mode, a, b in ((FilterMode.Equal, b"hello", None), (FilterMode.Equal, b"", None), (FilterMode.Lt, words[5], None),
+                           (FilterMode.Ge, b"m", None), (FilterMode.Range, b"b", b"q"), (FilterMode.NotEqual, fx[0], None)):
+            bits = ctx.bits(n)
+            r = ctx.scan(And(Leaf(0, mode, a, b)), [col], bits_out=bits)
+            want, cnt = O.bytes_match(int(mode), ptr, pool, a, val2=b)
+            assert (bits.bytes() == want).all() and r.count == cnt, mode
+            bits.free()
+        bits = ctx.bits(n)
+        st = [words[3], b"hello", fx[7], b"absent"]
+        ctx.scan(And(Leaf(0, FilterMode.In, st)), [col], bits_out=bits)
+        assert (bits.bytes() == O.bytes_inset(False, ptr, pool, st)).all()
+        bits.free()
+        col.free()
+        # a compact container whose rows leave its buffer is refused
+        bad = bytes([18]) + u32([0, 5]) + u32([4, 400]) + O.put_uvarint(8) + b"abcdefgh"
+        with pytest.raises(K.KnoxError) as e:
+            ctx.upload_string_containers([bad], 64)
+        assert e.value.code == -7
