@@ -172,6 +172,11 @@ int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *cons
  * bounds).  The pool of one column is limited to 4 GiB (32-bit StringPool offsets).            */
 int knox_col_upload_string_containers(knox_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
                                       size_t pack_rows, knox_col **out);
+/* Int128 / Int256 containers ([8][X0][X1], [9][X0][X1][X2][X3]: internal/encode/int128.go:115-137,
+ * int256.go:121-150; the children are ordinary 64-bit integer containers of any type above) -> the
+ * stride layout knox_match_wide takes: out_limbs[0..n_limbs) receive one 8-byte column per limb.  */
+int knox_col_upload_wide_containers(knox_ctx *ctx, int n_limbs /* 2 | 4 */, const uint8_t *const *bufs, const size_t *lens,
+                                    size_t n_bufs, size_t pack_rows, knox_col **out_limbs);
 /* Borrow memory that already lives on the device (16-byte aligned); never freed by knox.  */
 int knox_col_wrap(knox_ctx *ctx, int dtype, void *device_ptr, size_t n_rows, size_t pack_rows,
                   knox_col **out);
@@ -199,7 +204,10 @@ int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, kn
 int knox_bits_free(knox_bits *b);
 size_t knox_bits_size(const knox_bits *b);
 void *knox_bits_device_ptr(const knox_bits *b);
-int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host);  /* (size+7)/8 bytes */
+int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host);
+/* Bitmap container of a bool column -> bits (size must equal the container's N): [20] zero, [21] one,
+ * [22] dense (internal/encode/bitmap.go:103-135); [23] sparse (roaring) returns KNOX_E_UNSUPPORTED. */
+int knox_bits_upload_bitmap_container(knox_ctx *ctx, knox_bits *bits, const uint8_t *buf, size_t len);  /* (size+7)/8 bytes */
 int knox_bits_download(knox_ctx *ctx, const knox_bits *b, uint8_t *host);
 int knox_bits_zero(knox_ctx *ctx, knox_bits *b);                         /* Bitset.Zero :533 */
 int knox_bits_one(knox_ctx *ctx, knox_bits *b);                          /* Bitset.One  :520 */

@@ -1126,6 +1126,42 @@ KNOX_API int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint
     return rc;
 }
 
+// Int128 / Int256 containers (internal/encode/int128.go:115-137, int256.go:121-150): [8][X0 of int64][X1 of uint64],
+// [9][X0][X1][X2][X3] -- the stride layout the wide matchers take: one 8-byte limb column per limb, X0 first.
+KNOX_API int knox_col_upload_wide_containers(knox_ctx *ctx, int n_limbs, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
+                                             size_t pack_rows, knox_col **out_limbs) {
+    if (!ctx || !out_limbs || (n_limbs != 2 && n_limbs != 4) || (n_bufs && (!bufs || !lens))) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    for (int l = 0; l < n_limbs; l++) out_limbs[l] = nullptr;
+    // split every container into its limb children
+    std::vector<std::vector<const uint8_t *>> cp(n_limbs, std::vector<const uint8_t *>(n_bufs));
+    std::vector<std::vector<size_t>> cl(n_limbs, std::vector<size_t>(n_bufs));
+    for (size_t i = 0; i < n_bufs; i++) {
+        if (!bufs[i] || lens[i] < 2 || bufs[i][0] != (n_limbs == 2 ? 8 : 9)) return bufs[i] && lens[i] >= 2 ? KNOX_E_UNSUPPORTED : KNOX_E_INVALID;
+        size_t o = 1;
+        for (int l = 0; l < n_limbs; l++) {
+            size_t n = 0, consumed = 0;
+            if (o >= lens[i]) return KNOX_E_RANGE;
+            const int rc = container_measure(bufs[i] + o, lens[i] - o, 8, false, &n, &consumed);
+            if (rc) return rc;
+            cp[l][i] = bufs[i] + o;
+            cl[l][i] = consumed;
+            o += consumed;
+        }
+    }
+    for (int l = 0; l < n_limbs; l++) {
+        const int rc = knox_col_upload_raw_containers(ctx, l == 0 ? KNOX_INT64 : KNOX_UINT64, cp[l].data(), cl[l].data(), n_bufs, pack_rows, &out_limbs[l]);
+        if (rc || (l && out_limbs[l]->n_rows != out_limbs[0]->n_rows)) {
+            for (int k = 0; k <= l; k++) {
+                if (out_limbs[k]) knox_col_free(out_limbs[k]);
+                out_limbs[k] = nullptr;
+            }
+            return rc ? rc : KNOX_E_INVALID;
+        }
+    }
+    return KNOX_OK;
+}
+
 // String containers -> one bytes (StringPool) column: payloads are uploaded as they are, the row
 // pointers are built on the device.
 //   [16] constant    string_const.go:51-70      [n][len][val]
@@ -1503,6 +1539,29 @@ KNOX_API int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host) 
     hipSetDevice(ctx->device);
     HIPCHK(ctx, hipMemsetAsync(b->dev, 0, b->cap_bytes, ctx->stream));
     return upload(ctx, b->dev, host, bits_bytes(b->size));
+}
+
+// Bitmap containers of bool columns (internal/encode/bitmap.go:103-135, :240-262): [20] zero, [21] one,
+// [22] dense = the Bitset bytes; [23] sparse is a serialized roaring bitmap (internal/xroar): host path.
+KNOX_API int knox_bits_upload_bitmap_container(knox_ctx *ctx, knox_bits *b, const uint8_t *buf, size_t len) {
+    if (!ctx || !b || !buf || len < 3) return KNOX_E_INVALID;
+    const uint8_t type = buf[0];
+    if (type < 20 || type > 23) return KNOX_E_INVALID;
+    size_t o = 1;
+    uint64_t n = 0, sz = 0;
+    int k = knox_uvarint(buf + o, len - o, &n);
+    if (k == 0) return KNOX_E_INVALID;
+    o += (size_t)k;
+    k = knox_uvarint(buf + o, len - o, &sz);
+    if (k == 0) return KNOX_E_INVALID;
+    o += (size_t)k;
+    if (n != b->size) return KNOX_E_INVALID;
+    if (o + sz > len) return KNOX_E_RANGE;
+    if (type == 20) return knox_bits_zero(ctx, b);
+    if (type == 21) return knox_bits_one(ctx, b);
+    if (type == 23) return KNOX_E_UNSUPPORTED;
+    if (sz < bits_bytes(b->size)) return KNOX_E_RANGE;
+    return knox_bits_upload(ctx, b, buf + o);
 }
 
 KNOX_API int knox_bits_download(knox_ctx *ctx, const knox_bits *b, uint8_t *host) {

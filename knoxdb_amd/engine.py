@@ -134,6 +134,11 @@ class Bits:
         check(_lib.lib().knox_bits_upload(self.ctx.h, self.h, _ptr(host) if host.size else None))
         return self
 
+    def upload_bitmap_container(self, container):
+        c = bytes(container)
+        check(_lib.lib().knox_bits_upload_bitmap_container(self.ctx.h, self.h, c, len(c)), "knox_bits_upload_bitmap_container")
+        return self
+
     def bytes(self, poison=0):
         n = (self.size + 7) >> 3
         out = np.full(n + poison, 0xFA, dtype=np.uint8)
@@ -340,6 +345,16 @@ class Context:
         check(self.L.knox_col_upload_raw_containers(self.h, int(dtype), ptrs, lens, len(bufs), pack_rows, C.byref(h)),
               "knox_col_upload_raw_containers")
         return Column(self, h, dtype, keep=bufs, pack_rows=pack_rows)
+
+    def upload_wide_containers(self, n_limbs, containers, pack_rows=0):
+        """Int128 / Int256 containers -> limb columns (most significant first) for match_wide"""
+        bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(1, len(bufs)))(*[b.size for b in bufs])
+        outs = (C.c_void_p * n_limbs)()
+        check(self.L.knox_col_upload_wide_containers(self.h, n_limbs, ptrs, lens, len(bufs), pack_rows, outs), "knox_col_upload_wide_containers")
+        return [Column(self, C.c_void_p(outs[l]), BlockType.Int64 if l == 0 else BlockType.Uint64, keep=bufs, pack_rows=pack_rows)
+                for l in range(n_limbs)]
 
     def upload_string_containers(self, containers, pack_rows=0):
         """One on-disk string container (bytes) per pack -> one bytes (StringPool) column."""

@@ -369,3 +369,47 @@ def test_gpu_ingest_of_string_containers():
         with pytest.raises(K.KnoxError) as e:
             ctx.upload_string_containers([bad], 64)
         assert e.value.code == -7
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_of_wide_and_bitmap_containers():
+    """[8]/[9] Int128 / Int256 containers -> limb columns for knox_match_wide (int128.go:115-137,
+    int256.go:121-150); [20]/[21]/[22] bitmap containers -> bool column bitsets (bitmap.go:103-135)"""
+    import knoxdb_amd as K
+    from knoxdb_amd.types import FilterMode
+    rng = np.random.default_rng(41)
+    n = 3000
+    with K.Context(0) as ctx:
+        for nl, tag in ((2, 8), (4, 9)):
+            limbs = [rng.integers(0, 3, size=n).astype(np.uint64) for _ in range(nl)]
+            limbs[0] = (limbs[0].astype(np.int64) - 1).view(np.uint64)
+            limbs[-1] = rng.integers(0, 1 << 40, size=n).astype(np.uint64)
+            kids = [bytes(O.bitpack_container_store(O.I64 if l == 0 else O.U64, limbs[l].view(np.int64) if l == 0 else limbs[l])) for l in range(nl)]
+            kids[1] = bytes(O.raw_container_store(O.U64, limbs[1]))  # mixed child encodings
+            c = bytes([tag]) + b"".join(kids)
+            cols = ctx.upload_wide_containers(nl, [c, c], n)
+            for l in range(nl):
+                assert (cols[l].download().view(np.uint64) == np.concatenate([limbs[l], limbs[l]])).all()
+            a = [int(x[n // 2]) for x in limbs]
+            bits, cnt = ctx.match_wide(cols, FilterMode.Le, a)
+            want, wcnt = O.cmp_wide(O.OPNAME["le"], [np.concatenate([x, x]) for x in limbs], a)
+            assert (bits.bytes() == want).all() and cnt == wcnt
+            for o in cols:
+                o.free()
+            bits.free()
+        m = 1003
+        dense = np.packbits(rng.random(m) < 0.4, bitorder="little")
+        for cont, want in ((bytes([20]) + O.put_uvarint(m) + O.put_uvarint(0), np.zeros_like(dense)),
+                           (bytes([21]) + O.put_uvarint(m) + O.put_uvarint(0), O.bits_one(m)),
+                           (bytes([22]) + O.put_uvarint(m) + O.put_uvarint(dense.size) + dense.tobytes(), dense)):
+            b = ctx.bits(m).upload_bitmap_container(cont)
+            assert (b.bytes(poison=32) == want).all()
+            # the bool matcher over it (match_bits.go): column == true
+            out = ctx.bits(m)
+            b.match_bool(FilterMode.Equal, True, out=out)
+            assert (out.bytes() == want).all()
+            b.free()
+            out.free()
+        with pytest.raises(K.KnoxError) as e:  # sparse = roaring: host path
+            ctx.bits(m).upload_bitmap_container(bytes([23]) + O.put_uvarint(m) + O.put_uvarint(4) + b"abcd")
+        assert e.value.code == -5
