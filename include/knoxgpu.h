@@ -323,6 +323,12 @@ int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_state *state
  * i128 loops add the popcount of the unmasked byte (int128.go:40-41), documented in DESIGN.md. */
 int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 | 4 */, int op, const uint64_t *a,
                     const uint64_t *b /* RANGE only */, const knox_bits *mask, knox_bits *bits, int64_t *count);
+/* Int128 / Int256 IN / NOT IN (i128InSetMatcher / i128NotInSetMatcher and the i256 twins,
+ * operator/filter/match_i128.go:318-430, match_i256.go): set = n_set values of n_limbs uint64, most
+ * significant first, any order, duplicates allowed.  Matching rows are OR-ed into bits (bits.Set,
+ * bits pre-zeroed by the caller); with a mask only mask-selected rows are tested.               */
+int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 | 4 */, int negate, const uint64_t *set,
+                        size_t n_set, const knox_bits *mask, knox_bits *bits);
 
 /* Matcher.MatchRangeVectors (operator/filter/match.go:66-71; numeric forms match_num.go:357-371,
  * 396-403, 429-434, 460-465, 491-496, 522-527, 573-588): vectorized zone-map test over the

@@ -120,6 +120,7 @@ SIGNATURES = {
     "knox_bits_placement": (_i, [_vp, C.POINTER(C.c_double), _pi]),
     "knox_bits_wrap": (_i, [_vp, _vp, _sz, _pp]),
     "knox_bits_alloc_for": (_i, [_vp, _sz, _vp, _pp]),
+    "knox_match_wide_set": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), _sz, _vp, _vp]),
     "knox_match_wide": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, C.POINTER(_i64)]),
     "knox_reduce_moments": (_i, [_vp, _vp, _vp, C.POINTER(AggState)]),
     "knox_reduce_buckets": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(AggState)]),

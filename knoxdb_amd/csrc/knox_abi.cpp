@@ -1695,6 +1695,45 @@ KNOX_API int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs,
     return KNOX_OK;
 }
 
+// Int128 / Int256 IN / NOT IN
+KNOX_API int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_limbs, int negate, const uint64_t *set, size_t n_set,
+                                 const knox_bits *mask, knox_bits *bits) {
+    if (!ctx || !limbs || !bits || (n_limbs != 2 && n_limbs != 4) || (n_set && !set) || n_set > 0xffffffffull) return KNOX_E_INVALID;
+    const size_t n_rows = limbs[0] ? limbs[0]->n_rows : 0;
+    for (int l = 0; l < n_limbs; l++)
+        if (!limbs[l] || limbs[l]->ctx != ctx || limbs[l]->n_rows != n_rows || limbs[l]->width != 8 || dtype_is_float(limbs[l]->dtype)) return KNOX_E_INVALID;
+    if (bits->size != n_rows || (mask && mask->size != n_rows)) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    // sorted unique keys in the kernel's order: unsigned lexicographic with the top limb's sign bit flipped
+    const size_t L = (size_t)n_limbs;
+    std::vector<size_t> idx(n_set);
+    for (size_t i = 0; i < n_set; i++) idx[i] = i;
+    auto key = [&](size_t i, size_t l) { return l == 0 ? set[i * L] ^ (1ull << 63) : set[i * L + l]; };
+    auto less = [&](size_t x, size_t y) {
+        for (size_t l = 0; l < L; l++)
+            if (key(x, l) != key(y, l)) return key(x, l) < key(y, l);
+        return false;
+    };
+    std::sort(idx.begin(), idx.end(), less);
+    idx.erase(std::unique(idx.begin(), idx.end(), [&](size_t x, size_t y) { return !less(x, y) && !less(y, x); }), idx.end());
+    std::vector<uint64_t> keys(idx.size() * L);
+    for (size_t k = 0; k < idx.size(); k++)
+        for (size_t l = 0; l < L; l++) keys[k * L + l] = key(idx[k], l);
+    int rc = ensure(ctx, ctx->bytes_val, keys.size() * 8 + 64);
+    if (rc) return rc;
+    if (!keys.empty()) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vector not retained
+    }
+    const uint64_t *lp[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int l = 0; l < n_limbs; l++) lp[l] = (const uint64_t *)limbs[l]->dev;
+    hipError_t e = launch_wide_inset(ctx->stream, n_limbs, negate != 0, lp, n_rows, (const uint64_t *)ctx->bytes_val.p, (uint32_t)idx.size(),
+                                     (uint8_t *)bits->dev, mask ? (const uint8_t *)mask->dev : nullptr);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    return KNOX_OK;
+}
+
 KNOX_API int knox_bits_popcount(knox_ctx *ctx, const knox_bits *b, int64_t *count) {
     if (!ctx || !b || !count) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);

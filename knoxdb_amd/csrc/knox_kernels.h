@@ -136,6 +136,9 @@ struct WideArgs {
     unsigned long long *count;  // pre-zeroed, nullable
 };
 hipError_t launch_wide_cmp(hipStream_t s, int n_limbs, int grid, const WideArgs &w);
+// wide IN / NOT IN: keys = sorted unique set, n_limbs words per value, top limb sign-flipped; matches OR-ed into bits
+hipError_t launch_wide_inset(hipStream_t s, int n_limbs, bool negate, const uint64_t *const *limbs, uint64_t n_rows, const uint64_t *keys,
+                             uint32_t n_keys, uint8_t *bits, const uint8_t *mask);
 
 // bitset combinators on 64-bit words (buffers padded to a multiple of 8 bytes)
 enum BitOp { BIT_AND = 0, BIT_ANDNOT = 1, BIT_OR = 2, BIT_XOR = 3, BIT_NEG = 4, BIT_COPY = 5, BIT_ONE = 6 };

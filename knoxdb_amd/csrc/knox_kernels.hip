@@ -1449,6 +1449,62 @@ __global__ void __launch_bounds__(kBlock) wide_cmp_kernel(const WideArgs w) {
     if (lane == 0 && cnt && w.count) atomicAdd(w.count, (unsigned long long)cnt);
 }
 
+// Int128 / Int256 IN / NOT IN (i128InSetMatcher / i128NotInSetMatcher.MatchVector, match_i128.go:318-430 and
+// the i256 twins): membership in a sorted set; keys[k * L + l] = limb l (most significant first, top limb
+// already sign-flipped) of set value k.  One lane per row, bits.Set semantics (OR), mask-selected rows only.
+template <int L>
+__global__ void __launch_bounds__(kBlock) wide_inset_kernel(int negate, const uint64_t *l0, const uint64_t *l1, const uint64_t *l2,
+                                                            const uint64_t *l3, uint64_t n_rows, const uint64_t *keys, uint32_t n_keys,
+                                                            uint8_t *bits, const uint8_t *mask) {
+    const uint64_t *limb[4] = {l0, l1, l2, l3};
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            uint64_t x[L];
+#pragma unroll
+            for (int l = 0; l < L; l++) x[l] = limb[l][row];
+            x[0] ^= 1ull << 63;
+            uint32_t lo = 0, hi = n_keys;
+            bool found = false;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t *k = keys + (uint64_t)mid * L;
+                int c = 0;  // key <=> x
+#pragma unroll
+                for (int l = 0; l < L; l++)
+                    if (c == 0 && k[l] != x[l]) c = k[l] < x[l] ? -1 : 1;
+                if (c == 0) { found = true; break; }
+                if (c < 0) lo = mid + 1; else hi = mid;
+            }
+            m = negate ? !found : found;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) byte &= mask[bi];
+                if (byte) bits[bi] |= byte;
+            }
+        }
+    }
+}
+
+hipError_t launch_wide_inset(hipStream_t s, int n_limbs, bool negate, const uint64_t *const *limbs, uint64_t n_rows, const uint64_t *keys,
+                             uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    if (n_limbs == 2) KNOX_LAUNCH(wide_inset_kernel<2>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], nullptr, nullptr, n_rows, keys, n_keys, bits, mask);
+    if (n_limbs == 4) KNOX_LAUNCH(wide_inset_kernel<4>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], limbs[2], limbs[3], n_rows, keys, n_keys, bits, mask);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_wide_cmp(hipStream_t s, int n_limbs, int grid, const WideArgs &w) {
     if (grid < 1) grid = 1;
     if (n_limbs == 2) KNOX_LAUNCH((wide_cmp_kernel<2>), grid, w);

@@ -456,6 +456,17 @@ class Context:
               "knox_match_wide")
         return out, cnt.value
 
+    def match_wide_set(self, limbs, values, negate=False, mask=None, bits=None):
+        """Int128 / Int256 IN / NOT IN: values = list of limb tuples (most significant first) -> Bits"""
+        n = len(limbs)
+        arr = (C.c_void_p * n)(*[c.h for c in limbs])
+        flat = [int(x) & (2**64 - 1) for v in values for x in v]
+        sv = (C.c_uint64 * max(1, len(flat)))(*flat)
+        out = bits if bits is not None else self.bits(limbs[0].rows)
+        check(self.L.knox_match_wide_set(self.h, arr, n, 1 if negate else 0, sv, len(values), mask.h if mask is not None else None, out.h),
+              "knox_match_wide_set")
+        return out
+
     def reduce(self, col, mask=None, row_base=0, moments=False):
         """Masked reduction of one column; moments=True adds the var/std second pass."""
         st = AggState()

@@ -99,3 +99,31 @@ def test_wide_extremes_and_errors(ctx):
         ctx.match_wide([cols[0], f], FilterMode.Lt, [0, 0])
     with pytest.raises(K.KnoxError):  # IN is not a wide mode
         ctx.match_wide(cols, FilterMode.In, [0, 0])
+
+
+@pytest.mark.parametrize("nl", [2, 4])
+def test_wide_in_not_in(ctx, nl):
+    """i128 / i256 InSet / NotInSet matchers (match_i128.go:318-430): membership, bits.Set semantics, mask"""
+    rng = np.random.default_rng(60 + nl)
+    n = 5000 + 3
+    limbs = [rng.integers(0, 3, size=n).astype(np.uint64) for _ in range(nl)]
+    limbs[0] = (limbs[0].astype(np.int64) - 1).view(np.uint64)  # signed top limb: -1, 0, 1
+    cols = upload_limbs(ctx, limbs)
+    rows = [tuple(int(l[i]) for l in limbs) for i in range(n)]
+    sets = [[rows[5], rows[77], rows[5], tuple([2**64 - 1] * nl)], [], [rows[i] for i in range(0, 200)], [tuple([7] * nl)]]
+    mask_h = rng.integers(0, 256, size=O.bitfield_len(n)).astype(np.uint8)
+    mask_h[-1] &= 0xFF >> (8 - n % 8)
+    mask = ctx.bits(n).upload(mask_h)
+    for st in sets:
+        member = np.array([r in set(st) for r in rows])
+        for negate in (False, True):
+            want = np.packbits(member != negate, bitorder="little")
+            got = ctx.match_wide_set(cols, st, negate=negate)
+            assert (got.bytes(poison=32) == want).all(), (nl, len(st), negate)
+            gm = ctx.match_wide_set(cols, st, negate=negate, mask=mask)
+            assert (gm.bytes() == (want & mask_h)).all()
+            got.free()
+            gm.free()
+    for o in cols:
+        o.free()
+    mask.free()
