@@ -330,6 +330,25 @@ int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 | 4 
 int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 | 4 */, int negate, const uint64_t *set,
                         size_t n_set, const knox_bits *mask, knox_bits *bits);
 
+/* ---- bit-packed columns scanned as they are ------------------------------------------------- *
+ * The reference compares on the packed form (internal/encode/bitpack/cmp_*.go behind
+ * BitpackContainer.Match*, int_bitpack.go); so does the device: the [4] containers of consecutive
+ * packs stay packed in HBM (log2/8 bytes per value instead of 8) and knox_packed_scan evaluates one
+ * numeric leaf on them -- selection bitset, count, wrapping sum, per-pack counts -- without ever
+ * materializing the values.  dtype KNOX_INT64 / KNOX_UINT64; pack_rows a multiple of 4096; every
+ * container but the last holds exactly pack_rows values.  Results are identical to
+ * knox_col_upload_raw_containers + knox_scan on the same containers.                          */
+typedef struct knox_packed knox_packed;
+int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
+                       size_t pack_rows, knox_packed **out);
+int knox_packed_free(knox_packed *p);
+size_t knox_packed_rows(const knox_packed *p);
+size_t knox_packed_bytes(const knox_packed *p); /* packed payload resident in HBM */
+/* op / a / b as in a knox_pred leaf.  bits_out nullable; pack_counts (host, n_packs) needs bits_out;
+ * sum_state (nullable unless want_sum) receives count + isum (knox_agg_value: Sum, Count).      */
+int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint64_t a, uint64_t b, int want_sum,
+                     knox_bits *bits_out, int64_t *pack_counts, int64_t *count, knox_agg_state *sum_state);
+
 /* Matcher.MatchRangeVectors (operator/filter/match.go:66-71; numeric forms match_num.go:357-371,
  * 396-403, 429-434, 460-465, 491-496, 522-527, 573-588): vectorized zone-map test over the
  * per-pack min / max statistics columns (one row per pack) -- which packs MAY contain a match.

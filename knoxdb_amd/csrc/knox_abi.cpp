@@ -2504,6 +2504,147 @@ KNOX_API int knox_scan(knox_ctx *ctx, const knox_pred *nodes, int n_nodes, knox_
     return knox_scan_collect(ctx, pack_counts, states, n_aggs, out);
 }
 
+// ---- resident bit-packed columns: scanned as they are --------------------------------------------------
+struct knox_packed {
+    knox_ctx *ctx;
+    int dtype;
+    size_t n_rows, pack_rows, n_packs;
+    uint64_t *d_words;
+    PackedPack *d_packs;
+    size_t words_bytes;
+};
+
+KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs, size_t pack_rows,
+                                knox_packed **out) {
+    if (!ctx || !out || !n_bufs || !bufs || !lens || (dtype != KNOX_INT64 && dtype != KNOX_UINT64)) return KNOX_E_INVALID;
+    if (pack_rows == 0 || (pack_rows & 4095) || n_bufs > 0xffffffffull) return KNOX_E_INVALID;  // whole 4096-value wave chunks
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    std::vector<PackedPack> packs(n_bufs);
+    std::vector<const uint8_t *> payload(n_bufs);
+    std::vector<size_t> payload_len(n_bufs);
+    size_t words = 0, rows = 0;
+    for (size_t i = 0; i < n_bufs; i++) {
+        if (!bufs[i] || lens[i] < 2) return KNOX_E_INVALID;
+        if (bufs[i][0] != 4) return KNOX_E_UNSUPPORTED;  // only bit-packed containers stay packed
+        size_t o = 1;
+        uint64_t minv = 0, l2 = 0, n = 0;
+        int k = knox_uvarint(bufs[i] + o, lens[i] - o, &minv);
+        if (k == 0) return KNOX_E_INVALID;
+        o += (size_t)k;
+        k = knox_uvarint(bufs[i] + o, lens[i] - o, &l2);
+        if (k == 0 || l2 > 64) return KNOX_E_INVALID;
+        o += (size_t)k;
+        k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
+        if (k == 0) return KNOX_E_INVALID;
+        o += (size_t)k;
+        const uint64_t sz = ((l2 * n + 63) & ~63ull) / 8;
+        if (o + sz > lens[i]) return KNOX_E_RANGE;
+        if (n > pack_rows || (i + 1 < n_bufs && n != pack_rows) || n == 0) return KNOX_E_INVALID;  // only the last pack may be short
+        packs[i] = {words, minv, (uint32_t)n, (uint32_t)l2};
+        payload[i] = bufs[i] + o;
+        payload_len[i] = (size_t)sz;
+        words += (size_t)sz / 8;
+        rows += (size_t)n;
+    }
+    knox_packed *p = new (std::nothrow) knox_packed();
+    if (!p) return KNOX_E_NOMEM;
+    p->ctx = ctx;
+    p->dtype = dtype;
+    p->n_rows = rows;
+    p->pack_rows = pack_rows;
+    p->n_packs = n_bufs;
+    p->d_words = nullptr;
+    p->d_packs = nullptr;
+    p->words_bytes = words * 8;
+    // + 64 bytes: the kernel reads one word past a field's word unconditionally
+    if (dev_malloc(ctx, (void **)&p->d_words, words * 8 + 64) != hipSuccess || dev_malloc(ctx, (void **)&p->d_packs, n_bufs * sizeof(PackedPack) + 64) != hipSuccess) {
+        if (p->d_words) hipFree(p->d_words);
+        delete p;
+        return KNOX_E_NOMEM;
+    }
+    int rc = KNOX_OK;
+    if (hipMemsetAsync((char *)p->d_words + words * 8, 0, 64, ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
+    for (size_t i = 0; i < n_bufs && !rc; i++) rc = upload(ctx, p->d_words + packs[i].word_off, payload[i], payload_len[i]);
+    if (!rc) rc = upload(ctx, p->d_packs, packs.data(), n_bufs * sizeof(PackedPack));
+    if (rc) {
+        hipFree(p->d_words);
+        hipFree(p->d_packs);
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_packed_free(knox_packed *p) {
+    if (!p) return KNOX_E_INVALID;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    if (p->d_words) hipFree(p->d_words);
+    if (p->d_packs) hipFree(p->d_packs);
+    delete p;
+    return KNOX_OK;
+}
+
+KNOX_API size_t knox_packed_rows(const knox_packed *p) { return p ? p->n_rows : 0; }
+KNOX_API size_t knox_packed_bytes(const knox_packed *p) { return p ? p->words_bytes : 0; }
+
+// one leaf (any numeric mode) + count [+ wrapping sum] [+ bitset] [+ per-pack counts] straight on the packed words
+KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint64_t a, uint64_t b, int want_sum, knox_bits *bits_out,
+                              int64_t *pack_counts, int64_t *count, knox_agg_state *sum_state) {
+    if (!ctx || !p || p->ctx != ctx || (want_sum && !sum_state)) return KNOX_E_INVALID;
+    if (bits_out && bits_out->size != p->n_rows) return KNOX_E_INVALID;
+    if (pack_counts && !bits_out) return KNOX_E_INVALID;  // per-pack counts come from the bitset
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    LeafHost lh;
+    int rc = make_leaf(p->dtype, op, a, b, lh);
+    if (rc) return rc;
+    const int grid_max = std::max(1, ctx->n_cus * 8);
+    rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid_max + 1) * 16);
+    if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (rc) return rc;
+    PackedScanArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.words = p->d_words;
+    pa.packs = p->d_packs;
+    pa.n_packs = (uint32_t)p->n_packs;
+    pa.groups_per_pack = (uint32_t)(p->pack_rows / 4096);
+    pa.pack_rows = p->pack_rows;
+    pa.n_rows = p->n_rows;
+    pa.lo = lh.lo;
+    pa.diff = lh.diff;
+    pa.key_xor = 0;  // integer leaves compare raw bits (the reference's unsigned-difference form)
+    pa.negate = lh.neg ? 1u : 0u;
+    pa.want_sum = want_sum ? 1u : 0u;
+    pa.bits = bits_out ? bits_out->dev : nullptr;
+    pa.partials = (AggPartial *)ctx->partials.p;
+    const uint64_t n_chunks = (uint64_t)p->n_packs * pa.groups_per_pack;
+    const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8;  // latency bound: 32 waves/CU (tools/bench_packed.py sweep)
+    const int grid = (int)std::min<uint64_t>((n_chunks + kWavesPerBlock - 1) / kWavesPerBlock, (uint64_t)std::min(grid_max, ctx->n_cus * blocks_per_cu));
+    prof_mark(ctx, 0);
+    hipError_t e = launch_packed_scan(ctx->stream, grid, pa);
+    prof_mark(ctx, 1);
+    if (e == hipSuccess)
+        e = launch_finalize(ctx->stream, 8, pa.partials, grid, nullptr, 0, p->dtype, (AggStateDev *)ctx->states.p, (int64_t *)((AggStateDev *)ctx->states.p + 16));
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    if (pack_counts) {
+        rc = ensure(ctx, ctx->pack_counts, p->n_packs * 8 + 64);
+        if (rc) return rc;
+        e = launch_popcount_segments(ctx->stream, bits_out->dev, p->n_rows, p->pack_rows, (int64_t *)ctx->pack_counts.p, p->n_packs);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+        rc = download(ctx, pack_counts, ctx->pack_counts.p, p->n_packs * 8);
+        if (rc) return rc;
+    }
+    AggStateDev st;
+    HIPCHK(ctx, hipMemcpyAsync(&st, ctx->states.p, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) *count = st.count;
+    if (sum_state) memcpy(sum_state, &st, sizeof st);
+    return KNOX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // zone-map test over the statistics columns (Matcher.MatchRangeVectors)
 // ------------------------------------------------------------------------------------------------

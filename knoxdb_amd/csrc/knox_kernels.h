@@ -177,6 +177,30 @@ hipError_t launch_bloom_build_bytes(hipStream_t s, const uint64_t *ptr, const ui
 hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows,
                               uint8_t *filters, const uint64_t *offsets);
 
+// ---- scan directly on bit-packed containers (no materialization) -----------------------------------------
+struct PackedPack {        // one bit-packed container ([4][For][log2][N][words], int_bitpack.go:93-133) resident in HBM
+    uint64_t word_off;     // first 64-bit word of the pack inside the words buffer
+    uint64_t minv;         // For
+    uint32_t n;            // values
+    uint32_t log2;         // bits per value
+};
+struct PackedScanArgs {
+    const uint64_t *words;
+    const PackedPack *packs;
+    uint32_t n_packs;
+    uint32_t groups_per_pack;  // pack_rows / 4096
+    uint64_t pack_rows;
+    uint64_t n_rows;
+    uint64_t lo, diff;         // key space of the 8-byte column type: hit = U(key(v) - lo) <= diff
+    uint64_t key_xor;          // sign flip for signed columns (0 for unsigned)
+    uint32_t negate;           // 1: hit = !in_range
+    uint32_t want_sum;
+    uint64_t *bits;            // nullable
+    AggPartial *partials;      // [grid]
+};
+// one wave per 4096 values: lane l evaluates values l, l + 64, ...; a wave64 ballot IS the bitset word
+hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a);
+
 // bit-packed container payload -> materialized values: out[i] = T((stream >> i*log2) & mask) + minv
 hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
                                  uint64_t n_values, void *dst);

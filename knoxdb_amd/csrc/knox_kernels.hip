@@ -29,6 +29,7 @@
 //   * float sums are double-double (error-free TwoSum) so the rounded result is the exact
 //     sum rounded once; integer sums wrap mod 2^64 exactly like Go.
 #include "knox_kernels.h"
+#include <utility>
 
 #define KNOX_HD __host__ __device__
 #define KNOX_XXH3_CONST __constant__
@@ -2137,6 +2138,84 @@ hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packe
     case 1: KNOX_LAUNCH((bitpack_decode_kernel<1>), (int)g, packed, n_words, log2, minv, n_values, dst);
     default: return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scan on bit-packed containers without materializing them (the reference compares on the packed
+// form too: internal/encode/bitpack/cmp_*.go, int_bitpack.go Match*).  Value i of a pack is the
+// log2-bit field at bit i*log2 of its word stream, plus For (bitpack/decode.go:56-74).
+//
+// Work shape: one wave per 4096 values; in step t lane l evaluates value t*64 + l, so
+//   * the wave64 ballot of the hits IS the bitset word of rows [t*64, t*64+64) -- no bit shuffling;
+//     lane t parks word t and after 64 steps the wave stores 64 words = 512 contiguous bytes;
+//   * (l*log2) & 63 -- the field's shift -- is the same in every step (t*64*log2 is a multiple of 64
+//     bits), only the word index advances by log2 per step; the lanes of a step read log2 + 1
+//     consecutive words: one cache-line-sized access.
+// Traffic: log2/8 + 1/8 bytes per row instead of 8 + 1/8.
+// ---------------------------------------------------------------------------------------------
+typedef uint64_t u64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool SUM>
+__global__ void __launch_bounds__(kBlock) packed_scan_kernel(const PackedScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_chunks = (uint64_t)a.n_packs * a.groups_per_pack;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint64_t n_words_bits = (a.n_rows + 63) >> 6;
+    Acc acc;
+    acc.init();
+    uint64_t cnt = 0;
+    for (uint64_t wc = wave0; wc < n_chunks; wc += n_waves) {
+        const uint32_t pack = (uint32_t)(wc / a.groups_per_pack);
+        const uint64_t base = (wc % a.groups_per_pack) * 4096;  // first value of the chunk inside its pack
+        const PackedPack hp = a.packs[pack];
+        const uint32_t b = hp.log2;
+        const uint64_t mask = b >= 64 ? ~0ull : ((1ull << b) - 1);
+        const uint32_t sh = (uint32_t)(lane * b) & 63u, wl = (uint32_t)(lane * b) >> 6;
+        const uint64_t *wp = a.words + hp.word_off + (base >> 6) * b + wl;
+        const uint64_t c0 = (hp.minv ^ a.key_xor) - a.lo;  // key(field + For) - lo = field + c0 when no carry crosses the sign flip:
+                                                            // the flip is an xor of the top bit = an add of 2^63 mod 2^64, so it commutes
+        // lane t ends up holding the ballot of step t
+        uint32_t my_lo = 0, my_hi = 0;
+        uint64_t sum = 0;  // of the FIELDS of the hits; For is added once per chunk: + For * hits
+        const bool full = base + 4096 <= hp.n;  // only the last chunk of a short last pack needs the row bound
+        // 8 steps per round: the eight 16-byte loads are issued before any of them is consumed
+#pragma unroll 1
+        for (uint32_t t0 = 0; t0 < 64; t0 += 8) {
+            u64x2u w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = __builtin_nontemporal_load((const u64x2u *)(wp + (uint64_t)(t0 + k) * b));
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t t = t0 + k;
+                uint64_t field = w[k].x >> sh;
+                if (sh != 0) field |= w[k].y << (64 - sh);
+                field &= mask;
+                bool hit = ((field + c0) <= a.diff) != (a.negate != 0);
+                if (!full) hit = hit && (base + t * 64 + (uint32_t)lane < hp.n);
+                const uint64_t word = __ballot(hit);
+                // lane t parks the ballot of step t (v_writelane would do it in two instructions, but it takes
+                // the lane select from m0 / an inline constant only: measured slower and fragile as inline asm)
+                my_lo = lane == (int)t ? (uint32_t)word : my_lo;
+                my_hi = lane == (int)t ? (uint32_t)(word >> 32) : my_hi;
+                if constexpr (SUM) sum += hit ? field : 0ull;
+            }
+        }
+        const uint64_t myword = ((uint64_t)my_hi << 32) | my_lo;
+        const uint64_t wi = (((uint64_t)pack * a.pack_rows + base) >> 6) + (uint64_t)lane;
+        if (a.bits != nullptr && wi < n_words_bits) __builtin_nontemporal_store(myword, a.bits + wi);
+        const uint64_t hits = (uint64_t)__builtin_popcountll(myword);  // lane t: hits of step t
+        cnt += hits;
+        if constexpr (SUM) acc.isum += sum + hp.minv * hits;  // wrapping: sum over lanes = sum of fields + For * all hits
+    }
+    acc.count = cnt;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+    if (a.want_sum) KNOX_LAUNCH(packed_scan_kernel<true>, grid, a);
+    KNOX_LAUNCH(packed_scan_kernel<false>, grid, a);
 }
 
 // ---------------------------------------------------------------------------------------------

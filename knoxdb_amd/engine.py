@@ -346,6 +346,15 @@ class Context:
               "knox_col_upload_raw_containers")
         return Column(self, h, dtype, keep=bufs, pack_rows=pack_rows)
 
+    def packed_upload(self, dtype, containers, pack_rows):
+        """bit-packed containers of consecutive packs, kept packed in HBM (knox_packed_upload)"""
+        bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(1, len(bufs)))(*[b.size for b in bufs])
+        h = C.c_void_p()
+        check(self.L.knox_packed_upload(self.h, int(dtype), ptrs, lens, len(bufs), pack_rows, C.byref(h)), "knox_packed_upload")
+        return Packed(self, h, BlockType(dtype), len(bufs))
+
     def upload_wide_containers(self, n_limbs, containers, pack_rows=0):
         """Int128 / Int256 containers -> limb columns (most significant first) for match_wide"""
         bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
@@ -508,6 +517,38 @@ class Context:
         h = C.c_void_p()
         check(self.L.knox_bloom_build_u64(self.h, col.h, factor, C.byref(h)))
         return Bloom(self, h)
+
+
+class Packed:
+    """A column of bit-packed containers resident in HBM, scanned without materialization."""
+
+    def __init__(self, ctx, handle, dtype, n_packs):
+        self.ctx, self.h, self.dtype, self.n_packs = ctx, handle, dtype, n_packs
+
+    @property
+    def rows(self):
+        return _lib.lib().knox_packed_rows(self.h)
+
+    @property
+    def nbytes(self):
+        return _lib.lib().knox_packed_bytes(self.h)
+
+    def scan(self, mode, a, b=None, want_sum=False, bits_out=None, pack_counts=False):
+        """-> (count, sum state or None, per-pack counts or None)"""
+        av = value_bits(self.dtype, a)
+        bv = value_bits(self.dtype, b) if b is not None else 0
+        cnt = C.c_int64()
+        st = AggState()
+        pc = np.zeros(self.n_packs, dtype=np.int64) if pack_counts else None
+        check(_lib.lib().knox_packed_scan(self.ctx.h, self.h, int(mode), av, bv, 1 if want_sum else 0, bits_out.h if bits_out is not None else None,
+                                          pc.ctypes.data_as(C.POINTER(C.c_int64)) if pc is not None else None, C.byref(cnt), C.byref(st)),
+              "knox_packed_scan")
+        return cnt.value, (st if want_sum else None), pc
+
+    def free(self):
+        if self.h:
+            check(_lib.lib().knox_packed_free(self.h))
+            self.h = None
 
 
 class Bloom:
