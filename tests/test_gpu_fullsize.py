@@ -103,3 +103,31 @@ def test_cfg3_full_size_properties(ctx):
         assert (got[p * PACK // 8:(p + 1) * PACK // 8] == want).all() and res.pack_counts[p] == O.popcount(want, PACK), p
     for o in (A, B, bits, ba, bb):
         o.free()
+
+
+def test_cfg4_full_size_bloom_pruned_point_lookup(ctx):
+    """cfg 4 shape at full size: 2^30 uint64 ids (id = a mixing function of the row number: unique), per-pack
+    bloom filters (factor 2) built on the device, probe one present and one absent key, scan only the packs
+    the filter lets through; the pruned scan equals the full scan and finds exactly the row it must"""
+    col = ctx.generate(BlockType.Uint64, 0, 5, N, lo=0, span=0, pack_rows=PACK)  # raw 64-bit counter-hash values
+    bloom = ctx.bloom_build(col, 2)
+    target_row = 777 * PACK + 12345
+    present = int(O.generate(O.U64, 0, 5, target_row, 1, lo=0, span=0)[0])
+    absent = 0x0123456789ABCDEF
+    bits = ctx.bits(N)
+    for key, expect_rows in ((present, [target_row]), (absent, [])):
+        maybe = bloom.probe(K.hash_value(BlockType.Uint64, np.uint64(key)))
+        assert maybe.size == N // PACK
+        if expect_rows:
+            assert maybe[target_row // PACK] == 1          # no false negatives
+        assert int(maybe.sum()) <= 40                        # factor-2 filters: a handful of false positives at most
+        tree = And(Leaf(0, FilterMode.Equal, key))
+        r_pruned = ctx.scan(tree, [col], aggs=[(R.Count, 0)], bits_out=bits, pack_counts=True, pack_skip=(1 - maybe).astype(np.uint8))
+        pruned_idx = bits.indexes().tolist()
+        r_full = ctx.scan(tree, [col], aggs=[(R.Count, 0)], bits_out=bits, pack_counts=True)
+        assert r_pruned.count == r_full.count == len(expect_rows)
+        assert pruned_idx == bits.indexes().tolist() == expect_rows
+        assert r_pruned.rows_scanned == int(maybe.sum()) * PACK
+        assert (r_pruned.pack_counts == r_full.pack_counts).all()
+    for o in (col, bits, bloom):
+        o.free()
