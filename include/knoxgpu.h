@@ -335,7 +335,7 @@ int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 
  * BitpackContainer.Match*, int_bitpack.go); so does the device: the [4] containers of consecutive
  * packs stay packed in HBM (log2/8 bytes per value instead of 8) and knox_packed_scan evaluates one
  * numeric leaf on them -- selection bitset, count, wrapping sum, per-pack counts -- without ever
- * materializing the values.  dtype KNOX_INT64 / KNOX_UINT64; pack_rows a multiple of 4096; every
+ * materializing the values.  Any integer dtype; pack_rows a multiple of 4096; every
  * container but the last holds exactly pack_rows values.  Results are identical to
  * knox_col_upload_raw_containers + knox_scan on the same containers.                          */
 typedef struct knox_packed knox_packed;

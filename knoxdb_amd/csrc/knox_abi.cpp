@@ -2516,7 +2516,7 @@ struct knox_packed {
 
 KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs, size_t pack_rows,
                                 knox_packed **out) {
-    if (!ctx || !out || !n_bufs || !bufs || !lens || (dtype != KNOX_INT64 && dtype != KNOX_UINT64)) return KNOX_E_INVALID;
+    if (!ctx || !out || !n_bufs || !bufs || !lens || dtype_width(dtype) == 0 || dtype_is_float(dtype) || dtype == KNOX_BYTES) return KNOX_E_INVALID;
     if (pack_rows == 0 || (pack_rows & 4095) || n_bufs > 0xffffffffull) return KNOX_E_INVALID;  // whole 4096-value wave chunks
     *out = nullptr;
     hipSetDevice(ctx->device);
@@ -2616,6 +2616,7 @@ KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint6
     pa.lo = lh.lo;
     pa.diff = lh.diff;
     pa.key_xor = 0;  // integer leaves compare raw bits (the reference's unsigned-difference form)
+    pa.wmask = wmask(dtype_width(p->dtype));
     pa.negate = lh.neg ? 1u : 0u;
     pa.want_sum = want_sum ? 1u : 0u;
     pa.bits = bits_out ? bits_out->dev : nullptr;
@@ -2627,7 +2628,7 @@ KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint6
     hipError_t e = launch_packed_scan(ctx->stream, grid, pa);
     prof_mark(ctx, 1);
     if (e == hipSuccess)
-        e = launch_finalize(ctx->stream, 8, pa.partials, grid, nullptr, 0, p->dtype, (AggStateDev *)ctx->states.p, (int64_t *)((AggStateDev *)ctx->states.p + 16));
+        e = launch_finalize(ctx->stream, dtype_width(p->dtype), pa.partials, grid, nullptr, 0, p->dtype, (AggStateDev *)ctx->states.p, (int64_t *)((AggStateDev *)ctx->states.p + 16));
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     if (pack_counts) {
         rc = ensure(ctx, ctx->pack_counts, p->n_packs * 8 + 64);

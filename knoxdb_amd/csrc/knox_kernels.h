@@ -193,6 +193,7 @@ struct PackedScanArgs {
     uint64_t n_rows;
     uint64_t lo, diff;         // key space of the 8-byte column type: hit = U(key(v) - lo) <= diff
     uint64_t key_xor;          // sign flip for signed columns (0 for unsigned)
+    uint64_t wmask;            // value mask of the column type (2^(8W) - 1): T wraps, and so does the compare
     uint32_t negate;           // 1: hit = !in_range
     uint32_t want_sum;
     uint64_t *bits;            // nullable

@@ -2191,7 +2191,7 @@ __global__ void __launch_bounds__(kBlock) packed_scan_kernel(const PackedScanArg
                 uint64_t field = w[k].x >> sh;
                 if (sh != 0) field |= w[k].y << (64 - sh);
                 field &= mask;
-                bool hit = ((field + c0) <= a.diff) != (a.negate != 0);
+                bool hit = (((field + c0) & a.wmask) <= a.diff) != (a.negate != 0);
                 if (!full) hit = hit && (base + t * 64 + (uint32_t)lane < hp.n);
                 const uint64_t word = __ballot(hit);
                 // lane t parks the ballot of step t (v_writelane would do it in two instructions, but it takes

@@ -85,5 +85,41 @@ def test_packed_upload_rejects_what_it_cannot_scan(ctx):
     with pytest.raises(K.KnoxError) as e:   # raw containers do not stay packed
         ctx.packed_upload(BlockType.Int64, [O.raw_container_store(O.I64, x)], 8192)
     assert e.value.code == -5
-    with pytest.raises(K.KnoxError):   # 4-byte columns: decode path
-        ctx.packed_upload(BlockType.Int32, [bp], 8192)
+    with pytest.raises(K.KnoxError):   # float columns are never bit-packed
+        ctx.packed_upload(BlockType.Float64, [bp], 8192)
+
+
+@pytest.mark.parametrize("bt,dt,npdt", [(BlockType.Int32, O.I32, np.int32), (BlockType.Uint32, O.U32, np.uint32), (BlockType.Int16, O.I16, np.int16),
+                                        (BlockType.Uint16, O.U16, np.uint16), (BlockType.Int8, O.I8, np.int8), (BlockType.Uint8, O.U8, np.uint8)])
+def test_packed_scan_narrow_types(ctx, bt, dt, npdt):
+    """narrower integer columns: value = T(field + For) wraps in T and so does the compare (signed minimum
+    as For, full-range containers)"""
+    rng = np.random.default_rng(500 + int(bt))
+    info = np.iinfo(npdt)
+    pack, last = 4096, 1000
+    for spread in (3, info.max // 2 if info.min < 0 else info.max // 3, None):
+        packs = []
+        for n in (pack, pack, last):
+            if spread is None:
+                v = rng.integers(info.min, info.max, size=n, endpoint=True).astype(npdt)
+                v[0], v[-1] = info.min, info.max
+            else:
+                v = (info.min + rng.integers(0, spread + 1, size=n)).astype(npdt)
+            packs.append(v)
+        conts = [O.bitpack_container_store(dt, p) for p in packs]
+        whole = np.concatenate(packs)
+        n = whole.size
+        pk = ctx.packed_upload(bt, conts, pack)
+        col = ctx.upload_raw_containers(bt, conts, pack)
+        srt = np.sort(whole)
+        a, b = srt[n // 4].item(), srt[3 * n // 4].item()
+        for mode in MODES:
+            bits_p = ctx.bits(n)
+            cnt, st, pc = pk.scan(mode, a, b if mode == FilterMode.Range else None, want_sum=True, bits_out=bits_p, pack_counts=True)
+            res = ctx.scan(And(Leaf(0, mode, a, b if mode == FilterMode.Range else None)), [col], aggs=[(R.Sum, 0)])
+            want, wcnt = O.cmp(dt, int(mode), whole, a, b if mode == FilterMode.Range else 0)
+            assert (bits_p.bytes(poison=32) == want).all() and cnt == wcnt == res.count, (bt, mode, spread)
+            assert K.agg_value(st, R.Sum)[0] == res.value(0)[0], (bt, mode, spread)
+            bits_p.free()
+        pk.free()
+        col.free()
