@@ -2,6 +2,8 @@
 result ring, borrowed device memory on a caller's stream, error codes instead of crashes."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -210,6 +212,7 @@ def test_two_threads_two_contexts_scan_concurrently():
             assert cnt == pc == bc == int(m.sum()) and s == int(data[i][m].sum()), (i, rep)
 
 
+@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
 def test_placement_aware_allocation_is_transparent():
     """Large owned columns are probed at allocation (knox_ctx_set_placement): results are the same
     with it on or off, slow candidates are held and come back when it is switched off / at close."""
@@ -264,6 +267,7 @@ def test_pinned_host_memory_round_trip(ctx):
     ctx.host_free(back)
 
 
+@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
 def test_placement_search_with_spacers_returns_everything(monkeypatch):
     """the write-buffer search parks 4 GiB spacers after every second miss and must give all of them
     (and every rejected candidate) back; KNOX_PLACEMENT_FORCE_MISS drives it through that path"""
