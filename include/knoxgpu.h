@@ -65,7 +65,11 @@ enum knox_op {
 /* ---- reducer functions (internal/reducer/reducer.go:25-45) -------------------------- */
 enum knox_reducer {
     KNOX_R_SUM = 0, KNOX_R_FIRST = 1, KNOX_R_LAST = 2, KNOX_R_MIN = 3, KNOX_R_MAX = 4,
-    KNOX_R_MEAN = 5, KNOX_R_VAR = 6, KNOX_R_STD = 7, KNOX_R_COUNT = 8
+    KNOX_R_MEAN = 5, KNOX_R_VAR = 6, KNOX_R_STD = 7, KNOX_R_COUNT = 8,
+    /* join reducers (reducer.go:432-731): rows sharing one raw timestamp are summed before the
+     * reducer proper sees them; only knox_reduce_buckets_sequential evaluates these           */
+    KNOX_R_FIRST_JOIN = 9, KNOX_R_LAST_JOIN = 10, KNOX_R_MIN_JOIN = 11, KNOX_R_MAX_JOIN = 12,
+    KNOX_R_MEAN_JOIN = 13, KNOX_R_VAR_JOIN = 14, KNOX_R_STD_JOIN = 15
 };
 
 typedef struct knox_ctx knox_ctx;   /* device + stream + workspace                       */
@@ -386,6 +390,16 @@ int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mas
 int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                         const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                         size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states);
+
+/* The literal form of the same: window k's reducer is the reference's own, applied row by row
+ * (one lane per window), so Value() is bit-exact for EVERY reducer -- Welford mean / var / std
+ * and the join reducers KNOX_R_*_JOIN (reducer.go:432-731; join = the row's raw timestamp equals
+ * the previous selected row's, pkg/series/series.go:200-203) included.  values_out holds
+ * n_buckets values of the column's type, seen_out[k] = Value()'s ok (0: no reducer / no group).
+ * Same ordering contract and flags bit0 as knox_reduce_buckets.                              */
+int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
+                                   const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
+                                   size_t n_buckets, int func, int flags, void *values_out, uint8_t *seen_out);
 
 /* Literal sequential reducer (one lane, row order) -- reproduces reducer.go bit for bit,
  * including Welford mean/var; slow, used for parity tests on small inputs.                  */

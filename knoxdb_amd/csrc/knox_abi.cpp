@@ -2876,6 +2876,48 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
     return download(ctx, states, base + off_states, n_buckets * sizeof(AggStateDev));
 }
 
+KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask,
+                                            int64_t t_from, int64_t step, size_t n_buckets, int func, int flags, void *values_out,
+                                            uint8_t *seen_out) {
+    if (!ctx || !time_col || !value_col || !values_out || !seen_out || step <= 0 || n_buckets == 0 || n_buckets > (1u << 26)) return KNOX_E_INVALID;
+    if (time_col->dtype != KNOX_INT64 || value_col->dtype == KNOX_BYTES || time_col->n_rows != value_col->n_rows) return KNOX_E_INVALID;
+    if (mask && mask->size != value_col->n_rows) return KNOX_E_INVALID;
+    if (func < 0 || func > KNOX_R_STD_JOIN) return KNOX_E_INVALID;
+    if ((__int128)t_from + (__int128)step * (__int128)n_buckets > (__int128)INT64_MAX) return KNOX_E_RANGE;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    const size_t n_rows = value_col->n_rows;
+    const size_t off_vals = ((n_buckets + 2) * 8 + 63) & ~(size_t)63;
+    const size_t off_seen = off_vals + ((n_buckets * 8 + 63) & ~(size_t)63);
+    int rc = ensure(ctx, ctx->misc, 256);
+    if (!rc) rc = ensure(ctx, ctx->idx_scratch, off_seen + n_buckets + 64);
+    if (rc) return rc;
+    uint32_t *d_flag = (uint32_t *)((char *)ctx->misc.p + 32);
+    if (!(flags & 1)) {
+        HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    }
+    char *base = (char *)ctx->idx_scratch.p;
+    uint64_t *d_start = (uint64_t *)base;
+    hipError_t e = launch_bucket_bounds(ctx->stream, (const int64_t *)time_col->dev, n_rows, t_from, step, n_buckets, d_start);
+    // the window bounds never leave the device: the reducer lanes read them in place
+    if (e == hipSuccess)
+        e = launch_bucket_sequential(ctx->stream, value_col->dtype, func, (const int64_t *)time_col->dev, value_col->dev,
+                                     mask ? (const uint8_t *)mask->dev : nullptr, d_start, (uint32_t)n_buckets, base + off_vals,
+                                     (uint8_t *)(base + off_seen));
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    uint32_t unsorted = 0;
+    if (!(flags & 1)) {
+        HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (unsorted) return KNOX_E_UNSUPPORTED;
+    }
+    rc = download(ctx, values_out, base + off_vals, n_buckets * (size_t)value_col->width);
+    if (!rc) rc = download(ctx, seen_out, base + off_seen, n_buckets);
+    return rc;
+}
+
 KNOX_API int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const knox_bits *mask, int func, void *value_out, int *seen,
                                     int64_t *row) {
     if (!ctx || !col || !value_out || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;

@@ -230,6 +230,8 @@ hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);
 
 // literal sequential reducer (one lane)
+hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
+                                    const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen);
 hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows,
                                     const uint8_t *mask, uint64_t *out3 /* value bits, seen, row */);
 

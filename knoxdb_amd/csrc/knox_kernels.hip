@@ -2575,6 +2575,111 @@ __global__ void reduce_seq_kernel(int func, const T *src, uint64_t n, const uint
     out[2] = row;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Literal reducers per time window: one lane owns one window [start[k], start[k+1]) and applies
+// the reference's reducer statement by statement in row order -- plain reducers (reducer.go:
+// 130-429) and the join reducers (reducer.go:432-731), whose `join` argument is "this row's raw
+// timestamp equals the previous streamed row's" (pkg/series/series.go:200-203).  Equal raw
+// timestamps always share a window, so the flag is window-local.  Bit-exact with the reference
+// for every reducer (Welford included); throughput is one row per lane-step, which is what the
+// mode is for: parity and small / many-window series, not the 1B-row scan.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SeqJoinRed {
+    bool seen = false, done = false;
+    T v = 0, j = 0;
+    uint64_t n = 0;
+    double mean = 0, m2 = 0;
+
+    __device__ inline void welford(int func, T x) {
+        n++;
+        const double d = (double)x - mean;
+        mean += d / (double)n;
+        if (func != 5 && func != 13) m2 += d * ((double)x - mean);
+    }
+    __device__ inline void push_join(int func, T x, bool join) {
+        if (func == 10) { seen = true; v = join ? (T)(v + x) : x; return; }          // LastJoin :476-483
+        if (!seen) { seen = true; if (func == 9) v = x; else j = x; return; }        // r.t.IsZero()
+        switch (func) {
+        case 9: if (join && !done) v = (T)(v + x); else done = true; break;          // FirstJoin :447-457
+        case 12: if (join) j = (T)(j + x); else { if (v < j) v = j; j = x; } break;  // MaxJoin :504-518
+        case 11: if (join) j = (T)(j + x); else { if (j < v) v = j; j = x; } break;  // MinJoin :541-555
+        default: if (join) j = (T)(j + x); else { welford(func, j); j = x; } break;  // Mean/Var/StdJoin :578-731
+        }
+    }
+    __device__ inline void push(int func, T x) {
+        switch (func) {
+        case 8: v = (T)(v + 1); break;
+        case 0: v = (T)(v + x); break;
+        case 1: if (!seen) v = x; break;
+        case 2: v = x; break;
+        case 4: if (!seen || v < x) v = x; break;
+        case 3: if (!seen || v > x) v = x; break;
+        default: welford(func, x); break;
+        }
+        seen = true;
+    }
+    // Reducer.Value(): the join reducers flush the pending group first
+    __device__ inline T value(int func, bool *ok) {
+        if (func >= 11 && seen) push_join(func, func == 11 ? j : (T)0, false);
+        const bool mom = func == 5 || func == 6 || func == 7 || func >= 13;
+        *ok = mom ? n > 0 : seen;
+        switch (func) {
+        case 5: case 13: return (T)mean;
+        case 6: case 14: return n < 2 ? (T)__builtin_nan("") : (T)(m2 / (double)(n - 1));
+        case 7: case 15: return n < 2 ? (T)__builtin_nan("") : (T)__builtin_sqrt(m2 / (double)(n - 1));
+        default: return v;
+        }
+    }
+};
+
+template <typename T>
+__global__ void bucket_seq_kernel(int func, const int64_t *__restrict__ time, const T *__restrict__ src, const uint8_t *__restrict__ bits,
+                                  const uint64_t *__restrict__ start, uint32_t n_buckets, T *__restrict__ out_v, uint8_t *__restrict__ out_seen) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    SeqJoinRed<T> r;
+    bool have_prev = false;
+    int64_t prev = 0;
+    const uint64_t e = start[k + 1];
+    for (uint64_t i = start[k]; i < e; i++) {
+        if (bits != nullptr && !((bits[i >> 3] >> (i & 7)) & 1)) continue;
+        const T x = src[i];
+        if (func >= 9) {
+            const int64_t t = time[i];
+            r.push_join(func, x, have_prev && t == prev);
+            prev = t;
+            have_prev = true;
+        } else
+            r.push(func, x);
+    }
+    bool ok;
+    out_v[k] = r.value(func, &ok);
+    out_seen[k] = ok ? 1 : 0;
+}
+
+hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
+                                    const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen) {
+    const int tpb = 64;
+    const int grid = (int)((n_buckets + tpb - 1) / tpb);
+#define KNOX_BSEQ(T) hipLaunchKernelGGL((bucket_seq_kernel<T>), dim3(grid), dim3(tpb), 0, s, func, time, (const T *)col, mask, start, n_buckets, (T *)out_v, out_seen); break
+    switch (dtype) {
+    case 1: KNOX_BSEQ(int64_t);
+    case 2: KNOX_BSEQ(int32_t);
+    case 3: KNOX_BSEQ(int16_t);
+    case 4: KNOX_BSEQ(int8_t);
+    case 5: KNOX_BSEQ(uint64_t);
+    case 6: KNOX_BSEQ(uint32_t);
+    case 7: KNOX_BSEQ(uint16_t);
+    case 8: KNOX_BSEQ(uint8_t);
+    case 9: KNOX_BSEQ(double);
+    case 10: KNOX_BSEQ(float);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_BSEQ
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows, const uint8_t *mask,
                                     uint64_t *out3) {
 #define KNOX_SEQ(T) hipLaunchKernelGGL((reduce_seq_kernel<T>), dim3(1), dim3(64), 0, s, func, (const T *)col, n_rows, mask, out3); break

@@ -492,6 +492,16 @@ class Context:
                                          n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), states), "knox_reduce_buckets")
         return [states[i] for i in range(n_buckets)]
 
+    def reduce_buckets_sequential(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
+        """The reference's own reducer per window, row by row (bit-exact Value() for every reducer, join
+        reducers included) -> (values[n_buckets], seen[n_buckets])."""
+        vals = np.zeros(n_buckets, dtype=NP_DTYPE[value_col.dtype])
+        seen = np.zeros(n_buckets, dtype=np.uint8)
+        check(self.L.knox_reduce_buckets_sequential(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
+                                                    n_buckets, int(func), 1 if assume_sorted else 0, _ptr(vals), _ptr(seen)),
+              "knox_reduce_buckets_sequential")
+        return vals, seen.astype(bool)
+
     def reduce_sequential(self, col, func, mask=None):
         out = np.zeros(1, dtype=NP_DTYPE[col.dtype])
         seen, row = C.c_int(), C.c_int64()

@@ -48,6 +48,14 @@ class ReducerFunc(enum.IntEnum):
     Var = 6
     Std = 7
     Count = 8
+    # join reducers (reducer.go:432-731): evaluated by Context.reduce_buckets_sequential only
+    FirstJoin = 9
+    LastJoin = 10
+    MinJoin = 11
+    MaxJoin = 12
+    MeanJoin = 13
+    VarJoin = 14
+    StdJoin = 15
 
 
 NP_DTYPE = {

@@ -36,7 +36,9 @@ enum { KO_I64 = 1, KO_I32 = 2, KO_I16 = 3, KO_I8 = 4, KO_U64 = 5, KO_U32 = 6, KO
 enum { KO_EQ = 1, KO_NE = 2, KO_GT = 3, KO_GE = 4, KO_LT = 5, KO_LE = 6, KO_RG = 9 };
 /* reducer funcs    internal/reducer/reducer.go:25-45 */
 enum { KO_R_SUM = 0, KO_R_FIRST = 1, KO_R_LAST = 2, KO_R_MIN = 3, KO_R_MAX = 4, KO_R_MEAN = 5,
-       KO_R_VAR = 6, KO_R_STD = 7, KO_R_COUNT = 8 };
+       KO_R_VAR = 6, KO_R_STD = 7, KO_R_COUNT = 8,
+       KO_R_FIRST_JOIN = 9, KO_R_LAST_JOIN = 10, KO_R_MIN_JOIN = 11, KO_R_MAX_JOIN = 12, KO_R_MEAN_JOIN = 13,
+       KO_R_VAR_JOIN = 14, KO_R_STD_JOIN = 15 };
 
 /* ------------------------------------------------------------------------------------------
  * bitset helpers: internal/bitset/generic/utils.go:12-24
@@ -794,7 +796,51 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
  * window in place (:120-141).  Output = (window time, Value()) per reducer in list order.
  * ---------------------------------------------------------------------------------------- */
 #define KO_BUCKET(NAME, T)                                                                      \
-    typedef struct { int64_t t; int seen; T v; int64_t n; double mean, m2; } NAME##_red;        \
+    typedef struct { int64_t t; int seen; T v; int64_t n; double mean, m2; T j; int done; } NAME##_red; \
+    /* join reducers (reducer.go:432-731): rows with the same raw timestamp as the previous streamed row \
+     * (join, pkg/series/series.go:200-203) are summed into r.j before the reducer proper sees them;    \
+     * `!r->seen` stands for r.t.IsZero().  Value() of the join reducers flushes r.j first.             \
+     * The code below is the reference's, statement by statement, quirks included (MaxJoin / MinJoin    \
+     * start from r.v = 0).  */                                                                         \
+    static void NAME##_reduce_join(int func, NAME##_red *r, T x, int64_t t, int join) {         \
+        if (func == KO_R_LAST_JOIN) { r->t = t; r->seen = 1; if (join) r->v = (T)(r->v + x); else r->v = x; return; } \
+        if (!r->seen) { /* r.t.IsZero() */                                                      \
+            r->t = t; r->seen = 1;                                                              \
+            if (func == KO_R_FIRST_JOIN) r->v = x; else r->j = x;                               \
+            return;                                                                             \
+        }                                                                                       \
+        switch (func) {                                                                         \
+        case KO_R_FIRST_JOIN: if (join && !r->done) r->v = (T)(r->v + x); else r->done = 1; break; \
+        case KO_R_MAX_JOIN: if (join) r->j = (T)(r->j + x); else { if (r->v < r->j) r->v = r->j; r->j = x; } break; \
+        case KO_R_MIN_JOIN: if (join) r->j = (T)(r->j + x); else { if (r->j < r->v) r->v = r->j; r->j = x; } break; \
+        default: /* mean / var / std join */                                                    \
+            if (join) r->j = (T)(r->j + x);                                                     \
+            else {                                                                              \
+                r->n++;                                                                         \
+                double d = (double)r->j - r->mean;                                              \
+                r->mean += d / (double)r->n;                                                    \
+                if (func != KO_R_MEAN_JOIN) r->m2 += d * ((double)r->j - r->mean);              \
+                r->j = x;                                                                       \
+            }                                                                                   \
+        }                                                                                       \
+    }                                                                                           \
+    /* Reducer.Value(): returns seen, writes the value */                                       \
+    static int NAME##_value(int func, NAME##_red *r, T *out) {                                  \
+        switch (func) {                                                                         \
+        case KO_R_MEAN: *out = (T)r->mean; return r->n > 0;                                     \
+        case KO_R_VAR: *out = r->n < 2 ? (T)NAN : (T)(r->m2 / (double)(r->n - 1)); return r->n > 0; \
+        case KO_R_STD: *out = r->n < 2 ? (T)NAN : (T)sqrt(r->m2 / (double)(r->n - 1)); return r->n > 0; \
+        case KO_R_MAX_JOIN: if (r->seen) NAME##_reduce_join(func, r, (T)0, r->t, 0); *out = r->v; return r->seen; \
+        case KO_R_MIN_JOIN: if (r->seen) NAME##_reduce_join(func, r, r->j, r->t, 0); *out = r->v; return r->seen; \
+        case KO_R_MEAN_JOIN: if (r->seen) NAME##_reduce_join(func, r, (T)0, r->t, 0); *out = (T)r->mean; return r->n > 0; \
+        case KO_R_VAR_JOIN: case KO_R_STD_JOIN: {                                               \
+            if (r->seen) NAME##_reduce_join(func, r, (T)0, r->t, 0);                            \
+            if (r->n < 2) *out = (T)NAN;                                                        \
+            else *out = func == KO_R_VAR_JOIN ? (T)(r->m2 / (double)(r->n - 1)) : (T)sqrt(r->m2 / (double)(r->n - 1)); \
+            return r->n > 0; }                                                                  \
+        default: *out = r->v; return r->seen;                                                   \
+        }                                                                                       \
+    }                                                                                           \
     static void NAME##_reduce(int func, NAME##_red *r, T x, int64_t t) {                        \
         switch (func) {                                                                         \
         case KO_R_COUNT: if (!r->seen) r->t = t; r->v = (T)(r->v + 1); break;                   \
@@ -803,11 +849,12 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
         case KO_R_LAST: r->t = t; r->v = x; break;                                              \
         case KO_R_MAX: if (!r->seen || r->v < x) { r->t = t; r->v = x; } break;                 \
         case KO_R_MIN: if (!r->seen || r->v > x) { r->t = t; r->v = x; } break;                 \
-        default: { /* mean (Welford) */                                                         \
+        default: { /* mean / var / std (Welford) :318-429 */                                    \
             if (r->n == 0) r->t = t;                                                            \
             r->n++;                                                                             \
             double d = (double)x - r->mean;                                                     \
             r->mean += d / (double)r->n;                                                        \
+            if (func != KO_R_MEAN) r->m2 += d * ((double)x - r->mean);                          \
             break; }                                                                            \
         }                                                                                       \
         r->seen = 1;                                                                            \
@@ -815,10 +862,12 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
     static int64_t NAME##_run(int func, const int64_t *times, const T *vals, int64_t n, const uint8_t *bits, \
                               int64_t from, int64_t step, int64_t *out_t, T *out_v, int64_t cap) { \
         NAME##_red *reds = (NAME##_red *)calloc((size_t)cap + 1, sizeof(NAME##_red));           \
-        int64_t nr = 0, last = 0, next = 0;                                                     \
-        int have_next = 0; /* b.next is the zero time until the first row */                    \
+        int64_t nr = 0, last = 0, next = 0, prev_raw = 0;                                       \
+        int have_next = 0, have_prev = 0; /* b.next / series' `last` are the zero time until the first row */ \
         for (int64_t i = 0; i < n; i++) {                                                       \
             if (!KO_SELECTED(i)) continue;                                                      \
+            const int join = have_prev && prev_raw == times[i]; /* series.go:200-203 */          \
+            prev_raw = times[i]; have_prev = 1;                                                 \
             int64_t d = times[i] - from, q = d / step;                                          \
             if ((d % step != 0) && ((d < 0) != (step < 0))) q--; /* floor division */           \
             const int64_t t = from + q * step;                                                  \
@@ -837,11 +886,12 @@ KO_EXPORT int64_t ko_bytes_match(int op, const uint64_t *ptr, int64_t n, const u
                     target = idx;                                                               \
                 } else target = idx - 1;                                                        \
             }                                                                                   \
-            NAME##_reduce(func, &reds[target], vals[i], t);                                     \
+            if (func >= KO_R_FIRST_JOIN) NAME##_reduce_join(func, &reds[target], vals[i], t, join); \
+            else NAME##_reduce(func, &reds[target], vals[i], t);                                \
         }                                                                                       \
         for (int64_t k = 0; k < nr; k++) {                                                      \
             out_t[k] = reds[k].t;                                                               \
-            out_v[k] = (func == KO_R_MEAN) ? (T)reds[k].mean : reds[k].v;                       \
+            NAME##_value(func, &reds[k], &out_v[k]);                                            \
         }                                                                                       \
         free(reds);                                                                             \
         return nr;                                                                              \

@@ -16,6 +16,7 @@ _SO = os.path.join(_HERE, "libknox_oracle.so")
 I64, I32, I16, I8, U64, U32, U16, U8, F64, F32, BYTES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12
 EQ, NE, GT, GE, LT, LE, IN, NIN, RG = 1, 2, 3, 4, 5, 6, 7, 8, 9
 R_SUM, R_FIRST, R_LAST, R_MIN, R_MAX, R_MEAN, R_VAR, R_STD, R_COUNT = range(9)
+R_FIRST_JOIN, R_LAST_JOIN, R_MIN_JOIN, R_MAX_JOIN, R_MEAN_JOIN, R_VAR_JOIN, R_STD_JOIN = range(9, 16)
 
 NP = {I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8, U64: np.uint64, U32: np.uint32,
       U16: np.uint16, U8: np.uint8, F64: np.float64, F32: np.float32}
