@@ -59,7 +59,9 @@ enum knox_dtype {
 enum knox_op {
     KNOX_EQ = 1, KNOX_NE = 2, KNOX_GT = 3, KNOX_GE = 4, KNOX_LT = 5, KNOX_LE = 6,
     KNOX_IN = 7, KNOX_NOTIN = 8 /* value in / not in a set: val = array of column-type values */,
-    KNOX_RANGE = 9 /* Between [a,b] */, KNOX_TRUE = 11, KNOX_FALSE = 12
+    KNOX_RANGE = 9 /* Between [a,b] */,
+    KNOX_REGEXP = 10 /* bytes columns: val = the pattern text (Go regexp / RE2 syntax) */,
+    KNOX_TRUE = 11, KNOX_FALSE = 12
 };
 
 /* ---- reducer functions (internal/reducer/reducer.go:25-45) -------------------------- */
@@ -368,6 +370,20 @@ int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col
 int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op,
                                    const uint8_t *val, uint64_t val_len, const uint8_t *val2, uint64_t val2_len,
                                    const knox_bits *mask /* nullable */, knox_bits *bits);
+
+/* bytesRegexpMatcher (operator/filter/match_bytes.go:543-609): MatchVector = regexp.Match(row) for every
+ * (masked) row of a bytes column.  The pattern is compiled on the host into a DFA over rune classes and
+ * the rows are walked one per lane, decoding runes exactly as Go does (invalid byte = U+FFFD, width 1).
+ * bits: overwritten when mask is NULL; with a mask only masked rows are evaluated and their hits OR-ed in
+ * (the reference's bits.Set(i) loop).  Syntax: Go's regexp/syntax (RE2) -- literals, escapes, classes,
+ * Perl and POSIX classes, . * + ? {n,m} (lazy forms too), groups and named groups, | , ^ $ \A \z \b \B,
+ * flags i m s U.  KNOX_E_UNSUPPORTED = outside that subset (\p{..}, case folding of non-ASCII runes, a DFA
+ * above 4096 states): the caller keeps regexp.Match for that condition.  The same program serves a
+ * KNOX_REGEXP leaf of knox_scan (val/val_len = pattern).                                       */
+int knox_match_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pattern, uint64_t pattern_len,
+                      const knox_bits *mask /* nullable */, knox_bits *bits, int64_t *count /* nullable */);
+/* MatchValue (match_bytes.go:578-580) for one value, host only: 1 match, 0 no match, <0 error.  */
+int knox_regexp_match_value(const uint8_t *pattern, uint64_t pattern_len, const uint8_t *value, uint64_t value_len);
 
 /* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
 int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,

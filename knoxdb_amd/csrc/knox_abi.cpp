@@ -21,6 +21,7 @@
 
 #include "../../include/knoxgpu.h"
 #include "knox_kernels.h"
+#include "knox_regex.h"
 #include "knox_xxh3.h"  // host flavour: KNOX_HD / KNOX_XXH3_CONST empty
 
 using namespace knox;
@@ -2107,6 +2108,47 @@ static int run_moments(knox_ctx *ctx, const knox_col *col, const uint32_t *mask,
     return KNOX_OK;
 }
 
+// bytes REGEXP: compile on the host, stage the DFA image in ctx->bytes_val, one lane per row
+static int run_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pat, uint64_t pat_len, const uint8_t *mask, uint8_t *bits) {
+    if (col->dtype != KNOX_BYTES) return KNOX_E_INVALID;  // only string/byte blocks support regexp (operator/filter/match.go:76)
+    if (pat_len && !pat) return KNOX_E_INVALID;
+    if (pat_len > (1u << 20)) return KNOX_E_RANGE;
+    knox_regex::Program pg;
+    const int st = knox_regex::compile(pat, (size_t)pat_len, pg);
+    if (st != knox_regex::OK) return KNOX_E_UNSUPPORTED;  // syntax outside the implemented subset / DFA too large: host regexp.Match
+    const size_t tb = (size_t)pg.n_states * pg.n_classes * 2;
+    const size_t image = tb + pg.n_states + 128;                 // table | flags | ascii (what the kernel stages in LDS)
+    const size_t off_lo = (image + 15) & ~(size_t)15;
+    const size_t off_cls = off_lo + pg.bound_lo.size() * 4;
+    const size_t total = off_cls + pg.bound_class.size() + 16;
+    std::vector<uint8_t> h(total, 0);
+    memcpy(h.data(), pg.table.data(), tb);
+    memcpy(h.data() + tb, pg.flags.data(), pg.n_states);
+    memcpy(h.data() + tb + pg.n_states, pg.ascii_class, 128);
+    memcpy(h.data() + off_lo, pg.bound_lo.data(), pg.bound_lo.size() * 4);
+    memcpy(h.data() + off_cls, pg.bound_class.data(), pg.bound_class.size());
+    int rc = ensure(ctx, ctx->bytes_val, total);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, h.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host image not retained
+    const uint8_t *d = (const uint8_t *)ctx->bytes_val.p;
+    RegexProg dp;
+    dp.table = (const uint16_t *)d;
+    dp.flags = d + tb;
+    dp.ascii_class = d + tb + pg.n_states;
+    dp.bound_lo = (const uint32_t *)(d + off_lo);
+    dp.bound_class = d + off_cls;
+    dp.n_bounds = (uint32_t)pg.bound_lo.size();
+    dp.n_classes = pg.n_classes;
+    dp.n_states = pg.n_states;
+    hipError_t e = launch_regexp_match(ctx->stream, dp, (uint32_t)image, (const uint64_t *)col->dev, col->n_rows, col->buf, bits, mask);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
 // one leaf -> its own bitset (multi-pass plan)
 static uint64_t order_key(int dtype, uint64_t bits);
 
@@ -2154,9 +2196,10 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
         }
         return KNOX_OK;
     }
+    if (p.op == KNOX_REGEXP) return run_regexp(ctx, col, p.val, p.val_len, nullptr, (uint8_t *)bits);
     if (col->dtype == KNOX_BYTES) {
         const bool ordered = p.op == KNOX_LT || p.op == KNOX_LE || p.op == KNOX_GT || p.op == KNOX_GE || p.op == KNOX_RANGE;
-        if (p.op != KNOX_EQ && p.op != KNOX_NE && !ordered) return KNOX_E_UNSUPPORTED;  // regexp: host path
+        if (p.op != KNOX_EQ && p.op != KNOX_NE && !ordered) return KNOX_E_UNSUPPORTED;
         if (p.val_len > 0xffffffffull || (p.val_len && !p.val)) return KNOX_E_INVALID;
         const size_t len2 = p.op == KNOX_RANGE ? (size_t)p.val2_len : 0;
         if (len2 > 0xffffffffull || (len2 && !p.val2)) return KNOX_E_INVALID;
@@ -2329,7 +2372,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     int width = 0;
     for (int l = 0; l < n_leaves && fused; l++) {
         const knox_col *c = cols[nodes[leaf_nodes[l]].col];
-        if (c->dtype == KNOX_BYTES || nodes[leaf_nodes[l]].op == KNOX_IN || nodes[leaf_nodes[l]].op == KNOX_NOTIN) fused = false;
+        if (c->dtype == KNOX_BYTES || nodes[leaf_nodes[l]].op == KNOX_IN || nodes[leaf_nodes[l]].op == KNOX_NOTIN || nodes[leaf_nodes[l]].op == KNOX_REGEXP) fused = false;
         else if (width == 0) width = c->width;
         else if (c->width != width) fused = false;
     }
@@ -2874,6 +2917,27 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
     }
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     return download(ctx, states, base + off_states, n_buckets * sizeof(AggStateDev));
+}
+
+// bytesRegexpMatcher.MatchVector (match_bytes.go:587-609): bits.Set(i) for every (masked) row the pattern matches
+KNOX_API int knox_match_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pattern, uint64_t pattern_len, const knox_bits *mask,
+                               knox_bits *bits, int64_t *count) {
+    if (!ctx || !col || !bits || bits->size != col->n_rows) return KNOX_E_INVALID;
+    if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    int rc = run_regexp(ctx, col, pattern, pattern_len, mask ? (const uint8_t *)mask->dev : nullptr, (uint8_t *)bits->dev);
+    if (rc) return rc;
+    if (count) return knox_bits_popcount(ctx, bits, count);
+    return KNOX_OK;
+}
+
+// bytesRegexpMatcher.MatchValue (match_bytes.go:578-580) for one value: pure host code, the same compiled program
+KNOX_API int knox_regexp_match_value(const uint8_t *pattern, uint64_t pattern_len, const uint8_t *value, uint64_t value_len) {
+    if ((pattern_len && !pattern) || (value_len && !value)) return KNOX_E_INVALID;
+    knox_regex::Program pg;
+    if (knox_regex::compile(pattern, (size_t)pattern_len, pg) != knox_regex::OK) return KNOX_E_UNSUPPORTED;
+    return knox_regex::match_host(pg, value, (size_t)value_len) ? 1 : 0;
 }
 
 KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask,

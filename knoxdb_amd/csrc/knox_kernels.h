@@ -230,6 +230,17 @@ hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);
 
 // literal sequential reducer (one lane)
+// compiled REGEXP program on the device (knox_regex.h): table | flags | ascii_class are one contiguous image
+struct RegexProg {
+    const uint16_t *table;
+    const uint8_t *flags;
+    const uint8_t *ascii_class;
+    const uint32_t *bound_lo;
+    const uint8_t *bound_class;
+    uint32_t n_bounds, n_classes, n_states;
+};
+hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                               uint8_t *bits, const uint8_t *mask);
 hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
                                     const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen);
 hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows,

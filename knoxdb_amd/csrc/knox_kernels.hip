@@ -33,6 +33,7 @@
 
 #define KNOX_HD __host__ __device__
 #define KNOX_XXH3_CONST __constant__
+#include "knox_regex.h"
 #include "knox_xxh3.h"
 
 namespace knox {
@@ -2573,6 +2574,86 @@ __global__ void reduce_seq_kernel(int func, const T *src, uint64_t n, const uint
     out[0] = raw;
     out[1] = seen ? 1 : 0;
     out[2] = row;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bytes REGEXP (operator/filter/match_bytes.go:587-609: re.Match(row) for every row).  The host
+// compiles the pattern into a DFA over rune classes (knox_regex.h); one lane = one row: decode a
+// rune the way Go does (utf8.DecodeRune, invalid byte = U+FFFD of width 1), map it to its class
+// (table for ASCII, binary search above), step table[state][class]; state 0 = ACCEPT (absorbing),
+// flags bit1 = dead (no accepting state reachable) -> the lane stops early either way.  Tables of
+// up to 48 KiB are staged in LDS, larger ones are read through L2.
+// ---------------------------------------------------------------------------------------------
+template <bool LDS>
+__global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf, uint8_t *bits,
+                                                              const uint8_t *mask) {
+    extern __shared__ __align__(16) uint8_t rx_lds[];
+    const uint16_t *table = pg.table;
+    const uint8_t *flags = pg.flags, *ascii = pg.ascii_class;
+    if constexpr (LDS) {
+        // image layout (host): [table u16 * n_states*n_classes][flags n_states][ascii 128]
+        const uint32_t tb = pg.n_states * pg.n_classes * 2, total = tb + pg.n_states + 128;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) rx_lds[i] = ((const uint8_t *)pg.table)[i];
+        __syncthreads();
+        table = (const uint16_t *)rx_lds;
+        flags = rx_lds + tb;
+        ascii = flags + pg.n_states;
+    }
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows && (mask == nullptr || ((mask[row >> 3] >> (row & 7)) & 1))) {
+            const uint64_t p = ptr[row];
+            const uint8_t *s = buf + (uint32_t)(p >> 32);
+            const uint32_t len = (uint32_t)p;
+            uint32_t state = 1, pos = 0;
+            bool decided = false;
+            while (pos < len) {
+                uint32_t w;
+                const uint32_t r = knox_regex::decode_rune(s + pos, len - pos, w);
+                pos += w;
+                uint32_t cls;
+                if (r < 0x80) cls = ascii[r];
+                else {
+                    uint32_t lo = 0, hi = pg.n_bounds;
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (pg.bound_lo[mid] <= r) lo = mid; else hi = mid;
+                    }
+                    cls = pg.bound_class[lo];
+                }
+                state = table[state * pg.n_classes + cls];
+                if (state == 0) { m = true; decided = true; break; }
+                if (flags[state] & 2) { decided = true; break; }
+            }
+            if (!decided) m = flags[state] & 1;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                const uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) { if (byte) bits[bi] |= byte; }  // bits.Set(i) for the masked rows that match
+                else bits[bi] = byte;
+            }
+        }
+    }
+}
+
+hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
+                               uint8_t *bits, const uint8_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    if (image_bytes <= 48 * 1024)
+        hipLaunchKernelGGL((regexp_match_kernel<true>), dim3((unsigned)g), dim3(kBlock), image_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+    else
+        hipLaunchKernelGGL((regexp_match_kernel<false>), dim3((unsigned)g), dim3(kBlock), 0, s, pg, ptr, n_rows, buf, bits, mask);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

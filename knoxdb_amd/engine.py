@@ -453,6 +453,15 @@ class Context:
                                                     mask.h if mask is not None else None, out.h), "knox_match_range_vectors_bytes")
         return out
 
+    def match_regexp(self, col, pattern, mask=None, bits=None):
+        """bytesRegexpMatcher.MatchVector: Go regexp.Match per row of a bytes column -> (Bits, count)."""
+        pat = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
+        out = bits if bits is not None else self.bits(col.rows)
+        cnt = C.c_int64()
+        check(self.L.knox_match_regexp(self.h, col.h, pat, len(pat), mask.h if mask is not None else None, out.h, C.byref(cnt)),
+              "knox_match_regexp")
+        return out, cnt.value
+
     def match_wide(self, limbs, mode, a, b=None, mask=None, bits=None):
         """Int128 / Int256 matcher over limb columns (most significant first) -> (Bits, count)."""
         n = len(limbs)
@@ -593,6 +602,16 @@ def hash_bytes(val):
     """hash.Hash: XXH3-64 of a byte string (knox_hash_bytes)"""
     v = bytes(val)
     return _lib.lib().knox_hash_bytes(v, len(v))
+
+
+def regexp_match_value(pattern, value):
+    """bytesRegexpMatcher.MatchValue for one value (host): True / False; KnoxError(UNSUPPORTED) outside the subset"""
+    pat = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
+    v = bytes(value)
+    rc = _lib.lib().knox_regexp_match_value(pat, len(pat), v, len(v))
+    if rc < 0:
+        check(rc, "knox_regexp_match_value")
+    return bool(rc)
 
 
 def hash_value(dtype, v):

@@ -34,6 +34,7 @@ class FilterMode(enum.IntEnum):
     In = 7
     NotIn = 8
     Range = 9
+    Regexp = 10   # bytes columns, value = pattern text (Go regexp syntax)
     True_ = 11
     False_ = 12
 

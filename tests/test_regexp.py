@@ -1,0 +1,205 @@
+"""'Next' row f4: the bytes REGEXP matcher (internal/operator/filter/match_bytes.go:543-609 = Go's
+regexp.Match per row).  Checker: oracle/regexp_oracle.py (Go rune decoding + CPython's `re` behind a
+syntax translation), pinned by the reference's own vector (operator/filter/match_test.go:244-283) and by
+hand-worked cases from the RE2 syntax page.  The device path compiles the pattern to a rune-class DFA on
+the host and walks one row per lane."""
+import random
+
+import numpy as np
+import pytest
+
+import knoxdb_amd as K
+from oracle import regexp_oracle as RO
+
+# (pattern, value, expected): Go semantics worked out by hand
+HAND = [
+    ("Hel.*", b"Hello", True), ("Hel.*", b"World", False),          # the reference's vector
+    ("", b"", True), ("", b"abc", True), ("x*", b"", True), ("x+", b"", False),
+    ("^a+b$", b"aaab", True), ("^a+b$", b"aaabc", False), ("^a+b$", b"xaab", False),
+    ("o$", b"foo", True), ("o$", b"foo\n", False),                   # $ is end of TEXT without (?m)
+    ("(?m)o$", b"foo\nbar", True), ("(?m)^b$", b"a\nb\nc", True), ("^b$", b"a\nb\nc", False),
+    (r"\Aab\z", b"ab", True), (r"\Aab\z", b"ab\n", False),
+    (r"\bfoo\b", b"a foo b", True), (r"\bfoo\b", b"afoo", False), (r"\Boo\b", b"foo", True), (r"\bfoo\b", b"foo", True),
+    (r"\b", b"", False), (r"\B", b"", True), (r"\b", b"-", False), (r"\b", b"a", True),
+    ("a.c", b"a\nc", False), ("(?s)a.c", b"a\nc", True),
+    # runes, not bytes: one invalid byte is one rune U+FFFD; a valid multi-byte rune is one rune
+    ("^a.c$", b"a\xffc", True), ("^a.c$", b"a\xe2\x82\xacc", True), ("^a..c$", b"a\xe2\x82c", True), ("^a...c$", b"a\xe2\x82\xacc", False),
+    ("^.$", b"\xf0\x9f\x98\x80", True), ("^..$", b"\xf0\x9f\x98", False), ("^...$", b"\xf0\x9f\x98", True),
+    ("^.$", b"\xed\xa0\x80", False), ("^...$", b"\xed\xa0\x80", True),       # surrogate encoding: three invalid bytes
+    ("^.$", b"\xc0\x80", False), ("^..$", b"\xc0\x80", True),                   # overlong: two invalid bytes
+    ("�", b"\xff", True), ("[^a]", b"\xff", True), ("é", b"\xc3\xa9", True), ("é", b"\xc3", False),
+    (r"\x{20ac}", b"\xe2\x82\xac", True), (r"\xe9", b"\xc3\xa9", True), (r"\101", b"A", True), (r"\0", b"\x00", True),
+    ("(ab|cd){2,3}e", b"zzabcde", True), ("(ab|cd){2,3}e", b"abe", False), ("a{2}", b"aba", False), ("a{2,}", b"baaa", True),
+    ("a{,2}", b"a{,2}", True), ("a{", b"a{", True), ("a{1", b"a{1", True),    # not a repeat: literal braces
+    ("[[:alpha:]]+\\d", b"--ab1", True), ("[[:^alpha:]]", b"abc", False), ("[[:^alpha:]]", b"ab1", True),
+    ("[[:punct:]]", b"a-b", True), ("[[:word:]]", b"-_-", True), ("[]a]", b"]", True), ("[^]a]", b"]a", False), ("[a-]", b"-", True),
+    (r"[\d\-x]", b"-", True), (r"[^\D]", b"a5", True), (r"[^\D]", b"ab", False), (r"\D", b"5", False), (r"\W", b"a_1", False),
+    (r"\s", b"\v", False), (r"\s", b"\f", True),                                # Go's \s has no vertical tab
+    ("(?i)hello", b"HeLLo", True), ("(?i)kelvin", b"\xe2\x84\xaaELVIN", True), ("(?i)s", b"\xc5\xbf", True), ("(?i)[k]", b"\xe2\x84\xaa", True),
+    ("(?i)[^k]", b"\xe2\x84\xaa", False), ("(?i)\\W", b"\xe2\x84\xaa", False), ("\\W", b"\xe2\x84\xaa", True), ("(?i:a)b", b"Ab", True), ("(?i:a)b", b"AB", False),
+    ("a(?i)b|c", b"aB", True), ("a(?i)b|c", b"C", True), ("(a(?i)b)c", b"aBC", False), ("(?i)a(?-i)b", b"AB", False), ("(?i)a(?-i)b", b"Ab", True),
+    (r"\Qa.b\E", b"a.b", True), (r"\Qa.b\E", b"axb", False), (r"\Q+", b"+", True),
+    ("(?P<x>a)(?<y>b)", b"ab", True), ("(?U)a+", b"a", True), ("a+?b*?c??", b"a", True), ("(?:a*)*b", b"aab", True), ("(a*)+$", b"b", True),
+    ("a|", b"zzz", True), ("(|a)b", b"b", True), ("()", b"", True), ("a**", None, "unsupported"), ("a*?*", None, "unsupported"), ("*", None, "unsupported"),
+    ("(", None, "unsupported"), (")", None, "unsupported"), ("[a", None, "unsupported"), (r"\pL", None, "unsupported"), (r"\1", None, "unsupported"),
+    ("(?i)é", None, "unsupported"), ("a{1001}", None, "unsupported"), ("[b-a]", None, "unsupported"), (r"\8", None, "unsupported"), ("(?z)", None, "unsupported"),
+]
+
+
+def test_hand_worked_cases():
+    for pat, val, want in HAND:
+        if want == "unsupported":
+            with pytest.raises(K.KnoxError) as e:
+                K.regexp_match_value(pat, b"x")
+            assert e.value.code == -5, pat
+        else:
+            assert K.regexp_match_value(pat, val) is want, (pat, val)
+
+
+def test_oracle_agrees_with_the_hand_cases_it_can_express():
+    n = 0
+    for pat, val, want in HAND:
+        if want == "unsupported":
+            continue
+        try:
+            got = RO.regexp_match(pat, [val])[0]
+        except NotImplementedError:
+            continue
+        if pat in ("(?i)kelvin", "(?i)s", "(?i)[k]", "(?i)[^k]", "(?i)\\W", r"\s") and (b"\xe2\x84\xaa" in val or b"\xc5\xbf" in val or val == b"\v"):
+            continue   # documented gaps of the checker (module docstring)
+        assert got is want, (pat, val)
+        n += 1
+    assert n > 70
+
+
+ATOMS = ["a", "b", "c", "d", "e", "0", "1", " ", "-", "_", r"\.", r"\*", ".", "[a-c]", "[^a-c]", "[b-e0-1_]", r"\d", r"\w", r"\s", r"\D", r"\W", r"\S",
+         "é", "€", "😀", r"\x41", r"\x{e9}", "[é€]", "[^é]", "[[:digit:]]", "[[:upper:]]", "\\n"]
+ASSERTS = ["^", "$", r"\A", r"\z", r"\b", r"\B"]
+REPEATS = ["*", "+", "?", "{2}", "{1,3}", "{2,}", "*?", "+?", "??", "{0,2}?"]
+ROW_ALPHABET = ["a", "b", "c", "d", "e", "A", "B", "C", "0", "1", "2", " ", "_", "-", ".", "*", "\n", "é", "€", "😀"]
+BAD_BYTES = [b"\xff", b"\xe2\x82", b"\xc3", b"\xf0\x9f", b"\x80", b"\xed\xa0\x80"]
+
+
+def gen_pattern(rng, depth=0):
+    parts = []
+    for _ in range(rng.randint(1, 4)):
+        r = rng.random()
+        if r < 0.12 and depth < 3:
+            atom = rng.choice(["(", "(?:"]) + gen_pattern(rng, depth + 1) + ")"
+        elif r < 0.22:
+            parts.append(rng.choice(ASSERTS))
+            continue
+        else:
+            atom = rng.choice(ATOMS)
+        if rng.random() < 0.35:
+            atom += rng.choice(REPEATS)
+        parts.append(atom)
+    p = "".join(parts)
+    if depth < 3 and rng.random() < 0.2:
+        p += "|" + gen_pattern(rng, depth + 1)
+    return p
+
+
+def gen_rows(rng, n):
+    rows = []
+    for _ in range(n):
+        parts = []
+        for _ in range(rng.randint(0, 12)):
+            parts.append(rng.choice(BAD_BYTES) if rng.random() < 0.08 else rng.choice(ROW_ALPHABET).encode())
+        rows.append(b"".join(parts))
+    return rows
+
+
+def gen_cases(seed, n_patterns):
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n_patterns:
+        prefix = rng.choice(["", "", "", "(?i)", "(?s)", "(?m)", "(?is)", "(?ms)"])
+        pat = prefix + gen_pattern(rng)
+        if "i" in prefix and (any(ord(ch) >= 0x80 for ch in pat) or "\\x{e9}" in pat):
+            continue   # folding of non-ASCII runes: refused by the device (hand cases cover it)
+        out.append(pat)
+    return out
+
+
+def test_random_patterns_match_the_oracle_on_the_host_walk():
+    rng = random.Random(5)
+    rows = gen_rows(rng, 300) + [b"", b"\n", b"a", b"\xff"]
+    checked = 0
+    for pat in gen_cases(11, 400):
+        want = RO.regexp_match(pat, rows)
+        got = [K.regexp_match_value(pat, r) for r in rows]
+        assert got == want, (pat, [r for r, g, w in zip(rows, got, want) if g != w][:3])
+        checked += 1
+    assert checked == 400
+
+
+def pool(rows):
+    ptr = np.zeros(len(rows), dtype=np.uint64)
+    off = 0
+    for i, r in enumerate(rows):
+        ptr[i] = (off << 32) | len(r)
+        off += len(r)
+    return ptr, np.frombuffer(b"".join(rows) + b"\0" * 8, dtype=np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_regexp_rows_match_the_oracle():
+    from knoxdb_amd import And, Leaf, Or
+    from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc
+    rng = random.Random(23)
+    n = 20000 + 37
+    rows = gen_rows(rng, n)
+    ptr, buf = pool(rows)
+    nrng = np.random.default_rng(3)
+    mask_h = np.packbits(nrng.random(n) < 0.5, bitorder="little")
+    # > 48 KiB of tables: the global-memory form of the kernel
+    big = "(?:[ab]*a[ab]{9})|q|w|r|t|y|u|i|o|p|s|f|g|h|j|k|l|z|x|v|n|m|Q|W|R|T|Y|U|I|O|P"
+    pats = gen_cases(31, 60) + [p for p, v, w in HAND if w != "unsupported"] + [big]
+    with K.Context(0) as ctx:
+        col = ctx.upload_bytes(ptr, buf, 4096)
+        mask = ctx.bits(n).upload(mask_h)
+        for pat in pats:
+            try:
+                want = np.array(RO.regexp_match(pat, rows), dtype=bool)
+            except NotImplementedError:
+                want = np.array([K.regexp_match_value(pat, r) for r in rows[:2000]] + [False] * (n - 2000), dtype=bool)
+                bits, cnt = ctx.match_regexp(col, pat)
+                got = np.unpackbits(bits.bytes(), bitorder="little")[:n].astype(bool)
+                assert (got[:2000] == want[:2000]).all(), pat
+                bits.free()
+                continue
+            bits, cnt = ctx.match_regexp(col, pat)
+            raw = bits.bytes()
+            got = np.unpackbits(raw, bitorder="little")[:n].astype(bool)
+            assert (got == want).all(), (pat, np.flatnonzero(got != want)[:3])
+            assert cnt == int(want.sum())
+            assert raw.tobytes() == np.packbits(want, bitorder="little").tobytes()     # tail bits stay clear
+            bits.free()
+            # masked form: only masked rows are evaluated, hits are OR-ed into the caller's bits
+            pre = np.packbits(nrng.random(n) < 0.1, bitorder="little")
+            b2 = ctx.bits(n).upload(pre)
+            _, cnt2 = ctx.match_regexp(col, pat, mask=mask, bits=b2)
+            want2 = np.packbits(want, bitorder="little") & mask_h | pre
+            assert b2.bytes().tobytes() == want2.tobytes(), pat
+            b2.free()
+        # as a leaf of a scan plan, combined with a numeric leaf
+        ids = np.arange(n, dtype=np.int64)
+        idc = ctx.upload(ids, 4096)
+        out = ctx.bits(n)
+        res = ctx.scan(And(Leaf(0, FilterMode.Regexp, b"^[a-c]+.*\\d"), Leaf(1, FilterMode.Lt, n // 2)), [col, idc],
+                       aggs=[(ReducerFunc.Count, 1), (ReducerFunc.Sum, 1)], bits_out=out)
+        want = np.array(RO.regexp_match("^[a-c]+.*\\d", rows), dtype=bool) & (ids < n // 2)
+        assert res.count == int(want.sum())
+        assert out.bytes().tobytes() == np.packbits(want, bitorder="little").tobytes()
+        assert int(K.agg_value(res.states[1], ReducerFunc.Sum)[0]) == int(ids[want].sum())
+        # refusals: syntax outside the subset, and regexp on a numeric column
+        with pytest.raises(K.KnoxError) as e:
+            ctx.match_regexp(col, r"\pL+")
+        assert e.value.code == -5
+        with pytest.raises(K.KnoxError):
+            ctx.match_regexp(idc, "a")
+        # empty column
+        ecol = ctx.upload_bytes(np.zeros(0, np.uint64), np.zeros(8, np.uint8))
+        eb, ec = ctx.match_regexp(ecol, "a")
+        assert ec == 0
