@@ -2611,9 +2611,17 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
             const uint32_t len = (uint32_t)p;
             uint32_t state = 1, pos = 0;
             bool decided = false;
+            // the row's bytes travel in 8-byte pieces (unaligned loads; the pool is padded by 8 bytes): a rune
+            // is decoded from the register as long as its 4-byte window lies inside the piece
+            uint64_t piece = 0;
+            uint32_t pbase = 0x80000000u;
             while (pos < len) {
+                if (pos - pbase > 4u) {
+                    __builtin_memcpy(&piece, s + pos, 8);
+                    pbase = pos;
+                }
                 uint32_t w;
-                const uint32_t r = knox_regex::decode_rune(s + pos, len - pos, w);
+                const uint32_t r = knox_regex::decode_rune_word((uint32_t)(piece >> (8 * (pos - pbase))), len - pos, w);
                 pos += w;
                 uint32_t cls;
                 if (r < 0x80) cls = ascii[r];
@@ -2625,9 +2633,10 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
                     }
                     cls = pg.bound_class[lo];
                 }
-                state = table[state * pg.n_classes + cls];
-                if (state == 0) { m = true; decided = true; break; }
-                if (flags[state] & 2) { decided = true; break; }
+                const uint32_t e = table[state * pg.n_classes + cls];
+                if (e == 0) { m = true; decided = true; break; }
+                if (e & knox_regex::kDeadBit) { decided = true; break; }
+                state = e;
             }
             if (!decided) m = flags[state] & 1;
         }

@@ -33,6 +33,7 @@ constexpr uint32_t kMaxRune = 0x10FFFF;
 constexpr int kMaxNfa = 20000;      // NFA nodes (repeat expansion bound)
 constexpr int kMaxStates = 4096;    // DFA states
 constexpr int kMaxClasses = 255;    // rune classes
+constexpr uint16_t kDeadBit = 0x8000;  // table entry: the target state is dead (no accepting state reachable)
 
 struct Range { uint32_t lo, hi; };
 using Set = std::vector<Range>;
@@ -568,7 +569,7 @@ struct Program {
     uint8_t ascii_class[128];
     std::vector<uint32_t> bound_lo;    // runes >= 0x80: interval i starts at bound_lo[i] (sorted), ends before the next
     std::vector<uint8_t> bound_class;
-    std::vector<uint16_t> table;       // [n_states][n_classes]; state 0 = ACCEPT, state 1 = start
+    std::vector<uint16_t> table;       // [n_states][n_classes]: target state | kDeadBit; state 0 = ACCEPT, state 1 = start
     std::vector<uint8_t> flags;        // bit0: accepting at end of text, bit1: dead (no accepting state reachable)
 };
 
@@ -733,6 +734,9 @@ inline int compile(const uint8_t *pat, size_t len, Program &out) {
     }
     for (int d = 0; d < ns; d++)
         if (!live[d]) flags[d] |= 2;
+    // a transition into a dead state carries kDeadBit: the walk stops without a second lookup
+    for (size_t i = 0; i < table.size(); i++)
+        if (flags[table[i]] & 2) table[i] |= kDeadBit;
 
     out.n_states = (uint32_t)ns;
     out.n_classes = (uint32_t)ncls;
@@ -782,6 +786,29 @@ KNOX_RX_HD inline uint32_t decode_rune(const uint8_t *p, uint32_t n, uint32_t &w
     return ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
 }
 
+// the same decoder on the first bytes of the rune held in a register (little endian: byte 0 in bits 0-7)
+KNOX_RX_HD inline uint32_t decode_rune_word(uint32_t wd, uint32_t n, uint32_t &width) {
+    const uint32_t b0 = wd & 0xff;
+    width = 1;
+    if (b0 < 0x80) return b0;
+    if (b0 < 0xC2 || b0 > 0xF4) return 0xFFFD;
+    uint32_t size, lo = 0x80, hi = 0xBF;
+    if (b0 < 0xE0) size = 2;
+    else if (b0 < 0xF0) { size = 3; if (b0 == 0xE0) lo = 0xA0; else if (b0 == 0xED) hi = 0x9F; }
+    else { size = 4; if (b0 == 0xF0) lo = 0x90; else if (b0 == 0xF4) hi = 0x8F; }
+    if (n < size) return 0xFFFD;
+    const uint32_t b1 = (wd >> 8) & 0xff;
+    if (b1 < lo || b1 > hi) return 0xFFFD;
+    if (size == 2) { width = 2; return ((b0 & 0x1F) << 6) | (b1 & 0x3F); }
+    const uint32_t b2 = (wd >> 16) & 0xff;
+    if (b2 < 0x80 || b2 > 0xBF) return 0xFFFD;
+    if (size == 3) { width = 3; return ((b0 & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F); }
+    const uint32_t b3 = wd >> 24;
+    if (b3 < 0x80 || b3 > 0xBF) return 0xFFFD;
+    width = 4;
+    return ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
+}
+
 // host-side walk of the compiled program (unit tests of the compiler; the product path is the kernel)
 inline bool match_host(const Program &pg, const uint8_t *s, size_t n) {
     uint32_t state = 1;
@@ -800,9 +827,10 @@ inline bool match_host(const Program &pg, const uint8_t *s, size_t n) {
             }
             cls = pg.bound_class[lo];
         }
-        state = pg.table[(size_t)state * pg.n_classes + cls];
-        if (state == 0) return true;
-        if (pg.flags[state] & 2) return false;
+        const uint16_t e = pg.table[(size_t)state * pg.n_classes + cls];
+        if (e == 0) return true;
+        if (e & kDeadBit) return false;
+        state = e;
     }
     return pg.flags[state] & 1;
 }

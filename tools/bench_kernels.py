@@ -95,3 +95,31 @@ plan = ctx.plan(And(Leaf(0, F.Equal, keys[7].tobytes())), [bc], aggs=[])
 def bytes_scan():
     ctx.scan_async(plan, bits_out=bb); ctx.scan_collect(plan, 0)
 rec("bytes EQ 32-byte keys, 2^24 rows (whole scan call)", timeit(bytes_scan, reps=10, warm=3), nrow * (8 + L32 + 0.125))
+# bytes REGEXP on the same 32-byte binary keys (mostly invalid UTF-8: every byte is decoded) and on ASCII log-like rows
+rxb = ctx.bits(nrow)
+for pat in ("Hel.*", "^.{3}a", "(?i)[a-f0-9]{4}-\\d+$"):
+    rec("bytes REGEXP %-22s 32-byte random keys, 2^24 rows" % repr(pat), timeit(lambda: ctx.match_regexp(bc, pat, bits=rxb), reps=5, warm=2), nrow * (8 + L32 + 0.125))
+words = [b"GET /index.html 200", b"POST /api/v1/items 201", b"GET /static/app.js 304", b"Hello World", b"error: timeout id=ab12-77", b"WARN disk 93%"]
+lens = np.array([len(w) for w in words])
+pickw = rng.integers(0, len(words), size=nrow)
+offs = np.concatenate([[0], np.cumsum(lens[pickw])[:-1]]).astype(np.uint64)
+ptrw = (offs << np.uint64(32)) | lens[pickw].astype(np.uint64)
+table = np.zeros((len(words), lens.max()), dtype=np.uint8)
+for i, w in enumerate(words):
+    table[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
+sel = np.arange(lens.max())[None, :] < lens[pickw][:, None]
+bufw = np.concatenate([table[pickw][sel], np.zeros(8, np.uint8)])
+wc = ctx.upload_bytes(ptrw, bufw, pack)
+wbytes = nrow * 8.125 + int(lens[pickw].sum())
+for pat in ("Hel.*", "^GET .* 304$", "(?i)[a-f0-9]{4}-\\d+$", "\\b\\d{3}\\b"):
+    rec("bytes REGEXP %-22s ASCII log rows (avg %.0f B), 2^24 rows" % (repr(pat), lens[pickw].mean()), timeit(lambda: ctx.match_regexp(wc, pat, bits=rxb), reps=5, warm=2), wbytes)
+# literal per-window reducers (one lane per window)
+nt = 1 << 24
+tcol = ctx.upload((1_700_000_000 + np.cumsum(rng.integers(0, 3, size=nt))).astype(np.int64), pack)
+vcol = ctx.upload(rng.standard_normal(nt), pack)
+t_host_from = 1_700_000_000
+for nbk in (1 << 10, 1 << 16):
+    stepw = int(2 * nt / nbk) + 1
+    for fn in (R.Mean, R.StdJoin):
+        rec("literal window reducer %-8s 2^24 rows -> %d windows (whole call)" % (fn.name, nbk),
+            timeit(lambda: ctx.reduce_buckets_sequential(tcol, vcol, fn, t_host_from, stepw, nbk, assume_sorted=True), reps=3, warm=1), nt * 16)
