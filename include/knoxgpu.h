@@ -396,10 +396,13 @@ int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mas
 /* Time-window aggregation ("next" row f1): what pkg/series feeds row-at-a-time into
  * NativeBucket.Push (internal/reducer/bucket_native.go:104-159): one reducer per window
  * [t_from + k*step, t_from + (k+1)*step), k < n_buckets, over the rows `mask` selects.
- * time_col is an int64 column (the reference's time field is int64 internally) that must be
- * NON-DECREASING over the scanned rows -- then every window is one contiguous row range and the
- * result equals the reference's for any reducer; out-of-order timestamps (which the reference
- * handles by inserting reducers) return KNOX_E_UNSUPPORTED so the caller keeps the host path.
+ * time_col is an int64 column (the reference's time field is int64 internally).  When it is
+ * NON-DECREASING over the scanned rows every window is one contiguous row range and is reduced in
+ * place.  Out-of-order timestamps (the reference finds / inserts the window's reducer by time,
+ * bucket_native.go:123-141) take a second path: the selected rows are sorted by window index
+ * (stable, so each window keeps its stream order), the values gathered, and the same reduction runs
+ * on the gathered rows; row ids in the states are the caller's.  Either way window k's state is
+ * what the reference's reducer for that window saw.
  * states[k] is the window's mergeable state (count == 0: the reference created no reducer).
  * flags bit0: the caller guarantees the order, skip the verification pass.
  * flags bit1: also run the var/std second pass per window (states carry the m_* moments).    */
@@ -412,7 +415,7 @@ int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col 
  * and the join reducers KNOX_R_*_JOIN (reducer.go:432-731; join = the row's raw timestamp equals
  * the previous selected row's, pkg/series/series.go:200-203) included.  values_out holds
  * n_buckets values of the column's type, seen_out[k] = Value()'s ok (0: no reducer / no group).
- * Same ordering contract and flags bit0 as knox_reduce_buckets.                              */
+ * Needs a non-decreasing time column (KNOX_E_UNSUPPORTED otherwise); flags bit0 as above.      */
 int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                                    const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                                    size_t n_buckets, int func, int flags, void *values_out, uint8_t *seen_out);

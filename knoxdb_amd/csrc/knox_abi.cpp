@@ -2837,6 +2837,104 @@ KNOX_API int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_
     return KNOX_OK;
 }
 
+// windows -> states on the device: each window's row range [start[k], start[k+1]) of `vals` is cut into work
+// items, reduced, and merged per window in row order.  *states_dev = AggStateDev[n_buckets] inside ctx->tmp_vals.
+static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint32_t *mask, size_t n_rows, uint64_t row_base,
+                          const std::vector<uint64_t> &start, size_t n_buckets, int flags, char **states_dev) {
+    const int width = dtype_width(dtype);
+    const uint64_t chunk = 1u << 16;
+    std::vector<BucketItem> items;
+    std::vector<uint32_t> item_start(n_buckets + 1);
+    for (size_t k = 0; k < n_buckets; k++) {
+        item_start[k] = (uint32_t)items.size();
+        for (uint64_t b = start[k]; b < start[k + 1]; b += chunk) {
+            BucketItem it;
+            it.begin = b;
+            it.end = std::min<uint64_t>(b + chunk, start[k + 1]);
+            it.bucket = (uint32_t)k;
+            it._pad = 0;
+            items.push_back(it);
+        }
+    }
+    item_start[n_buckets] = (uint32_t)items.size();
+    const size_t n_items = items.size();
+    const size_t off_items = 0, off_istart = (n_items * sizeof(BucketItem) + 63) & ~(size_t)63;
+    const size_t off_partials = (off_istart + (n_buckets + 1) * 4 + 63) & ~(size_t)63;
+    const size_t off_states = (off_partials + n_items * sizeof(AggPartial) + 63) & ~(size_t)63;
+    int rc = ensure(ctx, ctx->tmp_vals, off_states + n_buckets * sizeof(AggStateDev) + 64);
+    if (rc) return rc;
+    char *base = (char *)ctx->tmp_vals.p;
+    if (n_items) HIPCHK(ctx, hipMemcpyAsync(base + off_items, items.data(), n_items * sizeof(BucketItem), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(base + off_istart, item_start.data(), (n_buckets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors are not retained
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.agg_col = vals;
+    a.agg_flavor = dtype_flavor(dtype);
+    a.mask = mask;
+    a.n_rows = n_rows;
+    a.row_base = row_base;
+    a.partials = (AggPartial *)(base + off_partials);
+    const int grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cus * 8);
+    hipError_t e = launch_bucket_reduce(ctx->stream, width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
+    if (e == hipSuccess)
+        e = launch_bucket_finalize(ctx->stream, width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, vals, row_base, dtype,
+                                   (AggStateDev *)(base + off_states));
+    if (e == hipSuccess && (flags & 2)) {
+        // var/std: second pass over the same work items, each centred on its window's mean
+        rc = ensure(ctx, ctx->mom_partials, (n_items + 1) * 4 * sizeof(double));
+        if (rc) return rc;
+        e = launch_bucket_moments(ctx->stream, width, a.agg_flavor, grid, vals, a.mask, (const BucketItem *)(base + off_items), (uint32_t)n_items,
+                                  (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, (AggStateDev *)(base + off_states),
+                                  (double *)ctx->mom_partials.p);
+    }
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    *states_dev = base + off_states;
+    return KNOX_OK;
+}
+
+// out-of-order timestamps (bucket_native.go:123-141 finds / inserts the window's reducer by time): the selected rows
+// are brought into window order by a STABLE sort of (window index, row id) -- rows of one window keep their stream
+// order, which is all the reducers can observe -- the values are gathered, and the ordered pipeline runs on the
+// gathered column; the row ids inside the states are mapped back through the permutation.
+static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
+                                    int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
+    const size_t n_rows = value_col->n_rows;
+    if (n_rows > 0xfffffff0ull) return KNOX_E_UNSUPPORTED;
+    const size_t w = (size_t)value_col->width;
+    const size_t arr = (n_rows * 4 + 255) & ~(size_t)255;
+    size_t tmp_bytes = 0;
+    unsigned key_bits = 1;
+    while ((1ull << key_bits) <= n_buckets) key_bits++;  // keys 0..n_buckets (n_buckets = not selected / outside every window)
+    hipError_t e = launch_sort_pairs_u32(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, n_rows, key_bits, ctx->stream);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+    const size_t off_vals = 4 * arr + tmp_bytes;
+    int rc = ensure(ctx, ctx->idx_rows, off_vals + n_rows * w + 256);
+    if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + 64);
+    if (rc) return rc;
+    char *sb = (char *)ctx->idx_rows.p;
+    uint32_t *k0 = (uint32_t *)sb, *k1 = (uint32_t *)(sb + arr), *i0 = (uint32_t *)(sb + 2 * arr), *i1 = (uint32_t *)(sb + 3 * arr);
+    void *tmp = sb + 4 * arr;
+    void *gathered = sb + off_vals;
+    e = launch_window_keys(ctx->stream, (const int64_t *)time_col->dev, n_rows, mask ? (const uint8_t *)mask->dev : nullptr, t_from, step,
+                           (uint32_t)n_buckets, k0, i0);
+    if (e == hipSuccess) e = launch_sort_pairs_u32(tmp, tmp_bytes, k0, k1, i0, i1, n_rows, key_bits, ctx->stream);
+    if (e == hipSuccess) e = launch_gather_rows(ctx->stream, (int)w, value_col->dev, i1, n_rows, gathered);
+    uint64_t *d_start = (uint64_t *)ctx->idx_scratch.p;
+    if (e == hipSuccess) e = launch_key_bounds(ctx->stream, k1, n_rows, (uint32_t)n_buckets, d_start);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    std::vector<uint64_t> start(n_buckets + 1);
+    HIPCHK(ctx, hipMemcpyAsync(start.data(), d_start, (n_buckets + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    char *st = nullptr;
+    rc = reduce_windows(ctx, gathered, value_col->dtype, nullptr, (size_t)start[n_buckets], 0, start, n_buckets, flags, &st);
+    if (rc) return rc;
+    e = launch_remap_rows(ctx->stream, (AggStateDev *)st, (uint32_t)n_buckets, i1, row_base);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    return download(ctx, states, st, n_buckets * sizeof(AggStateDev));
+}
+
 KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
                                  int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
     if (!ctx || !time_col || !value_col || !states || step <= 0 || n_buckets == 0 || n_buckets > (1u << 26)) return KNOX_E_INVALID;
@@ -2866,57 +2964,12 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
     HIPCHK(ctx, hipMemcpyAsync(start.data(), d_start, (n_buckets + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!(flags & 1)) HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (unsorted) return KNOX_E_UNSUPPORTED;  // out-of-order timestamps: the reference's insert path, host only
-    // 3. work items: each window's row range cut into chunks
-    const uint64_t chunk = 1u << 16;
-    std::vector<BucketItem> items;
-    std::vector<uint32_t> item_start(n_buckets + 1);
-    for (size_t k = 0; k < n_buckets; k++) {
-        item_start[k] = (uint32_t)items.size();
-        for (uint64_t b = start[k]; b < start[k + 1]; b += chunk) {
-            BucketItem it;
-            it.begin = b;
-            it.end = std::min<uint64_t>(b + chunk, start[k + 1]);
-            it.bucket = (uint32_t)k;
-            it._pad = 0;
-            items.push_back(it);
-        }
-    }
-    item_start[n_buckets] = (uint32_t)items.size();
-    const size_t n_items = items.size();
-    const size_t off_items = 0, off_istart = (n_items * sizeof(BucketItem) + 63) & ~(size_t)63;
-    const size_t off_partials = (off_istart + (n_buckets + 1) * 4 + 63) & ~(size_t)63;
-    const size_t off_states = (off_partials + n_items * sizeof(AggPartial) + 63) & ~(size_t)63;
-    rc = ensure(ctx, ctx->tmp_vals, off_states + n_buckets * sizeof(AggStateDev) + 64);
+    if (unsorted) return reduce_buckets_unordered(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, states);
+    // 3. reduce the windows' row ranges
+    char *st = nullptr;
+    rc = reduce_windows(ctx, value_col->dev, value_col->dtype, mask ? (const uint32_t *)mask->dev : nullptr, n_rows, row_base, start, n_buckets, flags, &st);
     if (rc) return rc;
-    char *base = (char *)ctx->tmp_vals.p;
-    if (n_items) HIPCHK(ctx, hipMemcpyAsync(base + off_items, items.data(), n_items * sizeof(BucketItem), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(base + off_istart, item_start.data(), (n_buckets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors are not retained
-    // 4. reduce every work item, then merge per window in row order
-    ScanArgs a;
-    memset(&a, 0, sizeof a);
-    a.agg_col = value_col->dev;
-    a.agg_flavor = dtype_flavor(value_col->dtype);
-    a.mask = mask ? (const uint32_t *)mask->dev : nullptr;
-    a.n_rows = n_rows;
-    a.row_base = row_base;
-    a.partials = (AggPartial *)(base + off_partials);
-    const int grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cus * 8);
-    e = launch_bucket_reduce(ctx->stream, value_col->width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
-    if (e == hipSuccess)
-        e = launch_bucket_finalize(ctx->stream, value_col->width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, value_col->dev,
-                                   row_base, value_col->dtype, (AggStateDev *)(base + off_states));
-    if (e == hipSuccess && (flags & 2)) {
-        // var/std: second pass over the same work items, each centred on its window's mean
-        rc = ensure(ctx, ctx->mom_partials, (n_items + 1) * 4 * sizeof(double));
-        if (rc) return rc;
-        e = launch_bucket_moments(ctx->stream, value_col->width, a.agg_flavor, grid, value_col->dev, a.mask, (const BucketItem *)(base + off_items),
-                                  (uint32_t)n_items, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, (AggStateDev *)(base + off_states),
-                                  (double *)ctx->mom_partials.p);
-    }
-    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-    return download(ctx, states, base + off_states, n_buckets * sizeof(AggStateDev));
+    return download(ctx, states, st, n_buckets * sizeof(AggStateDev));
 }
 
 // bytesRegexpMatcher.MatchVector (match_bytes.go:587-609): bits.Set(i) for every (masked) row the pattern matches

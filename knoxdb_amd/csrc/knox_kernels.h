@@ -230,6 +230,14 @@ hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);
 
 // literal sequential reducer (one lane)
+// out-of-order time windows (knox_sort.hip)
+hipError_t launch_window_keys(hipStream_t s, const int64_t *time, uint64_t n_rows, const uint8_t *mask, int64_t t_from, int64_t step,
+                              uint32_t n_buckets, uint32_t *keys, uint32_t *idx);
+hipError_t launch_sort_pairs_u32(void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
+                                 uint32_t *vals_out, size_t n, unsigned key_bits, hipStream_t s);
+hipError_t launch_gather_rows(hipStream_t s, int width, const void *src, const uint32_t *idx, uint64_t n, void *dst);
+hipError_t launch_key_bounds(hipStream_t s, const uint32_t *keys, uint64_t n, uint32_t n_buckets, uint64_t *start);
+hipError_t launch_remap_rows(hipStream_t s, AggStateDev *states, uint32_t n_buckets, const uint32_t *idx, uint64_t row_base);
 // compiled REGEXP program on the device (knox_regex.h): table | flags | ascii_class are one contiguous image
 struct RegexProg {
     const uint16_t *table;

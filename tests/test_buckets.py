@@ -81,10 +81,65 @@ def test_gpu_buckets_match_native_bucket_semantics():
                                 assert K.agg_value(states[k], R.Mean)[0] == npdt(exact_mean)
                 vcol.free()
             tcol.free(); mask.free()
-        # out-of-order timestamps are refused, not silently mis-aggregated
+        # out-of-order timestamps: the reference finds / inserts the window's reducer by time
+        # (bucket_native.go:123-141); the device sorts the selected rows by window (stable) and reduces
+        for n, step, frac in ((600, 4, 0.5), (200000, 50, 0.02), (1 << 20, 1000, 0.3), (5000, 7, 1.0)):
+            base = 1_700_000_000 + np.cumsum(rng.integers(0, 3, size=n))
+            t = base.copy()
+            k = max(1, int(n * frac))
+            where = rng.integers(0, n, size=k)
+            t[where] = base[rng.integers(0, n, size=k)]          # rows carrying some other row's timestamp
+            t = t.astype(np.int64)
+            t_from = int(t.min()) + 5                             # some rows before the first window
+            nb = int((t.max() - t_from) // step)                  # and some after the last
+            nb = max(nb, 1)
+            inside = (t >= t_from) & (t < t_from + nb * step)
+            tcol = ctx.upload(t, 4096)
+            bits_h = np.packbits(rng.random(n) < 0.7, bitorder="little")
+            mask = ctx.bits(n).upload(bits_h)
+            for bt_k, o, npdt in ((BlockType.Int64, O.I64, np.int64), (BlockType.Float64, O.F64, np.float64), (BlockType.Uint16, O.U16, np.uint16),
+                                  (BlockType.Int8, O.I8, np.int8), (BlockType.Float32, O.F32, np.float32)):
+                if np.dtype(npdt).kind == "f":
+                    v = (rng.integers(0, 1 << 20, n) / 1024.0).astype(npdt)
+                    v[rng.integers(0, n, 5)] = np.nan
+                else:
+                    info = np.iinfo(npdt)
+                    v = rng.integers(info.min, info.max, n, endpoint=True, dtype=npdt)
+                vcol = ctx.upload(v, 4096)
+                for m, mh in ((None, None), (mask, bits_h)):
+                    states = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=m, row_base=1000, moments=True)
+                    sel = np.unpackbits(mh, bitorder="little")[:n].astype(bool) if mh is not None else np.ones(n, bool)
+                    sel_in = np.packbits(sel & inside, bitorder="little")   # the oracle has no upper window limit: cut there
+                    for f in FUNCS:
+                        if npdt == np.float32 and f == O.R_SUM:
+                            continue
+                        if np.dtype(npdt).kind == "f" and f == O.R_SUM:
+                            vv = np.where(np.isnan(v), 0, v)               # NaN sums compared separately below
+                            if np.isnan(v[sel & inside]).any():
+                                continue
+                        want_t, want_v = O.buckets(o, f, t, v, sel_in, t_from, step)
+                        order = np.argsort(want_t, kind="stable")          # Emit walks the windows in time order
+                        got = [(t_from + k * step, K.agg_value(st, KF[f])[0]) for k, st in enumerate(states) if st.count > 0]
+                        assert [g[0] for g in got] == want_t[order].tolist(), (n, f)
+                        gv = np.array([g[1] for g in got], dtype=npdt)
+                        assert gv.tobytes() == want_v[order].tobytes(), (n, bt_k, f)
+                    # row ids inside the states are the caller's rows (+ row_base)
+                    win = (t - t_from) // step
+                    for k in (0, nb // 3, nb - 1):
+                        rows = np.flatnonzero(sel & inside & (win == k))
+                        if rows.size:
+                            assert states[k].first_row == rows[0] + 1000 and states[k].last_row == rows[-1] + 1000
+                            assert states[k].count == rows.size
+                            if npdt == np.int8 and rows.size > 1:       # the var/std second pass runs on the gathered rows too
+                                want_var = np.var(v[rows].astype(np.float64), ddof=1)
+                                if want_var < 127:
+                                    assert K.agg_value(states[k], R.Var)[0] == np.int8(want_var)
+                vcol.free()
+            tcol.free(); mask.free()
+        # the literal per-window mode needs ordered time
         t = np.array([5, 6, 7, 3, 9, 10] * 100, dtype=np.int64)
         tcol, vcol = ctx.upload(t), ctx.upload(np.arange(600, dtype=np.int64))
         with pytest.raises(K.KnoxError) as e:
-            ctx.reduce_buckets(tcol, vcol, 0, 4, 3)
+            ctx.reduce_buckets_sequential(tcol, vcol, R.Sum, 0, 4, 3)
         assert e.value.code == -5
         tcol.free(); vcol.free()
