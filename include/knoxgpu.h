@@ -432,6 +432,19 @@ int knox_agg_value(const knox_agg_state *state, int func, void *value_out, int *
 /* Merge n states of consecutive row ranges (rank order = row order) -- pure host code.      */
 int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out);
 
+/* NativeBucket.Emit's gap filling (bucket_native.go:161-218, Fill fill.go:59-85) over the dense per-window
+ * values of knox_reduce_buckets / _sequential -- pure host code, everything but the string formatting:
+ * window k (time t_from + k*step) with seen[k] emits its value; a window without a reducer is filled per
+ * `mode` from the previous and the next reducer (the reference's start / end behaviour kept: `last`
+ * starts as the first reducer, `next` past the last reducer is `last`).  Linear fill interpolates over
+ * time.Time.Unix() seconds: units_per_second converts the raw time unit (1e9 for nanoseconds).
+ * out_flags[k]: 0 nothing emitted, 1 out_values[k] emitted, 2 null emitted.  At most `limit` entries
+ * are emitted; *n_out = that count.                                                           */
+enum knox_fill_mode { KNOX_FILL_NONE = 0, KNOX_FILL_NULL = 1, KNOX_FILL_LAST = 2, KNOX_FILL_LINEAR = 3, KNOX_FILL_ZERO = 4 };
+int knox_fill_windows(int dtype, int mode, const void *values, const uint8_t *seen, size_t n_buckets,
+                      int64_t t_from, int64_t step, int64_t units_per_second, size_t limit, void *out_values,
+                      uint8_t *out_flags, size_t *n_out);
+
 /* ---- bloom pre-filter: internal/filter/bloom/bloom.go:136-150,182 -------------------- *
  * A knox_bloom holds the per-pack filters of one column resident on the device: n_packs
  * serialized filters [k][m/8 bytes] (bloom.go:48-60,83-101) concatenated, offsets[n_packs+1]

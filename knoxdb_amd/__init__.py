@@ -7,4 +7,4 @@ falls back to a CPU implementation: without the built library importing the engi
 from .types import BlockType, FilterMode, ReducerFunc  # noqa: F401
 from ._lib import KnoxError, SO_PATH  # noqa: F401
 from .engine import (And, Bits, Column, Context, Leaf, Or, agg_combine, agg_value, device_count,  # noqa: F401
-                     hash_bytes, hash_value, regexp_match_value)
+                     fill_windows, hash_bytes, hash_value, regexp_match_value)

@@ -134,6 +134,7 @@ SIGNATURES = {
     "knox_reduce_buckets_sequential": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _i, _i, _vp, _vp]),
     "knox_reduce_sequential": (_i, [_vp, _vp, _vp, _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_value": (_i, [C.POINTER(AggState), _i, _vp, _pi, C.POINTER(_i64)]),
+    "knox_fill_windows": (_i, [_i, _i, _vp, _vp, _sz, _i64, _i64, _i64, _sz, _vp, _vp, C.POINTER(_sz)]),
     "knox_agg_combine": (_i, [C.POINTER(AggState), _i, C.POINTER(AggState)]),
     "knox_bloom_upload": (_i, [_vp, _vp, _vp, _sz, _pp]),
     "knox_bloom_build": (_i, [_vp, _vp, _i, _pp]),

@@ -3175,6 +3175,80 @@ static uint64_t order_key(int dtype, uint64_t bits) {
     return dtype_is_signed(dtype) ? (bits ^ sign) : bits;
 }
 
+// ---- NativeBucket.Emit's gap filling over dense per-window values (pure host code) --------------
+// bucket_native.go:161-218 walks the windows from trange.From; a window without a reducer is filled by
+// Fill(mode, step, last.Time(), next.Time(), lastVal, nextVal) (fill.go:59-85), where `last` starts as the
+// FIRST reducer and `next` is the next reducer or, past the last one, `last` again -- quirks kept: a gap before
+// the first window is "filled" from the first reducer, linear fill outside the reducers divides 0 by 0.
+template <typename T>
+static size_t fill_windows(int mode, const T *vals, const uint8_t *seen, size_t n, int64_t t_from, int64_t step, int64_t ups, size_t limit,
+                           T *out, uint8_t *flags) {
+    memset(flags, 0, n);
+    size_t first = 0;
+    while (first < n && !seen[first]) first++;
+    if (first == n) return 0;  // no reducers: Emit writes nothing
+    auto unix_s = [&](size_t k) {  // time.Time.Unix(): seconds, floored
+        const int64_t t = t_from + (int64_t)k * step;
+        int64_t q = t / ups;
+        if ((t % ups != 0) && ((t < 0) != (ups < 0))) q--;
+        return q;
+    };
+    size_t last = first, next_seen = first, count = 0;
+    for (size_t k = 0; k < n && count < limit; k++) {
+        while (next_seen < n && (next_seen < k || !seen[next_seen])) next_seen++;  // reducers[idx]
+        const size_t next = next_seen < n ? next_seen : last;
+        if (next != k) {
+            switch (mode) {
+            case KNOX_FILL_NULL: out[k] = 0; flags[k] = 2; count++; break;
+            case KNOX_FILL_LAST: out[k] = vals[last]; flags[k] = 1; count++; break;
+            case KNOX_FILL_ZERO: out[k] = 0; flags[k] = 1; count++; break;
+            case KNOX_FILL_LINEAR: {
+                // linearFill (fill.go:56-61): the slope between (prevTime, prevVal) and (nextTime, nextVal), in seconds
+                const double m = (double)(T)(vals[next] - vals[last]) / (double)(unix_s(next) - unix_s(last));
+                const double x = (double)(unix_s(k) - unix_s(last));
+                const double b = (double)vals[last];
+                out[k] = (T)(m * x + b);
+                flags[k] = 1;
+                count++;
+                break;
+            }
+            default: break;  // none
+            }
+            continue;
+        }
+        out[k] = vals[k];
+        flags[k] = 1;
+        count++;
+        last = k;
+    }
+    return count;
+}
+
+KNOX_API int knox_fill_windows(int dtype, int mode, const void *values, const uint8_t *seen, size_t n_buckets, int64_t t_from, int64_t step,
+                               int64_t units_per_second, size_t limit, void *out_values, uint8_t *out_flags, size_t *n_out) {
+    if (!values || !seen || !out_values || !out_flags || step <= 0 || units_per_second <= 0) return KNOX_E_INVALID;
+    if (mode < KNOX_FILL_NONE || mode > KNOX_FILL_ZERO) return KNOX_E_INVALID;
+    if ((__int128)t_from + (__int128)step * (__int128)n_buckets > (__int128)INT64_MAX) return KNOX_E_RANGE;
+    size_t c;
+#define KNOX_FILL(T) c = fill_windows<T>(mode, (const T *)values, seen, n_buckets, t_from, step, units_per_second, limit, (T *)out_values, out_flags); break
+    switch (dtype) {
+    case KNOX_INT64: KNOX_FILL(int64_t);
+    case KNOX_INT32: KNOX_FILL(int32_t);
+    case KNOX_INT16: KNOX_FILL(int16_t);
+    case KNOX_INT8: KNOX_FILL(int8_t);
+    case KNOX_UINT64: KNOX_FILL(uint64_t);
+    case KNOX_UINT32: KNOX_FILL(uint32_t);
+    case KNOX_UINT16: KNOX_FILL(uint16_t);
+    case KNOX_UINT8: KNOX_FILL(uint8_t);
+    case KNOX_FLOAT64: KNOX_FILL(double);
+    case KNOX_FLOAT32: KNOX_FILL(float);
+    default: return KNOX_E_INVALID;
+    }
+#undef KNOX_FILL
+    if (n_out) *n_out = c;
+    return KNOX_OK;
+}
+
 KNOX_API int knox_agg_combine(const knox_agg_state *states, int n, knox_agg_state *out) {
     if (!states || !out || n <= 0) return KNOX_E_INVALID;
     knox_agg_state r = states[0];

@@ -604,6 +604,22 @@ def hash_bytes(val):
     return _lib.lib().knox_hash_bytes(v, len(v))
 
 
+FILL_MODES = {"none": 0, "null": 1, "last": 2, "linear": 3, "zero": 4}
+
+
+def fill_windows(dtype, mode, values, seen, t_from, step, units_per_second=1, limit=None):
+    """NativeBucket.Emit's gap filling over dense per-window values -> (values, flags 0/1/2, emitted count)"""
+    vals = np.ascontiguousarray(values, dtype=NP_DTYPE[BlockType(dtype)])
+    sn = np.ascontiguousarray(seen, dtype=np.uint8)
+    out = np.zeros_like(vals)
+    flags = np.zeros(vals.size, dtype=np.uint8)
+    n = C.c_size_t()
+    check(_lib.lib().knox_fill_windows(int(dtype), FILL_MODES[mode] if isinstance(mode, str) else int(mode), _ptr(vals), _ptr(sn), vals.size,
+                                       t_from, step, units_per_second, vals.size if limit is None else limit, _ptr(out), _ptr(flags), C.byref(n)),
+          "knox_fill_windows")
+    return out, flags, n.value
+
+
 def regexp_match_value(pattern, value):
     """bytesRegexpMatcher.MatchValue for one value (host): True / False; KnoxError(UNSUPPORTED) outside the subset"""
     pat = pattern.encode() if isinstance(pattern, str) else bytes(pattern)

@@ -358,3 +358,50 @@ def simd_scan_i64_bw_sum(src, pack_rows, a, b, threads, bits=None):
     s = C.c_int64()
     cnt = lib().ko_simd_scan_i64_bw_sum(_p(src), src.size, pack_rows, a, b, _p(bits), threads, C.byref(s))
     return bits, cnt, s.value
+
+
+def emit_fill(dtype, mode, reducers, t_from, t_to, step, units_per_second=1, limit=None):
+    """NativeBucket.Emit (internal/reducer/bucket_native.go:161-218) with Fill / linearFill (fill.go:56-85), minus
+    the string formatting: reducers = [(window time, value)] sorted by time -> [(window time, value | None)] in
+    emission order (None = the JSON null of FillModeNull).  Pure Python, small cases only."""
+    T = NP[dtype]
+    is_float = np.dtype(T).kind == "f"
+    out = []
+    if not reducers:
+        return out
+    limit = limit if limit is not None else 1 << 62
+    last, idx = reducers[0], 0
+
+    def unix(t):
+        return t // units_per_second          # time.Time.Unix(): floored seconds
+
+    step_t = t_from
+    while step_t <= t_to and len(out) < limit:
+        nxt = reducers[idx] if idx < len(reducers) else last
+        if nxt[0] != step_t:
+            if mode == "null":
+                out.append((step_t, None))
+            elif mode == "last":
+                out.append((step_t, T(last[1])))
+            elif mode == "zero":
+                out.append((step_t, T(0)))
+            elif mode == "linear":
+                with np.errstate(all="ignore"):
+                    diff = T(nxt[1]) - T(last[1])          # in T: wraps for integers
+                    den = np.float64(unix(nxt[0]) - unix(last[0]))
+                    m = np.float64(diff) / den             # 0/0 -> NaN, x/0 -> Inf as in Go
+                    x = np.float64(unix(step_t) - unix(last[0]))
+                    y = m * x + np.float64(last[1])
+                    if is_float:
+                        out.append((step_t, T(y)))
+                    else:
+                        info = np.iinfo(T)
+                        ok = np.isfinite(y) and info.min <= np.trunc(y) <= info.max and abs(y) < 2.0 ** 63
+                        out.append((step_t, T(np.trunc(y)) if ok else "platform-defined"))
+            step_t += step
+            continue
+        out.append((step_t, T(nxt[1])))
+        idx += 1
+        last = nxt
+        step_t += step
+    return out
