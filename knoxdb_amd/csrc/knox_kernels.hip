@@ -1549,8 +1549,10 @@ __global__ void __launch_bounds__(kBlock) bitop_kernel(uint64_t *dst, const uint
         const bool wany = __any(any != 0);
         const bool wnot = __any(notall != 0);
         if ((threadIdx.x & 63) == 0) {
-            if (wany) atomicOr(&flags[0], 1u);
-            if (wnot) atomicOr(&flags[1], 1u);
+            // same-address atomics serialize in L2 (16K waves -> ~0.2 ms): look first, only the first few waves that
+            // find the flag clear pay for the read-modify-write
+            if (wany && __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[0], 1u);
+            if (wnot && __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[1], 1u);
         }
     }
 }
@@ -1581,7 +1583,15 @@ __global__ void __launch_bounds__(kBlock) popcount_kernel(const uint64_t *bits, 
         c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+    __shared__ uint64_t sm[kBlock / 64];  // one atomic per workgroup: same-address atomics serialize in L2
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sm[w];
+        if (t) atomicAdd(out, (unsigned long long)t);
+    }
 }
 
 hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bits, unsigned long long *count_out) {
