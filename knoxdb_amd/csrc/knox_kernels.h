@@ -35,6 +35,8 @@ struct AggPartial {
     uint64_t minkey, minrow;
     uint64_t maxkey, maxrow;
     uint64_t firstrow, lastrow;
+    uint64_t xlo;   // integer columns: exact 128-bit sum (xhi:xlo)
+    int64_t xhi;
 };
 
 struct ScanArgs {

@@ -152,18 +152,42 @@ __device__ __forceinline__ void dd_add(double &hi, double &lo, double h2, double
     hi = s;
 }
 
+// exact 128-bit integer sum (|S| < 2^106, true for any column that fits one GPU) -> double-double with hi + lo == S
+__device__ __forceinline__ void int128_to_dd(uint64_t xlo, int64_t xhi, double &hi, double &lo) {
+    const double p1 = (double)xhi * 18446744073709551616.0;            // exact: |xhi| < 2^42
+    const double p2 = (double)(uint32_t)(xlo >> 32) * 4294967296.0;    // exact
+    const double p3 = (double)(uint32_t)xlo;                            // exact
+    double s = p1 + p2;
+    double bb = s - p1;
+    const double e1 = (p1 - (s - bb)) + (p2 - bb);                      // TwoSum: exact
+    const double s2 = s + p3;
+    bb = s2 - s;
+    const double e2 = (s - (s2 - bb)) + (p3 - bb);
+    const double l = e1 + e2;                                           // integers below 2^54: exact
+    hi = s2 + l;                                                        // renormalize (Fast2Sum, |s2| >= |l|)
+    lo = l - (hi - s2);
+}
+
 struct Acc {
     uint64_t count, isum;
-    double hi, lo;
+    double hi, lo;        // float columns: double-double sum of the selected values
+    uint64_t xlo;         // integer columns: the EXACT 128-bit sum of the selected values (xhi:xlo, two's complement) --
+    int64_t xhi;          // what Mean / Var need instead of a float64 running sum (finalize turns it into hi + lo)
     uint64_t minkey, minrow, maxkey, maxrow, firstrow, lastrow1;  // lastrow1 = row + 1, 0 = none
+    __device__ __forceinline__ void add128(uint64_t v, int64_t vhi) {
+        const uint64_t t = xlo + v;
+        xhi += vhi + (int64_t)(t < v);
+        xlo = t;
+    }
     __device__ __forceinline__ void init() {
-        count = 0; isum = 0; hi = 0.0; lo = 0.0;
+        count = 0; isum = 0; hi = 0.0; lo = 0.0; xlo = 0; xhi = 0;
         minkey = 0; minrow = kNoRow; maxkey = 0; maxrow = kNoRow; firstrow = kNoRow; lastrow1 = 0;
     }
     __device__ __forceinline__ void merge(const Acc &b) {
         count += b.count;
         isum += b.isum;
         dd_add(hi, lo, b.hi, b.lo);
+        add128(b.xlo, b.xhi);
         if (b.minrow != kNoRow && (minrow == kNoRow || b.minkey < minkey || (b.minkey == minkey && b.minrow < minrow))) {
             minkey = b.minkey; minrow = b.minrow;
         }
@@ -174,6 +198,14 @@ struct Acc {
         lastrow1 = b.lastrow1 > lastrow1 ? b.lastrow1 : lastrow1;
     }
 };
+
+// the value sign-extended to 64 bit (two's complement)
+template <int W> __device__ __forceinline__ uint64_t sext_u64(typename WT<W>::U e) {
+    if constexpr (W == 8) return (uint64_t)e;
+    else if constexpr (W == 4) return (uint64_t)(int64_t)(int32_t)e;
+    else if constexpr (W == 2) return (uint64_t)(int64_t)(int16_t)e;
+    else return (uint64_t)(int64_t)(int8_t)e;
+}
 
 // value -> float64 exactly as Go's float64(v) conversion of the column type
 template <int W> __device__ __forceinline__ double to_f64(typename WT<W>::U e, uint32_t flavor) {
@@ -199,9 +231,14 @@ __device__ __forceinline__ void acc_update(Acc &acc, typename WT<W>::U e, uint32
         acc.isum += hit ? (uint64_t)e : 0ull;
     }
     if constexpr ((AGG & A_FSUM) != 0) {
-        double x = to_f64<W>(e, flavor);
-        x = hit ? x : 0.0;
-        dd_add(acc.hi, acc.lo, x, 0.0);
+        if (flavor == FL_FLOAT) {
+            double x = to_f64<W>(e, flavor);
+            x = hit ? x : 0.0;
+            dd_add(acc.hi, acc.lo, x, 0.0);
+        } else if (hit) {
+            const uint64_t v = flavor == FL_SIGNED ? sext_u64<W>(e) : (uint64_t)e;
+            acc.add128(v, flavor == FL_SIGNED ? (int64_t)v >> 63 : 0);
+        }
     }
     if constexpr ((AGG & A_MINMAX) != 0) {
         // MinReducer / MaxReducer (reducer.go:256-296): strict compare, first occurrence wins;
@@ -324,7 +361,7 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
             for (int j = 0; j < K; j++) acc.isum += ((q[u] >> j) & 1u) ? (uint64_t)elem<W>(r[u], j) : 0ull;
         }
     }
-    if constexpr ((AGG & A_FSUM) != 0) {
+    if constexpr ((AGG & A_FSUM) != 0 && FLV == FL_FLOAT) {
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
 #pragma unroll
@@ -336,6 +373,31 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
                 acc.lo += (acc.hi - (s - bb)) + (x - bb);
                 acc.hi = s;
             }
+        }
+    }
+    if constexpr ((AGG & A_FSUM) != 0 && FLV != FL_FLOAT) {
+        // integers: the exact sum.  8-byte values carry into the high word one by one; narrower values cannot
+        // overflow 64 bits within one iteration (<= 64 values), so the iteration's sum is added once
+        if constexpr (W == 8) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const uint64_t v = ((q[u] >> j) & 1u) ? (uint64_t)elem<W>(r[u], j) : 0ull;
+                    acc.add128(v, FLV == FL_SIGNED ? (int64_t)v >> 63 : 0);
+                }
+            }
+        } else {
+            uint64_t it = 0;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const uint64_t v = FLV == FL_SIGNED ? sext_u64<W>(elem<W>(r[u], j)) : (uint64_t)elem<W>(r[u], j);
+                    it += ((q[u] >> j) & 1u) ? v : 0ull;
+                }
+            }
+            acc.add128(it, FLV == FL_SIGNED ? (int64_t)it >> 63 : 0);
         }
     }
     if constexpr ((AGG & A_MINMAX) != 0) {
@@ -380,6 +442,8 @@ __device__ __forceinline__ void wave_reduce(Acc &a) {
         b.isum = shfl_down_u64(a.isum, off);
         b.hi = shfl_down_f64(a.hi, off);
         b.lo = shfl_down_f64(a.lo, off);
+        b.xlo = shfl_down_u64(a.xlo, off);
+        b.xhi = (int64_t)shfl_down_u64((uint64_t)a.xhi, off);
         b.minkey = shfl_down_u64(a.minkey, off);
         b.minrow = shfl_down_u64(a.minrow, off);
         b.maxkey = shfl_down_u64(a.maxkey, off);
@@ -401,7 +465,7 @@ __device__ __forceinline__ void block_reduce_store(Acc &acc, AggPartial *out) {
         Acc t = sm[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); w++) t.merge(sm[w]);
         AggPartial p;
-        p.count = t.count; p.isum = t.isum; p.hi = t.hi; p.lo = t.lo;
+        p.count = t.count; p.isum = t.isum; p.hi = t.hi; p.lo = t.lo; p.xlo = t.xlo; p.xhi = t.xhi;
         p.minkey = t.minkey; p.minrow = t.minrow; p.maxkey = t.maxkey; p.maxrow = t.maxrow;
         p.firstrow = t.firstrow; p.lastrow = t.lastrow1;
         *out = p;
@@ -766,7 +830,7 @@ __global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *part
     for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
         const AggPartial p = partials[i];
         Acc b;
-        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo;
+        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo; b.xlo = p.xlo; b.xhi = p.xhi;
         b.minkey = p.minkey; b.minrow = p.minrow; b.maxkey = p.maxkey; b.maxrow = p.maxrow;
         b.firstrow = p.firstrow; b.lastrow1 = p.lastrow;
         acc.merge(b);
@@ -787,6 +851,7 @@ __global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *part
             s.isum = t.isum;
             s.fsum_hi = t.hi;
             s.fsum_lo = t.lo;
+            if (dtype <= 8) int128_to_dd(t.xlo, t.xhi, s.fsum_hi, s.fsum_lo);
             s.min_row = t.minrow == kNoRow ? -1 : (int64_t)t.minrow;
             s.max_row = t.maxrow == kNoRow ? -1 : (int64_t)t.maxrow;
             s.first_row = t.firstrow == kNoRow ? -1 : (int64_t)t.firstrow;
@@ -1207,7 +1272,7 @@ __global__ void __launch_bounds__(kBlock) bucket_finalize_kernel(const AggPartia
     for (uint32_t i = item_start[k]; i < item_start[k + 1]; i++) {
         const AggPartial p = partials[i];
         Acc b;
-        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo;
+        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo; b.xlo = p.xlo; b.xhi = p.xhi;
         b.minkey = p.minkey; b.minrow = p.minrow; b.maxkey = p.maxkey; b.maxrow = p.maxrow;
         b.firstrow = p.firstrow; b.lastrow1 = p.lastrow;
         t.merge(b);
@@ -1219,6 +1284,7 @@ __global__ void __launch_bounds__(kBlock) bucket_finalize_kernel(const AggPartia
     s.isum = t.isum;
     s.fsum_hi = t.hi;
     s.fsum_lo = t.lo;
+    if (dtype <= 8) int128_to_dd(t.xlo, t.xhi, s.fsum_hi, s.fsum_lo);
     s.min_row = t.minrow == kNoRow ? -1 : (int64_t)t.minrow;
     s.max_row = t.maxrow == kNoRow ? -1 : (int64_t)t.maxrow;
     s.first_row = t.firstrow == kNoRow ? -1 : (int64_t)t.firstrow;

@@ -42,23 +42,26 @@ def rec(name, ms, nbytes):
     rows.append((name, ms, nbytes / ms / 1e6))
     print("%-58s %9.4f ms %9.1f GB/s  (%.0f%% of 8 TB/s)" % (name, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
 
-bits = ctx.bits(n)
+bits = None
 for bt, w, lo, span, a, b in ((B.Int64, 8, -(1 << 40), 1 << 41, -(1 << 38), 1 << 38), (B.Int32, 4, -(1 << 30), 1 << 31, -(1 << 28), 1 << 28),
                               (B.Int16, 2, -(1 << 15), 1 << 16, -(1 << 13), 1 << 13), (B.Uint8, 1, 0, 256, 64, 127)):
     col = ctx.generate(bt, 0, 2, n, lo=lo, span=span, pack_rows=pack)
+    bits = ctx.bits(n, for_col=col)   # a bitset of the column's placement class
     plan = ctx.plan(And(Leaf(0, F.Range, a, b)), [col], aggs=[(R.Sum, 0)])
     rec("scan %s Between + sum + bitset" % bt.name, scan_ms(plan, bits), n * (w + 0.125))
     plan = ctx.plan(And(Leaf(0, F.Range, a, b)), [col], aggs=[(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.First, 0), (R.Last, 0)])
     rec("scan %s Between + ALL aggs + bitset" % bt.name, scan_ms(plan, bits), n * (w + 0.125))
-    col.free()
+    col.free(); bits.free()
 for bt, w in ((B.Float64, 8), (B.Float32, 4)):
     col = ctx.generate(bt, 2, 4, n, pack_rows=pack)
+    bits = ctx.bits(n, for_col=col)
     plan = ctx.plan(And(Leaf(0, F.Lt, 0.25)), [col], aggs=[(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0)])
     rec("scan %s Lt + sum/min/max/mean + bitset" % bt.name, scan_ms(plan, bits), n * (w + 0.125))
-    col.free()
+    col.free(); bits.free()
 c1 = ctx.generate(B.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=pack)
 c2 = ctx.generate(B.Int64, 0, 3, n, lo=-(1 << 40), span=1 << 41, pack_rows=pack)
 c3 = ctx.generate(B.Float64, 2, 4, n, pack_rows=pack)
+bits = ctx.bits(n, for_col=c1)
 plan = ctx.plan(And(Leaf(0, F.Gt, 0), Or(Leaf(1, F.Lt, 0), Leaf(2, F.Ge, 0.5))), [c1, c2, c3], aggs=[(R.Sum, 0)])
 rec("scan 3 leaves A>0 AND (B<0 OR C>=.5) + sum(A)", scan_ms(plan, bits), n * (24 + 0.125))
 plan = ctx.plan(And(Leaf(0, F.Gt, 0)), [c1, c2], aggs=[(R.Sum, 1)])
