@@ -1839,6 +1839,12 @@ hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bit
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool bytes_equal(const uint8_t *p, const uint8_t *v, uint32_t n) {
     uint32_t i = 0;
+    for (; i + 16 <= n; i += 16) {  // 16-byte pieces: half the load instructions of the row, the value side is wave-uniform
+        u32x4 x, y;
+        __builtin_memcpy(&x, p + i, 16);
+        __builtin_memcpy(&y, v + i, 16);
+        if (((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0) return false;
+    }
     for (; i + 8 <= n; i += 8) {
         uint64_t x, y;
         __builtin_memcpy(&x, p + i, 8);
