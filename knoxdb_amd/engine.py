@@ -206,7 +206,13 @@ class Bits:
         check(_lib.lib().knox_bits_popcount_segments(self.ctx.h, self.h, seg_bits, _ptr(out), n))
         return out
 
-    def indexes(self, capacity=None):
+    def indexes(self, capacity=None, out=None):
+        """Bitset.Indexes.  out: caller's uint32 buffer (e.g. Context.host_array: page-locked, DMA'd in place) ->
+        a view of it, no copy."""
+        if out is not None:
+            n = C.c_size_t()
+            check(_lib.lib().knox_bits_indexes(self.ctx.h, self.h, _ptr(out), out.size, C.byref(n)))
+            return out[:n.value]
         cap = self.count() + 8 if capacity is None else capacity  # Bitset.Indexes pads the result by 7 (iterator.go:277-289)
         out = np.zeros(max(cap, 1), dtype=np.uint32)
         n = C.c_size_t()

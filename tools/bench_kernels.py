@@ -82,7 +82,12 @@ rec("bits segment_counts 2^20 (incl. D2H)", timeit(lambda: bits.segment_counts(p
 ctx.scan(And(Leaf(0, F.Range, -(1 << 34), 1 << 34)), [c1], bits_out=bits)   # ~1.6 % density
 k = bits.count()
 t0 = time.perf_counter(); idx = bits.indexes(); t1 = time.perf_counter()
-rec("bits indexes, %.1f%% density, %d hits (incl. D2H)" % (100.0 * k / n, k), (t1 - t0) * 1e3, nb + 4 * k)
+rec("bits indexes, %.1f%% density, %d hits (incl. D2H to a fresh numpy array)" % (100.0 * k / n, k), (t1 - t0) * 1e3, nb + 4 * k)
+pin = ctx.host_array(k + 8, np.uint32)
+bits.indexes(out=pin)
+t0 = time.perf_counter(); idx = bits.indexes(out=pin); t1 = time.perf_counter()
+rec("bits indexes, same, into knox_host_alloc memory (DMA in place)", (t1 - t0) * 1e3, nb + 4 * k)
+ctx.host_free(pin)
 c1.free()
 # bytes EQ
 L32 = 32
