@@ -203,3 +203,16 @@ def test_gpu_regexp_rows_match_the_oracle():
         ecol = ctx.upload_bytes(np.zeros(0, np.uint64), np.zeros(8, np.uint8))
         eb, ec = ctx.match_regexp(ecol, "a")
         assert ec == 0
+
+
+def test_regexp_compiler_under_sanitizers(tmp_path):
+    """ASan + UBSan over random pattern fragments; also checks every table bound the kernel indexes with."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_regex")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(root, "knoxdb_amd", "csrc"), os.path.join(root, "tests", "cpp", "fuzz_regex.cpp"), "-o", exe])
+    out = subprocess.run([exe, "15000", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "compiled" in out.stdout
