@@ -81,6 +81,11 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     args = ap.parse_args()
 
+    # exactly ONE line goes to stdout: libraries that print banners there (RCCL's version header) are sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -92,7 +97,9 @@ def main():
     backend = os.environ.get("KNOX_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # KNOX_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, barriers, state all-gather over RCCL) even
+    # with one rank -- the rehearsal a 1-GPU box allows for the nccl backend
+    if world > 1 or os.environ.get("KNOX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -123,26 +130,38 @@ def main():
     plan = ctx.plan(And(Leaf(0, FilterMode.Range, a, b)), [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
     ctx.sync()
 
+    gather = kdist.StateGather(2, torch.device("cuda", local_rank) if backend == "nccl" else None) if dist is not None else None
+
     def enqueue():
         ctx.scan_async(plan, bits_out=bits, pack_counts=True, row_base=row_base)
 
     def collect():
         res = ctx.scan_collect(plan, n_packs)
         if dist is not None:
-            merged, total = kdist.allgather_states(res.states, res.count,
-                                                   device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+            merged, total = gather(res.states, res.count)
             return res, merged, total
         return res, res.states, res.count
 
+    # scans queued ahead of the one being collected.  With ranks > 1 every collect() ends in the RCCL all-gather of
+    # the states, whose kernel can only start when the running scan's workgroups retire: a second queued scan keeps
+    # the device busy over that wait (the library's result ring holds 4 scans in flight).
+    depth = int(os.environ.get("KNOX_BENCH_DEPTH", "2" if dist is not None else "1"))
+
     def run(k):
-        """k steps, software-pipelined one deep: step i+1 is enqueued before step i's results are
+        """k steps, software-pipelined: up to `depth` later steps are enqueued before step i's results are
         collected (every step's bitset, pack counts and aggregates are produced and collected; the
         device just never idles between steps, as under a host with several queries in flight)."""
-        enqueue()
-        for _ in range(k - 1):
+        queued = 0
+        for _ in range(min(depth, k)):
             enqueue()
-            collect()
-        return collect()
+            queued += 1
+        last = None
+        for _ in range(k):
+            if queued < k:
+                enqueue()
+                queued += 1
+            last = collect()
+        return last
 
     run(max(1, args.warmup))
     ctx.L.knox_prof_enable(ctx.h, 1)
@@ -219,7 +238,8 @@ def main():
         sample = min(n_rows, 1 << args.cpu_sample_log2)
         out["cpu_baseline"] = cpu_baseline(sample, pack_rows, a, b, res.pack_counts)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     col.free()
     bits.free()
     ctx.close()

@@ -52,3 +52,44 @@ def allgather_states(states, count, device=None, group=None):
     merged = [agg_combine([per_rank[r][0][i] for r in range(world)]) for i in range(len(states))]
     total = sum(c for _, c in per_rank)
     return merged, total
+
+
+class StateGather:
+    """The per-step exchange with everything allocated once: a page-locked host buffer each way, one device tensor
+    each way, ONE collective (all_gather_into_tensor) and ONE device-to-host copy per call -- the exchange is a few
+    hundred bytes, so its cost is launches and synchronisations, not bandwidth.  device=None: CPU tensors (gloo)."""
+
+    def __init__(self, n_states, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.n_states = n_states
+        self.world = dist.get_world_size(group)
+        self.nbytes = n_states * C.sizeof(AggState) + 8
+        self.device = device
+        if device is not None:
+            self.h_in = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+            self.h_out = torch.empty(self.nbytes * self.world, dtype=torch.uint8).pin_memory()
+            self.d_in = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+            self.d_out = torch.empty(self.nbytes * self.world, dtype=torch.uint8, device=device)
+        else:
+            self.h_in = torch.empty(self.nbytes, dtype=torch.uint8)
+            self.h_out = torch.empty(self.nbytes * self.world, dtype=torch.uint8)
+
+    def __call__(self, states, count):
+        torch, dist = self.torch, self.dist
+        mine = states_to_bytes(states, count)
+        assert len(mine) == self.nbytes
+        self.h_in.numpy()[:] = np.frombuffer(mine, dtype=np.uint8)
+        if self.device is not None:
+            self.d_in.copy_(self.h_in, non_blocking=True)
+            dist.all_gather_into_tensor(self.d_out, self.d_in, group=self.group)
+            self.h_out.copy_(self.d_out, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            parts = [self.h_out[r * self.nbytes:(r + 1) * self.nbytes] for r in range(self.world)]
+            dist.all_gather(parts, self.h_in, group=self.group)
+        raw = self.h_out.numpy().tobytes()
+        per_rank = [bytes_to_states(raw[r * self.nbytes:(r + 1) * self.nbytes], self.n_states) for r in range(self.world)]
+        merged = [agg_combine([per_rank[r][0][i] for r in range(self.world)]) for i in range(self.n_states)]
+        return merged, sum(c for _, c in per_rank)

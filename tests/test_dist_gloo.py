@@ -30,6 +30,11 @@ def _worker(rank, world, port, q):
     bits, cnt = O.cmp(O.I64, O.RG, x, -(1 << 38), 1 << 38)
     st = _state_from_oracle(O.I64, K.BlockType.Int64, x, bits, first * pack)
     merged, total = kdist.allgather_states([st], cnt)
+    # the preallocated form bench.py uses every step must give the same merge (twice: buffers are reused)
+    g = kdist.StateGather(1)
+    for _ in range(2):
+        m2, t2 = g([st], cnt)
+        assert t2 == total and bytes(m2[0]) == bytes(merged[0])
     res = {f: K.agg_value(merged[0], f) for f in (K.ReducerFunc.Sum, K.ReducerFunc.Min, K.ReducerFunc.Max,
                                                    K.ReducerFunc.First, K.ReducerFunc.Last)}
     q.put((rank, total, {int(k): (int(v[0]), v[1], v[2]) for k, v in res.items()}))
