@@ -120,3 +120,74 @@ func Scan(c *Ctx, preds []Pred, cols []*Column, aggs []Agg, rowBase uint64, pack
 		(*C.int64_t)(unsafe.SliceData(packCounts)), &states[0], &out)
 	return states[:len(aggs)], int64(out.count), errOf(rc)
 }
+
+// UploadBytes holds a StringPool (pkg/stringx/pool.go:45-58: ptr = off<<32 | len, plus the payload) on the device.
+func UploadBytes(c *Ctx, ptr []uint64, buf []byte, packRows int) (*Column, error) {
+	var col *C.knox_col
+	rc := C.knox_col_upload_bytes(c.p, (*C.uint64_t)(unsafe.SliceData(ptr)), C.size_t(len(ptr)),
+		(*C.uint8_t)(unsafe.SliceData(buf)), C.size_t(len(buf)), C.size_t(packRows), &col)
+	return &Column{col}, errOf(rc)
+}
+
+// MatchRegexp is bytesRegexpMatcher.MatchVector (internal/operator/filter/match_bytes.go:587-609) for a resident
+// bytes column: pattern = re.String().  An error wrapping "unsupported" means the pattern is outside the
+// implemented syntax subset -> keep the re.Match loop for this matcher.
+func MatchRegexp(c *Ctx, col *Column, pattern string, mask, bits *Bits) (int64, error) {
+	var mp *C.knox_bits
+	if mask != nil {
+		mp = mask.p
+	}
+	var cnt C.int64_t
+	pat := []byte(pattern)
+	rc := C.knox_match_regexp(c.p, col.p, (*C.uint8_t)(unsafe.SliceData(pat)), C.uint64_t(len(pat)), mp, bits.p, &cnt)
+	return int64(cnt), errOf(rc)
+}
+
+// ReduceBuckets is what pkg/series feeds row by row into NativeBucket.Push (internal/reducer/bucket_native.go:
+// 104-159): one mergeable state per window [from + k*step, from + (k+1)*step); timestamps in any order.
+func ReduceBuckets(c *Ctx, timeCol, valueCol *Column, mask *Bits, from, step int64, nBuckets int, rowBase uint64,
+	moments bool) ([]AggState, error) {
+	var mp *C.knox_bits
+	if mask != nil {
+		mp = mask.p
+	}
+	flags := C.int(0)
+	if moments {
+		flags |= 2
+	}
+	states := make([]AggState, nBuckets)
+	rc := C.knox_reduce_buckets(c.p, timeCol.p, valueCol.p, mp, C.int64_t(from), C.int64_t(step), C.size_t(nBuckets),
+		C.uint64_t(rowBase), flags, &states[0])
+	return states, errOf(rc)
+}
+
+// ReduceBucketsLiteral applies the reference's own reducer (plain or join, reducer.go:130-731) row by row per
+// window: values[k], seen[k] = Reducer.Value() of window k, bit for bit.  fn = knox_reducer, T = the column type.
+func ReduceBucketsLiteral[T Number](c *Ctx, timeCol, valueCol *Column, mask *Bits, from, step int64, nBuckets, fn int) ([]T, []bool, error) {
+	var mp *C.knox_bits
+	if mask != nil {
+		mp = mask.p
+	}
+	vals := make([]T, nBuckets)
+	seen8 := make([]uint8, nBuckets)
+	rc := C.knox_reduce_buckets_sequential(c.p, timeCol.p, valueCol.p, mp, C.int64_t(from), C.int64_t(step),
+		C.size_t(nBuckets), C.int(fn), 0, unsafe.Pointer(unsafe.SliceData(vals)), (*C.uint8_t)(unsafe.SliceData(seen8)))
+	seen := make([]bool, nBuckets)
+	for i, s := range seen8 {
+		seen[i] = s != 0
+	}
+	return vals, seen, errOf(rc)
+}
+
+// FillWindows is the gap walk of NativeBucket.Emit (bucket_native.go:161-218) with Fill (fill.go:59-85) over dense
+// window values: flags[k] 0 = nothing emitted, 1 = out[k], 2 = null.  mode = knox_fill_mode; Emit keeps only the
+// string formatting.
+func FillWindows[T Number](dtype, mode int, vals []T, seen []uint8, from, step, unitsPerSecond int64, limit int) ([]T, []uint8, int, error) {
+	out := make([]T, len(vals))
+	flags := make([]uint8, len(vals))
+	var n C.size_t
+	rc := C.knox_fill_windows(C.int(dtype), C.int(mode), unsafe.Pointer(unsafe.SliceData(vals)), (*C.uint8_t)(unsafe.SliceData(seen)),
+		C.size_t(len(vals)), C.int64_t(from), C.int64_t(step), C.int64_t(unitsPerSecond), C.size_t(limit),
+		unsafe.Pointer(unsafe.SliceData(out)), (*C.uint8_t)(unsafe.SliceData(flags)), &n)
+	return out, flags, int(n), errOf(rc)
+}
