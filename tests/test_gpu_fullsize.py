@@ -131,3 +131,59 @@ def test_cfg4_full_size_bloom_pruned_point_lookup(ctx):
         assert (r_pruned.pack_counts == r_full.pack_counts).all()
     for o in (col, bits, bloom):
         o.free()
+
+
+def test_time_windows_full_size_properties(ctx):
+    """f1 at BASELINE size: 2^30 rows in 1024 windows (= the packs), ordered clock; then 2^26 rows with a fully
+    shuffled clock through the stable-sort path.  Linearity / partition properties + sampled windows vs the oracle."""
+    a, b = -(1 << 38), 1 << 38
+    col = ctx.generate(BlockType.Int64, 0, 2, N, lo=-(1 << 40), span=1 << 41, pack_rows=PACK)
+    clock = ctx.generate(BlockType.Int64, 3, 0, N, lo=5_000_000, pack_rows=PACK)       # t = 5e6 + row id
+    bits = ctx.bits(N)
+    res = ctx.scan(And(Leaf(0, FilterMode.Range, a, b)), [col], aggs=[(R.Sum, 0)], bits_out=bits, pack_counts=True)
+    states = ctx.reduce_buckets(clock, col, 5_000_000, PACK, N // PACK, mask=bits, moments=True)
+    assert [s.count for s in states] == res.pack_counts.tolist()                          # windows == packs here
+    assert sum(int(K.agg_value(s, R.Sum)[0]) for s in states) % (1 << 64) == int(res.value(0)[0]) % (1 << 64)
+    merged = K.agg_combine(states)
+    whole = ctx.reduce(col, bits, moments=True)
+    for f in (R.Count, R.Sum, R.Min, R.Max, R.First, R.Last, R.Mean):
+        assert K.agg_value(merged, f) == K.agg_value(whole, f), f
+    assert abs(K.agg_value(merged, R.Std)[0] - K.agg_value(whole, R.Std)[0]) <= 1
+    for p in SAMPLE:
+        x = O.generate(O.I64, 0, 2, p * PACK, PACK, lo=-(1 << 40), span=1 << 41)
+        wb, wc = O.cmp(O.I64, O.RG, x, a, b)
+        for f, of in ((R.Sum, O.R_SUM), (R.Min, O.R_MIN), (R.Max, O.R_MAX), (R.First, O.R_FIRST), (R.Last, O.R_LAST)):
+            want = O.reduce(O.I64, of, x, wb)
+            got = K.agg_value(states[p], f)
+            assert got[0] == want[0] and got[1] == want[1], (p, f)
+    # a window grid that does not line up with the packs: counts still partition the selection
+    states2 = ctx.reduce_buckets(clock, col, 5_000_000 - 12345, 777_777, (N + 12345) // 777_777 + 1, mask=bits)
+    assert sum(s.count for s in states2) == res.count
+    assert sum(int(K.agg_value(s, R.Sum)[0]) for s in states2) % (1 << 64) == int(res.value(0)[0]) % (1 << 64)
+    for o in (col, clock, bits):
+        o.free()
+    # shuffled clock: every row carries a uniformly random timestamp
+    n2 = 1 << 26
+    col = ctx.generate(BlockType.Int64, 0, 2, n2, lo=-(1 << 40), span=1 << 41, pack_rows=PACK)
+    clock = ctx.generate(BlockType.Int64, 0, 9, n2, lo=1000, span=1 << 20, pack_rows=PACK)
+    bits = ctx.bits(n2)
+    res = ctx.scan(And(Leaf(0, FilterMode.Range, a, b)), [col], aggs=[(R.Sum, 0)], bits_out=bits)
+    nb, step = 4096, 256
+    states = ctx.reduce_buckets(clock, col, 1000, step, nb, mask=bits)                   # 4096 * 256 = 2^20: every row inside
+    assert sum(s.count for s in states) == res.count
+    assert sum(int(K.agg_value(s, R.Sum)[0]) for s in states) % (1 << 64) == int(res.value(0)[0]) % (1 << 64)
+    merged = K.agg_combine(states)   # NOT row order across windows: only the order-free reducers compare
+    whole = ctx.reduce(col, bits)
+    for f in (R.Count, R.Sum, R.Min, R.Max):
+        assert K.agg_value(merged, f)[0] == K.agg_value(whole, f)[0], f
+    # first 2^20 rows on the host: their contribution to a few windows is a lower bound witness of first_row
+    t0 = O.generate(O.I64, 0, 9, 0, PACK, lo=1000, span=1 << 20)
+    x0 = O.generate(O.I64, 0, 2, 0, PACK, lo=-(1 << 40), span=1 << 41)
+    wb0, _ = O.cmp(O.I64, O.RG, x0, a, b)
+    sel0 = np.unpackbits(wb0, bitorder="little")[:PACK].astype(bool)
+    for k in (0, 17, 4095):
+        rows = np.flatnonzero(sel0 & ((t0 - 1000) // step == k))
+        if rows.size:   # the window's first row in stream order is the first such row of the first pack
+            assert states[k].first_row == rows[0] and K.agg_value(states[k], R.First)[0] == x0[rows[0]]
+    for o in (col, clock, bits):
+        o.free()
