@@ -245,7 +245,7 @@ def agg_value(state, func):
 
 
 def agg_combine(states):
-    arr = (AggState * len(states))(*states)
+    arr = states if isinstance(states, C.Array) else (AggState * len(states))(*states)
     out = AggState()
     check(_lib.lib().knox_agg_combine(arr, len(states), C.byref(out)))
     return out
@@ -505,7 +505,7 @@ class Context:
         states = (AggState * n_buckets)()
         check(self.L.knox_reduce_buckets(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
                                          n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), states), "knox_reduce_buckets")
-        return [states[i] for i in range(n_buckets)]
+        return states   # ctypes array: indexable / iterable, no per-window Python objects until touched
 
     def reduce_buckets_sequential(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
         """The reference's own reducer per window, row by row (bit-exact Value() for every reducer, join
