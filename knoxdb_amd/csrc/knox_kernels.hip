@@ -354,24 +354,67 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
                                          const uint32_t (&q)[kUnroll], uint64_t row0, uint64_t row_base, int lane) {
     constexpr int K = WT<W>::K;
     constexpr int RPL = 64 * K;
+    uint64_t it_z = 0;  // this iteration's sum of the selected raw (zero-extended) values
     if constexpr ((AGG & A_ISUM) != 0) {
+        if constexpr (W <= 2) {  // <= 64 values below 2^16: a 32-bit partial sum cannot overflow
+            uint32_t t = 0;
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
+            for (int u = 0; u < kUnroll; u++) {
 #pragma unroll
-            for (int j = 0; j < K; j++) acc.isum += ((q[u] >> j) & 1u) ? (uint64_t)elem<W>(r[u], j) : 0ull;
+                for (int j = 0; j < K; j++) t += ((q[u] >> j) & 1u) ? (uint32_t)elem<W>(r[u], j) : 0u;
+            }
+            it_z = t;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) it_z += ((q[u] >> j) & 1u) ? (uint64_t)elem<W>(r[u], j) : 0ull;
+            }
         }
+        acc.isum += it_z;
     }
     if constexpr ((AGG & A_FSUM) != 0 && FLV == FL_FLOAT) {
+        bool done = false;
+        if constexpr (W == 4) {
+            // float32: the 16 selected values of one iteration add up EXACTLY in float64 when their exponents span at
+            // most 24 binades (24-bit significands, 4 carry bits: every partial sum needs <= 52 bits), which is what
+            // real columns look like -- then one error-free TwoSum per iteration replaces sixteen.  Zeros are ignored
+            // by the test (min over mag - 1 wraps them to the top); Inf / NaN take the per-value path below.
+            static_assert(kUnroll * K <= 16, "the exactness bound below assumes at most 16 values per iteration");
+            uint32_t amax = 0, amin = 0xffffffffu;
+            double it = 0.0;
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
+            for (int u = 0; u < kUnroll; u++) {
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                double x = to_f64_c<W, FLV>(elem<W>(r[u], j));
-                x = ((q[u] >> j) & 1u) ? x : 0.0;
-                const double s = acc.hi + x;
+                for (int j = 0; j < K; j++) {
+                    const uint32_t xb = ((q[u] >> j) & 1u) ? (uint32_t)elem<W>(r[u], j) : 0u;
+                    const uint32_t mag = xb & 0x7fffffffu;
+                    amax = mag > amax ? mag : amax;
+                    amin = (mag - 1u) < amin ? (mag - 1u) : amin;
+                    it += (double)__uint_as_float(xb);
+                }
+            }
+            const bool ok = amax < 0x7f800000u && (amin == 0xffffffffu || ((amax >> 23) - ((amin + 1u) >> 23)) <= 24u);
+            if (__all(ok)) {
+                const double s = acc.hi + it;
                 const double bb = s - acc.hi;
-                acc.lo += (acc.hi - (s - bb)) + (x - bb);
+                acc.lo += (acc.hi - (s - bb)) + (it - bb);
                 acc.hi = s;
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    double x = to_f64_c<W, FLV>(elem<W>(r[u], j));
+                    x = ((q[u] >> j) & 1u) ? x : 0.0;
+                    const double s = acc.hi + x;
+                    const double bb = s - acc.hi;
+                    acc.lo += (acc.hi - (s - bb)) + (x - bb);
+                    acc.hi = s;
+                }
             }
         }
     }
@@ -387,14 +430,29 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
                     acc.add128(v, FLV == FL_SIGNED ? (int64_t)v >> 63 : 0);
                 }
             }
+        } else if constexpr (FLV == FL_UNSIGNED && (AGG & A_ISUM) != 0) {
+            acc.add128(it_z, 0);  // unsigned: the exact sum is the raw sum, already formed above
         } else {
             uint64_t it = 0;
+            if constexpr (W <= 2) {  // as above: 64 values of at most 16 bits fit an int32 partial sum
+                int32_t t = 0;
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
+                for (int u = 0; u < kUnroll; u++) {
 #pragma unroll
-                for (int j = 0; j < K; j++) {
-                    const uint64_t v = FLV == FL_SIGNED ? sext_u64<W>(elem<W>(r[u], j)) : (uint64_t)elem<W>(r[u], j);
-                    it += ((q[u] >> j) & 1u) ? v : 0ull;
+                    for (int j = 0; j < K; j++) {
+                        const int32_t v = FLV == FL_SIGNED ? (int32_t)(int64_t)sext_u64<W>(elem<W>(r[u], j)) : (int32_t)elem<W>(r[u], j);
+                        t += ((q[u] >> j) & 1u) ? v : 0;
+                    }
+                }
+                it = (uint64_t)(int64_t)t;
+            } else {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) {
+                        const uint64_t v = FLV == FL_SIGNED ? sext_u64<W>(elem<W>(r[u], j)) : (uint64_t)elem<W>(r[u], j);
+                        it += ((q[u] >> j) & 1u) ? v : 0ull;
+                    }
                 }
             }
             acc.add128(it, FLV == FL_SIGNED ? (int64_t)it >> 63 : 0);
@@ -402,12 +460,30 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
     }
     if constexpr ((AGG & A_MINMAX) != 0) {
         bool trig = false;
+        if constexpr (W < 8) {
+            // keys fit 32 bits: the iteration's min / max over the selected values (unselected: the neutral element)
+            // with v_min / v_max, then ONE compare pair -- no per-value 64-bit compares and mask arithmetic
+            uint32_t imin = 0xffffffffu, imax = 0u;
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
+            for (int u = 0; u < kUnroll; u++) {
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                const uint64_t key = okey_raw<W, FLV>(elem<W>(r[u], j));
-                trig = trig || (((q[u] >> j) & 1u) && (key < wm.smin || key > wm.smax));
+                for (int j = 0; j < K; j++) {
+                    const uint32_t key = (uint32_t)okey_raw<W, FLV>(elem<W>(r[u], j));
+                    const bool sel = ((q[u] >> j) & 1u) != 0;
+                    const uint32_t kmin = sel ? key : 0xffffffffu, kmax = sel ? key : 0u;
+                    imin = kmin < imin ? kmin : imin;
+                    imax = kmax > imax ? kmax : imax;
+                }
+            }
+            trig = (uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const uint64_t key = okey_raw<W, FLV>(elem<W>(r[u], j));
+                    trig = trig || (((q[u] >> j) & 1u) && (key < wm.smin || key > wm.smax));
+                }
             }
         }
         if (__any(trig)) {
