@@ -2117,14 +2117,22 @@ static int run_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pat, ui
     const int st = knox_regex::compile(pat, (size_t)pat_len, pg);
     if (st != knox_regex::OK) return KNOX_E_UNSUPPORTED;  // syntax outside the implemented subset / DFA too large: host regexp.Match
     const size_t tb = (size_t)pg.n_states * pg.n_classes * 2;
-    const size_t image = tb + pg.n_states + 128;                 // table | flags | ascii (what the kernel stages in LDS)
+    // ASCII runes step through a direct [state][byte] table when it fits the LDS budget with the rest of the image
+    const size_t db_want = (size_t)pg.n_states * 256;
+    const size_t db = (db_want + tb + pg.n_states + 128 <= 40 * 1024) ? db_want : 0;
+    const size_t image = db + tb + pg.n_states + 128;            // [direct] | table | flags | ascii (what the kernel stages in LDS)
     const size_t off_lo = (image + 15) & ~(size_t)15;
     const size_t off_cls = off_lo + pg.bound_lo.size() * 4;
     const size_t total = off_cls + pg.bound_class.size() + 16;
     std::vector<uint8_t> h(total, 0);
-    memcpy(h.data(), pg.table.data(), tb);
-    memcpy(h.data() + tb, pg.flags.data(), pg.n_states);
-    memcpy(h.data() + tb + pg.n_states, pg.ascii_class, 128);
+    if (db) {
+        uint16_t *d16 = (uint16_t *)h.data();
+        for (uint32_t st = 0; st < pg.n_states; st++)
+            for (uint32_t b = 0; b < 128; b++) d16[st * 128 + b] = pg.table[(size_t)st * pg.n_classes + pg.ascii_class[b]] & 0x7fff;  // plain target: ACCEPT and dead states are absorbing
+    }
+    memcpy(h.data() + db, pg.table.data(), tb);
+    memcpy(h.data() + db + tb, pg.flags.data(), pg.n_states);
+    memcpy(h.data() + db + tb + pg.n_states, pg.ascii_class, 128);
     memcpy(h.data() + off_lo, pg.bound_lo.data(), pg.bound_lo.size() * 4);
     memcpy(h.data() + off_cls, pg.bound_class.data(), pg.bound_class.size());
     int rc = ensure(ctx, ctx->bytes_val, total);
@@ -2133,9 +2141,10 @@ static int run_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pat, ui
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host image not retained
     const uint8_t *d = (const uint8_t *)ctx->bytes_val.p;
     RegexProg dp;
-    dp.table = (const uint16_t *)d;
-    dp.flags = d + tb;
-    dp.ascii_class = d + tb + pg.n_states;
+    dp.direct = db ? (const uint16_t *)d : nullptr;
+    dp.table = (const uint16_t *)(d + db);
+    dp.flags = d + db + tb;
+    dp.ascii_class = d + db + tb + pg.n_states;
     dp.bound_lo = (const uint32_t *)(d + off_lo);
     dp.bound_class = d + off_cls;
     dp.n_bounds = (uint32_t)pg.bound_lo.size();

@@ -242,6 +242,7 @@ hipError_t launch_key_bounds(hipStream_t s, const uint32_t *keys, uint64_t n, ui
 hipError_t launch_remap_rows(hipStream_t s, AggStateDev *states, uint32_t n_buckets, const uint32_t *idx, uint64_t row_base);
 // compiled REGEXP program on the device (knox_regex.h): table | flags | ascii_class are one contiguous image
 struct RegexProg {
+    const uint16_t *direct;  // [n_states][128]: table[state][ascii_class[byte]] folded, or nullptr (image too large for LDS)
     const uint16_t *table;
     const uint8_t *flags;
     const uint8_t *ascii_class;

@@ -2742,19 +2742,22 @@ __global__ void reduce_seq_kernel(int func, const T *src, uint64_t n, const uint
 // flags bit1 = dead (no accepting state reachable) -> the lane stops early either way.  Tables of
 // up to 48 KiB are staged in LDS, larger ones are read through L2.
 // ---------------------------------------------------------------------------------------------
-template <bool LDS>
+template <bool LDS, bool DIRECT>
 __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf, uint8_t *bits,
                                                               const uint8_t *mask) {
     extern __shared__ __align__(16) uint8_t rx_lds[];
-    const uint16_t *table = pg.table;
+    const uint16_t *table = pg.table, *direct = pg.direct;
     const uint8_t *flags = pg.flags, *ascii = pg.ascii_class;
     if constexpr (LDS) {
-        // image layout (host): [table u16 * n_states*n_classes][flags n_states][ascii 128]
-        const uint32_t tb = pg.n_states * pg.n_classes * 2, total = tb + pg.n_states + 128;
-        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) rx_lds[i] = ((const uint8_t *)pg.table)[i];
+        // image layout (host): [direct u16 * n_states*128 (DIRECT only)][table u16 * n_states*n_classes][flags n_states][ascii 128]
+        const uint32_t db = DIRECT ? pg.n_states * 256u : 0u;
+        const uint32_t tb = pg.n_states * pg.n_classes * 2, total = db + tb + pg.n_states + 128;
+        const uint8_t *image = DIRECT ? (const uint8_t *)pg.direct : (const uint8_t *)pg.table;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) rx_lds[i] = image[i];
         __syncthreads();
-        table = (const uint16_t *)rx_lds;
-        flags = rx_lds + tb;
+        direct = (const uint16_t *)rx_lds;
+        table = (const uint16_t *)(rx_lds + db);
+        flags = rx_lds + db + tb;
         ascii = flags + pg.n_states;
     }
     const int lane = threadIdx.x & 63;
@@ -2769,29 +2772,93 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
             const uint32_t len = (uint32_t)p;
             uint32_t state = 1, pos = 0;
             bool decided = false;
-            // the row's bytes travel in 8-byte pieces (unaligned loads; the pool is padded by 8 bytes): a rune
-            // is decoded from the register as long as its 4-byte window lies inside the piece
+            // the first 32 bytes of the row are fetched at once (two unaligned 16-byte loads; the pool is padded) and
+            // the 4-byte decode window is cut out of registers: one HBM round trip per row instead of one per 5 bytes.
+            // Longer rows continue in 8-byte pieces.
+            uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            if (len != 0) {
+                u32x4 a, b;
+                __builtin_memcpy(&a, s, 16);
+                __builtin_memcpy(&b, s + 16, 16);
+                w0 = ((uint64_t)a.y << 32) | a.x; w1 = ((uint64_t)a.w << 32) | a.z;
+                w2 = ((uint64_t)b.y << 32) | b.x; w3 = ((uint64_t)b.w << 32) | b.z;
+                if constexpr (DIRECT) {
+                    // ASCII prefix of the row, one preloaded dword at a time (static register indexing, no shifts): up to
+                    // four table steps per dword; ACCEPT (0) and the dead states are absorbing, so they are looked at
+                    // once per dword.  The walk is VALU-issue bound (wave64: 4 cycles per instruction).  A partial last
+                    // dword still takes four lookups (bytes past the row masked to 7 bits) and keeps the right one.
+                    const uint32_t w32[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (!decided && pos == 4u * k && pos < len) {
+                            const uint32_t win = w32[k], rem = len - pos;
+                            const uint32_t hm = rem >= 4u ? 0x80808080u : (0x00808080u >> (8u * (3u - rem)));
+                            if ((win & hm) == 0u) {
+                                const uint32_t s1 = direct[state * 128u + (win & 0x7fu)];
+                                const uint32_t s2 = direct[s1 * 128u + ((win >> 8) & 0x7fu)];
+                                const uint32_t s3 = direct[s2 * 128u + ((win >> 16) & 0x7fu)];
+                                const uint32_t s4 = direct[s3 * 128u + ((win >> 24) & 0x7fu)];
+                                state = rem >= 4u ? s4 : rem == 3u ? s3 : rem == 2u ? s2 : s1;
+                                pos += rem < 4u ? rem : 4u;
+                                if (state == 0u) { m = true; decided = true; }
+                                else if (flags[state] & 2) decided = true;
+                            }
+                        }
+                    }
+                }
+            }
             uint64_t piece = 0;
             uint32_t pbase = 0x80000000u;
-            while (pos < len) {
-                if (pos - pbase > 4u) {
-                    __builtin_memcpy(&piece, s + pos, 8);
-                    pbase = pos;
+            while (!decided && pos < len) {
+                uint32_t win;
+                if (pos <= 28u) {
+                    const uint32_t idx = pos >> 3, sh = (pos & 7u) * 8u;
+                    const uint64_t lo = idx == 0 ? w0 : idx == 1 ? w1 : idx == 2 ? w2 : w3;
+                    const uint64_t hi = idx == 0 ? w1 : idx == 1 ? w2 : w3;  // idx 3: pos <= 28 keeps the window inside w3
+                    win = (uint32_t)(lo >> sh);
+                    if (sh > 32u) win |= (uint32_t)(hi << (64u - sh));
+                } else {
+                    if (pos - pbase > 4u) {
+                        __builtin_memcpy(&piece, s + pos, 8);
+                        pbase = pos;
+                    }
+                    win = (uint32_t)(piece >> (8 * (pos - pbase)));
+                }
+                if constexpr (DIRECT) {
+                    // four ASCII bytes inside the row: four table steps back to back.  ACCEPT (state 0) and the dead
+                    // states are absorbing, so they are only looked at once per word -- the walk is VALU-issue bound
+                    // (wave64: 4 cycles per instruction), every instruction per rune counts
+                    if (pos + 4u <= len && (win & 0x80808080u) == 0u) {
+                        state = direct[state * 128u + (win & 0xffu)];
+                        state = direct[state * 128u + ((win >> 8) & 0xffu)];
+                        state = direct[state * 128u + ((win >> 16) & 0xffu)];
+                        state = direct[state * 128u + (win >> 24)];
+                        pos += 4u;
+                        if (state == 0u) { m = true; decided = true; break; }
+                        if (flags[state] & 2) { decided = true; break; }
+                        continue;
+                    }
                 }
                 uint32_t w;
-                const uint32_t r = knox_regex::decode_rune_word((uint32_t)(piece >> (8 * (pos - pbase))), len - pos, w);
+                const uint32_t r = knox_regex::decode_rune_word(win, len - pos, w);
                 pos += w;
-                uint32_t cls;
-                if (r < 0x80) cls = ascii[r];
-                else {
-                    uint32_t lo = 0, hi = pg.n_bounds;
-                    while (hi - lo > 1) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (pg.bound_lo[mid] <= r) lo = mid; else hi = mid;
+                uint32_t e;
+                if (DIRECT && r < 0x80) {
+                    e = direct[state * 128u + r];  // plain target state (no dead bit in the direct table)
+                    if (e != 0 && (flags[e] & 2)) e |= knox_regex::kDeadBit;
+                } else {
+                    uint32_t cls;
+                    if (r < 0x80) cls = ascii[r];
+                    else {
+                        uint32_t lo = 0, hi = pg.n_bounds;
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (pg.bound_lo[mid] <= r) lo = mid; else hi = mid;
+                        }
+                        cls = pg.bound_class[lo];
                     }
-                    cls = pg.bound_class[lo];
+                    e = table[state * pg.n_classes + cls];
                 }
-                const uint32_t e = table[state * pg.n_classes + cls];
                 if (e == 0) { m = true; decided = true; break; }
                 if (e & knox_regex::kDeadBit) { decided = true; break; }
                 state = e;
@@ -2816,10 +2883,12 @@ hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t imag
     if (n_rows == 0) return hipSuccess;
     uint64_t g = (n_rows + kBlock - 1) / kBlock;
     if (g > 2048 * 4) g = 2048 * 4;
-    if (image_bytes <= 48 * 1024)
-        hipLaunchKernelGGL((regexp_match_kernel<true>), dim3((unsigned)g), dim3(kBlock), image_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+    if (pg.direct != nullptr)  // host guarantees: the image with the direct table fits the LDS budget
+        hipLaunchKernelGGL((regexp_match_kernel<true, true>), dim3((unsigned)g), dim3(kBlock), image_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+    else if (image_bytes <= 48 * 1024)
+        hipLaunchKernelGGL((regexp_match_kernel<true, false>), dim3((unsigned)g), dim3(kBlock), image_bytes, s, pg, ptr, n_rows, buf, bits, mask);
     else
-        hipLaunchKernelGGL((regexp_match_kernel<false>), dim3((unsigned)g), dim3(kBlock), 0, s, pg, ptr, n_rows, buf, bits, mask);
+        hipLaunchKernelGGL((regexp_match_kernel<false, false>), dim3((unsigned)g), dim3(kBlock), 0, s, pg, ptr, n_rows, buf, bits, mask);
     return hipGetLastError();
 }
 

@@ -100,11 +100,11 @@ def gen_pattern(rng, depth=0):
     return p
 
 
-def gen_rows(rng, n):
+def gen_rows(rng, n, max_parts=12):
     rows = []
     for _ in range(n):
         parts = []
-        for _ in range(rng.randint(0, 12)):
+        for _ in range(rng.randint(0, max_parts)):
             parts.append(rng.choice(BAD_BYTES) if rng.random() < 0.08 else rng.choice(ROW_ALPHABET).encode())
         rows.append(b"".join(parts))
     return rows
@@ -183,6 +183,17 @@ def test_gpu_regexp_rows_match_the_oracle():
             want2 = np.packbits(want, bitorder="little") & mask_h | pre
             assert b2.bytes().tobytes() == want2.tobytes(), pat
             b2.free()
+        # long rows (past the 32 preloaded bytes: the walk continues in 8-byte pieces), ASCII-heavy and mixed
+        long_rows = gen_rows(rng, 3000, max_parts=150) + [b"x" * 31 + b"ab1", b"y" * 32 + b"ab1", b"z" * 33 + b"\xc3\xa9" * 9 + b"ab1", b"a" * 1000 + b"b"]
+        lptr, lbuf = pool(long_rows)
+        lcol = ctx.upload_bytes(lptr, lbuf, 4096)
+        for pat in gen_cases(77, 40) + ["ab1$", "^z+é{9}ab", "a{1000}b", "(?s)^.{33}$", "[^a]$"]:
+            want = np.array(RO.regexp_match(pat, long_rows), dtype=bool)
+            bits, cnt = ctx.match_regexp(lcol, pat)
+            got = np.unpackbits(bits.bytes(), bitorder="little")[:len(long_rows)].astype(bool)
+            assert (got == want).all(), (pat, np.flatnonzero(got != want)[:3])
+            bits.free()
+        lcol.free()
         # as a leaf of a scan plan, combined with a numeric leaf
         ids = np.arange(n, dtype=np.int64)
         idc = ctx.upload(ids, 4096)
