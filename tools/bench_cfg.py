@@ -58,6 +58,18 @@ elif args.cfg == 3:
         vals = [res.value(i)[0] for i in range(len(aggs))]
         print(json.dumps({"cfg": 3, "aggs": name, "kernel_ms": ms, "rows_per_s": n / ms * 1e3, "achieved_GBs": gbs,
                           "frac_8TBs": gbs / 8000, "count": res.count, "values": [float(v) for v in vals]}))
+    # the read-only form of the same tree (no bitset, no per-pack counts): the two-stream ceiling on this box
+    plan = ctx.plan(tree, [a, b], aggs=[])
+    ctx.L.knox_prof_enable(ctx.h, 1)
+    for _ in range(10):
+        ctx.scan_async(plan); ctx.scan_collect(plan, 0)
+    import ctypes as C
+    kms, kn = C.c_double(), C.c_int()
+    ctx.L.knox_prof_read(ctx.h, C.byref(kms), C.byref(kn))
+    ctx.L.knox_prof_enable(ctx.h, 0)
+    ro = kms.value / max(1, kn.value)
+    print(json.dumps({"cfg": 3, "aggs": "read-only ceiling (count, no bitset)", "kernel_ms": ro, "achieved_GBs": n * 16.0 / ro / 1e6,
+                      "placement_a": a.placement, "placement_b": b.placement, "placement_bits": bits.placement}))
 elif args.cfg == 6:
     # time-window aggregation (next row f1): 2^30 rows, time = row id, windows of 2^16 / 2^10 rows
     tcol = ctx.generate(BlockType.Int64, 3, 0, n, lo=1_000_000, pack_rows=pack)
