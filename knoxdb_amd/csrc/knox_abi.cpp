@@ -2150,6 +2150,7 @@ static int run_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pat, ui
     dp.n_bounds = (uint32_t)pg.bound_lo.size();
     dp.n_classes = pg.n_classes;
     dp.n_states = pg.n_states;
+    dp.lds_image_bytes = (uint32_t)image;
     hipError_t e = launch_regexp_match(ctx->stream, dp, (uint32_t)image, (const uint64_t *)col->dev, col->n_rows, col->buf, bits, mask);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;

@@ -249,6 +249,7 @@ struct RegexProg {
     const uint32_t *bound_lo;
     const uint8_t *bound_class;
     uint32_t n_bounds, n_classes, n_states;
+    uint32_t lds_image_bytes;  // bytes of [direct] | table | flags | ascii the kernel stages
 };
 hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
                                uint8_t *bits, const uint8_t *mask);

@@ -2760,6 +2760,20 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
         flags = rx_lds + db + tb;
         ascii = flags + pg.n_states;
     }
+    // the class intervals of the runes above ASCII: staged too when they are few (they almost always are)
+    const uint32_t *bound_lo = pg.bound_lo;
+    const uint8_t *bound_class = pg.bound_class;
+    if constexpr (LDS) {
+        if (pg.n_bounds <= 96u) {
+            const uint32_t base = (pg.lds_image_bytes + 3u) & ~3u;
+            uint32_t *blo = (uint32_t *)(rx_lds + base);
+            uint8_t *bcl = rx_lds + base + 4u * pg.n_bounds;
+            for (uint32_t i = threadIdx.x; i < pg.n_bounds; i += blockDim.x) { blo[i] = pg.bound_lo[i]; bcl[i] = pg.bound_class[i]; }
+            __syncthreads();
+            bound_lo = blo;
+            bound_class = bcl;
+        }
+    }
     const int lane = threadIdx.x & 63;
     const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint64_t ngroups = (n_rows + 63) >> 6;
@@ -2853,9 +2867,9 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
                         uint32_t lo = 0, hi = pg.n_bounds;
                         while (hi - lo > 1) {
                             const uint32_t mid = (lo + hi) >> 1;
-                            if (pg.bound_lo[mid] <= r) lo = mid; else hi = mid;
+                            if (bound_lo[mid] <= r) lo = mid; else hi = mid;
                         }
-                        cls = pg.bound_class[lo];
+                        cls = bound_class[lo];
                     }
                     e = table[state * pg.n_classes + cls];
                 }
@@ -2883,10 +2897,11 @@ hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t imag
     if (n_rows == 0) return hipSuccess;
     uint64_t g = (n_rows + kBlock - 1) / kBlock;
     if (g > 2048 * 4) g = 2048 * 4;
+    const uint32_t lds_bytes = ((image_bytes + 3u) & ~3u) + 96u * 5u + 16u;  // image + (<= 96) staged class intervals
     if (pg.direct != nullptr)  // host guarantees: the image with the direct table fits the LDS budget
-        hipLaunchKernelGGL((regexp_match_kernel<true, true>), dim3((unsigned)g), dim3(kBlock), image_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+        hipLaunchKernelGGL((regexp_match_kernel<true, true>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, ptr, n_rows, buf, bits, mask);
     else if (image_bytes <= 48 * 1024)
-        hipLaunchKernelGGL((regexp_match_kernel<true, false>), dim3((unsigned)g), dim3(kBlock), image_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+        hipLaunchKernelGGL((regexp_match_kernel<true, false>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, ptr, n_rows, buf, bits, mask);
     else
         hipLaunchKernelGGL((regexp_match_kernel<false, false>), dim3((unsigned)g), dim3(kBlock), 0, s, pg, ptr, n_rows, buf, bits, mask);
     return hipGetLastError();
