@@ -1358,17 +1358,20 @@ KNOX_API void *knox_col_device_ptr(const knox_col *col) { return col ? col->dev 
 // A write buffer (bitset, scratch) of the class that is fast with column region `col` (`rows` int64 rows,
 // rows/8 <= bytes): candidates are probed as a pair with the scan kernel; mismatches are only held while
 // the search runs (they are small).  Falls back to a plain allocation when nothing can be probed.
-static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t bytes, const void *col, uint64_t col_rows, double *rate, int *tried) {
+// `width`: bytes per value of the real column; the probe reads the column's memory as int64 rows (`col_rows` of them)
+// whatever the type, the part of the write buffer that belongs to a chunk is where the real scan puts its bits.
+static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t bytes, const void *col, uint64_t col_rows, double *rate, int *tried,
+                                          int width = 8) {
     if (rate) *rate = 0.0;
     if (tried) *tried = 0;
     const uint64_t tr = (uint64_t)tile_rows(8) * 2;
-    uint64_t rows = std::min<uint64_t>(std::min<uint64_t>(col_rows, kProbeChunkRows), (uint64_t)bytes * 8);
+    uint64_t rows = std::min<uint64_t>(std::min<uint64_t>(col_rows, kProbeChunkRows), (uint64_t)bytes * (uint64_t)width);  // the probe writes rows/8 bytes
     rows -= rows % tr;
     if (!ctx->placement || !col || rows < ((uint64_t)1 << 24)) return dev_malloc(ctx, out, bytes);
     hipStreamSynchronize(ctx->stream);
     // every (column chunk, the part of the write buffer that chunk's bits go to) pair the scan will
     // really use is probed: either buffer may straddle a class boundary
-    const uint64_t span = std::min<uint64_t>(col_rows - col_rows % tr, (uint64_t)bytes * 8 - ((uint64_t)bytes * 8) % tr);
+    const uint64_t span = std::min<uint64_t>(col_rows - col_rows % tr, (uint64_t)bytes * (uint64_t)width - ((uint64_t)bytes * (uint64_t)width) % tr);
     std::vector<uint64_t> chunk_off;
     std::vector<double> chunk_ro;
     for (uint64_t off = 0; off + rows <= span; off += kProbeChunkRows) {
@@ -1383,7 +1386,7 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     auto probe_all = [&](void *p) {  // mix rate of the worst pair, scaled to chunk 0's read-only rate
         double worst = 0.0;
         for (size_t i = 0; i < chunk_off.size(); i++) {
-            const double r = probe_pair(ctx, (const char *)col + chunk_off[i] * 8, rows, (char *)p + (chunk_off[i] >> 3));
+            const double r = probe_pair(ctx, (const char *)col + chunk_off[i] * 8, rows, (char *)p + chunk_off[i] / (uint64_t)width);  // byte B of the column <-> bits byte B / (8 * width)
             if (r <= 0.0) return 0.0;
             const double scaled = r / chunk_ro[i] * ro;
             if (worst == 0.0 || scaled < worst) worst = scaled;
@@ -1393,6 +1396,7 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     };
     std::vector<std::pair<void *, double>> cands;
     std::vector<void *> spacers;
+    size_t spacer_bytes = 0;
     int accept = -1;
     const char *fm = getenv("KNOX_PLACEMENT_FORCE_MISS");  // tests: treat the first N candidates as misses
     const int force_miss = fm ? atoi(fm) : 0;
@@ -1412,9 +1416,18 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
             break;
         }
         if ((k & 1) == 1 && spacers.size() < 32) {
+            // 4, 4, 8, 8, 16, 16, 32 ... GiB: runs of one class are tens of GiB long, equal steps of 4 GiB did not
+            // always get out of one within 40 candidates; never more than 60 % of what is free
+            size_t want = (size_t)4 << (30 + std::min<size_t>(spacers.size() / 2, 3));
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+            while (want > ((size_t)4 << 30) && spacer_bytes + want > (size_t)(0.6 * (double)(free_b + spacer_bytes))) want >>= 1;
             void *sp = nullptr;
-            if (hipMalloc(&sp, (size_t)4 << 30) == hipSuccess) spacers.push_back(sp);
-            else (void)hipGetLastError();
+            if (spacer_bytes + want <= (size_t)(0.6 * (double)(free_b + spacer_bytes)) && hipMalloc(&sp, want) == hipSuccess) {
+                spacers.push_back(sp);
+                spacer_bytes += want;
+            } else
+                (void)hipGetLastError();
         }
     }
     for (void *sp : spacers) hipFree(sp);
@@ -1438,8 +1451,9 @@ static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col
     if (b.cap >= bytes) return KNOX_OK;
     if (!ctx->placement || !col || col->n_rows < ((uint64_t)1 << 24)) return ensure(ctx, b, bytes);
     const void *rc = col->dev;
-    uint64_t rr = col->n_rows;
-    if (col->width != 8 || col->dtype == KNOX_BYTES) rc = get_ref_col(ctx, &rr);
+    uint64_t rr = col->n_rows * (uint64_t)col->width / 8;  // the column's memory as int64 rows
+    int pw = col->width;
+    if (col->dtype == KNOX_BYTES) { rc = get_ref_col(ctx, &rr); pw = 8; }
     if (!rc) return ensure(ctx, b, bytes);
     if (b.p) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1449,7 +1463,7 @@ static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col
     }
     size_t cap = std::max<size_t>(bytes, (size_t)(kProbeChunkRows >> 3) + 256);
     cap = (cap + 255) & ~(size_t)255;
-    hipError_t e = write_buf_alloc_matched(ctx, &b.p, cap, rc, rr, nullptr, nullptr);
+    hipError_t e = write_buf_alloc_matched(ctx, &b.p, cap, rc, rr, nullptr, nullptr, pw);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         b.p = nullptr;
@@ -1469,8 +1483,9 @@ static int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, 
     b->size = size_bits;
     b->cap_bytes = bits_padded(size_bits) + 64;
     hipError_t e;
-    if (for_col && for_col->width == 8 && for_col->dtype != KNOX_BYTES)
-        e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, for_col->dev, for_col->n_rows, &b->probe_gbs, &b->probe_candidates);
+    if (for_col && for_col->dtype != KNOX_BYTES)  // any numeric column: the probe pairs memory regions, not types
+        e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, for_col->dev, for_col->n_rows * (uint64_t)for_col->width / 8, &b->probe_gbs,
+                                    &b->probe_candidates, for_col->width);
     else if (ctx->placement && (for_col || size_bits >= ((size_t)1 << 27))) {
         // any other large bitset: the class of this context's placed columns (they all share one)
         uint64_t rr = 0;
