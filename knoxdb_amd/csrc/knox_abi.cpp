@@ -1386,11 +1386,17 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     auto probe_all = [&](void *p) {  // mix rate of the worst pair, scaled to chunk 0's read-only rate
         double worst = 0.0;
         for (size_t i = 0; i < chunk_off.size(); i++) {
-            const double r = probe_pair(ctx, (const char *)col + chunk_off[i] * 8, rows, (char *)p + chunk_off[i] / (uint64_t)width);  // byte B of the column <-> bits byte B / (8 * width)
-            if (r <= 0.0) return 0.0;
-            const double scaled = r / chunk_ro[i] * ro;
-            if (worst == 0.0 || scaled < worst) worst = scaled;
-            if (r / chunk_ro[i] < kMatchRatio) break;  // already a miss
+            // byte B of the column <-> bits byte B / (8 * width); one probe writes rows/8 bytes, the real scan of this
+            // chunk writes 8/width times as many: every such part is probed
+            bool miss = false;
+            for (int part = 0; part < 8 / width && !miss; part++) {
+                const double r = probe_pair(ctx, (const char *)col + chunk_off[i] * 8, rows, (char *)p + chunk_off[i] / (uint64_t)width + (uint64_t)part * (rows >> 3));
+                if (r <= 0.0) return 0.0;
+                const double scaled = r / chunk_ro[i] * ro;
+                if (worst == 0.0 || scaled < worst) worst = scaled;
+                miss = r / chunk_ro[i] < kMatchRatio;
+            }
+            if (miss) break;  // already a miss
         }
         return worst;
     };
