@@ -93,6 +93,12 @@ struct knox_ctx {
     struct Held { void *p; size_t bytes; };
     std::vector<Held> held;
     size_t held_bytes = 0;
+    // freed column buffers >= 256 MiB are kept for the next column of exactly that size instead of going back to
+    // the driver: returning a multi-GiB buffer slows its live neighbours (measured: read-only 7.15 -> 6.8-6.95 TB/s,
+    // the scan down to 0.78 of peak on one box), and a reused block keeps its measured placement
+    struct Cached { void *p; size_t bytes; double probe_gbs, probe_ratio; };
+    std::vector<Cached> cache;
+    size_t cache_bytes = 0;
     int placement = 1;             // 0 = plain hipMalloc
     DevBuf probe_bits;             // reference bitset window (fixed size): defines the class placed buffers match
     const void *ref_col = nullptr; // a placed column (still alive) that write buffers are matched against
@@ -119,6 +125,7 @@ struct knox_col {
     double probe_gbs = 0.0;    // placement probe of the accepted buffer: mix rate of its worst chunk (0 = not probed)
     double probe_ratio = 0.0;  // mix / read-only of that chunk (>= 0.90: same class as the context's reference)
     int probe_candidates = 0;
+    size_t alloc_bytes = 0;    // size of the owned allocation behind `dev` (block cache key)
 };
 
 struct knox_bits {
@@ -160,11 +167,14 @@ static void release_held(knox_ctx *ctx) {
     for (auto &h : ctx->held) hipFree(h.p);
     ctx->held.clear();
     ctx->held_bytes = 0;
+    for (auto &c : ctx->cache) hipFree(c.p);
+    ctx->cache.clear();
+    ctx->cache_bytes = 0;
 }
 // hipMalloc that gives the held (slow-probed) regions back to the driver before reporting OOM
 static hipError_t dev_malloc(knox_ctx *ctx, void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && ctx && !ctx->held.empty()) {
+    if (e != hipSuccess && ctx && (!ctx->held.empty() || !ctx->cache.empty())) {
         (void)hipGetLastError();
         hipStreamSynchronize(ctx->stream);
         release_held(ctx);
@@ -383,8 +393,8 @@ KNOX_API int knox_ctx_set_placement(knox_ctx *ctx, int mode) {
 
 KNOX_API int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *held_regions) {
     if (!ctx) return KNOX_E_INVALID;
-    if (held_bytes) *held_bytes = (int64_t)ctx->held_bytes;
-    if (held_regions) *held_regions = (int)ctx->held.size();
+    if (held_bytes) *held_bytes = (int64_t)(ctx->held_bytes + ctx->cache_bytes);  // unlike regions held + freed blocks kept for reuse
+    if (held_regions) *held_regions = (int)(ctx->held.size() + ctx->cache.size());
     return KNOX_OK;
 }
 
@@ -532,6 +542,7 @@ static constexpr size_t kProbeMinBytes = (size_t)256 << 20;
 static constexpr uint64_t kProbeChunkRows = (uint64_t)1 << 28;  // probe granularity: 2 GiB of int64 against a 32 MiB bitset window
 static constexpr int kProbeCandidates = 6;
 static constexpr int kMaxCandidates = 40;
+static constexpr size_t kCacheCapBytes = (size_t)64 << 30;  // freed column blocks kept for reuse (given back under memory pressure)
 static constexpr double kMatchRatio = 0.90;  // mix / read-only: ~0.95 like classes, ~0.84 unlike
 static constexpr size_t kHeldCapBytes = (size_t)96 << 30;
 
@@ -616,7 +627,20 @@ static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, double *ratio) {
 static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
     const char *fl = getenv("KNOX_COL_MALLOC_FLAGS");  // diagnostics: hipExtMallocWithFlags flag (e.g. 4 = contiguous)
     if (fl && atoi(fl) > 0) return hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl));
+    c->alloc_bytes = bytes;
     if (!ctx->placement || bytes < kProbeMinBytes) return dev_malloc(ctx, &c->dev, bytes);
+    for (size_t i = 0; i < ctx->cache.size(); i++) {
+        if (ctx->cache[i].bytes == bytes && ctx->cache[i].probe_ratio >= kMatchRatio) {  // a block this context freed earlier
+            c->dev = ctx->cache[i].p;
+            c->probe_gbs = ctx->cache[i].probe_gbs;
+            c->probe_ratio = ctx->cache[i].probe_ratio;
+            c->probe_candidates = 0;
+            ctx->cache_bytes -= bytes;
+            ctx->cache.erase(ctx->cache.begin() + (long)i);
+            if (!ctx->ref_col) { ctx->ref_col = c->dev; ctx->ref_rows = bytes / 8; }
+            return hipSuccess;
+        }
+    }
     hipStreamSynchronize(ctx->stream);
     struct Cand { void *p; double mix, ratio; };
     std::vector<Cand> cands;
@@ -1340,8 +1364,14 @@ KNOX_API int knox_col_free(knox_col *col) {
     hipSetDevice(col->ctx->device);
     hipStreamSynchronize(col->ctx->stream);
     if (col->owned && col->dev) {
-        if (col->ctx->ref_col == col->dev) col->ctx->ref_col = nullptr;
-        hipFree(col->dev);
+        knox_ctx *ctx = col->ctx;
+        if (ctx->ref_col == col->dev) ctx->ref_col = nullptr;
+        if (ctx->placement && col->alloc_bytes >= kProbeMinBytes && col->probe_ratio >= kMatchRatio &&
+            ctx->cache_bytes + col->alloc_bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
+            ctx->cache.push_back({col->dev, col->alloc_bytes, col->probe_gbs, col->probe_ratio});
+            ctx->cache_bytes += col->alloc_bytes;
+        } else
+            hipFree(col->dev);
     }
     if (col->buf) hipFree(col->buf);
     delete col;
