@@ -16,7 +16,8 @@ def short(name):
 
 
 print("# rocprofv3 summary of `python3 bench.py --no-cpu-baseline` = the default run, 20 steps + 3 warmup (%s)" % os.path.basename(root))
-print("# scan_kernel<8, 1, 1u, false, false, 0u> = the timed scans; <..., 1u> (FLV 1) = the allocator's placement probes")
+print("# scan_kernel<8, 1, 1u, false, false, 0u> = the scans: 12 of bench.py's setup check + 3 warmup + 20 timed; <..., 1u> (FLV 1) = the allocator's placement probes;")
+print("# scan_kernel<8, 1, 0u, ...> = the read-only form (setup: two candidate columns and the pair check; after the timed region: the ceiling)")
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("\n## kernel stats (--kernel-trace --stats)")
     print("%-92s %7s %12s %12s %8s" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
