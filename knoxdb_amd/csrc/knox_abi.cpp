@@ -1431,7 +1431,7 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
         return worst;
     };
     std::vector<std::pair<void *, double>> cands;
-    std::vector<void *> spacers;
+    std::vector<std::pair<void *, size_t>> spacers;
     size_t spacer_bytes = 0;
     int accept = -1;
     const char *fm = getenv("KNOX_PLACEMENT_FORCE_MISS");  // tests: treat the first N candidates as misses
@@ -1460,13 +1460,23 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
             while (want > ((size_t)4 << 30) && spacer_bytes + want > (size_t)(0.6 * (double)(free_b + spacer_bytes))) want >>= 1;
             void *sp = nullptr;
             if (spacer_bytes + want <= (size_t)(0.6 * (double)(free_b + spacer_bytes)) && hipMalloc(&sp, want) == hipSuccess) {
-                spacers.push_back(sp);
+                spacers.push_back({sp, want});
                 spacer_bytes += want;
             } else
                 (void)hipGetLastError();
         }
     }
-    for (void *sp : spacers) hipFree(sp);
+    // nothing goes back to the driver while the context works (returning a large buffer slows its live neighbours):
+    // spacers and rejected candidates join the held regions, which are released under memory pressure, when
+    // placement is switched off and at close
+    auto park = [&](void *q, size_t n) {
+        if (ctx->held_bytes + n <= kHeldCapBytes) {
+            ctx->held.push_back({q, n});
+            ctx->held_bytes += n;
+        } else
+            hipFree(q);
+    };
+    for (auto &sp : spacers) park(sp.first, sp.second);
     if (cands.empty()) return hipErrorOutOfMemory;
     if (accept < 0) {
         accept = 0;
@@ -1474,7 +1484,7 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
             if (cands[i].second > cands[accept].second) accept = (int)i;
     }
     for (size_t i = 0; i < cands.size(); i++)
-        if ((int)i != accept) hipFree(cands[i].first);
+        if ((int)i != accept) park(cands[i].first, bytes);
     *out = cands[accept].first;
     if (rate) *rate = cands[accept].second;
     if (tried) *tried = (int)cands.size();

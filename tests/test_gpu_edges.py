@@ -269,8 +269,9 @@ def test_pinned_host_memory_round_trip(ctx):
 
 @pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
 def test_placement_search_with_spacers_returns_everything(monkeypatch):
-    """the write-buffer search parks 4 GiB spacers after every second miss and must give all of them
-    (and every rejected candidate) back; KNOX_PLACEMENT_FORCE_MISS drives it through that path"""
+    """the write-buffer search parks spacers after every second miss; spacers and rejected candidates are HELD
+    (returning memory to the driver slows live buffers) and must all come back when placement is
+    switched off; KNOX_PLACEMENT_FORCE_MISS drives the search through that path"""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     free0, free1, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
@@ -284,11 +285,15 @@ def test_placement_search_with_spacers_returns_everything(monkeypatch):
         bits = c.bits(n, for_col=col)
         monkeypatch.delenv("KNOX_PLACEMENT_FORCE_MISS")
         assert bits.placement[1] >= 8  # 7 forced misses (3 spacers parked on the way) + the one taken
+        info = c.placement_info()
+        assert info["held_bytes"] >= (12 << 30) and info["held_regions"] >= 10     # 7 candidates + spacers of 4, 4, 8 GiB
+        r = c.scan(And(Leaf(0, FilterMode.Lt, 1000)), [col], bits_out=bits)
+        assert r.count == 1000 == bits.count()
+        c.set_placement(False)   # everything held goes back
+        assert c.placement_info() == {"held_bytes": 0, "held_regions": 0}
         c.sync()
         hip.hipMemGetInfo(C.byref(free1), C.byref(tot))
         # only the accepted 4 MiB bitset (+ allocator granularity) stays allocated
         assert free0.value - free1.value < (64 << 20), (free0.value, free1.value)
-        r = c.scan(And(Leaf(0, FilterMode.Lt, 1000)), [col], bits_out=bits)
-        assert r.count == 1000 == bits.count()
         bits.free()
         col.free()
