@@ -1439,6 +1439,20 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     // Regions of one class come in runs of tens of GiB in the driver's allocation order, and a small
     // buffer moves through that order slowly: after every second miss a 4 GiB spacer is parked (and
     // given back at the end) so that the search reaches the next run.
+    // write buffers this context freed earlier (kept, not returned to the driver): one of the right size that is
+    // fast with this column is taken before anything new is allocated
+    for (size_t i = 0; i < ctx->cache.size() && force_miss == 0; i++) {
+        if (ctx->cache[i].bytes != bytes || ctx->cache[i].probe_ratio != -1.0) continue;  // -1: a write buffer, not a column block
+        const double r = probe_all(ctx->cache[i].p);
+        if (r > 0.0 && r / ro >= kMatchRatio) {
+            *out = ctx->cache[i].p;
+            if (rate) *rate = r;
+            if (tried) *tried = 1;
+            ctx->cache_bytes -= bytes;
+            ctx->cache.erase(ctx->cache.begin() + (long)i);
+            return hipSuccess;
+        }
+    }
     for (int k = 0; k < 40; k++) {
         void *p = nullptr;
         if ((cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes)) != hipSuccess) {
@@ -1588,7 +1602,14 @@ KNOX_API int knox_bits_free(knox_bits *b) {
     if (!b) return KNOX_E_INVALID;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    if (b->dev && b->owned) hipFree(b->dev);
+    if (b->dev && b->owned) {
+        knox_ctx *ctx = b->ctx;
+        if (ctx->placement && b->cap_bytes >= ((size_t)16 << 20) && ctx->cache_bytes + b->cap_bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
+            ctx->cache.push_back({b->dev, b->cap_bytes, 0.0, -1.0});  // kept for the next bitset of this size (re-probed against its column)
+            ctx->cache_bytes += b->cap_bytes;
+        } else
+            hipFree(b->dev);
+    }
     delete b;
     return KNOX_OK;
 }
