@@ -297,3 +297,41 @@ def test_placement_search_with_spacers_returns_everything(monkeypatch):
         assert free0.value - free1.value < (64 << 20), (free0.value, free1.value)
         bits.free()
         col.free()
+
+
+@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
+def test_freed_blocks_are_kept_and_reused_not_returned_to_the_driver():
+    """returning a large buffer to the driver slows its live neighbours: freed column blocks >= 256 MiB
+    and bitsets >= 16 MiB stay with the context, serve the next request of their size, and go back to the driver
+    when placement is switched off (or memory is needed, or at close)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    f0, f1, f2, tot = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    n = (1 << 25) + 4096          # 256 MiB + a little of int64
+    x = np.arange(n, dtype=np.int64)
+    with K.Context(0) as c:
+        col = c.upload(x, 1 << 20)
+        if col.placement[2] < 0.90:
+            pytest.skip("no block of the reference class on this box")
+        nbits = 1 << 28           # 32 MiB bitset
+        bits = c.bits(nbits)
+        p_col, p_bits = col.device_ptr, bits.device_ptr
+        c.sync()
+        hip.hipMemGetInfo(C.byref(f0), C.byref(tot))
+        col.free(); bits.free()
+        hip.hipMemGetInfo(C.byref(f1), C.byref(tot))
+        assert abs(f1.value - f0.value) < (8 << 20)          # nothing went back
+        assert c.placement_info()["held_bytes"] >= n * 8
+        col2 = c.upload(x + 1, 1 << 20)
+        assert col2.device_ptr == p_col and col2.placement[1] == 0     # the same block, no new candidates
+        r = c.scan(And(Leaf(0, FilterMode.Le, 10)), [col2], aggs=[(R.Sum, 0)])
+        assert r.count == 10 and int(r.value(0)[0]) == sum(range(1, 11))
+        bits2 = c.bits(nbits)
+        assert bits2.count() == 0                                       # zeroed whether reused or new
+        # the old bitset block is re-probed against the live column: taken if the pair is fast, else it stays cached
+        assert bits2.device_ptr == p_bits or c.placement_info()["held_bytes"] >= (32 << 20)
+        col2.free(); bits2.free()
+        c.set_placement(False)
+        c.sync()
+        hip.hipMemGetInfo(C.byref(f2), C.byref(tot))
+        assert f2.value - f0.value >= n * 8 - (16 << 20)     # now the driver has them
