@@ -171,6 +171,10 @@ static void release_held(knox_ctx *ctx) {
     ctx->cache.clear();
     ctx->cache_bytes = 0;
 }
+// a large buffer the context no longer needs: kept (as a write-buffer block for reuse) rather than returned to the
+// driver while the context works -- see knox_ctx::cache
+static void retire(knox_ctx *ctx, void *p, size_t bytes);
+
 // hipMalloc that gives the held (slow-probed) regions back to the driver before reporting OOM
 static hipError_t dev_malloc(knox_ctx *ctx, void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
@@ -188,7 +192,7 @@ static int ensure(knox_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.p) {
         // the stream may still be using the old buffer
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipFree(b.p));
+        retire(ctx, b.p, b.cap);
         b.p = nullptr;
         b.cap = 0;
     }
@@ -622,6 +626,14 @@ static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, double *ratio) {
     }
     *ratio = worst_ratio;
     return worst;
+}
+
+static void retire(knox_ctx *ctx, void *p, size_t bytes) {
+    if (ctx->placement && bytes >= ((size_t)16 << 20) && ctx->cache_bytes + bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
+        ctx->cache.push_back({p, bytes, 0.0, -1.0});
+        ctx->cache_bytes += bytes;
+    } else
+        hipFree(p);
 }
 
 static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
@@ -1517,7 +1529,7 @@ static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col
     if (!rc) return ensure(ctx, b, bytes);
     if (b.p) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipFree(b.p));
+        retire(ctx, b.p, b.cap);
         b.p = nullptr;
         b.cap = 0;
     }
@@ -1603,12 +1615,7 @@ KNOX_API int knox_bits_free(knox_bits *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     if (b->dev && b->owned) {
-        knox_ctx *ctx = b->ctx;
-        if (ctx->placement && b->cap_bytes >= ((size_t)16 << 20) && ctx->cache_bytes + b->cap_bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
-            ctx->cache.push_back({b->dev, b->cap_bytes, 0.0, -1.0});  // kept for the next bitset of this size (re-probed against its column)
-            ctx->cache_bytes += b->cap_bytes;
-        } else
-            hipFree(b->dev);
+        retire(b->ctx, b->dev, b->cap_bytes);  // kept for the next bitset of this size (re-probed against its column)
     }
     delete b;
     return KNOX_OK;
