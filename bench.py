@@ -9,7 +9,17 @@ generated on the device (counter-based generator) and are resident in
 timed region starts.  For N > 1 each rank owns a contiguous pack range (no data-path
 collective); only the 144-byte partial aggregate state crosses xGMI (RCCL all-gather) each step.
 
-Prints ONE JSON line (rank 0).
+Setup, outside the timed region and reported under "placement" in the JSON line: two candidate
+columns are generated and the one whose read-only scan is faster is kept; the bitset is allocated for that
+column (knox_bits_alloc_for: the pair is probed); the pair is then checked with the real kernel against its own
+read-only form and replaced when it falls short; nothing is returned to the driver before the measurement
+(freeing a multi-GiB neighbour slows the buffers that stay).  The timed region contains only the K steps.
+
+Environment (diagnostics, none needed): KNOX_PLACEMENT=0 plain hipMalloc; KNOX_BENCH_RETUNE_MIN pair-check threshold
+(default 0.925); KNOX_BENCH_DEPTH scans queued ahead; KNOX_BENCH_FORCE_DIST=1 / KNOX_BENCH_BACKEND=gloo rehearsal modes
+of the multi-rank path on a 1-GPU box.
+
+Prints ONE JSON line on stdout (rank 0); progress notes go to stderr.
 """
 import argparse
 import json
