@@ -12,7 +12,9 @@ collective); only the 144-byte partial aggregate state crosses xGMI (RCCL all-ga
 Setup, outside the timed region and reported under "placement" in the JSON line: two candidate
 columns are generated and the one whose read-only scan is faster is kept; the bitset is allocated for that
 column (knox_bits_alloc_for: the pair is probed); the pair is then checked with the real kernel against its own
-read-only form and replaced when it falls short; nothing is returned to the driver before the measurement
+read-only form; when it falls short the check first waits 2.5 s and measures again (a device still busy after
+somebody's large frees recovers by itself), then asks for other buffers and uses the best pair seen; nothing is
+returned to the driver before the measurement
 (freeing a multi-GiB neighbour slows the buffers that stay).  The timed region contains only the K steps.
 
 Environment (diagnostics, none needed): KNOX_PLACEMENT=0 plain hipMalloc; KNOX_BENCH_RETUNE_MIN pair-check threshold
@@ -201,7 +203,11 @@ def main():
             if attempt == 3:
                 break
             retuned += 1
-            if attempt % 2 == 0:                          # a new bitset for the same column
+            if attempt == 0:
+                # first suspicion: the device is still busy with somebody else's memory (a process that just exited
+                # with 100+ GiB allocated leaves the driver clearing it; such runs recover by themselves): wait, re-measure
+                time.sleep(2.5)
+            elif attempt == 1:                            # a new bitset for the same column
                 bits = ctx.bits(n_rows, for_col=col)
             else:                                         # a new column, and a bitset for it
                 col = make_col()
