@@ -227,3 +227,48 @@ def test_regexp_compiler_under_sanitizers(tmp_path):
     out = subprocess.run([exe, "15000", "3"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "compiled" in out.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_regexp_counts_at_scale():
+    """2^22 rows = the decimal strings of 0 .. 2^22-1: match counts with closed forms (size-independent properties),
+    through knox_match_regexp and through a scan plan, plus complement / partition identities."""
+    from knoxdb_amd import And, Leaf
+    from knoxdb_amd.types import FilterMode
+    n = 1 << 22
+    strs = np.arange(n).astype("S7")                      # NUL padded to 7 bytes
+    lens = np.char.str_len(strs).astype(np.uint64)
+    flat = strs.view(np.uint8).reshape(n, 7)
+    buf = np.concatenate([flat[np.arange(7)[None, :] < lens[:, None]], np.zeros(8, np.uint8)])
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    idx = np.arange(n)
+    first = idx // (10 ** (lens.astype(np.int64) - 1))
+    cases = {
+        "^1": int((first == 1).sum()),
+        "7$": int((idx % 10 == 7).sum()),
+        r"^\d{3}$": 900,
+        r"^\d{7}$": n - 1_000_000,
+        "^(12|34)": int(((idx // (10 ** np.maximum(lens.astype(np.int64) - 2, 0)) == 12) & (lens >= 2)).sum()
+                        + ((idx // (10 ** np.maximum(lens.astype(np.int64) - 2, 0)) == 34) & (lens >= 2)).sum()),
+        "^[0-9]*$": n,
+        "[^0-9]": 0,
+        "^0": 1,
+        "000$": int((idx % 1000 == 0).sum()) - 1,          # "0" itself has no three zeros
+    }
+    with K.Context(0) as ctx:
+        col = ctx.upload_bytes(ptr, buf, 1 << 16)
+        bits = ctx.bits(n)
+        for pat, want in cases.items():
+            _, cnt = ctx.match_regexp(col, pat, bits=bits)
+            assert cnt == want == bits.count(), (pat, cnt, want)
+            r = ctx.scan(And(Leaf(0, FilterMode.Regexp, pat.encode())), [col], pack_counts=True)
+            assert r.count == want and int(r.pack_counts.sum()) == want, pat
+        # partition: rows ending in an even digit + rows ending in an odd digit = all rows
+        _, even = ctx.match_regexp(col, "[02468]$", bits=bits)
+        odd_bits = ctx.bits(n)
+        _, odd = ctx.match_regexp(col, "[13579]$", bits=odd_bits)
+        assert even + odd == n and even == n // 2
+        bits.and_(odd_bits)
+        assert bits.count() == 0
+        col.free(); bits.free(); odd_bits.free()
