@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -163,7 +164,14 @@ static bool dtype_is_float(int dtype) { return dtype == KNOX_FLOAT64 || dtype ==
 static bool dtype_is_signed(int dtype) { return dtype >= KNOX_INT64 && dtype <= KNOX_INT8; }
 static uint32_t dtype_flavor(int dtype) { return dtype_is_float(dtype) ? FL_FLOAT : dtype_is_signed(dtype) ? FL_SIGNED : FL_UNSIGNED; }
 
-static void release_held(knox_ctx *ctx) {
+// Held regions and cached blocks are plain free memory that contexts keep away from the driver; every context of
+// the process is registered so that an allocation that fails can take them back from ALL contexts on its device
+// (several contexts may be alive at once: one per host thread).  g_mem_mu guards the registry and every
+// held / cache vector; it is never held across a HIP allocation.
+static std::mutex g_mem_mu;
+static std::vector<knox_ctx *> g_ctxs;
+
+static void release_held_locked(knox_ctx *ctx) {
     for (auto &h : ctx->held) hipFree(h.p);
     ctx->held.clear();
     ctx->held_bytes = 0;
@@ -171,18 +179,29 @@ static void release_held(knox_ctx *ctx) {
     ctx->cache.clear();
     ctx->cache_bytes = 0;
 }
+static void release_held(knox_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    release_held_locked(ctx);
+}
 // a large buffer the context no longer needs: kept (as a write-buffer block for reuse) rather than returned to the
 // driver while the context works -- see knox_ctx::cache
 static void retire(knox_ctx *ctx, void *p, size_t bytes);
 
-// hipMalloc that gives the held (slow-probed) regions back to the driver before reporting OOM
+// hipMalloc that gives the held (slow-probed) regions and cached blocks back to the driver before reporting OOM
 static hipError_t dev_malloc(knox_ctx *ctx, void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && ctx && (!ctx->held.empty() || !ctx->cache.empty())) {
+    if (e != hipSuccess && ctx) {
         (void)hipGetLastError();
-        hipStreamSynchronize(ctx->stream);
-        release_held(ctx);
-        e = hipMalloc(p, bytes);
+        bool any = false;
+        {
+            std::lock_guard<std::mutex> lk(g_mem_mu);
+            for (knox_ctx *c : g_ctxs) {
+                if (c->device != ctx->device || (c->held.empty() && c->cache.empty())) continue;
+                release_held_locked(c);  // free blocks: no stream of that context uses them
+                any = true;
+            }
+        }
+        if (any) e = hipMalloc(p, bytes);
     }
     return e;
 }
@@ -293,6 +312,10 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
     if (env) c->variant = atoi(env);
     env = getenv("KNOX_PLACEMENT");
     if (env) c->placement = atoi(env);
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mu);
+        g_ctxs.push_back(c);
+    }
     *out = c;
     return KNOX_OK;
 }
@@ -311,7 +334,11 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
         if (b->p) hipFree(b->p);
     if (ctx->probe_bits.p) hipFree(ctx->probe_bits.p);
     if (ctx->ref_scratch) hipFree(ctx->ref_scratch);
-    release_held(ctx);
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mu);
+        release_held_locked(ctx);
+        g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end());
+    }
     if (ctx->pev0) hipEventDestroy(ctx->pev0);
     if (ctx->pev1) hipEventDestroy(ctx->pev1);
     for (int i = 0; i < 2; i++) {
@@ -629,11 +656,15 @@ static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, double *ratio) {
 }
 
 static void retire(knox_ctx *ctx, void *p, size_t bytes) {
-    if (ctx->placement && bytes >= ((size_t)16 << 20) && ctx->cache_bytes + bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
-        ctx->cache.push_back({p, bytes, 0.0, -1.0});
-        ctx->cache_bytes += bytes;
-    } else
-        hipFree(p);
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mu);
+        if (ctx->placement && bytes >= ((size_t)16 << 20) && ctx->cache_bytes + bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
+            ctx->cache.push_back({p, bytes, 0.0, -1.0});
+            ctx->cache_bytes += bytes;
+            return;
+        }
+    }
+    hipFree(p);
 }
 
 static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
@@ -641,16 +672,19 @@ static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
     if (fl && atoi(fl) > 0) return hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl));
     c->alloc_bytes = bytes;
     if (!ctx->placement || bytes < kProbeMinBytes) return dev_malloc(ctx, &c->dev, bytes);
-    for (size_t i = 0; i < ctx->cache.size(); i++) {
-        if (ctx->cache[i].bytes == bytes && ctx->cache[i].probe_ratio >= kMatchRatio) {  // a block this context freed earlier
-            c->dev = ctx->cache[i].p;
-            c->probe_gbs = ctx->cache[i].probe_gbs;
-            c->probe_ratio = ctx->cache[i].probe_ratio;
-            c->probe_candidates = 0;
-            ctx->cache_bytes -= bytes;
-            ctx->cache.erase(ctx->cache.begin() + (long)i);
-            if (!ctx->ref_col) { ctx->ref_col = c->dev; ctx->ref_rows = bytes / 8; }
-            return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mu);
+        for (size_t i = 0; i < ctx->cache.size(); i++) {
+            if (ctx->cache[i].bytes == bytes && ctx->cache[i].probe_ratio >= kMatchRatio) {  // a block this context freed earlier
+                c->dev = ctx->cache[i].p;
+                c->probe_gbs = ctx->cache[i].probe_gbs;
+                c->probe_ratio = ctx->cache[i].probe_ratio;
+                c->probe_candidates = 0;
+                ctx->cache_bytes -= bytes;
+                ctx->cache.erase(ctx->cache.begin() + (long)i);
+                if (!ctx->ref_col) { ctx->ref_col = c->dev; ctx->ref_rows = bytes / 8; }
+                return hipSuccess;
+            }
         }
     }
     hipStreamSynchronize(ctx->stream);
@@ -690,12 +724,16 @@ static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
     for (size_t i = 0; i < cands.size(); i++) {
         if ((int)i == accept) continue;
         // unlike regions are kept away from the driver's free list while like ones can still be found
-        if (matched && ctx->held_bytes + bytes <= kHeldCapBytes) {
-            ctx->held.push_back({cands[i].p, bytes});
-            ctx->held_bytes += bytes;
-        } else {
-            hipFree(cands[i].p);
+        bool kept = false;
+        {
+            std::lock_guard<std::mutex> lk(g_mem_mu);
+            if (matched && ctx->held_bytes + bytes <= kHeldCapBytes) {
+                ctx->held.push_back({cands[i].p, bytes});
+                ctx->held_bytes += bytes;
+                kept = true;
+            }
         }
+        if (!kept) hipFree(cands[i].p);
     }
     c->dev = cands[accept].p;
     c->probe_gbs = cands[accept].mix;
@@ -1378,12 +1416,17 @@ KNOX_API int knox_col_free(knox_col *col) {
     if (col->owned && col->dev) {
         knox_ctx *ctx = col->ctx;
         if (ctx->ref_col == col->dev) ctx->ref_col = nullptr;
-        if (ctx->placement && col->alloc_bytes >= kProbeMinBytes && col->probe_ratio >= kMatchRatio &&
-            ctx->cache_bytes + col->alloc_bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
-            ctx->cache.push_back({col->dev, col->alloc_bytes, col->probe_gbs, col->probe_ratio});
-            ctx->cache_bytes += col->alloc_bytes;
-        } else
-            hipFree(col->dev);
+        bool kept = false;
+        {
+            std::lock_guard<std::mutex> lk(g_mem_mu);
+            if (ctx->placement && col->alloc_bytes >= kProbeMinBytes && col->probe_ratio >= kMatchRatio &&
+                ctx->cache_bytes + col->alloc_bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
+                ctx->cache.push_back({col->dev, col->alloc_bytes, col->probe_gbs, col->probe_ratio});
+                ctx->cache_bytes += col->alloc_bytes;
+                kept = true;
+            }
+        }
+        if (!kept) hipFree(col->dev);
     }
     if (col->buf) hipFree(col->buf);
     delete col;
@@ -1453,15 +1496,34 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     // given back at the end) so that the search reaches the next run.
     // write buffers this context freed earlier (kept, not returned to the driver): one of the right size that is
     // fast with this column is taken before anything new is allocated
-    for (size_t i = 0; i < ctx->cache.size() && force_miss == 0; i++) {
-        if (ctx->cache[i].bytes != bytes || ctx->cache[i].probe_ratio != -1.0) continue;  // -1: a write buffer, not a column block
-        const double r = probe_all(ctx->cache[i].p);
-        if (r > 0.0 && r / ro >= kMatchRatio) {
-            *out = ctx->cache[i].p;
-            if (rate) *rate = r;
+    if (force_miss == 0) {
+        std::vector<void *> mine;   // taken out under the lock, probed outside it, put back if they do not fit
+        {
+            std::lock_guard<std::mutex> lk(g_mem_mu);
+            for (size_t i = 0; i < ctx->cache.size();) {
+                if (ctx->cache[i].bytes == bytes && ctx->cache[i].probe_ratio == -1.0) {  // -1: a write buffer, not a column block
+                    mine.push_back(ctx->cache[i].p);
+                    ctx->cache_bytes -= bytes;
+                    ctx->cache.erase(ctx->cache.begin() + (long)i);
+                } else
+                    i++;
+            }
+        }
+        void *hit = nullptr;
+        double hit_rate = 0.0;
+        for (void *q : mine) {
+            if (!hit) {
+                const double r = probe_all(q);
+                if (r > 0.0 && r / ro >= kMatchRatio) { hit = q; hit_rate = r; continue; }
+            }
+            std::lock_guard<std::mutex> lk(g_mem_mu);
+            ctx->cache.push_back({q, bytes, 0.0, -1.0});
+            ctx->cache_bytes += bytes;
+        }
+        if (hit) {
+            *out = hit;
+            if (rate) *rate = hit_rate;
             if (tried) *tried = 1;
-            ctx->cache_bytes -= bytes;
-            ctx->cache.erase(ctx->cache.begin() + (long)i);
             return hipSuccess;
         }
     }
@@ -1496,11 +1558,15 @@ static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t byte
     // spacers and rejected candidates join the held regions, which are released under memory pressure, when
     // placement is switched off and at close
     auto park = [&](void *q, size_t n) {
-        if (ctx->held_bytes + n <= kHeldCapBytes) {
-            ctx->held.push_back({q, n});
-            ctx->held_bytes += n;
-        } else
-            hipFree(q);
+        {
+            std::lock_guard<std::mutex> lk(g_mem_mu);
+            if (ctx->held_bytes + n <= kHeldCapBytes) {
+                ctx->held.push_back({q, n});
+                ctx->held_bytes += n;
+                return;
+            }
+        }
+        hipFree(q);
     };
     for (auto &sp : spacers) park(sp.first, sp.second);
     if (cands.empty()) return hipErrorOutOfMemory;

@@ -335,3 +335,32 @@ def test_freed_blocks_are_kept_and_reused_not_returned_to_the_driver():
         c.sync()
         hip.hipMemGetInfo(C.byref(f2), C.byref(tot))
         assert f2.value - f0.value >= n * 8 - (16 << 20)     # now the driver has them
+
+
+@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
+def test_memory_held_by_one_context_is_given_back_when_another_needs_it(monkeypatch):
+    """held regions / cached blocks are free memory kept away from the driver: an allocation that would fail takes
+    them back from EVERY context of the process on that device"""
+    import ctypes as C
+    from knoxdb_amd.types import BlockType
+    hip = C.CDLL("libamdhip64.so")
+    free_b, tot = C.c_size_t(), C.c_size_t()
+    n = 1 << 25
+    with K.Context(0) as a, K.Context(0) as b:
+        col = a.upload(np.arange(n, dtype=np.int64), 1 << 20)
+        monkeypatch.setenv("KNOX_PLACEMENT_FORCE_MISS", "7")
+        bits = a.bits(n, for_col=col)
+        monkeypatch.delenv("KNOX_PLACEMENT_FORCE_MISS")
+        held = a.placement_info()["held_bytes"]
+        assert held >= (12 << 30)
+        a.sync()
+        hip.hipMemGetInfo(C.byref(free_b), C.byref(tot))
+        if free_b.value < (150 << 30):
+            pytest.skip("device memory mostly taken by somebody else")
+        want = free_b.value + held // 2              # more than the driver has, less than it has plus what `a` holds
+        big = b.generate(BlockType.Uint8, 0, 1, want, lo=0, span=200, pack_rows=1 << 20)
+        assert big.rows == want
+        assert a.placement_info() == {"held_bytes": 0, "held_regions": 0}
+        r = b.scan(And(Leaf(0, FilterMode.Lt, 100)), [big])
+        assert abs(r.count / want - 0.5) < 0.01
+        big.free(); bits.free(); col.free()
