@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     if ((a.debug & 8u) && (gridDim.x & 7u) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // per-wave-tile popcounts, laid out [workgroup][wave][round] so that a wave's counts are contiguous
     uint32_t *tcbase = a.tile_counts ? a.tile_counts + ((uint64_t)lb * kWavesPerBlock + (uint64_t)wave) * a.tc_rounds : nullptr;
-    uint32_t tcreg = 0, round = 0;
+    uint32_t tcreg = 0, round = 0, cnt_prev = 0;
     for (uint64_t vt = lb; vt < a.n_tiles; vt += gridDim.x) {
         // packs pruned by the caller's statistics are never touched: with a live-pack list the
         // virtual tile index walks only the surviving packs (their bitset ranges were zeroed by the host)
@@ -760,10 +760,12 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             // 16 iterations): whole 128-B lines, 16-byte-per-lane streaming (nt) stores.
             const uint32_t nv = iters * (WAVE_ROWS / 128);  // 16-byte vectors
             u32x4 *dst = (u32x4 *)(a.bits + (wrow0 >> 5));
-            uint32_t tc = 0;
+            // this lane's share of the burst's popcount is what its running count grew by (the wave total is all
+            // the per-tile count needs): no popcounts over the staged words
+            uint32_t tc = cnt32 - cnt_prev;
+            cnt_prev = cnt32;
             for (uint32_t v = lane; v < nv; v += 64) {
                 const u32x4 x = ((const u32x4 *)stage[wave])[v];
-                tc += __builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w);
                 // debug bit0 = diagnostics: words are assembled but never leave the CU
                 if (a.debug & 2u) dst[v] = x;  // diagnostics: plain (L2 write-back) store
                 else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
