@@ -81,6 +81,39 @@ def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts, min_seconds=10.0
             "gb_per_s": rows * BYTES_PER_ROW / dt / 1e9, "matches_gpu_counts": ok}
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher around it: start N rank processes (one per GPU, RCCL over xGMI between
+    them) and wait.  They are FRESH interpreters -- this parent has not touched the GPU and never does (a process
+    that has initialised HIP must not fork or exec its ranks) -- given RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* the
+    way torch.distributed.run would; rank 0 inherits stdout and prints the one JSON line."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30:   # a rank died: the others wait in a barrier for ever
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                          # exactly the processes started above
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,8 +123,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=29)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=-1)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     # exactly ONE line goes to stdout: libraries that print banners there (RCCL's version header) are sent to stderr
     sys.stdout.flush()
@@ -103,21 +137,32 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # KNOX_BENCH_BACKEND=gloo is a rehearsal mode only (several ranks sharing one GPU on a 1-GPU box)
+    # KNOX_BENCH_BACKEND=gloo is a rehearsal mode only (several ranks sharing one GPU on a 1-GPU box; on a box without
+    # a GPU it still brings the process group up before the device check below ends the run)
     backend = os.environ.get("KNOX_BENCH_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(device_index)
-    # KNOX_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, barriers, state all-gather over RCCL) even
+    n_dev = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if backend == "nccl" and n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    device_index = local_rank % max(1, n_dev)
+    # KNOX_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, barriers, the RCCL collectives) even
     # with one rank -- the rehearsal a 1-GPU box allows for the nccl backend
     if world > 1 or os.environ.get("KNOX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            torch.cuda.set_device(device_index)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        print("[rank %d] process group up: backend %s, %d rank(s)" % (rank, backend, dist.get_world_size()), file=sys.stderr, flush=True)
+        if args.gpus > 1 and dist.get_world_size() != args.gpus:
+            print("[rank %d] note: --gpus %d but the launcher started %d rank(s)" % (rank, args.gpus, dist.get_world_size()), file=sys.stderr)
+    if not torch.cuda.is_available():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(device_index)
     local_rank = device_index
 
     import numpy as np
@@ -132,8 +177,8 @@ def main():
     a, b = -(1 << 38), 1 << 38
     seed = 2 if world == 1 else 20 + rank  # cfg 2 seed 2, cfg 5 seeds 20..27
     ctx = K.Context(local_rank)
-    if args.blocks_per_cu or args.variant >= 0:
-        ctx.set_tuning(args.blocks_per_cu, args.variant)
+    if args.blocks_per_cu:
+        ctx.set_tuning(args.blocks_per_cu)
     # rank r owns global packs [r*n_packs, (r+1)*n_packs): row ids are offset by row_base
     first_pack, _ = kdist.shard_range(n_packs * world, rank, world)
     row_base = first_pack * pack_rows
@@ -222,7 +267,12 @@ def main():
         plan = ctx.plan(tree, [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
         ctx.sync()
 
-    gather = kdist.StateGather(2, torch.device("cuda", local_rank) if backend == "nccl" else None) if dist is not None else None
+    # the final aggregate is the ONLY thing that crosses ranks: one all-reduce(int64, sum) of {sum, count} per step
+    # (backend nccl = ncclAllReduce over xGMI); the all-gather of the full 144-byte states (what min / max / first /
+    # last / float sums need) runs in the warmup and must give the same answer
+    tdev = torch.device("cuda", local_rank) if backend == "nccl" else None
+    gather = kdist.StateGather(2, tdev) if dist is not None else None
+    reduce_sc = kdist.SumCountReduce(tdev) if dist is not None else None
 
     def enqueue():
         ctx.scan_async(plan, bits_out=bits, pack_counts=True, row_base=row_base)
@@ -230,9 +280,9 @@ def main():
     def collect():
         res = ctx.scan_collect(plan, n_packs)
         if dist is not None:
-            merged, total = gather(res.states, res.count)
-            return res, merged, total
-        return res, res.states, res.count
+            gsum, total = reduce_sc(int(res.states[0].isum), res.count)
+            return res, gsum, total
+        return res, int(res.states[0].isum), res.count
 
     # scans queued ahead of the one being collected.  With ranks > 1 every collect() ends in the RCCL all-gather of
     # the states, whose kernel can only start when the running scan's workgroups retire: a second queued scan keeps
@@ -255,14 +305,19 @@ def main():
             last = collect()
         return last
 
-    run(max(1, args.warmup))
+    wres, wsum, wtotal = run(max(1, args.warmup))
+    collectives_agree = None
+    if dist is not None:
+        merged, gtotal = gather(wres.states, wres.count)
+        collectives_agree = bool(gtotal == wtotal and int(merged[0].isum) == wsum and int(merged[1].count) == wtotal)
+        assert collectives_agree, "all-reduce {sum,count} != all-gather + combine"
     ctx.L.knox_prof_enable(ctx.h, 1)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.sync()
     t0 = time.perf_counter()
-    res, merged, total = run(args.steps)
+    res, gsum, total = run(args.steps)
     ctx.sync()
     torch.cuda.synchronize()
     if dist is not None:
@@ -295,7 +350,7 @@ def main():
     achieved = n_rows * BYTES_PER_ROW / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     total_rows = n_rows * world * args.steps
     value = total_rows / elapsed
-    sum_val = int(K.agg_value(merged[0], ReducerFunc.Sum)[0])
+    sum_val = gsum - (1 << 64) if gsum >= (1 << 63) else gsum   # Value() of the int64 SumReducer: the sum mod 2^64 as int64
 
     out = {
         "metric": "scanned rows/sec + achieved HBM GB/s, 1B-row int64 range filter+sum",
@@ -305,6 +360,8 @@ def main():
         "config": {"workload": "BASELINE configs[%d]: %s x 2^%d int64 rows, pack size 2^20, Between[-2^38,2^38] (25%% sel.) "
                                "+ sum + count, bitset + per-pack counts emitted" % (1 if world == 1 else 4, "%d GPU" % world, args.rows_log2),
                    "rows_per_gpu": n_rows, "pack_rows": pack_rows, "parallelism": "pack-sharded x%d" % world,
+                   "ranks_in_process_group": dist.get_world_size() if dist is not None else 1,
+                   "collective": ("all_reduce(int64 x3, sum) over %s every step; all_gather of the states agrees: %s" % (backend, collectives_agree)) if dist is not None else None,
                    "selected_rows": int(total), "sum_mod_2^64": sum_val},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KNOX_ABI_VERSION 2
+#define KNOX_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------------- */
 enum knox_err {
@@ -94,9 +94,8 @@ void *knox_ctx_stream(knox_ctx *ctx); /* hipStream_t */
 /* HIP-event stopwatch on the ctx stream (for achieved-GB/s measurement).                 */
 int knox_timer_start(knox_ctx *ctx);
 int knox_timer_stop(knox_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms      */
-/* Tuning knobs: workgroups per CU of the streaming kernels (0 = auto, <0 keeps the current
- * value); variant: 1 = default, 2 = diagnostics (bitset assembled, never stored), <0 keeps.  */
-int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu, int variant);
+/* Tuning knob: workgroups per CU of the streaming kernels (0 = auto, <0 keeps the current value).  */
+int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu);
 /* Page-locked host memory owned by the library (hipHostMalloc): the one kind of host memory the
  * library may be handed repeatedly without staging.  A Go host builds its block vectors in it
  * (unsafe.Slice over the pointer; arena hook, SURVEY.md 8b "Ownership") and knox_col_upload /
@@ -151,6 +150,29 @@ int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, s
 /* Bytes column in StringPool layout (pkg/stringx/pool.go:45-58): ptr[i] = off<<32 | len.  */
 int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf,
                           size_t buf_len, size_t pack_rows, knox_col **out);
+/* Bytes column held the way the reference holds it: ONE StringPool per pack (block) -- block.Bytes() of pack p is
+ * its own pool, ptr[i] = off<<32 | len with off relative to THAT pool (pkg/stringx/pool.go:45-58; matchers run per
+ * pool, match.go:20-51).  The column keeps the row pointers of all packs in one array and the pools concatenated in
+ * one payload buffer with a 64-bit base per pack, so only a single pack's pool is limited to 4 GiB -- 2^30 rows of
+ * 32-byte values (BASELINE configs[3]) are one resident column.  Create reserves room for max_packs packs of
+ * pack_rows rows (a multiple of 64) and max_pool_bytes of payload in total; append_pack adds the next pack (host
+ * slices, never retained): every pack but the last holds exactly pack_rows rows, a short pack ends the column.     */
+int knox_col_bytes_create(knox_ctx *ctx, size_t pack_rows, size_t max_packs, size_t max_pool_bytes, knox_col **out);
+int knox_col_bytes_append_pack(knox_ctx *ctx, knox_col *col, const uint64_t *ptr, size_t n_rows, const uint8_t *buf,
+                               size_t buf_len);
+/* Pack `pack` back as the reference would hold it: row pointers (relative to the pack's pool) and the pool.  Either
+ * output may be NULL; *n_rows_out / *buf_len_out (nullable) report the sizes.  A single-pool column is pack 0.       */
+int knox_col_bytes_download_pack(knox_ctx *ctx, const knox_col *col, size_t pack, uint64_t *ptr_out, size_t ptr_cap,
+                                 size_t *n_rows_out, uint8_t *buf_out, size_t buf_cap, size_t *buf_len_out);
+size_t knox_col_pool_bytes(const knox_col *col); /* payload bytes resident in HBM (bytes columns) */
+/* Synthetic bytes column generated on the device (DESIGN.md "synthetic data", kind 5; SURVEY.md 8d cfg 4): every row
+ * holds one of 2^window_bits * ceil(n_packs / packs_per_window) distinct keys of key_len bytes, clustered so that a
+ * key only occurs inside its window of packs_per_window consecutive packs:
+ *   key index of row i (pack p) = (p / packs_per_window) << window_bits | (r(i) & (2^window_bits - 1)),
+ *   key k = the first key_len bytes of the little-endian words mix64(8k + j + mix64(seed ^ 0x6b657973)), j = 0, 1, ..
+ * One pool per pack, rows stored in row order (ptr[i] = (i % pack_rows) * key_len << 32 | key_len).                  */
+int knox_col_generate_bytes(knox_ctx *ctx, uint64_t seed, size_t n_rows, size_t pack_rows, uint32_t key_len,
+                            uint32_t window_bits, uint32_t packs_per_window, knox_col **out);
 /* Ingest the ON-DISK containers of consecutive packs without a host decode pass ("next" row
  * f2): bufs[i] is the container of pack i exactly as stored by the reference:
  *   raw ints    [7][uvarint n values][LE values]            internal/encode/int_raw.go:73-94
@@ -175,7 +197,9 @@ int knox_col_upload_raw_containers(knox_ctx *ctx, int dtype, const uint8_t *cons
  *   compact     [18][uint32 container ofs][uint32 container len][uvarint buflen][buf]   string_compact.go:64-97
  *   dictionary  [19][ofs][len][uint32 container code][uvarint dictlen][dict]            string_dict.go:70-108
  * A row that would leave its payload returns KNOX_E_RANGE (nothing on the device ever reads out of
- * bounds).  The pool of one column is limited to 4 GiB (32-bit StringPool offsets).            */
+ * bounds).  When every container but the last holds exactly pack_rows rows (a multiple of 64) each pack keeps
+ * its own pool (see knox_col_bytes_create: no 4 GiB limit on the column); ragged containers share one pool of at
+ * most 4 GiB (32-bit StringPool offsets).                                                       */
 int knox_col_upload_string_containers(knox_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
                                       size_t pack_rows, knox_col **out);
 /* Int128 / Int256 containers ([8][X0][X1], [9][X0][X1][X2][X3]: internal/encode/int128.go:115-137,
@@ -482,6 +506,11 @@ int knox_comm_unique_id(uint8_t id[KNOX_COMM_ID_BYTES]);
 int knox_comm_init(knox_ctx *ctx, int n_ranks, int rank, const uint8_t id[KNOX_COMM_ID_BYTES]);
 int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *mine, int n_states,
                                knox_agg_state *merged /* n_states */, int64_t *count_inout);
+/* The order-free integer aggregates in ONE ncclAllReduce(ncclInt64, ncclSum) over xGMI: the wrapping integer sum
+ * (SumReducer, reducer.go:168-178; state.isum) and the selected-row count.  The sum crosses as two 32-bit halves, so
+ * the result is exactly the sum mod 2^64 for any reduction order -- bit-identical to the all-gather + combine above.
+ * min / max / first / last and float sums need rank order and take knox_comm_allgather_states.                   */
+int knox_comm_allreduce_sum_count(knox_ctx *ctx, uint64_t *isum_inout, int64_t *count_inout);
 int knox_comm_destroy(knox_ctx *ctx);
 
 #ifdef __cplusplus

@@ -67,13 +67,18 @@ SIGNATURES = {
     "knox_ctx_stream": (_vp, [_vp]),
     "knox_timer_start": (_i, [_vp]),
     "knox_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
-    "knox_ctx_set_tuning": (_i, [_vp, _i, _i]),
+    "knox_ctx_set_tuning": (_i, [_vp, _i]),
     "knox_prof_enable": (_i, [_vp, _i]),
     "knox_prof_read": (_i, [_vp, C.POINTER(C.c_double), _pi]),
     "knox_prof_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
     "knox_cmp": (_i64, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "knox_col_upload": (_i, [_vp, _i, _vp, _sz, _sz, _pp]),
     "knox_col_upload_bytes": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _pp]),
+    "knox_col_bytes_create": (_i, [_vp, _sz, _sz, _sz, _pp]),
+    "knox_col_bytes_append_pack": (_i, [_vp, _vp, _vp, _sz, _vp, _sz]),
+    "knox_col_bytes_download_pack": (_i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _sz, C.POINTER(_sz)]),
+    "knox_col_pool_bytes": (_sz, [_vp]),
+    "knox_col_generate_bytes": (_i, [_vp, _u64, _sz, _sz, C.c_uint32, C.c_uint32, C.c_uint32, _pp]),
     "knox_packed_upload": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _pp]),
     "knox_packed_free": (_i, [_vp]),
     "knox_packed_rows": (_sz, [_vp]),
@@ -149,6 +154,7 @@ SIGNATURES = {
     "knox_comm_unique_id": (_i, [_vp]),
     "knox_comm_init": (_i, [_vp, _i, _i, _vp]),
     "knox_comm_allgather_states": (_i, [_vp, C.POINTER(AggState), _i, C.POINTER(AggState), C.POINTER(_i64)]),
+    "knox_comm_allreduce_sum_count": (_i, [_vp, C.POINTER(_u64), C.POINTER(_i64)]),
     "knox_comm_destroy": (_i, [_vp]),
 }
 

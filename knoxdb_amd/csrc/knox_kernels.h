@@ -54,7 +54,7 @@ struct ScanArgs {
     uint64_t row_base;      // global id of local row 0
     uint32_t *bits;         // output bitset (nullable)
     const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)
-    uint32_t debug;         // diagnostics: bit0 = compute the bitset words but skip the global store
+    uint32_t debug;         // read by -DKNOX_DIAG builds only (make diag); the product kernels ignore it and the ABI leaves it 0
     uint32_t iters;         // wave iterations per tile (1..kMaxIters): tile = iters * tile_rows(width)
     uint32_t *tile_counts;  // nullable: [(workgroup * kWavesPerBlock + wave) * tc_rounds + round] = popcount of that wave tile's burst
     uint32_t tc_rounds;     // rounds per workgroup, padded to a multiple of 32 (one 128-byte line of counts)
@@ -81,7 +81,7 @@ int tile_rows(int width);  // rows per workgroup tile of the streaming kernels
 // Streaming scan: evaluates the leaves' truth table for n_tiles full tiles, writes bitset
 // words, accumulates count + aggregates into partials[0..grid).  width = bytes per value.
 hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, bool agg_separate,
-                       int grid, int variant, const ScanArgs &a);
+                       int grid, const ScanArgs &a);
 // placement probe: scan_kernel<8,1,ISUM> under a separate symbol
 hipError_t launch_probe_scan(hipStream_t s, int grid, const ScanArgs &a);
 // Tail / small-n path: rows [n_tiles*tile_rows, n_rows), byte-granular stores, one workgroup,
@@ -157,10 +157,26 @@ hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_
 hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
                           uint32_t *rows_out, uint64_t capacity, unsigned long long *n_out);
 
+// A bytes column on the device.  The reference holds ONE StringPool per pack (block): ptr[i] = off << 32 | len
+// with `off` relative to that pack's own buffer (pkg/stringx/pool.go:45-58).  A resident column keeps the row
+// pointers of all packs in one array and the pools concatenated in one payload buffer; pool_base[p] is where
+// pack p's pool starts inside it (64 bit: the column as a whole is not limited to 4 GiB, only one pack's pool is).
+// pool_base == nullptr: the whole column is one pool (offsets relative to buf).  `live` (nullable) is the compact
+// list of packs a pruned scan evaluates; rows of other packs are neither read nor written.
+struct BytesView {
+    const uint64_t *ptr;
+    const uint8_t *buf;
+    const uint64_t *pool_base;  // [n_packs + 1] or nullptr
+    uint64_t n_rows;
+    uint64_t pack_rows;         // a multiple of 64 whenever pool_base or live is set
+    uint32_t pack_shift;        // log2(pack_rows), 255 = not a power of two (divide)
+    uint32_t n_live;
+    const uint32_t *live;
+};
+
 // bytes column matchers (StringPool layout): mode = FilterMode 1 eq 2 ne 3 gt 4 ge 5 lt 6 le 9 range [val, val2]
-hipError_t launch_bytes_match(hipStream_t s, int mode, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                              const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2, uint8_t *bits, const uint8_t *mask,
-                              unsigned long long *count_out /* pre-zeroed */);
+hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const uint8_t *val, uint32_t vlen, const uint8_t *val2,
+                              uint32_t vlen2, uint8_t *bits, const uint8_t *mask, unsigned long long *count_out /* pre-zeroed */);
 
 // IN / NOT IN: membership of the value's canonical order key in a sorted key set (binary search);
 // matching rows are OR-ed into bits (bits.Set), only mask-selected rows are tested when mask != null
@@ -168,14 +184,13 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
                         const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask);
 
 // bytes IN / NOT IN: the set sorted + unique in StringPool form (set_ptr[i] = off << 32 | len into set_buf)
-hipError_t launch_bytes_inset(hipStream_t s, bool negate, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf, const uint64_t *set_ptr,
-                              uint32_t n_set, const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask);
+hipError_t launch_bytes_inset(hipStream_t s, bool negate, const BytesView &v, const uint64_t *set_ptr, uint32_t n_set,
+                              const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask);
 
 // bloom probe / build
 hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,
                               uint64_t h, uint8_t *maybe_out);
-hipError_t launch_bloom_build_bytes(hipStream_t s, const uint64_t *ptr, const uint8_t *pool, uint64_t n_rows, uint64_t pack_rows,
-                                    uint8_t *filters, const uint64_t *offsets);
+hipError_t launch_bloom_build_bytes(hipStream_t s, const BytesView &v, uint8_t *filters, const uint64_t *offsets);
 hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows,
                               uint8_t *filters, const uint64_t *offsets);
 
@@ -223,6 +238,11 @@ hipError_t launch_alprd_merge(hipStream_t s, int width, const uint16_t *left, co
 hipError_t launch_str_ptr(hipStream_t s, const uint32_t *ofs, const uint32_t *len, uint64_t n_entries, const uint32_t *code, uint64_t n,
                           uint64_t base, uint64_t *dst);
 hipError_t launch_ptr_check(hipStream_t s, const uint64_t *ptr, uint64_t n, uint64_t pool_len, uint32_t *flag /* pre-zeroed */);
+// synthetic bytes column (DESIGN.md "synthetic data", kind 5): row i of pack p holds key k = (p / packs_per_window) <<
+// window_bits | (r(i) & (2^window_bits - 1)); key k's bytes are the little-endian words mix64(8k + j + keymix); the
+// row's payload sits at (i % pack_rows) * key_len inside its pack's pool
+hipError_t launch_generate_bytes(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t pack_rows, uint32_t key_len,
+                                 uint32_t window_bits, uint32_t packs_per_window, uint64_t pool_stride, uint64_t *ptr, uint8_t *buf);
 // dictionary / run-end containers over already decoded children
 hipError_t launch_dict_gather(hipStream_t s, int width, const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst);
 hipError_t launch_runend_expand(hipStream_t s, int width, const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst);
@@ -251,8 +271,7 @@ struct RegexProg {
     uint32_t n_bounds, n_classes, n_states;
     uint32_t lds_image_bytes;  // bytes of [direct] | table | flags | ascii the kernel stages
 };
-hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                               uint8_t *bits, const uint8_t *mask);
+hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const BytesView &v, uint8_t *bits, const uint8_t *mask);
 hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
                                     const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen);
 hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows,

@@ -646,10 +646,12 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     if constexpr (W <= 2 && NL == 1) sw.init((uint32_t)lo[0], (uint32_t)diff[0], (tt & 2u) != 0, (tt & 1u) != 0);
     const int qshift = K * (lane & (G - 1));
 
+    uint32_t lb = blockIdx.x;
+#ifdef KNOX_DIAG
     // diagnostics (debug bit3): XCD-contiguous mapping -- workgroups are dealt round-robin over the 8
     // XCDs, so logical block (b%8)*(G/8) + b/8 gives every XCD one contiguous run of tiles per round
-    uint32_t lb = blockIdx.x;
     if ((a.debug & 8u) && (gridDim.x & 7u) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
     // per-wave-tile popcounts, laid out [workgroup][wave][round] so that a wave's counts are contiguous
     uint32_t *tcbase = a.tile_counts ? a.tile_counts + ((uint64_t)lb * kWavesPerBlock + (uint64_t)wave) * a.tc_rounds : nullptr;
     uint32_t tcreg = 0, round = 0, cnt_prev = 0;
@@ -766,10 +768,14 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             cnt_prev = cnt32;
             for (uint32_t v = lane; v < nv; v += 64) {
                 const u32x4 x = ((const u32x4 *)stage[wave])[v];
-                // debug bit0 = diagnostics: words are assembled but never leave the CU
-                if (a.debug & 2u) dst[v] = x;  // diagnostics: plain (L2 write-back) store
+#ifdef KNOX_DIAG
+                // diagnostics build only (make diag): debug bit0 = words are assembled but never leave the CU
+                if (a.debug & 2u) dst[v] = x;  // plain (L2 write-back) store
                 else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
                 else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
+#else
+                __builtin_nontemporal_store(x, dst + v);
+#endif
             }
             if (tcbase != nullptr) {
                 // popcount of this wave tile's burst, once per tile.  The counts of 32 consecutive
@@ -969,8 +975,7 @@ static hipError_t scan_sep(hipStream_t s, bool sep, int grid, const ScanArgs &a)
 }
 
 template <int W, int NL>
-static hipError_t scan_agg(hipStream_t s, unsigned agg, bool sep, int grid, int variant, const ScanArgs &a) {
-    (void)variant;
+static hipError_t scan_agg(hipStream_t s, unsigned agg, bool sep, int grid, const ScanArgs &a) {
     // aggregate classes instantiated: none | isum | full-without-isum (per flavour) | all (ints)
     constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
     if (agg == 0) return scan_anyf<W, NL, 0, false, FL_SIGNED>(s, grid, a);
@@ -985,24 +990,24 @@ static hipError_t scan_agg(hipStream_t s, unsigned agg, bool sep, int grid, int 
 }
 
 template <int W>
-static hipError_t scan_nl(hipStream_t s, int nl, unsigned agg, bool sep, int grid, int variant, const ScanArgs &a) {
+static hipError_t scan_nl(hipStream_t s, int nl, unsigned agg, bool sep, int grid, const ScanArgs &a) {
     switch (nl) {
-    case 1: return scan_agg<W, 1>(s, agg, sep, grid, variant, a);
-    case 2: return scan_agg<W, 2>(s, agg, sep, grid, variant, a);
-    case 3: return scan_agg<W, 3>(s, agg, sep, grid, variant, a);
-    case 4: return scan_agg<W, 4>(s, agg, sep, grid, variant, a);
+    case 1: return scan_agg<W, 1>(s, agg, sep, grid, a);
+    case 2: return scan_agg<W, 2>(s, agg, sep, grid, a);
+    case 3: return scan_agg<W, 3>(s, agg, sep, grid, a);
+    case 4: return scan_agg<W, 4>(s, agg, sep, grid, a);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, bool agg_separate, int grid, int variant,
+hipError_t launch_scan(hipStream_t s, int width, int n_leaves, unsigned agg, bool agg_separate, int grid,
                        const ScanArgs &a) {
     if (grid <= 0) return hipSuccess;
     switch (width) {
-    case 8: return scan_nl<8>(s, n_leaves, agg, agg_separate, grid, variant, a);
-    case 4: return scan_nl<4>(s, n_leaves, agg, agg_separate, grid, variant, a);
-    case 2: return scan_nl<2>(s, n_leaves, agg, agg_separate, grid, variant, a);
-    case 1: return scan_nl<1>(s, n_leaves, agg, agg_separate, grid, variant, a);
+    case 8: return scan_nl<8>(s, n_leaves, agg, agg_separate, grid, a);
+    case 4: return scan_nl<4>(s, n_leaves, agg, agg_separate, grid, a);
+    case 2: return scan_nl<2>(s, n_leaves, agg, agg_separate, grid, a);
+    case 1: return scan_nl<1>(s, n_leaves, agg, agg_separate, grid, a);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1949,57 +1954,155 @@ __device__ __forceinline__ int bytes_cmp3(const uint8_t *p, uint32_t n, const ui
     return n == m ? 0 : (n < m ? -1 : 1);
 }
 
+// ---- walking a bytes column (BytesView) in groups of 64 rows = one wave ------------------------------------
+// Without a live list group g covers rows [64g, 64g + 64).  With one, only the groups of the listed packs exist:
+// group g = group (g % gpp) of pack live[g / gpp], gpp = pack_rows / 64.  A group never straddles two packs
+// (pack_rows is a multiple of 64), so the pool base is wave-uniform.
+__device__ __forceinline__ uint64_t bv_ngroups(const BytesView &v) {
+    if (v.live != nullptr) return (uint64_t)v.n_live * (v.pack_rows >> 6);
+    return (v.n_rows + 63) >> 6;
+}
+__device__ __forceinline__ uint64_t bv_group_row0(const BytesView &v, uint64_t g) {
+    if (v.live == nullptr) return g << 6;
+    uint64_t li, in;
+    if (v.pack_shift != 255u) {
+        li = g >> (v.pack_shift - 6u);
+        in = g & ((1ull << (v.pack_shift - 6u)) - 1ull);
+    } else {
+        const uint64_t gpp = v.pack_rows >> 6;
+        li = g / gpp;
+        in = g - li * gpp;
+    }
+    return (uint64_t)v.live[li] * v.pack_rows + (in << 6);
+}
+__device__ __forceinline__ const uint8_t *bv_pool(const BytesView &v, uint64_t row0) {
+    if (v.pool_base == nullptr) return v.buf;
+    const uint64_t pack = v.pack_shift != 255u ? row0 >> v.pack_shift : row0 / v.pack_rows;
+    return v.buf + v.pool_base[pack];
+}
+// the wave's 64 result bits of the group starting at row0 -> bitset bytes: overwrite (mask == null; MatchEqual's
+// unmasked form overwrites every byte incl. a partial last one) or bits.Set for mask-selected rows only
+__device__ __forceinline__ void bv_store_group(uint64_t ballot, uint64_t row0, uint64_t n_rows, int lane, uint8_t *bits, const uint8_t *mask,
+                                               bool or_only) {
+    if (mask == nullptr && !or_only && row0 + 64 <= n_rows) {
+        if (lane == 0) *(uint64_t *)(bits + (row0 >> 3)) = ballot;  // row0 is a multiple of 64: one aligned 8-byte store
+        return;
+    }
+    if (lane < 8) {
+        const uint64_t r0 = row0 + 8 * (uint64_t)lane;
+        if (r0 < n_rows) {
+            uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+            const uint64_t bi = r0 >> 3;
+            if (mask != nullptr) byte &= mask[bi];
+            if (mask != nullptr || or_only) { if (byte) bits[bi] |= byte; }
+            else bits[bi] = byte;
+        }
+    }
+}
+
 // mode = FilterMode: 1 eq, 2 ne (MatchEqual / MatchNotEqual stringx/match.go:20-84), 3 gt, 4 ge, 5 lt,
 // 6 le, 9 range [val, val2] (MatchGreater.. / MatchBetween :86-251)
-__global__ void __launch_bounds__(kBlock) bytes_match_kernel(int mode, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                                                             const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2,
-                                                             uint8_t *bits, const uint8_t *mask, unsigned long long *count_out) {
+__global__ void __launch_bounds__(kBlock) bytes_match_kernel(int mode, BytesView v, const uint8_t *val, uint32_t vlen, const uint8_t *val2,
+                                                             uint32_t vlen2, uint8_t *bits, const uint8_t *mask,
+                                                             unsigned long long *count_out) {
     const int lane = threadIdx.x & 63;
     const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t ngroups = (n_rows + 63) >> 6;
+    const uint64_t ngroups = bv_ngroups(v);
     uint64_t cnt = 0;
     for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
-        const uint64_t row = (g << 6) + lane;
+        const uint64_t row0 = bv_group_row0(v, g);
+        const uint8_t *pool = bv_pool(v, row0);
+        const uint64_t row = row0 + lane;
         bool m = false;
-        if (row < n_rows) {
-            const uint64_t p = ptr[row];
+        if (row < v.n_rows) {
+            const uint64_t p = v.ptr[row];
             const uint32_t ofs = (uint32_t)(p >> 32), len = (uint32_t)p;
             if (mode <= 2) {
-                const bool eq = (len == vlen) && bytes_equal(buf + ofs, val, len);
+                const bool eq = (len == vlen) && bytes_equal(pool + ofs, val, len);
                 m = mode == 1 ? eq : !eq;
             } else {
-                const int c = bytes_cmp3(buf + ofs, len, val, vlen);
+                const int c = bytes_cmp3(pool + ofs, len, val, vlen);
                 switch (mode) {
                 case 3: m = c > 0; break;
                 case 4: m = c >= 0; break;
                 case 5: m = c < 0; break;
                 case 6: m = c <= 0; break;
-                default: m = c >= 0 && bytes_cmp3(buf + ofs, len, val2, vlen2) <= 0; break;
+                default: m = c >= 0 && bytes_cmp3(pool + ofs, len, val2, vlen2) <= 0; break;
                 }
             }
         }
         const uint64_t ballot = __ballot(m);
-        if (lane < 8) {
-            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
-            if (r0 < n_rows) {
-                const uint8_t byte = (uint8_t)(ballot >> (8 * lane));
-                const uint64_t bi = r0 >> 3;
-                if (mask != nullptr) bits[bi] |= (uint8_t)(byte & mask[bi]);  // only bits.Set(i) for masked rows
-                else bits[bi] = byte;                                         // overwrite incl. partial last byte
-            }
-        }
+        bv_store_group(ballot, row0, v.n_rows, lane, bits, mask, false);
         if (lane == 0) cnt += __builtin_popcountll(ballot);
     }
     if (lane == 0 && cnt && count_out) atomicAdd(count_out, (unsigned long long)cnt);
 }
 
-hipError_t launch_bytes_match(hipStream_t s, int mode, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                              const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2, uint8_t *bits, const uint8_t *mask,
-                              unsigned long long *count_out) {
-    if (n_rows == 0) return hipSuccess;
-    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+// EQ / NE against a value of >= 16 bytes: the streaming form.  A wave takes kEqGroups groups of 64 rows per
+// iteration: all row pointers first, then for every row whose length matches TWO independent 16-byte loads -- bytes
+// [0, 16) and [min(16, vlen - 16), +16), which cover the whole value up to 32 bytes -- so 12 loads per lane are in
+// flight instead of a pointer -> first piece -> second piece chain.  Values above 32 bytes finish in bytes_equal for
+// the rows that still match (rare).  Per row: 8 B pointer + len B payload read, 1/8 B written.
+constexpr int kEqGroups = 4;
+__global__ void __launch_bounds__(kBlock) bytes_eq_kernel(int negate, BytesView v, const uint8_t *val, uint32_t vlen, uint8_t *bits,
+                                                          const uint8_t *mask, unsigned long long *count_out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = bv_ngroups(v);
+    const uint32_t off_b = vlen >= 32u ? 16u : vlen - 16u;
+    u32x4 va, vb;
+    __builtin_memcpy(&va, val, 16);
+    __builtin_memcpy(&vb, val + off_b, 16);
+    uint64_t cnt = 0;
+    for (uint64_t g0 = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kEqGroups; g0 < ngroups; g0 += nwaves_total * kEqGroups) {
+        uint64_t row0[kEqGroups], p[kEqGroups];
+        const uint8_t *src[kEqGroups];
+#pragma unroll
+        for (int k = 0; k < kEqGroups; k++) {
+            const uint64_t g = g0 + k;
+            row0[k] = g < ngroups ? bv_group_row0(v, g) : v.n_rows;
+            const uint64_t row = row0[k] + lane;
+            p[k] = row < v.n_rows ? __builtin_nontemporal_load(v.ptr + row) : ~0ull;  // len 2^32-1 != vlen: never loads
+        }
+        u32x4 xa[kEqGroups], xb[kEqGroups];
+#pragma unroll
+        for (int k = 0; k < kEqGroups; k++) {
+            src[k] = (row0[k] < v.n_rows ? bv_pool(v, row0[k]) : v.buf) + (uint32_t)(p[k] >> 32);
+            xa[k] = va;
+            xb[k] = vb;
+            if ((uint32_t)p[k] == vlen) {
+                __builtin_memcpy(&xa[k], src[k], 16);
+                __builtin_memcpy(&xb[k], src[k] + off_b, 16);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kEqGroups; k++) {
+            if (g0 + k >= ngroups) break;
+            bool eq = (uint32_t)p[k] == vlen &&
+                      (((xa[k].x ^ va.x) | (xa[k].y ^ va.y) | (xa[k].z ^ va.z) | (xa[k].w ^ va.w) | (xb[k].x ^ vb.x) | (xb[k].y ^ vb.y) |
+                        (xb[k].z ^ vb.z) | (xb[k].w ^ vb.w)) == 0);
+            if (eq && vlen > 32u) eq = bytes_equal(src[k] + 32, val + 32, vlen - 32u);
+            const bool m = (row0[k] + lane < v.n_rows) && (negate ? !eq : eq);
+            const uint64_t ballot = __ballot(m);
+            bv_store_group(ballot, row0[k], v.n_rows, lane, bits, mask, false);
+            if (lane == 0) cnt += __builtin_popcountll(ballot);
+        }
+    }
+    if (lane == 0 && cnt && count_out) atomicAdd(count_out, (unsigned long long)cnt);
+}
+
+hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2,
+                              uint8_t *bits, const uint8_t *mask, unsigned long long *count_out) {
+    const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
+    if (ngroups == 0) return hipSuccess;
+    if (mode <= 2 && vlen >= 16u) {
+        uint64_t g = (ngroups + (uint64_t)kWavesPerBlock * kEqGroups - 1) / ((uint64_t)kWavesPerBlock * kEqGroups);
+        if (g > 256 * 8) g = 256 * 8;
+        KNOX_LAUNCH(bytes_eq_kernel, (int)g, mode == 2 ? 1 : 0, v, val, vlen, bits, mask, count_out);
+    }
+    uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
     if (g > 2048 * 4) g = 2048 * 4;
-    KNOX_LAUNCH(bytes_match_kernel, (int)g, mode, ptr, n_rows, buf, val, vlen, val2, vlen2, bits, mask, count_out);
+    KNOX_LAUNCH(bytes_match_kernel, (int)g, mode, v, val, vlen, val2, vlen2, bits, mask, count_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2073,49 +2176,43 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
 // membership of the row's bytes in the set.  The reference consults a hash map and confirms with
 // bytes.Equal, i.e. plain equality; here the set arrives sorted (bytes.Compare order) and unique in
 // StringPool form and every lane binary-searches it.  Matching rows are OR-ed into bits (bits.Set).
-__global__ void __launch_bounds__(kBlock) bytes_inset_kernel(int negate, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                                                             const uint64_t *set_ptr, uint32_t n_set, const uint8_t *set_buf, uint8_t *bits,
-                                                             const uint8_t *mask) {
+__global__ void __launch_bounds__(kBlock) bytes_inset_kernel(int negate, BytesView v, const uint64_t *set_ptr, uint32_t n_set,
+                                                             const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask) {
     const int lane = threadIdx.x & 63;
     const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t ngroups = (n_rows + 63) >> 6;
+    const uint64_t ngroups = bv_ngroups(v);
     for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
-        const uint64_t row = (g << 6) + lane;
+        const uint64_t row0 = bv_group_row0(v, g);
+        const uint8_t *pool = bv_pool(v, row0);
+        const uint64_t row = row0 + lane;
         bool m = false;
-        if (row < n_rows) {
-            const uint64_t p = ptr[row];
-            const uint8_t *v = buf + (uint32_t)(p >> 32);
+        if (row < v.n_rows) {
+            const uint64_t p = v.ptr[row];
+            const uint8_t *x = pool + (uint32_t)(p >> 32);
             const uint32_t len = (uint32_t)p;
             uint32_t lo = 0, hi = n_set;
             bool found = false;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 const uint64_t sp = set_ptr[mid];
-                const int c = bytes_cmp3(set_buf + (uint32_t)(sp >> 32), (uint32_t)sp, v, len);
+                const int c = bytes_cmp3(set_buf + (uint32_t)(sp >> 32), (uint32_t)sp, x, len);
                 if (c == 0) { found = true; break; }
                 if (c < 0) lo = mid + 1; else hi = mid;
             }
             m = negate ? !found : found;
         }
         const uint64_t ballot = __ballot(m);
-        if (lane < 8) {
-            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
-            if (r0 < n_rows) {
-                uint8_t byte = (uint8_t)(ballot >> (8 * lane));
-                const uint64_t bi = r0 >> 3;
-                if (mask != nullptr) byte &= mask[bi];
-                if (byte) bits[bi] |= byte;
-            }
-        }
+        bv_store_group(ballot, row0, v.n_rows, lane, bits, mask, true);
     }
 }
 
-hipError_t launch_bytes_inset(hipStream_t s, bool negate, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf, const uint64_t *set_ptr,
-                              uint32_t n_set, const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask) {
-    if (n_rows == 0) return hipSuccess;
-    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+hipError_t launch_bytes_inset(hipStream_t s, bool negate, const BytesView &v, const uint64_t *set_ptr, uint32_t n_set, const uint8_t *set_buf,
+                              uint8_t *bits, const uint8_t *mask) {
+    const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
+    if (ngroups == 0) return hipSuccess;
+    uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
     if (g > 2048 * 4) g = 2048 * 4;
-    KNOX_LAUNCH(bytes_inset_kernel, (int)g, negate ? 1 : 0, ptr, n_rows, buf, set_ptr, n_set, set_buf, bits, mask);
+    KNOX_LAUNCH(bytes_inset_kernel, (int)g, negate ? 1 : 0, v, set_ptr, n_set, set_buf, bits, mask);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2215,18 +2312,18 @@ __global__ void __launch_bounds__(kBlock) bloom_build_kernel(const void *col, ui
 }
 
 // bytes column (StringPool): hash.Hash = XXH3-64 of every row's bytes (pack/stats/filter.go:352-354), one lane per row
-__global__ void __launch_bounds__(kBlock) bloom_build_bytes_kernel(const uint64_t *ptr, const uint8_t *pool, uint64_t n_rows, uint64_t pack_rows,
-                                                                   uint8_t *filters, const uint64_t *offsets) {
+__global__ void __launch_bounds__(kBlock) bloom_build_bytes_kernel(BytesView v, uint8_t *filters, const uint64_t *offsets) {
     const uint64_t p = blockIdx.x;
     const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
     if (o1 <= o0 + 1) return;
     if (threadIdx.x == 0) filters[o0] = 4;
     const uint64_t bits_off = o0 + 1;
     const uint32_t mask = (uint32_t)((o1 - o0 - 1) * 8 - 1);
-    uint64_t r0 = p * pack_rows, r1 = r0 + pack_rows;
-    if (r1 > n_rows) r1 = n_rows;
+    uint64_t r0 = p * v.pack_rows, r1 = r0 + v.pack_rows;
+    if (r1 > v.n_rows) r1 = v.n_rows;
+    const uint8_t *pool = v.pool_base ? v.buf + v.pool_base[p] : v.buf;
     for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const uint64_t pr = ptr[r];
+        const uint64_t pr = v.ptr[r];
         const uint64_t h = knox_xxh3::hash(pool + (uint32_t)(pr >> 32), (uint64_t)(uint32_t)pr);
         uint32_t h0 = (uint32_t)h;
         const uint32_t h1 = (uint32_t)(h >> 32);
@@ -2240,11 +2337,10 @@ __global__ void __launch_bounds__(kBlock) bloom_build_bytes_kernel(const uint64_
     }
 }
 
-hipError_t launch_bloom_build_bytes(hipStream_t s, const uint64_t *ptr, const uint8_t *pool, uint64_t n_rows, uint64_t pack_rows,
-                                    uint8_t *filters, const uint64_t *offsets) {
-    const uint64_t n_packs = (n_rows + pack_rows - 1) / pack_rows;
+hipError_t launch_bloom_build_bytes(hipStream_t s, const BytesView &v, uint8_t *filters, const uint64_t *offsets) {
+    const uint64_t n_packs = (v.n_rows + v.pack_rows - 1) / v.pack_rows;
     if (n_packs == 0) return hipSuccess;
-    KNOX_LAUNCH(bloom_build_bytes_kernel, (int)n_packs, ptr, pool, n_rows, pack_rows, filters, offsets);
+    KNOX_LAUNCH(bloom_build_bytes_kernel, (int)n_packs, v, filters, offsets);
 }
 
 hipError_t launch_bloom_build(hipStream_t s, int width, const void *col, uint64_t n_rows, uint64_t pack_rows, uint8_t *filters,
@@ -2509,7 +2605,9 @@ __global__ void __launch_bounds__(kBlock) str_ptr_kernel(const uint32_t *ofs, co
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t k = code ? (uint64_t)code[i] : i;
         if (k >= n_entries) k = n_entries - 1;  // corrupt code: stay inside the entry table (ptr_check sees the rest)
-        dst[i] = ((base + ofs[k]) << 32) | (uint64_t)len[k];
+        uint64_t o = base + ofs[k];
+        if (o > 0xffffffffull) o = 0xffffffffull;  // corrupt offset: keep it out of range instead of wrapping (ptr_check flags it)
+        dst[i] = (o << 32) | (uint64_t)len[k];
     }
 }
 
@@ -2690,6 +2788,35 @@ hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint
     }
 }
 
+// synthetic bytes column (knox_kernels.h launch_generate_bytes; DESIGN.md "synthetic data" kind 5): one lane per row
+__global__ void __launch_bounds__(kBlock) generate_bytes_kernel(uint64_t seedmix, uint64_t keymix, uint64_t first_row, uint64_t n_rows,
+                                                                uint64_t pack_rows, uint32_t key_len, uint32_t window_bits,
+                                                                uint32_t packs_per_window, uint64_t pool_stride, uint64_t *ptr, uint8_t *buf) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = first_row + i;
+        const uint64_t pack = row / pack_rows, in = row - pack * pack_rows;
+        const uint64_t k = ((pack / packs_per_window) << window_bits) | (mix64(row + seedmix) & ((1ull << window_bits) - 1ull));
+        uint8_t *dst = buf + (i / pack_rows) * pool_stride + in * key_len;
+        for (uint32_t j = 0; j * 8u < key_len; j++) {
+            const uint64_t w = mix64(8ull * k + j + keymix);
+            const uint32_t nb = key_len - j * 8u < 8u ? key_len - j * 8u : 8u;
+            if ((key_len & 7u) == 0u) { ((uint64_t *)dst)[j] = w; continue; }  // pools are 64-byte aligned: whole words
+            for (uint32_t b = 0; b < nb; b++) dst[j * 8u + b] = (uint8_t)(w >> (8u * b));
+        }
+        ptr[i] = ((in * key_len) << 32) | key_len;
+    }
+}
+
+hipError_t launch_generate_bytes(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t pack_rows, uint32_t key_len,
+                                 uint32_t window_bits, uint32_t packs_per_window, uint64_t pool_stride, uint64_t *ptr, uint8_t *buf) {
+    if (n_rows == 0) return hipSuccess;
+    if (pack_rows == 0 || first_row % pack_rows || packs_per_window == 0 || window_bits > 40) return hipErrorInvalidValue;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    KNOX_LAUNCH(generate_bytes_kernel, (int)g, mix64(seed), mix64(seed ^ 0x6b657973ull), first_row, n_rows, pack_rows, key_len, window_bits,
+                packs_per_window, pool_stride, ptr, buf);
+}
+
 // ---------------------------------------------------------------------------------------------
 // literal sequential reducers (one lane, row order): internal/reducer/reducer.go:138-429
 // bit-for-bit the Go fold incl. Welford mean/var -- parity-test mode only, O(n) latency bound.
@@ -2745,8 +2872,7 @@ __global__ void reduce_seq_kernel(int func, const T *src, uint64_t n, const uint
 // up to 48 KiB are staged in LDS, larger ones are read through L2.
 // ---------------------------------------------------------------------------------------------
 template <bool LDS, bool DIRECT>
-__global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf, uint8_t *bits,
-                                                              const uint8_t *mask) {
+__global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, BytesView v, uint8_t *bits, const uint8_t *mask) {
     extern __shared__ __align__(16) uint8_t rx_lds[];
     const uint16_t *table = pg.table, *direct = pg.direct;
     const uint8_t *flags = pg.flags, *ascii = pg.ascii_class;
@@ -2778,13 +2904,16 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
     }
     const int lane = threadIdx.x & 63;
     const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t ngroups = (n_rows + 63) >> 6;
+    const uint64_t ngroups = bv_ngroups(v);
+    const uint64_t n_rows = v.n_rows;
     for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
-        const uint64_t row = (g << 6) + lane;
+        const uint64_t row0 = bv_group_row0(v, g);
+        const uint8_t *pool = bv_pool(v, row0);
+        const uint64_t row = row0 + lane;
         bool m = false;
         if (row < n_rows && (mask == nullptr || ((mask[row >> 3] >> (row & 7)) & 1))) {
-            const uint64_t p = ptr[row];
-            const uint8_t *s = buf + (uint32_t)(p >> 32);
+            const uint64_t p = v.ptr[row];
+            const uint8_t *s = pool + (uint32_t)(p >> 32);
             const uint32_t len = (uint32_t)p;
             uint32_t state = 1, pos = 0;
             bool decided = false;
@@ -2881,31 +3010,23 @@ __global__ void __launch_bounds__(kBlock) regexp_match_kernel(RegexProg pg, cons
             }
             if (!decided) m = flags[state] & 1;
         }
-        const uint64_t ballot = __ballot(m);
-        if (lane < 8) {
-            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
-            if (r0 < n_rows) {
-                const uint8_t byte = (uint8_t)(ballot >> (8 * lane));
-                const uint64_t bi = r0 >> 3;
-                if (mask != nullptr) { if (byte) bits[bi] |= byte; }  // bits.Set(i) for the masked rows that match
-                else bits[bi] = byte;
-            }
-        }
+        const uint64_t ballot = __ballot(m);  // unmasked rows never match: with a mask this is bits.Set(i) for the masked rows that do
+        bv_store_group(ballot, row0, n_rows, lane, bits, nullptr, mask != nullptr);
     }
 }
 
-hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const uint64_t *ptr, uint64_t n_rows, const uint8_t *buf,
-                               uint8_t *bits, const uint8_t *mask) {
-    if (n_rows == 0) return hipSuccess;
-    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const BytesView &v, uint8_t *bits, const uint8_t *mask) {
+    const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
+    if (ngroups == 0) return hipSuccess;
+    uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
     if (g > 2048 * 4) g = 2048 * 4;
     const uint32_t lds_bytes = ((image_bytes + 3u) & ~3u) + 96u * 5u + 16u;  // image + (<= 96) staged class intervals
     if (pg.direct != nullptr)  // host guarantees: the image with the direct table fits the LDS budget
-        hipLaunchKernelGGL((regexp_match_kernel<true, true>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+        hipLaunchKernelGGL((regexp_match_kernel<true, true>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, v, bits, mask);
     else if (image_bytes <= 48 * 1024)
-        hipLaunchKernelGGL((regexp_match_kernel<true, false>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, ptr, n_rows, buf, bits, mask);
+        hipLaunchKernelGGL((regexp_match_kernel<true, false>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, v, bits, mask);
     else
-        hipLaunchKernelGGL((regexp_match_kernel<false, false>), dim3((unsigned)g), dim3(kBlock), 0, s, pg, ptr, n_rows, buf, bits, mask);
+        hipLaunchKernelGGL((regexp_match_kernel<false, false>), dim3((unsigned)g), dim3(kBlock), 0, s, pg, v, bits, mask);
     return hipGetLastError();
 }
 

@@ -759,7 +759,7 @@ inline int compile(const uint8_t *pat, size_t len, Program &out) {
 }
 
 // ---- utf8.DecodeRune (unicode/utf8): invalid or short encodings are one rune U+FFFD of width 1 -------
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define KNOX_RX_HD __host__ __device__
 #else
 #define KNOX_RX_HD

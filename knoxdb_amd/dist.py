@@ -93,3 +93,34 @@ class StateGather:
         per_rank = [bytes_to_states(raw[r * self.nbytes:(r + 1) * self.nbytes], self.n_states) for r in range(self.world)]
         merged = [agg_combine([per_rank[r][0][i] for r in range(self.world)]) for i in range(self.n_states)]
         return merged, sum(c for _, c in per_rank)
+
+
+class SumCountReduce:
+    """The literal collective of the north star for the order-free integer aggregates: ONE all_reduce(int64, SUM) of
+    {low half of the wrapping sum, high half, count} (backend "nccl" = ncclAllReduce over xGMI).  The 64-bit sum
+    travels as two 32-bit halves so that no lane overflows and the result is exactly the sum mod 2^64 in any reduction
+    order -- bit-identical to StateGather + knox_agg_combine.  Everything is allocated once."""
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.device = torch, dist, group, device
+        self.h = torch.empty(3, dtype=torch.int64)
+        if device is not None:
+            self.h = self.h.pin_memory()
+            self.d = torch.empty(3, dtype=torch.int64, device=device)
+
+    def __call__(self, isum, count):
+        """isum: the state's wrapping sum (any Python int, taken mod 2^64); -> (sum mod 2^64, total count)"""
+        isum &= (1 << 64) - 1
+        hv = self.h.numpy()
+        hv[0], hv[1], hv[2] = isum & 0xFFFFFFFF, isum >> 32, count
+        if self.device is not None:
+            self.d.copy_(self.h, non_blocking=True)
+            self.dist.all_reduce(self.d, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.h.copy_(self.d, non_blocking=True)
+            self.torch.cuda.current_stream(self.device).synchronize()
+        else:
+            self.dist.all_reduce(self.h, op=self.dist.ReduceOp.SUM, group=self.group)
+        hv = self.h.numpy()
+        return (int(hv[0]) + (int(hv[1]) << 32)) & ((1 << 64) - 1), int(hv[2])

@@ -275,8 +275,16 @@ class Context:
     def sync(self):
         check(self.L.knox_ctx_sync(self.h))
 
-    def set_tuning(self, blocks_per_cu=0, variant=-1):
-        check(self.L.knox_ctx_set_tuning(self.h, blocks_per_cu, variant))
+    def set_tuning(self, blocks_per_cu=0):
+        check(self.L.knox_ctx_set_tuning(self.h, blocks_per_cu))
+
+    def diag_set_variant(self, variant):
+        """diagnostics libraries only (`make diag`, loaded through KNOXGPU_SO): the product exports no such switch"""
+        fn = getattr(self.L, "knox_diag_set_variant", None)
+        if fn is None:
+            raise RuntimeError("knox_diag_set_variant: not a diagnostics build (make -C knoxdb_amd/csrc diag; KNOXGPU_SO=knoxdb_amd/diag/libknoxgpu_p7.so)")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
+        check(fn(self.h, variant))
 
     def host_array(self, n, dtype):
         """numpy array over page-locked memory from knox_host_alloc (freed with .base_free())"""
@@ -341,6 +349,35 @@ class Context:
         check(self.L.knox_col_upload_bytes(self.h, _ptr(ptr) if ptr.size else None, ptr.size,
                                            _ptr(buf) if buf.size else None, buf.size, pack_rows, C.byref(h)))
         return Column(self, h, BlockType.Bytes, pack_rows=pack_rows)
+
+    def upload_bytes_packs(self, packs, pack_rows):
+        """One StringPool (ptr, buf) per pack, as the reference holds bytes blocks -> one resident bytes column."""
+        packs = [(np.ascontiguousarray(p, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint8)) for p, b in packs]
+        h = C.c_void_p()
+        check(self.L.knox_col_bytes_create(self.h, pack_rows, max(1, len(packs)), sum(b.size for _, b in packs), C.byref(h)),
+              "knox_col_bytes_create")
+        col = Column(self, h, BlockType.Bytes, pack_rows=pack_rows)
+        for p, b in packs:
+            check(self.L.knox_col_bytes_append_pack(self.h, h, _ptr(p), p.size, _ptr(b) if b.size else None, b.size),
+                  "knox_col_bytes_append_pack")
+        return col
+
+    def generate_bytes(self, seed, n_rows, pack_rows, key_len=32, window_bits=16, packs_per_window=4):
+        """synthetic bytes column, one pool per pack (knox_col_generate_bytes; SURVEY.md 8d cfg 4)"""
+        h = C.c_void_p()
+        check(self.L.knox_col_generate_bytes(self.h, seed, n_rows, pack_rows, key_len, window_bits, packs_per_window, C.byref(h)),
+              "knox_col_generate_bytes")
+        return Column(self, h, BlockType.Bytes, pack_rows=pack_rows)
+
+    def download_bytes_pack(self, col, pack):
+        """(ptr, buf) of one pack of a bytes column as the reference would hold it"""
+        n, bl = C.c_size_t(), C.c_size_t()
+        check(self.L.knox_col_bytes_download_pack(self.h, col.h, pack, None, 0, C.byref(n), None, 0, C.byref(bl)))
+        ptr = np.zeros(n.value, dtype=np.uint64)
+        buf = np.zeros(bl.value, dtype=np.uint8)
+        check(self.L.knox_col_bytes_download_pack(self.h, col.h, pack, _ptr(ptr) if n.value else None, n.value, None,
+                                                  _ptr(buf) if bl.value else None, bl.value, None), "knox_col_bytes_download_pack")
+        return ptr, buf
 
     def upload_raw_containers(self, dtype, containers, pack_rows=0):
         """One on-disk raw container (bytes) per pack -> one contiguous HBM column, no host decode."""

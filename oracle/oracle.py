@@ -405,3 +405,41 @@ def emit_fill(dtype, mode, reducers, t_from, t_to, step, units_per_second=1, lim
         last = nxt
         step_t += step
     return out
+
+
+# ---- synthetic bytes column (DESIGN.md "synthetic data", kind 5; SURVEY.md 8d cfg 4) -- numpy restatement of the
+# spec text in include/knoxgpu.h (knox_col_generate_bytes), independent of the device kernel
+def mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def bytes_key_index(seed, first_row, n, pack_rows, window_bits=16, packs_per_window=4):
+    """key index of rows [first_row, first_row + n)"""
+    rows = np.arange(first_row, first_row + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        r = mix64(rows + mix64(np.uint64(seed)))
+    pack = rows // np.uint64(pack_rows)
+    return ((pack // np.uint64(packs_per_window)) << np.uint64(window_bits)) | (r & np.uint64((1 << window_bits) - 1))
+
+
+def bytes_key(seed, k, key_len=32):
+    """the key_len bytes of key k"""
+    nw = (key_len + 7) // 8
+    with np.errstate(over="ignore"):
+        km = mix64(np.uint64(seed ^ 0x6B657973))
+        w = mix64(np.uint64(8) * np.asarray(k, dtype=np.uint64)[..., None] + np.arange(nw, dtype=np.uint64) + km)
+    b = np.ascontiguousarray(w.astype("<u8")).view(np.uint8).reshape(w.shape[:-1] + (nw * 8,))
+    return b[..., :key_len]
+
+
+def generate_bytes_pack(seed, pack, n, pack_rows, key_len=32, window_bits=16, packs_per_window=4):
+    """pack `pack` (n rows) of the synthetic bytes column as one StringPool: (ptr, buf, key indices)"""
+    k = bytes_key_index(seed, pack * pack_rows, n, pack_rows, window_bits, packs_per_window)
+    buf = np.ascontiguousarray(bytes_key(seed, k, key_len)).reshape(-1)
+    ptr = ((np.arange(n, dtype=np.uint64) * np.uint64(key_len)) << np.uint64(32)) | np.uint64(key_len)
+    return ptr, buf, k

@@ -35,6 +35,16 @@ def _worker(rank, world, port, q):
     for _ in range(2):
         m2, t2 = g([st], cnt)
         assert t2 == total and bytes(m2[0]) == bytes(merged[0])
+    # the north star's literal collective for the order-free integer aggregates: ONE all-reduce of {sum, count}
+    # (two 32-bit halves of the wrapping sum + the count) -- must equal the all-gather + combine bit for bit
+    red = kdist.SumCountReduce()
+    for _ in range(2):
+        gsum, gcnt = red(int(st.isum), cnt)
+        assert gcnt == total and gsum == int(merged[0].isum), (gsum, int(merged[0].isum))
+    # ... also when the partial sums sit at the wrap-around edge
+    edge = (1 << 64) - 1 - rank
+    esum, ecnt = red(edge, 1 << 40)
+    assert esum == sum((1 << 64) - 1 - r for r in range(world)) % (1 << 64) and ecnt == world << 40
     res = {f: K.agg_value(merged[0], f) for f in (K.ReducerFunc.Sum, K.ReducerFunc.Min, K.ReducerFunc.Max,
                                                    K.ReducerFunc.First, K.ReducerFunc.Last)}
     q.put((rank, total, {int(k): (int(v[0]), v[1], v[2]) for k, v in res.items()}))
@@ -74,3 +84,20 @@ def test_shard_range_partitions_exactly():
         for w in (1, 2, 3, 8):
             rs = [shard_range(n, r, w) for r in range(w)]
             assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`bench.py --gpus 2` with no launcher around it starts two rank processes itself (fresh interpreters, the parent
+    never touches the GPU); with the gloo rehearsal backend they bring the process group up even on a box without a GPU,
+    then refuse to run: there is no CPU fallback."""
+    import subprocess
+    env = dict(os.environ, KNOX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows-log2", "20", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert "[rank 0] process group up: backend gloo, 2 rank(s)" in r.stderr, r.stderr[-2000:]
+    assert "[rank 1] process group up: backend gloo, 2 rank(s)" in r.stderr, r.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no HIP device visible" in r.stderr and r.stdout.strip() == ""

@@ -133,6 +133,77 @@ def test_cfg4_full_size_bloom_pruned_point_lookup(ctx):
         o.free()
 
 
+def test_cfg4_full_size_bytes_column_bloom_then_eq(ctx):
+    """BASELINE configs[3], the []byte leg at full size: 2^30 rows of 32-byte `addr` values drawn from 2^24 distinct
+    keys (each key inside one window of 4 packs), ONE StringPool per pack (32 MiB pools, 32 GiB of payload: far above
+    the 4 GiB a single pool can address), per-pack bloom filters (factor 2) over the bytes column built on the
+    device, probe one present and one absent key, bytes EQ + count over the surviving packs.  Pruned scan == full
+    scan; the hits are exactly the rows the dataset's spec puts the key in; sampled packs equal the oracle's
+    StringPool.MatchEqual bit for bit; a mixed tree (bytes EQ AND uint64 range on the id column) agrees too."""
+    key_len, wb, ppw = 32, 16, 4
+    addr = ctx.generate_bytes(6, N, PACK, key_len, wb, ppw)
+    assert addr.rows == N and ctx.L.knox_col_pool_bytes(addr.h) == N * key_len
+    ids = ctx.generate(BlockType.Uint64, 3, 0, N, lo=0, pack_rows=PACK)     # id = row number
+    bloom = ctx.bloom_build(addr, 2)
+    assert bloom.packs == N // PACK
+    # the device generator against the spec on sampled packs (whole pools, byte for byte)
+    for p in (0, 1023):
+        want_ptr, want_buf, _ = O.generate_bytes_pack(6, p, PACK, PACK, key_len, wb, ppw)
+        ptr, buf = ctx.download_bytes_pack(addr, p)
+        assert (ptr == want_ptr).all() and (buf[: want_buf.size] == want_buf).all(), p
+    target_row = 777 * PACK + 12345
+    k = int(O.bytes_key_index(6, target_row, 1, PACK, wb, ppw)[0])
+    present = bytes(O.bytes_key(6, k, key_len))
+    absent = bytes(O.bytes_key(6, (1 << 40) + 99, key_len))
+    bits = ctx.bits(N)
+    for key, is_present in ((present, True), (absent, False)):
+        maybe = bloom.probe(K.hash_bytes(key))
+        want_rows = []
+        if is_present:
+            w0 = (k >> wb) * ppw
+            for p in range(w0, w0 + ppw):
+                ki = O.bytes_key_index(6, p * PACK, PACK, PACK, wb, ppw)
+                hit = np.flatnonzero(ki == np.uint64(k))
+                want_rows += (hit + p * PACK).tolist()
+                if hit.size:
+                    assert maybe[p] == 1                                    # no false negatives
+            assert target_row in want_rows
+        assert int(maybe.sum()) <= (ppw if is_present else 0) + 8           # factor-2 filters: a handful of false positives at most
+        tree = And(Leaf(0, FilterMode.Equal, key))
+        r_pruned = ctx.scan(tree, [addr, ids], aggs=[(R.Count, 1), (R.Sum, 1)], bits_out=bits, pack_counts=True,
+                            pack_skip=(1 - maybe).astype(np.uint8))
+        pruned_idx = bits.indexes().tolist()
+        r_full = ctx.scan(tree, [addr, ids], aggs=[(R.Count, 1), (R.Sum, 1)], bits_out=bits, pack_counts=True)
+        assert pruned_idx == bits.indexes().tolist() == want_rows
+        assert r_pruned.count == r_full.count == len(want_rows)
+        assert int(r_pruned.value(1)[0]) == int(r_full.value(1)[0]) == sum(want_rows)
+        assert (r_pruned.pack_counts == r_full.pack_counts).all()
+        assert r_pruned.rows_scanned == int(maybe.sum()) * PACK and r_full.rows_scanned == N
+        got = bits.bytes()
+        for p in (0, target_row // PACK, 1023):
+            ptr, buf, _ = O.generate_bytes_pack(6, p, PACK, PACK, key_len, wb, ppw)
+            wbits, wcnt = O.bytes_match(O.EQ, ptr, buf, key)
+            assert (got[p * PACK // 8:(p + 1) * PACK // 8] == wbits).all() and r_full.pack_counts[p] == wcnt, p
+    maybe = bloom.probe(K.hash_bytes(present))
+    r = ctx.scan(And(Leaf(0, FilterMode.Equal, present), Leaf(1, FilterMode.Le, target_row)), [addr, ids], aggs=[(R.Max, 1), (R.Count, 1)],
+                 bits_out=bits, pack_skip=(1 - maybe).astype(np.uint8))
+    assert int(r.value(0)[0]) == target_row and r.count == sum(1 for x in present_rows(k, wb, ppw, key_len) if x <= target_row)
+    # NE is the complement (size-independent property at 2^30 rows)
+    r_ne = ctx.scan(And(Leaf(0, FilterMode.NotEqual, present)), [addr, ids], aggs=[(R.Count, 1)], bits_out=bits)
+    assert r_ne.count == N - len(present_rows(k, wb, ppw, key_len))
+    for o in (addr, ids, bits, bloom):
+        o.free()
+
+
+def present_rows(k, wb, ppw, key_len):
+    rows = []
+    w0 = (k >> wb) * ppw
+    for p in range(w0, w0 + ppw):
+        ki = O.bytes_key_index(6, p * PACK, PACK, PACK, wb, ppw)
+        rows += (np.flatnonzero(ki == np.uint64(k)) + p * PACK).tolist()
+    return rows
+
+
 def test_time_windows_full_size_properties(ctx):
     """f1 at BASELINE size: 2^30 rows in 1024 windows (= the packs), ordered clock; then 2^26 rows with a fully
     shuffled clock through the stable-sort path.  Linearity / partition properties + sampled windows vs the oracle."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary configs of BASELINE.json (not the headline): steady-state kernel time + achieved GB/s.
   cfg3: 2^30 float64 rows x 2 columns, `A >= 256 AND B < 0.5`, min/max/mean(A) + count
-  cfg4: 2^30 uint64 ids, per-pack bloom (factor 2) probe then EQ, count
+  cfg4: 2^30 uint64 ids + 2^30 32-byte []byte keys (one StringPool per pack), per-pack bloom (factor 2) probe then EQ, count
 """
 import argparse, ctypes as C, json, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -110,3 +110,35 @@ elif args.cfg == 4:
                           "full_GBs": n * 8.125 / ms_full / 1e6, "pruned_GBs_over_scanned_packs": scanned * pack * 8.125 / ms_pruned / 1e6 if scanned else None,
                           "effective_rows_per_s_incl_pruned": n / ms_pruned * 1e3, "bloom_build_s": t_build, "bloom_probe_s": t_probe,
                           "filter_bytes": int(ctx.L.knox_bloom_bytes(bloom.h))}))
+    # the []byte leg (BASELINE configs[3]): 32-byte `addr` values from 2^24 distinct keys, each key inside one window of
+    # 4 packs; one StringPool per pack; per-pack bloom over the bytes column (XXH3-64 of every row, on the device)
+    ids.free(); bloom.free()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    t0 = time.perf_counter()
+    addr = ctx.generate_bytes(6, n, pack, 32, 16, 4)
+    ctx.sync()
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bloom = ctx.bloom_build(addr, 2)
+    ctx.sync()
+    t_build = time.perf_counter() - t0
+    ptr, buf = ctx.download_bytes_pack(addr, min(777, n // pack - 1))
+    present = bytes(buf[12345 * 32:12346 * 32])
+    absent = bytes(range(32))
+    B_ROW = 8 + 32 + 0.125
+    for name, key in (("present", present), ("absent", absent)):
+        t0 = time.perf_counter()
+        maybe = bloom.probe(K.hash_bytes(key))
+        t_probe = time.perf_counter() - t0
+        plan = ctx.plan(And(Leaf(0, FilterMode.Equal, key)), [addr], aggs=[])
+        ms_full, r_full = timed(plan, bits, args.steps)
+        ms_pruned, r_pruned = timed(plan, bits, args.steps, skip=(1 - maybe).astype(np.uint8))
+        scanned = int(maybe.sum())
+        print(json.dumps({"cfg": 4, "leg": "bytes", "key": name, "packs_maybe": scanned, "packs": n // pack, "count_full": r_full.count,
+                          "count_pruned": r_pruned.count, "rows_scanned_pruned": r_pruned.rows_scanned, "bytes_per_row": B_ROW,
+                          "kernel_ms_full": ms_full, "kernel_ms_pruned": ms_pruned, "full_GBs": n * B_ROW / ms_full / 1e6,
+                          "full_frac_8TBs": n * B_ROW / ms_full / 1e6 / 8000, "full_rows_per_s": n / ms_full * 1e3,
+                          "pruned_GBs_over_scanned_packs": scanned * pack * B_ROW / ms_pruned / 1e6 if scanned else None,
+                          "effective_rows_per_s_incl_pruned": n / ms_pruned * 1e3, "generate_s": t_gen, "bloom_build_s": t_build,
+                          "bloom_probe_s": t_probe, "filter_bytes": int(ctx.L.knox_bloom_bytes(bloom.h)),
+                          "pool_bytes": int(ctx.L.knox_col_pool_bytes(addr.h))}))

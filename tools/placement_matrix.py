@@ -40,7 +40,9 @@ for ci, col in enumerate(cols):
     row = []
     for it, bpc, var in configs:
         os.environ["KNOX_ITERS"] = str(it)
-        ctx.set_tuning(bpc, var)
+        ctx.set_tuning(bpc)
+        if var != 1:
+            ctx.diag_set_variant(var)  # diagnostics library only
         row.append(run(col, 14))
     res.append(row)
     print("%3d | " % ci + " ".join("%6.0f" % x for x in row))

@@ -18,7 +18,7 @@ ap.add_argument("--rows-log2", type=int, default=30)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--bpc", type=str, default="2,4,8,12,16,32")
-ap.add_argument("--variants", type=str, default="0,1")
+ap.add_argument("--variants", type=str, default="1")
 ap.add_argument("--modes", type=str, default="count,bits,bits+sum")
 ap.add_argument("--dtype", type=str, default="i64")
 args = ap.parse_args()
@@ -54,7 +54,9 @@ ctx.L.knox_prof_enable(ctx.h, 1)
 for r in range(args.rounds + 1):
     for c in configs:
         bpc, var, mode = c
-        ctx.set_tuning(bpc, var)
+        ctx.set_tuning(bpc)
+        if var != 1:
+            ctx.diag_set_variant(var)  # diagnostics library only (KNOXGPU_SO=knoxdb_amd/diag/...)
         plan, b = plans[mode]
         ctx.scan_async(plan, bits_out=b)
         for _ in range(args.steps - 1):

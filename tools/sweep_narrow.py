@@ -25,7 +25,7 @@ for bt, w, lo, span, a, b in ((B.Uint8, 1, 0, 256, 64, 127), (B.Int16, 2, -(1 <<
         os.environ["KNOX_ITERS"] = str(it)
         row = []
         for bpc in (2, 3, 4, 6, 8):
-            ctx.set_tuning(bpc, -1)
+            ctx.set_tuning(bpc)
             row.append(rate(col, bits, plan, w + .125))
         print(bt.name, "iters", it, " ".join("b%d:%5.0f" % (b_, r) for b_, r in zip((2, 3, 4, 6, 8), row)), col.placement[2])
     col.free()

@@ -22,10 +22,10 @@ def run(col, b, steps, aggs):
 run(cols[0], bits, 80, [(ReducerFunc.Sum, 0)])
 print("col: count | store flavours: nt, none, plain, sc1, sc0sc1, sc0, nt sc1, nt sc0 sc1")
 for ci, col in enumerate(cols):
-    ctx.set_tuning(0, 1)
+    ctx.diag_set_variant(1)  # needs a diagnostics library: KNOXGPU_SO=knoxdb_amd/diag/libknoxgpu_p7.so
     a = run(col, None, 16, [(ReducerFunc.Count, 0)])
     row = []
     for var in (1, 2, 3, 4, 5, 6, 7, 8):
-        ctx.set_tuning(0, var)
+        ctx.diag_set_variant(var)
         row.append(run(col, bits, 16, [(ReducerFunc.Sum, 0)]))
     print("col %2d: %5.0f | " % (ci, a) + " ".join("%5.0f" % x for x in row))
