@@ -9,17 +9,18 @@ generated on the device (counter-based generator) and are resident in
 timed region starts.  For N > 1 each rank owns a contiguous pack range (no data-path
 collective); only the 144-byte partial aggregate state crosses xGMI (RCCL all-gather) each step.
 
-Setup, outside the timed region and reported under "placement" in the JSON line: two candidate
-columns are generated and the one whose read-only scan is faster is kept; the bitset is allocated for that
-column (knox_bits_alloc_for: the pair is probed); the pair is then checked with the real kernel against its own
-read-only form; when it falls short the check first waits 2.5 s and measures again (a device still busy after
-somebody's large frees recovers by itself), then asks for other buffers and uses the best pair seen; nothing is
-returned to the driver before the measurement
-(freeing a multi-GiB neighbour slows the buffers that stay).  The timed region contains only the K steps.
+Setup, outside the timed region and reported under "placement" in the JSON line: the context's
+device-memory arena gets an explicit budget (KNOX_BENCH_ARENA_GIB, default 64), the column is generated into it, the
+bitset is allocated FOR that column (a write buffer verified against it, knox_bits_alloc_for) and the pair is checked ONCE with
+the real kernel against its own read-only form (a second look after 2.5 s only when the device was evidently still
+busy with somebody else's freed memory).  The timed region contains only the K steps.
 
-Environment (diagnostics, none needed): KNOX_PLACEMENT=0 plain hipMalloc; KNOX_BENCH_RETUNE_MIN pair-check threshold
-(default 0.925); KNOX_BENCH_DEPTH scans queued ahead; KNOX_BENCH_FORCE_DIST=1 / KNOX_BENCH_BACKEND=gloo rehearsal modes
-of the multi-rank path on a 1-GPU box.
+After the timed region (all outside it): the read-only ceiling, the 0 % / 100 % selectivity runs of the same scan, the
+in-run parity against the oracle (bitset memcmp on a 64-pack sample, XOR checksum of ALL bitset words, count and
+wrapping sum of the whole run), and the CPU baseline (scalar port @ 1 thread, AVX2 @ 1 thread, AVX2 @ all cores).
+
+Environment (diagnostics, none needed): KNOX_PLACEMENT=0 plain hipMalloc; KNOX_BENCH_DEPTH scans queued ahead;
+KNOX_BENCH_FORCE_DIST=1 / KNOX_BENCH_BACKEND=gloo rehearsal modes of the multi-rank path on a 1-GPU box.
 
 Prints ONE JSON line on stdout (rank 0); progress notes go to stderr.
 """
@@ -36,14 +37,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 BYTES_PER_ROW = 8.125  # 8 B value read + 1/8 B bitset written
 
 
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts, min_seconds=10.0):
     """The oracle's literal restatement of the reference flow (cmp -> Indexes -> SumReducer per
     row), one thread like the reference's one-goroutine pack loop (pack/table/query.go:195-219),
     on the first `sample_rows` rows of the same workload, repeated until >= min_seconds of CPU
-    work have been timed."""
+    work have been timed; beside it the AVX2 port of the compare kernel with the masked sum fused
+    (the strategy of internal/cmp/avx2/int64_AVX2_amd64.s:1154-1330) on ONE thread -- the figure
+    closest to the reference's published 1.8-2.8 G rows/s per core -- and on every host core."""
     import numpy as np
     from oracle import oracle as O
-    x = O.generate(O.I64, 0, 2, 0, sample_rows, lo=-(1 << 40), span=1 << 41)
+    cores = host_cores()
+    x = O.generate_mt(O.I64, 0, 2, 0, sample_rows, lo=-(1 << 40), span=1 << 41, threads=cores)
     passes, dt = 0, 0.0
     while dt < min_seconds and passes < 64:
         t0 = time.perf_counter()
@@ -54,31 +65,68 @@ def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts, min_seconds=10.0
     if gpu_pack_counts is not None:
         ok = int(gpu_pack_counts[: sample_rows // pack_rows].sum()) == int(cnt)
     rows = sample_rows * passes
-    # extra figure: AVX2, pack-parallel over every host core, compare+sum fused (oracle/knox_cpu_simd.c)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
-    simd = None
-    try:
-        sbits = np.zeros((sample_rows + 7) >> 3, dtype=np.uint8)
-        O.simd_scan_i64_bw_sum(x, pack_rows, a, b, cores, sbits)  # warm the pages
-        sp, sdt = 0, 0.0
-        while sdt < 3.0 and sp < 64:
-            t0 = time.perf_counter()
-            _, scnt, ssum = O.simd_scan_i64_bw_sum(x, pack_rows, a, b, cores, sbits)
-            sdt += time.perf_counter() - t0
-            sp += 1
-        simd = {"value": sample_rows * sp / sdt, "unit": "rows/s", "cores": cores, "avx2": bool(O.lib().ko_simd_has_avx2()),
-                "gb_per_s": sample_rows * sp * BYTES_PER_ROW / sdt / 1e9, "matches_port": bool(scnt == cnt and ssum == s),
-                "note": "AVX2 cmp+movemask+popcnt with the masked sum fused, pack-parallel over all host cores"}
-    except Exception as e:  # the baseline must never break the bench line
-        simd = {"error": str(e)}
-    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "simd_all_cores": simd,
+
+    def simd(threads, seconds):
+        try:
+            sbits = np.zeros((sample_rows + 7) >> 3, dtype=np.uint8)
+            O.simd_scan_i64_bw_sum(x, pack_rows, a, b, threads, sbits)  # warm the pages
+            sp, sdt = 0, 0.0
+            while sdt < seconds and sp < 64:
+                t0 = time.perf_counter()
+                _, scnt, ssum = O.simd_scan_i64_bw_sum(x, pack_rows, a, b, threads, sbits)
+                sdt += time.perf_counter() - t0
+                sp += 1
+            return {"value": sample_rows * sp / sdt, "unit": "rows/s", "cores": threads, "avx2": bool(O.lib().ko_simd_has_avx2()),
+                    "gb_per_s": sample_rows * sp * BYTES_PER_ROW / sdt / 1e9,
+                    "matches_port": bool(scnt == cnt and ssum == s and (sbits == bits).all()),
+                    "note": "AVX2 cmp + movemask + popcnt with the masked sum fused (oracle/knox_cpu_simd.c), pack-parallel over %d thread(s)" % threads}
+        except Exception as e:  # the baseline must never break the bench line
+            return {"error": str(e)}
+
+    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "simd_1_thread": simd(1, 4.0), "simd_all_cores": simd(cores, 3.0),
             "sample": "first %d rows (%d packs of 2^20) of the same workload x %d passes, oracle/knox_oracle.c "
                       "ko_scan_i64_bw_sum (cmp_bw -> Indexes -> SumReducer per row), %.1f s timed, gcc -O2, 1 thread"
                       % (sample_rows, sample_rows // pack_rows, passes, dt),
             "gb_per_s": rows * BYTES_PER_ROW / dt / 1e9, "matches_gpu_counts": ok}
+
+
+def in_run_parity(ctx, col_seed, n_rows, pack_rows, a, b, bits, res, row_seed_first=0):
+    """SURVEY.md 8(d) "parity checks in-run", outside the timed region: (1) the bitset bytes of a 64-pack sample equal the
+    oracle's cmp_bw output (memcmp), their counts and wrapping sum too; (2) the XOR of ALL 64-bit bitset words, the total
+    count and the wrapping sum of the WHOLE run equal the CPU's over all rows (AVX2 port on every core -- itself checked
+    against the literal port on the sample -- over rows regenerated on the host from the generator's spec)."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = host_cores()
+    n_packs = n_rows // pack_rows
+    got = bits.bytes()
+    pb = pack_rows >> 3
+    sample = sorted(set(int(p) for p in np.linspace(0, n_packs - 1, 64)))
+    ok_bits = ok_counts = True
+    ssum = 0
+    for p in sample:
+        x = O.generate(O.I64, 0, col_seed, p * pack_rows, pack_rows, lo=-(1 << 40), span=1 << 41)
+        wb, wc = O.cmp(O.I64, O.RG, x, a, b)
+        ok_bits = ok_bits and bool((got[p * pb:(p + 1) * pb] == wb).all())
+        ok_counts = ok_counts and int(res.pack_counts[p]) == int(wc)
+        ssum += int(O.reduce(O.I64, O.R_SUM, x, wb)[0])
+    # the whole run, chunk by chunk (bounded host memory)
+    chunk = min(n_rows, 1 << 27)
+    xbuf = np.empty(chunk, dtype=np.int64)
+    cbits = np.zeros(chunk >> 3, dtype=np.uint8)
+    xor_cpu, cnt_cpu, sum_cpu = np.uint64(0), 0, 0
+    for r0 in range(0, n_rows, chunk):
+        O.generate_mt(O.I64, 0, col_seed, r0, chunk, lo=-(1 << 40), span=1 << 41, threads=cores, out=xbuf)
+        _, c, s_ = O.simd_scan_i64_bw_sum(xbuf, pack_rows, a, b, cores, cbits)
+        xor_cpu ^= np.bitwise_xor.reduce(cbits.view(np.uint64))
+        cnt_cpu += int(c)
+        sum_cpu = (sum_cpu + int(s_)) % (1 << 64)
+    xor_gpu = np.bitwise_xor.reduce(got.view(np.uint64))
+    gsum = int(res.states[0].isum) % (1 << 64)
+    return {"sample_packs": len(sample), "sample_bitsets_equal_oracle": ok_bits, "sample_pack_counts_equal": ok_counts,
+            "whole_run_rows_checked": n_rows, "xor_of_all_bitset_words": "%016x" % int(xor_gpu),
+            "xor_equals_cpu": bool(xor_gpu == xor_cpu), "count_equals_cpu": bool(res.count == cnt_cpu),
+            "sum_equals_cpu": bool(gsum == sum_cpu), "sample_sum_mod_2^64": ssum % (1 << 64)}
 
 
 def launch_ranks(n):
@@ -149,6 +197,7 @@ def main():
     if world > 1 or os.environ.get("KNOX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")   # only the one-rank rehearsal comes without a launcher
         if backend == "nccl":
             torch.cuda.set_device(device_index)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
@@ -184,8 +233,8 @@ def main():
     row_base = first_pack * pack_rows
     import ctypes as C
 
-    def make_col():
-        return ctx.generate(BlockType.Int64, 0, seed, n_rows, first_row=0, lo=-(1 << 40), span=1 << 41, pack_rows=pack_rows)
+    arena_gib = float(os.environ.get("KNOX_BENCH_ARENA_GIB", "64"))
+    ctx.set_arena(int(arena_gib * 2**30))   # explicit budget of the context's device-memory arena (include/knoxgpu.h)
 
     def kernel_ms(p, out_bits, reps):
         """mean duration of the scan kernel over `reps` launches (the library's own HIP events on its stream)"""
@@ -199,73 +248,27 @@ def main():
         return ms.value / max(1, k.value)
 
     tree = And(Leaf(0, FilterMode.Range, a, b))
-    col = make_col()
-    tuned = n_rows >= (1 << 26) and os.environ.get("KNOX_PLACEMENT", "1") != "0"
-    ro_rates = []
-    parked = []
-    if tuned:
-        # Some regions read ~4 % slower than others whatever is written next to them (the allocator's ratio test cannot
-        # see that: it is relative).  Candidate columns are generated and timed with the read-only form of the scan,
-        # the fastest one is kept -- setup work, outside the timed region, reported in the JSON line.
-        # (up to 5 candidates while none reads at the rate every fresh box has shown, 7.1+ TB/s; all stay allocated)
-        cands = []
-        for k in range(5):
-            c = col if k == 0 else make_col()
-            p0 = ctx.plan(tree, [c], aggs=[])
-            kernel_ms(p0, None, 6)                        # clock ramp
-            cands.append((kernel_ms(p0, None, 8), c))
-            ro_rates.append(n_rows * 8.0 / (cands[-1][0] * 1e6))
-            if k >= 1 and max(ro_rates) >= 0.885 * HBM_PEAK_GBS:
-                break
-        keep = min(range(len(cands)), key=lambda i: cands[i][0])
-        if cands[0][0] <= cands[keep][0] * 1.01:
-            keep = 0
-        # NOT freed before the timed run: returning a multi-GiB neighbour to the driver slows the column that stays
-        # (measured, same box, alternating: read-only 7.14 -> 6.95 TB/s, on another box 7.15 -> 6.80 with the scan
-        # falling to 0.78 of peak) -- everything this setup replaces is parked and freed after the measurement
-        parked += [c for i, (_, c) in enumerate(cands) if i != keep]
-        col = cands[keep][1]
-    bits = ctx.bits(n_rows, for_col=col)  # selection bitset of the placement class that matches the column
+    t_setup = time.perf_counter()
+    col = ctx.generate(BlockType.Int64, 0, seed, n_rows, first_row=0, lo=-(1 << 40), span=1 << 41, pack_rows=pack_rows)
+    bits = ctx.bits(n_rows, for_col=col)   # the selection bitset: a write buffer verified against this very column
     plan = ctx.plan(tree, [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
     ctx.sync()
-    # Setup check with the real kernel (outside the timed region): the allocator's probes pair the column and the bitset
-    # region by region, but one run in about twenty still landed on a pair whose full-size scan ran well below its own
-    # read-only form.  A host that cares does what this does: measure, and ask the allocator for another bitset (then
-    # another column) while the old one is still held, so that the driver cannot hand the same region back.
-    retuned = 0
-    if tuned:
-        tried = []   # (scan ms, column, bitset): everything stays allocated, the fastest pair is used
-        for attempt in range(4):
-            plan = ctx.plan(tree, [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
-            ro_plan0 = ctx.plan(tree, [col], aggs=[])
+    # the ONE setup check, with the real kernel, outside the timed region: the scan against its own read-only form.  A low
+    # ratio right after start is almost always a device still busy clearing somebody else's freed memory: look once more
+    # after 2.5 s and report both; nothing else is tried, nothing is re-allocated.
+    checks = []
+    if n_rows >= (1 << 26):
+        ro_plan0 = ctx.plan(tree, [col], aggs=[])
+        for attempt in range(2):
             kernel_ms(plan, bits, 4)                      # clock ramp
             ro_ms, mix_ms = kernel_ms(ro_plan0, None, 6), kernel_ms(plan, bits, 8)
-            ratio = ro_ms / mix_ms
-            tried.append((mix_ms, col, bits))
-            print("[setup] attempt %d: read-only %.4f ms, scan %.4f ms, ratio %.3f, bits probe %s" % (attempt, ro_ms, mix_ms, ratio, bits.placement), file=sys.stderr)
-            if ratio >= float(os.environ.get("KNOX_BENCH_RETUNE_MIN", "0.925")):   # like pairs: 0.95-0.98, unlike ones: 0.84
+            checks.append({"read_only_ms": ro_ms, "scan_ms": mix_ms, "scan_over_read_only": ro_ms / mix_ms})
+            print("[setup] check %d: read-only %.4f ms, scan %.4f ms, ratio %.3f, bitset verified at allocation: %s" %
+                  (attempt, ro_ms, mix_ms, ro_ms / mix_ms, bits.pair_check), file=sys.stderr)
+            if ro_ms / mix_ms >= 0.925:
                 break
-            if attempt == 3:
-                break
-            retuned += 1
-            if attempt == 0:
-                # first suspicion: the device is still busy with somebody else's memory (a process that just exited
-                # with 100+ GiB allocated leaves the driver clearing it; such runs recover by themselves): wait, re-measure
-                time.sleep(2.5)
-            elif attempt == 1:                            # a new bitset for the same column
-                bits = ctx.bits(n_rows, for_col=col)
-            else:                                         # a new column, and a bitset for it
-                col = make_col()
-                bits = ctx.bits(n_rows, for_col=col)
-        best = min(range(len(tried)), key=lambda i: tried[i][0])
-        _, col, bits = tried[best]
-        keep_ids = {id(col), id(bits)}
-        for _, c_, b_ in tried:
-            for o in (c_, b_):
-                if id(o) not in keep_ids and all(o is not q for q in parked):
-                    parked.append(o)
-        plan = ctx.plan(tree, [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
-        ctx.sync()
+            time.sleep(2.5)
+    t_setup = time.perf_counter() - t_setup
 
     # the final aggregate is the ONLY thing that crosses ranks: one all-reduce(int64, sum) of {sum, count} per step
     # (backend nccl = ncclAllReduce over xGMI); the all-gather of the full 144-byte states (what min / max / first /
@@ -346,12 +349,33 @@ def main():
     read_only_gbs = n_rows * 8.0 * ro_n.value / (ro_ms.value * 1e6) if ro_ms.value > 0 else 0.0
     assert ro_res.count == res.count
 
-    kernel_ms = kms.value / max(1, kn.value)
-    achieved = n_rows * BYTES_PER_ROW / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    scan_ms = kms.value / max(1, kn.value)
+    achieved = n_rows * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     total_rows = n_rows * world * args.steps
     value = total_rows / elapsed
     sum_val = gsum - (1 << 64) if gsum >= (1 << 63) else gsum   # Value() of the int64 SumReducer: the sum mod 2^64 as int64
 
+    # 0 % and 100 % selectivity runs of the same scan, outside the timed region: same bytes moved, the
+    # aggregate work differs (no row / every row feeds the sum)
+    sel_runs = {}
+    if rank == 0 and n_rows >= (1 << 26):
+        for name, lo_, hi_ in (("0%", 1 << 50, (1 << 50) + 5), ("100%", -(1 << 41), 1 << 41)):
+            p_ = ctx.plan(And(Leaf(0, FilterMode.Range, lo_, hi_)), [col], aggs=[(ReducerFunc.Sum, 0), (ReducerFunc.Count, 0)])
+            kernel_ms(p_, bits, 4)
+            ms_ = kernel_ms(p_, bits, 10)
+            ctx.scan_async(p_, bits_out=bits, pack_counts=True, row_base=row_base)
+            r_ = ctx.scan_collect(p_, n_packs)
+            sel_runs[name] = {"kernel_ms": ms_, "gb_per_s": n_rows * BYTES_PER_ROW / ms_ / 1e6, "frac": n_rows * BYTES_PER_ROW / ms_ / 1e6 / HBM_PEAK_GBS,
+                              "selected_rows": int(r_.count)}
+        # leave the headline result in the bitset for the parity check below
+        ctx.scan_async(plan, bits_out=bits, pack_counts=True, row_base=row_base)
+        res = ctx.scan_collect(plan, n_packs)
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        parity = in_run_parity(ctx, seed, n_rows, pack_rows, a, b, bits, res)
+        assert parity["sample_bitsets_equal_oracle"] and parity["xor_equals_cpu"] and parity["count_equals_cpu"] and parity["sum_equals_cpu"], parity
+
+    ai = ctx.arena_info()
     out = {
         "metric": "scanned rows/sec + achieved HBM GB/s, 1B-row int64 range filter+sum",
         "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -365,21 +389,27 @@ def main():
                    "selected_rows": int(total), "sum_mod_2^64": sum_val},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": kernel_ms,
+                     "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": scan_ms,
                      "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW,
                      "read_only_ceiling_gb_per_s": read_only_gbs,
                      "frac_of_read_only_ceiling": achieved / read_only_gbs if read_only_gbs > 0 else None},
         "whole_step_gb_per_s": n_rows * BYTES_PER_ROW / (elapsed / args.steps) / 1e9,
-        # placement-aware allocation (include/knoxgpu.h knox_ctx_set_placement; KNOX_PLACEMENT=0 turns it off):
-        # the allocator's own probe of the column buffer and how many candidates it tried
-        "placement": {"enabled": os.environ.get("KNOX_PLACEMENT", "1") != "0", "probe_gb_per_s": col.placement[0],
-                      "probe_mix_over_read_only": col.placement[2], "candidates_tried": col.placement[1], "held_gib": ctx.placement_info()["held_bytes"] / 2**30, "setup_retunes": retuned, "setup_read_only_gb_per_s_of_the_candidate_columns": ro_rates,
-                      "bitset_probe_gb_per_s": bits.placement[0], "bitset_candidates_tried": bits.placement[1]},
+        "selectivity_runs": sel_runs,
+        "parity_in_run": parity,
+        # the context's device-memory arena (include/knoxgpu.h knox_ctx_set_arena; KNOX_PLACEMENT=0 = plain hipMalloc): the
+        # bitset is a write buffer chosen by running the scan on the (column, buffer) pair; nothing is held outside it
+        "placement": {"arena_enabled": ai["enabled"], "arena_budget_gib": ai["budget_gib"], "arena_mapped_gib": ai["mapped_gib"],
+                      "arena_used_gib": ai["used_gib"], "write_buffers_created": ai["write_buffers"], "spare_write_buffer_gib": ai["spare_write_buffer_gib"],
+                      "chunks_created": ai["chunks"], "probe_measurements": ai["probes"], "transient_spacer_gib": ai["transient_spacer_gib"],
+                      "bitset_pair_check_at_allocation": {"scan_over_read_only": bits.pair_check[0], "candidate_windows": bits.pair_check[1]},
+                      "held_outside_arena_bytes": ctx.placement_info()["held_bytes"], "setup_checks": checks, "setup_s": t_setup},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr) and args.rows_log2 == 30:
         try:
-            out["roofline"]["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tr))
+            out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = "profiles/traffic.json (%s; rocprofv3 --pmc passes of this command, tools/profile_round.sh)" % tj.get("measured", "round 1")
         except Exception:
             pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -388,8 +418,6 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    for o in parked:
-        o.free()
     col.free()
     bits.free()
     ctx.close()

@@ -104,24 +104,41 @@ int knox_ctx_set_tuning(knox_ctx *ctx, int blocks_per_cu);
 int knox_host_alloc(knox_ctx *ctx, size_t bytes, void **out);
 int knox_host_free(knox_ctx *ctx, void *p);
 
-/* Placement-aware allocation (default on; env KNOX_PLACEMENT=0 or mode 0 turns it off).
- * Measured on MI355X: every device buffer carries a binary placement class, and the
- * scan's read+write mix (8 B read / 0.125 B written per row) runs at ~6.9 TB/s when the column and
- * the bitset it writes are of the SAME class and at ~6.0 TB/s when they differ; read-only passes do
- * not see it, so mix rate / read-only rate of the same buffer (~0.95 vs ~0.84) tells the classes apart.  The library therefore (1) keeps one fixed reference bitset window per context and
- * probes every owned column buffer >= 256 MiB against it with the scan kernel right after
- * allocation -- a candidate of the other class is held back (so the driver cannot return the same
- * region) and another one is tried; (2) offers knox_bits_alloc_for, which returns a bitset of the
- * class that matches a given column.  Held regions go back to the driver when an allocation would
- * otherwise fail, when placement is switched off, and at knox_ctx_close.  Results never depend
- * on any of this.                                                                           */
-int knox_ctx_set_placement(knox_ctx *ctx, int mode /* 0 off, 1 on */);
+/* ---- device memory: one bounded arena per context (knoxdb_amd/csrc/knox_arena.h) ---------------- *
+ * Measured on MI355X: for the scan's read+write mix it matters where the bitset lies relative to the column.  Physical
+ * HBM falls into a few classes; a scan whose column and bitset lie in the SAME class runs at ~6.0 TB/s, in DIFFERENT
+ * classes at ~7.05 TB/s; read-only passes do not see it.  All device memory a context owns comes out of ONE arena:
+ * physical memory is taken from the driver only as allocations need it (HIP virtual-memory API), up to a hard budget,
+ * and is not returned before knox_ctx_close (or an explicit trim); columns of >= 1 GiB are assembled from 1 GiB chunks
+ * mapped back to back; a large write buffer allocated FOR a column (knox_bits_alloc_for, the scan's scratch bitsets) is
+ * a physical allocation of its own, chosen among candidates by running the scan kernel on that very (column, buffer)
+ * pair.  Nothing is held outside the arena's accounting.  Budget: KNOX_ARENA_GIB in the environment,
+ * knox_ctx_set_arena, default 3/4 of the device.  Mode 0 (or KNOX_PLACEMENT=0): plain hipMalloc / hipFree.
+ * Results never depend on any of this.                                                                           */
+int knox_ctx_set_placement(knox_ctx *ctx, int mode /* 0 plain allocations, 1 arena */);
+int knox_ctx_set_arena(knox_ctx *ctx, size_t budget_bytes);
+typedef struct knox_arena_info {
+    uint64_t budget_bytes;     /* the cap                                                   */
+    uint64_t mapped_bytes;     /* physical memory taken from the driver and kept so far     */
+    uint64_t used_bytes;       /* handed out to columns / bitsets / scratch right now       */
+    uint64_t peak_used_bytes;
+    uint64_t spare_write_buffer_bytes; /* write buffers that were candidates or were freed: the first candidates of the next request */
+    uint64_t transient_spacer_bytes;   /* physical memory taken AND released again while looking for a write buffer far away
+                                          in the driver's allocation order (never mapped, never held past the call)   */
+    int32_t write_buffers, chunks, probes; /* write buffers created, 1 GiB chunks created, probe measurements taken */
+    int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
+} knox_arena_info;
+int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out);
+/* Returns every FREE column chunk and every spare write buffer to the driver.  Explicit only: returning multi-GiB blocks
+ * slows live neighbours for a second or two (the driver clears them).                                             */
+int knox_ctx_arena_trim(knox_ctx *ctx, size_t *freed_bytes /* nullable */);
+/* Bytes / regions the context keeps away from the driver OUTSIDE the arena's accounting: always 0 (kept so that a
+ * host can assert it).                                                                                            */
 int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *held_regions);
-/* probe of this column's buffer: GB/s of the 8.125 B/row mix on its worst 2 GiB chunk (0 = not
- * probed), that rate divided by the chunk's read-only rate (>= 0.90: same class as the context's
- * reference bitset window; ~0.84: the other class), and the candidates tried                  */
-int knox_col_placement(const knox_col *col, double *probe_gbs, double *probe_ratio, int *candidates);
-int knox_bits_placement(const knox_bits *bits, double *probe_gbs, int *candidates);
+/* What knox_bits_alloc_for measured for this (column, bitset) pair when it chose the buffer: the scan of up to four
+ * 1 GiB samples of the column into the bitset over the read-only form of the same samples (worst sample; >= 0.95 = a
+ * fast pair; 0 = column below 1 GiB or bitset below 16 MiB: not measured) and the candidates it looked at.        */
+int knox_bits_pair_check(const knox_bits *bits, double *scan_over_read_only, int *candidates);
 /* Per-kernel stopwatch: while enabled, every launch of the dominant streaming kernel
  * (scan / reduce) is bracketed by HIP events on the ctx stream; knox_prof_read syncs, returns
  * the summed kernel time and launch count since the last read, and resets.                */
@@ -227,9 +244,9 @@ int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out);
  * and at least ((size_bits + 63) / 64) * 8 + 64 bytes long; tail bits must be zero; never freed
  * by the library.                                                                            */
 int knox_bits_wrap(knox_ctx *ctx, void *device_ptr, size_t size_bits, knox_bits **out);
-/* As knox_bits_alloc, but the buffer is chosen to be of the placement class that is fast with
- * scans of `col` (pair probe with the scan kernel, <= 12 small candidates).  Use it for the
- * selection bitset (bits_out) of scans over that column / over columns placed by this context. */
+/* As knox_bits_alloc, but for scans over `col`: for columns of >= 1 GiB the buffer is a physical allocation of its own,
+ * chosen among candidates by scanning samples of `col` into it (knox_bits_pair_check reports the measurement); works
+ * for borrowed columns (knox_col_wrap) too.  Plain knox_bits_alloc takes ordinary arena memory, unverified.       */
 int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, knox_bits **out); /* zeroed           */
 int knox_bits_free(knox_bits *b);
 size_t knox_bits_size(const knox_bits *b);

@@ -47,6 +47,13 @@ class AggState(C.Structure):
                 ("m_sq_hi", C.c_double), ("m_sq_lo", C.c_double)]
 
 
+class ArenaInfo(C.Structure):
+    """knox_arena_info -- the context's device-memory arena."""
+    _fields_ = [("budget_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64), ("used_bytes", C.c_uint64), ("peak_used_bytes", C.c_uint64),
+                ("spare_write_buffer_bytes", C.c_uint64), ("transient_spacer_bytes", C.c_uint64), ("write_buffers", C.c_int32),
+                ("chunks", C.c_int32), ("probes", C.c_int32), ("enabled", C.c_int32)]
+
+
 class ScanOut(C.Structure):
     _fields_ = [("count", C.c_int64), ("rows_scanned", C.c_int64)]
 
@@ -126,8 +133,10 @@ SIGNATURES = {
     "knox_host_free": (_i, [_vp, _vp]),
     "knox_ctx_set_placement": (_i, [_vp, _i]),
     "knox_ctx_placement_info": (_i, [_vp, C.POINTER(_i64), _pi]),
-    "knox_col_placement": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pi]),
-    "knox_bits_placement": (_i, [_vp, C.POINTER(C.c_double), _pi]),
+    "knox_ctx_set_arena": (_i, [_vp, _sz]),
+    "knox_ctx_arena_info": (_i, [_vp, C.POINTER(ArenaInfo)]),
+    "knox_ctx_arena_trim": (_i, [_vp, C.POINTER(_sz)]),
+    "knox_bits_pair_check": (_i, [_vp, C.POINTER(C.c_double), _pi]),
     "knox_bits_wrap": (_i, [_vp, _vp, _sz, _pp]),
     "knox_bits_alloc_for": (_i, [_vp, _sz, _vp, _pp]),
     "knox_match_wide_set": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), _sz, _vp, _vp]),

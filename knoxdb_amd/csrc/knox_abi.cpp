@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>  // types only: librccl is dlopen'ed on first knox_comm_* call
 
 #include "../../include/knoxgpu.h"
+#include "knox_arena.h"
 #include "knox_kernels.h"
 #include "knox_regex.h"
 #include "knox_xxh3.h"  // host flavour: KNOX_HD / KNOX_XXH3_CONST empty
@@ -37,6 +38,7 @@ static_assert(sizeof(knox_agg_state) == sizeof(AggStateDev), "knox_agg_state lay
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    const void *for_col = nullptr;  // the column region a verified write buffer was chosen for (knox_arena.h), nullptr = heap memory
 };
 
 struct knox_ctx {
@@ -91,23 +93,12 @@ struct knox_ctx {
     static constexpr int kProfRing = 512;
     hipEvent_t prof_ev[2 * kProfRing] = {};
     int prof_n = 0;
-    // placement-aware column allocation: candidates that probed slow are held so the
-    // driver cannot hand the same physical region out again; released under memory pressure
-    struct Held { void *p; size_t bytes; };
-    std::vector<Held> held;
-    size_t held_bytes = 0;
-    // freed column buffers >= 256 MiB are kept for the next column of exactly that size instead of going back to
-    // the driver: returning a multi-GiB buffer slows its live neighbours (measured: read-only 7.15 -> 6.8-6.95 TB/s,
-    // the scan down to 0.78 of peak on one box), and a reused block keeps its measured placement
-    struct Cached { void *p; size_t bytes; double probe_gbs, probe_ratio; };
-    std::vector<Cached> cache;
-    size_t cache_bytes = 0;
+    // All device memory of the context comes out of ONE bounded arena (knox_arena.h): physical chunks
+    // classified once, columns and the bitsets / scratch written beside them carved out of different placement classes
     int placement = 1;             // 0 = plain hipMalloc
-    DevBuf probe_bits;             // reference bitset window (fixed size): defines the class placed buffers match
-    const void *ref_col = nullptr; // a placed column (still alive) that write buffers are matched against
-    uint64_t ref_rows = 0;
-    void *ref_scratch = nullptr;   // 2 GiB placed stand-in, created on demand when no placed column is alive
-    hipEvent_t pev0 = nullptr, pev1 = nullptr;
+    Arena arena;
+    void *probe_partials = nullptr;  // the classification probes' own partial buffer (plain allocation: the arena cannot allocate while it grows)
+    hipEvent_t probe_ev[24] = {};
     // RCCL
     void *rccl = nullptr;
     ncclComm_t comm = nullptr;
@@ -125,10 +116,6 @@ struct knox_col {
     uint8_t *buf;   // bytes column payload
     size_t buf_len;
     bool owned;
-    double probe_gbs = 0.0;    // placement probe of the accepted buffer: mix rate of its worst chunk (0 = not probed)
-    double probe_ratio = 0.0;  // mix / read-only of that chunk (>= 0.90: same class as the context's reference)
-    int probe_candidates = 0;
-    size_t alloc_bytes = 0;    // size of the owned allocation behind `dev` (block cache key)
     // bytes column held the way the reference holds it, ONE StringPool per pack (pkg/stringx/pool.go:45-58: 32-bit
     // offsets are relative to the pack's own pool): pool_base[p] = where pack p's pool starts inside buf (device
     // array + host mirror, packs_cap + 1 entries); nullptr = the whole column is one pool
@@ -144,8 +131,8 @@ struct knox_bits {
     uint64_t *dev;
     size_t cap_bytes;
     bool owned = true;
-    double probe_gbs = 0.0;  // pair probe of the accepted buffer (knox_bits_alloc_for), 0 = not probed
-    int probe_candidates = 0;
+    double pair_ratio = 0.0;  // knox_bits_alloc_for: scan / read-only of the (column, this bitset) pair as verified at allocation, 0 = not verified
+    int pair_tried = 0;       // candidate windows looked at
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -173,62 +160,64 @@ static bool dtype_is_float(int dtype) { return dtype == KNOX_FLOAT64 || dtype ==
 static bool dtype_is_signed(int dtype) { return dtype >= KNOX_INT64 && dtype <= KNOX_INT8; }
 static uint32_t dtype_flavor(int dtype) { return dtype_is_float(dtype) ? FL_FLOAT : dtype_is_signed(dtype) ? FL_SIGNED : FL_UNSIGNED; }
 
-// Held regions and cached blocks are plain free memory that contexts keep away from the driver; every context of
-// the process is registered so that an allocation that fails can take them back from ALL contexts on its device
-// (several contexts may be alive at once: one per host thread).  g_mem_mu guards the registry and every
-// held / cache vector; it is never held across a HIP allocation.
-static std::mutex g_mem_mu;
-static std::vector<knox_ctx *> g_ctxs;
+static double arena_probe(void *user, const void *col, uint64_t rows, void *bits);
 
-static void release_held_locked(knox_ctx *ctx) {
-    for (auto &h : ctx->held) hipFree(h.p);
-    ctx->held.clear();
-    ctx->held_bytes = 0;
-    for (auto &c : ctx->cache) hipFree(c.p);
-    ctx->cache.clear();
-    ctx->cache_bytes = 0;
-}
-static void release_held(knox_ctx *ctx) {
-    std::lock_guard<std::mutex> lk(g_mem_mu);
-    release_held_locked(ctx);
-}
-// a large buffer the context no longer needs: kept (as a write-buffer block for reuse) rather than returned to the
-// driver while the context works -- see knox_ctx::cache
-static void retire(knox_ctx *ctx, void *p, size_t bytes);
-
-// hipMalloc that gives the held (slow-probed) regions and cached blocks back to the driver before reporting OOM
-static hipError_t dev_malloc(knox_ctx *ctx, void **p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && ctx) {
+// Device memory of a context: the arena when placement is on (kind READ = columns / payloads the scans stream through,
+// kind WRITE = bitsets / scratch they write), plain hipMalloc when it is off or the device has no virtual-memory API.
+// The arena's budget is a hard cap.
+static hipError_t dev_malloc(knox_ctx *ctx, void **p, size_t bytes, int kind = ARENA_READ) {
+    if (ctx && ctx->placement) {
+        const hipError_t e = ctx->arena.alloc(p, bytes, kind);
+        if (e != hipErrorNotSupported) return e;
         (void)hipGetLastError();
-        bool any = false;
-        {
-            std::lock_guard<std::mutex> lk(g_mem_mu);
-            for (knox_ctx *c : g_ctxs) {
-                if (c->device != ctx->device || (c->held.empty() && c->cache.empty())) continue;
-                release_held_locked(c);  // free blocks: no stream of that context uses them
-                any = true;
-            }
-        }
-        if (any) e = hipMalloc(p, bytes);
     }
-    return e;
+    return hipMalloc(p, bytes);
+}
+static void dev_free(knox_ctx *ctx, void *p) {
+    if (!p) return;
+    if (ctx && ctx->arena.release(p)) return;
+    (void)hipFree(p);
 }
 
-static int ensure(knox_ctx *ctx, DevBuf &b, size_t bytes) {
+static int ensure(knox_ctx *ctx, DevBuf &b, size_t bytes, int kind = ARENA_WRITE) {
     if (b.cap >= bytes) return KNOX_OK;
     if (b.p) {
         // the stream may still be using the old buffer
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        retire(ctx, b.p, b.cap);
+        dev_free(ctx, b.p);
         b.p = nullptr;
         b.cap = 0;
     }
     size_t cap = std::max<size_t>(bytes, 4096);
     cap = (cap + 255) & ~(size_t)255;
-    hipError_t e = dev_malloc(ctx, &b.p, cap);
+    hipError_t e = dev_malloc(ctx, &b.p, cap, kind);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
+        b.p = nullptr;
+        return KNOX_E_NOMEM;
+    }
+    b.cap = cap;
+    b.for_col = nullptr;
+    return KNOX_OK;
+}
+
+// scratch a scan WRITES while it streams through `col` (scratch bitsets of multi-pass plans, per-tile counts): large
+// buffers are verified against that column like a knox_bits_alloc_for bitset (knox_arena.h)
+struct knox_col;
+static int ensure_for(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col);
+
+// RCCL send / receive buffers stay ordinary hipMalloc memory (a few hundred bytes)
+static int ensure_plain(knox_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes) return KNOX_OK;
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t cap = (std::max<size_t>(bytes, 4096) + 255) & ~(size_t)255;
+    if (hipMalloc(&b.p, cap) != hipSuccess) {
+        (void)hipGetLastError();
         b.p = nullptr;
         return KNOX_E_NOMEM;
     }
@@ -323,10 +312,14 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
 #endif
     env = getenv("KNOX_PLACEMENT");
     if (env) c->placement = atoi(env);
-    {
-        std::lock_guard<std::mutex> lk(g_mem_mu);
-        g_ctxs.push_back(c);
-    }
+    // arena budget: KNOX_ARENA_GIB, knox_ctx_set_arena, or three quarters of the device; physical memory is only taken
+    // as allocations need it, 2 GiB at a time
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+    size_t budget = total_b / 4 * 3;
+    env = getenv("KNOX_ARENA_GIB");
+    if (env && atof(env) > 0) budget = (size_t)(atof(env) * (double)((size_t)1 << 30));
+    c->arena.configure(device, budget, arena_probe, c);
     *out = c;
     return KNOX_OK;
 }
@@ -340,18 +333,13 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
-                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val, &ctx->comm_buf};
-    for (DevBuf *b : bufs)
-        if (b->p) hipFree(b->p);
-    if (ctx->probe_bits.p) hipFree(ctx->probe_bits.p);
-    if (ctx->ref_scratch) hipFree(ctx->ref_scratch);
-    {
-        std::lock_guard<std::mutex> lk(g_mem_mu);
-        release_held_locked(ctx);
-        g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end());
-    }
-    if (ctx->pev0) hipEventDestroy(ctx->pev0);
-    if (ctx->pev1) hipEventDestroy(ctx->pev1);
+                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val};
+    for (DevBuf *b : bufs) dev_free(ctx, b->p);
+    if (ctx->comm_buf.p) hipFree(ctx->comm_buf.p);
+    if (ctx->probe_partials) hipFree(ctx->probe_partials);
+    ctx->arena.destroy();  // columns / bitsets still alive after this point are dangling: free them before closing the context
+    for (hipEvent_t e : ctx->probe_ev)
+        if (e) hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
         if (ctx->stage[i]) hipHostFree(ctx->stage[i]);
         if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
@@ -431,27 +419,47 @@ KNOX_API int knox_host_free(knox_ctx *ctx, void *p) {
 
 KNOX_API int knox_ctx_set_placement(knox_ctx *ctx, int mode) {
     if (!ctx || mode < 0 || mode > 1) return KNOX_E_INVALID;
-    ctx->placement = mode;
-    if (mode == 0) {
-        hipSetDevice(ctx->device);
-        hipStreamSynchronize(ctx->stream);
-        release_held(ctx);
-    }
+    ctx->placement = mode;  // allocations made so far stay where they are and are freed where they came from
     return KNOX_OK;
 }
 
+KNOX_API int knox_ctx_set_arena(knox_ctx *ctx, size_t budget_bytes) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (budget_bytes < ctx->arena.mapped_total) return KNOX_E_RANGE;  // already above it: free, knox_ctx_arena_trim, then shrink
+    ctx->arena.budget = budget_bytes;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
+    if (!ctx || !out) return KNOX_E_INVALID;
+    memset(out, 0, sizeof *out);
+    out->budget_bytes = ctx->arena.budget;
+    out->mapped_bytes = ctx->arena.mapped_total;
+    out->used_bytes = ctx->arena.used_bytes();
+    out->peak_used_bytes = ctx->arena.peak_used;
+    out->write_buffers = ctx->arena.write_buffers;
+    out->spare_write_buffer_bytes = ctx->arena.spare_bytes();
+    out->chunks = ctx->arena.chunks_created;
+    out->probes = ctx->arena.probes_run;
+    out->transient_spacer_bytes = ctx->arena.spacer_bytes_used;
+    out->enabled = ctx->placement && ctx->arena.usable;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_ctx_arena_trim(knox_ctx *ctx, size_t *freed_bytes) {
+    if (!ctx) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t f = ctx->arena.trim();
+    if (freed_bytes) *freed_bytes = f;
+    return KNOX_OK;
+}
+
+// bytes this context keeps from the driver WITHOUT having them in the arena's accounting: none, by construction
 KNOX_API int knox_ctx_placement_info(knox_ctx *ctx, int64_t *held_bytes, int *held_regions) {
     if (!ctx) return KNOX_E_INVALID;
-    if (held_bytes) *held_bytes = (int64_t)(ctx->held_bytes + ctx->cache_bytes);  // unlike regions held + freed blocks kept for reuse
-    if (held_regions) *held_regions = (int)(ctx->held.size() + ctx->cache.size());
-    return KNOX_OK;
-}
-
-KNOX_API int knox_col_placement(const knox_col *col, double *probe_gbs, double *probe_ratio, int *candidates) {
-    if (!col) return KNOX_E_INVALID;
-    if (probe_gbs) *probe_gbs = col->probe_gbs;
-    if (probe_ratio) *probe_ratio = col->probe_ratio;
-    if (candidates) *candidates = col->probe_candidates;
+    if (held_bytes) *held_bytes = 0;
+    if (held_regions) *held_regions = 0;
     return KNOX_OK;
 }
 
@@ -578,32 +586,25 @@ static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
 // columns
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
-// Placement-aware column allocation.  Measured on MI355X (profiles/r01_placement_*):
-// for the read+write mix of the scan (8 B read, 1/8 B written per row) a physical region of HBM is
-// either "fast" (~6.9 TB/s) or "slow" (~6.0 TB/s); the class is a property of the region (uniform
-// over an 8 GiB allocation, stable for the life of the process), read-only passes do not see it.
-// Large column buffers are therefore probed with the real scan kernel right after hipMalloc; a
-// candidate that is clearly slower than the best class seen is HELD (freeing it would make the
-// driver hand the same region out again) and another one is tried.  Held regions go back to the
-// driver when an allocation would otherwise fail, and at knox_ctx_close.
+// The arena's probe (knox_arena.h): scan / read-only for ONE (column region, write buffer) pair -- `rows` int64 rows at `p`
+// scanned into `bits` (rows/8 bytes, the read+write mix) against the read-only form of the same scan, ALTERNATING
+// launches timed one by one (a device that is busy with something else, e.g. the driver clearing memory, slows both
+// alike).  Runs under its own kernel symbol (launch_probe_scan) so profiles keep probes and scans apart.
 // ------------------------------------------------------------------------------------------------
-static constexpr size_t kProbeMinBytes = (size_t)256 << 20;
-static constexpr uint64_t kProbeChunkRows = (uint64_t)1 << 28;  // probe granularity: 2 GiB of int64 against a 32 MiB bitset window
-static constexpr int kProbeCandidates = 6;
-static constexpr int kMaxCandidates = 40;
-static constexpr size_t kCacheCapBytes = (size_t)64 << 30;  // freed column blocks kept for reuse (given back under memory pressure)
-static constexpr double kMatchRatio = 0.90;  // mix / read-only: ~0.95 like classes, ~0.84 unlike
-static constexpr size_t kHeldCapBytes = (size_t)96 << 30;
-
-// Steady-state GB/s of the scan for ONE (column region, bitset buffer) pair: `rows` int64 rows at `p`
-// scanned into `bits` (rows/8 bytes, the read+write mix), or read-only when bits == nullptr.
 static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits) {
     const uint32_t iters = 2;
     const uint64_t tr = (uint64_t)tile_rows(8) * iters;
-    if (rows < tr || rows % tr) return 0.0;
+    if (rows < tr || rows % tr || !bits) return 0.0;
     const int grid = ctx->n_cus * 2;
-    if (ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(ctx->n_cus * 8 + 1) * 16)) return 0.0;
-    if (!ctx->pev0 && (hipEventCreate(&ctx->pev0) != hipSuccess || hipEventCreate(&ctx->pev1) != hipSuccess)) return 0.0;
+    if (!ctx->probe_partials && hipMalloc(&ctx->probe_partials, sizeof(AggPartial) * (size_t)(grid + 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->probe_partials = nullptr;
+        return 0.0;
+    }
+    constexpr int kLaunches = 20;  // alternating read-only / scan; the first 4 of each are the clock ramp
+    if (!ctx->probe_ev[0])
+        for (int i = 0; i <= kLaunches; i++)
+            if (hipEventCreate(&ctx->probe_ev[i]) != hipSuccess) return 0.0;
     ScanArgs a;
     memset(&a, 0, sizeof a);
     a.leaf[0].col = p;
@@ -617,175 +618,27 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
     a.n_rows = rows;
     a.tail_first_row = rows;
     a.pack_shift = 255;
-    a.bits = (uint32_t *)bits;
-    a.partials = (AggPartial *)ctx->partials.p;
-    // batches of 4 launches until two consecutive batches agree within 1 % (the clock ramps over the
-    // first launches after idle); at least 3 batches
-    double prev = 0.0, cur = 0.0;
-    for (int batch = 0; batch < 16; batch++) {
-        if (hipEventRecord(ctx->pev0, ctx->stream) != hipSuccess) return 0.0;
-        for (int i = 0; i < 4; i++)
-            if (launch_probe_scan(ctx->stream, (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid), a) != hipSuccess) return 0.0;
+    a.partials = (AggPartial *)ctx->probe_partials;
+    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
+    if (hipEventRecord(ctx->probe_ev[0], ctx->stream) != hipSuccess) return 0.0;
+    for (int i = 0; i < kLaunches; i++) {
+        a.bits = (i & 1) ? (uint32_t *)bits : nullptr;
+        if (launch_probe_scan(ctx->stream, g, a) != hipSuccess || hipEventRecord(ctx->probe_ev[i + 1], ctx->stream) != hipSuccess) return 0.0;
+    }
+    if (hipEventSynchronize(ctx->probe_ev[kLaunches]) != hipSuccess) return 0.0;
+    float ro[kLaunches / 2], mix[kLaunches / 2];
+    int n_ro = 0, n_mix = 0;
+    for (int i = 8; i < kLaunches; i++) {
         float ms = 0.f;
-        if (hipEventRecord(ctx->pev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->pev1) != hipSuccess ||
-            hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1) != hipSuccess || ms <= 0.f)
-            return 0.0;
-        const double r = (double)rows * (bits ? 8.125 : 8.0) * 4 / ((double)ms * 1e6);  // GB/s
-        const bool stable = batch >= 2 && fabs(r - cur) <= 0.01 * r;
-        prev = cur;
-        cur = r;
-        if (stable) break;
+        if (hipEventElapsedTime(&ms, ctx->probe_ev[i], ctx->probe_ev[i + 1]) != hipSuccess || ms <= 0.f) return 0.0;
+        if (i & 1) mix[n_mix++] = ms; else ro[n_ro++] = ms;
     }
-    return std::max(cur, prev);
+    std::sort(ro, ro + n_ro);
+    std::sort(mix, mix + n_mix);
+    // rates: the scan moves 8.125 B per row, the read-only form 8 B
+    return ((double)ro[n_ro / 2] / 8.0) / ((double)mix[n_mix / 2] / 8.125);
 }
-
-// A column buffer against the context's reference bitset window (fixed size, allocated once: it
-// DEFINES the class every placed buffer of this context matches).  The buffer is probed chunk by
-// chunk -- a large allocation can straddle both classes.  The class test is self-normalising:
-// mix rate / read-only rate of the SAME chunk is ~0.95 for like classes and ~0.84 for unlike ones
-// at every probe size, so one threshold (kMatchRatio) serves all sizes and needs no history.
-// Returns the worst chunk's mix rate, *ratio = the worst chunk's ratio (0 = probe unavailable).
-static double probe_rate(knox_ctx *ctx, void *p, size_t bytes, double *ratio) {
-    *ratio = 0.0;
-    const uint64_t tr = (uint64_t)tile_rows(8) * 2;
-    const uint64_t total = (bytes / 8) - (bytes / 8) % tr;
-    if (total == 0) return 0.0;
-    if (ensure(ctx, ctx->probe_bits, (kProbeChunkRows >> 3) + 256)) return 0.0;
-    const uint64_t first = std::min<uint64_t>(total, kProbeChunkRows);
-    double worst = 0.0, worst_ratio = 0.0;
-    for (uint64_t off = 0; off < total; off += kProbeChunkRows) {
-        uint64_t rows = std::min<uint64_t>(kProbeChunkRows, total - off);
-        if (rows < first) {  // ragged last chunk: re-probe the last `first` rows
-            off = total - first;
-            rows = first;
-        }
-        const char *q = (const char *)p + off * 8;
-        const double ro = probe_pair(ctx, q, rows, nullptr);
-        const double mix = probe_pair(ctx, q, rows, ctx->probe_bits.p);
-        if (ro <= 0.0 || mix <= 0.0) return 0.0;
-        if (worst_ratio == 0.0 || mix / ro < worst_ratio) {
-            worst_ratio = mix / ro;
-            worst = mix;
-        }
-        if (off + rows >= total) break;
-    }
-    *ratio = worst_ratio;
-    return worst;
-}
-
-static void retire(knox_ctx *ctx, void *p, size_t bytes) {
-    {
-        std::lock_guard<std::mutex> lk(g_mem_mu);
-        if (ctx->placement && bytes >= ((size_t)16 << 20) && ctx->cache_bytes + bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
-            ctx->cache.push_back({p, bytes, 0.0, -1.0});
-            ctx->cache_bytes += bytes;
-            return;
-        }
-    }
-    hipFree(p);
-}
-
-static hipError_t col_alloc_placed(knox_ctx *ctx, knox_col *c, size_t bytes) {
-    const char *fl = getenv("KNOX_COL_MALLOC_FLAGS");  // diagnostics: hipExtMallocWithFlags flag (e.g. 4 = contiguous)
-    if (fl && atoi(fl) > 0) return hipExtMallocWithFlags(&c->dev, bytes, (unsigned)atoi(fl));
-    c->alloc_bytes = bytes;
-    if (!ctx->placement || bytes < kProbeMinBytes) return dev_malloc(ctx, &c->dev, bytes);
-    {
-        std::lock_guard<std::mutex> lk(g_mem_mu);
-        for (size_t i = 0; i < ctx->cache.size(); i++) {
-            if (ctx->cache[i].bytes == bytes && ctx->cache[i].probe_ratio >= kMatchRatio) {  // a block this context freed earlier
-                c->dev = ctx->cache[i].p;
-                c->probe_gbs = ctx->cache[i].probe_gbs;
-                c->probe_ratio = ctx->cache[i].probe_ratio;
-                c->probe_candidates = 0;
-                ctx->cache_bytes -= bytes;
-                ctx->cache.erase(ctx->cache.begin() + (long)i);
-                if (!ctx->ref_col) { ctx->ref_col = c->dev; ctx->ref_rows = bytes / 8; }
-                return hipSuccess;
-            }
-        }
-    }
-    hipStreamSynchronize(ctx->stream);
-    struct Cand { void *p; double mix, ratio; };
-    std::vector<Cand> cands;
-    int accept = -1;
-    hipError_t err = hipSuccess;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    // regions of one class come in runs of tens of GiB: up to half of what is free may be alive at once
-    const size_t budget_bytes = std::max((size_t)kProbeCandidates * bytes, (size_t)(0.5 * (double)free_b));
-    size_t spent = 0;
-    while ((int)cands.size() < kMaxCandidates && spent + bytes <= std::max(budget_bytes, bytes)) {
-        void *p = nullptr;
-        // while other candidates are being held, an OOM only ends the search
-        err = cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes);
-        if (err != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-        spent += bytes;
-        double ratio = 0.0;
-        const double mix = probe_rate(ctx, p, bytes, &ratio);
-        cands.push_back({p, mix, ratio});
-        if (mix <= 0.0 || ratio >= kMatchRatio) {  // probe unavailable: take it as it is
-            accept = (int)cands.size() - 1;
-            break;
-        }
-    }
-    if (cands.empty()) return err != hipSuccess ? err : hipErrorOutOfMemory;
-    if (accept < 0) {  // nothing of the reference's class within the budget: the best there is
-        accept = 0;
-        for (size_t i = 1; i < cands.size(); i++)
-            if (cands[i].ratio > cands[accept].ratio) accept = (int)i;
-    }
-    const bool matched = cands[accept].ratio >= kMatchRatio;
-    for (size_t i = 0; i < cands.size(); i++) {
-        if ((int)i == accept) continue;
-        // unlike regions are kept away from the driver's free list while like ones can still be found
-        bool kept = false;
-        {
-            std::lock_guard<std::mutex> lk(g_mem_mu);
-            if (matched && ctx->held_bytes + bytes <= kHeldCapBytes) {
-                ctx->held.push_back({cands[i].p, bytes});
-                ctx->held_bytes += bytes;
-                kept = true;
-            }
-        }
-        if (!kept) hipFree(cands[i].p);
-    }
-    c->dev = cands[accept].p;
-    c->probe_gbs = cands[accept].mix;
-    c->probe_ratio = cands[accept].ratio;
-    c->probe_candidates = (int)cands.size();
-    if (!ctx->ref_col && matched) {  // a placed column future bitset / scratch allocations are matched against
-        ctx->ref_col = c->dev;
-        ctx->ref_rows = bytes / 8;
-    }
-    return hipSuccess;
-}
-
-// A placed column region of this context to match write buffers against: a live placed column, or a
-// 2 GiB stand-in allocated (and placed) on demand and kept until the context closes.
-static const void *get_ref_col(knox_ctx *ctx, uint64_t *rows) {
-    if (ctx->ref_col) {
-        *rows = ctx->ref_rows;
-        return ctx->ref_col;
-    }
-    if (!ctx->placement) return nullptr;
-    if (!ctx->ref_scratch) {
-        knox_col tmp;
-        memset((void *)&tmp, 0, sizeof tmp);
-        const void *keep_ref = ctx->ref_col;
-        if (col_alloc_placed(ctx, &tmp, (size_t)kProbeChunkRows * 8 + 512) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        ctx->ref_col = keep_ref;  // the stand-in is not a user column: knox_col_free never sees it
-        ctx->ref_scratch = tmp.dev;
-    }
-    *rows = kProbeChunkRows;
-    return ctx->ref_scratch;
-}
+static double arena_probe(void *user, const void *col, uint64_t rows, void *bits) { return probe_pair((knox_ctx *)user, col, rows, bits); }
 
 static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bool alloc, knox_col **out) {
     if (!ctx || !out) return KNOX_E_INVALID;
@@ -807,7 +660,7 @@ static int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bo
     if (alloc) {
         // pad to a whole 16-byte vector so the streaming kernels never read past the allocation
         size_t bytes = ((n_rows * (size_t)w + 255) & ~(size_t)255) + 256;
-        hipError_t e = col_alloc_placed(ctx, c, bytes);
+        hipError_t e = dev_malloc(ctx, &c->dev, bytes, ARENA_READ);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             delete c;
@@ -843,7 +696,7 @@ KNOX_API int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_
     int rc = col_new(ctx, KNOX_BYTES, n_rows, pack_rows, true, out);
     if (rc) return rc;
     knox_col *c = *out;
-    hipError_t e = dev_malloc(ctx, (void **)&c->buf, buf_len + 256);
+    hipError_t e = dev_malloc(ctx, (void **)&c->buf, buf_len + 256, ARENA_READ);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         knox_col_free(c);
@@ -874,7 +727,7 @@ static int bytes_col_alloc(knox_ctx *ctx, size_t pack_rows, size_t max_packs, si
     c->packs_cap = max_packs;
     c->buf_cap = max_pool_bytes + 64 * max_packs;  // every pool starts on a 64-byte boundary
     c->h_pool_base = (uint64_t *)calloc(max_packs + 1, 8);
-    if (!c->h_pool_base || dev_malloc(ctx, (void **)&c->buf, c->buf_cap + 256) != hipSuccess ||
+    if (!c->h_pool_base || dev_malloc(ctx, (void **)&c->buf, c->buf_cap + 256, ARENA_READ) != hipSuccess ||
         dev_malloc(ctx, (void **)&c->pool_base, (max_packs + 1) * 8) != hipSuccess ||
         hipMemsetAsync(c->pool_base, 0, (max_packs + 1) * 8, ctx->stream) != hipSuccess) {
         knox_col_free(c);
@@ -1133,7 +986,7 @@ static int runend_rows(knox_ctx *ctx, const uint8_t *b, size_t len, int w, bool 
     if (!rc && (hipMemcpyAsync(&last, (const uint32_t *)d_ends + (n2 - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = KNOX_E_HIP;
-    hipFree(d_ends);
+    dev_free(ctx, d_ends);
     *rows = (size_t)last + 1;
     return rc;
 }
@@ -1168,7 +1021,7 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
             e = launch_bitpack_decode(ctx->stream, w, (const uint64_t *)d_packed, sz / 8, (uint32_t)l2, minv, nn, dst);
             if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
         }
-        hipFree(d_packed);
+        dev_free(ctx, d_packed);
         return rc;
     }
     if (type == 6) {
@@ -1177,7 +1030,7 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
         const size_t n_words = (size_t)plen / 8;
         void *d_packed = nullptr, *d_scr = nullptr;
         if (dev_malloc(ctx, &d_packed, (size_t)plen + 64) != hipSuccess) return KNOX_E_NOMEM;
-        if (dev_malloc(ctx, &d_scr, (n_words + 2) * 4 + 64) != hipSuccess) { hipFree(d_packed); return KNOX_E_NOMEM; }
+        if (dev_malloc(ctx, &d_scr, (n_words + 2) * 4 + 64) != hipSuccess) { dev_free(ctx, d_packed); return KNOX_E_NOMEM; }
         int rc = ensure(ctx, ctx->misc, 256);
         if (!rc) rc = upload(ctx, d_packed, b + o, (size_t)plen);
         if (!rc) {
@@ -1189,8 +1042,8 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
                 rc = KNOX_E_HIP;
             else if (tot < nn) rc = KNOX_E_INVALID;  // the words hold fewer values than the header claims
         }
-        hipFree(d_packed);
-        hipFree(d_scr);
+        dev_free(ctx, d_packed);
+        dev_free(ctx, d_scr);
         if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }
@@ -1203,15 +1056,15 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
         knox_uvarint(b + o + cl + cr, len - o - cl - cr, &shift);
         void *d_l = nullptr, *d_r = nullptr;
         if (dev_malloc(ctx, &d_l, nl * 2 + 64) != hipSuccess) return KNOX_E_NOMEM;
-        if (dev_malloc(ctx, &d_r, nr * (size_t)w + 64) != hipSuccess) { hipFree(d_l); return KNOX_E_NOMEM; }
+        if (dev_malloc(ctx, &d_r, nr * (size_t)w + 64) != hipSuccess) { dev_free(ctx, d_l); return KNOX_E_NOMEM; }
         rc = container_decode(ctx, b + o, len - o, 2, false, d_l, nl, depth + 1);
         if (!rc) rc = container_decode(ctx, b + o + cl, len - o - cl, w, false, d_r, nr, depth + 1);
         if (!rc) {
             e = launch_alprd_merge(ctx->stream, w, (const uint16_t *)d_l, d_r, (uint32_t)shift, nl, dst);
             if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
         }
-        hipFree(d_l);
-        hipFree(d_r);
+        dev_free(ctx, d_l);
+        dev_free(ctx, d_r);
         if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }
@@ -1256,9 +1109,9 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
             }
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = KNOX_E_HIP;
-        if (d_enc) hipFree(d_enc);
-        if (d_pat) hipFree(d_pat);
-        if (d_pos) hipFree(d_pos);
+        if (d_enc) dev_free(ctx, d_enc);
+        if (d_pat) dev_free(ctx, d_pat);
+        if (d_pos) dev_free(ctx, d_pos);
         if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }
@@ -1282,7 +1135,7 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
         if (rc) return rc;
         void *d1 = nullptr, *d2 = nullptr;
         if (dev_malloc(ctx, &d1, n1 * (size_t)w + 64) != hipSuccess) return KNOX_E_NOMEM;
-        if (dev_malloc(ctx, &d2, n2 * (dict ? 2 : 4) + 64) != hipSuccess) { hipFree(d1); return KNOX_E_NOMEM; }
+        if (dev_malloc(ctx, &d2, n2 * (dict ? 2 : 4) + 64) != hipSuccess) { dev_free(ctx, d1); return KNOX_E_NOMEM; }
         rc = container_decode(ctx, b + o, len - o, w, isf, d1, n1, depth + 1);
         if (!rc) rc = container_decode(ctx, b + o + c1, len - o - c1, dict ? 2 : 4, false, d2, n2, depth + 1);
         if (!rc) {
@@ -1290,8 +1143,8 @@ static int container_decode(knox_ctx *ctx, const uint8_t *b, size_t len, int w, 
                      : launch_runend_expand(ctx->stream, w, d1, (const uint32_t *)d2, n2, n, dst);
             if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
         }
-        hipFree(d1);
-        hipFree(d2);
+        dev_free(ctx, d1);
+        dev_free(ctx, d2);
         if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
         return rc;
     }
@@ -1465,7 +1318,7 @@ KNOX_API int knox_col_upload_string_containers(knox_ctx *ctx, const uint8_t *con
         *out = nullptr;
         return code;
     };
-    if (dev_malloc(ctx, (void **)&c->buf, total_pool + 256) != hipSuccess) return fail(KNOX_E_NOMEM);
+    if (dev_malloc(ctx, (void **)&c->buf, total_pool + 256, ARENA_READ) != hipSuccess) return fail(KNOX_E_NOMEM);
     c->buf_len = total_pool;
     if (per_pack) {
         c->h_pool_base = (uint64_t *)malloc((n_bufs + 1) * 8);
@@ -1507,9 +1360,9 @@ KNOX_API int knox_col_upload_string_containers(knox_ctx *ctx, const uint8_t *con
                                    rel, dst);
                 if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KNOX_E_HIP;
             }
-            if (d_ofs) hipFree(d_ofs);
-            if (d_len) hipFree(d_len);
-            if (d_code) hipFree(d_code);
+            if (d_ofs) dev_free(ctx, d_ofs);
+            if (d_len) dev_free(ctx, d_len);
+            if (d_code) dev_free(ctx, d_code);
             if (rc) {
                 if (rc == KNOX_E_HIP) ctx->last_hip = (int)e;
                 return fail(rc);
@@ -1567,23 +1420,9 @@ KNOX_API int knox_col_free(knox_col *col) {
     if (!col) return KNOX_E_INVALID;
     hipSetDevice(col->ctx->device);
     hipStreamSynchronize(col->ctx->stream);
-    if (col->owned && col->dev) {
-        knox_ctx *ctx = col->ctx;
-        if (ctx->ref_col == col->dev) ctx->ref_col = nullptr;
-        bool kept = false;
-        {
-            std::lock_guard<std::mutex> lk(g_mem_mu);
-            if (ctx->placement && col->alloc_bytes >= kProbeMinBytes && col->probe_ratio >= kMatchRatio &&
-                ctx->cache_bytes + col->alloc_bytes <= kCacheCapBytes && ctx->cache.size() < 64) {
-                ctx->cache.push_back({col->dev, col->alloc_bytes, col->probe_gbs, col->probe_ratio});
-                ctx->cache_bytes += col->alloc_bytes;
-                kept = true;
-            }
-        }
-        if (!kept) hipFree(col->dev);
-    }
-    if (col->buf) hipFree(col->buf);
-    if (col->pool_base) hipFree(col->pool_base);
+    if (col->owned) dev_free(col->ctx, col->dev);
+    dev_free(col->ctx, col->buf);
+    dev_free(col->ctx, col->pool_base);
     free(col->h_pool_base);
     delete col;
     return KNOX_OK;
@@ -1596,174 +1435,36 @@ KNOX_API void *knox_col_device_ptr(const knox_col *col) { return col ? col->dev 
 // ------------------------------------------------------------------------------------------------
 // device bitsets
 // ------------------------------------------------------------------------------------------------
-// A write buffer (bitset, scratch) of the class that is fast with column region `col` (`rows` int64 rows,
-// rows/8 <= bytes): candidates are probed as a pair with the scan kernel; mismatches are only held while
-// the search runs (they are small).  Falls back to a plain allocation when nothing can be probed.
-// `width`: bytes per value of the real column; the probe reads the column's memory as int64 rows (`col_rows` of them)
-// whatever the type, the part of the write buffer that belongs to a chunk is where the real scan puts its bits.
-static hipError_t write_buf_alloc_matched(knox_ctx *ctx, void **out, size_t bytes, const void *col, uint64_t col_rows, double *rate, int *tried,
-                                          int width = 8) {
-    if (rate) *rate = 0.0;
-    if (tried) *tried = 0;
-    const uint64_t tr = (uint64_t)tile_rows(8) * 2;
-    uint64_t rows = std::min<uint64_t>(std::min<uint64_t>(col_rows, kProbeChunkRows), (uint64_t)bytes * (uint64_t)width);  // the probe writes rows/8 bytes
-    rows -= rows % tr;
-    if (!ctx->placement || !col || rows < ((uint64_t)1 << 24)) return dev_malloc(ctx, out, bytes);
-    hipStreamSynchronize(ctx->stream);
-    // every (column chunk, the part of the write buffer that chunk's bits go to) pair the scan will
-    // really use is probed: either buffer may straddle a class boundary
-    const uint64_t span = std::min<uint64_t>(col_rows - col_rows % tr, (uint64_t)bytes * (uint64_t)width - ((uint64_t)bytes * (uint64_t)width) % tr);
-    std::vector<uint64_t> chunk_off;
-    std::vector<double> chunk_ro;
-    for (uint64_t off = 0; off + rows <= span; off += kProbeChunkRows) {
-        const double ro_c = probe_pair(ctx, (const char *)col + off * 8, rows, nullptr);
-        if (ro_c <= 0.0) return dev_malloc(ctx, out, bytes);
-        chunk_off.push_back(off);
-        chunk_ro.push_back(ro_c);
-        if (rows < kProbeChunkRows) break;
-    }
-    if (chunk_off.empty()) return dev_malloc(ctx, out, bytes);
-    const double ro = chunk_ro[0];
-    auto probe_all = [&](void *p) {  // mix rate of the worst pair, scaled to chunk 0's read-only rate
-        double worst = 0.0;
-        for (size_t i = 0; i < chunk_off.size(); i++) {
-            // byte B of the column <-> bits byte B / (8 * width); one probe writes rows/8 bytes, the real scan of this
-            // chunk writes 8/width times as many: every such part is probed
-            bool miss = false;
-            for (int part = 0; part < 8 / width && !miss; part++) {
-                const double r = probe_pair(ctx, (const char *)col + chunk_off[i] * 8, rows, (char *)p + chunk_off[i] / (uint64_t)width + (uint64_t)part * (rows >> 3));
-                if (r <= 0.0) return 0.0;
-                const double scaled = r / chunk_ro[i] * ro;
-                if (worst == 0.0 || scaled < worst) worst = scaled;
-                miss = r / chunk_ro[i] < kMatchRatio;
-            }
-            if (miss) break;  // already a miss
-        }
-        return worst;
-    };
-    std::vector<std::pair<void *, double>> cands;
-    std::vector<std::pair<void *, size_t>> spacers;
-    size_t spacer_bytes = 0;
-    int accept = -1;
-    const char *fm = getenv("KNOX_PLACEMENT_FORCE_MISS");  // tests: treat the first N candidates as misses
-    const int force_miss = fm ? atoi(fm) : 0;
-    // Regions of one class come in runs of tens of GiB in the driver's allocation order, and a small
-    // buffer moves through that order slowly: after every second miss a 4 GiB spacer is parked (and
-    // given back at the end) so that the search reaches the next run.
-    // write buffers this context freed earlier (kept, not returned to the driver): one of the right size that is
-    // fast with this column is taken before anything new is allocated
-    if (force_miss == 0) {
-        std::vector<void *> mine;   // taken out under the lock, probed outside it, put back if they do not fit
-        {
-            std::lock_guard<std::mutex> lk(g_mem_mu);
-            for (size_t i = 0; i < ctx->cache.size();) {
-                if (ctx->cache[i].bytes == bytes && ctx->cache[i].probe_ratio == -1.0) {  // -1: a write buffer, not a column block
-                    mine.push_back(ctx->cache[i].p);
-                    ctx->cache_bytes -= bytes;
-                    ctx->cache.erase(ctx->cache.begin() + (long)i);
-                } else
-                    i++;
-            }
-        }
-        void *hit = nullptr;
-        double hit_rate = 0.0;
-        for (void *q : mine) {
-            if (!hit) {
-                const double r = probe_all(q);
-                if (r > 0.0 && r / ro >= kMatchRatio) { hit = q; hit_rate = r; continue; }
-            }
-            std::lock_guard<std::mutex> lk(g_mem_mu);
-            ctx->cache.push_back({q, bytes, 0.0, -1.0});
-            ctx->cache_bytes += bytes;
-        }
-        if (hit) {
-            *out = hit;
-            if (rate) *rate = hit_rate;
-            if (tried) *tried = 1;
-            return hipSuccess;
-        }
-    }
-    for (int k = 0; k < 40; k++) {
-        void *p = nullptr;
-        if ((cands.empty() ? dev_malloc(ctx, &p, bytes) : hipMalloc(&p, bytes)) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-        const double r = probe_all(p);
-        cands.push_back({p, r});
-        if ((r <= 0.0 || r / ro >= kMatchRatio) && k >= force_miss) {
-            accept = (int)cands.size() - 1;
-            break;
-        }
-        if ((k & 1) == 1 && spacers.size() < 32) {
-            // 4, 4, 8, 8, 16, 16, 32 ... GiB: runs of one class are tens of GiB long, equal steps of 4 GiB did not
-            // always get out of one within 40 candidates; never more than 60 % of what is free
-            size_t want = (size_t)4 << (30 + std::min<size_t>(spacers.size() / 2, 3));
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-            while (want > ((size_t)4 << 30) && spacer_bytes + want > (size_t)(0.6 * (double)(free_b + spacer_bytes))) want >>= 1;
-            void *sp = nullptr;
-            if (spacer_bytes + want <= (size_t)(0.6 * (double)(free_b + spacer_bytes)) && hipMalloc(&sp, want) == hipSuccess) {
-                spacers.push_back({sp, want});
-                spacer_bytes += want;
-            } else
-                (void)hipGetLastError();
-        }
-    }
-    // nothing goes back to the driver while the context works (returning a large buffer slows its live neighbours):
-    // spacers and rejected candidates join the held regions, which are released under memory pressure, when
-    // placement is switched off and at close
-    auto park = [&](void *q, size_t n) {
-        {
-            std::lock_guard<std::mutex> lk(g_mem_mu);
-            if (ctx->held_bytes + n <= kHeldCapBytes) {
-                ctx->held.push_back({q, n});
-                ctx->held_bytes += n;
-                return;
-            }
-        }
-        hipFree(q);
-    };
-    for (auto &sp : spacers) park(sp.first, sp.second);
-    if (cands.empty()) return hipErrorOutOfMemory;
-    if (accept < 0) {
-        accept = 0;
-        for (size_t i = 1; i < cands.size(); i++)
-            if (cands[i].second > cands[accept].second) accept = (int)i;
-    }
-    for (size_t i = 0; i < cands.size(); i++)
-        if ((int)i != accept) park(cands[i].first, bytes);
-    *out = cands[accept].first;
-    if (rate) *rate = cands[accept].second;
-    if (tried) *tried = (int)cands.size();
-    return hipSuccess;
+// the stream a write buffer is verified against: the column's values (bytes columns: the pool, the larger stream)
+static void col_stream(const knox_col *col, const void **p, size_t *bytes) {
+    const bool pool = col->dtype == KNOX_BYTES && col->buf_len >= col->n_rows * 8;
+    *p = pool ? (const void *)col->buf : (const void *)col->dev;
+    *bytes = pool ? col->buf_len : col->n_rows * (size_t)col->width;
 }
 
-// grow-only scratch that the scan WRITES next to its bitset: same placement class as the column it is
-// written for (at least one probe window large so that the class can be measured)
-static int ensure_matched(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col) {
-    if (b.cap >= bytes) return KNOX_OK;
-    if (!ctx->placement || !col || col->n_rows < ((uint64_t)1 << 24)) return ensure(ctx, b, bytes);
-    const void *rc = col->dev;
-    uint64_t rr = col->n_rows * (uint64_t)col->width / 8;  // the column's memory as int64 rows
-    int pw = col->width;
-    if (col->dtype == KNOX_BYTES) { rc = get_ref_col(ctx, &rr); pw = 8; }
-    if (!rc) return ensure(ctx, b, bytes);
+static int ensure_for(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col) {
+    const void *cp = nullptr;
+    size_t cb = 0;
+    if (col && col->n_rows) col_stream(col, &cp, &cb);
+    if (!ctx->placement || !cp || cb < ((size_t)1 << 30) || bytes < ((size_t)16 << 20)) return ensure(ctx, b, bytes, ARENA_WRITE);
+    if (b.cap >= bytes && b.for_col == cp) return KNOX_OK;
     if (b.p) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        retire(ctx, b.p, b.cap);
+        dev_free(ctx, b.p);
         b.p = nullptr;
         b.cap = 0;
     }
-    size_t cap = std::max<size_t>(bytes, (size_t)(kProbeChunkRows >> 3) + 256);
-    cap = (cap + 255) & ~(size_t)255;
-    hipError_t e = write_buf_alloc_matched(ctx, &b.p, cap, rc, rr, nullptr, nullptr, pw);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t cap = (std::max(bytes, b.cap) + 255) & ~(size_t)255;
+    hipError_t e = ctx->arena.alloc_write_for(&b.p, cap, cp, cb, (double)cb / (double)col->n_rows, nullptr, nullptr);
+    if (e == hipErrorNotSupported) return ensure(ctx, b, bytes, ARENA_WRITE);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         b.p = nullptr;
         return KNOX_E_NOMEM;
     }
     b.cap = cap;
+    b.for_col = cp;
     return KNOX_OK;
 }
 
@@ -1776,18 +1477,16 @@ static int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, 
     b->ctx = ctx;
     b->size = size_bits;
     b->cap_bytes = bits_padded(size_bits) + 64;
-    hipError_t e;
-    if (for_col && for_col->dtype != KNOX_BYTES)  // any numeric column: the probe pairs memory regions, not types
-        e = write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, for_col->dev, for_col->n_rows * (uint64_t)for_col->width / 8, &b->probe_gbs,
-                                    &b->probe_candidates, for_col->width);
-    else if (ctx->placement && (for_col || size_bits >= ((size_t)1 << 27))) {
-        // any other large bitset: the class of this context's placed columns (they all share one)
-        uint64_t rr = 0;
-        const void *rc = get_ref_col(ctx, &rr);
-        e = rc ? write_buf_alloc_matched(ctx, (void **)&b->dev, b->cap_bytes, rc, rr, &b->probe_gbs, &b->probe_candidates)
-               : dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
-    } else
-        e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes);
+    hipError_t e = hipErrorNotSupported;
+    if (for_col && ctx->placement && for_col->n_rows) {
+        // a write buffer of its own, verified against the column itself (knox_arena.h)
+        (void)hipStreamSynchronize(ctx->stream);
+        const void *cp;
+        size_t cb;
+        col_stream(for_col, &cp, &cb);
+        e = ctx->arena.alloc_write_for((void **)&b->dev, b->cap_bytes, cp, cb, (double)cb / (double)for_col->n_rows, &b->pair_ratio, &b->pair_tried);
+    }
+    if (e == hipErrorNotSupported) e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes, ARENA_WRITE);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         delete b;
@@ -1796,7 +1495,7 @@ static int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, 
     e = hipMemsetAsync(b->dev, 0, b->cap_bytes, ctx->stream);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
-        hipFree(b->dev);
+        dev_free(ctx, b->dev);
         delete b;
         return KNOX_E_HIP;
     }
@@ -1811,10 +1510,10 @@ KNOX_API int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col
     return bits_alloc(ctx, size_bits, col, out);
 }
 
-KNOX_API int knox_bits_placement(const knox_bits *b, double *probe_gbs, int *candidates) {
+KNOX_API int knox_bits_pair_check(const knox_bits *b, double *scan_over_read_only, int *candidates) {
     if (!b) return KNOX_E_INVALID;
-    if (probe_gbs) *probe_gbs = b->probe_gbs;
-    if (candidates) *candidates = b->probe_candidates;
+    if (scan_over_read_only) *scan_over_read_only = b->pair_ratio;
+    if (candidates) *candidates = b->pair_tried;
     return KNOX_OK;
 }
 
@@ -1836,9 +1535,7 @@ KNOX_API int knox_bits_free(knox_bits *b) {
     if (!b) return KNOX_E_INVALID;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    if (b->dev && b->owned) {
-        retire(b->ctx, b->dev, b->cap_bytes);  // kept for the next bitset of this size (re-probed against its column)
-    }
+    if (b->dev && b->owned) dev_free(b->ctx, b->dev);
     delete b;
     return KNOX_OK;
 }
@@ -2378,7 +2075,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     if (per_pack_tiles && bits && !diag_no_counts && pack_rows && tile_counts_on && a.live_packs == nullptr && g > 0) {
         const uint64_t rounds = ((a.n_tiles + (uint64_t)g - 1) / (uint64_t)g + 31) & ~(uint64_t)31;
         if (a.tail_first_row == n_rows && n_rows % pack_rows == 0 && pack_rows % tr == 0 && pack_rows / tr <= 0xffffffffull &&
-            rounds <= 0xffffffffull && ensure_matched(ctx, ctx->tile_counts, (size_t)g * kWavesPerBlock * rounds * 4 + 256, lcols[0]) == KNOX_OK) {
+            rounds <= 0xffffffffull && ensure(ctx, ctx->tile_counts, (size_t)g * kWavesPerBlock * rounds * 4 + 256, ARENA_WRITE) == KNOX_OK) {
             a.tile_counts = (uint32_t *)ctx->tile_counts.p;
             a.tc_rounds = (uint32_t)rounds;
             *per_pack_tiles = (uint32_t)(pack_rows / tr);
@@ -2738,7 +2435,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                            (n_agg_cols == 1 && fused && cols[agg_cols[0]]->width != width);
     uint64_t *bits = bits_out ? bits_out->dev : nullptr;
     if (need_bits && !bits) {
-        rc = ensure_matched(ctx, ctx->tmp_bits, (bits_padded(n_rows) + 64) * 8, cols[0]);  // result + up to 7 stack temporaries
+        rc = ensure_for(ctx, ctx->tmp_bits, (bits_padded(n_rows) + 64) * 8, cols[0]);  // result + up to 7 stack temporaries, written while the columns stream
         if (rc) return rc;
         bits = (uint64_t *)ctx->tmp_bits.p;
         HIPCHK(ctx, hipMemsetAsync(bits, 0, bits_padded(n_rows) + 64, ctx->stream));
@@ -2794,7 +2491,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         if (bits_out == nullptr && bits == nullptr) return KNOX_E_INVALID;
         bool all_leaves_skipped = pack_skip != nullptr;
         const size_t stride = (bits_padded(n_rows) + 64) / 8;  // uint64 words per scratch bitset
-        rc = ensure_matched(ctx, ctx->tmp_bits, stride * 8 * 8, cols[0]);
+        rc = ensure_for(ctx, ctx->tmp_bits, stride * 8 * 8, cols[0]);
         if (rc) return rc;
         if (!bits_out) bits = (uint64_t *)ctx->tmp_bits.p;
         uint64_t *pool = (uint64_t *)ctx->tmp_bits.p;
@@ -2975,7 +2672,7 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
     p->words_bytes = words * 8;
     // + 64 bytes: the kernel reads one word past a field's word unconditionally
     if (dev_malloc(ctx, (void **)&p->d_words, words * 8 + 64) != hipSuccess || dev_malloc(ctx, (void **)&p->d_packs, n_bufs * sizeof(PackedPack) + 64) != hipSuccess) {
-        if (p->d_words) hipFree(p->d_words);
+        if (p->d_words) dev_free(p->ctx, p->d_words);
         delete p;
         return KNOX_E_NOMEM;
     }
@@ -2984,8 +2681,8 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
     for (size_t i = 0; i < n_bufs && !rc; i++) rc = upload(ctx, p->d_words + packs[i].word_off, payload[i], payload_len[i]);
     if (!rc) rc = upload(ctx, p->d_packs, packs.data(), n_bufs * sizeof(PackedPack));
     if (rc) {
-        hipFree(p->d_words);
-        hipFree(p->d_packs);
+        dev_free(p->ctx, p->d_words);
+        dev_free(p->ctx, p->d_packs);
         delete p;
         return rc;
     }
@@ -2997,8 +2694,8 @@ KNOX_API int knox_packed_free(knox_packed *p) {
     if (!p) return KNOX_E_INVALID;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    if (p->d_words) hipFree(p->d_words);
-    if (p->d_packs) hipFree(p->d_packs);
+    if (p->d_words) dev_free(p->ctx, p->d_words);
+    if (p->d_packs) dev_free(p->ctx, p->d_packs);
     delete p;
     return KNOX_OK;
 }
@@ -3740,10 +3437,10 @@ static int bloom_alloc(knox_ctx *ctx, const uint64_t *offsets, size_t n_packs, k
     b->n_packs = n_packs;
     b->bytes = (size_t)offsets[n_packs];
     b->h_offsets.assign(offsets, offsets + n_packs + 1);
-    if (hipMalloc((void **)&b->d_filters, b->bytes + 64) != hipSuccess || hipMalloc((void **)&b->d_offsets, (n_packs + 1) * 8 + 64) != hipSuccess ||
-        hipMalloc((void **)&b->d_maybe, n_packs + 64) != hipSuccess) {
-        if (b->d_filters) hipFree(b->d_filters);
-        if (b->d_offsets) hipFree(b->d_offsets);
+    if (dev_malloc(ctx, (void **)&b->d_filters, b->bytes + 64) != hipSuccess || dev_malloc(ctx, (void **)&b->d_offsets, (n_packs + 1) * 8 + 64) != hipSuccess ||
+        dev_malloc(ctx, (void **)&b->d_maybe, n_packs + 64) != hipSuccess) {
+        if (b->d_filters) dev_free(b->ctx, b->d_filters);
+        if (b->d_offsets) dev_free(b->ctx, b->d_offsets);
         delete b;
         return KNOX_E_NOMEM;
     }
@@ -3834,9 +3531,9 @@ KNOX_API int knox_bloom_free(knox_bloom *b) {
     if (!b) return KNOX_E_INVALID;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    if (b->d_filters) hipFree(b->d_filters);
-    if (b->d_offsets) hipFree(b->d_offsets);
-    if (b->d_maybe) hipFree(b->d_maybe);
+    if (b->d_filters) dev_free(b->ctx, b->d_filters);
+    if (b->d_offsets) dev_free(b->ctx, b->d_offsets);
+    if (b->d_maybe) dev_free(b->ctx, b->d_maybe);
     delete b;
     return KNOX_OK;
 }
@@ -3904,7 +3601,7 @@ KNOX_API int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *min
     // payload per rank: n_states states + one int64 count
     const size_t per = sizeof(knox_agg_state) * (size_t)n_states + 8;
     const size_t total = per * (size_t)ctx->n_ranks;
-    int rc = ensure(ctx, ctx->comm_buf, per + total + 64);
+    int rc = ensure_plain(ctx, ctx->comm_buf, per + total + 64);
     if (rc) return rc;
     std::vector<uint8_t> h(per + total);
     if (n_states) memcpy(h.data(), mine, sizeof(knox_agg_state) * (size_t)n_states);
@@ -3912,7 +3609,7 @@ KNOX_API int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *min
     memcpy(h.data() + per - 8, &c, 8);
     uint8_t *d_send = (uint8_t *)ctx->comm_buf.p;
     uint8_t *d_recv = d_send + ((per + 63) & ~(size_t)63);
-    rc = ensure(ctx, ctx->comm_buf, ((per + 63) & ~(size_t)63) + total + 64);
+    rc = ensure_plain(ctx, ctx->comm_buf, ((per + 63) & ~(size_t)63) + total + 64);
     if (rc) return rc;
     d_send = (uint8_t *)ctx->comm_buf.p;
     d_recv = d_send + ((per + 63) & ~(size_t)63);
@@ -3947,7 +3644,7 @@ KNOX_API int knox_comm_allreduce_sum_count(knox_ctx *ctx, uint64_t *isum_inout, 
     if (!ctx || !isum_inout || !count_inout) return KNOX_E_INVALID;
     if (!ctx->comm) return KNOX_E_COMM;
     hipSetDevice(ctx->device);
-    int rc = ensure(ctx, ctx->comm_buf, 64);
+    int rc = ensure_plain(ctx, ctx->comm_buf, 64);
     if (rc) return rc;
     int64_t h[3] = {(int64_t)(*isum_inout & 0xffffffffull), (int64_t)(*isum_inout >> 32), *count_inout};
     int64_t *d = (int64_t *)ctx->comm_buf.p;

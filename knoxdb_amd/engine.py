@@ -83,13 +83,6 @@ class Column:
     def device_ptr(self):
         return _lib.lib().knox_col_device_ptr(self.h)
 
-    @property
-    def placement(self):
-        """(probe GB/s of the scan's read+write mix, candidates tried, mix / read-only ratio); zeros = not probed"""
-        g, r, k = C.c_double(), C.c_double(), C.c_int()
-        check(_lib.lib().knox_col_placement(self.h, C.byref(g), C.byref(r), C.byref(k)))
-        return g.value, k.value, r.value
-
     def download(self, first=0, n=None):
         n = self.rows - first if n is None else n
         out = np.empty(n, dtype=NP_DTYPE[self.dtype])
@@ -117,10 +110,11 @@ class Bits:
         self.h = h
 
     @property
-    def placement(self):
-        g, k = C.c_double(), C.c_int()
-        check(_lib.lib().knox_bits_placement(self.h, C.byref(g), C.byref(k)))
-        return g.value, k.value
+    def pair_check(self):
+        """(scan / read-only of the verified (column, bitset) pair, candidate windows looked at); (0.0, 0) = not verified"""
+        r, k = C.c_double(), C.c_int()
+        check(_lib.lib().knox_bits_pair_check(self.h, C.byref(r), C.byref(k)))
+        return r.value, k.value
 
     @property
     def device_ptr(self):
@@ -302,8 +296,24 @@ class Context:
         check(self.L.knox_host_free(self.h, p), "knox_host_free")
 
     def set_placement(self, on=True):
-        """placement-aware column allocation (include/knoxgpu.h: knox_ctx_set_placement)"""
+        """device memory from the context's arena (on) or plain hipMalloc (off): include/knoxgpu.h knox_ctx_set_placement"""
         check(self.L.knox_ctx_set_placement(self.h, 1 if on else 0))
+
+    def set_arena(self, budget_bytes):
+        check(self.L.knox_ctx_set_arena(self.h, budget_bytes), "knox_ctx_set_arena")
+
+    def arena_info(self):
+        a = _lib.ArenaInfo()
+        check(self.L.knox_ctx_arena_info(self.h, C.byref(a)))
+        return {"budget_gib": a.budget_bytes / 2**30, "mapped_gib": a.mapped_bytes / 2**30, "used_gib": a.used_bytes / 2**30,
+                "peak_used_gib": a.peak_used_bytes / 2**30, "write_buffers": a.write_buffers, "chunks": a.chunks, "probes": a.probes,
+                "enabled": bool(a.enabled), "transient_spacer_gib": a.transient_spacer_bytes / 2**30,
+                "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30}
+
+    def arena_trim(self):
+        f = C.c_size_t()
+        check(self.L.knox_ctx_arena_trim(self.h, C.byref(f)))
+        return f.value
 
     def placement_info(self):
         b, r = C.c_int64(), C.c_int()

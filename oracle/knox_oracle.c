@@ -23,6 +23,7 @@
  * Go -> C precedence traps are parenthesised explicitly.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1248,6 +1249,35 @@ KO_EXPORT int ko_generate(int dtype, int kind, uint64_t seed, int64_t first_row,
         }
     }
     return 0;
+}
+
+/* the same generator over `threads` host threads (counter based: every slice is independent) -- bench.py's full-run
+ * checksum regenerates all 2^30 rows on the host */
+typedef struct { int dtype, kind; uint64_t seed; int64_t first_row, n, lo; uint64_t span; void *dst; int rc; } ko_genjob;
+static void *ko_gen_worker(void *arg) {
+    ko_genjob *j = (ko_genjob *)arg;
+    j->rc = ko_generate(j->dtype, j->kind, j->seed, j->first_row, j->n, j->lo, j->span, j->dst);
+    return NULL;
+}
+KO_EXPORT int ko_generate_mt(int dtype, int kind, uint64_t seed, int64_t first_row, int64_t n, int64_t lo, uint64_t span, void *dst,
+                             int threads) {
+    static const int width[11] = {0, 8, 4, 2, 1, 8, 4, 2, 1, 8, 4};
+    if (dtype < 1 || dtype > 10) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t tid[256];
+    ko_genjob jobs[256];
+    for (int t = 0; t < threads; t++) {
+        const int64_t r0 = n * t / threads, r1 = n * (t + 1) / threads;
+        jobs[t] = (ko_genjob){dtype, kind, seed, first_row + r0, r1 - r0, lo, span, (char *)dst + r0 * width[dtype], 0};
+        pthread_create(&tid[t], NULL, ko_gen_worker, &jobs[t]);
+    }
+    int rc = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(tid[t], NULL);
+        if (jobs[t].rc) rc = jobs[t].rc;
+    }
+    return rc;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -340,6 +340,19 @@ def generate(dtype, kind, seed, first_row, n, lo=0, span=0):
     return out
 
 
+def generate_mt(dtype, kind, seed, first_row, n, lo=0, span=0, threads=None, out=None):
+    """generate() over several host threads (same values)"""
+    import os
+    threads = threads or len(os.sched_getaffinity(0))
+    out = np.empty(n, dtype=NP[dtype]) if out is None else out
+    L = lib()
+    L.ko_generate_mt.restype = C.c_int
+    L.ko_generate_mt.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int]
+    rc = L.ko_generate_mt(dtype, kind, seed, first_row, n, lo, span, _p(out), threads)
+    assert rc == 0
+    return out
+
+
 def scan_i64_bw_sum(src, pack_rows, a, b):
     src = np.ascontiguousarray(src, dtype=np.int64)
     n = src.size

@@ -213,34 +213,75 @@ def test_two_threads_two_contexts_scan_concurrently():
 
 
 @pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
-def test_placement_aware_allocation_is_transparent():
-    """Large owned columns are probed at allocation (knox_ctx_set_placement): results are the same
-    with it on or off, slow candidates are held and come back when it is switched off / at close."""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    free0, tot = C.c_size_t(), C.c_size_t()
-    n = (1 << 25) + 4096 * 3 + 17  # > 256 MiB of int64 -> probed
+def test_arena_allocation_is_transparent_and_bounded():
+    """All device memory of a context comes out of one arena (include/knoxgpu.h): results are the same with
+    it on or off; with it on nothing is held outside the arena, the mapped bytes never exceed the budget, the bitset
+    allocated FOR a column was verified against it, and a budget that is too small fails with NOMEM."""
+    n = (1 << 27) + 4096 * 3 + 17  # > 1 GiB of int64: assembled from probed chunks
     x = (np.arange(n, dtype=np.int64) * 2654435761) % 1000003
     want = int(((x >= 1000) & (x <= 500000)).sum())
     for on in (True, False):
         with K.Context(0) as c:
             c.set_placement(on)
-            hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
+            if on:
+                c.set_arena(16 << 30)
             col = c.upload(x, 1 << 20)
-            gbs, tried, ratio = col.placement
-            assert (gbs > 1000.0 and 1 <= tried <= 40 and 0.5 < ratio < 1.1) if on else (gbs == 0.0 and tried == 0)
-            bits = c.bits(n, for_col=col)  # knox_bits_alloc_for: the class that is fast with this column
-            bg, btried = bits.placement
-            assert (bg > 1000.0 and 1 <= btried <= 12) if on else (bg == 0.0 and btried == 0)
+            bits = c.bits(n, for_col=col)  # knox_bits_alloc_for: a class the column does not lie in
+            info = c.arena_info()
+            if on and info["enabled"]:
+                assert info["mapped_gib"] <= 16 and info["used_gib"] * 2**30 >= n * 8
+                ratio, tried = bits.pair_check          # the (column, bitset) pair was measured when the bitset was chosen
+                assert tried >= 1 and 0.7 < ratio < 1.1
+            else:
+                assert bits.pair_check == (0.0, 0) and info["mapped_gib"] == 0
             r = c.scan(And(Leaf(0, FilterMode.Range, 1000, 500000)), [col], aggs=[(R.Sum, 0)], bits_out=bits, pack_counts=True)
             assert r.count == want == bits.count() == int(r.pack_counts.sum())
             assert int(r.value(0)[0]) == int(x[(x >= 1000) & (x <= 500000)].sum())
-            bits.free()
-            info = c.placement_info()
-            assert info["held_bytes"] >= 0 and (on or info["held_regions"] == 0)
-            c.set_placement(False)  # gives every held region back
             assert c.placement_info() == {"held_bytes": 0, "held_regions": 0}
+            bits.free()
             col.free()
+            assert c.arena_info()["used_gib"] * 2**30 < (64 << 20)      # only the context's scratch is left
+    with K.Context(0) as c:
+        c.set_arena(4 << 30)
+        small = c.upload(x[:1 << 20], 1 << 16)
+        if c.arena_info()["enabled"]:
+            with pytest.raises(K.KnoxError) as e:
+                c.generate(K.BlockType.Int64, 0, 1, 1 << 30, pack_rows=1 << 20)      # 8 GiB do not fit a 4 GiB arena
+            assert e.value.code == -4
+            assert c.arena_info()["mapped_gib"] <= 4
+        small.free()
+
+
+@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
+def test_arena_reuses_freed_memory_and_trims_only_on_request():
+    """freed columns go back to the arena's free lists, not to the driver (returning multi-GiB blocks slows live
+    neighbours): the next column of that size lands on the same address; knox_ctx_arena_trim returns whole
+    free chunks; knox_ctx_close returns everything"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    f0, f1, f2, f3, tot = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(f0), C.byref(tot))
+    n = 3 << 27                     # 3 GiB of int64: spans chunks
+    with K.Context(0) as c:
+        c.set_arena(32 << 30)
+        col = c.generate(K.BlockType.Int64, 3, 0, n, lo=0, pack_rows=1 << 20)
+        if not c.arena_info()["enabled"]:
+            pytest.skip("no virtual-memory API on this device")
+        mapped = c.arena_info()["mapped_gib"]
+        c.sync()
+        hip.hipMemGetInfo(C.byref(f1), C.byref(tot))
+        col.free()
+        hip.hipMemGetInfo(C.byref(f2), C.byref(tot))
+        assert abs(f2.value - f1.value) < (8 << 20)                      # nothing went back to the driver
+        col2 = c.generate(K.BlockType.Int64, 3, 0, n, lo=1, pack_rows=1 << 20)
+        assert c.arena_info()["mapped_gib"] == mapped          # the same physical chunks again, nothing new from the driver
+        r = c.scan(And(Leaf(0, FilterMode.Le, 10)), [col2], aggs=[(R.Sum, 0)])
+        assert r.count == 10 and int(r.value(0)[0]) == sum(range(1, 11))
+        col2.free()
+        freed = c.arena_trim()
+        assert freed >= (3 << 30) and abs(c.arena_info()["mapped_gib"] * 2**30 - (mapped * 2**30 - freed)) <= (4 << 20)
+    hip.hipMemGetInfo(C.byref(f3), C.byref(tot))
+    assert f0.value - f3.value < (256 << 20)                             # the closed context holds nothing
 
 
 def test_pinned_host_memory_round_trip(ctx):
@@ -265,102 +306,3 @@ def test_pinned_host_memory_round_trip(ctx):
         o.free()
     ctx.host_free(pinned)
     ctx.host_free(back)
-
-
-@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
-def test_placement_search_with_spacers_returns_everything(monkeypatch):
-    """the write-buffer search parks spacers after every second miss; spacers and rejected candidates are HELD
-    (returning memory to the driver slows live buffers) and must all come back when placement is
-    switched off; KNOX_PLACEMENT_FORCE_MISS drives the search through that path"""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    free0, free1, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
-    n = 1 << 25
-    x = np.arange(n, dtype=np.int64)
-    with K.Context(0) as c:
-        col = c.upload(x, 1 << 20)
-        c.sync()
-        hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
-        monkeypatch.setenv("KNOX_PLACEMENT_FORCE_MISS", "7")
-        bits = c.bits(n, for_col=col)
-        monkeypatch.delenv("KNOX_PLACEMENT_FORCE_MISS")
-        assert bits.placement[1] >= 8  # 7 forced misses (3 spacers parked on the way) + the one taken
-        info = c.placement_info()
-        assert info["held_bytes"] >= (12 << 30) and info["held_regions"] >= 10     # 7 candidates + spacers of 4, 4, 8 GiB
-        r = c.scan(And(Leaf(0, FilterMode.Lt, 1000)), [col], bits_out=bits)
-        assert r.count == 1000 == bits.count()
-        c.set_placement(False)   # everything held goes back
-        assert c.placement_info() == {"held_bytes": 0, "held_regions": 0}
-        c.sync()
-        hip.hipMemGetInfo(C.byref(free1), C.byref(tot))
-        # only the accepted 4 MiB bitset (+ allocator granularity) stays allocated
-        assert free0.value - free1.value < (64 << 20), (free0.value, free1.value)
-        bits.free()
-        col.free()
-
-
-@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
-def test_freed_blocks_are_kept_and_reused_not_returned_to_the_driver():
-    """returning a large buffer to the driver slows its live neighbours: freed column blocks >= 256 MiB
-    and bitsets >= 16 MiB stay with the context, serve the next request of their size, and go back to the driver
-    when placement is switched off (or memory is needed, or at close)"""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    f0, f1, f2, tot = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-    n = (1 << 25) + 4096          # 256 MiB + a little of int64
-    x = np.arange(n, dtype=np.int64)
-    with K.Context(0) as c:
-        col = c.upload(x, 1 << 20)
-        if col.placement[2] < 0.90:
-            pytest.skip("no block of the reference class on this box")
-        nbits = 1 << 28           # 32 MiB bitset
-        bits = c.bits(nbits)
-        p_col, p_bits = col.device_ptr, bits.device_ptr
-        c.sync()
-        hip.hipMemGetInfo(C.byref(f0), C.byref(tot))
-        col.free(); bits.free()
-        hip.hipMemGetInfo(C.byref(f1), C.byref(tot))
-        assert abs(f1.value - f0.value) < (8 << 20)          # nothing went back
-        assert c.placement_info()["held_bytes"] >= n * 8
-        col2 = c.upload(x + 1, 1 << 20)
-        assert col2.device_ptr == p_col and col2.placement[1] == 0     # the same block, no new candidates
-        r = c.scan(And(Leaf(0, FilterMode.Le, 10)), [col2], aggs=[(R.Sum, 0)])
-        assert r.count == 10 and int(r.value(0)[0]) == sum(range(1, 11))
-        bits2 = c.bits(nbits)
-        assert bits2.count() == 0                                       # zeroed whether reused or new
-        # the old bitset block is re-probed against the live column: taken if the pair is fast, else it stays cached
-        assert bits2.device_ptr == p_bits or c.placement_info()["held_bytes"] >= (32 << 20)
-        col2.free(); bits2.free()
-        c.set_placement(False)
-        c.sync()
-        hip.hipMemGetInfo(C.byref(f2), C.byref(tot))
-        assert f2.value - f0.value >= n * 8 - (16 << 20)     # now the driver has them
-
-
-@pytest.mark.skipif(os.environ.get("KNOX_PLACEMENT") == "0", reason="placement switched off by the environment")
-def test_memory_held_by_one_context_is_given_back_when_another_needs_it(monkeypatch):
-    """held regions / cached blocks are free memory kept away from the driver: an allocation that would fail takes
-    them back from EVERY context of the process on that device"""
-    import ctypes as C
-    from knoxdb_amd.types import BlockType
-    hip = C.CDLL("libamdhip64.so")
-    free_b, tot = C.c_size_t(), C.c_size_t()
-    n = 1 << 25
-    with K.Context(0) as a, K.Context(0) as b:
-        col = a.upload(np.arange(n, dtype=np.int64), 1 << 20)
-        monkeypatch.setenv("KNOX_PLACEMENT_FORCE_MISS", "7")
-        bits = a.bits(n, for_col=col)
-        monkeypatch.delenv("KNOX_PLACEMENT_FORCE_MISS")
-        held = a.placement_info()["held_bytes"]
-        assert held >= (12 << 30)
-        a.sync()
-        hip.hipMemGetInfo(C.byref(free_b), C.byref(tot))
-        if free_b.value < (150 << 30):
-            pytest.skip("device memory mostly taken by somebody else")
-        want = free_b.value + held // 2              # more than the driver has, less than it has plus what `a` holds
-        big = b.generate(BlockType.Uint8, 0, 1, want, lo=0, span=200, pack_rows=1 << 20)
-        assert big.rows == want
-        assert a.placement_info() == {"held_bytes": 0, "held_regions": 0}
-        r = b.scan(And(Leaf(0, FilterMode.Lt, 100)), [big])
-        assert abs(r.count / want - 0.5) < 0.01
-        big.free(); bits.free(); col.free()

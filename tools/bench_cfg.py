@@ -43,13 +43,13 @@ if args.cfg == 0:
     pin[:] = host
     t0 = time.perf_counter(); colp = ctx.upload(pin, pack); ctx.sync(); t_pin = time.perf_counter() - t0
     print(json.dumps({"cfg": "pcie-pinned (knox_host_alloc)", "rows": m, "upload_s": t_pin, "upload_GBs": m * 8 / t_pin / 1e9,
-                      "placement": colp.placement}))
+                      }))
     print(json.dumps({"cfg": "pcie", "rows": m, "upload_s": t_up, "upload_GBs": m * 8 / t_up / 1e9, "first_scan_s": t_scan,
                       "pcie_inclusive_rows_per_s": m / (t_up + t_scan), "knox_cmp_2^16_rows_s": t_cmp}))
 elif args.cfg == 3:
     a = ctx.generate(BlockType.Float64, 1, 3, n, pack_rows=pack)
     b = ctx.generate(BlockType.Float64, 2, 4, n, pack_rows=pack)
-    bits = ctx.bits(n)
+    bits = ctx.bits(n, for_col=a)
     tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
     for name, aggs in (("count", [(R.Count, 0)]), ("min/max/mean", [(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Count, 0)])):
         plan = ctx.plan(tree, [a, b], aggs=aggs)
@@ -69,7 +69,7 @@ elif args.cfg == 3:
     ctx.L.knox_prof_enable(ctx.h, 0)
     ro = kms.value / max(1, kn.value)
     print(json.dumps({"cfg": 3, "aggs": "read-only ceiling (count, no bitset)", "kernel_ms": ro, "achieved_GBs": n * 16.0 / ro / 1e6,
-                      "placement_a": a.placement, "placement_b": b.placement, "placement_bits": bits.placement}))
+                      "bits_pair_check": bits.pair_check}))
 elif args.cfg == 6:
     # time-window aggregation (next row f1): 2^30 rows, time = row id, windows of 2^16 / 2^10 rows
     tcol = ctx.generate(BlockType.Int64, 3, 0, n, lo=1_000_000, pack_rows=pack)
@@ -90,7 +90,7 @@ elif args.cfg == 6:
                               "rows_per_s": n / dt, "GBs_incl_host": byts / dt / 1e9, "count0": st[0].count}))
 elif args.cfg == 4:
     ids = ctx.generate(BlockType.Uint64, 0, 5, n, lo=0, span=0, pack_rows=pack)   # raw 64-bit ids
-    bits = ctx.bits(n)
+    bits = ctx.bits(n, for_col=ids)
     t0 = time.perf_counter()
     bloom = ctx.bloom_build_u64(ids, 2)
     ctx.sync()
@@ -117,6 +117,8 @@ elif args.cfg == 4:
     t0 = time.perf_counter()
     addr = ctx.generate_bytes(6, n, pack, 32, 16, 4)
     ctx.sync()
+    bits.free()
+    bits = ctx.bits(n, for_col=addr)   # verified against the pool of the bytes column
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     bloom = ctx.bloom_build(addr, 2)

@@ -27,5 +27,5 @@ for bt, w, lo, span, a, b in ((B.Uint8, 1, 0, 256, 64, 127), (B.Int16, 2, -(1 <<
         for bpc in (2, 3, 4, 6, 8):
             ctx.set_tuning(bpc)
             row.append(rate(col, bits, plan, w + .125))
-        print(bt.name, "iters", it, " ".join("b%d:%5.0f" % (b_, r) for b_, r in zip((2, 3, 4, 6, 8), row)), col.placement[2])
+        print(bt.name, "iters", it, " ".join("b%d:%5.0f" % (b_, r) for b_, r in zip((2, 3, 4, 6, 8), row)), "")
     col.free()
