@@ -13,11 +13,11 @@
 // buffer) pair, and it is decided by running the scan kernel on that very pair.
 //
 // WHAT.  Physical memory is taken from the driver only as allocations need it, up to an explicit budget, and is not
-// returned before the context closes (or an explicit trim).  Columns (>= 1 GiB) are assembled from 1 GiB physical
-// chunks mapped back to back (hipMemCreate + the virtual-memory API; any chunks, in any order) -- all of ONE kind:
-// every chunk is probed once against one fixed 16 MiB reference window ("is a 1 GiB column here slow with it?": slow =
-// the window's class, fast = some other class), so that a write buffer that is fast with one part of a column is fast
-// with all of it.  Smaller things share an ordinary heap.  A large
+// returned before the context closes (or an explicit trim).  Columns (>= 1 GiB) live in one of two ZONES: every 1 GiB
+// physical chunk (hipMemCreate) is probed once against one fixed 16 MiB reference window ("is a 1 GiB column here slow
+// with it?": slow = the window's class, fast = some other class) and mapped at the end of its label's zone, so a zone
+// is one VA-contiguous heap of ONE kind of memory, whatever order the driver handed the chunks out in, and a write
+// buffer that is fast with one part of a column is fast with all of it.  Smaller things share an ordinary heap.  A large
 // write buffer that is allocated FOR a column (knox_bits_alloc_for, the scan's scratch bitsets) is a physical
 // allocation of its own, chosen among candidates: spare write buffers first, then a few new ones (small allocations
 // are served from the driver's leftover fragments, which lie all over the device: usually one of a handful is in
@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace knox {
@@ -48,9 +49,58 @@ enum ArenaKind { ARENA_READ = 0, ARENA_WRITE = 1 };
 // clearing freshly taken or released memory costs bandwidth for seconds -- hits both alike); <= 0 = failed
 typedef double (*ArenaProbeFn)(void *user, const void *col, uint64_t rows, void *bits);
 
+// Virtual addresses are used ONCE.  Measured on this stack (ROCm 7.2, tools/vmm_remap_check.py): after hipMemUnmap(va) +
+// hipMemMap(va, another handle) kernels that write through `va` still reach the FIRST handle's memory -- the new mapping
+// does not take effect -- so an address that has been mapped to one physical allocation is never mapped to another, in
+// this process, ever: every mapping gets a fresh range out of a process-wide bump allocator that returns nothing.
+class VaBump {
+  public:
+    static char *take(size_t bytes) {
+        static std::mutex mu;
+        static char *cur = nullptr;
+        static size_t left = 0;
+        const size_t gib = (size_t)1 << 30;
+        bytes = (bytes + gib - 1) & ~(gib - 1);  // 1 GiB steps: large page-table fragments everywhere
+        std::lock_guard<std::mutex> lk(mu);
+        if (left < bytes) {
+            const size_t want = std::max(bytes, (size_t)2 << 40);
+            void *p = nullptr;
+            if (hipMemAddressReserve(&p, want, gib, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipMemAddressReserve(&p, bytes, gib, nullptr, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return nullptr;
+                }
+                cur = (char *)p;
+                left = bytes;
+            } else {
+                cur = (char *)p;
+                left = want;
+            }
+        }
+        char *r = cur;
+        cur += bytes;
+        left -= bytes;
+        return r;
+    }
+    // a reservation of its own for a mapping that is not a whole number of GiB (hipMemSetAccess rejects some sub-GiB
+    // mappings inside a larger reservation, ROCm 7.2); never freed either
+    static char *take_own(size_t bytes) {
+        void *p = nullptr;
+        if (hipMemAddressReserve(&p, bytes, (size_t)2 << 20, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+        }
+        return (char *)p;
+    }
+};
+
 class Arena {
   public:
-    static constexpr size_t kChunk = (size_t)1 << 30;          // physical unit of columns
+    static constexpr size_t kChunk = (size_t)1 << 30;          // physical unit of columns = one labelling probe
     static constexpr size_t kSmallWrite = (size_t)16 << 20;    // write buffers below this share the heap (streams that short do not show the effect)
     static constexpr uint64_t kProbeRows = (uint64_t)1 << 27;  // one sample: 1 GiB of int64 rows, 16 MiB of bitset
     static constexpr double kFastAbove = 0.95;                 // scan / read-only: ~0.88 same class, ~0.98 different classes
@@ -76,13 +126,15 @@ class Arena {
         for (auto &w : spares) n += w.bytes;
         return n;
     }
+    size_t zone_bytes(int label) const { return zones[label - 1].mapped; }
 
-    // Columns / payloads of >= 1 GiB: whole 1 GiB chunks + a small tail, mapped back to back.  Everything else: the heap.
+    // Columns / payloads of >= 1 GiB: a range of ONE zone (chunks of one label, mapped back to back).  Everything else: the heap.
     hipError_t alloc(void **out, size_t bytes, int kind) {
         *out = nullptr;
         bytes = round_up(bytes);
         if (!init_once()) return hipErrorNotSupported;
-        if (kind == ARENA_READ && bytes >= kChunk) return big_alloc(out, bytes);
+        (void)kind;  // large buffers of either kind live in a zone; write buffers that matter are verified (alloc_write_for)
+        if (bytes >= kChunk) return zone_alloc(out, bytes);
         return heap_alloc(out, bytes);
     }
 
@@ -97,9 +149,8 @@ class Arena {
         bytes = round_up(bytes);
         if (!init_once()) return hipErrorNotSupported;
         const size_t sample = kProbeRows * 8, wrote = kProbeRows / 8;
-        if (!probe || !col || col_bytes < sample || bytes < std::max(kSmallWrite, wrote + 64) || bytes_per_row <= 0.0) return heap_alloc(out, bytes);
+        if (!probe || !col || col_bytes < sample || bytes < std::max(kSmallWrite, wrote + 64) || bytes_per_row <= 0.0) return alloc(out, bytes, ARENA_WRITE);
         const size_t wb_bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-        // the column's samples and their read-only rates, once
         constexpr int kMaxSamples = 4;
         const int n_s = (int)std::min<size_t>(kMaxSamples, col_bytes / sample);
         size_t offs[kMaxSamples] = {0}, boffs[kMaxSamples] = {0};
@@ -131,36 +182,42 @@ class Arena {
                 add_spare(w);
             }
         };
-        // 1. spare write buffers of a fitting size
-        for (size_t i = 0; i < spares.size();) {
-            if (spares[i].bytes < wb_bytes || spares[i].bytes > 2 * wb_bytes) { i++; continue; }
-            WBuf w = spares[i];
-            spares.erase(spares.begin() + (long)i);
-            const double r = measure(w.va);
-            dbg("spare write buffer (%zu MiB) vs the column: %.3f", w.bytes >> 20, r);
-            if (r >= kFastAbove) return take_wbuf(out, w, bytes, r, ratio_out, best);
-            consider(w, r);
-            spares_rotated++;
-            if (spares_rotated > 64) break;
+        // 1. spare write buffers of a fitting size (each at most once)
+        {
+            std::vector<WBuf> mine;
+            for (size_t i = 0; i < spares.size();) {
+                if (spares[i].bytes < wb_bytes || spares[i].bytes > 2 * wb_bytes) { i++; continue; }
+                mine.push_back(spares[i]);
+                spares.erase(spares.begin() + (long)i);
+            }
+            for (size_t i = 0; i < mine.size(); i++) {
+                const double r = measure(mine[i].va);
+                dbg("spare write buffer (%zu MiB) vs the column: %.3f", mine[i].bytes >> 20, r);
+                if (r >= kFastAbove) {
+                    for (size_t j = i + 1; j < mine.size(); j++) add_spare(mine[j]);
+                    return take_wbuf(out, mine[i], bytes, r, ratio_out, best);
+                }
+                consider(mine[i], r);
+            }
         }
-        spares_rotated = 0;
         // 2. a few new ones; 3. further away, behind transient spacers
-        auto try_new = [&](int n_tries, bool *hit) {
+        bool hit = false;
+        auto try_new = [&](int n_tries) {
             for (int k = 0; k < n_tries; k++) {
                 WBuf w;
                 if (!new_wbuf(wb_bytes, &w)) return false;
                 const double r = measure(w.va);
                 dbg("new write buffer (%zu MiB) vs the column: %.3f", w.bytes >> 20, r);
                 if (r >= kFastAbove) {
-                    *hit = true;
-                    return take_wbuf(out, w, bytes, r, ratio_out, best) == hipSuccess;
+                    hit = true;
+                    (void)take_wbuf(out, w, bytes, r, ratio_out, best);
+                    return true;
                 }
                 consider(w, r);
             }
             return true;
         };
-        bool hit = false;
-        bool can_go_on = try_new(kNearCandidates, &hit);
+        bool can_go_on = try_new(kNearCandidates);
         if (hit) return hipSuccess;
         std::vector<hipMemGenericAllocationHandle_t> spacers;
         for (int step = 0; step < kMaxSpacers && can_go_on && !hit; step++) {
@@ -177,7 +234,7 @@ class Arena {
             }
             spacers.push_back(sp);
             dbg("spacer %d taken (%zu GiB ahead in the allocation order)", step, (spacers.size() * kSpacer) >> 30);
-            can_go_on = try_new(3, &hit);
+            can_go_on = try_new(3);
         }
         if (!spacers.empty()) {
             (void)hipDeviceSynchronize();
@@ -186,7 +243,7 @@ class Arena {
             usleep(1500000);  // the driver clears what was released; it costs the whole device bandwidth while it runs
         }
         if (hit) return hipSuccess;
-        if (!best.va) return heap_alloc(out, bytes);
+        if (!best.va) return alloc(out, bytes, ARENA_WRITE);
         WBuf none;
         return take_wbuf(out, best, bytes, best_r, ratio_out, none);  // nothing fast within reach: the best there is
     }
@@ -195,44 +252,47 @@ class Arena {
     bool release(void *p) {
         auto s = smalls.find((char *)p);
         if (s != smalls.end()) {
-            give(small.free, s->second.off, s->second.len);
+            Extent &e = s->second.zone < 0 ? heap[(size_t)s->second.extent] : zones[s->second.zone].extents[(size_t)s->second.extent];
+            give(e.free, s->second.off, s->second.len);
             used -= s->second.len;
             smalls.erase(s);
             return true;
         }
         auto w = wbufs.find((char *)p);
-        if (w != wbufs.end()) {
-            used -= w->second.used;
-            WBuf wb = w->second;
-            wbufs.erase(w);
-            add_spare(wb);  // kept: the next request of that size tries it first
-            return true;
-        }
-        auto b = bigs.find((char *)p);
-        if (b == bigs.end()) return false;
-        Big big = b->second;
-        bigs.erase(b);
-        unmap_big(big);
-        (void)hipMemAddressFree(big.va, big.va_bytes);
-        for (int id : big.ids) free_chunks.push_back(id);
-        if (big.tail_bytes) {
-            (void)hipMemRelease(big.tail);  // a few MiB
-            mapped_total -= big.tail_bytes;
-        }
-        used -= big.bytes;
+        if (w == wbufs.end()) return false;
+        used -= w->second.used;
+        WBuf wb = w->second;
+        wbufs.erase(w);
+        add_spare(wb);  // kept: the next request of that size tries it first
         return true;
     }
 
-    // returns every free column chunk and every spare write buffer to the driver (explicit, never automatic)
+    // returns every whole free chunk at the top of a zone and every spare write buffer to the driver (explicit, never automatic)
     size_t trim() {
         size_t freed = 0;
-        for (int id : free_chunks) {
-            (void)hipMemRelease(chunks[(size_t)id].h);
-            chunks[(size_t)id].gone = true;
-            mapped_total -= kChunk;
-            freed += kChunk;
+        for (auto &z : zones) {
+            while (!z.extents.empty()) {
+                Extent &e = z.extents.back();
+                if (e.len < kChunk) break;
+                const size_t top = e.len - kChunk;
+                auto it = e.free.upper_bound(top);  // the free block that contains `top`, if any
+                if (it == e.free.begin()) break;
+                --it;
+                if (it->first + it->second != e.len) break;  // the top chunk is not entirely free
+                const size_t fo = it->first;
+                e.free.erase(it);
+                if (top > fo) e.free[fo] = top - fo;
+                (void)hipMemUnmap(e.va + top, kChunk);
+                (void)hipMemRelease(e.chunks.back());
+                e.chunks.pop_back();
+                e.len -= kChunk;
+                z.mapped -= kChunk;
+                mapped_total -= kChunk;
+                freed += kChunk;
+                z.sealed = true;  // the addresses above are used up: the zone continues in a new extent
+                if (e.len == 0) z.extents.pop_back();
+            }
         }
-        free_chunks.clear();
         for (auto &w : spares) {
             freed += w.bytes;
             drop_wbuf(w);
@@ -242,28 +302,23 @@ class Arena {
     }
 
     void destroy() {
-        for (auto &kv : bigs) {
-            unmap_big(kv.second);
-            (void)hipMemAddressFree(kv.second.va, kv.second.va_bytes);
-            if (kv.second.tail_bytes) (void)hipMemRelease(kv.second.tail);
-        }
-        bigs.clear();
         for (auto &kv : wbufs) drop_wbuf(kv.second);
         wbufs.clear();
         for (auto &w : spares) drop_wbuf(w);
         spares.clear();
         drop_wbuf(ref);
-        if (scratch_va) (void)hipMemAddressFree(scratch_va, kChunk);
-        scratch_va = nullptr;
-        if (small.va) {
-            for (size_t o = 0; o < small.mapped; o += kChunk) (void)hipMemUnmap(small.va + o, kChunk);  // mapping by mapping
-            (void)hipMemAddressFree(small.va, kSmallVa);
+        auto drop_extent = [&](Extent &e) {
+            for (size_t i = 0; i < e.chunks.size(); i++) {
+                (void)hipMemUnmap(e.va + i * kChunk, kChunk);  // mapping by mapping; the addresses are never used again
+                (void)hipMemRelease(e.chunks[i]);
+            }
+        };
+        for (auto &e : heap) drop_extent(e);
+        heap.clear();
+        for (auto &z : zones) {
+            for (auto &e : z.extents) drop_extent(e);
+            z = Zone();
         }
-        small = Heap();
-        for (auto &c : chunks)
-            if (!c.gone) (void)hipMemRelease(c.h);
-        chunks.clear();
-        free_chunks.clear();
         smalls.clear();
         mapped_total = used = 0;
         usable = false;
@@ -271,46 +326,36 @@ class Arena {
     }
 
   private:
-    struct Chunk {
-        hipMemGenericAllocationHandle_t h;
-        bool gone = false;
-        int label = 0;  // vs the reference window: 0 not probed, 1 slow (the window's class), 2 fast (another class)
-    };
-    struct Heap {  // VA-contiguous heap over whole chunks
+    struct Extent {  // a VA-contiguous run of chunks with a free list
         char *va = nullptr;
-        size_t mapped = 0;
+        size_t len = 0;
+        std::vector<hipMemGenericAllocationHandle_t> chunks;
         std::map<size_t, size_t> free;  // offset -> length
     };
-    struct Small { size_t off, len; };
+    struct Zone {  // chunks of one label, mapped back to back (one extent unless trim() cut the top off)
+        char *region = nullptr;
+        size_t region_len = 0, region_used = 0, mapped = 0;
+        bool sealed = false;
+        std::vector<Extent> extents;
+    };
+    struct Small { int zone, extent; size_t off, len; };  // zone: -1 = the heap, 0 / 1 = zones[zone]
     struct WBuf {  // a write buffer: one physical allocation, one mapping
         hipMemGenericAllocationHandle_t h;
         char *va = nullptr;
         size_t bytes = 0, used = 0;
     };
-    struct Big {
-        std::vector<int> ids;
-        hipMemGenericAllocationHandle_t tail;
-        size_t tail_bytes = 0;
-        char *va = nullptr;
-        size_t va_bytes = 0, bytes = 0;
-    };
-    static constexpr size_t kSmallVa = (size_t)64 << 30;
 
     int device = 0;
     ArenaProbeFn probe = nullptr;
     void *user = nullptr;
     bool inited = false;
     size_t used = 0;
-    int spares_rotated = 0;
-    char *scratch_va = nullptr;   // where a new chunk is mapped while it is probed
-    WBuf ref;                     // the reference window every chunk is labelled against (32 MiB, made with the first column)
-    std::vector<Chunk> chunks;
-    std::vector<int> free_chunks;
-    Heap small;
+    WBuf ref;  // the reference window every chunk is labelled against (32 MiB, made with the first column)
+    Zone zones[2];
+    std::vector<Extent> heap;
     std::vector<WBuf> spares;
     std::map<char *, Small> smalls;
     std::map<char *, WBuf> wbufs;
-    std::map<char *, Big> bigs;
 
     static size_t round_up(size_t bytes) {
         if (bytes == 0) bytes = 256;
@@ -330,18 +375,6 @@ class Arena {
     void account(size_t bytes) {
         used += bytes;
         peak_used = std::max(peak_used, used);
-    }
-    static void unmap_big(const Big &b) {  // mapping by mapping, as they were made
-        for (size_t i = 0; i < b.ids.size(); i++) (void)hipMemUnmap(b.va + i * kChunk, kChunk);
-        if (b.tail_bytes) (void)hipMemUnmap(b.va + b.ids.size() * kChunk, b.tail_bytes);
-    }
-    static void *reserve(size_t bytes) {
-        void *p = nullptr;
-        if (hipMemAddressReserve(&p, bytes, (size_t)1 << 30, nullptr, 0) == hipSuccess) return p;  // 1 GiB aligned: large page-table fragments
-        (void)hipGetLastError();
-        if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) == hipSuccess) return p;
-        (void)hipGetLastError();
-        return nullptr;
     }
     static bool take(std::map<size_t, size_t> &fl, size_t bytes, size_t *off) {
         for (auto it = fl.begin(); it != fl.end(); ++it) {
@@ -370,29 +403,21 @@ class Arena {
         }
         fl[off] = len;
     }
-    bool set_access(char *va, size_t bytes) {
-        hipMemAccessDesc d;
-        d.location.type = hipMemLocationTypeDevice;
-        d.location.id = device;
-        d.flags = hipMemAccessFlagsProtReadWrite;
-        const hipError_t e = hipMemSetAccess(va, bytes, &d, 1);
-        if (e != hipSuccess) {
-            dbg("hipMemSetAccess(%p, %zu) failed: %d", (void *)va, bytes, (int)e);
-            (void)hipGetLastError();
-            return false;
-        }
-        return true;
-    }
-    // with_access = false: the caller sets the access rights of the whole reservation in ONE call after the last mapping
-    // (per-mapping calls fail for some sub-GiB pieces that follow GiB pieces in one reservation, ROCm 7.2)
-    bool map_at(char *va, hipMemGenericAllocationHandle_t h, size_t bytes, bool with_access = true) {
-        const hipError_t e = hipMemMap(va, bytes, 0, h, 0);
+    bool map_at(char *va, hipMemGenericAllocationHandle_t h, size_t bytes) {
+        hipError_t e = hipMemMap(va, bytes, 0, h, 0);
         if (e != hipSuccess) {
             dbg("hipMemMap(%p, %zu) failed: %d", (void *)va, bytes, (int)e);
             (void)hipGetLastError();
             return false;
         }
-        if (with_access && !set_access(va, bytes)) {
+        hipMemAccessDesc d;
+        d.location.type = hipMemLocationTypeDevice;
+        d.location.id = device;
+        d.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, bytes, &d, 1);
+        if (e != hipSuccess) {
+            dbg("hipMemSetAccess(%p, %zu) failed: %d", (void *)va, bytes, (int)e);
+            (void)hipGetLastError();
             (void)hipMemUnmap(va, bytes);
             return false;
         }
@@ -415,77 +440,133 @@ class Arena {
     bool init_once() {
         if (inited) return usable;
         inited = true;
-        small.va = (char *)reserve(kSmallVa);
-        usable = small.va != nullptr && grow_small();
-        if (!usable && small.va) {  // no virtual-memory API, or not even one chunk: the caller falls back to plain hipMalloc
-            (void)hipMemAddressFree(small.va, kSmallVa);
-            small.va = nullptr;
-        }
+        usable = grow_heap();  // no virtual-memory API, or not even one chunk: the caller falls back to plain hipMalloc
         return usable;
     }
-    int new_chunk() {
-        Chunk c;
-        if (!create(kChunk, &c.h)) return -1;
-        chunks_created++;
-        chunks.push_back(c);
-        return (int)chunks.size() - 1;
-    }
-    // the chunk's label against the reference window (see the header comment)
-    void label_chunk(int id) {
-        Chunk &c = chunks[(size_t)id];
-        if (c.label || !probe) return;
-        if (!scratch_va) scratch_va = (char *)reserve(kChunk);
-        if (!ref.va && !new_wbuf((size_t)32 << 20, &ref)) return;
-        if (!scratch_va || !map_at(scratch_va, c.h, kChunk)) return;
-        // fresh physical memory may still be under the driver's own clearing pass: touch all of it once and wait
-        (void)hipMemsetAsync(scratch_va, 0, kChunk, nullptr);
-        (void)hipDeviceSynchronize();
-        double r = 0.0;
-        for (int rep = 0; rep < 2; rep++) {  // a reading near the threshold is taken again and averaged
-            const double x = probe(user, scratch_va, kProbeRows, ref.va);
-            probes_run++;
-            if (x <= 0.0) { r = 0.0; break; }
-            r = rep == 0 ? x : 0.5 * (r + x);
-            if (r < 0.915 || r > 0.965) break;
-        }
-        dbg("chunk %d vs the reference window: %.3f", id, r);
-        if (r > 0.0) c.label = r < 0.94 ? 1 : 2;
-        (void)hipDeviceSynchronize();
-        (void)hipMemUnmap(scratch_va, kChunk);
-    }
-    bool grow_small() {
-        if (small.mapped + kChunk > kSmallVa) return false;
-        int id = -1;
-        if (!free_chunks.empty()) {
-            id = free_chunks.back();
-            free_chunks.pop_back();
-        } else {
-            id = new_chunk();
-        }
-        if (id < 0) return false;
-        if (!map_at(small.va + small.mapped, chunks[(size_t)id].h, kChunk)) {
-            free_chunks.push_back(id);
+    bool grow_heap() {
+        Extent e;
+        hipMemGenericAllocationHandle_t h;
+        if (!create(kChunk, &h)) return false;
+        e.va = VaBump::take(kChunk);
+        if (!e.va || !map_at(e.va, h, kChunk)) {
+            (void)hipMemRelease(h);
+            mapped_total -= kChunk;
             return false;
         }
-        give(small.free, small.mapped, kChunk);
-        small.mapped += kChunk;
+        chunks_created++;
+        e.len = kChunk;
+        e.chunks.push_back(h);
+        e.free[0] = kChunk;
+        heap.push_back(e);
         return true;
     }
     hipError_t heap_alloc(void **out, size_t bytes) {
-        size_t off = 0;
-        while (!take(small.free, bytes, &off))
-            if (bytes > kChunk || !grow_small()) return hipErrorOutOfMemory;
-        smalls[small.va + off] = Small{off, bytes};
-        account(bytes);
-        *out = small.va + off;
-        return hipSuccess;
+        if (bytes > kChunk) return hipErrorOutOfMemory;
+        for (int pass = 0; pass < 2; pass++) {
+            for (size_t i = 0; i < heap.size(); i++) {
+                size_t off = 0;
+                if (!take(heap[i].free, bytes, &off)) continue;
+                smalls[heap[i].va + off] = Small{-1, (int)i, off, bytes};
+                account(bytes);
+                *out = heap[i].va + off;
+                return hipSuccess;
+            }
+            if (pass == 1 || !grow_heap()) break;
+        }
+        return hipErrorOutOfMemory;
+    }
+
+    // One more chunk: mapped once at a fresh address to be labelled against the reference window, then (re)mapped -- at
+    // another fresh address -- at the end of its label's zone.  Returns the zone index, -1 = no chunk.
+    int grow_zone() {
+        hipMemGenericAllocationHandle_t h;
+        if (!create(kChunk, &h)) return -1;
+        chunks_created++;
+        int label = 1;
+        if (probe) {
+            if (!ref.va && !new_wbuf((size_t)32 << 20, &ref)) {
+                (void)hipMemRelease(h);
+                mapped_total -= kChunk;
+                return -1;
+            }
+            char *pva = VaBump::take(kChunk);
+            if (!pva || !map_at(pva, h, kChunk)) {
+                (void)hipMemRelease(h);
+                mapped_total -= kChunk;
+                return -1;
+            }
+            // fresh physical memory may still be under the driver's own clearing pass: touch all of it once and wait
+            (void)hipMemsetAsync(pva, 0, kChunk, nullptr);
+            (void)hipDeviceSynchronize();
+            double r = 0.0;
+            for (int rep = 0; rep < 2; rep++) {  // a reading near the threshold is taken again and averaged
+                const double x = probe(user, pva, kProbeRows, ref.va);
+                probes_run++;
+                if (x <= 0.0) { r = 0.0; break; }
+                r = rep == 0 ? x : 0.5 * (r + x);
+                if (r < 0.915 || r > 0.965) break;
+            }
+            dbg("chunk %d vs the reference window: %.3f", chunks_created, r);
+            label = (r > 0.0 && r >= 0.94) ? 2 : 1;
+            (void)hipDeviceSynchronize();
+            (void)hipMemUnmap(pva, kChunk);  // pva is never used again
+        }
+        Zone &z = zones[label - 1];
+        if (!z.region || z.region_used + kChunk > z.region_len) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)288 << 30;
+            z.region_len = std::min(budget, total_b) + kChunk;
+            z.region = VaBump::take(z.region_len);
+            z.region_used = 0;
+            z.sealed = true;
+            if (!z.region) {
+                (void)hipMemRelease(h);
+                mapped_total -= kChunk;
+                return -1;
+            }
+        }
+        char *va = z.region + z.region_used;
+        if (!map_at(va, h, kChunk)) {
+            (void)hipMemRelease(h);
+            mapped_total -= kChunk;
+            return -1;
+        }
+        z.region_used += kChunk;
+        if (z.sealed || z.extents.empty()) {
+            Extent e;
+            e.va = va;
+            z.extents.push_back(e);
+            z.sealed = false;
+        }
+        Extent &e = z.extents.back();
+        give(e.free, e.len, kChunk);
+        e.len += kChunk;
+        e.chunks.push_back(h);
+        z.mapped += kChunk;
+        return label - 1;
+    }
+    hipError_t zone_alloc(void **out, size_t bytes) {
+        for (;;) {
+            for (int zi = 0; zi < 2; zi++)
+                for (size_t ei = 0; ei < zones[zi].extents.size(); ei++) {
+                    size_t off = 0;
+                    if (!take(zones[zi].extents[ei].free, bytes, &off)) continue;
+                    smalls[zones[zi].extents[ei].va + off] = Small{zi, (int)ei, off, bytes};
+                    account(bytes);
+                    *out = zones[zi].extents[ei].va + off;
+                    return hipSuccess;
+                }
+            if (grow_zone() < 0) {
+                dbg("zone_alloc: %zu bytes do not fit (mapped %zu of %zu)", bytes, mapped_total, budget);
+                return hipErrorOutOfMemory;
+            }
+        }
     }
 
     bool new_wbuf(size_t bytes, WBuf *w) {
         if (!create(bytes, &w->h)) return false;
-        w->va = (char *)reserve(bytes);
+        w->va = VaBump::take_own(bytes);
         if (!w->va || !map_at(w->va, w->h, bytes)) {
-            if (w->va) (void)hipMemAddressFree(w->va, bytes);
             (void)hipMemRelease(w->h);
             mapped_total -= bytes;
             w->va = nullptr;
@@ -501,8 +582,7 @@ class Arena {
     }
     void drop_wbuf(WBuf &w) {
         if (!w.va) return;
-        (void)hipMemUnmap(w.va, w.bytes);
-        (void)hipMemAddressFree(w.va, w.bytes);
+        (void)hipMemUnmap(w.va, w.bytes);  // the address is never used again
         (void)hipMemRelease(w.h);
         mapped_total -= w.bytes;
         w.va = nullptr;
@@ -518,81 +598,12 @@ class Arena {
     }
     hipError_t take_wbuf(void **out, WBuf &w, size_t bytes, double r, double *ratio_out, WBuf &other_best) {
         if (other_best.va && other_best.va != w.va) add_spare(other_best);
+        other_best.va = nullptr;
         w.used = bytes;
         wbufs[w.va] = w;
         account(bytes);
         *out = w.va;
         if (ratio_out) *ratio_out = r;
-        return hipSuccess;
-    }
-
-    // A column: n whole chunks + a small tail chunk, mapped back to back
-    hipError_t big_alloc(void **out, size_t bytes) {
-        const size_t n = bytes / kChunk;
-        const size_t tail = (bytes - n * kChunk + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-        // n free chunks of ONE label (whichever label gets there first); new chunks as long as the budget allows
-        std::vector<int> pick;
-        auto gather = [&]() {
-            for (int label = 1; label <= 2; label++) {
-                pick.clear();
-                for (int id : free_chunks)
-                    if (pick.size() < n && chunks[(size_t)id].label == label) pick.push_back(id);
-                if (pick.size() >= n) return true;
-            }
-            return false;
-        };
-        for (int id : free_chunks) label_chunk(id);
-        bool one_kind = gather();
-        while (!one_kind) {
-            if (mapped_total + kChunk + tail + ((size_t)256 << 20) > budget) break;
-            const int id = new_chunk();
-            if (id < 0) break;
-            label_chunk(id);
-            free_chunks.push_back(id);
-            one_kind = gather();
-        }
-        if (!one_kind) {  // the budget does not hold n chunks of one kind (or nothing can be probed): whatever is free
-            pick.clear();
-            for (int id : free_chunks)
-                if (pick.size() < n) pick.push_back(id);
-            dbg("big_alloc: no %zu chunks of one kind within the budget, %zu free", n, free_chunks.size());
-        }
-        if (pick.size() < n) {
-            dbg("big_alloc: %zu free chunks for %zu wanted (mapped %zu of %zu)", pick.size(), n, mapped_total, budget);
-            return hipErrorOutOfMemory;
-        }
-        Big b;
-        b.bytes = bytes;
-        b.va_bytes = n * kChunk + tail;
-        b.va = (char *)reserve(b.va_bytes);
-        if (!b.va) return hipErrorOutOfMemory;
-        if (tail && !create(tail, &b.tail)) {
-            (void)hipMemAddressFree(b.va, b.va_bytes);
-            return hipErrorOutOfMemory;
-        }
-        b.tail_bytes = tail;
-        b.ids = pick;
-        bool ok = true, tail_mapped = false;
-        size_t done = 0;
-        for (; done < n && ok; done++) ok = map_at(b.va + done * kChunk, chunks[(size_t)b.ids[done]].h, kChunk, false);
-        if (!ok) done--;  // the last one is not mapped
-        if (ok && tail) ok = tail_mapped = map_at(b.va + n * kChunk, b.tail, tail, false);
-        if (ok) ok = set_access(b.va, b.va_bytes);
-        if (!ok) {
-            dbg("big_alloc: mapping failed after %zu of %zu chunks", done, n);
-            for (size_t i = 0; i < done; i++) (void)hipMemUnmap(b.va + i * kChunk, kChunk);
-            if (tail_mapped) (void)hipMemUnmap(b.va + n * kChunk, tail);
-            if (tail) {
-                (void)hipMemRelease(b.tail);
-                mapped_total -= tail;
-            }
-            (void)hipMemAddressFree(b.va, b.va_bytes);
-            return hipErrorOutOfMemory;
-        }
-        for (int id : pick) free_chunks.erase(std::find(free_chunks.begin(), free_chunks.end(), id));
-        bigs[b.va] = b;
-        account(bytes);
-        *out = b.va;
         return hipSuccess;
     }
 };
