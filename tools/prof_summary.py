@@ -16,8 +16,9 @@ def short(name):
 
 
 print("# rocprofv3 summary of `python3 bench.py --no-cpu-baseline` = the default run, 20 steps + 3 warmup (%s)" % os.path.basename(root))
-print("# scan_kernel<8, 1, 1u, false, false, 0u> = the scans: 12 of bench.py's setup check + 3 warmup + 20 timed; <..., 1u> (FLV 1) = the allocator's placement probes;")
-print("# scan_kernel<8, 1, 0u, ...> = the read-only form (setup: two candidate columns and the pair check; after the timed region: the ceiling)")
+print("# scan_kernel<8, 1, 1u, false, false, 0u> = the scans: 12 of bench.py's one setup check + 3 warmup + 20 timed + 30 of the 0 % / 100 % selectivity runs;")
+print("# <..., 1u> (FLV 1) = the arena's probes (chunk labels, write-buffer verification: alternating read-only / scan launches over 1 GiB samples);")
+print("# scan_kernel<8, 1, 0u, ...> = the read-only form (setup check, and the ceiling after the timed region)")
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("\n## kernel stats (--kernel-trace --stats)")
     print("%-92s %7s %12s %12s %8s" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
@@ -54,6 +55,7 @@ if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
     t = {"kernel": "knox::scan_kernel<8,1,ISUM> (headline)", "FETCH_SIZE_KiB_raw": traffic["FETCH_SIZE"],
          "WRITE_SIZE_KiB_raw": traffic["WRITE_SIZE"], "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b,
          "hbm_bytes_per_launch": fetch_b + write_b, "source": os.path.basename(root),
+         "measured": "round 2, %s" % __import__("time").strftime("%Y-%m-%d"),
          "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM section)"}
     print("\n## HBM traffic per launch of the headline kernel\n" + json.dumps(t))
     if len(sys.argv) > 2:
