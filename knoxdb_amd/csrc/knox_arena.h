@@ -49,52 +49,41 @@ enum ArenaKind { ARENA_READ = 0, ARENA_WRITE = 1 };
 // clearing freshly taken or released memory costs bandwidth for seconds -- hits both alike); <= 0 = failed
 typedef double (*ArenaProbeFn)(void *user, const void *col, uint64_t rows, void *bits);
 
-// Virtual addresses are used ONCE.  Measured on this stack (ROCm 7.2, tools/vmm_remap_check.py): after hipMemUnmap(va) +
-// hipMemMap(va, another handle) kernels that write through `va` still reach the FIRST handle's memory -- the new mapping
-// does not take effect -- so an address that has been mapped to one physical allocation is never mapped to another, in
-// this process, ever: every mapping gets a fresh range out of a process-wide bump allocator that returns nothing.
+// Three facts about the HIP virtual-memory API on this stack (ROCm 7.2), all measured (tools/vmm_remap_check*.py):
+//  1. a virtual address that has been mapped to one physical allocation must never be mapped to another: after
+//     hipMemUnmap(va) + hipMemMap(va, another handle) kernels that write through `va` still reach the FIRST handle's
+//     memory -- also when the reservation was freed (hipMemAddressFree) and the same address reserved again;
+//  2. physical memory only goes back to the driver at hipMemAddressFree of the reservation it was mapped in -- unmapping
+//     and releasing the handle is not enough;
+//  3. hipMemAddressReserve honours its address hint.
+// So: every mapping unit (a heap chunk, a write buffer, the probe mapping of a new chunk, a zone's whole region) gets a
+// reservation of its own at an address NO reservation of this process has had before -- a process-wide cursor that only
+// moves up hands the hints out -- mappings are only ever added inside a zone's region, and a reservation is freed as
+// soon as nothing is mapped in it any more (the memory goes back, the address is not used again).
 class VaBump {
   public:
     static char *take(size_t bytes) {
         static std::mutex mu;
-        static char *cur = nullptr;
-        static size_t left = 0;
+        static uintptr_t cursor = (uintptr_t)0x100000000000ull;  // 16 TiB: far above what the runtime hands out by itself
         const size_t gib = (size_t)1 << 30;
-        bytes = (bytes + gib - 1) & ~(gib - 1);  // 1 GiB steps: large page-table fragments everywhere
+        const size_t span = ((bytes + gib - 1) & ~(gib - 1)) + gib;  // 1 GiB aligned (large page-table fragments) + a guard
         std::lock_guard<std::mutex> lk(mu);
-        if (left < bytes) {
-            const size_t want = std::max(bytes, (size_t)2 << 40);
+        for (int attempt = 0; attempt < 8 && cursor + span < (uintptr_t)0x700000000000ull; attempt++) {
             void *p = nullptr;
-            if (hipMemAddressReserve(&p, want, gib, nullptr, 0) != hipSuccess) {
+            const uintptr_t hint = cursor;
+            cursor += span;
+            if (hipMemAddressReserve(&p, bytes, gib, (void *)hint, 0) != hipSuccess) {
                 (void)hipGetLastError();
-                if (hipMemAddressReserve(&p, bytes, gib, nullptr, 0) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return nullptr;
-                }
-                cur = (char *)p;
-                left = bytes;
-            } else {
-                cur = (char *)p;
-                left = want;
+                continue;
             }
+            if ((uintptr_t)p == hint) return (char *)p;
+            (void)hipMemAddressFree(p, bytes);  // not where it was asked for: not an address this process controls
         }
-        char *r = cur;
-        cur += bytes;
-        left -= bytes;
-        return r;
+        return nullptr;
     }
-    // a reservation of its own for a mapping that is not a whole number of GiB (hipMemSetAccess rejects some sub-GiB
-    // mappings inside a larger reservation, ROCm 7.2); never freed either
-    static char *take_own(size_t bytes) {
-        void *p = nullptr;
-        if (hipMemAddressReserve(&p, bytes, (size_t)2 << 20, nullptr, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                return nullptr;
-            }
-        }
-        return (char *)p;
+    static char *take_own(size_t bytes) { return take(bytes); }
+    static void give_back(char *va, size_t bytes) {
+        if (va) (void)hipMemAddressFree(va, bytes);
     }
 };
 
@@ -267,31 +256,20 @@ class Arena {
         return true;
     }
 
-    // returns every whole free chunk at the top of a zone and every spare write buffer to the driver (explicit, never automatic)
+    // returns every zone that holds no allocation and every spare write buffer to the driver (explicit, never automatic).
+    // (A zone is one reservation: its memory goes back when the reservation is freed, i.e. all of it or nothing.)
     size_t trim() {
         size_t freed = 0;
-        for (auto &z : zones) {
-            while (!z.extents.empty()) {
-                Extent &e = z.extents.back();
-                if (e.len < kChunk) break;
-                const size_t top = e.len - kChunk;
-                auto it = e.free.upper_bound(top);  // the free block that contains `top`, if any
-                if (it == e.free.begin()) break;
-                --it;
-                if (it->first + it->second != e.len) break;  // the top chunk is not entirely free
-                const size_t fo = it->first;
-                e.free.erase(it);
-                if (top > fo) e.free[fo] = top - fo;
-                (void)hipMemUnmap(e.va + top, kChunk);
-                (void)hipMemRelease(e.chunks.back());
-                e.chunks.pop_back();
-                e.len -= kChunk;
-                z.mapped -= kChunk;
-                mapped_total -= kChunk;
-                freed += kChunk;
-                z.sealed = true;  // the addresses above are used up: the zone continues in a new extent
-                if (e.len == 0) z.extents.pop_back();
-            }
+        for (int zi = 0; zi < 2; zi++) {
+            Zone &z = zones[zi];
+            bool in_use = false;
+            for (auto &kv : smalls) in_use = in_use || kv.second.zone == zi;
+            if (in_use || !z.region) continue;
+            for (auto &e : z.extents) drop_extent(e);
+            for (auto &rg : z.regions) VaBump::give_back(rg.first, rg.second);
+            freed += z.mapped;
+            mapped_total -= z.mapped;
+            z = Zone();
         }
         for (auto &w : spares) {
             freed += w.bytes;
@@ -307,16 +285,14 @@ class Arena {
         for (auto &w : spares) drop_wbuf(w);
         spares.clear();
         drop_wbuf(ref);
-        auto drop_extent = [&](Extent &e) {
-            for (size_t i = 0; i < e.chunks.size(); i++) {
-                (void)hipMemUnmap(e.va + i * kChunk, kChunk);  // mapping by mapping; the addresses are never used again
-                (void)hipMemRelease(e.chunks[i]);
-            }
-        };
-        for (auto &e : heap) drop_extent(e);
+        for (auto &e : heap) {
+            drop_extent(e);
+            VaBump::give_back(e.va, kChunk);
+        }
         heap.clear();
         for (auto &z : zones) {
             for (auto &e : z.extents) drop_extent(e);
+            for (auto &rg : z.regions) VaBump::give_back(rg.first, rg.second);
             z = Zone();
         }
         smalls.clear();
@@ -337,6 +313,7 @@ class Arena {
         size_t region_len = 0, region_used = 0, mapped = 0;
         bool sealed = false;
         std::vector<Extent> extents;
+        std::vector<std::pair<char *, size_t>> regions;  // every reservation of the zone (one, unless the budget was raised later)
     };
     struct Small { int zone, extent; size_t off, len; };  // zone: -1 = the heap, 0 / 1 = zones[zone]
     struct WBuf {  // a write buffer: one physical allocation, one mapping
@@ -371,6 +348,13 @@ class Arena {
         vfprintf(stderr, fmt, ap);
         fprintf(stderr, "\n");
         va_end(ap);
+    }
+    static void drop_extent(Extent &e) {  // mapping by mapping, as they were made
+        for (size_t i = 0; i < e.chunks.size(); i++) {
+            (void)hipMemUnmap(e.va + i * kChunk, kChunk);
+            (void)hipMemRelease(e.chunks[i]);
+        }
+        e.chunks.clear();
     }
     void account(size_t bytes) {
         used += bytes;
@@ -449,6 +433,7 @@ class Arena {
         if (!create(kChunk, &h)) return false;
         e.va = VaBump::take(kChunk);
         if (!e.va || !map_at(e.va, h, kChunk)) {
+            VaBump::give_back(e.va, kChunk);
             (void)hipMemRelease(h);
             mapped_total -= kChunk;
             return false;
@@ -491,6 +476,7 @@ class Arena {
             }
             char *pva = VaBump::take(kChunk);
             if (!pva || !map_at(pva, h, kChunk)) {
+                VaBump::give_back(pva, kChunk);
                 (void)hipMemRelease(h);
                 mapped_total -= kChunk;
                 return -1;
@@ -509,7 +495,8 @@ class Arena {
             dbg("chunk %d vs the reference window: %.3f", chunks_created, r);
             label = (r > 0.0 && r >= 0.94) ? 2 : 1;
             (void)hipDeviceSynchronize();
-            (void)hipMemUnmap(pva, kChunk);  // pva is never used again
+            (void)hipMemUnmap(pva, kChunk);
+            VaBump::give_back(pva, kChunk);  // the probe mapping had a reservation of its own
         }
         Zone &z = zones[label - 1];
         if (!z.region || z.region_used + kChunk > z.region_len) {
@@ -517,6 +504,7 @@ class Arena {
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)288 << 30;
             z.region_len = std::min(budget, total_b) + kChunk;
             z.region = VaBump::take(z.region_len);
+            if (z.region) z.regions.push_back({z.region, z.region_len});
             z.region_used = 0;
             z.sealed = true;
             if (!z.region) {
@@ -567,6 +555,7 @@ class Arena {
         if (!create(bytes, &w->h)) return false;
         w->va = VaBump::take_own(bytes);
         if (!w->va || !map_at(w->va, w->h, bytes)) {
+            VaBump::give_back(w->va, bytes);
             (void)hipMemRelease(w->h);
             mapped_total -= bytes;
             w->va = nullptr;
@@ -582,8 +571,9 @@ class Arena {
     }
     void drop_wbuf(WBuf &w) {
         if (!w.va) return;
-        (void)hipMemUnmap(w.va, w.bytes);  // the address is never used again
+        (void)hipMemUnmap(w.va, w.bytes);
         (void)hipMemRelease(w.h);
+        VaBump::give_back(w.va, w.bytes);
         mapped_total -= w.bytes;
         w.va = nullptr;
     }
