@@ -1,7 +1,13 @@
 //go:build knoxgpu
 
-// Package knoxgpu binds libknoxgpu.so (include/knoxgpu.h): the MI355X implementation of the
-// KnoxDB pack-scan path.  NOT compiled in the knoxdb_amd repository (no Go toolchain there).
+// Package knoxgpu binds libknoxgpu.so (include/knoxgpu.h): the MI355X implementation of the KnoxDB pack-scan path.
+// Drop into internal/knoxgpu/ of blockwatch-cc/knoxdb.  NOT compiled in the knoxdb_amd repository (no Go toolchain
+// there): integration/check_go_calls.py checks every C call below against the header (names, arity, argument kinds),
+// tests/cpp/test_host.cpp drives the same entry points on the GPU.
+//
+// cgo rules observed: Go memory passed to C is only touched during the call (the library stages it through pinned
+// memory and never retains host pointers, include/knoxgpu.h "Conventions"); C handles are plain pointers owned by Go
+// wrapper structs with explicit Free / Close.
 package knoxgpu
 
 /*
@@ -15,18 +21,33 @@ import "C"
 import (
 	"errors"
 	"os"
+	"strconv"
+	"sync"
 	"unsafe"
 )
 
-// Enabled follows the env kill-switch pattern of internal/cpu/avx.go:43-89.
-var Enabled = os.Getenv("KNOX_NOGPU") == ""
+// Enabled follows the kill-switch pattern of internal/cpu/avx.go:43-89 (env NOAVX / NOAVX2 ...): KNOX_NOGPU=1 (any
+// strconv.ParseBool true) keeps every CPU kernel in place.
+func Enabled() bool {
+	v := os.Getenv("KNOX_NOGPU")
+	if v == "" {
+		return true
+	}
+	off, err := strconv.ParseBool(v)
+	return err != nil || !off
+}
 
 type Number interface {
 	int64 | int32 | int16 | int8 | uint64 | uint32 | uint16 | uint8 | float64 | float32
 }
 
-// Ctx is one device + one HIP stream; use one per OS thread (it is not re-entrant).
-type Ctx struct{ p *C.knox_ctx }
+// Ctx is one device + one HIP stream.  The library's contexts are not re-entrant; the reference runs many queries
+// concurrently (one goroutine per query, pack/table/query.go:195-219), so calls are serialised per Ctx.  A host that
+// wants parallel scans opens one Ctx per worker.
+type Ctx struct {
+	p  *C.knox_ctx
+	mu sync.Mutex
+}
 
 func errOf(rc C.int) error {
 	if rc == 0 {
@@ -40,154 +61,319 @@ func Open(device int) (*Ctx, error) {
 	if rc := C.knox_ctx_open(C.int(device), &c); rc != 0 {
 		return nil, errOf(rc)
 	}
-	return &Ctx{c}, nil
+	return &Ctx{p: c}, nil
 }
 
 func (c *Ctx) Close() { C.knox_ctx_close(c.p) }
 
-// Cmp has the shape of the cmp func vars (internal/cmp/cmp.go:6-114):
-// dtype = types.BlockType, mode = types.FilterMode.  Go memory is only read during the call.
-func Cmp[T Number](c *Ctx, dtype, mode int, src []T, a, b T, bits []byte) int64 {
+// SetArena sets the budget of the context's device-memory arena (the pack cache on the device).
+func (c *Ctx) SetArena(bytes uint64) error {
+	return errOf(C.knox_ctx_set_arena(c.p, C.size_t(bytes)))
+}
+
+// AsU64 reinterprets the signed top limb slice of an Int128Stride / Int256Stride (X0 []int64) as raw 64-bit words.
+func AsU64(x []int64) []uint64 {
+	return unsafe.Slice((*uint64)(unsafe.Pointer(unsafe.SliceData(x))), len(x))
+}
+
+// Cmp has the shape of the cmp func vars (internal/cmp/cmp.go:6-114): dtype = types.BlockType, mode =
+// types.FilterMode, bits = (len(src)+7)/8 zeroed bytes.  ok == false: the GPU call failed, use the CPU kernel.
+func Cmp[T Number](c *Ctx, dtype, mode int, src []T, a, b T, bits []byte) (int64, bool) {
 	if len(src) == 0 {
-		return 0
+		return 0, true // n == 0 returns 0 and writes nothing (cmp/tests/int64.go:212-213)
 	}
-	return int64(C.knox_cmp(c.p, C.int(dtype), C.int(mode),
-		unsafe.Pointer(unsafe.SliceData(src)), C.size_t(len(src)),
-		unsafe.Pointer(&a), unsafe.Pointer(&b),
-		(*C.uint8_t)(unsafe.SliceData(bits))))
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	n := C.knox_cmp(c.p, C.int(dtype), C.int(mode), unsafe.Pointer(unsafe.SliceData(src)), C.size_t(len(src)),
+		unsafe.Pointer(&a), unsafe.Pointer(&b), (*C.uint8_t)(unsafe.SliceData(bits)))
+	return int64(n), n >= 0
 }
 
 // Column is the device image of one column of a run of consecutive packs.
-type Column struct{ p *C.knox_col }
+type Column struct {
+	p *C.knox_col
+	n int
+}
 
 func Upload[T Number](c *Ctx, dtype int, vals []T, packRows int) (*Column, error) {
 	var col *C.knox_col
-	rc := C.knox_col_upload(c.p, C.int(dtype), unsafe.Pointer(unsafe.SliceData(vals)),
-		C.size_t(len(vals)), C.size_t(packRows), &col)
-	return &Column{col}, errOf(rc)
+	rc := C.knox_col_upload(c.p, C.int(dtype), unsafe.Pointer(unsafe.SliceData(vals)), C.size_t(len(vals)), C.size_t(packRows), &col)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Column{col, len(vals)}, nil
 }
 
-func (c *Column) Free() { C.knox_col_free(c.p) }
+// NewBytesColumn / AppendPack: a []byte column held as ONE StringPool per pack (pkg/stringx/pool.go:45-58):
+// ptr[i] = off<<32 | len relative to that pack's own buffer.
+func NewBytesColumn(c *Ctx, packRows, maxPacks int, maxPoolBytes uint64) (*Column, error) {
+	var col *C.knox_col
+	rc := C.knox_col_bytes_create(c.p, C.size_t(packRows), C.size_t(maxPacks), C.size_t(maxPoolBytes), &col)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Column{col, 0}, nil
+}
+
+func (col *Column) AppendPack(c *Ctx, ptr []uint64, buf []byte) error {
+	rc := C.knox_col_bytes_append_pack(c.p, col.p, (*C.uint64_t)(unsafe.SliceData(ptr)), C.size_t(len(ptr)),
+		(*C.uint8_t)(unsafe.SliceData(buf)), C.size_t(len(buf)))
+	if rc == 0 {
+		col.n += len(ptr)
+	}
+	return errOf(rc)
+}
+
+func (col *Column) Rows() int { return col.n }
+func (col *Column) Free()     { C.knox_col_free(col.p) }
 
 // Bits is a device-resident bitset.Bitset.
-type Bits struct{ p *C.knox_bits }
+type Bits struct {
+	p    *C.knox_bits
+	size int
+}
 
 func NewBits(c *Ctx, size int) (*Bits, error) {
 	var b *C.knox_bits
-	rc := C.knox_bits_alloc(c.p, C.size_t(size), &b)
-	return &Bits{b}, errOf(rc)
+	if rc := C.knox_bits_alloc(c.p, C.size_t(size), &b); rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Bits{b, size}, nil
 }
 
-// NewBitsFor allocates the selection bitset for scans over col: same HBM placement class as the
-// column (knox_bits_alloc_for; a bitset of the other class costs the scan ~13 %, DESIGN.md 7).
+// NewBitsFor: the selection bitset of scans over col (a write buffer verified against that column).
 func NewBitsFor(c *Ctx, size int, col *Column) (*Bits, error) {
 	var b *C.knox_bits
-	rc := C.knox_bits_alloc_for(c.p, C.size_t(size), col.p, &b)
-	return &Bits{b}, errOf(rc)
+	if rc := C.knox_bits_alloc_for(c.p, C.size_t(size), col.p, &b); rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Bits{b, size}, nil
 }
 
 func (b *Bits) Free() { C.knox_bits_free(b.p) }
 
-// Download copies the bitset into a Go slice of (size+7)/8 bytes (bitset.Bitset.Bytes()).
-func (b *Bits) Download(c *Ctx, dst []byte) error {
-	return errOf(C.knox_bits_download(c.p, b.p, (*C.uint8_t)(unsafe.SliceData(dst))))
+func (b *Bits) Upload(c *Ctx, host []byte) error {
+	return errOf(C.knox_bits_upload(c.p, b.p, (*C.uint8_t)(unsafe.SliceData(host))))
 }
 
-// Pred is one postfix node of a filter.Node tree (operator/filter/node.go:29-35).
-type Pred = C.knox_pred
-type Agg = C.knox_agg
-type AggState = C.knox_agg_state
+// Download fills host ((size+7)/8 bytes) -- what bitset.Bitset.Bytes() holds.
+func (b *Bits) Download(c *Ctx, host []byte) error {
+	return errOf(C.knox_bits_download(c.p, b.p, (*C.uint8_t)(unsafe.SliceData(host))))
+}
 
-// Scan replaces the per-pack filter.Match loop (pack/table/reader.go:334) for a resident run.
-func Scan(c *Ctx, preds []Pred, cols []*Column, aggs []Agg, rowBase uint64, packSkip []byte,
-	bits *Bits, packCounts []int64) (states []AggState, count int64, err error) {
+// Indexes = Bitset.Indexes (internal/bitset/iterator.go:269-290): ascending row ids of the set bits.
+func (b *Bits) Indexes(c *Ctx, dst []uint32) ([]uint32, error) {
+	var n C.size_t
+	rc := C.knox_bits_indexes(c.p, b.p, (*C.uint32_t)(unsafe.SliceData(dst)), C.size_t(cap(dst)), &n)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	return dst[:int(n)], nil
+}
+
+// MatchWide runs one Int128 / Int256 compare (cmp_i128_* / cmp_i256_*, internal/cmp/int128.go:14-471, int256.go:14-270)
+// over host limb slices, most significant first: uploads the limbs (and the mask), matches on the device, downloads
+// the bitset.  ok == false: fall back to the CPU kernel.  The returned count is the popcount of the result (the
+// reference's unrolled i128 loops count the unmasked byte: see include/knoxgpu.h knox_match_wide).
+func MatchWide(c *Ctx, limbs [][]uint64, mode int, a, b []uint64, mask, bits []byte, n int) (int64, bool) {
+	if n == 0 {
+		return 0, true
+	}
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	cols := make([]*C.knox_col, len(limbs))
+	defer func() {
+		for _, p := range cols {
+			if p != nil {
+				C.knox_col_free(p)
+			}
+		}
+	}()
+	const blockUint64 = 5
+	for i, l := range limbs {
+		if rc := C.knox_col_upload(c.p, C.int(blockUint64), unsafe.Pointer(unsafe.SliceData(l)), C.size_t(n), C.size_t(0), &cols[i]); rc != 0 {
+			return 0, false
+		}
+	}
+	var dbits, dmask *C.knox_bits
+	if rc := C.knox_bits_alloc(c.p, C.size_t(n), &dbits); rc != 0 {
+		return 0, false
+	}
+	defer C.knox_bits_free(dbits)
+	if mask != nil {
+		if rc := C.knox_bits_alloc(c.p, C.size_t(n), &dmask); rc != 0 {
+			return 0, false
+		}
+		defer C.knox_bits_free(dmask)
+		if rc := C.knox_bits_upload(c.p, dmask, (*C.uint8_t)(unsafe.SliceData(mask))); rc != 0 {
+			return 0, false
+		}
+	}
+	var bp *C.uint64_t
+	if b != nil {
+		bp = (*C.uint64_t)(unsafe.SliceData(b))
+	}
+	var cnt C.int64_t
+	rc := C.knox_match_wide(c.p, (**C.knox_col)(unsafe.SliceData(cols)), C.int(len(limbs)), C.int(mode),
+		(*C.uint64_t)(unsafe.SliceData(a)), bp, dmask, dbits, &cnt)
+	if rc != 0 {
+		return 0, false
+	}
+	if rc := C.knox_bits_download(c.p, dbits, (*C.uint8_t)(unsafe.SliceData(bits))); rc != 0 {
+		return 0, false
+	}
+	return int64(cnt), true
+}
+
+// ---- the tree boundary: filter.Match over every resident pack + the reducers ---------------------------------
+
+// Pred is one postfix node of a filter.Node tree (knox_pred, include/knoxgpu.h).
+type Pred struct {
+	Kind, NChild, Col, Op int
+	A, B                  uint64 // value bits of the column type (B: Range upper bound)
+	Val, Val2             []byte // bytes leaves / IN sets
+}
+
+const (
+	NodeLeaf, NodeAnd, NodeOr = 0, 1, 2
+)
+
+// Reducer codes follow internal/reducer/reducer.go:25-45.
+const (
+	RSum, RFirst, RLast, RMin, RMax, RMean, RVar, RStd, RCount = 0, 1, 2, 3, 4, 5, 6, 7, 8
+)
+
+type Agg struct{ Func, Col int }
+
+// State is knox_agg_state: the mergeable partial aggregate of one column.
+type State struct{ c C.knox_agg_state }
+
+type ScanResult struct {
+	Count, RowsScanned int64
+	PackCounts         []int64
+	States             []State
+}
+
+// Scan evaluates the tree over rows [0, n) of cols (one fused pass where it can), writes the selection bitset into
+// bitsOut (nullable), and folds the reducers.  packSkip (nullable): 1 = pack pruned by the caller's statistics.
+func (c *Ctx) Scan(nodes []Pred, cols []*Column, aggs []Agg, rowBase uint64, packSkip []byte, bitsOut *Bits, wantPackCounts bool, nPacks int) (*ScanResult, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	cn := make([]C.knox_pred, len(nodes))
+	var pin []unsafe.Pointer // C copies of the byte values: a C struct must not hold Go pointers (cgo rule)
+	defer func() {
+		for _, p := range pin {
+			C.free(p)
+		}
+	}()
+	cbytes := func(v []byte) (*C.uint8_t, C.uint64_t) {
+		if len(v) == 0 {
+			return nil, 0
+		}
+		p := C.CBytes(v)
+		pin = append(pin, p)
+		return (*C.uint8_t)(p), C.uint64_t(len(v))
+	}
+	for i, n := range nodes {
+		cn[i].kind, cn[i].nchild, cn[i].col, cn[i].op = C.int32_t(n.Kind), C.int32_t(n.NChild), C.int32_t(n.Col), C.int32_t(n.Op)
+		cn[i].a, cn[i].b = C.uint64_t(n.A), C.uint64_t(n.B)
+		cn[i].val, cn[i].val_len = cbytes(n.Val)
+		cn[i].val2, cn[i].val2_len = cbytes(n.Val2)
+	}
 	cc := make([]*C.knox_col, len(cols))
 	for i, col := range cols {
 		cc[i] = col.p
 	}
-	states = make([]AggState, max(1, len(aggs)))
-	var out C.knox_scan_out
-	var bp *C.knox_bits
-	if bits != nil {
-		bp = bits.p
+	ca := make([]C.knox_agg, len(aggs)+1)
+	for i, a := range aggs {
+		ca[i]._func, ca[i].col = C.int32_t(a.Func), C.int32_t(a.Col)
 	}
-	var ap *C.knox_agg
+	res := &ScanResult{States: make([]State, len(aggs))}
+	var pc *C.int64_t
+	if wantPackCounts {
+		res.PackCounts = make([]int64, nPacks)
+		pc = (*C.int64_t)(unsafe.SliceData(res.PackCounts))
+	}
+	var skip *C.uint8_t
+	if packSkip != nil {
+		skip = (*C.uint8_t)(unsafe.SliceData(packSkip))
+	}
+	var bo *C.knox_bits
+	if bitsOut != nil {
+		bo = bitsOut.p
+	}
+	var st *C.knox_agg_state
 	if len(aggs) > 0 {
-		ap = &aggs[0]
+		st = (*C.knox_agg_state)(unsafe.Pointer(unsafe.SliceData(res.States)))
 	}
-	rc := C.knox_scan(c.p, &preds[0], C.int(len(preds)), &cc[0], C.int(len(cc)), ap, C.int(len(aggs)),
-		C.uint64_t(rowBase), (*C.uint8_t)(unsafe.SliceData(packSkip)), bp,
-		(*C.int64_t)(unsafe.SliceData(packCounts)), &states[0], &out)
-	return states[:len(aggs)], int64(out.count), errOf(rc)
+	var out C.knox_scan_out
+	rc := C.knox_scan(c.p, (*C.knox_pred)(unsafe.SliceData(cn)), C.int(len(cn)), (**C.knox_col)(unsafe.SliceData(cc)), C.int(len(cc)),
+		(*C.knox_agg)(unsafe.SliceData(ca)), C.int(len(aggs)), C.uint64_t(rowBase), skip, bo, pc, st, &out)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	res.Count, res.RowsScanned = int64(out.count), int64(out.rows_scanned)
+	return res, nil
 }
 
-// UploadBytes holds a StringPool (pkg/stringx/pool.go:45-58: ptr = off<<32 | len, plus the payload) on the device.
-func UploadBytes(c *Ctx, ptr []uint64, buf []byte, packRows int) (*Column, error) {
-	var col *C.knox_col
-	rc := C.knox_col_upload_bytes(c.p, (*C.uint64_t)(unsafe.SliceData(ptr)), C.size_t(len(ptr)),
-		(*C.uint8_t)(unsafe.SliceData(buf)), C.size_t(len(buf)), C.size_t(packRows), &col)
-	return &Column{col}, errOf(rc)
+// Value is Reducer.Value() for reducer fn over a state: the value's raw bits (of the column type), seen, row.
+func (s *State) Value(fn int) (bits uint64, seen bool, row int64) {
+	var v C.uint64_t
+	var sn C.int
+	var r C.int64_t
+	C.knox_agg_value(&s.c, C.int(fn), unsafe.Pointer(&v), &sn, &r)
+	return uint64(v), sn != 0, int64(r)
 }
 
-// MatchRegexp is bytesRegexpMatcher.MatchVector (internal/operator/filter/match_bytes.go:587-609) for a resident
-// bytes column: pattern = re.String().  An error wrapping "unsupported" means the pattern is outside the
-// implemented syntax subset -> keep the re.Match loop for this matcher.
-func MatchRegexp(c *Ctx, col *Column, pattern string, mask, bits *Bits) (int64, error) {
-	var mp *C.knox_bits
-	if mask != nil {
-		mp = mask.p
-	}
-	var cnt C.int64_t
-	pat := []byte(pattern)
-	rc := C.knox_match_regexp(c.p, col.p, (*C.uint8_t)(unsafe.SliceData(pat)), C.uint64_t(len(pat)), mp, bits.p, &cnt)
-	return int64(cnt), errOf(rc)
+// Combine merges states of consecutive row ranges (rank order = row order).
+func Combine(states []State) State {
+	var out State
+	C.knox_agg_combine((*C.knox_agg_state)(unsafe.Pointer(unsafe.SliceData(states))), C.int(len(states)), &out.c)
+	return out
 }
 
-// ReduceBuckets is what pkg/series feeds row by row into NativeBucket.Push (internal/reducer/bucket_native.go:
-// 104-159): one mergeable state per window [from + k*step, from + (k+1)*step); timestamps in any order.
-func ReduceBuckets(c *Ctx, timeCol, valueCol *Column, mask *Bits, from, step int64, nBuckets int, rowBase uint64,
-	moments bool) ([]AggState, error) {
-	var mp *C.knox_bits
-	if mask != nil {
-		mp = mask.p
+// ---- per-pack bloom pre-filter (internal/filter/bloom/bloom.go:136-150) ------------------------------------------
+
+type Bloom struct{ p *C.knox_bloom }
+
+func BuildBloom(c *Ctx, col *Column, factor int) (*Bloom, error) {
+	var b *C.knox_bloom
+	if rc := C.knox_bloom_build(c.p, col.p, C.int(factor), &b); rc != 0 {
+		return nil, errOf(rc)
 	}
-	flags := C.int(0)
-	if moments {
-		flags |= 2
-	}
-	states := make([]AggState, nBuckets)
-	rc := C.knox_reduce_buckets(c.p, timeCol.p, valueCol.p, mp, C.int64_t(from), C.int64_t(step), C.size_t(nBuckets),
-		C.uint64_t(rowBase), flags, &states[0])
-	return states, errOf(rc)
+	return &Bloom{b}, nil
 }
 
-// ReduceBucketsLiteral applies the reference's own reducer (plain or join, reducer.go:130-731) row by row per
-// window: values[k], seen[k] = Reducer.Value() of window k, bit for bit.  fn = knox_reducer, T = the column type.
-func ReduceBucketsLiteral[T Number](c *Ctx, timeCol, valueCol *Column, mask *Bits, from, step int64, nBuckets, fn int) ([]T, []bool, error) {
-	var mp *C.knox_bits
-	if mask != nil {
-		mp = mask.p
-	}
-	vals := make([]T, nBuckets)
-	seen8 := make([]uint8, nBuckets)
-	rc := C.knox_reduce_buckets_sequential(c.p, timeCol.p, valueCol.p, mp, C.int64_t(from), C.int64_t(step),
-		C.size_t(nBuckets), C.int(fn), 0, unsafe.Pointer(unsafe.SliceData(vals)), (*C.uint8_t)(unsafe.SliceData(seen8)))
-	seen := make([]bool, nBuckets)
-	for i, s := range seen8 {
-		seen[i] = s != 0
-	}
-	return vals, seen, errOf(rc)
+// Probe = Filter.Contains(h) for every pack: maybe[p] == 1 when pack p may hold hash h.
+func (b *Bloom) Probe(c *Ctx, h uint64, maybe []byte) error {
+	return errOf(C.knox_bloom_probe(c.p, b.p, C.uint64_t(h), (*C.uint8_t)(unsafe.SliceData(maybe))))
 }
 
-// FillWindows is the gap walk of NativeBucket.Emit (bucket_native.go:161-218) with Fill (fill.go:59-85) over dense
-// window values: flags[k] 0 = nothing emitted, 1 = out[k], 2 = null.  mode = knox_fill_mode; Emit keeps only the
-// string formatting.
-func FillWindows[T Number](dtype, mode int, vals []T, seen []uint8, from, step, unitsPerSecond int64, limit int) ([]T, []uint8, int, error) {
-	out := make([]T, len(vals))
-	flags := make([]uint8, len(vals))
-	var n C.size_t
-	rc := C.knox_fill_windows(C.int(dtype), C.int(mode), unsafe.Pointer(unsafe.SliceData(vals)), (*C.uint8_t)(unsafe.SliceData(seen)),
-		C.size_t(len(vals)), C.int64_t(from), C.int64_t(step), C.int64_t(unitsPerSecond), C.size_t(limit),
-		unsafe.Pointer(unsafe.SliceData(out)), (*C.uint8_t)(unsafe.SliceData(flags)), &n)
-	return out, flags, int(n), errOf(rc)
+func (b *Bloom) Free() { C.knox_bloom_free(b.p) }
+
+// HashBytes = hash.Hash (internal/hash/hash.go:26, zeebo/xxh3): the probe value of a bytes matcher.
+func HashBytes(v []byte) uint64 {
+	return uint64(C.knox_hash_bytes((*C.uint8_t)(unsafe.SliceData(v)), C.size_t(len(v))))
+}
+
+// ---- multi-GPU: the final aggregate only (one process per GPU, RCCL over xGMI) -----------------------------------
+
+func (c *Ctx) CommInit(nRanks, rank int, id [128]byte) error {
+	return errOf(C.knox_comm_init(c.p, C.int(nRanks), C.int(rank), (*C.uint8_t)(unsafe.Pointer(&id[0]))))
+}
+
+// AllReduceSumCount: ONE ncclAllReduce(int64, sum) of {wrapping sum, count} over all ranks.
+func (c *Ctx) AllReduceSumCount(isum uint64, count int64) (uint64, int64, error) {
+	s, n := C.uint64_t(isum), C.int64_t(count)
+	rc := C.knox_comm_allreduce_sum_count(c.p, &s, &n)
+	return uint64(s), int64(n), errOf(rc)
+}
+
+// AllGatherStates: what min / max / first / last / float sums need (rank order = row order).
+func (c *Ctx) AllGatherStates(mine []State, count int64) ([]State, int64, error) {
+	merged := make([]State, len(mine))
+	n := C.int64_t(count)
+	rc := C.knox_comm_allgather_states(c.p, (*C.knox_agg_state)(unsafe.Pointer(unsafe.SliceData(mine))), C.int(len(mine)),
+		(*C.knox_agg_state)(unsafe.Pointer(unsafe.SliceData(merged))), &n)
+	return merged, int64(n), errOf(rc)
 }

@@ -1,0 +1,298 @@
+//go:build knoxgpu
+
+// Drop into internal/operator/ of blockwatch-cc/knoxdb.  The tree-level boundary:
+//
+//   PhysicalGpuFilter   a PushOperator (operator.go:37-42) with the contract of PhysicalFilter (filter.go:16-58):
+//                       Process evaluates the whole filter.Node tree over one package in ONE knox_scan (instead of
+//                       filter.Match's per-leaf MatchVector + Bitset.And / Or, match_core.go:14-190) and sets the
+//                       package's selection the same way (nil selection when every row matches).
+//   GpuAggregateResult  an engine.QueryResultConsumer (engine/interface.go:154-157) with the role of CountResult
+//                       (query/result.go:36-60): Append folds the reducers over the selected rows of every package
+//                       it is handed; states merge exactly (knox_agg_combine), Value() finalises.
+//
+// Columns of a package are uploaded once and kept on the device keyed by (pack key, version, field): the second query
+// over the same pack reads HBM only.  Packages with non-materialized blocks, or trees with leaf kinds the device
+// plan does not take, fall back to the CPU operator.
+// Not compiled in the knoxdb_amd repository (no Go toolchain there); see integration/check_go_calls.py.
+package operator
+
+import (
+	"context"
+	"math"
+
+	"blockwatch.cc/knoxdb/internal/bitset"
+	"blockwatch.cc/knoxdb/internal/block"
+	"blockwatch.cc/knoxdb/internal/knoxgpu"
+	"blockwatch.cc/knoxdb/internal/operator/filter"
+	"blockwatch.cc/knoxdb/internal/pack"
+	"blockwatch.cc/knoxdb/internal/types"
+)
+
+var (
+	_ PushOperator = (*PhysicalGpuFilter)(nil)
+)
+
+type colKey struct {
+	pack, version uint32
+	field         int
+}
+
+// deviceCols is the device-resident pack cache of one operator: bounded by the context's arena budget
+// (knoxgpu.Ctx.SetArena); a failing upload drops the oldest half and retries once.
+type deviceCols struct {
+	gpu   *knoxgpu.Ctx
+	cols  map[colKey]*knoxgpu.Column
+	order []colKey
+}
+
+func (d *deviceCols) get(pkg *pack.Package, field int) (*knoxgpu.Column, bool) {
+	k := colKey{pkg.Key(), pkg.Version(), field}
+	if c, ok := d.cols[k]; ok {
+		return c, true
+	}
+	b := pkg.Block(field)
+	if b == nil || !b.IsMaterialized() {
+		return nil, false
+	}
+	c, err := uploadBlock(d.gpu, b)
+	if err != nil {
+		d.evict(len(d.order) / 2)
+		if c, err = uploadBlock(d.gpu, b); err != nil {
+			return nil, false
+		}
+	}
+	d.cols[k] = c
+	d.order = append(d.order, k)
+	return c, true
+}
+
+func (d *deviceCols) evict(n int) {
+	for _, k := range d.order[:n] {
+		d.cols[k].Free()
+		delete(d.cols, k)
+	}
+	d.order = d.order[n:]
+}
+
+func uploadBlock(g *knoxgpu.Ctx, b *block.Block) (*knoxgpu.Column, error) {
+	t := int(b.Type())
+	switch b.Type() {
+	case types.BlockInt64:
+		return knoxgpu.Upload(g, t, block.NewAccessor[int64](b).Slice(), 0)
+	case types.BlockInt32:
+		return knoxgpu.Upload(g, t, block.NewAccessor[int32](b).Slice(), 0)
+	case types.BlockInt16:
+		return knoxgpu.Upload(g, t, block.NewAccessor[int16](b).Slice(), 0)
+	case types.BlockInt8:
+		return knoxgpu.Upload(g, t, block.NewAccessor[int8](b).Slice(), 0)
+	case types.BlockUint64:
+		return knoxgpu.Upload(g, t, block.NewAccessor[uint64](b).Slice(), 0)
+	case types.BlockUint32:
+		return knoxgpu.Upload(g, t, block.NewAccessor[uint32](b).Slice(), 0)
+	case types.BlockUint16:
+		return knoxgpu.Upload(g, t, block.NewAccessor[uint16](b).Slice(), 0)
+	case types.BlockUint8:
+		return knoxgpu.Upload(g, t, block.NewAccessor[uint8](b).Slice(), 0)
+	case types.BlockFloat64:
+		return knoxgpu.Upload(g, t, block.NewAccessor[float64](b).Slice(), 0)
+	case types.BlockFloat32:
+		return knoxgpu.Upload(g, t, block.NewAccessor[float32](b).Slice(), 0)
+	}
+	return nil, ErrTodo
+}
+
+// valueBits: the raw bits of a filter value of the column type, zero-extended (knox_pred.a / .b).
+func valueBits(v any) (uint64, bool) {
+	switch x := v.(type) {
+	case int64:
+		return uint64(x), true
+	case int32:
+		return uint64(uint32(x)), true
+	case int16:
+		return uint64(uint16(x)), true
+	case int8:
+		return uint64(uint8(x)), true
+	case uint64:
+		return x, true
+	case uint32:
+		return uint64(x), true
+	case uint16:
+		return uint64(x), true
+	case uint8:
+		return uint64(x), true
+	case float64:
+		return math.Float64bits(x), true
+	case float32:
+		return uint64(math.Float32bits(x)), true
+	}
+	return 0, false
+}
+
+// plan flattens a filter.Node tree (node.go:29-37) into the postfix form knox_scan takes: operands first, then one
+// AND / OR node popping nchild results.  cols receives the device columns in leaf order.  AnyMatch / Skip nodes are
+// dropped exactly where MatchAnd / MatchOr skip them (match_core.go:55-58, 129-135).
+func (op *PhysicalGpuFilter) plan(n *filter.Node, pkg *pack.Package, nodes []knoxgpu.Pred, cols []*knoxgpu.Column) ([]knoxgpu.Pred, []*knoxgpu.Column, bool) {
+	if n.IsLeaf() {
+		f := n.Filter
+		col, ok := op.dev.get(pkg, f.Index)
+		if !ok {
+			return nodes, cols, false
+		}
+		p := knoxgpu.Pred{Kind: knoxgpu.NodeLeaf, Col: len(cols), Op: int(f.Mode)}
+		switch f.Mode {
+		case types.FilterModeEqual, types.FilterModeNotEqual, types.FilterModeGt, types.FilterModeGe,
+			types.FilterModeLt, types.FilterModeLe:
+			if p.A, ok = valueBits(f.Value); !ok {
+				return nodes, cols, false
+			}
+		case types.FilterModeRange:
+			rg, isRange := f.Value.(filter.RangeValue)
+			if !isRange {
+				return nodes, cols, false
+			}
+			var okA, okB bool
+			p.A, okA = valueBits(rg[0])
+			p.B, okB = valueBits(rg[1])
+			if !okA || !okB {
+				return nodes, cols, false
+			}
+		default:
+			return nodes, cols, false // IN / NOT IN / regexp leaves: host-side sets are marshalled by the caller
+		}
+		return append(nodes, p), append(cols, col), true
+	}
+	kids := 0
+	for _, c := range n.Children {
+		if c.IsAnyMatch() || c.Skip {
+			continue
+		}
+		var ok bool
+		if nodes, cols, ok = op.plan(c, pkg, nodes, cols); !ok {
+			return nodes, cols, false
+		}
+		kids++
+	}
+	kind := knoxgpu.NodeAnd
+	if n.OrKind {
+		kind = knoxgpu.NodeOr
+	}
+	return append(nodes, knoxgpu.Pred{Kind: kind, NChild: kids}), cols, true
+}
+
+type PhysicalGpuFilter struct {
+	cpu  *PhysicalFilter // the fallback, same node
+	node *filter.Node
+	gpu  *knoxgpu.Ctx
+	dev  *deviceCols
+	bits *bitset.Bitset
+	err  error
+}
+
+// NewPhysicalGpuFilter has NewPhysicalFilter's signature (filter.go:22-27) plus the device context.
+func NewPhysicalGpuFilter(gpu *knoxgpu.Ctx, node *filter.Node, sz int) *PhysicalGpuFilter {
+	return &PhysicalGpuFilter{
+		cpu:  NewPhysicalFilter(node, sz),
+		node: node,
+		gpu:  gpu,
+		dev:  &deviceCols{gpu: gpu, cols: make(map[colKey]*knoxgpu.Column)},
+		bits: bitset.New(sz),
+	}
+}
+
+func (op *PhysicalGpuFilter) Process(ctx context.Context, src *pack.Package) (*pack.Package, Result) {
+	nodes, cols, ok := op.plan(op.node, src, nil, nil)
+	if !ok || len(cols) == 0 {
+		return op.cpu.Process(ctx, src)
+	}
+	dbits, err := knoxgpu.NewBitsFor(op.gpu, src.Len(), cols[0])
+	if err != nil {
+		return op.cpu.Process(ctx, src)
+	}
+	defer dbits.Free()
+	res, err := op.gpu.Scan(nodes, cols, nil, 0, nil, dbits, false, 1)
+	if err != nil {
+		return op.cpu.Process(ctx, src)
+	}
+	switch {
+	case res.Count == int64(src.Len()):
+		src.WithSelection(nil) // PhysicalFilter: `if op.bits.All()` (filter.go:31-32)
+	default:
+		sel, err := dbits.Indexes(op.gpu, make([]uint32, 0, res.Count))
+		if err != nil {
+			return op.cpu.Process(ctx, src)
+		}
+		src.WithSelection(sel)
+	}
+	return src, ResultOK
+}
+
+func (op *PhysicalGpuFilter) Finalize(ctx context.Context) error { return nil }
+func (op *PhysicalGpuFilter) Err() error                         { return op.err }
+
+func (op *PhysicalGpuFilter) Close() {
+	op.dev.evict(len(op.dev.order))
+	op.cpu.Close()
+	op.node = nil
+	op.bits.Close()
+	op.bits = nil
+	op.err = nil
+}
+
+// GpuAggregateResult folds reducers over the rows a filter selected, package by package.
+type GpuAggregateResult struct {
+	gpu    *knoxgpu.Ctx
+	node   *filter.Node
+	filter *PhysicalGpuFilter
+	aggs   []knoxgpu.Agg // Col = the FIELD index here; remapped to the scan's column list per package
+	states [][]knoxgpu.State
+	rows   int64
+	n      int
+}
+
+// NewGpuAggregateResult: aggs name a reducer (knoxgpu.RSum ...) and a field index of the package schema.
+func NewGpuAggregateResult(gpu *knoxgpu.Ctx, node *filter.Node, aggs []knoxgpu.Agg) *GpuAggregateResult {
+	return &GpuAggregateResult{gpu: gpu, node: node, filter: NewPhysicalGpuFilter(gpu, node, 0), aggs: aggs,
+		states: make([][]knoxgpu.State, len(aggs))}
+}
+
+// Append runs filter + reducers over one package in one fused scan; rows ids are offset by the rows seen so far, so
+// first / last / min / max report positions in stream order (rank order = row order across packages).
+func (r *GpuAggregateResult) Append(ctx context.Context, src *pack.Package) error {
+	nodes, cols, ok := r.filter.plan(r.node, src, nil, nil)
+	if !ok {
+		return ErrTodo
+	}
+	aggs := make([]knoxgpu.Agg, len(r.aggs))
+	for i, a := range r.aggs {
+		c, ok := r.filter.dev.get(src, a.Col)
+		if !ok {
+			return ErrTodo
+		}
+		aggs[i] = knoxgpu.Agg{Func: a.Func, Col: len(cols)}
+		cols = append(cols, c)
+	}
+	res, err := r.gpu.Scan(nodes, cols, aggs, uint64(r.rows), nil, nil, false, 1)
+	if err != nil {
+		return err
+	}
+	for i := range aggs {
+		r.states[i] = append(r.states[i], res.States[i])
+	}
+	r.rows += int64(src.Len())
+	r.n += int(res.Count)
+	return nil
+}
+
+func (r *GpuAggregateResult) Len() int { return r.n }
+
+// Value finalises aggregate i: the reducer's Value() bits (of the field's type) and its `ok`.
+func (r *GpuAggregateResult) Value(i int) (uint64, bool) {
+	if len(r.states[i]) == 0 {
+		return 0, false
+	}
+	st := knoxgpu.Combine(r.states[i])
+	bits, seen, _ := st.Value(r.aggs[i].Func)
+	return bits, seen
+}
+
+func (r *GpuAggregateResult) Close() { r.filter.Close() }

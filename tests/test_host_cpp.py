@@ -8,6 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_host")
+GO_EXE = os.path.join(ROOT, "tests", "cpp", "test_go_entries")
 
 
 def _build():
@@ -28,3 +29,24 @@ def test_host_mirror_runs_on_gpu():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host mirror ok" in out.stdout
+
+
+def _build_go_entries():
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "test_go_entries.cpp"),
+           "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "knoxdb_amd"), "-lknoxgpu",
+           "-Wl,-rpath," + os.path.join(ROOT, "knoxdb_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", GO_EXE]
+    subprocess.check_call(cmd)
+
+
+def test_go_entry_mirror_compiles_against_the_header():
+    """tests/cpp/test_go_entries.cpp makes the C calls of integration/go/knoxgpu/knoxgpu.go, wrapper by wrapper"""
+    _build_go_entries()
+    assert os.path.exists(GO_EXE)
+
+
+@pytest.mark.gpu
+def test_go_entry_mirror_runs_on_gpu():
+    _build_go_entries()
+    out = subprocess.run([GO_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "go entries ok" in out.stdout
