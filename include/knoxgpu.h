@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KNOX_ABI_VERSION 3
+#define KNOX_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------------- */
 enum knox_err {
@@ -274,6 +274,21 @@ int knox_bits_popcount_segments(knox_ctx *ctx, const knox_bits *b, size_t seg_bi
 /* Indexes :355 / Bitset.Indexes iterator.go:269: ascending uint32 row ids.  `capacity`
  * entries available in `rows` (host); *n_out receives the number written (= popcount).     */
 int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t capacity, size_t *n_out);
+/* The same into the context's own page-locked result buffer -- the default for large selections: no capacity to
+ * guess (the set bits are counted first) and no copy into pageable memory, whose first touch costs several times the
+ * PCIe transfer.  *rows_view points at *n_out row ids and stays valid until the next knox_bits_indexes_view /
+ * knox_reduce_buckets_values call on this ctx (Go: unsafe.Slice(view, n), copy out if it must outlive that).        */
+int knox_bits_indexes_view(knox_ctx *ctx, const knox_bits *b, const uint32_t **rows_view, size_t *n_out);
+/* Enqueue-only forms of the flag / count producing calls: the result lands in the SAME 4-slot result ring
+ * knox_scan_async uses (FIFO; a 5th uncollected result returns KNOX_E_BUSY), so a host walking a filter tree the way
+ * MatchAnd / MatchOr do (match_core.go:45-190) can enqueue several leaf merges and read their flags afterwards without
+ * a blocking read-back per call.  knox_bits_collect returns the OLDEST uncollected result, which must be a bitset
+ * result (a scan is collected by knox_scan_collect; the wrong collector returns KNOX_E_INVALID and consumes nothing):
+ * and_flag / or_flag fill any / all (count = -1), popcount fills count (any = all = -1).  All three nullable.        */
+int knox_bits_and_flag_async(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);
+int knox_bits_or_flag_async(knox_ctx *ctx, knox_bits *dst, const knox_bits *src);
+int knox_bits_popcount_async(knox_ctx *ctx, const knox_bits *b);
+int knox_bits_collect(knox_ctx *ctx, int *any, int *all, int64_t *count);
 
 /* Bool columns are bitsets; their vector matchers (internal/bitset/match.go:14-62 MatchEqual ..
  * MatchBetween) are copies / negations of the column.  `bits` must be zeroed by the caller; modes
@@ -450,6 +465,16 @@ int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mas
 int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                         const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                         size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states);
+
+/* Values only: Reducer.Value() of reducer `func` (KNOX_R_SUM .. KNOX_R_COUNT) for every window, finalised ON THE DEVICE
+ * by the same code knox_agg_value runs on the host (bit-identical by construction), so 8 + 1 bytes per window cross
+ * PCIe instead of a 144-byte state: values_view = n_buckets values of the column's type, seen_view[k] = Value()'s ok
+ * (0: the reference created no reducer for the window).  Both point into the context's page-locked result buffer and
+ * stay valid until the next knox_reduce_buckets_values / knox_bits_indexes_view call on this ctx.  flags bit0 as above;
+ * the var / std pass runs by itself for KNOX_R_VAR / KNOX_R_STD.  Feed the views to knox_fill_windows for Emit's gaps. */
+int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
+                               const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
+                               size_t n_buckets, int func, int flags, const void **values_view, const uint8_t **seen_view);
 
 /* The literal form of the same: window k's reducer is the reference's own, applied row by row
  * (one lane per window), so Value() is bit-exact for EVERY reducer -- Welford mean / var / std

@@ -122,6 +122,11 @@ SIGNATURES = {
     "knox_bits_popcount_segments": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "knox_bits_match_bool": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "knox_bits_indexes": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "knox_bits_indexes_view": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "knox_bits_and_flag_async": (_i, [_vp, _vp, _vp]),
+    "knox_bits_or_flag_async": (_i, [_vp, _vp, _vp]),
+    "knox_bits_popcount_async": (_i, [_vp, _vp]),
+    "knox_bits_collect": (_i, [_vp, _pi, _pi, C.POINTER(_i64)]),
     "knox_scan": (_i, [_vp, C.POINTER(Pred), _i, _pp, _i, C.POINTER(Agg), _i, _u64, _vp, _vp, _vp,
                        C.POINTER(AggState), C.POINTER(ScanOut)]),
     "knox_scan_async": (_i, [_vp, C.POINTER(Pred), _i, _pp, _i, C.POINTER(Agg), _i, _u64, _vp, _vp, _i]),
@@ -143,6 +148,7 @@ SIGNATURES = {
     "knox_match_wide": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, C.POINTER(_i64)]),
     "knox_reduce_moments": (_i, [_vp, _vp, _vp, C.POINTER(AggState)]),
     "knox_reduce_buckets": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(AggState)]),
+    "knox_reduce_buckets_values": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "knox_match_regexp": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, C.POINTER(_i64)]),
     "knox_regexp_match_value": (_i, [_vp, _u64, _vp, _u64]),
     "knox_reduce_buckets_sequential": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _i, _i, _vp, _vp]),

@@ -22,6 +22,7 @@
 
 #include "../../include/knoxgpu.h"
 #include "knox_arena.h"
+#include "knox_finalize.h"
 #include "knox_kernels.h"
 #include "knox_regex.h"
 #include "knox_xxh3.h"  // host flavour: KNOX_HD / KNOX_XXH3_CONST empty
@@ -69,7 +70,8 @@ struct knox_ctx {
     DevBuf tile_counts;  // fused scan: popcount per wave tile -> per-pack counts
     uint32_t tc_grid = 0, tc_rounds = 0;  // layout of tile_counts as the last scan wrote it
     DevBuf idx_scratch;  // indexes: block offsets
-    DevBuf idx_rows;     // indexes: row ids
+    DevBuf idx_rows;     // indexes: row ids; window sort: the keys of all rows
+    DevBuf sort_buf;     // window sort: the (key, row, value) triples, one or two sets
     DevBuf bytes_val;    // bytes leaf value
     // ring of pinned result mirrors: up to kResRing scans may be in flight (software
     // pipelining: enqueue scan i+1 before collecting scan i keeps the device busy)
@@ -84,9 +86,15 @@ struct knox_ctx {
         size_t n_packs = 0;
         bool has_pack_counts = false;
         uint64_t rows_scanned = 0;
+        int kind = 0;          // 0 scan, 1 bitset flags (any / all), 2 popcount
+        size_t bits_size = 0;  // kind 1: the bitset's size ("all" of an empty bitset is false)
     };
     static constexpr int kResRing = 4;
-    ResSlot res[kResRing];
+    ResSlot res[kResRing + 1];  // [kResRing]: the blocking bitset calls' own slot, never part of the FIFO
+    DevBuf ring_dev;            // 16 bytes of device results per slot (flags / popcount)
+    // large results (row ids, per-window values) land here; the *_view entry points hand out pointers into it
+    void *h_view = nullptr;
+    size_t h_view_cap = 0;
     uint64_t res_head = 0, res_tail = 0;  // head: next slot to fill, tail: oldest uncollected
     // per-kernel stopwatch (knox_prof_*)
     bool prof = false;
@@ -333,7 +341,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
-                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->bytes_val};
+                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->sort_buf, &ctx->bytes_val, &ctx->ring_dev};
     for (DevBuf *b : bufs) dev_free(ctx, b->p);
     if (ctx->comm_buf.p) hipFree(ctx->comm_buf.p);
     if (ctx->probe_partials) hipFree(ctx->probe_partials);
@@ -348,6 +356,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
         if (e) hipEventDestroy(e);
     for (auto &r : ctx->res) {
         if (r.h_res) hipHostFree(r.h_res);
+        if (ctx->h_view) { hipHostFree(ctx->h_view); ctx->h_view = nullptr; }
         if (r.h_packs) hipHostFree(r.h_packs);
         if (r.done) hipEventDestroy(r.done);
     }
@@ -571,13 +580,26 @@ static int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
     }
     int rc = stage_init(ctx);
     if (rc) return rc;
-    size_t off = 0;
-    while (off < bytes) {
-        const size_t n = std::min(bytes - off, knox_ctx::kStageBytes);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->stage[0], (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy((char *)dst + off, ctx->stage[0], n);
-        off += n;
+    // two ring slots: the DMA of chunk i+1 runs while chunk i is copied out to the caller's pageable memory
+    const size_t chunk = std::min<size_t>(knox_ctx::kStageBytes, (size_t)4 << 20);
+    size_t issued = 0, copied = 0;
+    int slot = 0;
+    size_t len[2] = {0, 0};
+    while (copied < bytes) {
+        while (issued < bytes && issued - copied < 2 * chunk && len[slot] == 0) {
+            const size_t n = std::min(bytes - issued, chunk);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->stage[slot], (const char *)src + issued, n, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+            len[slot] = n;
+            issued += n;
+            slot ^= 1;
+        }
+        const int done = len[slot] ? slot : slot ^ 1;  // the older of the slots in flight
+        HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[done]));
+        memcpy((char *)dst + copied, ctx->stage[done], len[done]);
+        copied += len[done];
+        len[done] = 0;
+        slot = done;
     }
     return KNOX_OK;
 }
@@ -1579,30 +1601,119 @@ KNOX_API int knox_bits_download(knox_ctx *ctx, const knox_bits *b, uint8_t *host
     return download(ctx, host, b->dev, bits_bytes(b->size));
 }
 
-static int bitop(knox_ctx *ctx, int op, knox_bits *dst, const knox_bits *src, int *any, int *all) {
-    if (!ctx || !dst) return KNOX_E_INVALID;
-    const bool binary = (op == BIT_AND || op == BIT_ANDNOT || op == BIT_OR || op == BIT_XOR || op == BIT_COPY);
-    if (binary && (!src || src->size != dst->size)) return KNOX_E_INVALID;  // size mismatch is a no-op in Go (bitset.go:400-518); an error here
-    hipSetDevice(ctx->device);
+// flag / count producing bitset calls write into a result slot: 16 device bytes -> the slot's pinned mirror + its event.
+// The blocking entry points use the extra slot [kResRing] and wait; the *_async ones take the next ring slot (the FIFO
+// knox_scan_async uses) and return.
+static int slot_prepare(knox_ctx *ctx, int slot_idx, uint32_t **dev16) {
+    int rc = ensure(ctx, ctx->ring_dev, 16 * (knox_ctx::kResRing + 1));
+    knox_ctx::ResSlot &slot = ctx->res[slot_idx];
+    if (!rc) rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, 16);
+    if (rc) return rc;
+    if (!slot.done) HIPCHK(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    *dev16 = (uint32_t *)((char *)ctx->ring_dev.p + 16 * slot_idx);
+    HIPCHK(ctx, hipMemsetAsync(*dev16, 0, 16, ctx->stream));
+    return KNOX_OK;
+}
+
+static int slot_finish(knox_ctx *ctx, int slot_idx, const uint32_t *dev16, int kind, size_t bits_size) {
+    knox_ctx::ResSlot &slot = ctx->res[slot_idx];
+    HIPCHK(ctx, hipMemcpyAsync(slot.h_res, dev16, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(slot.done, ctx->stream));
+    slot.kind = kind;
+    slot.bits_size = bits_size;
+    return KNOX_OK;
+}
+
+static int bitop_into_slot(knox_ctx *ctx, int op, knox_bits *dst, const knox_bits *src, int slot_idx) {
     uint32_t *flags = nullptr;
-    if (any || all) {
-        int rc = ensure(ctx, ctx->misc, 256);
-        if (rc) return rc;
-        flags = (uint32_t *)ctx->misc.p;
-        HIPCHK(ctx, hipMemsetAsync(flags, 0, 8, ctx->stream));
-    }
+    int rc = slot_prepare(ctx, slot_idx, &flags);
+    if (rc) return rc;
     hipError_t e = launch_bitop(ctx->stream, op, dst->dev, src ? src->dev : nullptr, dst->size, flags);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         return KNOX_E_HIP;
     }
-    if (flags) {
-        uint32_t h[2] = {0, 0};
-        HIPCHK(ctx, hipMemcpyAsync(h, flags, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (any) *any = h[0] != 0;
-        if (all) *all = (dst->size > 0) && (h[1] == 0);
+    return slot_finish(ctx, slot_idx, flags, 1, dst->size);
+}
+
+static int popcount_into_slot(knox_ctx *ctx, const knox_bits *b, int slot_idx) {
+    uint32_t *d = nullptr;
+    int rc = slot_prepare(ctx, slot_idx, &d);
+    if (rc) return rc;
+    hipError_t e = launch_popcount(ctx->stream, b->dev, b->size, (unsigned long long *)d);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
     }
+    return slot_finish(ctx, slot_idx, d, 2, b->size);
+}
+
+static int slot_read(knox_ctx *ctx, int slot_idx, int *any, int *all, int64_t *count) {
+    knox_ctx::ResSlot &slot = ctx->res[slot_idx];
+    HIPCHK(ctx, hipEventSynchronize(slot.done));
+    if (slot.kind == 1) {
+        const uint32_t *h = (const uint32_t *)slot.h_res;
+        if (any) *any = h[0] != 0;
+        if (all) *all = (slot.bits_size > 0) && (h[1] == 0);
+        if (count) *count = -1;
+    } else {
+        if (count) *count = (int64_t) * (const unsigned long long *)slot.h_res;
+        if (any) *any = -1;
+        if (all) *all = -1;
+    }
+    return KNOX_OK;
+}
+
+static int bitop(knox_ctx *ctx, int op, knox_bits *dst, const knox_bits *src, int *any, int *all) {
+    if (!ctx || !dst) return KNOX_E_INVALID;
+    const bool binary = (op == BIT_AND || op == BIT_ANDNOT || op == BIT_OR || op == BIT_XOR || op == BIT_COPY);
+    if (binary && (!src || src->size != dst->size)) return KNOX_E_INVALID;  // size mismatch is a no-op in Go (bitset.go:400-518); an error here
+    hipSetDevice(ctx->device);
+    if (any || all) {
+        int rc = bitop_into_slot(ctx, op, dst, src, knox_ctx::kResRing);
+        if (rc) return rc;
+        return slot_read(ctx, knox_ctx::kResRing, any, all, nullptr);
+    }
+    hipError_t e = launch_bitop(ctx->stream, op, dst->dev, src ? src->dev : nullptr, dst->size, nullptr);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
+
+static int bitop_async(knox_ctx *ctx, int op, knox_bits *dst, const knox_bits *src) {
+    if (!ctx || !dst || !src || src->size != dst->size) return KNOX_E_INVALID;
+    if (ctx->res_head - ctx->res_tail >= (uint64_t)knox_ctx::kResRing) return KNOX_E_BUSY;  // collect first
+    hipSetDevice(ctx->device);
+    int rc = bitop_into_slot(ctx, op, dst, src, (int)(ctx->res_head % knox_ctx::kResRing));
+    if (rc) return rc;
+    ctx->res_head++;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bits_and_flag_async(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop_async(ctx, BIT_AND, dst, src); }
+KNOX_API int knox_bits_or_flag_async(knox_ctx *ctx, knox_bits *dst, const knox_bits *src) { return bitop_async(ctx, BIT_OR, dst, src); }
+
+KNOX_API int knox_bits_popcount_async(knox_ctx *ctx, const knox_bits *b) {
+    if (!ctx || !b) return KNOX_E_INVALID;
+    if (ctx->res_head - ctx->res_tail >= (uint64_t)knox_ctx::kResRing) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    int rc = popcount_into_slot(ctx, b, (int)(ctx->res_head % knox_ctx::kResRing));
+    if (rc) return rc;
+    ctx->res_head++;
+    return KNOX_OK;
+}
+
+// the OLDEST uncollected result of the ring, which must be a bitset result (a scan is collected by knox_scan_collect)
+KNOX_API int knox_bits_collect(knox_ctx *ctx, int *any, int *all, int64_t *count) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (ctx->res_tail == ctx->res_head) return KNOX_E_INVALID;  // nothing in flight
+    const int idx = (int)(ctx->res_tail % knox_ctx::kResRing);
+    if (ctx->res[idx].kind == 0) return KNOX_E_INVALID;
+    int rc = slot_read(ctx, idx, any, all, count);
+    if (rc) return rc;
+    ctx->res_tail++;
     return KNOX_OK;
 }
 
@@ -1746,20 +1857,9 @@ KNOX_API int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_li
 KNOX_API int knox_bits_popcount(knox_ctx *ctx, const knox_bits *b, int64_t *count) {
     if (!ctx || !b || !count) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
-    int rc = ensure(ctx, ctx->misc, 256);
+    int rc = popcount_into_slot(ctx, b, knox_ctx::kResRing);
     if (rc) return rc;
-    unsigned long long *d = (unsigned long long *)((char *)ctx->misc.p + 64);
-    HIPCHK(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
-    hipError_t e = launch_popcount(ctx->stream, b->dev, b->size, d);
-    if (e != hipSuccess) {
-        ctx->last_hip = (int)e;
-        return KNOX_E_HIP;
-    }
-    unsigned long long h = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *count = (int64_t)h;
-    return KNOX_OK;
+    return slot_read(ctx, knox_ctx::kResRing, nullptr, nullptr, count);
 }
 
 KNOX_API int knox_bits_popcount_segments(knox_ctx *ctx, const knox_bits *b, size_t seg_bits, int64_t *counts, size_t n_counts) {
@@ -1777,8 +1877,8 @@ KNOX_API int knox_bits_popcount_segments(knox_ctx *ctx, const knox_bits *b, size
     return download(ctx, counts, ctx->pack_counts.p, n_seg * 8);
 }
 
-KNOX_API int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t capacity, size_t *n_out) {
-    if (!ctx || !b || !n_out || (capacity && !rows)) return KNOX_E_INVALID;
+// row ids of the set bits into ctx->idx_rows (device); *n = how many there are
+static int indexes_dev(knox_ctx *ctx, const knox_bits *b, size_t capacity, size_t *n) {
     if (b->size > 0xffffffffull) return KNOX_E_RANGE;  // uint32 row ids (pack-local in the reference)
     hipSetDevice(ctx->device);
     const size_t nwords = (b->size + 63) >> 6;
@@ -1796,9 +1896,36 @@ KNOX_API int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows
     unsigned long long h = 0;
     HIPCHK(ctx, hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *n_out = (size_t)h;
-    if (h > capacity) return KNOX_E_RANGE;
-    return download(ctx, rows, ctx->idx_rows.p, (size_t)h * 4);
+    *n = (size_t)h;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_bits_indexes(knox_ctx *ctx, const knox_bits *b, uint32_t *rows, size_t capacity, size_t *n_out) {
+    if (!ctx || !b || !n_out || (capacity && !rows)) return KNOX_E_INVALID;
+    int rc = indexes_dev(ctx, b, capacity, n_out);
+    if (rc) return rc;
+    if (*n_out > capacity) return KNOX_E_RANGE;
+    return download(ctx, rows, ctx->idx_rows.p, *n_out * 4);
+}
+
+// The same into the context's page-locked result buffer: no capacity to guess, no copy into pageable memory (whose
+// first touch costs more than the transfer).  *rows_view stays valid until the next *_view / *_values call on the ctx.
+KNOX_API int knox_bits_indexes_view(knox_ctx *ctx, const knox_bits *b, const uint32_t **rows_view, size_t *n_out) {
+    if (!ctx || !b || !n_out || !rows_view) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    // the count first (one streaming pass over the bitset), so the row buffers are sized exactly
+    int64_t cnt = 0;
+    int rc = knox_bits_popcount(ctx, b, &cnt);
+    if (rc) return rc;
+    rc = indexes_dev(ctx, b, (size_t)cnt, n_out);
+    if (!rc) rc = ensure_host(ctx, ctx->h_view, ctx->h_view_cap, std::max<size_t>(*n_out * 4, 64));
+    if (rc) return rc;
+    if (*n_out) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_view, ctx->idx_rows.p, *n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *rows_view = (const uint32_t *)ctx->h_view;
+    return KNOX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2328,6 +2455,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     hipSetDevice(ctx->device);
     if (ctx->res_head - ctx->res_tail >= (uint64_t)knox_ctx::kResRing) return KNOX_E_BUSY;  // collect first
     knox_ctx::ResSlot &slot = ctx->res[ctx->res_head % knox_ctx::kResRing];
+    slot.kind = 0;
     const size_t n_rows = cols[0]->n_rows;
     const size_t pack_rows = cols[0]->pack_rows;
     for (int i = 0; i < n_cols; i++)
@@ -2431,6 +2559,13 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     }
     bool any_moments = false;
     for (int s = 0; s < n_agg_cols; s++) any_moments = any_moments || (agg_needs[s] & A_NEED_MOMENTS) != 0;
+    // "pruned = no row matches, not read" is part of the contract.  The fused kernel honours it by walking only the
+    // surviving packs, which needs whole power-of-two packs of at least one tile; any other shape (a short last pack,
+    // small or odd pack sizes) takes the multi-pass plan, which clears the pruned ranges of the result.
+    if (fused && pack_skip && n_packs) {
+        const bool pow2 = !(pack_rows & (pack_rows - 1));
+        if (!pow2 || n_rows % pack_rows != 0 || (uint64_t)tile_rows(width) * pick_iters(ctx, n_rows, width, pack_rows) > pack_rows) fused = false;
+    }
     const bool need_bits = bits_out != nullptr || want_pack_counts || !fused || n_agg_cols > 1 || any_moments ||
                            (n_agg_cols == 1 && fused && cols[agg_cols[0]]->width != width);
     uint64_t *bits = bits_out ? bits_out->dev : nullptr;
@@ -2590,6 +2725,7 @@ KNOX_API int knox_scan_collect(knox_ctx *ctx, int64_t *pack_counts, knox_agg_sta
     if (!ctx || n_aggs < 0 || (n_aggs && !states)) return KNOX_E_INVALID;
     if (ctx->res_tail == ctx->res_head) return KNOX_E_INVALID;  // nothing in flight
     knox_ctx::ResSlot &slot = ctx->res[ctx->res_tail % knox_ctx::kResRing];
+    if (slot.kind != 0) return KNOX_E_INVALID;    // the oldest result is a bitset call's: knox_bits_collect
     HIPCHK(ctx, hipEventSynchronize(slot.done));  // waits for THIS scan only, later ones keep running
     ctx->res_tail++;
     const AggStateDev *st = (const AggStateDev *)slot.h_res;
@@ -2907,36 +3043,34 @@ KNOX_API int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_
     return KNOX_OK;
 }
 
-// windows -> states on the device: each window's row range [start[k], start[k+1]) of `vals` is cut into work
-// items, reduced, and merged per window in row order.  *states_dev = AggStateDev[n_buckets] inside ctx->tmp_vals.
+// windows -> states on the device: each window's row range [d_start[k], d_start[k+1]) of `vals` is cut into work
+// items (planned on the device: no host round trip of the bounds), reduced, and merged per window in row order.
+// *states_dev = AggStateDev[n_buckets] inside ctx->tmp_vals.  n_rows bounds the item count.
 static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint32_t *mask, size_t n_rows, uint64_t row_base,
-                          const std::vector<uint64_t> &start, size_t n_buckets, int flags, char **states_dev) {
+                          const uint64_t *d_start, size_t n_buckets, int flags, char **states_dev) {
     const int width = dtype_width(dtype);
-    const uint64_t chunk = 1u << 16;
-    std::vector<BucketItem> items;
-    std::vector<uint32_t> item_start(n_buckets + 1);
-    for (size_t k = 0; k < n_buckets; k++) {
-        item_start[k] = (uint32_t)items.size();
-        for (uint64_t b = start[k]; b < start[k + 1]; b += chunk) {
-            BucketItem it;
-            it.begin = b;
-            it.end = std::min<uint64_t>(b + chunk, start[k + 1]);
-            it.bucket = (uint32_t)k;
-            it._pad = 0;
-            items.push_back(it);
-        }
-    }
-    item_start[n_buckets] = (uint32_t)items.size();
-    const size_t n_items = items.size();
-    const size_t off_items = 0, off_istart = (n_items * sizeof(BucketItem) + 63) & ~(size_t)63;
-    const size_t off_partials = (off_istart + (n_buckets + 1) * 4 + 63) & ~(size_t)63;
-    const size_t off_states = (off_partials + n_items * sizeof(AggPartial) + 63) & ~(size_t)63;
+    const uint32_t chunk_shift = 16;
+    const size_t max_items = n_buckets + (n_rows >> chunk_shift) + 1;
+    if (max_items > 0xfffffff0ull) return KNOX_E_RANGE;
+    uint32_t plan_per = 0;
+    const uint32_t plan_blocks = window_plan_blocks((uint32_t)n_buckets, &plan_per);
+    const size_t off_istart = 0, off_bsum = ((n_buckets + 1) * 4 + 63) & ~(size_t)63;
+    const size_t off_items = (off_bsum + ((size_t)plan_blocks + 1) * 4 + 63) & ~(size_t)63;
+    const size_t off_partials = (off_items + max_items * sizeof(BucketItem) + 63) & ~(size_t)63;
+    const size_t off_states = (off_partials + max_items * sizeof(AggPartial) + 63) & ~(size_t)63;
     int rc = ensure(ctx, ctx->tmp_vals, off_states + n_buckets * sizeof(AggStateDev) + 64);
     if (rc) return rc;
     char *base = (char *)ctx->tmp_vals.p;
-    if (n_items) HIPCHK(ctx, hipMemcpyAsync(base + off_items, items.data(), n_items * sizeof(BucketItem), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(base + off_istart, item_start.data(), (n_buckets + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors are not retained
+    uint32_t *d_istart = (uint32_t *)(base + off_istart);
+    hipError_t e = launch_window_plan(ctx->stream, d_start, (uint32_t)n_buckets, chunk_shift, (uint32_t *)(base + off_bsum), d_istart);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    uint32_t n_items32 = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_items32, d_istart + n_buckets, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n_items = n_items32;
+    if (n_items > max_items) return KNOX_E_RANGE;  // cannot happen: the bound above is exact arithmetic
+    e = launch_window_items(ctx->stream, d_start, d_istart, (uint32_t)n_buckets, chunk_shift, n_items32, (BucketItem *)(base + off_items));
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     ScanArgs a;
     memset(&a, 0, sizeof a);
     a.agg_col = vals;
@@ -2946,7 +3080,7 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
     a.row_base = row_base;
     a.partials = (AggPartial *)(base + off_partials);
     const int grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cus * 8);
-    hipError_t e = launch_bucket_reduce(ctx->stream, width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
+    e = launch_bucket_reduce(ctx->stream, width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
     if (e == hipSuccess)
         e = launch_bucket_finalize(ctx->stream, width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, vals, row_base, dtype,
                                    (AggStateDev *)(base + off_states));
@@ -2964,50 +3098,71 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
 }
 
 // out-of-order timestamps (bucket_native.go:123-141 finds / inserts the window's reducer by time): the selected rows
-// are brought into window order by a STABLE sort of (window index, row id) -- rows of one window keep their stream
-// order, which is all the reducers can observe -- the values are gathered, and the ordered pipeline runs on the
-// gathered column; the row ids inside the states are mapped back through the permutation.
+// are brought into window order by a STABLE radix sort of (window index, row id, value) triples (knox_sort.hip) -- rows
+// of one window keep their stream order, which is all the reducers can observe -- and the ordered pipeline runs on the
+// sorted copy of the values; the row ids inside the states are mapped back through the sorted row ids.
 static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
-                                    int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
+                                    int64_t step, size_t n_buckets, uint64_t row_base, int flags, char **states_dev) {
     const size_t n_rows = value_col->n_rows;
     if (n_rows > 0xfffffff0ull) return KNOX_E_UNSUPPORTED;
     const size_t w = (size_t)value_col->width;
-    const size_t arr = (n_rows * 4 + 255) & ~(size_t)255;
-    size_t tmp_bytes = 0;
     unsigned key_bits = 1;
-    while ((1ull << key_bits) <= n_buckets) key_bits++;  // keys 0..n_buckets (n_buckets = not selected / outside every window)
-    hipError_t e = launch_sort_pairs_u32(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, n_rows, key_bits, ctx->stream);
-    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
-    const size_t off_vals = 4 * arr + tmp_bytes;
-    int rc = ensure(ctx, ctx->idx_rows, off_vals + n_rows * w + 256);
-    if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + 64);
+    while ((1ull << key_bits) < n_buckets) key_bits++;  // keys 0..n_buckets-1 (rows outside every window leave in the first pass)
+    uint32_t bits[4] = {0, 0, 0, 0};
+    int n_passes = 0;
+    window_sort_passes(key_bits, bits, &n_passes);
+    const WindowSortGeom g0 = window_sort_geom(n_rows, ctx->n_cus);
+    // scratch (idx_scratch): window bounds | histogram | digit totals;  idx_rows: keys of all rows;  sort_buf: the triples
+    const size_t off_hist = ((n_buckets + 2) * 8 + 255) & ~(size_t)255;
+    const size_t off_tot = off_hist + (((size_t)g0.nb * 256 * 4 + 255) & ~(size_t)255);
+    int rc = ensure(ctx, ctx->idx_scratch, off_tot + 256 * 4 + 64);
+    const size_t keys0_bytes = (n_rows * 4 + 255) & ~(size_t)255;
+    if (!rc) rc = ensure(ctx, ctx->idx_rows, keys0_bytes);
     if (rc) return rc;
-    char *sb = (char *)ctx->idx_rows.p;
-    uint32_t *k0 = (uint32_t *)sb, *k1 = (uint32_t *)(sb + arr), *i0 = (uint32_t *)(sb + 2 * arr), *i1 = (uint32_t *)(sb + 3 * arr);
-    void *tmp = sb + 4 * arr;
-    void *gathered = sb + off_vals;
-    e = launch_window_keys(ctx->stream, (const int64_t *)time_col->dev, n_rows, mask ? (const uint8_t *)mask->dev : nullptr, t_from, step,
-                           (uint32_t)n_buckets, k0, i0);
-    if (e == hipSuccess) e = launch_sort_pairs_u32(tmp, tmp_bytes, k0, k1, i0, i1, n_rows, key_bits, ctx->stream);
-    if (e == hipSuccess) e = launch_gather_rows(ctx->stream, (int)w, value_col->dev, i1, n_rows, gathered);
-    uint64_t *d_start = (uint64_t *)ctx->idx_scratch.p;
-    if (e == hipSuccess) e = launch_key_bounds(ctx->stream, k1, n_rows, (uint32_t)n_buckets, d_start);
+    char *sa = (char *)ctx->idx_scratch.p;
+    uint64_t *d_start = (uint64_t *)sa;
+    uint32_t *d_hist = (uint32_t *)(sa + off_hist), *d_tot = (uint32_t *)(sa + off_tot);
+    hipError_t e = launch_window_sort_begin(ctx->stream, (const int64_t *)time_col->dev, n_rows, mask ? (const uint8_t *)mask->dev : nullptr, t_from,
+                                            step, (uint32_t)n_buckets, g0, bits[0], (uint32_t *)ctx->idx_rows.p, d_hist, d_tot);
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-    std::vector<uint64_t> start(n_buckets + 1);
-    HIPCHK(ctx, hipMemcpyAsync(start.data(), d_start, (n_buckets + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t tot[256];
+    HIPCHK(ctx, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    char *st = nullptr;
-    rc = reduce_windows(ctx, gathered, value_col->dtype, nullptr, (size_t)start[n_buckets], 0, start, n_buckets, flags, &st);
+    size_t n_sel = 0;
+    for (uint32_t t : tot) n_sel += t;
+    // the triples: two sets when there is more than one pass
+    const size_t arr4 = (n_sel * 4 + 255) & ~(size_t)255, arrw = (n_sel * w + 255) & ~(size_t)255;
+    const size_t set = 2 * arr4 + arrw;
+    rc = ensure(ctx, ctx->sort_buf, (n_passes > 1 ? 2 : 1) * set + 256);
     if (rc) return rc;
-    e = launch_remap_rows(ctx->stream, (AggStateDev *)st, (uint32_t)n_buckets, i1, row_base);
+    const char *sb = (const char *)ctx->idx_rows.p;
+    char *cur = (char *)ctx->sort_buf.p, *oth = cur + set;
+    auto K = [&](char *b) { return (uint32_t *)b; };
+    auto I = [&](char *b) { return (uint32_t *)(b + arr4); };
+    auto V = [&](char *b) { return (void *)(b + 2 * arr4); };
+    e = launch_window_sort_first(ctx->stream, (int)w, (const uint32_t *)sb, value_col->dev, n_rows, g0, bits[0], d_hist, d_tot, K(cur), I(cur), V(cur));
+    const WindowSortGeom g1 = window_sort_geom(n_sel, ctx->n_cus);  // never more workgroups than g0: the histogram fits
+    uint32_t shift = bits[0];
+    for (int p = 1; p < n_passes && e == hipSuccess; p++) {
+        e = launch_window_sort_pass(ctx->stream, (int)w, K(cur), I(cur), V(cur), n_sel, g1, shift, bits[p], d_hist, d_tot, K(oth), I(oth), V(oth));
+        std::swap(cur, oth);
+        shift += bits[p];
+    }
+    if (e == hipSuccess) e = launch_key_bounds(ctx->stream, K(cur), n_sel, (uint32_t)n_buckets, d_start);
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-    return download(ctx, states, st, n_buckets * sizeof(AggStateDev));
+    char *st = nullptr;
+    rc = reduce_windows(ctx, V(cur), value_col->dtype, nullptr, n_sel, 0, d_start, n_buckets, flags, &st);
+    if (rc) return rc;
+    e = launch_remap_rows(ctx->stream, (AggStateDev *)st, (uint32_t)n_buckets, I(cur), row_base);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    *states_dev = st;
+    return KNOX_OK;
 }
 
-KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
-                                 int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
-    if (!ctx || !time_col || !value_col || !states || step <= 0 || n_buckets == 0 || n_buckets > (1u << 26)) return KNOX_E_INVALID;
+// the windows' states on the device (ordered time: reduced in place; out-of-order time: the sorted copy)
+static int reduce_buckets_dev(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
+                              int64_t step, size_t n_buckets, uint64_t row_base, int flags, char **states_dev) {
+    if (!ctx || !time_col || !value_col || step <= 0 || n_buckets == 0 || n_buckets > (1u << 26)) return KNOX_E_INVALID;
     if (time_col->dtype != KNOX_INT64 || value_col->dtype == KNOX_BYTES || time_col->n_rows != value_col->n_rows) return KNOX_E_INVALID;
     if (mask && mask->size != value_col->n_rows) return KNOX_E_INVALID;
     // every window edge must be representable
@@ -3016,30 +3171,60 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
     hipSetDevice(ctx->device);
     const size_t n_rows = value_col->n_rows;
     int rc = ensure(ctx, ctx->misc, 256);
-    if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + (n_buckets + 2) * 4 + 64);
+    if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + 64);
     if (rc) return rc;
     // 1. order check (one streaming pass over the time column) unless the caller vouches for it
     uint32_t *d_flag = (uint32_t *)((char *)ctx->misc.p + 32);
+    uint32_t unsorted = 0;
     if (!(flags & 1)) {
         HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
         hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+        HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    // 2. first row of every window edge
+    // 2. first row of every window edge (stays on the device)
     uint64_t *d_start = (uint64_t *)ctx->idx_scratch.p;
     hipError_t e = launch_bucket_bounds(ctx->stream, (const int64_t *)time_col->dev, n_rows, t_from, step, n_buckets, d_start);
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-    std::vector<uint64_t> start(n_buckets + 1);
-    uint32_t unsorted = 0;
-    HIPCHK(ctx, hipMemcpyAsync(start.data(), d_start, (n_buckets + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (!(flags & 1)) HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (unsorted) return reduce_buckets_unordered(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, states);
+    if (!(flags & 1)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (unsorted) return reduce_buckets_unordered(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, states_dev);
     // 3. reduce the windows' row ranges
+    return reduce_windows(ctx, value_col->dev, value_col->dtype, mask ? (const uint32_t *)mask->dev : nullptr, n_rows, row_base, d_start, n_buckets,
+                          flags, states_dev);
+}
+
+KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
+                                 int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
+    if (!states) return KNOX_E_INVALID;
     char *st = nullptr;
-    rc = reduce_windows(ctx, value_col->dev, value_col->dtype, mask ? (const uint32_t *)mask->dev : nullptr, n_rows, row_base, start, n_buckets, flags, &st);
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, &st);
     if (rc) return rc;
     return download(ctx, states, st, n_buckets * sizeof(AggStateDev));
+}
+
+// Reducer.Value() of every window, finalised on the device: 8 (value) + 1 (seen) bytes per window cross PCIe into the
+// context's page-locked result buffer; the caller gets views (valid until the next *_view / *_values call on the ctx)
+KNOX_API int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
+                                        int64_t step, size_t n_buckets, int func, int flags, const void **values_view,
+                                        const uint8_t **seen_view) {
+    if (!values_view || !seen_view || func < KNOX_R_SUM || func > KNOX_R_COUNT) return KNOX_E_INVALID;
+    if (func == KNOX_R_VAR || func == KNOX_R_STD) flags |= 2;
+    char *st = nullptr;
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, flags, &st);
+    if (rc) return rc;
+    const size_t w = (size_t)value_col->width;
+    const size_t off_seen = (n_buckets * w + 63) & ~(size_t)63, bytes = off_seen + n_buckets;
+    rc = ensure(ctx, ctx->pack_counts, bytes + 64);
+    if (!rc) rc = ensure_host(ctx, ctx->h_view, ctx->h_view_cap, bytes);
+    if (rc) return rc;
+    char *d = (char *)ctx->pack_counts.p;
+    hipError_t e = launch_window_values(ctx->stream, (int)w, (const AggStateDev *)st, (uint32_t)n_buckets, func, d, (uint8_t *)d + off_seen);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_view, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *values_view = ctx->h_view;
+    *seen_view = (const uint8_t *)ctx->h_view + off_seen;
+    return KNOX_OK;
 }
 
 // bytesRegexpMatcher.MatchVector (match_bytes.go:587-609): bits.Set(i) for every (masked) row the pattern matches
@@ -3131,106 +3316,18 @@ KNOX_API int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const kn
 // ---- Reducer.Value() from a merged state (pure host code) ------------------------------------
 static void store_value(int dtype, void *out, uint64_t bits) { memcpy(out, &bits, (size_t)dtype_width(dtype)); }
 
-static double dd_to_double(double hi, double lo) {
-    if (!(fabs(hi) <= 1.7976931348623157e308)) return hi;
-    return (double)((__float128)hi + (__float128)lo);
-}
-
+// Reducer.Value(): the arithmetic lives in knox_finalize.h, shared with the device's per-window finaliser
 KNOX_API int knox_agg_value(const knox_agg_state *st, int func, void *value_out, int *seen, int64_t *row) {
     if (!st || !value_out) return KNOX_E_INVALID;
-    const int dtype = st->dtype;
-    const int w = dtype_width(dtype);
-    if (w == 0) return KNOX_E_INVALID;
-    const bool isf = dtype_is_float(dtype);
-    const bool any = st->count > 0;
-    if (seen) *seen = any ? 1 : 0;
-    if (row) *row = any ? st->first_row : -1;
-    uint64_t zero = 0;
-    memcpy(value_out, &zero, (size_t)w);
-    if (!any) return KNOX_OK;
-    auto as_f64 = [&](uint64_t bits) {
-        if (dtype == KNOX_FLOAT64) { double d; memcpy(&d, &bits, 8); return d; }
-        float f; uint32_t u = (uint32_t)bits; memcpy(&f, &u, 4); return (double)f;
-    };
-    auto put_float = [&](double d) {
-        if (dtype == KNOX_FLOAT64) memcpy(value_out, &d, 8);
-        else { float f = (float)d; memcpy(value_out, &f, 4); }
-    };
-    switch (func) {
-    case KNOX_R_COUNT: {  // CountReducer counts in T (reducer.go:138-148)
-        if (isf) put_float(dtype == KNOX_FLOAT64 ? (double)st->count : (double)(float)st->count);
-        else store_value(dtype, value_out, (uint64_t)st->count);
-        break;
-    }
-    case KNOX_R_SUM:
-        if (isf) put_float(dd_to_double(st->fsum_hi, st->fsum_lo));
-        else store_value(dtype, value_out, st->isum);  // wraps in T like Go
-        break;
-    case KNOX_R_MEAN: {
-        // exact_sum / n rounded once (reference: sequential Welford, see DESIGN.md on parity)
-        double mean;
-        if (!(fabs(st->fsum_hi) <= 1.7976931348623157e308)) mean = st->fsum_hi;
-        else mean = (double)(((__float128)st->fsum_hi + (__float128)st->fsum_lo) / (__float128)st->count);
-        if (isf) put_float(mean);
-        else if (dtype_is_signed(dtype)) store_value(dtype, value_out, (uint64_t)(int64_t)mean);  // T(r.mean) truncates toward zero
-        else store_value(dtype, value_out, (uint64_t)mean);
-        break;
-    }
-    case KNOX_R_FIRST:
-        store_value(dtype, value_out, st->first_bits);
-        if (row) *row = st->first_row;
-        break;
-    case KNOX_R_LAST:
-        store_value(dtype, value_out, st->last_bits);
-        if (row) *row = st->last_row;
-        break;
-    case KNOX_R_MIN:
-    case KNOX_R_MAX: {
-        // a NaN first value is adopted and then sticks (reducer.go:256-296): r.v < NaN and r.v > NaN are false
-        if (isf && isnan(as_f64(st->first_bits))) {
-            store_value(dtype, value_out, st->first_bits);
-            if (row) *row = st->first_row;
-            break;
-        }
-        const bool mn = func == KNOX_R_MIN;
-        if ((mn ? st->min_row : st->max_row) < 0) {  // unreachable for ints; floats: all later values NaN handled above
-            store_value(dtype, value_out, st->first_bits);
-            if (row) *row = st->first_row;
-            break;
-        }
-        store_value(dtype, value_out, mn ? st->min_bits : st->max_bits);
-        if (row) *row = mn ? st->min_row : st->max_row;
-        break;
-    }
-    case KNOX_R_VAR:
-    case KNOX_R_STD: {
-        // VarReducer / StdReducer.Value (reducer.go:376-381,416-421): m2/(n-1), NaN for n < 2.
-        // m2 = Q - D*D/n from the second-pass moments, evaluated in binary128 and rounded once.
-        if (!(st->flags & 2u)) return KNOX_E_INVALID;  // state carries no moments (knox_reduce_moments)
-        double v;
-        if (st->count < 2) {
-            v = NAN;
-        } else {
-            const __float128 n = (__float128)st->count;
-            const __float128 D = (__float128)st->m_dev_hi + (__float128)st->m_dev_lo, Q = (__float128)st->m_sq_hi + (__float128)st->m_sq_lo;
-            __float128 m2 = Q - D * D / n;
-            if (m2 < 0) m2 = 0;  // cannot happen mathematically; guards the last-bit residue
-            v = (double)(m2 / (n - 1));
-            if (!(fabs(st->m_sq_hi) <= 1.7976931348623157e308)) v = st->m_sq_hi + st->m_sq_lo;  // non-finite input: NaN like Welford
-            if (func == KNOX_R_STD) v = sqrt(v);
-        }
-        if (isf) { put_float(v); break; }
-        // T(float64) for integer T: truncation toward zero; NaN / out-of-range results are
-        // implementation-specific in Go (spec: "the behavior is implementation-dependent") -> 0 here
-        const double lim = ldexp(1.0, 8 * w - (dtype_is_signed(dtype) ? 1 : 0));
-        if (!(v == v) || v >= lim || v <= -lim) break;
-        if (dtype_is_signed(dtype)) store_value(dtype, value_out, (uint64_t)(int64_t)v);
-        else if (v > 0) store_value(dtype, value_out, (uint64_t)v);
-        break;
-    }
-    default:
-        return KNOX_E_UNSUPPORTED;
-    }
+    uint64_t bits = 0;
+    int sn = 0;
+    int64_t r = -1;
+    const int rc = knox_fin::agg_value_bits(*st, func, &bits, &sn, &r);
+    if (rc == -5) return KNOX_E_UNSUPPORTED;
+    if (rc) return KNOX_E_INVALID;
+    store_value(st->dtype, value_out, bits);
+    if (seen) *seen = sn;
+    if (row) *row = r;
     return KNOX_OK;
 }
 

@@ -252,14 +252,33 @@ hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint
                            uint64_t n_rows, int64_t lo, uint64_t span, void *dst);
 
 // literal sequential reducer (one lane)
-// out-of-order time windows (knox_sort.hip)
-hipError_t launch_window_keys(hipStream_t s, const int64_t *time, uint64_t n_rows, const uint8_t *mask, int64_t t_from, int64_t step,
-                              uint32_t n_buckets, uint32_t *keys, uint32_t *idx);
-hipError_t launch_sort_pairs_u32(void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
-                                 uint32_t *vals_out, size_t n, unsigned key_bits, hipStream_t s);
-hipError_t launch_gather_rows(hipStream_t s, int width, const void *src, const uint32_t *idx, uint64_t n, void *dst);
+// out-of-order time windows (knox_sort.hip): stable LSD radix sort of (window, row, value) triples, 1..4 passes of <= 8 bits
+constexpr int kWindowSortItems = 12;  // elements per thread and tile of the scatter kernel
+struct WindowSortGeom {
+    uint32_t nb;         // workgroups
+    uint64_t per_block;  // elements per workgroup (a multiple of the tile)
+};
+WindowSortGeom window_sort_geom(uint64_t n, int n_cus);
+void window_sort_passes(unsigned key_bits, uint32_t bits[4], int *n_passes);
+// keys[n_rows] (0xffffffff = row not selected / outside every window); hist[nb*256] scanned, tot[256] = per-digit totals
+hipError_t launch_window_sort_begin(hipStream_t s, const int64_t *time, uint64_t n_rows, const uint8_t *mask, int64_t t_from, int64_t step,
+                                    uint32_t n_buckets, WindowSortGeom g, uint32_t bits0, uint32_t *keys, uint32_t *hist, uint32_t *tot);
+hipError_t launch_window_sort_first(hipStream_t s, int width, const uint32_t *keys, const void *value_col, uint64_t n_rows, WindowSortGeom g,
+                                    uint32_t bits0, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out, uint32_t *idx_out,
+                                    void *val_out);
+hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
+                                   WindowSortGeom g, uint32_t shift, uint32_t nbits, uint32_t *hist, uint32_t *tot, uint32_t *keys_out,
+                                   uint32_t *idx_out, void *val_out);
 hipError_t launch_key_bounds(hipStream_t s, const uint32_t *keys, uint64_t n, uint32_t n_buckets, uint64_t *start);
 hipError_t launch_remap_rows(hipStream_t s, AggStateDev *states, uint32_t n_buckets, const uint32_t *idx, uint64_t row_base);
+// per-window work items planned on the device: item_start[0..n_buckets] (last = item count), then the items
+uint32_t window_plan_blocks(uint32_t n_buckets, uint32_t *per_block);
+hipError_t launch_window_plan(hipStream_t s, const uint64_t *start, uint32_t n_buckets, uint32_t chunk_shift, uint32_t *block_sum,
+                              uint32_t *item_start);
+hipError_t launch_window_items(hipStream_t s, const uint64_t *start, const uint32_t *item_start, uint32_t n_buckets, uint32_t chunk_shift,
+                               uint32_t n_items, BucketItem *items);
+// Reducer.Value() per window (knox_finalize.h): values[k] of `width` bytes, seen[k]
+hipError_t launch_window_values(hipStream_t s, int width, const AggStateDev *states, uint32_t n_buckets, int func, void *values, uint8_t *seen);
 // compiled REGEXP program on the device (knox_regex.h): table | flags | ascii_class are one contiguous image
 struct RegexProg {
     const uint16_t *direct;  // [n_states][128]: table[state][ascii_class[byte]] folded, or nullptr (image too large for LDS)

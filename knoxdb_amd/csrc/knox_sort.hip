@@ -1,31 +1,72 @@
-// Out-of-order time windows (internal/reducer/bucket_native.go:123-141: Push finds or inserts the window's
-// reducer by time, so rows may arrive in any time order).  The device brings the SELECTED rows into window
-// order with a stable sort of (window index, row id) pairs; within a window the rows keep their stream order,
-// which is the only order a reducer can observe.  The sort itself is rocPRIM's device radix sort (a plain
-// library primitive, like a BLAS call -- the knox-specific kernels around it are hand-written): it is not on
-// the headline path, ordered time columns never come here.
+// Time windows beyond the plain ordered reduction (internal/reducer/bucket_native.go:104-159):
+//
+//  * out-of-order timestamps (bucket_native.go:123-141: Push finds or inserts the window's reducer by time, so rows may
+//    arrive in any time order): the SELECTED rows are brought into window order by a stable LSD radix sort written for
+//    exactly this shape -- the key range is known (window index < n_buckets, so 1..4 passes of <= 8 bits), rows that are
+//    not selected or fall outside every window are dropped in the first pass, and the VALUE travels with the (window, row)
+//    pair, so there is no random gather afterwards and the reduction reads a contiguous, window-ordered copy.  Within a
+//    window the rows keep their stream order, which is the only order a reducer can observe.
+//  * work-item planning for the per-window reduction on the device (no host round trip of the window bounds), and
+//  * Reducer.Value() per window on the device (knox_finalize.h): 8 bytes per window cross PCIe instead of 144.
+//
+// Sort structure per pass (classic reduce-then-scan, no inter-workgroup waiting): every workgroup owns one contiguous
+// range of the input; (1) digit histogram per workgroup, (2) scan over workgroups per digit, (3) scatter: the range is
+// walked tile by tile, each tile is ranked stably (wave-level match-any over the digit bits, per-wave LDS counters),
+// reordered through LDS and written out as contiguous per-digit runs.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
+#include "knox_finalize.h"
 #include "knox_kernels.h"
 
 namespace knox {
 
 namespace {
 constexpr int kSortBlock = 256;
-}
+constexpr int kSortWaves = kSortBlock / 64;
+constexpr int kRadix = 256;
+constexpr uint32_t kNoKey = 0xffffffffu;
 
-// key = window index of the row's timestamp; rows that are not selected or fall outside every window get
-// the sentinel n_buckets and sort to the end
-__global__ void __launch_bounds__(kSortBlock) window_keys_kernel(const int64_t *__restrict__ time, uint64_t n_rows, const uint8_t *__restrict__ mask,
-                                                                 int64_t t_from, int64_t step, uint32_t n_buckets, uint32_t *__restrict__ keys,
-                                                                 uint32_t *__restrict__ idx) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += stride) {
-        uint32_t k = n_buckets;
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// exclusive scan of one value per thread over the 256 threads of the workgroup; *total = sum.  `tmp` = 4 LDS words.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    __syncthreads();  // tmp may still be read by the previous use
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+        const uint32_t t = tmp[w];
+        if ((uint32_t)w < wave) base += t;
+        all += t;
+    }
+    *total = all;
+    return base + inc - v;
+}
+}  // namespace
+
+// ---- pass 0, step 1: window keys + digit histogram ------------------------------------------------------------------
+// key = window index of the row's timestamp; rows that are not selected or fall outside every window get kNoKey and
+// leave the sort in the first scatter
+__global__ void __launch_bounds__(kSortBlock) window_keys_hist_kernel(const int64_t *__restrict__ time, uint64_t n_rows, const uint8_t *__restrict__ mask,
+                                                                      int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t per_block,
+                                                                      uint32_t dmask, uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = begin + per_block < n_rows ? begin + per_block : n_rows;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += kSortBlock) {
+        uint32_t k = kNoKey;
         if (mask == nullptr || ((mask[i >> 3] >> (i & 7)) & 1)) {
             const int64_t t = time[i];
             if (t >= t_from) {
@@ -34,43 +75,232 @@ __global__ void __launch_bounds__(kSortBlock) window_keys_kernel(const int64_t *
             }
         }
         keys[i] = k;
-        idx[i] = (uint32_t)i;
+        if (k != kNoKey) atomicAdd(&h[k & dmask], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = h[threadIdx.x];
+}
+
+// ---- later passes, step 1: digit histogram of the keys as the previous pass left them --------------------------------
+__global__ void __launch_bounds__(kSortBlock) key_hist_kernel(const uint32_t *__restrict__ keys, uint64_t n, uint64_t per_block, uint32_t shift,
+                                                              uint32_t dmask, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = begin + per_block < n ? begin + per_block : n;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += kSortBlock) atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
+    __syncthreads();
+    hist[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = h[threadIdx.x];
+}
+
+// ---- step 2: one workgroup per digit: hist[b][d] -> number of elements with digit d in workgroups < b; tot[d] = all ----
+__global__ void __launch_bounds__(kSortBlock) hist_scan_kernel(uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ tot) {
+    __shared__ uint32_t tmp[kSortWaves];
+    const uint32_t d = blockIdx.x;
+    const uint32_t per = (nb + kSortBlock - 1) / kSortBlock;
+    const uint32_t b0 = threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += hist[(uint64_t)b * kRadix + d];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, tmp, &total);
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t c = hist[(uint64_t)b * kRadix + d];
+        hist[(uint64_t)b * kRadix + d] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) tot[d] = total;
+}
+
+// ---- step 3: stable scatter ------------------------------------------------------------------------------------------
+// U = the value's storage type (uint8_t .. uint64_t).  FIRST: the input is (keys[i], row i, value_col[i]) with kNoKey
+// rows dropped; otherwise the (key, row, value) triples of the previous pass.  ITEMS elements per thread and tile; wave w
+// of a tile owns the elements [w*64*ITEMS, (w+1)*64*ITEMS) of it, element (j, lane) at j*64 + lane (coalesced loads,
+// element order == offset order, which is what makes the ranking stable).
+template <typename U, bool FIRST, int ITEMS>
+__global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ idx_in,
+                                                                  const U *__restrict__ val_in, uint64_t n, uint64_t per_block, uint32_t shift,
+                                                                  uint32_t nbits, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ tot,
+                                                                  uint32_t *__restrict__ keys_out, uint32_t *__restrict__ idx_out,
+                                                                  U *__restrict__ val_out) {
+    constexpr int TILE = kSortBlock * ITEMS;
+    __shared__ uint32_t run_off[kRadix];             // next free output slot per digit for this workgroup
+    __shared__ uint32_t cnt[kSortWaves][kRadix];     // per-wave digit counters of the tile -> offset of the wave inside the digit
+    __shared__ uint32_t tile_start[kRadix];          // first sorted position of the digit inside the tile
+    __shared__ uint32_t gbase[kRadix];               // output slot of that position
+    __shared__ uint32_t tmp[kSortWaves + 1];
+    __shared__ uint32_t s_key[TILE], s_idx[TILE];
+    __shared__ U s_val[TILE];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const uint32_t dmask = (1u << nbits) - 1;
+    {
+        tile_start[tid] = tot[tid];
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t d = 0; d < tid; d++) base += tile_start[d];
+        run_off[tid] = base + hist[(uint64_t)blockIdx.x * kRadix + tid];
+        __syncthreads();
+    }
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = begin + per_block < n ? begin + per_block : n;
+    for (uint64_t tile0 = begin; tile0 < end; tile0 += TILE) {
+#pragma unroll
+        for (int w = 0; w < kSortWaves; w++) cnt[w][tid] = 0;
+        __syncthreads();
+        uint32_t key[ITEMS], rank[ITEMS], row[ITEMS];
+        U val[ITEMS];
+        // phase 1: load + rank inside the wave's chunk
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const uint64_t e = tile0 + (uint64_t)wave * (64 * ITEMS) + (uint64_t)j * 64 + lane;
+            key[j] = kNoKey;
+            if (e < end) {
+                key[j] = keys_in[e];
+                if (FIRST) {
+                    row[j] = (uint32_t)e;
+                } else {
+                    row[j] = idx_in[e];
+                }
+                val[j] = val_in[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const bool active = key[j] != kNoKey;  // later passes: always true below `end` (kNoKey never survives pass 0)
+            const uint32_t d = (key[j] >> shift) & dmask;
+            uint64_t peers = __ballot(active);
+            for (uint32_t b = 0; b < nbits; b++) {
+                const bool bit = (d >> b) & 1;
+                const uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            const uint32_t group = (uint32_t)__popcll(peers);
+            uint32_t c = 0;
+            if (active) c = cnt[wave][d];
+            // all lanes of the wave have read before any writes: LDS operations of one wave retire in order
+            if (active && below == group - 1) cnt[wave][d] = c + group;
+            rank[j] = c + below;
+        }
+        __syncthreads();
+        // phase 2: digit d (= tid): waves' offsets inside the digit, the digit's start inside the tile, its output slot
+        {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < kSortWaves; w++) {
+                const uint32_t c = cnt[w][tid];
+                cnt[w][tid] = total;
+                total += c;
+            }
+            uint32_t n_tile;
+            const uint32_t st = block_exclusive_scan(total, tmp, &n_tile);
+            tile_start[tid] = st;
+            gbase[tid] = run_off[tid];
+            run_off[tid] += total;
+            if (tid == 0) tmp[kSortWaves] = n_tile;
+        }
+        __syncthreads();
+        // phase 3: into sorted position inside the tile
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            if (key[j] != kNoKey) {
+                const uint32_t d = (key[j] >> shift) & dmask;
+                const uint32_t pos = tile_start[d] + cnt[wave][d] + rank[j];
+                s_key[pos] = key[j];
+                s_idx[pos] = row[j];
+                s_val[pos] = val[j];
+            }
+        }
+        __syncthreads();
+        // phase 4: contiguous runs per digit
+        const uint32_t n_tile = tmp[kSortWaves];
+        for (uint32_t i = tid; i < n_tile; i += kSortBlock) {
+            const uint32_t k = s_key[i];
+            const uint32_t d = (k >> shift) & dmask;
+            const uint32_t dst = gbase[d] + (i - tile_start[d]);
+            keys_out[dst] = k;
+            idx_out[dst] = s_idx[i];
+            val_out[dst] = s_val[i];
+        }
+        __syncthreads();
     }
 }
 
-hipError_t launch_window_keys(hipStream_t s, const int64_t *time, uint64_t n_rows, const uint8_t *mask, int64_t t_from, int64_t step,
-                              uint32_t n_buckets, uint32_t *keys, uint32_t *idx) {
-    if (n_rows == 0) return hipSuccess;
-    uint64_t g = (n_rows + kSortBlock - 1) / kSortBlock;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(window_keys_kernel, dim3((unsigned)g), dim3(kSortBlock), 0, s, time, n_rows, mask, t_from, step, n_buckets, keys, idx);
+namespace {
+template <typename U>
+hipError_t scatter_launch(hipStream_t s, bool first, uint32_t nb, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
+                          uint64_t per_block, uint32_t shift, uint32_t nbits, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out,
+                          uint32_t *idx_out, void *val_out) {
+    constexpr int ITEMS = kWindowSortItems;
+    if (first)
+        hipLaunchKernelGGL((sort_scatter_kernel<U, true, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n, per_block,
+                           shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
+    else
+        hipLaunchKernelGGL((sort_scatter_kernel<U, false, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n,
+                           per_block, shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
     return hipGetLastError();
 }
 
-// stable LSD radix sort over the low key_bits of the keys; tmp == nullptr: size query
-hipError_t launch_sort_pairs_u32(void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
-                                 uint32_t *vals_out, size_t n, unsigned key_bits, hipStream_t s) {
-    return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, key_bits, s);
-}
-
-template <typename U>
-__global__ void __launch_bounds__(kSortBlock) gather_rows_kernel(const U *__restrict__ src, const uint32_t *__restrict__ idx, uint64_t n, U *__restrict__ dst) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
-}
-
-hipError_t launch_gather_rows(hipStream_t s, int width, const void *src, const uint32_t *idx, uint64_t n, void *dst) {
-    if (n == 0) return hipSuccess;
-    uint64_t g = (n + kSortBlock - 1) / kSortBlock;
-    if (g > 8192) g = 8192;
+hipError_t scatter_any(hipStream_t s, int width, bool first, uint32_t nb, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in,
+                       uint64_t n, uint64_t per_block, uint32_t shift, uint32_t nbits, const uint32_t *hist, const uint32_t *tot,
+                       uint32_t *keys_out, uint32_t *idx_out, void *val_out) {
     switch (width) {
-    case 8: hipLaunchKernelGGL((gather_rows_kernel<uint64_t>), dim3((unsigned)g), dim3(kSortBlock), 0, s, (const uint64_t *)src, idx, n, (uint64_t *)dst); break;
-    case 4: hipLaunchKernelGGL((gather_rows_kernel<uint32_t>), dim3((unsigned)g), dim3(kSortBlock), 0, s, (const uint32_t *)src, idx, n, (uint32_t *)dst); break;
-    case 2: hipLaunchKernelGGL((gather_rows_kernel<uint16_t>), dim3((unsigned)g), dim3(kSortBlock), 0, s, (const uint16_t *)src, idx, n, (uint16_t *)dst); break;
-    case 1: hipLaunchKernelGGL((gather_rows_kernel<uint8_t>), dim3((unsigned)g), dim3(kSortBlock), 0, s, (const uint8_t *)src, idx, n, (uint8_t *)dst); break;
+    case 8: return scatter_launch<uint64_t>(s, first, nb, keys_in, idx_in, val_in, n, per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
+    case 4: return scatter_launch<uint32_t>(s, first, nb, keys_in, idx_in, val_in, n, per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
+    case 2: return scatter_launch<uint16_t>(s, first, nb, keys_in, idx_in, val_in, n, per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
+    case 1: return scatter_launch<uint8_t>(s, first, nb, keys_in, idx_in, val_in, n, per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
     default: return hipErrorInvalidValue;
     }
+}
+}  // namespace
+
+WindowSortGeom window_sort_geom(uint64_t n, int n_cus) {
+    WindowSortGeom g;
+    const uint64_t tile = (uint64_t)kSortBlock * kWindowSortItems;
+    uint64_t nb = (n + tile - 1) / tile;
+    const uint64_t cap = (uint64_t)n_cus * 4;
+    if (nb > cap) nb = cap;
+    if (nb == 0) nb = 1;
+    g.nb = (uint32_t)nb;
+    g.per_block = ((n + nb - 1) / nb + tile - 1) / tile * tile;
+    return g;
+}
+
+void window_sort_passes(unsigned key_bits, uint32_t bits[4], int *n_passes) {
+    const int p = key_bits <= 8 ? 1 : key_bits <= 16 ? 2 : key_bits <= 24 ? 3 : 4;
+    unsigned left = key_bits;
+    for (int i = 0; i < p; i++) {
+        bits[i] = (left + (p - i) - 1) / (p - i);  // split evenly: 15 bits -> 8 + 7
+        left -= bits[i];
+    }
+    *n_passes = p;
+}
+
+// keys[i] for every row + the first pass's histogram, scanned: tot[d] = selected rows with low digit d (their sum = the
+// rows inside windows, read by the host to size the sort buffers)
+hipError_t launch_window_sort_begin(hipStream_t s, const int64_t *time, uint64_t n_rows, const uint8_t *mask, int64_t t_from, int64_t step,
+                                    uint32_t n_buckets, WindowSortGeom g, uint32_t bits0, uint32_t *keys, uint32_t *hist, uint32_t *tot) {
+    hipLaunchKernelGGL(window_keys_hist_kernel, dim3(g.nb), dim3(kSortBlock), 0, s, time, n_rows, mask, t_from, step, n_buckets, g.per_block,
+                       (1u << bits0) - 1, keys, hist);
+    hipLaunchKernelGGL(hist_scan_kernel, dim3(kRadix), dim3(kSortBlock), 0, s, hist, g.nb, tot);
     return hipGetLastError();
+}
+
+// pass 0: (keys, row id, value_col) -> buffer A, dropping kNoKey rows
+hipError_t launch_window_sort_first(hipStream_t s, int width, const uint32_t *keys, const void *value_col, uint64_t n_rows, WindowSortGeom g,
+                                    uint32_t bits0, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out, uint32_t *idx_out,
+                                    void *val_out) {
+    return scatter_any(s, width, true, g.nb, keys, nullptr, value_col, n_rows, g.per_block, 0, bits0, hist, tot, keys_out, idx_out, val_out);
+}
+
+// pass p >= 1 over the n selected triples
+hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
+                                   WindowSortGeom g, uint32_t shift, uint32_t nbits, uint32_t *hist, uint32_t *tot, uint32_t *keys_out,
+                                   uint32_t *idx_out, void *val_out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(key_hist_kernel, dim3(g.nb), dim3(kSortBlock), 0, s, keys_in, n, g.per_block, shift, (1u << nbits) - 1, hist);
+    hipLaunchKernelGGL(hist_scan_kernel, dim3(kRadix), dim3(kSortBlock), 0, s, hist, g.nb, tot);
+    return scatter_any(s, width, false, g.nb, keys_in, idx_in, val_in, n, g.per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
 }
 
 // start[k] = first sorted position whose key is >= k, k = 0..n_buckets (start[n_buckets] = rows inside windows)
@@ -103,6 +333,129 @@ __global__ void __launch_bounds__(kSortBlock) remap_rows_kernel(AggStateDev *sta
 
 hipError_t launch_remap_rows(hipStream_t s, AggStateDev *states, uint32_t n_buckets, const uint32_t *idx, uint64_t row_base) {
     hipLaunchKernelGGL(remap_rows_kernel, dim3((n_buckets + kSortBlock - 1) / kSortBlock), dim3(kSortBlock), 0, s, states, n_buckets, idx, row_base);
+    return hipGetLastError();
+}
+
+// ---- work items of the per-window reduction, planned on the device ---------------------------------------------------
+// window k's row range [start[k], start[k+1]) is cut into items of at most 2^chunk_shift rows.
+// item_start[k] = number of items of the windows before k (k = 0..n_buckets: the last entry is the item count).
+__global__ void __launch_bounds__(kSortBlock) item_count_kernel(const uint64_t *__restrict__ start, uint32_t n_buckets, uint32_t chunk_shift,
+                                                                uint32_t per_block, uint32_t *__restrict__ block_sum) {
+    __shared__ uint32_t tmp[kSortWaves];
+    const uint64_t chunk = 1ull << chunk_shift;
+    const uint32_t k0 = blockIdx.x * per_block;
+    uint32_t sum = 0;
+    for (uint32_t k = k0 + threadIdx.x; k < k0 + per_block && k < n_buckets; k += kSortBlock) sum += (uint32_t)((start[k + 1] - start[k] + chunk - 1) >> chunk_shift);
+    uint32_t total;
+    block_exclusive_scan(sum, tmp, &total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kSortBlock) item_block_scan_kernel(uint32_t *__restrict__ block_sum, uint32_t n_blocks) {
+    __shared__ uint32_t tmp[kSortWaves];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += kSortBlock) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < n_blocks ? block_sum[b] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, tmp, &total);
+        if (b < n_blocks) block_sum[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) block_sum[n_blocks] = carry;  // the item count
+}
+
+__global__ void __launch_bounds__(kSortBlock) item_start_kernel(const uint64_t *__restrict__ start, uint32_t n_buckets, uint32_t chunk_shift,
+                                                                uint32_t per_block, const uint32_t *__restrict__ block_sum, uint32_t n_blocks,
+                                                                uint32_t *__restrict__ item_start) {
+    __shared__ uint32_t tmp[kSortWaves];
+    const uint64_t chunk = 1ull << chunk_shift;
+    const uint32_t k0 = blockIdx.x * per_block;
+    uint32_t carry = block_sum[blockIdx.x];
+    for (uint32_t kb = k0; kb < k0 + per_block && kb < n_buckets; kb += kSortBlock) {
+        const uint32_t k = kb + threadIdx.x;
+        const uint32_t v = (k < k0 + per_block && k < n_buckets) ? (uint32_t)((start[k + 1] - start[k] + chunk - 1) >> chunk_shift) : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, tmp, &total);
+        if (k < k0 + per_block && k < n_buckets) item_start[k] = carry + ex;
+        carry += total;
+    }
+    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) item_start[n_buckets] = block_sum[n_blocks];
+}
+
+// one thread per item: its window by binary search over item_start, its row range from the window's start
+__global__ void __launch_bounds__(kSortBlock) item_fill_kernel(const uint64_t *__restrict__ start, const uint32_t *__restrict__ item_start,
+                                                               uint32_t n_buckets, uint32_t chunk_shift, BucketItem *__restrict__ items) {
+    const uint32_t n_items = item_start[n_buckets];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    uint32_t lo = 0, hi = n_buckets;  // last k with item_start[k] <= i (windows without items share a value with their successor)
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (item_start[mid] <= i) lo = mid; else hi = mid;
+    }
+    // skip back over empty windows is not needed: item_start[lo] <= i < item_start[lo + 1] holds for the LAST such lo
+    const uint64_t b = start[lo] + ((uint64_t)(i - item_start[lo]) << chunk_shift);
+    const uint64_t e = b + (1ull << chunk_shift) < start[lo + 1] ? b + (1ull << chunk_shift) : start[lo + 1];
+    BucketItem it;
+    it.begin = b;
+    it.end = e;
+    it.bucket = lo;
+    it._pad = 0;
+    items[i] = it;
+}
+
+uint32_t window_plan_blocks(uint32_t n_buckets, uint32_t *per_block) {
+    uint32_t per = 4096;
+    uint32_t nb = (n_buckets + per - 1) / per;
+    if (nb == 0) nb = 1;
+    *per_block = per;
+    return nb;
+}
+
+// item_start[0..n_buckets] from start[0..n_buckets]; block_sum = window_plan_blocks() + 1 scratch words
+hipError_t launch_window_plan(hipStream_t s, const uint64_t *start, uint32_t n_buckets, uint32_t chunk_shift, uint32_t *block_sum,
+                              uint32_t *item_start) {
+    uint32_t per;
+    const uint32_t nb = window_plan_blocks(n_buckets, &per);
+    hipLaunchKernelGGL(item_count_kernel, dim3(nb), dim3(kSortBlock), 0, s, start, n_buckets, chunk_shift, per, block_sum);
+    hipLaunchKernelGGL(item_block_scan_kernel, dim3(1), dim3(kSortBlock), 0, s, block_sum, nb);
+    hipLaunchKernelGGL(item_start_kernel, dim3(nb), dim3(kSortBlock), 0, s, start, n_buckets, chunk_shift, per, block_sum, nb, item_start);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_items(hipStream_t s, const uint64_t *start, const uint32_t *item_start, uint32_t n_buckets, uint32_t chunk_shift,
+                               uint32_t n_items, BucketItem *items) {
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(item_fill_kernel, dim3((n_items + kSortBlock - 1) / kSortBlock), dim3(kSortBlock), 0, s, start, item_start, n_buckets,
+                       chunk_shift, items);
+    return hipGetLastError();
+}
+
+// ---- Reducer.Value() per window on the device --------------------------------------------------------------------------
+template <typename U>
+__global__ void __launch_bounds__(kSortBlock) window_values_kernel(const AggStateDev *__restrict__ states, uint32_t n_buckets, int func,
+                                                                   U *__restrict__ values, uint8_t *__restrict__ seen) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    uint64_t bits = 0;
+    int sn = 0;
+    int64_t row = -1;
+    const int rc = knox_fin::agg_value_bits(states[k], func, &bits, &sn, &row);
+    values[k] = (U)bits;
+    seen[k] = (rc == 0 && sn) ? 1 : 0;
+}
+
+hipError_t launch_window_values(hipStream_t s, int width, const AggStateDev *states, uint32_t n_buckets, int func, void *values, uint8_t *seen) {
+    if (n_buckets == 0) return hipSuccess;
+    const dim3 g((n_buckets + kSortBlock - 1) / kSortBlock), b(kSortBlock);
+    switch (width) {
+    case 8: hipLaunchKernelGGL((window_values_kernel<uint64_t>), g, b, 0, s, states, n_buckets, func, (uint64_t *)values, seen); break;
+    case 4: hipLaunchKernelGGL((window_values_kernel<uint32_t>), g, b, 0, s, states, n_buckets, func, (uint32_t *)values, seen); break;
+    case 2: hipLaunchKernelGGL((window_values_kernel<uint16_t>), g, b, 0, s, states, n_buckets, func, (uint16_t *)values, seen); break;
+    case 1: hipLaunchKernelGGL((window_values_kernel<uint8_t>), g, b, 0, s, states, n_buckets, func, (uint8_t *)values, seen); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -200,13 +200,33 @@ class Bits:
         check(_lib.lib().knox_bits_popcount_segments(self.ctx.h, self.h, seg_bits, _ptr(out), n))
         return out
 
+    def indexes_view(self):
+        """Bitset.Indexes into the context's page-locked result buffer: a zero-copy uint32 view, valid until the next
+        indexes_view / reduce_buckets_values call on the context (copy it to keep it)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(_lib.lib().knox_bits_indexes_view(self.ctx.h, self.h, C.byref(p), C.byref(n)), "knox_bits_indexes_view")
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,))
+
+    def and_flag_async(self, o):
+        check(_lib.lib().knox_bits_and_flag_async(self.ctx.h, self.h, o.h), "knox_bits_and_flag_async")
+
+    def or_flag_async(self, o):
+        check(_lib.lib().knox_bits_or_flag_async(self.ctx.h, self.h, o.h), "knox_bits_or_flag_async")
+
+    def count_async(self):
+        check(_lib.lib().knox_bits_popcount_async(self.ctx.h, self.h), "knox_bits_popcount_async")
+
     def indexes(self, capacity=None, out=None):
         """Bitset.Indexes.  out: caller's uint32 buffer (e.g. Context.host_array: page-locked, DMA'd in place) ->
-        a view of it, no copy."""
+        a view of it, no copy.  Without arguments: a copy of indexes_view()."""
         if out is not None:
             n = C.c_size_t()
             check(_lib.lib().knox_bits_indexes(self.ctx.h, self.h, _ptr(out), out.size, C.byref(n)))
             return out[:n.value]
+        if capacity is None:
+            return self.indexes_view().copy()
         cap = self.count() + 8 if capacity is None else capacity  # Bitset.Indexes pads the result by 7 (iterator.go:277-289)
         out = np.zeros(max(cap, 1), dtype=np.uint32)
         n = C.c_size_t()
@@ -553,6 +573,24 @@ class Context:
         check(self.L.knox_reduce_buckets(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
                                          n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), states), "knox_reduce_buckets")
         return states   # ctypes array: indexable / iterable, no per-window Python objects until touched
+
+    def reduce_buckets_values(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
+        """Reducer.Value() per window, finalised on the device -> (values[n_buckets] of the column's type, seen[n_buckets])
+        as zero-copy views of the context's page-locked result buffer (valid until the next *_view / *_values call)."""
+        pv, ps = C.c_void_p(), C.c_void_p()
+        check(self.L.knox_reduce_buckets_values(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
+                                                n_buckets, int(func), 1 if assume_sorted else 0, C.byref(pv), C.byref(ps)),
+              "knox_reduce_buckets_values")
+        dt = np.dtype(NP_DTYPE[value_col.dtype])
+        vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_uint8)), shape=(n_buckets * dt.itemsize,)).view(dt)
+        seen = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_uint8)), shape=(n_buckets,))
+        return vals, seen
+
+    def bits_collect(self):
+        """Oldest uncollected async bitset result -> (any, all, count); the fields that do not apply are None."""
+        a, l, c = C.c_int(), C.c_int(), C.c_int64()
+        check(self.L.knox_bits_collect(self.h, C.byref(a), C.byref(l), C.byref(c)), "knox_bits_collect")
+        return (None if a.value < 0 else bool(a.value), None if l.value < 0 else bool(l.value), None if c.value < 0 else c.value)
 
     def reduce_buckets_sequential(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
         """The reference's own reducer per window, row by row (bit-exact Value() for every reducer, join

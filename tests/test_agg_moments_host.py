@@ -92,3 +92,33 @@ def test_missing_moments_is_refused():
         K.agg_value(st, R.Var)
     good = make_state(np.array([4.0, 5.0]))
     assert not (K.agg_combine([good, st]).flags & 2)
+
+
+def test_mean_and_var_are_the_correctly_rounded_exact_values_on_random_states():
+    """knox_finalize.h evaluates exact_sum / n and (Q - D*D/n) / (n-1) in double-double; the same code finalises the
+    per-window values on the device.  Against exact rationals, rounded once, over many random states incl. huge counts,
+    cancellation (D far from 0) and sums whose low word matters."""
+    rng = np.random.default_rng(20260)
+    st = AggState()
+    st.dtype = int(BlockType.Float64)
+    st.flags = 3
+    st.first_row = st.last_row = st.min_row = st.max_row = 0
+    for _ in range(4000):
+        n = int(rng.choice([1, 2, 3, 7, 10, 1000, 65536, 10 ** 6 + 3, 2 ** 30, 2 ** 31 - 1, int(rng.integers(1, 2 ** 32))]))
+        hi = float(rng.standard_normal() * 10.0 ** int(rng.integers(-5, 15)))
+        lo = float(np.spacing(hi) * rng.uniform(-0.5, 0.5))
+        st.count, st.fsum_hi, st.fsum_lo = n, hi, lo
+        want = float((Fraction(hi) + Fraction(lo)) / n)
+        assert K.agg_value(st, R.Mean)[0] == want, (hi, lo, n)
+        assert K.agg_value(st, R.Sum)[0] == float(Fraction(hi) + Fraction(lo))
+        if n >= 2:
+            q = abs(hi) * float(rng.uniform(0.5, 2.0)) + 1.0
+            ql = float(np.spacing(q) * rng.uniform(-0.5, 0.5))
+            d = float(rng.uniform(-1, 1)) * math.sqrt(q * n) * 0.7          # D*D/n <= Q/2: m2 stays positive
+            dl = float(np.spacing(d) * rng.uniform(-0.5, 0.5))
+            st.m_sq_hi, st.m_sq_lo, st.m_dev_hi, st.m_dev_lo = q, ql, d, dl
+            D, Q = Fraction(d) + Fraction(dl), Fraction(q) + Fraction(ql)
+            want_v = float((Q - D * D / n) / (n - 1))
+            got = K.agg_value(st, R.Var)[0]
+            assert got == want_v, (q, ql, d, dl, n)
+            assert K.agg_value(st, R.Std)[0] == math.sqrt(want_v)

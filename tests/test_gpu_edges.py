@@ -55,6 +55,35 @@ def test_odd_pack_sizes_and_short_last_pack(ctx, pack_rows):
     col.free(); bits.free()
 
 
+@pytest.mark.parametrize("n,pack_rows", [(3 * 4096 + 100, 4096), (5 * 960 + 7, 960), (8 * 65536, 65536), (3 * 65536 + 5, 65536), (4 * 1024, 1024)])
+def test_pruned_packs_never_match_whatever_the_pack_shape(ctx, n, pack_rows):
+    """pack_skip[p] = 1 means "no row of pack p matches" (pack/stats/match.go:112-195 pruned it) for the bitset, the count,
+    the per-pack counts AND the aggregates -- also when the packs are too small or too ragged for the fused kernel's
+    pack-granular walk (a short last pack is the normal case in the reference)."""
+    rng = np.random.default_rng(n + pack_rows)
+    n_packs = (n + pack_rows - 1) // pack_rows
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    f = (rng.integers(0, 4096, n) / 16.0).astype(np.float64)
+    skip = (rng.random(n_packs) < 0.4).astype(np.uint8)
+    skip[min(1, n_packs - 1)] = 1
+    live = ~np.repeat(skip.astype(bool), pack_rows)[:n]
+    cv, cf = ctx.upload(v, pack_rows), ctx.upload(f, pack_rows)
+    bits = ctx.bits(n)
+    for tree, want in ((And(Leaf(0, FilterMode.Lt, 250)), (v < 250) & live),
+                       (And(Leaf(0, FilterMode.Range, -500, 500), Leaf(1, FilterMode.Ge, 64.0)), (v >= -500) & (v <= 500) & (f >= 64.0) & live)):
+        res = ctx.scan(tree, [cv, cf], aggs=[(R.Sum, 0), (R.Max, 1), (R.Count, 0)], bits_out=bits, pack_counts=True, pack_skip=skip)
+        assert res.count == int(want.sum())
+        assert (np.unpackbits(bits.bytes(), bitorder="little")[:n].astype(bool) == want).all()
+        assert res.pack_counts.tolist() == [int(want[p * pack_rows:(p + 1) * pack_rows].sum()) for p in range(n_packs)]
+        assert res.value(0)[0] == int(v[want].sum()) and res.value(2)[0] == int(want.sum())
+        assert res.value(1)[0] == f[want].max() and res.value(1)[2] == int(np.flatnonzero(want & (f == f[want].max()))[0])
+        # without a result bitset the contract is the same
+        res2 = ctx.scan(tree, [cv, cf], aggs=[(R.Sum, 0)], pack_skip=skip)
+        assert res2.count == int(want.sum()) and res2.value(0)[0] == int(v[want].sum())
+    for o in (cv, cf, bits):
+        o.free()
+
+
 def test_result_ring_is_fifo_and_bounded(ctx):
     x = np.arange(100000, dtype=np.int64)
     col = ctx.upload(x, 1024)

@@ -1,0 +1,158 @@
+"""The host-facing tails of the window / selection path:
+
+  * knox_reduce_buckets_values: Reducer.Value() per window finalised on the device == knox_agg_value over the states
+    knox_reduce_buckets returns (same code, knox_finalize.h), every reducer, every width, ordered and out-of-order time;
+  * the hand-written stable radix sort behind out-of-order time (knox_sort.hip): 1, 2, 3 and 4 digit passes, against a
+    stable numpy argsort -- First / Last observe the stream order inside a window, which is exactly what stability means;
+  * knox_bits_indexes_view == knox_bits_indexes; the async flag / count ring shared with knox_scan_async."""
+import numpy as np
+import pytest
+
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf
+from knoxdb_amd.types import BlockType as B, FilterMode as F, ReducerFunc as R
+
+pytestmark = pytest.mark.gpu
+
+FUNCS = [R.Sum, R.First, R.Last, R.Min, R.Max, R.Mean, R.Var, R.Std, R.Count]
+NP = {B.Int64: np.int64, B.Float64: np.float64, B.Float32: np.float32, B.Int16: np.int16, B.Uint8: np.uint8, B.Uint32: np.uint32}
+
+
+def _values(rng, bt, n):
+    dt = NP[bt]
+    if np.dtype(dt).kind == "f":
+        v = (rng.integers(-(1 << 18), 1 << 18, n) / 64.0).astype(dt)
+        v[rng.integers(0, n, 7)] = np.nan
+        v[rng.integers(0, n, 7)] = -0.0
+        return v
+    info = np.iinfo(dt)
+    return rng.integers(info.min, info.max, n, endpoint=True, dtype=dt)
+
+
+def test_window_values_equal_the_host_finalised_states():
+    rng = np.random.default_rng(88)
+    with K.Context(0) as ctx:
+        for ordered in (True, False):
+            n, step = 150_000, 37
+            t = 1_000_000 + np.cumsum(rng.integers(0, 3, n))
+            if not ordered:
+                t = rng.permutation(t)
+            t = t.astype(np.int64)
+            t_from = int(t.min()) + 11
+            nb = int((t.max() - t_from) // step) - 2         # rows before the first and after the last window
+            tcol = ctx.upload(t, 4096)
+            bits_h = np.packbits(rng.random(n) < 0.55, bitorder="little")
+            mask = ctx.bits(n).upload(bits_h)
+            for bt in (B.Int64, B.Float64, B.Float32, B.Int16, B.Uint8):
+                v = _values(rng, bt, n)
+                vcol = ctx.upload(v, 4096)
+                for m in (None, mask):
+                    states = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=m, moments=True)
+                    for f in FUNCS:
+                        vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                        vals, seen = vals.copy(), seen.copy()
+                        want = np.zeros(nb, dtype=NP[bt])
+                        want_seen = np.zeros(nb, dtype=np.uint8)
+                        for k in range(nb):
+                            val, sn, _ = K.agg_value(states[k], f)
+                            want[k], want_seen[k] = val, sn
+                        assert (seen == want_seen).all(), (ordered, bt, f)
+                        if np.dtype(NP[bt]).kind == "f":   # NaN payloads are not part of Value()'s contract; signed zeros are
+                            assert np.array_equal(vals, want, equal_nan=True) and (np.signbit(vals) == np.signbit(want))[~np.isnan(want)].all(), (ordered, bt, f)
+                        else:
+                            assert vals.tobytes() == want.tobytes(), (ordered, bt, f)
+                vcol.free()
+            tcol.free(); mask.free()
+
+
+@pytest.mark.parametrize("nb,n", [(200, 300_000), (60_000, 1 << 20), (70_000, 1 << 20), ((1 << 24) + 5, 1 << 21), (1, 5000), (256, 70_001), (257, 4097)])
+def test_out_of_order_windows_sort_is_stable_for_every_pass_count(nb, n):
+    """keys < 2^8: 1 pass, < 2^16: 2, < 2^24: 3, above: 4 digit passes"""
+    rng = np.random.default_rng(nb)
+    step, t_from = 10, 5000
+    key = rng.integers(-2, nb + 2, n)                      # some rows before / after every window
+    t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
+    sel = rng.random(n) < 0.7
+    inside = sel & (key >= 0) & (key < nb)
+    with K.Context(0) as ctx:
+        tcol = ctx.upload(t, 4096)
+        mask = ctx.bits(n).upload(np.packbits(sel, bitorder="little"))
+        rows = np.flatnonzero(inside)
+        order = rows[np.argsort(key[rows], kind="stable")]    # window order, stream order inside a window
+        ks = key[order]
+        first_pos = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+        last_pos = np.r_[first_pos[1:] - 1, ks.size - 1]
+        present = ks[first_pos]
+        for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8):
+            dt = NP[bt]
+            info = np.iinfo(dt)
+            v = rng.integers(info.min, info.max, n, endpoint=True, dtype=dt)
+            vcol = ctx.upload(v, 4096)
+            got = {}
+            for f in (R.First, R.Last, R.Count, R.Sum, R.Max):
+                vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=mask)
+                got[f] = (vals.copy(), seen.copy())
+            seen = got[R.First][1]
+            assert np.flatnonzero(seen).tolist() == present.tolist()
+            assert (got[R.First][0][present] == v[order[first_pos]]).all(), bt
+            assert (got[R.Last][0][present] == v[order[last_pos]]).all(), bt
+            cnt = np.bincount(ks, minlength=nb)[present]
+            assert (got[R.Count][0][present] == cnt.astype(dt)).all(), bt          # CountReducer counts in T
+            sums = np.zeros(nb, dtype=np.uint64)
+            np.add.at(sums, ks, v[order].astype(np.int64).astype(np.uint64))
+            udt = np.dtype("u%d" % np.dtype(dt).itemsize)                            # SumReducer wraps in T
+            assert (got[R.Sum][0].view(udt)[present] == sums[present].astype(udt)).all(), bt
+            mx = np.full(nb, info.min, dtype=np.int64)
+            np.maximum.at(mx, ks, v[order].astype(np.int64))
+            assert (got[R.Max][0][present].astype(np.int64) == mx[present]).all(), bt
+            # windows without rows: Value() is the zero value, seen 0
+            assert not got[R.Sum][0][seen == 0].any()
+            vcol.free()
+        tcol.free(); mask.free()
+
+
+def test_indexes_view_is_indexes_without_a_copy():
+    rng = np.random.default_rng(5)
+    with K.Context(0) as ctx:
+        for n, p in ((1 << 22, 0.3), (100_003, 0.9), (64, 0.5), (1 << 20, 0.0), (1 << 20, 1.0), (1, 1.0)):
+            sel = rng.random(n) < p if 0 < p < 1 else np.full(n, bool(p))
+            bits = ctx.bits(n).upload(np.packbits(sel, bitorder="little"))
+            view = bits.indexes_view()
+            want = np.flatnonzero(sel).astype(np.uint32)
+            assert view.dtype == np.uint32 and view.shape == want.shape and (view == want).all()
+            assert (bits.indexes() == want).all()
+            buf = np.zeros(want.size + 3, dtype=np.uint32)
+            assert (bits.indexes(out=buf) == want).all()
+            bits.free()
+
+
+def test_async_flags_share_the_result_ring_with_the_scans():
+    rng = np.random.default_rng(9)
+    n = 1 << 18
+    with K.Context(0) as ctx:
+        ha, hb = rng.random(n) < 0.5, rng.random(n) < 0.5
+        a = ctx.bits(n).upload(np.packbits(ha, bitorder="little"))
+        b = ctx.bits(n).upload(np.packbits(hb, bitorder="little"))
+        z = ctx.bits(n)
+        col = ctx.upload(np.arange(n, dtype=np.int64), 4096)
+        plan = ctx.plan(And(Leaf(0, F.Lt, 1000)), [col])
+        a.and_flag_async(b)                  # a &= b           -> any True, all False
+        a.count_async()                      #                  -> popcount(a & b)
+        ctx.scan_async(plan)                 # a scan in between
+        z.or_flag_async(z)                   # 0 | 0            -> any False, all False
+        with pytest.raises(K.KnoxError):     # 5th uncollected result: busy
+            a.count_async()
+        assert ctx.bits_collect() == (True, False, None)
+        assert ctx.bits_collect() == (None, None, int((ha & hb).sum()))
+        with pytest.raises(K.KnoxError):     # the oldest is the scan's: wrong collector, nothing consumed
+            ctx.bits_collect()
+        assert ctx.scan_collect(plan).count == 1000
+        assert ctx.bits_collect() == (False, False, None)
+        with pytest.raises(K.KnoxError):     # nothing in flight
+            ctx.bits_collect()
+        # the blocking calls keep working and agree
+        z.one()
+        assert z.or_flag(a) == (True, True)
+        assert a.count() == int((ha & hb).sum())
+        for o in (a, b, z, col):
+            o.free()
