@@ -3080,7 +3080,13 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
     a.row_base = row_base;
     a.partials = (AggPartial *)(base + off_partials);
     const int grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cus * 8);
-    e = launch_bucket_reduce(ctx->stream, width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
+    // many small windows (a few hundred rows each): one wave per item instead of one workgroup per item
+    const bool small_items = n_items > (size_t)ctx->n_cus * 8 && n_rows / n_items < 2048;
+    if (small_items)
+        e = launch_bucket_reduce_waves(ctx->stream, width, (int)std::min<size_t>((n_items + 3) / 4, (size_t)ctx->n_cus * 16), a,
+                                       (const BucketItem *)(base + off_items), (uint32_t)n_items);
+    else
+        e = launch_bucket_reduce(ctx->stream, width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
     if (e == hipSuccess)
         e = launch_bucket_finalize(ctx->stream, width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, vals, row_base, dtype,
                                    (AggStateDev *)(base + off_states));

@@ -342,6 +342,122 @@ struct FirstLast {
     }
 };
 
+// 4-byte columns: the same contract as agg_iter below, organised around ONE all-ones / zero mask per value
+// (v_bfe_i32 of the selection bit) instead of a compare + select per use -- these instantiations are VALU bound:
+//   xb = e & m                         the selected raw value or 0: feeds the wrapping sum, the exact sum and the maximum
+//   sums (integers)                    Z = sum of xb (zero-extended, 64 bit); signed: exact sum = Z - 2^32 * #negatives
+//   sums (float32)                     as in agg_iter: sixteen values add exactly in float64 when their exponents span <= 24
+//   min / max pre-filter               v_min / v_max of bfi(m, e, neutral) in the column's OWN order (i32 / u32 / f32 --
+//                                      v_min_f32 / v_max_f32 drop NaNs, which are never candidates); converted to order
+//                                      keys once per iteration and compared with the wave's best keys
+template <unsigned AGG, unsigned FLV>
+__device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl, const u32x4 (&r)[kUnroll],
+                                            const uint32_t (&q)[kUnroll], uint64_t row0, uint64_t row_base, int lane) {
+    constexpr int W = 4, K = 4, RPL = 256;
+    static_assert(kUnroll * K <= 16, "the float exactness bound assumes at most 16 values per iteration");
+    constexpr bool ISF = FLV == FL_FLOAT;
+    constexpr bool ZSUM = (AGG & A_ISUM) != 0 || ((AGG & A_FSUM) != 0 && !ISF);
+    uint64_t z = 0;
+    uint32_t neg = 0;
+    uint32_t amax = 0, amin = 0xffffffffu;
+    double it = 0.0;
+    int32_t smin = 0x7fffffff, smax = (int32_t)0x80000000;
+    uint32_t umin = 0xffffffffu, umax = 0u;
+    float fmn = __uint_as_float(0x7f800000u), fmx = __uint_as_float(0xff800000u);
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const uint32_t e = (uint32_t)elem<W>(r[u], j);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)q[u], j, 1);  // all ones when selected
+            const uint32_t xb = e & m;
+            if constexpr (ZSUM) z += xb;
+            if constexpr ((AGG & A_FSUM) != 0 && FLV == FL_SIGNED) neg += xb >> 31;
+            if constexpr ((AGG & A_FSUM) != 0 && ISF) {
+                const uint32_t mag = xb & 0x7fffffffu;
+                amax = mag > amax ? mag : amax;
+                amin = (mag - 1u) < amin ? (mag - 1u) : amin;
+                it += (double)__uint_as_float(xb);
+            }
+            if constexpr ((AGG & A_MINMAX) != 0) {
+                if constexpr (FLV == FL_SIGNED) {
+                    const int32_t lo = (int32_t)(xb | (0x7fffffffu & ~m)), hi = (int32_t)(xb | (0x80000000u & ~m));
+                    smin = lo < smin ? lo : smin;
+                    smax = hi > smax ? hi : smax;
+                } else if constexpr (FLV == FL_UNSIGNED) {
+                    const uint32_t lo = xb | ~m;
+                    umin = lo < umin ? lo : umin;
+                    umax = xb > umax ? xb : umax;
+                } else {
+                    fmn = fminf(fmn, __uint_as_float(xb | (0x7f800000u & ~m)));
+                    fmx = fmaxf(fmx, __uint_as_float(xb | (0xff800000u & ~m)));
+                }
+            }
+        }
+    }
+    if constexpr ((AGG & A_ISUM) != 0) acc.isum += z;
+    if constexpr ((AGG & A_FSUM) != 0 && !ISF) {
+        if constexpr (FLV == FL_UNSIGNED) {
+            acc.add128(z, 0);
+        } else {
+            const uint64_t sv = z - ((uint64_t)neg << 32);  // sign-extended sum: |.| < 2^36
+            acc.add128(sv, (int64_t)sv >> 63);
+        }
+    }
+    if constexpr ((AGG & A_FSUM) != 0 && ISF) {
+        // zeros are ignored by the span test (min over mag - 1 wraps them to the top); Inf / NaN take the per-value path
+        const bool ok = amax < 0x7f800000u && (amin == 0xffffffffu || ((amax >> 23) - ((amin + 1u) >> 23)) <= 24u);
+        if (__all(ok)) {
+            const double s = acc.hi + it;
+            const double bb = s - acc.hi;
+            acc.lo += (acc.hi - (s - bb)) + (it - bb);
+            acc.hi = s;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    double x = to_f64_c<W, FLV>(elem<W>(r[u], j));
+                    x = ((q[u] >> j) & 1u) ? x : 0.0;
+                    const double s = acc.hi + x;
+                    const double bb = s - acc.hi;
+                    acc.lo += (acc.hi - (s - bb)) + (x - bb);
+                    acc.hi = s;
+                }
+            }
+        }
+    }
+    if constexpr ((AGG & A_MINMAX) != 0) {
+        uint32_t imin, imax;
+        if constexpr (FLV == FL_SIGNED) {
+            imin = (uint32_t)smin ^ 0x80000000u;
+            imax = (uint32_t)smax ^ 0x80000000u;
+        } else if constexpr (FLV == FL_UNSIGNED) {
+            imin = umin;
+            imax = umax;
+        } else {
+            imin = (uint32_t)fkey<W>(__float_as_uint(fmn));
+            imax = (uint32_t)fkey<W>(__float_as_uint(fmx));
+        }
+        if (__any((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax)) {
+#pragma unroll 1
+            for (int u = 0; u < kUnroll; u++) {
+                const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
+#pragma unroll
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+            }
+            wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
+            wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
+        }
+    }
+    if constexpr ((AGG & A_FIRSTLAST) != 0) {
+        uint64_t qq = 0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) qq |= (uint64_t)q[u] << (u * K);
+        fl.update(row0, qq);
+    }
+}
+
 // One wave iteration (kUnroll 16-byte loads of this lane, selection bits q[u]) into the
 // accumulator.  Same results as one acc_update per row, organised so the common case is cheap:
 //   * sums: error-free TwoSum per selected value, no branch (a non-finite running sum keeps an
@@ -354,6 +470,10 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
                                          const uint32_t (&q)[kUnroll], uint64_t row0, uint64_t row_base, int lane) {
     constexpr int K = WT<W>::K;
     constexpr int RPL = 64 * K;
+    if constexpr (W == 4) {
+        agg_iter_w4<AGG, FLV>(acc, wm, fl, r, q, row0, row_base, lane);
+        return;
+    }
     uint64_t it_z = 0;  // this iteration's sum of the selected raw (zero-extended) values
     if constexpr ((AGG & A_ISUM) != 0) {
         if constexpr (W <= 2) {  // <= 64 values below 2^16: a 32-bit partial sum cannot overflow
@@ -759,18 +879,17 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // per-wave-tile popcounts, laid out [workgroup][wave][round] so that a wave's counts are contiguous
     uint32_t *tcbase = a.tile_counts ? a.tile_counts + ((uint64_t)lb * kWavesPerBlock + (uint64_t)wave) * a.tc_rounds : nullptr;
     uint32_t tcreg = 0, round = 0, cnt_prev = 0;
-    for (uint64_t vt = lb; vt < a.n_tiles; vt += gridDim.x) {
-        // packs pruned by the caller's statistics are never touched: with a live-pack list the
-        // virtual tile index walks only the surviving packs (their bitset ranges were zeroed by the host)
+    // packs pruned by the caller's statistics are never touched: with a live-pack list the virtual tile index walks
+    // only the surviving packs (their bitset ranges were zeroed by the host).  A wave owns iters*WAVE_ROWS consecutive
+    // rows of its tile (one contiguous bitset burst): the first of them
+    auto wave_row0 = [&](uint64_t vt) -> uint64_t {
         uint64_t tile = vt;
         if (a.live_packs != nullptr) tile = ((uint64_t)a.live_packs[vt >> a.tpp_shift] << a.tpp_shift) + (vt & ((1ull << a.tpp_shift) - 1));
-        // a wave owns iters*WAVE_ROWS consecutive rows of the tile (one contiguous bitset burst)
-        const uint64_t wrow0 = (tile * kWavesPerBlock + (uint64_t)wave) * iters * WAVE_ROWS;
-#pragma unroll 1
-        for (uint32_t it = 0; it < iters; it++) {
-        const uint64_t row0 = wrow0 + (uint64_t)it * WAVE_ROWS;  // wave-uniform
+        return (tile * kWavesPerBlock + (uint64_t)wave) * iters * WAVE_ROWS;
+    };
+    // the kUnroll 16-byte loads per column of one wave iteration
+    auto load_iter = [&](u32x4 (&r)[NL][kUnroll], u32x4 (&ra)[kUnroll], uint64_t row0) {
         const uint64_t vec0 = row0 / K + lane;
-        u32x4 r[NL][kUnroll];
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             const u32x4 *p = (const u32x4 *)a.leaf[l].col + vec0;
@@ -786,12 +905,16 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
 #pragma unroll
         for (int l = 0; l < NL; l++) ld_fence(r[l][0], r[l][1], r[l][2], r[l][3]);
 #endif
-        u32x4 ra[kUnroll];
         if constexpr (SEP && AGG != 0) {
             const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) ra[u] = ld16<true>(p + u * 64);
         }
+    };
+    // one wave iteration over loaded registers: predicate, bitset words into the LDS stage, aggregates; the last
+    // iteration of a tile writes the wave's burst
+    auto body = [&](const u32x4 (&r)[NL][kUnroll], const u32x4 (&ra)[kUnroll], uint64_t wrow0, uint32_t it) {
+        const uint64_t row0 = wrow0 + (uint64_t)it * WAVE_ROWS;  // wave-uniform
         uint32_t q[kUnroll];
         constexpr bool kSwar = W <= 2 && NL == 1 && !SEP && (AGG == 0 || AGG == A_ISUM);
         constexpr bool kSwarAgg = W <= 2 && NL == 1 && !SEP && !kSwar && FLV != FL_FLOAT;  // every other aggregate class of the narrow types
@@ -817,6 +940,18 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             uint32_t qq = 0;
+            if constexpr (NL == 1 && W >= 4 && (AGG & ~A_ISUM) != 0) {
+                // VALU-bound instantiations: the compare's carry shifts straight into the word, qq = 2*qq + (d <= diff),
+                // highest element first (one v_addc instead of a select + or per value)
+#pragma unroll
+                for (int j = K - 1; j >= 0; j--) {
+                    U x = elem<W>(r[0][u], j);
+                    if constexpr (ANYF) x = fkey<W>(x);
+                    const U d = (U)(x - lo[0]);
+                    if constexpr (W == 4) asm("v_cmp_ge_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qq) : "v"(d), "s"(diff[0]) : "vcc");
+                    else asm("v_cmp_ge_u64 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qq) : "v"(d), "s"(diff[0]) : "vcc");
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 if constexpr (NL == 1) {
@@ -833,6 +968,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
                     }
                     qq |= ((tt >> idx) & 1u) << j;
                 }
+            }
             }
             if constexpr (NL == 1) qq = (qq & m1) | (~qq & m0);
             q[u] = qq;
@@ -870,7 +1006,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             if constexpr (SEP) agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
             else agg_iter<W, AGG, FLV>(acc, wm, fl, r[0], q, row0, a.row_base, lane);
         }
-        }  // it
+        if (it + 1 == iters) {
         if (a.bits != nullptr) {
             // LDS ops of one wave execute in order: the reads below see the words written above.
             // One burst of iters * WAVE_ROWS/8 contiguous bytes per wave (1 KiB for 8-byte types at
@@ -906,6 +1042,51 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
                 tcreg = lane == (int)(round & 31u) ? total : tcreg;
                 if ((round & 31u) == 31u && lane < 32) tcbase[(round & ~31u) + lane] = tcreg;
                 round++;
+            }
+        }
+        }
+    };
+    // Aggregate-heavy single-column scans are software pipelined: the loads of the NEXT wave iteration (the next tile's
+    // first one at a tile's end) are in flight while the current one is evaluated -- two register sets, roles fixed by an
+    // even iteration count, no register moves.  With 2-3 workgroups per CU resident, waiting out the full HBM latency
+    // once per iteration is what these instantiations were bound by (measured: float32 +4 %, int16 ALL +7 %, int32 ALL
+    // +2 %).  The plain filter / filter+sum kernels do so little between loads that the extra loads in flight only
+    // disturb the read / write mix at the memory controllers (int64 headline -10 %): they keep the simple loop.
+    constexpr bool kPipe = NL == 1 && !SEP && (AGG & ~A_ISUM) != 0;
+    if (kPipe && (iters & 1u) == 0) {
+        u32x4 ra[kUnroll];
+        u32x4 ra_a[NL][kUnroll], rb[NL][kUnroll];
+        uint64_t vt = lb;
+        if (vt < a.n_tiles) {
+            uint64_t w0 = wave_row0(vt);
+            load_iter(ra_a, ra, w0);
+            for (;;) {
+                const uint64_t vn = vt + gridDim.x;
+                const bool more = vn < a.n_tiles;  // wave-uniform
+                const uint64_t wn = more ? wave_row0(vn) : 0;
+#pragma unroll 1
+                for (uint32_t it = 0; it < iters; it += 2) {
+                    load_iter(rb, ra, w0 + (uint64_t)(it + 1) * WAVE_ROWS);
+                    body(ra_a, ra, w0, it);
+                    // always issued (at the very end: a reload of this tile's first rows, never used), so the waits below
+                    // count on a fixed number of loads in flight and only wait for the older set
+                    load_iter(ra_a, ra, it + 2 < iters ? w0 + (uint64_t)(it + 2) * WAVE_ROWS : more ? wn : w0);
+                    body(rb, ra, w0, it + 1);
+                }
+                if (!more) break;
+                vt = vn;
+                w0 = wn;
+            }
+        }
+    } else {
+        for (uint64_t vt = lb; vt < a.n_tiles; vt += gridDim.x) {
+            const uint64_t w0 = wave_row0(vt);
+#pragma unroll 1
+            for (uint32_t it = 0; it < iters; it++) {
+                u32x4 r[NL][kUnroll];
+                u32x4 ra[kUnroll];
+                load_iter(r, ra, w0 + (uint64_t)it * WAVE_ROWS);
+                body(r, ra, w0, it);
             }
         }
     }
@@ -1439,6 +1620,53 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_kernel(const ScanArgs a,
     }
 }
 
+// many small windows: one WAVE per work item -- no workgroup barrier and no LDS round per item (a window of a few hundred
+// rows costs a few loop iterations + one wave reduction); the rows are taken lane-strided, first / last ride in the Acc
+template <int W, unsigned AGG, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_reduce_wave_kernel(const ScanArgs a, const BucketItem *items, uint32_t n_items) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = gridDim.x * kWavesPerBlock;
+    const uint8_t *mask8 = (const uint8_t *)a.mask;
+    for (uint32_t it = wave; it < n_items; it += n_waves) {
+        const uint64_t rb = items[it].begin, re = items[it].end;
+        Acc acc;
+        acc.init();
+        for (uint64_t row = rb + lane; row < re; row += 64) {
+            const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
+            acc.count += hit;
+            acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+        }
+        wave_reduce(acc);
+        if (lane == 0) {
+            AggPartial p;
+            p.count = acc.count; p.isum = acc.isum; p.hi = acc.hi; p.lo = acc.lo; p.xlo = acc.xlo; p.xhi = acc.xhi;
+            p.minkey = acc.minkey; p.minrow = acc.minrow; p.maxkey = acc.maxkey; p.maxrow = acc.maxrow;
+            p.firstrow = acc.firstrow; p.lastrow = acc.lastrow1;
+            a.partials[it] = p;
+        }
+    }
+}
+
+template <int W> static hipError_t bucket_reduce_waves_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) KNOX_LAUNCH((bucket_reduce_wave_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+    }
+    if (a.agg_flavor == FL_SIGNED) KNOX_LAUNCH((bucket_reduce_wave_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    KNOX_LAUNCH((bucket_reduce_wave_kernel<W, A_ALL, FL_UNSIGNED>), grid, a, items, n_items);
+}
+
+hipError_t launch_bucket_reduce_waves(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    if (n_items == 0 || grid <= 0) return hipSuccess;
+    switch (width) {
+    case 8: return bucket_reduce_waves_w<8>(s, grid, a, items, n_items);
+    case 4: return bucket_reduce_waves_w<4>(s, grid, a, items, n_items);
+    case 2: return bucket_reduce_waves_w<2>(s, grid, a, items, n_items);
+    case 1: return bucket_reduce_waves_w<1>(s, grid, a, items, n_items);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 template <int W> static hipError_t bucket_reduce_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
     constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
     if constexpr (W >= 4) {
@@ -1810,11 +2038,11 @@ __global__ void __launch_bounds__(kBlock) bitop_kernel(uint64_t *dst, const uint
         notall |= (~d) & vm;
     }
     if (flags != nullptr) {
-        const bool wany = __any(any != 0);
-        const bool wnot = __any(notall != 0);
-        if ((threadIdx.x & 63) == 0) {
-            // same-address atomics serialize in L2 (16K waves -> ~0.2 ms): look first, only the first few waves that
-            // find the flag clear pay for the read-modify-write
+        // one look per WORKGROUP (same-address traffic serializes in L2): only the first few workgroups that find a flag
+        // clear pay for the read-modify-write
+        const int wany = __syncthreads_or(any != 0);
+        const int wnot = __syncthreads_or(notall != 0);
+        if (threadIdx.x == 0) {
             if (wany && __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[0], 1u);
             if (wnot && __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[1], 1u);
         }
@@ -1825,7 +2053,7 @@ hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *sr
     const uint64_t nwords = (size_bits + 63) >> 6;
     if (nwords == 0) return hipSuccess;
     uint64_t g = (nwords + kBlock - 1) / kBlock;
-    if (g > 4096) g = 4096;
+    if (g > 1024) g = 1024;
     const int grid = (int)g;
     switch (op) {
     case BIT_AND: KNOX_LAUNCH((bitop_kernel<BIT_AND>), grid, dst, src, nwords, size_bits, flags);

@@ -46,9 +46,11 @@ cases = [
     ("i64 x2 AND + sum", ["i64", "i64b"], lambda: And(Leaf(0, F.Gt, 0), Leaf(1, F.Lt, 0)), [(R.Sum, 0)], 16.125),
     ("i32 Between+sum", ["i32"], lambda: And(Leaf(0, F.Range, -(1 << 28), 1 << 28)), [(R.Sum, 0)], 4.125),
     ("f32 Lt+sum/min/max/mean", ["f32"], lambda: And(Leaf(0, F.Lt, 0.25)), [(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0)], 4.125),
+    ("i32 Between+ALL", ["i32"], lambda: And(Leaf(0, F.Range, -(1 << 28), 1 << 28)), ALLA, 4.125),
     ("i16 Between+sum", ["i16"], lambda: And(Leaf(0, F.Range, -(1 << 13), 1 << 13)), [(R.Sum, 0)], 2.125),
     ("i16 Between+ALL", ["i16"], lambda: And(Leaf(0, F.Range, -(1 << 13), 1 << 13)), ALLA, 2.125),
     ("u8 Between+sum", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), [(R.Sum, 0)], 1.125),
+    ("u8 Between+ALL", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), ALLA, 1.125),
 ]
 
 

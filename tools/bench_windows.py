@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
-"""Time-window aggregation timings (whole calls): ordered clock at 2^30 rows, shuffled clock (stable-sort path) at 2^28."""
+"""Time-window aggregation and selection-vector timings (whole calls, wall clock around the C call):
+ordered clock at 2^30 / 2^28 rows, shuffled clock (hand-written stable radix sort path) at 2^28 / 2^26, each as
+  states  knox_reduce_buckets          144-byte states to the caller's (pageable) memory
+  values  knox_reduce_buckets_values   Reducer.Value() finalised on the device, 8+1 B/window into the pinned result buffer
+and knox_bits_indexes / knox_bits_indexes_view of 16.8 M hits, and the flag / count calls blocking vs through the ring."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import knoxdb_amd as K
 from knoxdb_amd import And, Leaf
 from knoxdb_amd.types import BlockType as B, FilterMode as F, ReducerFunc as R
 
 ctx = K.Context(0)
 PACK = 1 << 20
+quick = "--quick" in sys.argv
 
 
 def timed(fn, reps=5):
@@ -19,7 +25,7 @@ def timed(fn, reps=5):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-for lg, shuffled in ((30, False), (28, False), (28, True), (26, True)):
+for lg, shuffled in ((28, False), (28, True)) if quick else ((30, False), (28, False), (28, True), (26, True)):
     n = 1 << lg
     col = ctx.generate(B.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=PACK)
     clock = ctx.generate(B.Int64, 0, 9, n, lo=1000, span=1 << 20, pack_rows=PACK) if shuffled else ctx.generate(B.Int64, 3, 0, n, lo=1000, pack_rows=PACK)
@@ -29,6 +35,44 @@ for lg, shuffled in ((30, False), (28, False), (28, True), (26, True)):
         step = ((1 << 20) if shuffled else n) // nb
         ms = timed(lambda: ctx.reduce_buckets(clock, col, 1000, max(step, 1), nb, mask=bits))
         ms_v = timed(lambda: ctx.reduce_buckets(clock, col, 1000, max(step, 1), nb, mask=bits, moments=True))
-        print("2^%d rows, %s clock, %7d windows: %8.2f ms  (%.1f G rows/s); with var/std %8.2f ms" % (
-            lg, "shuffled" if shuffled else "ordered ", nb, ms, n / ms / 1e6, ms_v))
+        ms_sum = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Sum, 1000, max(step, 1), nb, mask=bits))
+        ms_std = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Std, 1000, max(step, 1), nb, mask=bits))
+        print("2^%d rows, %s clock, %7d windows: states %8.2f ms (%.1f G rows/s), with var/std %8.2f ms | values: sum %7.2f ms (%.1f G rows/s), std %7.2f ms" % (
+            lg, "shuffled" if shuffled else "ordered ", nb, ms, n / ms / 1e6, ms_v, ms_sum, n / ms_sum / 1e6, ms_std), flush=True)
     col.free(); clock.free(); bits.free()
+
+# selection vector of 16.8 M hits out of 2^26 rows
+n = 1 << 26
+col = ctx.generate(B.Int64, 0, 2, n, lo=0, span=1 << 20, pack_rows=PACK)
+bits = ctx.bits(n, for_col=col)
+res = ctx.scan(And(Leaf(0, F.Lt, 1 << 18)), [col], bits_out=bits)
+pinned = ctx.host_array(res.count + 8, np.uint32)
+print("indexes of %.1f M hits: view (pinned result buffer) %.2f ms | into knox_host_alloc memory %.2f ms | into a fresh pageable numpy array %.2f ms" % (
+    res.count / 1e6, timed(lambda: bits.indexes_view()), timed(lambda: bits.indexes(out=pinned)), timed(lambda: bits.indexes(capacity=res.count + 8))), flush=True)
+
+# flags / counts: blocking calls vs four enqueued + four collected
+a, b = ctx.bits(n), ctx.bits(n)
+a.one(); b.one()
+
+
+def ring4():
+    for _ in range(4):
+        a.and_flag_async(b)
+    for _ in range(4):
+        ctx.bits_collect()
+
+
+def ring4c():
+    for _ in range(4):
+        a.count_async()
+    for _ in range(4):
+        ctx.bits_collect()
+
+
+print("2^26-bit bitsets: and_flag blocking %.1f us/call, through the ring %.1f us/call | popcount blocking %.1f us/call, through the ring %.1f us/call" % (
+    timed(lambda: a.and_flag(b), 50) * 1e3, timed(ring4, 50) * 1e3 / 4, timed(lambda: a.count(), 50) * 1e3, timed(ring4c, 50) * 1e3 / 4), flush=True)
+small = ctx.bits(1 << 16)
+small.one()
+print("2^16-bit bitset (one pack): popcount blocking %.1f us/call, through the ring %.1f us/call" % (
+    timed(lambda: small.count(), 200) * 1e3,
+    timed(lambda: ([small.count_async() for _ in range(4)], [ctx.bits_collect() for _ in range(4)]), 200) * 1e3 / 4), flush=True)
