@@ -253,7 +253,9 @@ size_t knox_bits_size(const knox_bits *b);
 void *knox_bits_device_ptr(const knox_bits *b);
 int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host);
 /* Bitmap container of a bool column -> bits (size must equal the container's N): [20] zero, [21] one,
- * [22] dense (internal/encode/bitmap.go:103-135); [23] sparse (roaring) returns KNOX_E_UNSUPPORTED. */
+ * [22] dense (internal/encode/bitmap.go:103-135); [23] sparse = a serialized xroar bitmap (internal/xroar:
+ * key node + array / bitmap containers), decoded with bounds checks on the host into the dense form (it is chosen for
+ * < 1 bit in 16 set, so the dense bytes are at most twice its size). */
 int knox_bits_upload_bitmap_container(knox_ctx *ctx, knox_bits *bits, const uint8_t *buf, size_t len);  /* (size+7)/8 bytes */
 int knox_bits_download(knox_ctx *ctx, const knox_bits *b, uint8_t *host);
 int knox_bits_zero(knox_ctx *ctx, knox_bits *b);                         /* Bitset.Zero :533 */

@@ -1574,6 +1574,58 @@ KNOX_API int knox_bits_upload(knox_ctx *ctx, knox_bits *b, const uint8_t *host) 
 
 // Bitmap containers of bool columns (internal/encode/bitmap.go:103-135, :240-262): [20] zero, [21] one,
 // [22] dense = the Bitset bytes; [23] sparse is a serialized roaring bitmap (internal/xroar): host path.
+// TBitmapSparse [23]: the payload is a serialized xroar bitmap (internal/xroar/bitmap.go:98-113, keys.go:3-26,
+// container.go:33-78,356-377 -- the sroar layout): uint16 words; the first u64[0] words are the key node: u64[1] = number
+// of keys, then (key, offset) pairs, key = the value's upper 48 bits, offset = the container's position in words.  A
+// container is [size][type][cardinality lo][cardinality hi] + data: type 0 = `cardinality` sorted low-16-bit values,
+// type 1 = 4096 words of one bit per value, MSB first (bitmapMask[i] = 1 << (15 - i)).  Decoded on the host into the
+// dense LSB-first bytes of the bitset (the container is chosen for < 1 bit in 16 set, bitmap.go:253-257: the dense form
+// is at most twice its size); every offset and value is bounds-checked.
+static int roaring_to_dense(const uint8_t *buf, size_t len, size_t n_bits, std::vector<uint8_t> &dense) {
+    dense.assign(bits_bytes(n_bits), 0);
+    if (len < 8) return KNOX_OK;  // NewFromBytes: "len(src) < 8 -> New()": empty
+    if (len & 1) return KNOX_E_INVALID;
+    const size_t n_words = len / 2;
+    auto w16 = [&](size_t i) { uint16_t v; memcpy(&v, buf + 2 * i, 2); return v; };
+    auto w64 = [&](size_t i) { uint64_t v; memcpy(&v, buf + 8 * i, 8); return v; };
+    const uint64_t node_words = w64(0);
+    if (node_words < 8 || node_words > n_words || (node_words & 3)) return KNOX_E_RANGE;
+    const uint64_t n_keys = w64(1);
+    if (n_keys > (node_words / 4 - 2) / 2) return KNOX_E_RANGE;
+    for (uint64_t i = 0; i < n_keys; i++) {
+        const uint64_t key = w64(2 + 2 * i), off = w64(3 + 2 * i);
+        if (key & 0xffffull) return KNOX_E_INVALID;
+        if (off + 4 > n_words) return KNOX_E_RANGE;
+        const size_t size = w16(off), type = w16(off + 1), card = (size_t)w16(off + 2) + (size_t)w16(off + 3);
+        if (size < 4 || off + size > n_words) return KNOX_E_RANGE;
+        if (card == 0) continue;  // the container New() makes for key 0
+        if (key >= n_bits) return KNOX_E_RANGE;
+        if (type == 0) {
+            if (4 + card > size) return KNOX_E_RANGE;
+            for (size_t j = 0; j < card; j++) {
+                const uint64_t v = key | w16(off + 4 + j);
+                if (v >= n_bits) return KNOX_E_RANGE;
+                dense[v >> 3] |= (uint8_t)(1u << (v & 7));
+            }
+        } else if (type == 1) {
+            if (size < 4 + 4096) return KNOX_E_RANGE;
+            for (size_t wi = 0; wi < 4096; wi++) {
+                uint16_t x = w16(off + 4 + wi);
+                while (x) {
+                    const int lead = __builtin_clz((unsigned)x) - 16;  // MSB first: bit 15 is value 16*wi + 0
+                    const uint64_t v = key | (uint64_t)(wi * 16 + (size_t)lead);
+                    if (v >= n_bits) return KNOX_E_RANGE;
+                    dense[v >> 3] |= (uint8_t)(1u << (v & 7));
+                    x = (uint16_t)(x & ~(0x8000u >> lead));
+                }
+            }
+        } else {
+            return KNOX_E_INVALID;
+        }
+    }
+    return KNOX_OK;
+}
+
 KNOX_API int knox_bits_upload_bitmap_container(knox_ctx *ctx, knox_bits *b, const uint8_t *buf, size_t len) {
     if (!ctx || !b || !buf || len < 3) return KNOX_E_INVALID;
     const uint8_t type = buf[0];
@@ -1590,7 +1642,12 @@ KNOX_API int knox_bits_upload_bitmap_container(knox_ctx *ctx, knox_bits *b, cons
     if (o + sz > len) return KNOX_E_RANGE;
     if (type == 20) return knox_bits_zero(ctx, b);
     if (type == 21) return knox_bits_one(ctx, b);
-    if (type == 23) return KNOX_E_UNSUPPORTED;
+    if (type == 23) {
+        std::vector<uint8_t> dense;
+        int rc = roaring_to_dense(buf + o, (size_t)sz, b->size, dense);
+        if (rc) return rc;
+        return b->size ? knox_bits_upload(ctx, b, dense.data()) : KNOX_OK;
+    }
     if (sz < bits_bytes(b->size)) return KNOX_E_RANGE;
     return knox_bits_upload(ctx, b, buf + o);
 }

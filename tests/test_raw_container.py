@@ -410,6 +410,92 @@ def test_gpu_ingest_of_wide_and_bitmap_containers():
             assert (out.bytes() == want).all()
             b.free()
             out.free()
-        with pytest.raises(K.KnoxError) as e:  # sparse = roaring: host path
-            ctx.bits(m).upload_bitmap_container(bytes([23]) + O.put_uvarint(m) + O.put_uvarint(4) + b"abcd")
-        assert e.value.code == -5
+        # sparse [23] = a serialized xroar bitmap: see test_gpu_sparse_bitmap_container; a payload shorter than 8 bytes is
+        # the empty bitmap (NewFromBytes, xroar/bitmap.go:98-102), a node size beyond the buffer is refused
+        b = ctx.bits(m).upload_bitmap_container(bytes([23]) + O.put_uvarint(m) + O.put_uvarint(4) + b"abcd")
+        assert not b.bytes().any()
+        b.free()
+        with pytest.raises(K.KnoxError) as e:
+            ctx.bits(m).upload_bitmap_container(bytes([23]) + O.put_uvarint(m) + O.put_uvarint(16) + b"\xff" * 16)
+        assert e.value.code == -7
+
+
+def sroar_from_sorted(vals):
+    """The bytes xroar.NewFromSorted(vals).Bytes() lays out (internal/xroar/bitmap.go:52-79,121-185, keys.go:3-26,
+    container.go:33-78,356-377), restated as a builder for tests: uint16 words; a key node of u64s [node size in words,
+    number of keys, (key, container offset) ...]; the empty 64-word container New() makes for key 0; then one container
+    per 65536-value block: <= 2048 values -> array [size = 8 + n][type 0][cardinality][0] + the sorted low words, more ->
+    bitmap [4100][type 1][cardinality lo][cardinality hi] + 4096 words, value x at word x >> 4, bit 15 - (x & 15)."""
+    blocks = {}
+    for v in vals:
+        blocks.setdefault(int(v) & ~0xffff, []).append(int(v) & 0xffff)
+    if not blocks:
+        return b""                                     # Bytes() of an empty bitmap is nil
+    keys = sorted(set(blocks) | {0})
+    cap = len(keys) + 1                                # one spare slot, as a node that was grown for the keys has
+    node_words = 4 * (2 + 2 * cap)
+    words = [0] * node_words
+    off0 = len(words)
+    words += [64, 0, 0, 0] + [0] * 60                  # New(): the container of key 0, minContainerSize
+    offs = {0: off0}
+    for k in sorted(blocks):
+        lows = blocks[k]
+        off = len(words)
+        if len(lows) <= 2048:
+            words += [8 + len(lows), 0, len(lows), 0] + lows + [0, 0, 0, 0]
+        else:
+            card = len(lows)
+            c = [4100, 1, min(card, 0xffff), max(card - 0xffff, 0)] + [0] * 4096
+            for x in lows:
+                c[4 + (x >> 4)] |= 1 << (15 - (x & 15))
+            words += c
+        offs[k] = off                                  # setKey: key 0's offset is replaced, the empty container stays behind
+    node = [node_words, len(keys)]
+    for k in keys:
+        node += [k, offs[k]]
+    node += [0] * (2 + 2 * cap - len(node))
+    buf = np.array(words, dtype=np.uint16)
+    buf[:node_words] = np.array(node, dtype=np.uint64).view(np.uint16)
+    return buf.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_bitmap_container():
+    """TBitmapSparse [23]: array containers, bitmap containers (> 2048 values in a block, incl. a full block whose
+    cardinality needs both header words), several blocks, the orphaned key-0 container; malformed payloads are refused"""
+    import knoxdb_amd as K
+    rng = np.random.default_rng(23)
+    with K.Context(0) as ctx:
+        cases = [
+            (1 << 20, np.sort(rng.choice(1 << 20, 3000, replace=False))),                               # arrays in 16 blocks
+            (300_000, np.unique(np.r_[np.arange(65536, 131072), rng.choice(300_000, 500), [0, 299_999]])),  # a FULL block: bitmap, cardinality 65536
+            (200_001, np.unique(np.r_[rng.choice(np.arange(131072, 196608), 5000, replace=False), [7, 200_000]])),  # bitmap container, no key 0 values but one
+            (70_000, np.array([69_999])),                                                                # a single value outside block 0
+            (1000, np.array([], dtype=np.int64)),                                                        # empty
+        ]
+        for n, vals in cases:
+            payload = sroar_from_sorted(vals)
+            cont = bytes([23]) + O.put_uvarint(n) + O.put_uvarint(len(payload)) + payload
+            want = np.zeros(n, dtype=bool)
+            want[vals] = True
+            b = ctx.bits(n).upload_bitmap_container(cont)
+            assert (b.bytes(poison=32) == np.packbits(want, bitorder="little")).all(), n
+            assert b.count() == len(vals)
+            b.free()
+        # a value beyond the bitset, a container offset beyond the buffer, an unknown container type
+        n = 70_000
+        for mutate in ("value", "offset", "type"):
+            payload = bytearray(sroar_from_sorted(np.array([5, 66_000])))
+            w = np.frombuffer(payload, dtype=np.uint16).copy()
+            node_words = int(np.frombuffer(payload[:8], dtype=np.uint64)[0])
+            last_off = int(np.frombuffer(payload[:2 * node_words], dtype=np.uint64)[2 + 2 * 1 + 1])   # key 65536's container
+            if mutate == "value":
+                w[last_off + 4] = 60_000                                                       # 65536 + 60000 >= 70000
+            elif mutate == "offset":
+                w[:node_words].view(np.uint64)[2 + 2 * 1 + 1] = len(w) + 10
+            else:
+                w[last_off + 1] = 7
+            cont = bytes([23]) + O.put_uvarint(n) + O.put_uvarint(w.nbytes) + w.tobytes()
+            with pytest.raises(K.KnoxError) as e:
+                ctx.bits(n).upload_bitmap_container(cont)
+            assert e.value.code in (-7, -1), mutate
