@@ -13,20 +13,22 @@
 // buffer) pair, and it is decided by running the scan kernel on that very pair.
 //
 // WHAT.  Physical memory is taken from the driver only as allocations need it, up to an explicit budget, and is not
-// returned before the context closes (or an explicit trim).  Columns (>= 1 GiB) live in one of two ZONES: every 1 GiB
-// physical chunk (hipMemCreate) is probed once against one fixed 16 MiB reference window ("is a 1 GiB column here slow
-// with it?": slow = the window's class, fast = some other class) and mapped at the end of its label's zone, so a zone
-// is one VA-contiguous heap of ONE kind of memory, whatever order the driver handed the chunks out in, and a write
-// buffer that is fast with one part of a column is fast with all of it.  Smaller things share an ordinary heap.  A large
-// write buffer that is allocated FOR a column (knox_bits_alloc_for, the scan's scratch bitsets) is a physical
-// allocation of its own, chosen among candidates: spare write buffers first, then a few new ones (small allocations
-// are served from the driver's leftover fragments, which lie all over the device: usually one of a handful is in
-// another class), then candidates from FURTHER AWAY in the driver's allocation order, reached with transient spacers
-// (physical memory that is never mapped and is released again before the call returns).  Every candidate is VERIFIED:
-// up to four 1 GiB samples of the column are scanned into the part of the candidate their bits really go to; the first
-// candidate whose worst sample runs at >= 0.95 of its read-only form is taken.  Rejected candidates stay in the arena
-// as spare write buffers (the first candidates of the next request: what is slow with one column is fast with a
-// column of another class); nothing is held outside the accounting.
+// returned before the context closes (or an explicit trim).  Columns (>= 1 GiB) live in ZONES, one per placement class:
+// every 1 GiB physical chunk (hipMemCreate) is probed against the reference window of each class met so far ("is a
+// 1 GiB column here slow with it?": slow = that window's class; fast with all of them = a class of its own, whose
+// reference window becomes the first 32 MiB of this very chunk) and mapped at the end of its class's zone, so a zone is
+// one VA-contiguous heap of ONE class of memory, whatever order the driver handed the chunks out in, and a write buffer
+// that is fast with one part of a column is fast with all of it.  Smaller things share an ordinary heap.  A large write
+// buffer that is allocated FOR a column (knox_bits_alloc_for, the scan's scratch bitsets) is chosen among candidates:
+// spare write buffers first, then a few new physical allocations of their own (small allocations are served from the
+// driver's leftover fragments, which lie all over the device: usually one of a handful is in another class), then a
+// range at the TOP of another class's zone (columns fill zones from the bottom) -- taking chunks, which stay as column
+// space, for a few chunks if no other class has been met.  Every candidate is VERIFIED: up to sixteen 1 GiB samples of
+// the column are scanned into the part of the candidate their bits really go to; the first candidate whose worst sample
+// runs at >= 0.95 of its read-only form is taken.  Rejected candidates stay in the arena as spare write buffers (the
+// first candidates of the next request: what is slow with one column is fast with a column of another class); nothing
+// is held outside the accounting and nothing is handed back to the driver during a search (the driver clears returned
+// memory, which costs the whole device bandwidth for a second or two).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -94,14 +96,15 @@ class Arena {
     static constexpr uint64_t kProbeRows = (uint64_t)1 << 27;  // one sample: 1 GiB of int64 rows, 16 MiB of bitset
     static constexpr double kFastAbove = 0.95;                 // scan / read-only: ~0.88 same class, ~0.98 different classes
     static constexpr int kNearCandidates = 6;                  // new write buffers looked at before reaching further
-    static constexpr size_t kSpacer = (size_t)24 << 30;        // transient, never mapped: skips ahead in the driver's allocation order
-    static constexpr int kMaxSpacers = 6;
+    static constexpr int kMaxClasses = 4;                      // placement classes told apart (three were ever seen on one device)
+    static constexpr size_t kRefBytes = (size_t)32 << 20;      // a class's reference window
+    static constexpr int kMaxGrowForWrite = 8;                 // chunks taken at most while looking for memory of another class
     static constexpr size_t kMaxSpareBytes = (size_t)6 << 30;  // spare write buffers kept (beyond: returned to the driver; they are small)
 
     bool usable = false;
     size_t budget = 0, mapped_total = 0, peak_used = 0;
     int chunks_created = 0, probes_run = 0, write_buffers = 0;
-    size_t spacer_bytes_used = 0;  // transient spacers taken and released again so far (reporting)
+    size_t spacer_bytes_used = 0;  // always 0 (the transient spacers of earlier versions are gone; kept for the info struct)
 
     void configure(int device_, size_t budget_, ArenaProbeFn fn, void *user_) {
         device = device_;
@@ -115,7 +118,8 @@ class Arena {
         for (auto &w : spares) n += w.bytes;
         return n;
     }
-    size_t zone_bytes(int label) const { return zones[label - 1].mapped; }
+    size_t zone_bytes(int label) const { return label >= 1 && label <= kMaxClasses ? zones[label - 1].mapped : 0; }
+    int classes_seen() const { return n_refs; }
 
     // Columns / payloads of >= 1 GiB: a range of ONE zone (chunks of one label, mapped back to back).  Everything else: the heap.
     hipError_t alloc(void **out, size_t bytes, int kind) {
@@ -140,7 +144,7 @@ class Arena {
         const size_t sample = kProbeRows * 8, wrote = kProbeRows / 8;
         if (!probe || !col || col_bytes < sample || bytes < std::max(kSmallWrite, wrote + 64) || bytes_per_row <= 0.0) return alloc(out, bytes, ARENA_WRITE);
         const size_t wb_bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-        constexpr int kMaxSamples = 4;
+        constexpr int kMaxSamples = 16;  // every GiB of a column up to 16 GiB (a small write buffer can be made of fragments of several classes)
         const int n_s = (int)std::min<size_t>(kMaxSamples, col_bytes / sample);
         size_t offs[kMaxSamples] = {0}, boffs[kMaxSamples] = {0};
         for (int i = 0; i < n_s; i++) {
@@ -154,6 +158,7 @@ class Arena {
                 const double r = probe(user, (const char *)col + offs[i], kProbeRows, va + boffs[i]);
                 probes_run++;
                 if (r <= 0.0) return -1.0;
+                if (r < kFastAbove) dbg("  sample %d of %d (column GiB %zu): %.3f", i, n_s, offs[i] >> 30, r);
                 worst = std::min(worst, r);
                 if (worst < kFastAbove - 0.03) break;  // out already
             }
@@ -171,6 +176,42 @@ class Arena {
                 add_spare(w);
             }
         };
+        // 0. memory of a KNOWN other class, if some has been met: column chunks are labelled by class (grow_zone), so a range
+        //    at the top of another class's zone is fast with this column by construction -- verified like every candidate
+        const int zc = zone_of(col);
+        bool zone_failed[kMaxClasses] = {false, false, false, false};
+        auto try_zones = [&]() {
+            // every other class with room is measured: class pairs differ (0.97 against 1.00 of the read-only rate), the
+            // best one is taken; the first at >= 0.99 ends the search
+            char *zbest = nullptr;
+            double zbest_r = -1.0;
+            for (int zi = 0; zi < kMaxClasses && zc >= 0; zi++) {
+                if (zi == zc || zone_failed[zi]) continue;
+                char *va = nullptr;
+                if (!zone_take_top(zi, wb_bytes, &va)) continue;
+                const double r = measure(va);
+                dbg("write buffer (%zu MiB) at the top of zone %d vs the column in zone %d: %.3f", wb_bytes >> 20, zi, zc, r);
+                if (r < kFastAbove) zone_failed[zi] = true;  // its label says "another class" and the pair is slow all the same: leave that zone alone
+                if (r > zbest_r) {
+                    if (zbest) (void)release(zbest);
+                    zbest = va;
+                    zbest_r = r;
+                } else {
+                    (void)release(va);
+                }
+                if (zbest_r >= 0.99) break;
+            }
+            if (zbest && zbest_r >= kFastAbove) {
+                if (best.va) add_spare(best);
+                best.va = nullptr;
+                *out = zbest;
+                if (ratio_out) *ratio_out = zbest_r;
+                return true;
+            }
+            if (zbest) (void)release(zbest);
+            return false;
+        };
+        if (try_zones()) return hipSuccess;
         // 1. spare write buffers of a fitting size (each at most once)
         {
             std::vector<WBuf> mine;
@@ -189,7 +230,7 @@ class Arena {
                 consider(mine[i], r);
             }
         }
-        // 2. a few new ones; 3. further away, behind transient spacers
+        // 2. a few new ones
         bool hit = false;
         auto try_new = [&](int n_tries) {
             for (int k = 0; k < n_tries; k++) {
@@ -206,32 +247,19 @@ class Arena {
             }
             return true;
         };
-        bool can_go_on = try_new(kNearCandidates);
+        (void)try_new(kNearCandidates);
         if (hit) return hipSuccess;
-        std::vector<hipMemGenericAllocationHandle_t> spacers;
-        for (int step = 0; step < kMaxSpacers && can_go_on && !hit; step++) {
-            hipMemAllocationProp prop = {};
-            prop.type = hipMemAllocationTypePinned;
-            prop.location.type = hipMemLocationTypeDevice;
-            prop.location.id = device;
-            hipMemGenericAllocationHandle_t sp;
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < kSpacer + ((size_t)8 << 30)) break;
-            if (hipMemCreate(&sp, kSpacer, &prop, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                break;
-            }
-            spacers.push_back(sp);
-            dbg("spacer %d taken (%zu GiB ahead in the allocation order)", step, (spacers.size() * kSpacer) >> 30);
-            can_go_on = try_new(3);
+        // 3. no other class met yet (or its zone is full): take a few more chunks -- they stay as column space of their
+        //    class -- and look again
+        for (int grown = 0; zc >= 0 && grown < kMaxGrowForWrite && grown_for_write < 2 * kMaxGrowForWrite; grown++) {
+            if (grow_zone() < 0) break;
+            grown_for_write++;  // over the arena's life: a device whose free memory is one long run of one class is not mapped chunk by chunk in vain
+            if (try_zones()) return hipSuccess;
         }
-        if (!spacers.empty()) {
-            (void)hipDeviceSynchronize();
-            for (auto &sp : spacers) (void)hipMemRelease(sp);
-            spacer_bytes_used += spacers.size() * kSpacer;
-            usleep(1500000);  // the driver clears what was released; it costs the whole device bandwidth while it runs
-        }
-        if (hit) return hipSuccess;
+        // Nothing fast within reach (the free memory around is all of the column's class, a run longer than what was
+        // looked at): the best candidate there is.  An earlier version then skipped ahead in the driver's allocation order
+        // with transient 24 GiB spacers; measured on a box in exactly this state it found nothing in 144 GiB, and handing
+        // the spacers back made the driver clear them, which slows the whole device for seconds -- removed.
         if (!best.va) return alloc(out, bytes, ARENA_WRITE);
         WBuf none;
         return take_wbuf(out, best, bytes, best_r, ratio_out, none);  // nothing fast within reach: the best there is
@@ -260,16 +288,22 @@ class Arena {
     // (A zone is one reservation: its memory goes back when the reservation is freed, i.e. all of it or nothing.)
     size_t trim() {
         size_t freed = 0;
-        for (int zi = 0; zi < 2; zi++) {
-            Zone &z = zones[zi];
-            bool in_use = false;
-            for (auto &kv : smalls) in_use = in_use || kv.second.zone == zi;
-            if (in_use || !z.region) continue;
-            for (auto &e : z.extents) drop_extent(e);
-            for (auto &rg : z.regions) VaBump::give_back(rg.first, rg.second);
-            freed += z.mapped;
-            mapped_total -= z.mapped;
-            z = Zone();
+        bool any_in_use = false;
+        for (auto &kv : smalls) any_in_use = any_in_use || kv.second.zone >= 0;
+        if (!any_in_use) {  // the zones of classes 1.. hold their class's reference window: all of them go, or none
+            for (auto &z : zones) {
+                if (!z.region) continue;
+                for (auto &e : z.extents) drop_extent(e);
+                for (auto &rg : z.regions) VaBump::give_back(rg.first, rg.second);
+                freed += z.mapped;
+                mapped_total -= z.mapped;
+                z = Zone();
+            }
+            for (int c = 1; c < kMaxClasses; c++) ref_va[c] = nullptr;
+            if (n_refs > 1) {
+                used -= (size_t)(n_refs - 1) * kRefBytes;
+                n_refs = 1;
+            }
         }
         for (auto &w : spares) {
             freed += w.bytes;
@@ -296,6 +330,8 @@ class Arena {
             z = Zone();
         }
         smalls.clear();
+        for (auto &r : ref_va) r = nullptr;
+        n_refs = 0;
         mapped_total = used = 0;
         usable = false;
         inited = false;
@@ -315,7 +351,7 @@ class Arena {
         std::vector<Extent> extents;
         std::vector<std::pair<char *, size_t>> regions;  // every reservation of the zone (one, unless the budget was raised later)
     };
-    struct Small { int zone, extent; size_t off, len; };  // zone: -1 = the heap, 0 / 1 = zones[zone]
+    struct Small { int zone, extent; size_t off, len; };  // zone: -1 = the heap, else zones[zone]
     struct WBuf {  // a write buffer: one physical allocation, one mapping
         hipMemGenericAllocationHandle_t h;
         char *va = nullptr;
@@ -327,8 +363,11 @@ class Arena {
     void *user = nullptr;
     bool inited = false;
     size_t used = 0;
-    WBuf ref;  // the reference window every chunk is labelled against (32 MiB, made with the first column)
-    Zone zones[2];
+    WBuf ref;  // class 0's reference window (32 MiB of its own, made with the first column): "class 0" is whatever it lies in
+    char *ref_va[kMaxClasses] = {nullptr, nullptr, nullptr, nullptr};  // class c's reference window; c >= 1: the first 32 MiB of zone c
+    int n_refs = 0;
+    int grown_for_write = 0;
+    Zone zones[kMaxClasses];
     std::vector<Extent> heap;
     std::vector<WBuf> spares;
     std::map<char *, Small> smalls;
@@ -367,6 +406,47 @@ class Arena {
             fl.erase(it);
             if (l > bytes) fl[o + bytes] = l - bytes;
             *off = o;
+            return true;
+        }
+        return false;
+    }
+    // the highest fitting range (write buffers inside column zones: columns fill a zone from the bottom)
+    static bool take_top(std::map<size_t, size_t> &fl, size_t bytes, size_t *off) {
+        for (auto it = fl.rbegin(); it != fl.rend(); ++it) {
+            if (it->second < bytes) continue;
+            const size_t o = it->first, l = it->second;
+            fl.erase(std::next(it).base());
+            if (l > bytes) fl[o] = l - bytes;
+            *off = o + l - bytes;
+            return true;
+        }
+        return false;
+    }
+    static bool take_at(std::map<size_t, size_t> &fl, size_t at, size_t bytes) {  // exactly [at, at + bytes)
+        auto it = fl.upper_bound(at);
+        if (it == fl.begin()) return false;
+        --it;
+        const size_t o = it->first, l = it->second;
+        if (o > at || o + l < at + bytes) return false;
+        fl.erase(it);
+        if (at > o) fl[o] = at - o;
+        if (o + l > at + bytes) fl[at + bytes] = o + l - (at + bytes);
+        return true;
+    }
+    int zone_of(const void *p) const {
+        for (int zi = 0; zi < kMaxClasses; zi++)
+            for (auto &rg : zones[zi].regions)
+                if ((const char *)p >= rg.first && (const char *)p < rg.first + rg.second) return zi;
+        return -1;
+    }
+    bool zone_take_top(int zi, size_t bytes, char **va) {
+        Zone &z = zones[zi];
+        for (size_t ei = z.extents.size(); ei-- > 0;) {
+            size_t off = 0;
+            if (!take_top(z.extents[ei].free, bytes, &off)) continue;
+            *va = z.extents[ei].va + off;
+            smalls[*va] = Small{zi, (int)ei, off, bytes};
+            account(bytes);
             return true;
         }
         return false;
@@ -468,11 +548,16 @@ class Arena {
         if (!create(kChunk, &h)) return -1;
         chunks_created++;
         int label = 1;
+        bool founder = false;  // the first chunk of a class not met before: its first 32 MiB become that class's reference window
         if (probe) {
-            if (!ref.va && !new_wbuf((size_t)32 << 20, &ref)) {
-                (void)hipMemRelease(h);
-                mapped_total -= kChunk;
-                return -1;
+            if (!ref.va) {
+                if (!new_wbuf(kRefBytes, &ref)) {
+                    (void)hipMemRelease(h);
+                    mapped_total -= kChunk;
+                    return -1;
+                }
+                ref_va[0] = ref.va;
+                n_refs = 1;
             }
             char *pva = VaBump::take(kChunk);
             if (!pva || !map_at(pva, h, kChunk)) {
@@ -484,16 +569,28 @@ class Arena {
             // fresh physical memory may still be under the driver's own clearing pass: touch all of it once and wait
             (void)hipMemsetAsync(pva, 0, kChunk, nullptr);
             (void)hipDeviceSynchronize();
-            double r = 0.0;
-            for (int rep = 0; rep < 2; rep++) {  // a reading near the threshold is taken again and averaged
-                const double x = probe(user, pva, kProbeRows, ref.va);
-                probes_run++;
-                if (x <= 0.0) { r = 0.0; break; }
-                r = rep == 0 ? x : 0.5 * (r + x);
-                if (r < 0.915 || r > 0.965) break;
+            // a chunk belongs to the class whose reference window it is SLOW with (same class = slow); fast with all of
+            // them = a class of its own
+            int cls = -1, closest = 0;
+            double lowest = 2.0;
+            for (int c = 0; c < n_refs && cls < 0; c++) {
+                double r = 0.0;
+                for (int rep = 0; rep < 2; rep++) {  // a reading near the threshold is taken again and averaged
+                    const double x = probe(user, pva, kProbeRows, ref_va[c]);
+                    probes_run++;
+                    if (x <= 0.0) { r = 0.0; break; }
+                    r = rep == 0 ? x : 0.5 * (r + x);
+                    if (r < 0.915 || r > 0.965) break;
+                }
+                dbg("chunk %d vs the reference window of class %d: %.3f", chunks_created, c, r);
+                if (r > 0.0 && r < lowest) { lowest = r; closest = c; }
+                if (r > 0.0 && r < 0.94) cls = c;
             }
-            dbg("chunk %d vs the reference window: %.3f", chunks_created, r);
-            label = (r > 0.0 && r >= 0.94) ? 2 : 1;
+            if (cls < 0) {
+                if (n_refs < kMaxClasses && lowest <= 1.5) { cls = n_refs; founder = true; }
+                else cls = closest;
+            }
+            label = cls + 1;
             (void)hipDeviceSynchronize();
             (void)hipMemUnmap(pva, kChunk);
             VaBump::give_back(pva, kChunk);  // the probe mapping had a reservation of its own
@@ -531,11 +628,19 @@ class Arena {
         e.len += kChunk;
         e.chunks.push_back(h);
         z.mapped += kChunk;
+        if (founder && take_at(e.free, e.len - kChunk, kRefBytes)) {
+            ref_va[label - 1] = va;
+            n_refs = label;
+            account(kRefBytes);
+            (void)hipMemsetAsync(va, 0, kRefBytes, nullptr);
+            (void)hipDeviceSynchronize();
+            dbg("class %d met: its reference window is the start of chunk %d", label - 1, chunks_created);
+        }
         return label - 1;
     }
     hipError_t zone_alloc(void **out, size_t bytes) {
         for (;;) {
-            for (int zi = 0; zi < 2; zi++)
+            for (int zi = 0; zi < kMaxClasses; zi++)
                 for (size_t ei = 0; ei < zones[zi].extents.size(); ei++) {
                     size_t off = 0;
                     if (!take(zones[zi].extents[ei].free, bytes, &off)) continue;

@@ -16,6 +16,7 @@ n = 1 << lg
 
 
 def rate(ctx, col, bits, steps=14):
+    """bits = None: the read-only form of the same scan (count + sum, no bitset)"""
     plan = ctx.plan(And(Leaf(0, FilterMode.Range, -(1 << 38), 1 << 38)), [col], aggs=[(ReducerFunc.Sum, 0)])
     ctx.scan_async(plan, bits_out=bits)
     for _ in range(steps - 1):
@@ -26,7 +27,7 @@ def rate(ctx, col, bits, steps=14):
     k = C.c_int()
     ctx.L.knox_prof_read_each(ctx.h, ms, 512, C.byref(k))
     v = [ms[i] for i in range(k.value)]
-    return n * 8.125 / statistics.median(v[len(v) // 2:]) / 1e6
+    return n * (8.125 if bits is not None else 8.0) / statistics.median(v[len(v) // 2:]) / 1e6
 
 
 for on in (True, False):
@@ -39,10 +40,13 @@ for on in (True, False):
     bitsets = [ctx.bits(n, for_col=c) for c in cols]
     rate(ctx, cols[0], bitsets[0], 60)
     rates = [rate(ctx, c, b) for c, b in zip(cols, bitsets)]
+    ro = [rate(ctx, c, None) for c in cols]
     print("arena %s: %s  held outside: %s" % ("on " if on else "off", json.dumps(ctx.arena_info()), ctx.placement_info()))
     print("  candidates : " + " ".join("%5d" % b.pair_check[1] for b in bitsets))
     print("  pair check : " + " ".join("%5.3f" % b.pair_check[0] for b in bitsets))
     print("  scan GB/s  : " + " ".join("%5.0f" % r for r in rates))
+    print("  read-only  : " + " ".join("%5.0f" % r for r in ro))
+    print("  scan / ro  : " + " ".join("%5.3f" % (a / b) for a, b in zip(rates, ro)))
     print("  min %.0f  median %.0f  max %.0f" % (min(rates), statistics.median(rates), max(rates)))
     for o in cols + bitsets:
         o.free()
