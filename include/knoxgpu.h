@@ -109,9 +109,11 @@ int knox_host_free(knox_ctx *ctx, void *p);
  * HBM falls into a few classes; a scan whose column and bitset lie in the SAME class runs at ~6.0 TB/s, in DIFFERENT
  * classes at ~7.05 TB/s; read-only passes do not see it.  All device memory a context owns comes out of ONE arena:
  * physical memory is taken from the driver only as allocations need it (HIP virtual-memory API), up to a hard budget,
- * and is not returned before knox_ctx_close (or an explicit trim); columns of >= 1 GiB are assembled from 1 GiB chunks
- * mapped back to back; a large write buffer allocated FOR a column (knox_bits_alloc_for, the scan's scratch bitsets) is
- * a physical allocation of its own, chosen among candidates by running the scan kernel on that very (column, buffer)
+ * and is not returned before knox_ctx_close (or an explicit trim); every 1 GiB chunk is labelled with its class once
+ * (probed against one reference window per class met so far) and mapped into that class's zone, so columns of >= 1 GiB
+ * are class-pure; a large write buffer allocated FOR a column (knox_bits_alloc_for, the scan's scratch bitsets) comes
+ * from the top of ANOTHER class's zone (else: spare or fresh physical allocations of its own) and is verified by running
+ * the scan kernel over every GiB of that very (column, buffer)
  * pair.  Nothing is held outside the arena's accounting.  Budget: KNOX_ARENA_GIB in the environment,
  * knox_ctx_set_arena, default 3/4 of the device.  Mode 0 (or KNOX_PLACEMENT=0): plain hipMalloc / hipFree.
  * Results never depend on any of this.                                                                           */
@@ -123,8 +125,8 @@ typedef struct knox_arena_info {
     uint64_t used_bytes;       /* handed out to columns / bitsets / scratch right now       */
     uint64_t peak_used_bytes;
     uint64_t spare_write_buffer_bytes; /* write buffers that were candidates or were freed: the first candidates of the next request */
-    uint64_t transient_spacer_bytes;   /* physical memory taken AND released again while looking for a write buffer far away
-                                          in the driver's allocation order (never mapped, never held past the call)   */
+    uint64_t transient_spacer_bytes;   /* always 0 since ABI 4 (an earlier search skipped ahead in the driver's allocation
+                                          order with transient allocations; the field keeps the struct layout)       */
     int32_t write_buffers, chunks, probes; /* write buffers created, 1 GiB chunks created, probe measurements taken */
     int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
 } knox_arena_info;
