@@ -350,6 +350,14 @@ struct FirstLast {
 //   min / max pre-filter               v_min / v_max of bfi(m, e, neutral) in the column's OWN order (i32 / u32 / f32 --
 //                                      v_min_f32 / v_max_f32 drop NaNs, which are never candidates); converted to order
 //                                      keys once per iteration and compared with the wave's best keys
+// (m & a) | (~m & b) as ONE instruction: written out, the compiler rebuilds the selection from the result bit with a
+// shift + compare + select per use (3 instructions)
+__device__ __forceinline__ uint32_t bfi_b32(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "s"(b));
+    return d;
+}
+
 template <unsigned AGG, unsigned FLV>
 __device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl, const u32x4 (&r)[kUnroll],
                                             const uint32_t (&q)[kUnroll], uint64_t row0, uint64_t row_base, int lane) {
@@ -381,16 +389,16 @@ __device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl,
             }
             if constexpr ((AGG & A_MINMAX) != 0) {
                 if constexpr (FLV == FL_SIGNED) {
-                    const int32_t lo = (int32_t)(xb | (0x7fffffffu & ~m)), hi = (int32_t)(xb | (0x80000000u & ~m));
+                    const int32_t lo = (int32_t)bfi_b32(m, e, 0x7fffffffu), hi = (int32_t)bfi_b32(m, e, 0x80000000u);
                     smin = lo < smin ? lo : smin;
                     smax = hi > smax ? hi : smax;
                 } else if constexpr (FLV == FL_UNSIGNED) {
-                    const uint32_t lo = xb | ~m;
+                    const uint32_t lo = bfi_b32(m, e, 0xffffffffu);
                     umin = lo < umin ? lo : umin;
                     umax = xb > umax ? xb : umax;
                 } else {
-                    fmn = fminf(fmn, __uint_as_float(xb | (0x7f800000u & ~m)));
-                    fmx = fmaxf(fmx, __uint_as_float(xb | (0xff800000u & ~m)));
+                    fmn = fminf(fmn, __uint_as_float(bfi_b32(m, e, 0x7f800000u)));
+                    fmx = fmaxf(fmx, __uint_as_float(bfi_b32(m, e, 0xff800000u)));
                 }
             }
         }
