@@ -382,9 +382,15 @@ __device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl,
             if constexpr (ZSUM) z += xb;
             if constexpr ((AGG & A_FSUM) != 0 && FLV == FL_SIGNED) neg += xb >> 31;
             if constexpr ((AGG & A_FSUM) != 0 && ISF) {
-                const uint32_t mag = xb & 0x7fffffffu;
-                amax = mag > amax ? mag : amax;
-                amin = (mag - 1u) < amin ? (mag - 1u) : amin;
+                // smallest non-zero magnitude, as 2*|x| - 2 in one v_lshl_add (the sign bit leaves on the left; zeros and
+                // unselected values wrap to the top and never win the minimum).  The largest magnitude comes from the
+                // min / max pre-filter below when there is one, else it is tracked here.
+                const uint32_t w2 = (xb << 1) + 0xfffffffeu;
+                amin = w2 < amin ? w2 : amin;
+                if constexpr ((AGG & A_MINMAX) == 0) {
+                    const uint32_t mag = xb & 0x7fffffffu;
+                    amax = mag > amax ? mag : amax;
+                }
                 it += (double)__uint_as_float(xb);
             }
             if constexpr ((AGG & A_MINMAX) != 0) {
@@ -413,8 +419,14 @@ __device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl,
         }
     }
     if constexpr ((AGG & A_FSUM) != 0 && ISF) {
-        // zeros are ignored by the span test (min over mag - 1 wraps them to the top); Inf / NaN take the per-value path
-        const bool ok = amax < 0x7f800000u && (amin == 0xffffffffu || ((amax >> 23) - ((amin + 1u) >> 23)) <= 24u);
+        // zeros are ignored by the span test; Inf takes the per-value path (a NaN makes the sum NaN on either path).  With
+        // a min / max pre-filter the largest magnitude is the larger of |min| and |max| of the selected values
+        if constexpr ((AGG & A_MINMAX) != 0) {
+            const uint32_t a0 = __float_as_uint(fmn) & 0x7fffffffu, a1 = __float_as_uint(fmx) & 0x7fffffffu;
+            amax = a0 > a1 ? a0 : a1;
+        }
+        const uint32_t mmin = (amin >> 1) + 1u;  // the smallest non-zero magnitude (amin = 2*mag - 2)
+        const bool ok = amin >= 0xfffffffeu || (amax < 0x7f800000u && ((amax >> 23) - (mmin >> 23)) <= 24u);
         if (__all(ok)) {
             const double s = acc.hi + it;
             const double bb = s - acc.hi;
