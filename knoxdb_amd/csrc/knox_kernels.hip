@@ -2460,7 +2460,11 @@ hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const
     if (ngroups == 0) return hipSuccess;
     if (mode <= 2 && vlen >= 16u) {
         uint64_t g = (ngroups + (uint64_t)kWavesPerBlock * kEqGroups - 1) / ((uint64_t)kWavesPerBlock * kEqGroups);
-        if (g > 256 * 8) g = 256 * 8;
+        // one wave iteration per wave: measured on 2^30 x 32-byte keys (tools/bench_cfg.py --cfg 4), workgroups that walk
+        // the column grid-stride (2048 of them: 7.4-7.5 ms) are 15 % slower than one workgroup per 1024 rows in launch
+        // order (6.50 ms = 6.6 TB/s = 83 % of the HBM peak): pointer -> payload is a dependent chain, and neighbours in
+        // launch order keep the DRAM pages they touch close together
+        if (g > ((uint64_t)1 << 20)) g = (uint64_t)1 << 20;
         KNOX_LAUNCH(bytes_eq_kernel, (int)g, mode == 2 ? 1 : 0, v, val, vlen, bits, mask, count_out);
     }
     uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
