@@ -92,6 +92,14 @@ struct knox_ctx {
     static constexpr int kResRing = 4;
     ResSlot res[kResRing + 1];  // [kResRing]: the blocking bitset calls' own slot, never part of the FIFO
     DevBuf ring_dev;            // 16 bytes of device results per slot (flags / popcount)
+    // A single-pass scan without a var / std pass has nothing that reads its result block on the device: the block
+    // [16 states][16 counts][pack counts] is then written straight into the slot's page-locked mirror (res_dst), and its
+    // whole follow-up work -- finalize + per-pack counts -- is ONE launch (post_packs): what a step costs beyond the scan
+    // kernel is ~6.5 us of dispatch gap per dependent launch, so two launches and a copy become one launch
+    char *res_dst = nullptr;
+    size_t post_packs = 0;       // != 0: run_fused also writes this many per-pack counts at res_dst + post_packs_off
+    size_t post_packs_off = 0;
+    bool post_packs_done = false;
     // large results (row ids, per-window values) land here; the *_view entry points hand out pointers into it
     void *h_view = nullptr;
     size_t h_view_cap = 0;
@@ -2276,9 +2284,16 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     if (slot != 15) prof_mark(ctx, 1);
     const bool has_tail = a.tail_first_row < a.n_rows;
     if (e == hipSuccess && has_tail) e = launch_scan_tail(ctx->stream, width, n_leaves, agg, g, a);
-    if (e == hipSuccess)
+    char *res = ctx->res_dst ? ctx->res_dst : (char *)ctx->states.p;
+    ctx->post_packs_done = false;
+    if (e == hipSuccess && ctx->res_dst && ctx->post_packs && per_pack_tiles && *per_pack_tiles != 0) {
+        e = launch_finalize_packs(ctx->stream, width, a.partials, g + (has_tail ? 1 : 0), agg_col ? agg_col->dev : nullptr, row_base, dtype_for_state,
+                                  (AggStateDev *)res + slot, (int64_t *)((AggStateDev *)res + 16) + slot, a.tile_counts, ctx->tc_grid,
+                                  ctx->tc_rounds, *per_pack_tiles, ctx->post_packs, (int64_t *)(res + ctx->post_packs_off));
+        ctx->post_packs_done = e == hipSuccess;
+    } else if (e == hipSuccess)
         e = launch_finalize(ctx->stream, width, a.partials, g + (has_tail ? 1 : 0), agg_col ? agg_col->dev : nullptr, row_base, dtype_for_state,
-                            (AggStateDev *)ctx->states.p + slot, (int64_t *)((AggStateDev *)ctx->states.p + 16) + slot);
+                            (AggStateDev *)res + slot, (int64_t *)((AggStateDev *)res + 16) + slot);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         return KNOX_E_HIP;
@@ -2635,6 +2650,9 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
 
     int first_reduce_slot = 0;
     uint32_t per_pack_tiles = 0;  // != 0: the fused kernel left per-wave-tile counts
+    bool direct = false;          // the result block is written straight into the slot's page-locked mirror
+    bool packs_done = false;      // ... and the per-pack counts came with the finalize launch
+    static const bool direct_ok = !(getenv("KNOX_DIRECT_RESULTS") && atoi(getenv("KNOX_DIRECT_RESULTS")) == 0);  // 0: diagnostics
     if (fused) {
         LeafHost lh[kMaxLeaves];
         const knox_col *lc[kMaxLeaves];
@@ -2673,8 +2691,21 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         uint64_t tt;
         rc = make_truth_table(nodes, n_nodes, lof, neg, n_leaves, tt);
         if (rc) return rc;
+        // nothing after this pass reads the result block on the device: it is written where the host will read it
+        direct = n_agg_cols <= first_reduce_slot && !any_moments && direct_ok;
+        if (direct) {
+            rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, res_bytes);
+            if (rc) return rc;
+            ctx->res_dst = (char *)slot.h_res;
+            ctx->post_packs = want_pack_counts ? n_packs : 0;
+            ctx->post_packs_off = res_base;
+        }
         rc = run_fused(ctx, width, lh, lc, n_leaves, tt, ac, acls, n_rows, pack_rows, row_base, pack_skip ? &skip : nullptr, (uint32_t *)bits, 0,
                        grid, ac ? ac->dtype : lc[0]->dtype, want_pack_counts ? &per_pack_tiles : nullptr);
+        ctx->res_dst = nullptr;
+        ctx->post_packs = 0;
+        packs_done = ctx->post_packs_done;
+        ctx->post_packs_done = false;
         if (rc) return rc;
         if (skip.used) slot.rows_scanned = n_rows - rows_pruned;
     } else {
@@ -2760,18 +2791,23 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     // ---- per-pack counts from the bitset
     slot.has_pack_counts = false;
     slot.n_packs = n_packs;
-    if (want_pack_counts && n_packs) {
+    if (want_pack_counts && n_packs && packs_done) {
+        slot.has_pack_counts = true;
+    } else if (want_pack_counts && n_packs) {
+        char *res = direct ? (char *)slot.h_res : (char *)ctx->states.p;
         hipError_t e = per_pack_tiles
                            ? launch_pack_counts(ctx->stream, (const uint32_t *)ctx->tile_counts.p, ctx->tc_grid, ctx->tc_rounds, per_pack_tiles,
-                                                n_packs, (int64_t *)((char *)ctx->states.p + res_base))
-                           : launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)((char *)ctx->states.p + res_base), n_packs);
+                                                n_packs, (int64_t *)(res + res_base))
+                           : launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)(res + res_base), n_packs);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         slot.has_pack_counts = true;
     }
     // ---- small results -> this scan's pinned mirror (one copy), then its completion event
-    rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, res_bytes);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(slot.h_res, ctx->states.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!direct) {
+        rc = ensure_host(ctx, slot.h_res, slot.h_res_cap, res_bytes);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(slot.h_res, ctx->states.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (!slot.done) HIPCHK(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(slot.done, ctx->stream));
     ctx->res_head++;

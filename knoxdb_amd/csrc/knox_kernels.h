@@ -92,6 +92,10 @@ hipError_t launch_scan_tail(hipStream_t s, int width, int n_leaves, unsigned agg
 hipError_t launch_reduce(hipStream_t s, int width, unsigned agg, int grid, const ScanArgs &a);
 // Merge partials[0..n_partials) in order, fetch the adopted values, write the state and the
 // total count.
+// finalize + per-pack counts from the per-tile counts as ONE launch (a scan's whole follow-up work)
+hipError_t launch_finalize_packs(hipStream_t s, int width, const AggPartial *partials, int n_partials, const void *agg_col, uint64_t row_base,
+                                 int dtype, AggStateDev *state_out, int64_t *count_out, const uint32_t *tile_counts, uint32_t grid,
+                                 uint32_t rounds, uint32_t tiles_per_pack, uint64_t n_packs, int64_t *pack_counts);
 hipError_t launch_finalize(hipStream_t s, int width, const AggPartial *partials, int n_partials,
                            const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out,
                            int64_t *count_out);

@@ -1221,9 +1221,8 @@ __global__ void __launch_bounds__(kBlock) scan_tail_kernel(const ScanArgs a, int
 // finalize: ordered merge of the workgroup partials, fetch adopted values
 // ---------------------------------------------------------------------------------------------
 template <int W>
-__global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *partials, int n_partials, const void *agg_col,
-                                                          uint64_t row_base, int dtype, AggStateDev *state_out,
-                                                          int64_t *count_out) {
+__device__ __forceinline__ void finalize_body(const AggPartial *partials, int n_partials, const void *agg_col, uint64_t row_base, int dtype,
+                                              AggStateDev *state_out, int64_t *count_out) {
     __shared__ Acc sm[kBlock / 64];
     Acc acc;
     acc.init();
@@ -1264,6 +1263,42 @@ __global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *part
             *state_out = s;
         }
     }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) finalize_kernel(const AggPartial *partials, int n_partials, const void *agg_col,
+                                                          uint64_t row_base, int dtype, AggStateDev *state_out,
+                                                          int64_t *count_out) {
+    finalize_body<W>(partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+}
+
+// one wave per pack: the pack's count from the scan kernel's per-wave-tile counts ([workgroup][wave][round], tile t was
+// round t / grid of workgroup t % grid)
+__device__ __forceinline__ void pack_counts_body(uint32_t block, const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
+                                                 uint64_t n_packs, int64_t *counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t p = (uint64_t)block * (kBlock / 64) + (threadIdx.x >> 6);
+    if (p >= n_packs) return;
+    uint64_t c = 0;
+    for (uint32_t i = lane; i < tiles_per_pack * kWavesPerBlock; i += 64) {
+        const uint64_t tile = p * tiles_per_pack + i / kWavesPerBlock;
+        const uint32_t wave = i % kWavesPerBlock;
+        c += tile_counts[((tile % grid) * kWavesPerBlock + wave) * (uint64_t)rounds + tile / grid];
+    }
+    for (int off = 32; off >= 1; off >>= 1) c += (uint64_t)__shfl_down((unsigned long long)c, off, 64);
+    if (lane == 0) counts[p] = (int64_t)c;
+}
+
+// A scan's whole follow-up work as ONE launch: workgroup 0 merges the workgroup partials into the aggregate state, the
+// others turn the per-tile counts into per-pack counts.  (What a step costs beyond the scan kernel is the dispatch gap
+// per dependent launch, ~6.5 us each, not the duration of these small kernels.)
+template <int W>
+__global__ void __launch_bounds__(kBlock) finalize_packs_kernel(const AggPartial *partials, int n_partials, const void *agg_col, uint64_t row_base,
+                                                                int dtype, AggStateDev *state_out, int64_t *count_out,
+                                                                const uint32_t *tile_counts, uint32_t grid, uint32_t rounds,
+                                                                uint32_t tiles_per_pack, uint64_t n_packs, int64_t *pack_counts) {
+    if (blockIdx.x == 0) finalize_body<W>(partials, n_partials, agg_col, row_base, dtype, state_out, count_out);
+    else pack_counts_body(blockIdx.x - 1, tile_counts, grid, rounds, tiles_per_pack, n_packs, pack_counts);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1375,6 +1410,19 @@ hipError_t launch_reduce(hipStream_t s, int width, unsigned agg, int grid, const
     case 4: return reduce_w<4>(s, agg, grid, a);
     case 2: return reduce_w<2>(s, agg, grid, a);
     case 1: return reduce_w<1>(s, agg, grid, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_finalize_packs(hipStream_t s, int width, const AggPartial *partials, int n_partials, const void *agg_col, uint64_t row_base,
+                                 int dtype, AggStateDev *state_out, int64_t *count_out, const uint32_t *tile_counts, uint32_t grid,
+                                 uint32_t rounds, uint32_t tiles_per_pack, uint64_t n_packs, int64_t *pack_counts) {
+    const int g = 1 + (int)((n_packs + kBlock / 64 - 1) / (kBlock / 64));
+    switch (width) {
+    case 8: KNOX_LAUNCH((finalize_packs_kernel<8>), g, partials, n_partials, agg_col, row_base, dtype, state_out, count_out, tile_counts, grid, rounds, tiles_per_pack, n_packs, pack_counts);
+    case 4: KNOX_LAUNCH((finalize_packs_kernel<4>), g, partials, n_partials, agg_col, row_base, dtype, state_out, count_out, tile_counts, grid, rounds, tiles_per_pack, n_packs, pack_counts);
+    case 2: KNOX_LAUNCH((finalize_packs_kernel<2>), g, partials, n_partials, agg_col, row_base, dtype, state_out, count_out, tile_counts, grid, rounds, tiles_per_pack, n_packs, pack_counts);
+    case 1: KNOX_LAUNCH((finalize_packs_kernel<1>), g, partials, n_partials, agg_col, row_base, dtype, state_out, count_out, tile_counts, grid, rounds, tiles_per_pack, n_packs, pack_counts);
     default: return hipErrorInvalidValue;
     }
 }
@@ -2148,17 +2196,7 @@ __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bi
 // round t / grid of workgroup t % grid): one wave per pack
 __global__ void __launch_bounds__(kBlock) pack_counts_kernel(const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
                                                              uint64_t n_packs, int64_t *counts) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t p = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (p >= n_packs) return;
-    uint64_t c = 0;
-    for (uint32_t i = lane; i < tiles_per_pack * kWavesPerBlock; i += 64) {
-        const uint64_t tile = p * tiles_per_pack + i / kWavesPerBlock;
-        const uint32_t wave = i % kWavesPerBlock;
-        c += tile_counts[((tile % grid) * kWavesPerBlock + wave) * (uint64_t)rounds + tile / grid];
-    }
-    for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
-    if (lane == 0) counts[p] = (int64_t)c;
+    pack_counts_body(blockIdx.x, tile_counts, grid, rounds, tiles_per_pack, n_packs, counts);
 }
 
 hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
