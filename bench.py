@@ -280,11 +280,19 @@ def main():
     def enqueue():
         ctx.scan_async(plan, bits_out=bits, pack_counts=True, row_base=row_base)
 
+    pending = []  # the previous step's all-reduce, still in flight behind this step's scan
+
     def collect():
         res = ctx.scan_collect(plan, n_packs)
         if dist is not None:
-            gsum, total = reduce_sc(int(res.states[0].isum), res.count)
-            return res, gsum, total
+            # this step's exchange is enqueued, the previous step's is read: the collective never stalls the host
+            # between two scans (every step's whole-table answer is still produced inside the timed region -- the
+            # last one is read by run() before it returns)
+            pending.append(reduce_sc.start(int(res.states[0].isum), res.count))
+            if len(pending) > 1:
+                gsum, total = reduce_sc.finish(pending.pop(0))
+                return res, gsum, total
+            return res, None, None
         return res, int(res.states[0].isum), res.count
 
     # scans queued ahead of the one being collected.  With ranks > 1 every collect() ends in the RCCL all-gather of
@@ -306,6 +314,9 @@ def main():
                 enqueue()
                 queued += 1
             last = collect()
+        if dist is not None:
+            last = (last[0],) + tuple(reduce_sc.finish(pending.pop(0)))
+            assert not pending
         return last
 
     wres, wsum, wtotal = run(max(1, args.warmup))

@@ -99,28 +99,44 @@ class SumCountReduce:
     """The literal collective of the north star for the order-free integer aggregates: ONE all_reduce(int64, SUM) of
     {low half of the wrapping sum, high half, count} (backend "nccl" = ncclAllReduce over xGMI).  The 64-bit sum
     travels as two 32-bit halves so that no lane overflows and the result is exactly the sum mod 2^64 in any reduction
-    order -- bit-identical to StateGather + knox_agg_combine.  Everything is allocated once."""
+    order -- bit-identical to StateGather + knox_agg_combine.  Everything is allocated once.
 
-    def __init__(self, device=None, group=None):
+    start() / finish() split the exchange so that a host can keep it in flight behind the next scan (a query's answer
+    is then read one step later, exactly like the scans' own result ring): `slots` exchanges may be outstanding."""
+
+    def __init__(self, device=None, group=None, slots=2):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group, self.device = torch, dist, group, device
-        self.h = torch.empty(3, dtype=torch.int64)
+        self.slots, self._next = slots, 0
+        self.h = [torch.empty(3, dtype=torch.int64) for _ in range(slots)]
         if device is not None:
-            self.h = self.h.pin_memory()
-            self.d = torch.empty(3, dtype=torch.int64, device=device)
+            self.h = [t.pin_memory() for t in self.h]
+            self.d = [torch.empty(3, dtype=torch.int64, device=device) for _ in range(slots)]
+            self.ev = [torch.cuda.Event() for _ in range(slots)]
 
-    def __call__(self, isum, count):
-        """isum: the state's wrapping sum (any Python int, taken mod 2^64); -> (sum mod 2^64, total count)"""
+    def start(self, isum, count):
+        """enqueue one exchange; -> the handle finish() takes.  isum: any Python int, taken mod 2^64"""
+        k = self._next
+        self._next = (k + 1) % self.slots
         isum &= (1 << 64) - 1
-        hv = self.h.numpy()
+        hv = self.h[k].numpy()
         hv[0], hv[1], hv[2] = isum & 0xFFFFFFFF, isum >> 32, count
         if self.device is not None:
-            self.d.copy_(self.h, non_blocking=True)
-            self.dist.all_reduce(self.d, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.h.copy_(self.d, non_blocking=True)
-            self.torch.cuda.current_stream(self.device).synchronize()
+            self.d[k].copy_(self.h[k], non_blocking=True)
+            self.dist.all_reduce(self.d[k], op=self.dist.ReduceOp.SUM, group=self.group)  # the stream waits, not the host
+            self.h[k].copy_(self.d[k], non_blocking=True)
+            self.ev[k].record(self.torch.cuda.current_stream(self.device))
         else:
-            self.dist.all_reduce(self.h, op=self.dist.ReduceOp.SUM, group=self.group)
-        hv = self.h.numpy()
+            self.dist.all_reduce(self.h[k], op=self.dist.ReduceOp.SUM, group=self.group)
+        return k
+
+    def finish(self, k):
+        """-> (sum mod 2^64, total count) of exchange k"""
+        if self.device is not None:
+            self.ev[k].synchronize()
+        hv = self.h[k].numpy()
         return (int(hv[0]) + (int(hv[1]) << 32)) & ((1 << 64) - 1), int(hv[2])
+
+    def __call__(self, isum, count):
+        return self.finish(self.start(isum, count))

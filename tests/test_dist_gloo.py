@@ -41,6 +41,11 @@ def _worker(rank, world, port, q):
     for _ in range(2):
         gsum, gcnt = red(int(st.isum), cnt)
         assert gcnt == total and gsum == int(merged[0].isum), (gsum, int(merged[0].isum))
+    # the split form bench.py keeps in flight behind the next scan: two exchanges outstanding, read in order
+    h0 = red.start(int(st.isum), cnt)
+    h1 = red.start(7 + rank, 3)
+    assert red.finish(h0) == (int(merged[0].isum), total)
+    assert red.finish(h1) == (sum(7 + r for r in range(world)), 3 * world)
     # ... also when the partial sums sit at the wrap-around edge
     edge = (1 << 64) - 1 - rank
     esum, ecnt = red(edge, 1 << 40)
