@@ -196,3 +196,41 @@ def test_bloom_prefilter_then_eq_count(ctx):
     assert r.pack_counts[target_row // pack] == 0 and r.count == n - pack - sum(1 for x in present_rows if x // pack != target_row // pack and x >= 5)
     for o in (col, ids, bloom, bits):
         o.free()
+
+
+def test_every_bytes_mode_on_a_column_large_enough_for_full_grids(ctx):
+    """2^22 generated rows (64 packs of 2^16, one pool per pack): every wave takes ONE group of 64 rows in EQ / IN (no
+    grid-stride walk) and the ordered modes run their full workgroup count -- compared with numpy on the generator's
+    key indices (keys are 32 random bytes: their order is the order of their first 8 bytes, big endian)."""
+    n, pack, seed = 1 << 22, 1 << 16, 11
+    col = ctx.generate_bytes(seed, n, pack)
+    kidx = np.concatenate([O.bytes_key_index(seed, p * pack, pack, pack) for p in range(n // pack)])
+    uniq = np.unique(kidx)
+    keyb = O.bytes_key(seed, uniq)                                            # (n_keys, 32)
+    head = keyb[:, :8].copy().view(">u8").reshape(-1).astype(np.uint64)       # first 8 bytes as big-endian numbers
+    assert np.unique(head).size == head.size                                  # so bytes.Compare == compare of the heads
+    row_head = head[np.searchsorted(uniq, kidx)]
+    pick = uniq[[3, len(uniq) // 2, len(uniq) - 5]]
+    vals = [bytes(O.bytes_key(seed, np.array([k], dtype=np.uint64))[0]) for k in pick]
+    hv = [int(head[np.searchsorted(uniq, k)]) for k in pick]
+    bits = ctx.bits(n)
+
+    def got(tree):
+        res = ctx.scan(tree, [col], bits_out=bits)
+        b = np.unpackbits(bits.bytes(), bitorder="little")[:n].astype(bool)
+        assert res.count == int(b.sum())
+        return b
+
+    assert (got(And(Leaf(0, FilterMode.Equal, vals[1]))) == (kidx == pick[1])).all()
+    assert (got(And(Leaf(0, FilterMode.NotEqual, vals[1]))) == (kidx != pick[1])).all()
+    assert (got(And(Leaf(0, FilterMode.Lt, vals[1]))) == (row_head < np.uint64(hv[1]))).all()
+    assert (got(And(Leaf(0, FilterMode.Ge, vals[1]))) == (row_head >= np.uint64(hv[1]))).all()
+    lo, hi = sorted(zip(hv, vals))[0], sorted(zip(hv, vals))[-1]
+    assert (got(And(Leaf(0, FilterMode.Range, lo[1], hi[1]))) == ((row_head >= np.uint64(lo[0])) & (row_head <= np.uint64(hi[0])))).all()
+    member = np.isin(kidx, pick)
+    assert (got(And(Leaf(0, FilterMode.In, vals))) == member).all()
+    assert (got(And(Leaf(0, FilterMode.NotIn, vals))) == ~member).all()
+    # a tree mixing them (multi-pass plan over scratch bitsets)
+    want = (kidx == pick[0]) | ((row_head < np.uint64(hv[1])) & ~member)
+    assert (got(Or(Leaf(0, FilterMode.Equal, vals[0]), And(Leaf(0, FilterMode.Lt, vals[1]), Leaf(0, FilterMode.NotIn, vals)))) == want).all()
+    col.free(); bits.free()
