@@ -470,6 +470,11 @@ int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col 
                         const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                         size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states);
 
+/* The same states as a VIEW into the context's page-locked result buffer (valid until the next *_view / *_values call on
+ * this ctx): 144 B per window at DMA rate -- for hosts that merge windows across GPUs with knox_agg_combine.         */
+int knox_reduce_buckets_view(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
+                             const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
+                             size_t n_buckets, uint64_t row_base, int flags, const knox_agg_state **states_view);
 /* Values only: Reducer.Value() of reducer `func` (KNOX_R_SUM .. KNOX_R_COUNT) for every window, finalised ON THE DEVICE
  * by the same code knox_agg_value runs on the host (bit-identical by construction), so 8 + 1 bytes per window cross
  * PCIe instead of a 144-byte state: values_view = n_buckets values of the column's type, seen_view[k] = Value()'s ok

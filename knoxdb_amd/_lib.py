@@ -148,6 +148,7 @@ SIGNATURES = {
     "knox_match_wide": (_i, [_vp, _pp, _i, _i, C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, C.POINTER(_i64)]),
     "knox_reduce_moments": (_i, [_vp, _vp, _vp, C.POINTER(AggState)]),
     "knox_reduce_buckets": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(AggState)]),
+    "knox_reduce_buckets_view": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _u64, _i, C.POINTER(C.POINTER(AggState))]),
     "knox_reduce_buckets_values": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "knox_match_regexp": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, C.POINTER(_i64)]),
     "knox_regexp_match_value": (_i, [_vp, _u64, _vp, _u64]),

@@ -3301,6 +3301,23 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
     return download(ctx, states, st, n_buckets * sizeof(AggStateDev));
 }
 
+// The mergeable states themselves into the context's page-locked result buffer (a view, like knox_bits_indexes_view):
+// for hosts that merge windows across GPUs.  144 B per window cross PCIe at DMA rate instead of through pageable memory.
+KNOX_API int knox_reduce_buckets_view(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
+                                      int64_t step, size_t n_buckets, uint64_t row_base, int flags, const knox_agg_state **states_view) {
+    if (!states_view) return KNOX_E_INVALID;
+    char *st = nullptr;
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, &st);
+    if (rc) return rc;
+    const size_t bytes = n_buckets * sizeof(AggStateDev);
+    rc = ensure_host(ctx, ctx->h_view, ctx->h_view_cap, bytes);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_view, st, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *states_view = (const knox_agg_state *)ctx->h_view;
+    return KNOX_OK;
+}
+
 // Reducer.Value() of every window, finalised on the device: 8 (value) + 1 (seen) bytes per window cross PCIe into the
 // context's page-locked result buffer; the caller gets views (valid until the next *_view / *_values call on the ctx)
 KNOX_API int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,

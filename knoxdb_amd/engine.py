@@ -574,6 +574,15 @@ class Context:
                                          n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), states), "knox_reduce_buckets")
         return states   # ctypes array: indexable / iterable, no per-window Python objects until touched
 
+    def reduce_buckets_view(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False):
+        """reduce_buckets into the context's page-locked result buffer: a ctypes array VIEW of n_buckets states (valid
+        until the next *_view / *_values call; no copy into pageable memory)"""
+        p = C.POINTER(AggState)()
+        check(self.L.knox_reduce_buckets_view(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
+                                              n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), C.byref(p)),
+              "knox_reduce_buckets_view")
+        return C.cast(p, C.POINTER(AggState * n_buckets)).contents
+
     def reduce_buckets_values(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
         """Reducer.Value() per window, finalised on the device -> (values[n_buckets] of the column's type, seen[n_buckets])
         as zero-copy views of the context's page-locked result buffer (valid until the next *_view / *_values call)."""

@@ -48,6 +48,8 @@ def test_window_values_equal_the_host_finalised_states():
                 vcol = ctx.upload(v, 4096)
                 for m in (None, mask):
                     states = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=m, moments=True)
+                    view = ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=m, moments=True)
+                    assert bytes(view) == bytes(states), (ordered, bt)        # the page-locked view holds the same states
                     for f in FUNCS:
                         vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
                         vals, seen = vals.copy(), seen.copy()

@@ -35,10 +35,11 @@ for lg, shuffled in ((28, False), (28, True)) if quick else ((30, False), (28, F
         step = ((1 << 20) if shuffled else n) // nb
         ms = timed(lambda: ctx.reduce_buckets(clock, col, 1000, max(step, 1), nb, mask=bits))
         ms_v = timed(lambda: ctx.reduce_buckets(clock, col, 1000, max(step, 1), nb, mask=bits, moments=True))
+        ms_view = timed(lambda: ctx.reduce_buckets_view(clock, col, 1000, max(step, 1), nb, mask=bits))
         ms_sum = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Sum, 1000, max(step, 1), nb, mask=bits))
         ms_std = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Std, 1000, max(step, 1), nb, mask=bits))
-        print("2^%d rows, %s clock, %7d windows: states %8.2f ms (%.1f G rows/s), with var/std %8.2f ms | values: sum %7.2f ms (%.1f G rows/s), std %7.2f ms" % (
-            lg, "shuffled" if shuffled else "ordered ", nb, ms, n / ms / 1e6, ms_v, ms_sum, n / ms_sum / 1e6, ms_std), flush=True)
+        print("2^%d rows, %s clock, %7d windows: states %8.2f ms (%.1f G rows/s), with var/std %8.2f ms, as a pinned view %7.2f ms | values: sum %7.2f ms (%.1f G rows/s), std %7.2f ms" % (
+            lg, "shuffled" if shuffled else "ordered ", nb, ms, n / ms / 1e6, ms_v, ms_view, ms_sum, n / ms_sum / 1e6, ms_std), flush=True)
     col.free(); clock.free(); bits.free()
 
 # selection vector of 16.8 M hits out of 2^26 rows
