@@ -158,3 +158,27 @@ def test_async_flags_share_the_result_ring_with_the_scans():
         assert a.count() == int((ha & hb).sum())
         for o in (a, b, z, col):
             o.free()
+
+
+def test_out_of_order_windows_with_nothing_selected_or_nothing_inside():
+    rng = np.random.default_rng(3)
+    n, nb, step, t_from = 100_000, 300, 10, 1000
+    t = rng.permutation(t_from + rng.integers(0, nb * step, n)).astype(np.int64)
+    v = rng.integers(-100, 100, n).astype(np.int64)
+    with K.Context(0) as ctx:
+        tcol, vcol = ctx.upload(t, 4096), ctx.upload(v, 4096)
+        none = ctx.bits(n)                                     # nothing selected
+        vals, seen = ctx.reduce_buckets_values(tcol, vcol, R.Sum, t_from, step, nb, mask=none)
+        assert not seen.any() and not vals.any()
+        states = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=none)
+        assert all(st.count == 0 for st in states)
+        # every row outside the windows (all timestamps before t_from + ... shifted far away)
+        vals, seen = ctx.reduce_buckets_values(tcol, vcol, R.Count, t_from + 10 * nb * step, step, nb)
+        assert not seen.any()
+        # and exactly one selected row
+        one = ctx.bits(n).upload(np.packbits(np.arange(n) == 777, bitorder="little"))
+        vals, seen = ctx.reduce_buckets_values(tcol, vcol, R.First, t_from, step, nb, mask=one)
+        k = (int(t[777]) - t_from) // step
+        assert seen.sum() == 1 and seen[k] == 1 and vals[k] == v[777]
+        for o in (tcol, vcol, none, one):
+            o.free()
