@@ -258,7 +258,7 @@ WindowSortGeom window_sort_geom(uint64_t n, int n_cus) {
     WindowSortGeom g;
     const uint64_t tile = (uint64_t)kSortBlock * kWindowSortItems;
     uint64_t nb = (n + tile - 1) / tile;
-    const uint64_t cap = (uint64_t)n_cus * 4;
+    const uint64_t cap = (uint64_t)n_cus * 16;  // measured (tools/bench_windows.py, 2^28 shuffled rows): 2 -> 5.0 ms, 4 -> 4.0, 8 -> 3.55, 16 .. 32 -> 3.5, 128 -> 3.8
     if (nb > cap) nb = cap;
     if (nb == 0) nb = 1;
     g.nb = (uint32_t)nb;
