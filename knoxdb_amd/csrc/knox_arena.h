@@ -1,4 +1,4 @@
-// knox_arena.h -- one bounded device-memory arena per context (host code, included by knox_abi.cpp only).
+// knox_arena.h -- one bounded device-memory arena per context (host code, reached through knox_internal.h).
 //
 // WHY.  Measured on MI355X (tools/placement_vmm.py, placement_census.py, placement_finemap.py): for the
 // scan's read+write mix (8 B read, 1/8 B written per row) it matters WHERE the bitset lies relative to the column.

@@ -1,0 +1,479 @@
+// knox_bitset.hip -- bitset combinators, popcounts, Indexes (bitset -> row ids), Int128 / Int256 compares and the numeric
+// IN / NOT IN matcher: kernels that read or write selection bitsets without touching the streaming scan.
+#include "knox_dev.h"
+
+namespace knox {
+
+// ---------------------------------------------------------------------------------------------
+// Int128 / Int256 compares over the stride layout (internal/cmp/int128.go:14-471, int256.go:14-270;
+// num.Int128Stride{X0 []int64, X1 []uint64}, Int256Stride{X0..X3}): one 8-byte limb column per
+// limb, most significant first.  The order is lexicographic with a signed top limb
+// (pkg/num/int128.go:541-555, int256.go:701-713): the host flips the sign bit of a[0] / b[0], the
+// kernel flips it on the loaded top limb, and every limb compares unsigned.  A lane owns 2 adjacent
+// rows per 16-byte load of every limb column (the W = 8 layout), words are assembled with the same
+// DPP butterfly as the scan kernel.  result = hits & mask (bits pre-zeroed per the Matcher
+// contract); rows past the last full tile are written byte-granular (poison-tail rule).
+// ---------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ bool wide_hit(uint32_t op, const uint64_t (&x)[L], const uint64_t (&a)[L], const uint64_t (&b)[L]) {
+    bool lt = false, eq = true;  // row <=> a
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        lt = lt || (eq && x[l] < a[l]);
+        eq = eq && x[l] == a[l];
+    }
+    switch (op) {
+    case 1: return eq;            // FilterModeEqual
+    case 2: return !eq;           // NotEqual
+    case 3: return !lt && !eq;    // Gt
+    case 4: return !lt;           // Ge
+    case 5: return lt;            // Lt
+    case 6: return lt || eq;      // Le
+    default: {                    // Range: a <= x && x <= b
+        bool gt = false, e2 = true;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            gt = gt || (e2 && x[l] > b[l]);
+            e2 = e2 && x[l] == b[l];
+        }
+        return !lt && !gt;
+    }
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(kBlock) wide_cmp_kernel(const WideArgs w) {
+    constexpr int RPL = 128;               // rows per wave-load (64 lanes x 2)
+    constexpr int WAVE_ROWS = RPL * kUnroll;
+    constexpr uint64_t SIGN = 1ull << 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint64_t a[L], b[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) { a[l] = w.a[l]; b[l] = w.b[l]; }
+    uint32_t cnt = 0;
+    for (uint64_t tile = blockIdx.x; tile < w.n_tiles; tile += gridDim.x) {
+        const uint64_t row0 = (tile * kWavesPerBlock + (uint64_t)wave) * WAVE_ROWS;
+        u32x4 r[L][kUnroll];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const u32x4 *p = (const u32x4 *)w.limb[l] + row0 / 2 + lane;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<true>(p + u * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            uint32_t q = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                uint64_t x[L];
+#pragma unroll
+                for (int l = 0; l < L; l++) x[l] = elem<8>(r[l][u], j);
+                x[0] ^= SIGN;
+                q |= (wide_hit<L>(w.op, x, a, b) ? 1u : 0u) << j;
+            }
+            uint32_t word = pack_word<2>(q, lane);  // complete in every lane of the 16-lane group
+            const uint64_t wi = ((row0 + (uint64_t)u * RPL) >> 5) + (lane >> 4);
+            if ((lane & 15) == 0) {
+                if (w.mask) word &= w.mask[wi];
+                w.bits[wi] = word;
+                cnt += __builtin_popcount(word);
+            }
+        }
+    }
+    // ragged tail by workgroup 0: thread t owns output bytes t, t + 256, ...
+    if (blockIdx.x == 0) {
+        const uint64_t start = w.n_tiles * (uint64_t)(kWavesPerBlock * WAVE_ROWS);
+        if (start < w.n_rows) {
+            const uint64_t nbytes = (w.n_rows - start + 7) >> 3;
+            const uint8_t *mask8 = (const uint8_t *)w.mask;
+            for (uint64_t bi = threadIdx.x; bi < nbytes; bi += blockDim.x) {
+                uint32_t out = 0;
+                for (int k = 0; k < 8; k++) {
+                    const uint64_t row = start + 8 * bi + k;
+                    if (row >= w.n_rows) break;
+                    uint64_t x[L];
+#pragma unroll
+                    for (int l = 0; l < L; l++) x[l] = w.limb[l][row];
+                    x[0] ^= SIGN;
+                    out |= (wide_hit<L>(w.op, x, a, b) ? 1u : 0u) << k;
+                }
+                if (mask8) out &= mask8[(start >> 3) + bi];
+                ((uint8_t *)w.bits)[(start >> 3) + bi] = (uint8_t)out;
+                cnt += __builtin_popcount(out);
+            }
+        }
+    }
+    // count: wave reduce, one atomic per wave
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0 && cnt && w.count) atomicAdd(w.count, (unsigned long long)cnt);
+}
+
+// Int128 / Int256 IN / NOT IN (i128InSetMatcher / i128NotInSetMatcher.MatchVector, match_i128.go:318-430 and
+// the i256 twins): membership in a sorted set; keys[k * L + l] = limb l (most significant first, top limb
+// already sign-flipped) of set value k.  One lane per row, bits.Set semantics (OR), mask-selected rows only.
+template <int L>
+__global__ void __launch_bounds__(kBlock) wide_inset_kernel(int negate, const uint64_t *l0, const uint64_t *l1, const uint64_t *l2,
+                                                            const uint64_t *l3, uint64_t n_rows, const uint64_t *keys, uint32_t n_keys,
+                                                            uint8_t *bits, const uint8_t *mask) {
+    const uint64_t *limb[4] = {l0, l1, l2, l3};
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            uint64_t x[L];
+#pragma unroll
+            for (int l = 0; l < L; l++) x[l] = limb[l][row];
+            x[0] ^= 1ull << 63;
+            uint32_t lo = 0, hi = n_keys;
+            bool found = false;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t *k = keys + (uint64_t)mid * L;
+                int c = 0;  // key <=> x
+#pragma unroll
+                for (int l = 0; l < L; l++)
+                    if (c == 0 && k[l] != x[l]) c = k[l] < x[l] ? -1 : 1;
+                if (c == 0) { found = true; break; }
+                if (c < 0) lo = mid + 1; else hi = mid;
+            }
+            m = negate ? !found : found;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) byte &= mask[bi];
+                if (byte) bits[bi] |= byte;
+            }
+        }
+    }
+}
+
+hipError_t launch_wide_inset(hipStream_t s, int n_limbs, bool negate, const uint64_t *const *limbs, uint64_t n_rows, const uint64_t *keys,
+                             uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    if (n_limbs == 2) KNOX_LAUNCH(wide_inset_kernel<2>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], nullptr, nullptr, n_rows, keys, n_keys, bits, mask);
+    if (n_limbs == 4) KNOX_LAUNCH(wide_inset_kernel<4>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], limbs[2], limbs[3], n_rows, keys, n_keys, bits, mask);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wide_cmp(hipStream_t s, int n_limbs, int grid, const WideArgs &w) {
+    if (grid < 1) grid = 1;
+    if (n_limbs == 2) KNOX_LAUNCH((wide_cmp_kernel<2>), grid, w);
+    if (n_limbs == 4) KNOX_LAUNCH((wide_cmp_kernel<4>), grid, w);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bitset combinators (internal/bitset/generic/bitset.go:13-330) on 64-bit words.
+// The last word is masked to `size` bits (bytemask semantics extended to the padded word).
+// flags[0] |= any set bit, flags[1] |= any valid bit clear (all == !flags[1]).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t valid_mask(uint64_t word, uint64_t nwords, uint64_t size_bits) {
+    if (word + 1 < nwords || (size_bits & 63) == 0) return ~0ull;
+    return (~0ull) >> (64 - (size_bits & 63));
+}
+
+template <int OP>
+__global__ void __launch_bounds__(kBlock) bitop_kernel(uint64_t *dst, const uint64_t *src, uint64_t nwords,
+                                                       uint64_t size_bits, uint32_t *flags) {
+    uint64_t any = 0, notall = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t vm = valid_mask(i, nwords, size_bits);
+        uint64_t d = dst[i];
+        uint64_t sv = 0;
+        if constexpr (OP == BIT_AND || OP == BIT_ANDNOT || OP == BIT_OR || OP == BIT_XOR || OP == BIT_COPY) sv = src[i];
+        if constexpr (OP == BIT_AND) d &= sv;
+        if constexpr (OP == BIT_ANDNOT) d &= ~sv;
+        if constexpr (OP == BIT_OR) d |= sv;
+        if constexpr (OP == BIT_XOR) d ^= sv;
+        if constexpr (OP == BIT_NEG) d = ~d;
+        if constexpr (OP == BIT_COPY) d = sv;
+        if constexpr (OP == BIT_ONE) d = ~0ull;
+        d &= vm;
+        dst[i] = d;
+        any |= d;
+        notall |= (~d) & vm;
+    }
+    if (flags != nullptr) {
+        // one look per WORKGROUP (same-address traffic serializes in L2): only the first few workgroups that find a flag
+        // clear pay for the read-modify-write
+        const int wany = __syncthreads_or(any != 0);
+        const int wnot = __syncthreads_or(notall != 0);
+        if (threadIdx.x == 0) {
+            if (wany && __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[0], 1u);
+            if (wnot && __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[1], 1u);
+        }
+    }
+}
+
+hipError_t launch_bitop(hipStream_t s, int op, uint64_t *dst, const uint64_t *src, uint64_t size_bits, uint32_t *flags) {
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    if (nwords == 0) return hipSuccess;
+    uint64_t g = (nwords + kBlock - 1) / kBlock;
+    if (g > 1024) g = 1024;
+    const int grid = (int)g;
+    switch (op) {
+    case BIT_AND: KNOX_LAUNCH((bitop_kernel<BIT_AND>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_ANDNOT: KNOX_LAUNCH((bitop_kernel<BIT_ANDNOT>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_OR: KNOX_LAUNCH((bitop_kernel<BIT_OR>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_XOR: KNOX_LAUNCH((bitop_kernel<BIT_XOR>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_NEG: KNOX_LAUNCH((bitop_kernel<BIT_NEG>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_COPY: KNOX_LAUNCH((bitop_kernel<BIT_COPY>), grid, dst, src, nwords, size_bits, flags);
+    case BIT_ONE: KNOX_LAUNCH((bitop_kernel<BIT_ONE>), grid, dst, src, nwords, size_bits, flags);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// PopCount generic/bitset.go:332-353
+__global__ void __launch_bounds__(kBlock) popcount_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                          unsigned long long *out) {
+    uint64_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x)
+        c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
+    __shared__ uint64_t sm[kBlock / 64];  // one atomic per workgroup: same-address atomics serialize in L2
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += sm[w];
+        if (t) atomicAdd(out, (unsigned long long)t);
+    }
+}
+
+hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bits, unsigned long long *count_out) {
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    if (nwords == 0) return hipSuccess;
+    uint64_t g = (nwords + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    KNOX_LAUNCH(popcount_kernel, (int)g, bits, nwords, size_bits, count_out);
+}
+
+// per-segment popcount: one workgroup per segment (seg_bits multiple of 64)
+__global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                              uint64_t seg_words, int64_t *counts, uint64_t n_seg) {
+    __shared__ uint64_t sm[kBlock / 64];
+    for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        const uint64_t w0 = seg * seg_words;
+        uint64_t w1 = w0 + seg_words;
+        if (w1 > nwords) w1 = nwords;
+        uint64_t c = 0;
+        if (((w0 | w1) & 1) == 0 && w1 < nwords) {
+            // whole 16-byte vectors, no partial last word in this segment: 16 B per lane, 4 loads in flight
+            const u32x4 *v = (const u32x4 *)(bits + w0);
+            const uint64_t nvec = (w1 - w0) >> 1;
+#pragma unroll 4
+            for (uint64_t k = threadIdx.x; k < nvec; k += blockDim.x) {
+                const u32x4 x = v[k];
+                c += __builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w);
+            }
+        } else {
+            for (uint64_t i = w0 + threadIdx.x; i < w1; i += blockDim.x) c += __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) counts[seg] = (int64_t)(sm[0] + sm[1] + sm[2] + sm[3]);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
+                                    int64_t *counts, uint64_t n_seg) {
+    if (n_seg == 0) return hipSuccess;
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    uint64_t g = n_seg > 65535 ? 65535 : n_seg;
+    KNOX_LAUNCH(popcount_seg_kernel, (int)g, bits, nwords, size_bits, seg_bits >> 6, counts, n_seg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Indexes (generic/bitset.go:355-396): bitset -> ascending uint32 row ids.
+// chunk = 16384 bits = 256 words per workgroup; counts -> exclusive scan -> ordered write.
+// ---------------------------------------------------------------------------------------------
+constexpr int kIdxWords = kBlock;  // one 64-bit word per thread: 16384 bits per workgroup
+
+__global__ void __launch_bounds__(kBlock) idx_count_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                           uint32_t *block_counts) {
+    __shared__ uint32_t sm[kBlock / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * kIdxWords + threadIdx.x;
+    uint32_t c = 0;
+    if (i < nwords) c = __builtin_popcountll(bits[i] & valid_mask(i, nwords, size_bits));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// inclusive scan of one value per thread over a 64-lane wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// single workgroup exclusive scan in place, 4 entries per thread per round (4096 per round);
+// total written to counts[n] and *n_out
+__global__ void __launch_bounds__(1024) idx_scan_kernel(uint32_t *counts, uint64_t n, unsigned long long *n_out) {
+    __shared__ uint32_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;  // identical in every thread
+    for (uint64_t base = 0; base < n; base += 4096) {
+        const uint64_t i = base + 4 * (uint64_t)threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + k < n ? counts[i + k] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t incl = wave_incl_scan(mine, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wsum[w];
+            before += w < wave ? t : 0;
+            total += t;
+        }
+        uint32_t o = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < n) counts[i + k] = o;
+            o += v[k];
+        }
+        carry += total;
+        __syncthreads();  // wsum is rewritten next round
+    }
+    if (threadIdx.x == 0) {
+        counts[n] = carry;
+        *n_out = carry;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) idx_write_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
+                                                           const uint32_t *block_offsets, uint32_t *rows_out, uint64_t capacity) {
+    __shared__ uint32_t wsum[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * kIdxWords + threadIdx.x;
+    uint64_t w = 0;
+    if (i < nwords) w = bits[i] & valid_mask(i, nwords, size_bits);
+    const uint32_t c = __builtin_popcountll(w);
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; k++) before += k < wave ? wsum[k] : 0;
+    if (c) {
+        uint64_t o = (uint64_t)block_offsets[blockIdx.x] + before + incl - c;
+        const uint32_t row0 = (uint32_t)(i << 6);
+        while (w) {
+            const int k = __builtin_ctzll(w);
+            if (o < capacity) rows_out[o] = row0 + k;
+            o++;
+            w &= w - 1;
+        }
+    }
+}
+
+// exclusive scan of n 32-bit counts in place by one workgroup, the total to *n_out (also used by the simple8 decoder)
+hipError_t launch_idx_scan(hipStream_t s, uint32_t *counts, uint64_t n, unsigned long long *n_out) {
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, s, counts, n, n_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch, uint32_t *rows_out,
+                          uint64_t capacity, unsigned long long *n_out) {
+    const uint64_t nwords = (size_bits + 63) >> 6;
+    const uint64_t nblocks = (nwords + kIdxWords - 1) / kIdxWords;
+    if (nblocks == 0) return hipMemsetAsync(n_out, 0, sizeof(*n_out), s);
+    hipLaunchKernelGGL(idx_count_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bits, nwords, size_bits, scratch);
+    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, nblocks, n_out);
+    hipLaunchKernelGGL(idx_write_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bits, nwords, size_bits, scratch, rows_out,
+                       capacity);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// IN / NOT IN set matchers (operator/filter/match_num.go:672-690,789-808, match_float.go:57-73):
+// one lane = one row; the value's canonical order key (floats: -0 -> +0, NaN never a member) is
+// looked up by binary search in the sorted key set; wave ballot -> 8 result bytes OR-ed into bits.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) inset_kernel(uint32_t flavor, int negate, const void *col, uint64_t n_rows,
+                                                       const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+    using U = typename WT<W>::U;
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            const U e = load_elem<W>(col, row);
+            const U mag = e & (WT<W>::MASK ^ WT<W>::SIGN);
+            uint64_t key;
+            bool isnan = false;
+            if (flavor == FL_FLOAT) {
+                U expmask;
+                if constexpr (W == 8) expmask = 0x7ff0000000000000ull; else expmask = 0x7f800000u;
+                isnan = mag > expmask;
+                key = (mag == 0) ? (uint64_t)WT<W>::SIGN : (uint64_t)fkey<W>(e);
+            } else {
+                key = (flavor == FL_SIGNED) ? (uint64_t)(e ^ WT<W>::SIGN) : (uint64_t)e;
+            }
+            bool found = false;
+            if (!isnan) {
+                uint32_t lo = 0, hi = n_keys;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t k = keys[mid];
+                    if (k < key) lo = mid + 1; else hi = mid;
+                }
+                found = lo < n_keys && keys[lo] == key;
+            }
+            m = negate ? !found : found;
+        }
+        const uint64_t ballot = __ballot(m);
+        if (lane < 8) {
+            const uint64_t r0 = (g << 6) + 8 * (uint64_t)lane;
+            if (r0 < n_rows) {
+                uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                const uint64_t bi = r0 >> 3;
+                if (mask != nullptr) byte &= mask[bi];
+                if (byte) bits[bi] |= byte;
+            }
+        }
+    }
+}
+
+hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
+                        const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 2048 * 4) g = 2048 * 4;
+    switch (width) {
+    case 8: KNOX_LAUNCH((inset_kernel<8>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 4: KNOX_LAUNCH((inset_kernel<4>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 2: KNOX_LAUNCH((inset_kernel<2>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 1: KNOX_LAUNCH((inset_kernel<1>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+
+}  // namespace knox

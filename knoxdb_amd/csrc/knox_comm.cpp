@@ -1,0 +1,132 @@
+// knox_comm.cpp -- RCCL exchange of the final partial aggregates (pack shards never move).  librccl is dlopen'ed on the
+// first knox_comm_* call so that a single-GPU host needs no RCCL at all.
+#include "knox_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// RCCL: exchange of the final partial aggregates only (pack shards never move)
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return KNOX_OK;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return KNOX_E_COMM;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.CommDestroy) return KNOX_E_COMM;
+    g_rccl.lib = lib;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_unique_id(uint8_t id[KNOX_COMM_ID_BYTES]) {
+    if (!id) return KNOX_E_INVALID;
+    static_assert(sizeof(ncclUniqueId) == KNOX_COMM_ID_BYTES, "ncclUniqueId size");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return KNOX_E_COMM;
+    memcpy(id, &u, sizeof u);
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_init(knox_ctx *ctx, int n_ranks, int rank, const uint8_t id[KNOX_COMM_ID_BYTES]) {
+    if (!ctx || !id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return KNOX_E_INVALID;
+    int rc = rccl_load();
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    if (g_rccl.CommInitRank(&ctx->comm, n_ranks, u, rank) != ncclSuccess) {
+        ctx->comm = nullptr;
+        return KNOX_E_COMM;
+    }
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *mine, int n_states, knox_agg_state *merged, int64_t *count_inout) {
+    if (!ctx || n_states < 0 || n_states > 14 || (n_states && (!mine || !merged))) return KNOX_E_INVALID;
+    if (!ctx->comm) return KNOX_E_COMM;
+    hipSetDevice(ctx->device);
+    // payload per rank: n_states states + one int64 count
+    const size_t per = sizeof(knox_agg_state) * (size_t)n_states + 8;
+    const size_t total = per * (size_t)ctx->n_ranks;
+    int rc = ensure_plain(ctx, ctx->comm_buf, per + total + 64);
+    if (rc) return rc;
+    std::vector<uint8_t> h(per + total);
+    if (n_states) memcpy(h.data(), mine, sizeof(knox_agg_state) * (size_t)n_states);
+    int64_t c = count_inout ? *count_inout : 0;
+    memcpy(h.data() + per - 8, &c, 8);
+    uint8_t *d_send = (uint8_t *)ctx->comm_buf.p;
+    uint8_t *d_recv = d_send + ((per + 63) & ~(size_t)63);
+    rc = ensure_plain(ctx, ctx->comm_buf, ((per + 63) & ~(size_t)63) + total + 64);
+    if (rc) return rc;
+    d_send = (uint8_t *)ctx->comm_buf.p;
+    d_recv = d_send + ((per + 63) & ~(size_t)63);
+    HIPCHK(ctx, hipMemcpyAsync(d_send, h.data(), per, hipMemcpyHostToDevice, ctx->stream));
+    if (g_rccl.AllGather(d_send, d_recv, per, ncclUint8, ctx->comm, ctx->stream) != ncclSuccess) return KNOX_E_COMM;
+    HIPCHK(ctx, hipMemcpyAsync(h.data() + per, d_recv, total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // deterministic merge in rank order on every rank (rank order == global row order)
+    std::vector<knox_agg_state> tmp((size_t)ctx->n_ranks);
+    for (int s = 0; s < n_states; s++) {
+        for (int r = 0; r < ctx->n_ranks; r++) memcpy(&tmp[(size_t)r], h.data() + per + per * (size_t)r + sizeof(knox_agg_state) * (size_t)s, sizeof(knox_agg_state));
+        rc = knox_agg_combine(tmp.data(), ctx->n_ranks, &merged[s]);
+        if (rc) return rc;
+    }
+    if (count_inout) {
+        int64_t sum = 0;
+        for (int r = 0; r < ctx->n_ranks; r++) {
+            int64_t v;
+            memcpy(&v, h.data() + per + per * (size_t)r + per - 8, 8);
+            sum += v;
+        }
+        *count_inout = sum;
+    }
+    return KNOX_OK;
+}
+
+// The literal collective of the north star: ONE ncclAllReduce(ncclInt64, ncclSum) for the order-free integer
+// aggregates {SumReducer (wrapping, reducer.go:168-178), CountReducer / CountResult}.  The 64-bit wrapping sum travels
+// as two 32-bit halves in int64 lanes, so no lane can overflow for any number of ranks a node has and the result is
+// exactly the sum mod 2^64 whatever the reduction order: bit-identical to knox_comm_allgather_states + combine.
+KNOX_API int knox_comm_allreduce_sum_count(knox_ctx *ctx, uint64_t *isum_inout, int64_t *count_inout) {
+    if (!ctx || !isum_inout || !count_inout) return KNOX_E_INVALID;
+    if (!ctx->comm) return KNOX_E_COMM;
+    hipSetDevice(ctx->device);
+    int rc = ensure_plain(ctx, ctx->comm_buf, 64);
+    if (rc) return rc;
+    int64_t h[3] = {(int64_t)(*isum_inout & 0xffffffffull), (int64_t)(*isum_inout >> 32), *count_inout};
+    int64_t *d = (int64_t *)ctx->comm_buf.p;
+    HIPCHK(ctx, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    if (g_rccl.AllReduce(d, d, 3, ncclInt64, ncclSum, ctx->comm, ctx->stream) != ncclSuccess) return KNOX_E_COMM;
+    HIPCHK(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *isum_inout = (uint64_t)h[0] + ((uint64_t)h[1] << 32);
+    *count_inout = h[2];
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_destroy(knox_ctx *ctx) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+    return KNOX_OK;
+}
+

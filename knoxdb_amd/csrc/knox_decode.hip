@@ -1,0 +1,469 @@
+// knox_decode.hip -- container ingest on the device (bit-packed, simple8, ALP / ALP-RD, dictionary, run-end, constant /
+// delta, string containers), the scan that runs on bit-packed words directly, and the synthetic-data generators.
+#include "knox_dev.h"
+
+namespace knox {
+
+// ---------------------------------------------------------------------------------------------
+// Bit-packed integer container decode (internal/encode/bitpack/decode.go:56-74 DecodeValue):
+// value i = T((word[i*log2 >> 6] >> (i*log2 & 63) | word[+1] << (64 - shift)) & mask) + minv.
+// One lane per value: the packed words are read through L1/L2 (neighbouring lanes share them),
+// the materialized column is written with full-width coalesced stores.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) bitpack_decode_kernel(const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
+                                                                uint64_t n_values, void *dst) {
+    const uint64_t mask = log2 >= 64 ? ~0ull : ((1ull << log2) - 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        if (log2 > 0) {
+            const uint64_t idx = i * log2, pos = idx >> 6;
+            const uint32_t shift = (uint32_t)(idx & 63);
+            uint64_t word = packed[pos] >> shift;
+            if (64 - shift < log2 && pos + 1 < n_words) word |= packed[pos + 1] << (64 - shift);
+            v = word & mask;
+        }
+        v += minv;
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
+                                 uint64_t n_values, void *dst) {
+    if (n_values == 0) return hipSuccess;
+    uint64_t g = (n_values + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    switch (width) {
+    case 8: KNOX_LAUNCH((bitpack_decode_kernel<8>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    case 4: KNOX_LAUNCH((bitpack_decode_kernel<4>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    case 2: KNOX_LAUNCH((bitpack_decode_kernel<2>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    case 1: KNOX_LAUNCH((bitpack_decode_kernel<1>), (int)g, packed, n_words, log2, minv, n_values, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scan on bit-packed containers without materializing them (the reference compares on the packed
+// form too: internal/encode/bitpack/cmp_*.go, int_bitpack.go Match*).  Value i of a pack is the
+// log2-bit field at bit i*log2 of its word stream, plus For (bitpack/decode.go:56-74).
+//
+// Work shape: one wave per 4096 values; in step t lane l evaluates value t*64 + l, so
+//   * the wave64 ballot of the hits IS the bitset word of rows [t*64, t*64+64) -- no bit shuffling;
+//     lane t parks word t and after 64 steps the wave stores 64 words = 512 contiguous bytes;
+//   * (l*log2) & 63 -- the field's shift -- is the same in every step (t*64*log2 is a multiple of 64
+//     bits), only the word index advances by log2 per step; the lanes of a step read log2 + 1
+//     consecutive words: one cache-line-sized access.
+// Traffic: log2/8 + 1/8 bytes per row instead of 8 + 1/8.
+// ---------------------------------------------------------------------------------------------
+typedef uint64_t u64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool SUM>
+__global__ void __launch_bounds__(kBlock) packed_scan_kernel(const PackedScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_chunks = (uint64_t)a.n_packs * a.groups_per_pack;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint64_t n_words_bits = (a.n_rows + 63) >> 6;
+    Acc acc;
+    acc.init();
+    uint64_t cnt = 0;
+    for (uint64_t wc = wave0; wc < n_chunks; wc += n_waves) {
+        const uint32_t pack = (uint32_t)(wc / a.groups_per_pack);
+        const uint64_t base = (wc % a.groups_per_pack) * 4096;  // first value of the chunk inside its pack
+        const PackedPack hp = a.packs[pack];
+        const uint32_t b = hp.log2;
+        const uint64_t mask = b >= 64 ? ~0ull : ((1ull << b) - 1);
+        const uint32_t sh = (uint32_t)(lane * b) & 63u, wl = (uint32_t)(lane * b) >> 6;
+        const uint64_t *wp = a.words + hp.word_off + (base >> 6) * b + wl;
+        const uint64_t c0 = (hp.minv ^ a.key_xor) - a.lo;  // key(field + For) - lo = field + c0 when no carry crosses the sign flip:
+                                                            // the flip is an xor of the top bit = an add of 2^63 mod 2^64, so it commutes
+        // lane t ends up holding the ballot of step t
+        uint32_t my_lo = 0, my_hi = 0;
+        uint64_t sum = 0;  // of the FIELDS of the hits; For is added once per chunk: + For * hits
+        const bool full = base + 4096 <= hp.n;  // only the last chunk of a short last pack needs the row bound
+        // 8 steps per round: the eight 16-byte loads are issued before any of them is consumed
+#pragma unroll 1
+        for (uint32_t t0 = 0; t0 < 64; t0 += 8) {
+            u64x2u w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = __builtin_nontemporal_load((const u64x2u *)(wp + (uint64_t)(t0 + k) * b));
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t t = t0 + k;
+                uint64_t field = w[k].x >> sh;
+                if (sh != 0) field |= w[k].y << (64 - sh);
+                field &= mask;
+                bool hit = (((field + c0) & a.wmask) <= a.diff) != (a.negate != 0);
+                if (!full) hit = hit && (base + t * 64 + (uint32_t)lane < hp.n);
+                const uint64_t word = __ballot(hit);
+                // lane t parks the ballot of step t (v_writelane would do it in two instructions, but it takes
+                // the lane select from m0 / an inline constant only: measured slower and fragile as inline asm)
+                my_lo = lane == (int)t ? (uint32_t)word : my_lo;
+                my_hi = lane == (int)t ? (uint32_t)(word >> 32) : my_hi;
+                if constexpr (SUM) sum += hit ? field : 0ull;
+            }
+        }
+        const uint64_t myword = ((uint64_t)my_hi << 32) | my_lo;
+        const uint64_t wi = (((uint64_t)pack * a.pack_rows + base) >> 6) + (uint64_t)lane;
+        if (a.bits != nullptr && wi < n_words_bits) __builtin_nontemporal_store(myword, a.bits + wi);
+        const uint64_t hits = (uint64_t)__builtin_popcountll(myword);  // lane t: hits of step t
+        cnt += hits;
+        if constexpr (SUM) acc.isum += sum + hp.minv * hits;  // wrapping: sum over lanes = sum of fields + For * all hits
+    }
+    acc.count = cnt;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+    if (a.want_sum) KNOX_LAUNCH(packed_scan_kernel<true>, grid, a);
+    KNOX_LAUNCH(packed_scan_kernel<false>, grid, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Simple8 containers (internal/encode/int_s8b.go:87-115, s8b/generic/decode.go:15-80, unpack_for.go):
+// every 64-bit word carries a 4-bit selector (bits 60..63) and n values of b bits, LSB first;
+// selectors 0 / 1 are runs of 128 zeros / ones.  value = field + minv.  A word's position in the
+// output is the prefix sum of the counts before it: count -> exclusive scan -> unpack, one lane per word.
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ uint8_t kS8bN[16] = {128, 128, 60, 30, 20, 15, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1};
+__device__ __constant__ uint8_t kS8bBits[16] = {0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 15, 20, 30, 60};
+
+__global__ void __launch_bounds__(kBlock) s8b_count_kernel(const uint64_t *words, uint64_t n_words, uint32_t *counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) counts[i] = kS8bN[words[i] >> 60];
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) s8b_unpack_kernel(const uint64_t *words, uint64_t n_words, const uint32_t *offsets, uint64_t minv,
+                                                            uint64_t n, void *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const uint64_t v = words[i];
+    const uint32_t sel = (uint32_t)(v >> 60);
+    const uint32_t cnt = kS8bN[sel], b = kS8bBits[sel];
+    const uint64_t mask = b == 60 ? 0xFFFFFFFFFFFFFFFull : ((1ull << b) - 1);
+    const uint64_t pos = offsets[i];
+    for (uint32_t j = 0; j < cnt && pos + j < n; j++) {
+        const uint64_t field = sel < 2 ? (uint64_t)sel : ((v >> (j * b)) & mask);
+        const uint64_t x = field + minv;
+        if constexpr (W == 8) ((uint64_t *)dst)[pos + j] = x;
+        else if constexpr (W == 4) ((uint32_t *)dst)[pos + j] = (uint32_t)x;
+        else if constexpr (W == 2) ((uint16_t *)dst)[pos + j] = (uint16_t)x;
+        else ((uint8_t *)dst)[pos + j] = (uint8_t)x;
+    }
+}
+
+// scratch: n_words + 1 uint32 (counts -> offsets, total at [n_words]); n_out: device counter
+hipError_t launch_s8b_decode(hipStream_t s, int width, const uint64_t *words, uint64_t n_words, uint64_t minv, uint64_t n, uint32_t *scratch,
+                             unsigned long long *n_out, void *dst) {
+    if (n_words == 0 || n == 0) return hipSuccess;
+    const int g = (int)((n_words + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(s8b_count_kernel, dim3(g), dim3(kBlock), 0, s, words, n_words, scratch);
+    { const hipError_t e = launch_idx_scan(s, scratch, n_words, n_out); if (e != hipSuccess) return e; }
+    switch (width) {
+    case 8: KNOX_LAUNCH(s8b_unpack_kernel<8>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    case 4: KNOX_LAUNCH(s8b_unpack_kernel<4>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    case 2: KNOX_LAUNCH(s8b_unpack_kernel<2>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    case 1: KNOX_LAUNCH(s8b_unpack_kernel<1>, g, words, n_words, (const uint32_t *)scratch, minv, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ALP float containers (internal/encode/float_alp.go:109-165, alp/decoder.go:40-130): value i =
+// T(enc[i]) * F10[factor] * IF10[exponent] -- two separate multiplications in T's arithmetic, left
+// to right (this file is compiled with -ffp-contract=off) -- then the exceptions are patched in.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) alp_decode_kernel(const void *enc, uint64_t f_bits, uint64_t e_bits, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if constexpr (W == 8) {
+            const double f = __longlong_as_double((long long)f_bits), e = __longlong_as_double((long long)e_bits);
+            double v = (double)((const int64_t *)enc)[i];
+            v = v * f;
+            v = v * e;
+            ((double *)dst)[i] = v;
+        } else {
+            const float f = __uint_as_float((uint32_t)f_bits), e = __uint_as_float((uint32_t)e_bits);
+            float v = (float)((const int32_t *)enc)[i];
+            v = v * f;
+            v = v * e;
+            ((float *)dst)[i] = v;
+        }
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) patch_scatter_kernel(const void *patches, const uint32_t *pos, uint64_t n_patch, uint64_t n, void *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_patch) return;
+    const uint64_t p = pos[i];
+    if (p >= n) return;
+    if constexpr (W == 8) ((uint64_t *)dst)[p] = ((const uint64_t *)patches)[i];
+    else ((uint32_t *)dst)[p] = ((const uint32_t *)patches)[i];
+}
+
+// ALP-RD (float_alprd.go:80-110, alp/rd.go:200-225): IEEE bits = uint(left) << shift | right
+template <int W>
+__global__ void __launch_bounds__(kBlock) alprd_merge_kernel(const uint16_t *left, const void *right, uint32_t shift, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = ((uint64_t)left[i] << shift) | ((const uint64_t *)right)[i];
+        else ((uint32_t *)dst)[i] = ((uint32_t)left[i] << shift) | ((const uint32_t *)right)[i];
+    }
+}
+
+hipError_t launch_alprd_merge(hipStream_t s, int width, const uint16_t *left, const void *right, uint32_t shift, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (width == 8) KNOX_LAUNCH(alprd_merge_kernel<8>, (int)g, left, right, shift, n, dst);
+    if (width == 4) KNOX_LAUNCH(alprd_merge_kernel<4>, (int)g, left, right, shift, n, dst);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_alp_decode(hipStream_t s, int width, const void *enc, uint64_t f_bits, uint64_t e_bits, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (width == 8) KNOX_LAUNCH(alp_decode_kernel<8>, (int)g, enc, f_bits, e_bits, n, dst);
+    if (width == 4) KNOX_LAUNCH(alp_decode_kernel<4>, (int)g, enc, f_bits, e_bits, n, dst);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_patch_scatter(hipStream_t s, int width, const void *patches, const uint32_t *pos, uint64_t n_patch, uint64_t n, void *dst) {
+    if (n_patch == 0) return hipSuccess;
+    const int g = (int)((n_patch + kBlock - 1) / kBlock);
+    if (width == 8) KNOX_LAUNCH(patch_scatter_kernel<8>, g, patches, pos, n_patch, n, dst);
+    if (width == 4) KNOX_LAUNCH(patch_scatter_kernel<4>, g, patches, pos, n_patch, n, dst);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// String containers -> StringPool rows (ptr = off << 32 | len into the column's payload buffer):
+// compact (string_compact.go:64-105) row i = buf[ofs[i] : ofs[i] + len[i]], dictionary
+// (string_dict.go:70-120) row i = dict[ofs[code[i]] : + len[code[i]]]; `base` = where this container's
+// payload starts inside the column's buffer.  ptr_check flags any row that leaves the buffer.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) str_ptr_kernel(const uint32_t *ofs, const uint32_t *len, uint64_t n_entries, const uint32_t *code,
+                                                         uint64_t n, uint64_t base, uint64_t *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = code ? (uint64_t)code[i] : i;
+        if (k >= n_entries) k = n_entries - 1;  // corrupt code: stay inside the entry table (ptr_check sees the rest)
+        uint64_t o = base + ofs[k];
+        if (o > 0xffffffffull) o = 0xffffffffull;  // corrupt offset: keep it out of range instead of wrapping (ptr_check flags it)
+        dst[i] = (o << 32) | (uint64_t)len[k];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) ptr_check_kernel(const uint64_t *ptr, uint64_t n, uint64_t pool_len, uint32_t *flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = ptr[i];
+        if ((p >> 32) + (p & 0xffffffffull) > pool_len) atomicOr(flag, 1u);
+    }
+}
+
+hipError_t launch_str_ptr(hipStream_t s, const uint32_t *ofs, const uint32_t *len, uint64_t n_entries, const uint32_t *code, uint64_t n,
+                          uint64_t base, uint64_t *dst) {
+    if (n == 0) return hipSuccess;
+    if (n_entries == 0) return hipErrorInvalidValue;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    KNOX_LAUNCH(str_ptr_kernel, (int)g, ofs, len, n_entries, code, n, base, dst);
+}
+
+hipError_t launch_ptr_check(hipStream_t s, const uint64_t *ptr, uint64_t n, uint64_t pool_len, uint32_t *flag) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    KNOX_LAUNCH(ptr_check_kernel, (int)g, ptr, n, pool_len, flag);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dictionary and run-end containers (internal/encode/int_dict.go:76-103, int_runend.go:84-120 and the
+// float twins float_dict.go:75-102, float_runend.go:80-110), children already decoded on the device:
+//   dictionary  value i = dict[codes[i]]           (codes: uint16)
+//   run-end     value i = values[k], k = first run with ends[k] >= i   (ends: uint32, inclusive)
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) dict_gather_kernel(const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c = codes[i];
+        if (c >= n_dict) c = n_dict - 1;  // corrupt input: stay inside the dictionary
+        const auto v = load_elem<W>(dict, c);
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) runend_expand_kernel(const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n_runs;  // first k with ends[k] >= i (sort.Search)
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)ends[mid] >= i) hi = mid; else lo = mid + 1;
+        }
+        if (lo >= n_runs) lo = n_runs - 1;
+        const auto v = load_elem<W>(values, lo);
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_dict_gather(hipStream_t s, int width, const void *dict, uint64_t n_dict, const uint16_t *codes, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    if (n_dict == 0) return hipErrorInvalidValue;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    switch (width) {
+    case 8: KNOX_LAUNCH(dict_gather_kernel<8>, (int)g, dict, n_dict, codes, n, dst);
+    case 4: KNOX_LAUNCH(dict_gather_kernel<4>, (int)g, dict, n_dict, codes, n, dst);
+    case 2: KNOX_LAUNCH(dict_gather_kernel<2>, (int)g, dict, n_dict, codes, n, dst);
+    case 1: KNOX_LAUNCH(dict_gather_kernel<1>, (int)g, dict, n_dict, codes, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_runend_expand(hipStream_t s, int width, const void *values, const uint32_t *ends, uint64_t n_runs, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    if (n_runs == 0) return hipErrorInvalidValue;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    switch (width) {
+    case 8: KNOX_LAUNCH(runend_expand_kernel<8>, (int)g, values, ends, n_runs, n, dst);
+    case 4: KNOX_LAUNCH(runend_expand_kernel<4>, (int)g, values, ends, n_runs, n, dst);
+    case 2: KNOX_LAUNCH(runend_expand_kernel<2>, (int)g, values, ends, n_runs, n, dst);
+    case 1: KNOX_LAUNCH(runend_expand_kernel<1>, (int)g, values, ends, n_runs, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Constant and delta containers (internal/encode/int_const.go:67-88, int_delta.go:70-95, float_const.go:67-86):
+// value i = T(i) * delta + base, wrapping in T (delta = 0: constant; floats: base = the IEEE bits).
+// Nothing but three varints crosses PCIe; the column is written at HBM rate.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) affine_fill_kernel(uint64_t base, uint64_t delta, uint64_t n, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = i * delta + base;  // low W bytes = T(i) * delta + base in T's arithmetic
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = v;
+        else if constexpr (W == 4) ((uint32_t *)dst)[i] = (uint32_t)v;
+        else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)v;
+        else ((uint8_t *)dst)[i] = (uint8_t)v;
+    }
+}
+
+hipError_t launch_affine_fill(hipStream_t s, int width, uint64_t base, uint64_t delta, uint64_t n, void *dst) {
+    if (n == 0) return hipSuccess;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    switch (width) {
+    case 8: KNOX_LAUNCH(affine_fill_kernel<8>, (int)g, base, delta, n, dst);
+    case 4: KNOX_LAUNCH(affine_fill_kernel<4>, (int)g, base, delta, n, dst);
+    case 2: KNOX_LAUNCH(affine_fill_kernel<2>, (int)g, base, delta, n, dst);
+    case 1: KNOX_LAUNCH(affine_fill_kernel<1>, (int)g, base, delta, n, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic columns (DESIGN.md "synthetic data"): r(i) = mix64(i + mix64(seed))
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t gen_u64(int kind, uint64_t seedmix, uint64_t i, int64_t lo, uint64_t span) {
+    const uint64_t r = mix64(i + seedmix);
+    switch (kind) {
+    case 0: return span ? (uint64_t)lo + __umul64hi(r, span) : r;
+    case 1: return (uint64_t)__double_as_longlong((double)(r >> 44) * 0x1p-10);
+    case 2: return (uint64_t)__double_as_longlong((double)(r >> 11) * 0x1p-53);
+    case 3: return i + (uint64_t)lo;
+    case 4: {
+        if ((r & 0xfffff) == 0) {
+            const uint64_t sel = (r >> 20) % 5;
+            return sel == 0 ? 0x7ff8000000000000ull : sel == 1 ? 0x7ff0000000000000ull : sel == 2 ? 0xfff0000000000000ull
+                 : sel == 3 ? 0x8000000000000000ull : 0ull;
+        }
+        const double d = ((double)(int64_t)(r >> 11) * 0x1p-53 - 0.5) * 0x1p21;
+        return (uint64_t)__double_as_longlong(d);
+    }
+    default: return 0;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) generate_kernel(int to_f32, int kind, uint64_t seedmix, uint64_t first_row,
+                                                          uint64_t n_rows, int64_t lo, uint64_t span, void *dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t u = gen_u64(kind, seedmix, first_row + i, lo, span);
+        if constexpr (W == 8) ((uint64_t *)dst)[i] = u;
+        else if constexpr (W == 4) {
+            if (to_f32) {
+                const float f = (kind == 1 || kind == 2 || kind == 4) ? (float)__longlong_as_double((long long)u) : (float)(int64_t)u;
+                ((float *)dst)[i] = f;
+            } else ((uint32_t *)dst)[i] = (uint32_t)u;
+        } else if constexpr (W == 2) ((uint16_t *)dst)[i] = (uint16_t)u;
+        else ((uint8_t *)dst)[i] = (uint8_t)u;
+    }
+}
+
+hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                           int64_t lo, uint64_t span, void *dst) {
+    if (n_rows == 0) return hipSuccess;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    const uint64_t sm = mix64(seed);
+    switch (width) {
+    case 8: KNOX_LAUNCH((generate_kernel<8>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    case 4: KNOX_LAUNCH((generate_kernel<4>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    case 2: KNOX_LAUNCH((generate_kernel<2>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    case 1: KNOX_LAUNCH((generate_kernel<1>), (int)g, to_f32 ? 1 : 0, kind, sm, first_row, n_rows, lo, span, dst);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// synthetic bytes column (knox_kernels.h launch_generate_bytes; DESIGN.md "synthetic data" kind 5): one lane per row
+__global__ void __launch_bounds__(kBlock) generate_bytes_kernel(uint64_t seedmix, uint64_t keymix, uint64_t first_row, uint64_t n_rows,
+                                                                uint64_t pack_rows, uint32_t key_len, uint32_t window_bits,
+                                                                uint32_t packs_per_window, uint64_t pool_stride, uint64_t *ptr, uint8_t *buf) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = first_row + i;
+        const uint64_t pack = row / pack_rows, in = row - pack * pack_rows;
+        const uint64_t k = ((pack / packs_per_window) << window_bits) | (mix64(row + seedmix) & ((1ull << window_bits) - 1ull));
+        uint8_t *dst = buf + (i / pack_rows) * pool_stride + in * key_len;
+        for (uint32_t j = 0; j * 8u < key_len; j++) {
+            const uint64_t w = mix64(8ull * k + j + keymix);
+            const uint32_t nb = key_len - j * 8u < 8u ? key_len - j * 8u : 8u;
+            if ((key_len & 7u) == 0u) { ((uint64_t *)dst)[j] = w; continue; }  // pools are 64-byte aligned: whole words
+            for (uint32_t b = 0; b < nb; b++) dst[j * 8u + b] = (uint8_t)(w >> (8u * b));
+        }
+        ptr[i] = ((in * key_len) << 32) | key_len;
+    }
+}
+
+hipError_t launch_generate_bytes(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t pack_rows, uint32_t key_len,
+                                 uint32_t window_bits, uint32_t packs_per_window, uint64_t pool_stride, uint64_t *ptr, uint8_t *buf) {
+    if (n_rows == 0) return hipSuccess;
+    if (pack_rows == 0 || first_row % pack_rows || packs_per_window == 0 || window_bits > 40) return hipErrorInvalidValue;
+    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    KNOX_LAUNCH(generate_bytes_kernel, (int)g, mix64(seed), mix64(seed ^ 0x6b657973ull), first_row, n_rows, pack_rows, key_len, window_bits,
+                packs_per_window, pool_stride, ptr, buf);
+}
+
+
+}  // namespace knox

@@ -1,5 +1,6 @@
-// knox_kernels.h -- internal interface between the C ABI (knox_abi.hip) and the gfx950
-// kernels (knox_kernels.hip).  Not installed; the public surface is include/knoxgpu.h.
+// knox_kernels.h -- internal interface between the host side of the C ABI (knox_abi.cpp and its sibling .cpp files) and
+// the gfx950 kernel translation units (knox_scan / knox_agg / knox_window / knox_bitset / knox_bytes / knox_bloom /
+// knox_decode / knox_sort .hip).  Not installed; the public surface is include/knoxgpu.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -160,6 +161,7 @@ hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
                                     int64_t *counts, uint64_t n_seg);
 // bitset -> ascending uint32 row ids; scratch holds ceil(size/16384)+1 uint32 block offsets
+hipError_t launch_idx_scan(hipStream_t s, uint32_t *counts, uint64_t n, unsigned long long *n_out);  // in-place exclusive scan, one workgroup
 hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
                           uint32_t *rows_out, uint64_t capacity, unsigned long long *n_out);
 

@@ -1,0 +1,337 @@
+// knox_scan.hip -- the streaming scan kernel (predicate tree of <= 4 leaves -> bitset + per-tile counts + aggregates),
+// the dominant kernel of the path.  Compiled once per column width (-DKNOX_SCAN_W=8|4|2|1 -> knox_scan_w8.o ...) so the
+// four families of instantiations build in parallel; launch_scan (knox_agg.hip) dispatches on the width.
+#include "knox_dev.h"
+
+#ifndef KNOX_SCAN_W
+#error "compile with -DKNOX_SCAN_W=8|4|2|1"
+#endif
+
+namespace knox {
+
+template <int W, int NL, unsigned AGG, bool SEP, bool ANYF, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;                       // rows per wave-load
+    constexpr int WAVE_ROWS = RPL * kUnroll;
+    constexpr uint32_t QMASK = (K == 32) ? 0xffffffffu : ((1u << K) - 1u);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    // the wave's bitset words of up to kMaxIters iterations, written out as one contiguous burst
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][kMaxIters * WAVE_ROWS / 32];
+
+    Acc acc;
+    acc.init();
+    WaveMM wm;
+    wm.init();
+    FirstLast fl;
+    fl.init();
+    uint32_t cnt32 = 0;
+    const uint32_t iters = a.iters;
+
+    U lo[NL], diff[NL];
+    bool isf[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        lo[l] = (U)a.leaf[l].lo;
+        diff[l] = (U)a.leaf[l].diff;
+        isf[l] = a.leaf[l].is_float != 0;
+    }
+    const uint32_t tt = (uint32_t)a.tt;  // <= 16 table entries for <= 4 leaves
+    // single leaf: q = in-range bits, then (q & m1) | (~q & m0) applies hit / negated / constant
+    const uint32_t m1 = (tt & 2u) ? QMASK : 0u, m0 = (tt & 1u) ? QMASK : 0u;
+    Swar<(W <= 2 ? W : 1)> sw;
+    if constexpr (W <= 2 && NL == 1) sw.init((uint32_t)lo[0], (uint32_t)diff[0], (tt & 2u) != 0, (tt & 1u) != 0);
+    const int qshift = K * (lane & (G - 1));
+    // order-key range the selected values of a plain single-leaf range predicate can take (narrow integer types): the
+    // leaf's [lo, lo + diff] in key space when it does not wrap, the whole type otherwise
+    uint64_t mm_lo = 0, mm_hi = (uint64_t)WT<W>::MASK;
+    if constexpr (W <= 2 && NL == 1 && FLV != FL_FLOAT) {
+        if (tt == 2u) {
+            const uint64_t klo = (uint64_t)((lo[0] ^ (FLV == FL_SIGNED ? WT<W>::SIGN : (U)0)) & WT<W>::MASK);
+            if (klo + (uint64_t)diff[0] <= (uint64_t)WT<W>::MASK) { mm_lo = klo; mm_hi = klo + (uint64_t)diff[0]; }
+        }
+    }
+
+    uint32_t lb = blockIdx.x;
+#ifdef KNOX_DIAG
+    // diagnostics (debug bit3): XCD-contiguous mapping -- workgroups are dealt round-robin over the 8
+    // XCDs, so logical block (b%8)*(G/8) + b/8 gives every XCD one contiguous run of tiles per round
+    if ((a.debug & 8u) && (gridDim.x & 7u) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    // per-wave-tile popcounts, laid out [workgroup][wave][round] so that a wave's counts are contiguous
+    uint32_t *tcbase = a.tile_counts ? a.tile_counts + ((uint64_t)lb * kWavesPerBlock + (uint64_t)wave) * a.tc_rounds : nullptr;
+    uint32_t tcreg = 0, round = 0, cnt_prev = 0;
+    // packs pruned by the caller's statistics are never touched: with a live-pack list the virtual tile index walks
+    // only the surviving packs (their bitset ranges were zeroed by the host).  A wave owns iters*WAVE_ROWS consecutive
+    // rows of its tile (one contiguous bitset burst): the first of them
+    auto wave_row0 = [&](uint64_t vt) -> uint64_t {
+        uint64_t tile = vt;
+        if (a.live_packs != nullptr) tile = ((uint64_t)a.live_packs[vt >> a.tpp_shift] << a.tpp_shift) + (vt & ((1ull << a.tpp_shift) - 1));
+        return (tile * kWavesPerBlock + (uint64_t)wave) * iters * WAVE_ROWS;
+    };
+    // the kUnroll 16-byte loads per column of one wave iteration
+    auto load_iter = [&](u32x4 (&r)[NL][kUnroll], u32x4 (&ra)[kUnroll], uint64_t row0) {
+        const uint64_t vec0 = row0 / K + lane;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const u32x4 *p = (const u32x4 *)a.leaf[l].col + vec0;
+#pragma unroll
+#ifdef KNOX_LOAD_POLICY
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16_policy(p + u * 64);
+#else
+            for (int u = 0; u < kUnroll; u++) r[l][u] = ld16<true>(p + u * 64);
+#endif
+        }
+#ifdef KNOX_LOAD_POLICY
+        static_assert(kUnroll == 4, "ld_fence takes 4 registers");
+#pragma unroll
+        for (int l = 0; l < NL; l++) ld_fence(r[l][0], r[l][1], r[l][2], r[l][3]);
+#endif
+        if constexpr (SEP && AGG != 0) {
+            const u32x4 *p = (const u32x4 *)a.agg_col + vec0;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) ra[u] = ld16<true>(p + u * 64);
+        }
+    };
+    // one wave iteration over loaded registers: predicate, bitset words into the LDS stage, aggregates; the last
+    // iteration of a tile writes the wave's burst
+    auto body = [&](const u32x4 (&r)[NL][kUnroll], const u32x4 (&ra)[kUnroll], uint64_t wrow0, uint32_t it) {
+        const uint64_t row0 = wrow0 + (uint64_t)it * WAVE_ROWS;  // wave-uniform
+        uint32_t q[kUnroll];
+        constexpr bool kSwar = W <= 2 && NL == 1 && !SEP && (AGG == 0 || AGG == A_ISUM);
+        constexpr bool kSwarAgg = W <= 2 && NL == 1 && !SEP && !kSwar && FLV != FL_FLOAT;  // every other aggregate class of the narrow types
+        if constexpr (kSwarAgg) {
+            constexpr int WS = W <= 2 ? W : 1;
+            constexpr unsigned FS = FLV == FL_FLOAT ? FL_UNSIGNED : FLV;
+            // Every selected value lies inside the predicate's own range, so once the wave holds a value AT both ends of
+            // that range (strict compares: first occurrence wins) no later row can change its min / max: the min / max
+            // work is dropped for the rest of the wave's rows (wave-uniform branch; low-cardinality columns get there fast)
+            if ((AGG & A_MINMAX) != 0 && wm.smin <= mm_lo && wm.smax >= mm_hi)
+                agg_iter_swar<WS, (AGG & ~A_MINMAX), FS>(acc, wm, fl, sw, r[0], q, cnt32, row0, a.row_base, lane);
+            else
+                agg_iter_swar<WS, AGG, FS>(acc, wm, fl, sw, r[0], q, cnt32, row0, a.row_base, lane);
+        } else if constexpr (kSwar) {
+            uint32_t sum32 = 0;  // <= 64 values x 255 resp. 32 x 65535 per iteration
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                q[u] = swar_load<W, AGG == A_ISUM>(sw, r[0][u], sum32);
+                cnt32 += __builtin_popcount(q[u]);
+            }
+            if constexpr (AGG == A_ISUM) acc.isum += sum32;
+        } else {
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            uint32_t qq = 0;
+            if constexpr (NL == 1 && W >= 4 && (AGG & ~A_ISUM) != 0) {
+                // VALU-bound instantiations: the compare's carry shifts straight into the word, qq = 2*qq + (d <= diff),
+                // highest element first (one v_addc instead of a select + or per value)
+#pragma unroll
+                for (int j = K - 1; j >= 0; j--) {
+                    U x = elem<W>(r[0][u], j);
+                    if constexpr (ANYF) x = fkey<W>(x);
+                    const U d = (U)(x - lo[0]);
+                    if constexpr (W == 4) asm("v_cmp_ge_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qq) : "v"(d), "s"(diff[0]) : "vcc");
+                    else asm("v_cmp_ge_u64 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(qq) : "v"(d), "s"(diff[0]) : "vcc");
+                }
+            } else {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                if constexpr (NL == 1) {
+                    U x = elem<W>(r[0][u], j);
+                    if constexpr (ANYF && W >= 4) x = fkey<W>(x);  // one leaf and ANYF: it is the float one
+                    qq |= ((((U)(x - lo[0])) & WT<W>::MASK) <= diff[0] ? 1u : 0u) << j;
+                } else {
+                    uint32_t idx = 0;
+#pragma unroll
+                    for (int l = 0; l < NL; l++) {
+                        U x = elem<W>(r[l][u], j);
+                        if constexpr (ANYF && W >= 4) x = isf[l] ? fkey<W>(x) : x;
+                        idx |= ((((U)(x - lo[l])) & WT<W>::MASK) <= diff[l] ? 1u : 0u) << l;
+                    }
+                    qq |= ((tt >> idx) & 1u) << j;
+                }
+            }
+            }
+            if constexpr (NL == 1) qq = (qq & m1) | (~qq & m0);
+            q[u] = qq;
+            cnt32 += __builtin_popcount(qq);
+        }
+        }  // !kSwar
+        if (a.bits != nullptr) {
+            // assemble the 32-bit words (4 independent DPP chains), stage them in LDS so the wave's
+            // bitset leaves as ONE 16-byte-per-lane store
+            uint32_t w[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) w[u] = q[u] << qshift;
+            if constexpr (G >= 2) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0xB1>(w[u]);   // quad_perm [1,0,3,2]
+            }
+            if constexpr (G >= 4) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0x4E>(w[u]);   // quad_perm [2,3,0,1]
+            }
+            if constexpr (G >= 8) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0x141>(w[u]);  // row_half_mirror
+            }
+            if constexpr (G >= 16) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) w[u] |= dpp_mov<0x140>(w[u]);  // row_mirror
+            }
+            if ((lane & (G - 1)) == 0) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) stage[wave][it * (WAVE_ROWS / 32) + u * (64 / G) + (lane / G)] = w[u];
+            }
+        }
+        if constexpr (AGG != 0 && !kSwar && !kSwarAgg) {
+            if constexpr (SEP) agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
+            else agg_iter<W, AGG, FLV>(acc, wm, fl, r[0], q, row0, a.row_base, lane);
+        }
+        if (it + 1 == iters) {
+        if (a.bits != nullptr) {
+            // LDS ops of one wave execute in order: the reads below see the words written above.
+            // One burst of iters * WAVE_ROWS/8 contiguous bytes per wave (1 KiB for 8-byte types at
+            // 16 iterations): whole 128-B lines, 16-byte-per-lane streaming (nt) stores.
+            const uint32_t nv = iters * (WAVE_ROWS / 128);  // 16-byte vectors
+            u32x4 *dst = (u32x4 *)(a.bits + (wrow0 >> 5));
+            // this lane's share of the burst's popcount is what its running count grew by (the wave total is all
+            // the per-tile count needs): no popcounts over the staged words
+            uint32_t tc = cnt32 - cnt_prev;
+            cnt_prev = cnt32;
+            for (uint32_t v = lane; v < nv; v += 64) {
+                const u32x4 x = ((const u32x4 *)stage[wave])[v];
+#ifdef KNOX_DIAG
+                // diagnostics build only (make diag): debug bit0 = words are assembled but never leave the CU
+                if (a.debug & 2u) dst[v] = x;  // plain (L2 write-back) store
+                else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
+                else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
+#else
+                __builtin_nontemporal_store(x, dst + v);
+#endif
+            }
+            if (tcbase != nullptr) {
+                // popcount of this wave tile's burst, once per tile.  The counts of 32 consecutive
+                // rounds are parked one per lane and leave as ONE full 128-byte line (no partial writes).
+                // (DPP row butterfly + 4 readlanes: a ds_bpermute shuffle chain here costs ~700 cycles of
+                // exposed latency per tile, 5 % of the kernel at 2 workgroups/CU)
+                tc += dpp_mov<0xB1>(tc);
+                tc += dpp_mov<0x4E>(tc);
+                tc += dpp_mov<0x141>(tc);
+                tc += dpp_mov<0x140>(tc);
+                const uint32_t total = (uint32_t)(__builtin_amdgcn_readlane((int)tc, 0) + __builtin_amdgcn_readlane((int)tc, 16) +
+                                                  __builtin_amdgcn_readlane((int)tc, 32) + __builtin_amdgcn_readlane((int)tc, 48));
+                tcreg = lane == (int)(round & 31u) ? total : tcreg;
+                if ((round & 31u) == 31u && lane < 32) tcbase[(round & ~31u) + lane] = tcreg;
+                round++;
+            }
+        }
+        }
+    };
+    // Aggregate-heavy single-column scans are software pipelined: the loads of the NEXT wave iteration (the next tile's
+    // first one at a tile's end) are in flight while the current one is evaluated -- two register sets, roles fixed by an
+    // even iteration count, no register moves.  With 2-3 workgroups per CU resident, waiting out the full HBM latency
+    // once per iteration is what these instantiations were bound by (measured: float32 +4 %, int16 ALL +7 %, int32 ALL
+    // +2 %).  The plain filter / filter+sum kernels do so little between loads that the extra loads in flight only
+    // disturb the read / write mix at the memory controllers (int64 headline -10 %): they keep the simple loop.
+    constexpr bool kPipe = NL == 1 && !SEP && (AGG & ~A_ISUM) != 0;
+    if (kPipe && (iters & 1u) == 0) {
+        u32x4 ra[kUnroll];
+        u32x4 ra_a[NL][kUnroll], rb[NL][kUnroll];
+        uint64_t vt = lb;
+        if (vt < a.n_tiles) {
+            uint64_t w0 = wave_row0(vt);
+            load_iter(ra_a, ra, w0);
+            for (;;) {
+                const uint64_t vn = vt + gridDim.x;
+                const bool more = vn < a.n_tiles;  // wave-uniform
+                const uint64_t wn = more ? wave_row0(vn) : 0;
+#pragma unroll 1
+                for (uint32_t it = 0; it < iters; it += 2) {
+                    load_iter(rb, ra, w0 + (uint64_t)(it + 1) * WAVE_ROWS);
+                    body(ra_a, ra, w0, it);
+                    // always issued (at the very end: a reload of this tile's first rows, never used), so the waits below
+                    // count on a fixed number of loads in flight and only wait for the older set
+                    load_iter(ra_a, ra, it + 2 < iters ? w0 + (uint64_t)(it + 2) * WAVE_ROWS : more ? wn : w0);
+                    body(rb, ra, w0, it + 1);
+                }
+                if (!more) break;
+                vt = vn;
+                w0 = wn;
+            }
+        }
+    } else {
+        for (uint64_t vt = lb; vt < a.n_tiles; vt += gridDim.x) {
+            const uint64_t w0 = wave_row0(vt);
+#pragma unroll 1
+            for (uint32_t it = 0; it < iters; it++) {
+                u32x4 r[NL][kUnroll];
+                u32x4 ra[kUnroll];
+                load_iter(r, ra, w0 + (uint64_t)it * WAVE_ROWS);
+                body(r, ra, w0, it);
+            }
+        }
+    }
+    if (tcbase != nullptr && (round & 31u) != 0 && lane < (int)(round & 31u)) tcbase[(round & ~31u) + lane] = tcreg;
+    acc.count = cnt32;
+    if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+template <int W, int NL, unsigned AGG, bool SEP, unsigned FLV>
+static hipError_t scan_anyf(hipStream_t s, int grid, const ScanArgs &a) {
+    bool anyf = false;
+    for (int l = 0; l < NL; l++) anyf = anyf || a.leaf[l].is_float != 0;
+    if constexpr (W >= 4) {
+        if (anyf) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true, FLV>), grid, a);
+    }
+    KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, false, FLV>), grid, a);
+}
+
+template <int W, int NL, unsigned AGG, unsigned FLV>
+static hipError_t scan_sep(hipStream_t s, bool sep, int grid, const ScanArgs &a) {
+    return sep ? scan_anyf<W, NL, AGG, true, FLV>(s, grid, a) : scan_anyf<W, NL, AGG, false, FLV>(s, grid, a);
+}
+
+template <int W, int NL>
+static hipError_t scan_agg(hipStream_t s, unsigned agg, bool sep, int grid, const ScanArgs &a) {
+    // aggregate classes instantiated: none | isum | full-without-isum (per flavour) | all (ints)
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if (agg == 0) return scan_anyf<W, NL, 0, false, FL_SIGNED>(s, grid, a);
+    if (agg == A_ISUM) return scan_sep<W, NL, A_ISUM, FL_SIGNED>(s, sep, grid, a);
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) return scan_sep<W, NL, FF, FL_FLOAT>(s, sep, grid, a);
+    }
+    if ((agg & A_ISUM) == 0) {
+        return a.agg_flavor == FL_SIGNED ? scan_sep<W, NL, FF, FL_SIGNED>(s, sep, grid, a) : scan_sep<W, NL, FF, FL_UNSIGNED>(s, sep, grid, a);
+    }
+    return a.agg_flavor == FL_SIGNED ? scan_sep<W, NL, A_ALL, FL_SIGNED>(s, sep, grid, a) : scan_sep<W, NL, A_ALL, FL_UNSIGNED>(s, sep, grid, a);
+}
+
+template <int W>
+hipError_t scan_nl(hipStream_t s, int nl, unsigned agg, bool sep, int grid, const ScanArgs &a) {
+    switch (nl) {
+    case 1: return scan_agg<W, 1>(s, agg, sep, grid, a);
+    case 2: return scan_agg<W, 2>(s, agg, sep, grid, a);
+    case 3: return scan_agg<W, 3>(s, agg, sep, grid, a);
+    case 4: return scan_agg<W, 4>(s, agg, sep, grid, a);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template hipError_t scan_nl<KNOX_SCAN_W>(hipStream_t s, int nl, unsigned agg, bool sep, int grid, const ScanArgs &a);
+
+#if KNOX_SCAN_W == 8
+// The allocator's placement probe (knox_abi.cpp): the headline code path under its own symbol
+// (FLV is irrelevant to an integer sum), so that profiles keep probe launches and real scans apart.
+hipError_t launch_probe_scan(hipStream_t s, int grid, const ScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+    KNOX_LAUNCH((scan_kernel<8, 1, A_ISUM, false, false, FL_UNSIGNED>), grid, a);
+}
+#endif
+
+}  // namespace knox

@@ -1,0 +1,443 @@
+// knox_window.hip -- time-window (NativeBucket) aggregation over ordered time columns: window bounds, work items,
+// per-window reduce / finalize / moments, and the literal per-window reducers incl. the join reducers (parity mode).
+// The sort that brings out-of-order time into window order is knox_sort.hip.
+#include "knox_dev.h"
+
+namespace knox {
+
+// ---------------------------------------------------------------------------------------------
+// Time-window aggregation ("next" row f1): pkg/series/series.go:192-246 -> NativeBucket.Push
+// (internal/reducer/bucket_native.go:104-159) keeps one reducer per window [from + k*step,
+// from + (k+1)*step).  With a non-decreasing time column every window is ONE contiguous row range:
+// the ranges come from a binary search per window edge, are cut into work items, each work item is
+// reduced by one workgroup with the same exact machinery as the global aggregates, and the
+// partials of a window are merged in row order.  Out-of-order timestamps (which the reference
+// handles by inserting reducers, :123-141) are detected and refused: the caller keeps the host path.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) sorted_check_kernel(const int64_t *time, uint64_t n_rows, uint32_t *flag) {
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    const uint64_t npairs = n_rows >> 1;  // 16-byte vectors of two timestamps
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < ((npairs + 63) & ~63ull); v += (uint64_t)gridDim.x * blockDim.x) {
+        int64_t e0 = INT64_MIN, e1 = INT64_MIN;
+        const bool in = v < npairs;
+        if (in) {
+            const u32x4 r = ld16<true>((const u32x4 *)time + v);
+            e0 = (int64_t)(((uint64_t)r.y << 32) | r.x);
+            e1 = (int64_t)(((uint64_t)r.w << 32) | r.z);
+            bad = bad || e0 > e1;
+        }
+        int64_t nxt = (int64_t)__shfl_down((unsigned long long)e0, 1, 64);  // first timestamp of the next lane's pair
+        if (lane == 63 || v + 1 >= npairs) nxt = (2 * v + 2 < n_rows) ? time[2 * v + 2] : INT64_MAX;
+        if (in) bad = bad || e1 > nxt;
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_sorted_check(hipStream_t s, const int64_t *time, uint64_t n_rows, uint32_t *flag) {
+    if (n_rows < 2) return hipSuccess;
+    uint64_t g = ((n_rows >> 1) + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    if (g == 0) g = 1;
+    KNOX_LAUNCH(sorted_check_kernel, (int)g, time, n_rows, flag);
+}
+
+__global__ void __launch_bounds__(kBlock) bucket_bounds_kernel(const int64_t *time, uint64_t n_rows, int64_t t_from, int64_t step,
+                                                               uint64_t n_buckets, uint64_t *row_start) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_buckets) return;
+    const int64_t edge = t_from + (int64_t)k * step;  // host checked: no overflow
+    uint64_t lo = 0, hi = n_rows;                    // lower_bound(time, edge)
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (time[mid] < edge) lo = mid + 1; else hi = mid;
+    }
+    row_start[k] = lo;
+}
+
+hipError_t launch_bucket_bounds(hipStream_t s, const int64_t *time, uint64_t n_rows, int64_t t_from, int64_t step, uint64_t n_buckets,
+                                uint64_t *row_start) {
+    KNOX_LAUNCH(bucket_bounds_kernel, (int)((n_buckets + 1 + kBlock - 1) / kBlock), time, n_rows, t_from, step, n_buckets, row_start);
+}
+
+template <int W, unsigned AGG, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_reduce_kernel(const ScanArgs a, const BucketItem *items, uint32_t n_items) {
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint8_t *mask8 = (const uint8_t *)a.mask;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint64_t rb = items[it].begin, re = items[it].end;
+        Acc acc;
+        acc.init();
+        WaveMM wm;
+        wm.init();
+        FirstLast fl;
+        fl.init();
+        uint32_t cnt32 = 0;
+        // aligned middle: whole wave tiles, vector path
+        const uint64_t a0 = (rb + WAVE_ROWS - 1) / WAVE_ROWS, a1 = re / WAVE_ROWS;  // tile indices [a0, a1)
+        for (uint64_t t = a0 + wave; t < a1; t += kWavesPerBlock) {
+            const uint64_t row0 = t * WAVE_ROWS;
+            const u32x4 *p = (const u32x4 *)a.agg_col + row0 / K + lane;
+            u32x4 ra[kUnroll];
+            uint32_t q[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                ra[u] = ld16<true>(p + u * 64);
+                q[u] = a.mask ? a.mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                q[u] = (q[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+                cnt32 += __builtin_popcount(q[u]);
+            }
+            agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
+        }
+        // ragged edges (or the whole item when it holds no aligned tile): one row per lane, rows
+        // ascending per lane, exact per-row update
+        const uint64_t e0 = a0 < a1 ? a0 * WAVE_ROWS : re;  // head edge [rb, e0)
+        const uint64_t e1 = a0 < a1 ? a1 * WAVE_ROWS : re;  // tail edge [e1, re)
+        for (int part = 0; part < 2; part++) {
+            const uint64_t lo = part == 0 ? rb : e1, hi = part == 0 ? e0 : re;
+            for (uint64_t row = lo + threadIdx.x; row < hi; row += blockDim.x) {
+                const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
+                acc.count += hit;
+                acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+            }
+        }
+        acc.count += cnt32;
+        if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
+        block_reduce_store(acc, a.partials + it);
+        __syncthreads();  // block_reduce_store's LDS is reused by the next item
+    }
+}
+
+// many small windows: one WAVE per work item -- no workgroup barrier and no LDS round per item (a window of a few hundred
+// rows costs a few loop iterations + one wave reduction); the rows are taken lane-strided, first / last ride in the Acc
+template <int W, unsigned AGG, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_reduce_wave_kernel(const ScanArgs a, const BucketItem *items, uint32_t n_items) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = gridDim.x * kWavesPerBlock;
+    const uint8_t *mask8 = (const uint8_t *)a.mask;
+    for (uint32_t it = wave; it < n_items; it += n_waves) {
+        const uint64_t rb = items[it].begin, re = items[it].end;
+        Acc acc;
+        acc.init();
+        for (uint64_t row = rb + lane; row < re; row += 64) {
+            const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
+            acc.count += hit;
+            acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+        }
+        wave_reduce(acc);
+        if (lane == 0) {
+            AggPartial p;
+            p.count = acc.count; p.isum = acc.isum; p.hi = acc.hi; p.lo = acc.lo; p.xlo = acc.xlo; p.xhi = acc.xhi;
+            p.minkey = acc.minkey; p.minrow = acc.minrow; p.maxkey = acc.maxkey; p.maxrow = acc.maxrow;
+            p.firstrow = acc.firstrow; p.lastrow = acc.lastrow1;
+            a.partials[it] = p;
+        }
+    }
+}
+
+template <int W> static hipError_t bucket_reduce_waves_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) KNOX_LAUNCH((bucket_reduce_wave_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+    }
+    if (a.agg_flavor == FL_SIGNED) KNOX_LAUNCH((bucket_reduce_wave_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    KNOX_LAUNCH((bucket_reduce_wave_kernel<W, A_ALL, FL_UNSIGNED>), grid, a, items, n_items);
+}
+
+hipError_t launch_bucket_reduce_waves(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    if (n_items == 0 || grid <= 0) return hipSuccess;
+    switch (width) {
+    case 8: return bucket_reduce_waves_w<8>(s, grid, a, items, n_items);
+    case 4: return bucket_reduce_waves_w<4>(s, grid, a, items, n_items);
+    case 2: return bucket_reduce_waves_w<2>(s, grid, a, items, n_items);
+    case 1: return bucket_reduce_waves_w<1>(s, grid, a, items, n_items);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int W> static hipError_t bucket_reduce_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) KNOX_LAUNCH((bucket_reduce_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+    }
+    if (a.agg_flavor == FL_SIGNED) KNOX_LAUNCH((bucket_reduce_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    KNOX_LAUNCH((bucket_reduce_kernel<W, A_ALL, FL_UNSIGNED>), grid, a, items, n_items);
+}
+
+hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    if (n_items == 0 || grid <= 0) return hipSuccess;
+    switch (width) {
+    case 8: return bucket_reduce_w<8>(s, grid, a, items, n_items);
+    case 4: return bucket_reduce_w<4>(s, grid, a, items, n_items);
+    case 2: return bucket_reduce_w<2>(s, grid, a, items, n_items);
+    case 1: return bucket_reduce_w<1>(s, grid, a, items, n_items);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// one thread per window: ordered merge of its work items' partials, fetch adopted values
+template <int W>
+__global__ void __launch_bounds__(kBlock) bucket_finalize_kernel(const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                                                 const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    Acc t;
+    t.init();
+    for (uint32_t i = item_start[k]; i < item_start[k + 1]; i++) {
+        const AggPartial p = partials[i];
+        Acc b;
+        b.count = p.count; b.isum = p.isum; b.hi = p.hi; b.lo = p.lo; b.xlo = p.xlo; b.xhi = p.xhi;
+        b.minkey = p.minkey; b.minrow = p.minrow; b.maxkey = p.maxkey; b.maxrow = p.maxrow;
+        b.firstrow = p.firstrow; b.lastrow1 = p.lastrow;
+        t.merge(b);
+    }
+    AggStateDev s;
+    s.dtype = dtype;
+    s.flags = 1u;
+    s.count = (int64_t)t.count;
+    s.isum = t.isum;
+    s.fsum_hi = t.hi;
+    s.fsum_lo = t.lo;
+    if (dtype <= 8) int128_to_dd(t.xlo, t.xhi, s.fsum_hi, s.fsum_lo);
+    s.min_row = t.minrow == kNoRow ? -1 : (int64_t)t.minrow;
+    s.max_row = t.maxrow == kNoRow ? -1 : (int64_t)t.maxrow;
+    s.first_row = t.firstrow == kNoRow ? -1 : (int64_t)t.firstrow;
+    s.last_row = t.lastrow1 == 0 ? -1 : (int64_t)(t.lastrow1 - 1);
+    s.min_bits = s.min_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.minrow - row_base) : 0;
+    s.max_bits = s.max_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.maxrow - row_base) : 0;
+    s.first_bits = s.first_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.firstrow - row_base) : 0;
+    s.last_bits = s.last_row >= 0 ? (uint64_t)load_elem<W>(agg_col, t.lastrow1 - 1 - row_base) : 0;
+    s.m_shift = 0.0; s.m_dev_hi = 0.0; s.m_dev_lo = 0.0; s.m_sq_hi = 0.0; s.m_sq_lo = 0.0;
+    state_out[k] = s;
+}
+
+hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                  const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out) {
+    if (n_buckets == 0) return hipSuccess;
+    const int grid = (int)((n_buckets + kBlock - 1) / kBlock);
+    switch (width) {
+    case 8: KNOX_LAUNCH((bucket_finalize_kernel<8>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    case 4: KNOX_LAUNCH((bucket_finalize_kernel<4>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    case 2: KNOX_LAUNCH((bucket_finalize_kernel<2>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    case 1: KNOX_LAUNCH((bucket_finalize_kernel<1>), grid, partials, item_start, n_buckets, agg_col, row_base, dtype, state_out);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// var/std per window: the same work items again, each centred on ITS window's mean (already in
+// states[bucket]); 4 doubles per work item, merged per window in row order
+template <int W, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_moments_kernel(const void *col, const uint32_t *mask, const BucketItem *items, uint32_t n_items,
+                                                                const AggStateDev *states, double *partials) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
+    __shared__ Mom sm[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint8_t *mask8 = (const uint8_t *)mask;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint64_t rb = items[it].begin, re = items[it].end;
+        const double k0 = moments_shift(states + items[it].bucket, 0.0);
+        Mom m;
+        m.init();
+        const uint64_t a0 = (rb + WAVE_ROWS - 1) / WAVE_ROWS, a1 = re / WAVE_ROWS;
+        for (uint64_t t = a0 + wave; t < a1; t += kWavesPerBlock) {
+            const uint64_t row0 = t * WAVE_ROWS;
+            const u32x4 *p = (const u32x4 *)col + row0 / K + lane;
+            u32x4 r[kUnroll];
+            uint32_t q[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                r[u] = ld16<true>(p + u * 64);
+                q[u] = mask ? mask[((row0 + (uint64_t)u * RPL) >> 5) + (lane / G)] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t qq = (q[u] >> (K * (lane & (G - 1)))) & ((1u << K) - 1u);
+#pragma unroll
+                for (int j = 0; j < K; j++) m.add(to_f64_c<W, FLV>(elem<W>(r[u], j)), k0, ((qq >> j) & 1u) != 0);
+            }
+        }
+        const uint64_t e0 = a0 < a1 ? a0 * WAVE_ROWS : re;
+        const uint64_t e1 = a0 < a1 ? a1 * WAVE_ROWS : re;
+        for (int part = 0; part < 2; part++) {
+            const uint64_t lo = part == 0 ? rb : e1, hi = part == 0 ? e0 : re;
+            for (uint64_t row = lo + threadIdx.x; row < hi; row += blockDim.x) {
+                const bool hit = mask8 ? ((mask8[row >> 3] >> (row & 7)) & 1u) != 0 : true;
+                m.add(to_f64_c<W, FLV>((U)load_elem<W>(col, row)), k0, hit);
+            }
+        }
+        mom_block_reduce(m, sm);
+        if (threadIdx.x == 0) {
+            double *o = partials + 4 * (size_t)it;
+            o[0] = m.qh; o[1] = m.ql; o[2] = m.dh; o[3] = m.dl;
+        }
+        __syncthreads();  // sm is reused by the next item
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bucket_moments_finalize_kernel(const double *partials, const uint32_t *item_start, uint32_t n_buckets,
+                                                                         AggStateDev *states) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    Mom m;
+    m.init();
+    for (uint32_t i = item_start[k]; i < item_start[k + 1]; i++) {
+        Mom o;
+        o.qh = partials[4 * (size_t)i]; o.ql = partials[4 * (size_t)i + 1]; o.dh = partials[4 * (size_t)i + 2]; o.dl = partials[4 * (size_t)i + 3];
+        m.merge(o);
+    }
+    AggStateDev *s = states + k;
+    s->m_shift = moments_shift(s, 0.0);
+    s->m_dev_hi = m.dh; s->m_dev_lo = m.dl; s->m_sq_hi = m.qh; s->m_sq_lo = m.ql;
+    s->flags |= 2u;
+}
+
+template <int W>
+static hipError_t bucket_moments_w(hipStream_t s, uint32_t flavor, int grid, const void *col, const uint32_t *mask, const BucketItem *items,
+                                   uint32_t n_items, const AggStateDev *states, double *partials) {
+    if constexpr (W >= 4) {
+        if (flavor == FL_FLOAT) KNOX_LAUNCH((bucket_moments_kernel<W, FL_FLOAT>), grid, col, mask, items, n_items, states, partials);
+    }
+    if (flavor == FL_SIGNED) KNOX_LAUNCH((bucket_moments_kernel<W, FL_SIGNED>), grid, col, mask, items, n_items, states, partials);
+    KNOX_LAUNCH((bucket_moments_kernel<W, FL_UNSIGNED>), grid, col, mask, items, n_items, states, partials);
+}
+
+hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask,
+                                 const BucketItem *items, uint32_t n_items, const uint32_t *item_start, uint32_t n_buckets,
+                                 AggStateDev *states, double *partials) {
+    if (n_buckets == 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (n_items != 0 && grid > 0) {
+        switch (width) {
+        case 8: e = bucket_moments_w<8>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 4: e = bucket_moments_w<4>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 2: e = bucket_moments_w<2>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 1: e = bucket_moments_w<1>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        default: return hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(bucket_moments_finalize_kernel, dim3((n_buckets + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const double *)partials,
+                       item_start, n_buckets, states);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Literal reducers per time window: one lane owns one window [start[k], start[k+1]) and applies
+// the reference's reducer statement by statement in row order -- plain reducers (reducer.go:
+// 130-429) and the join reducers (reducer.go:432-731), whose `join` argument is "this row's raw
+// timestamp equals the previous streamed row's" (pkg/series/series.go:200-203).  Equal raw
+// timestamps always share a window, so the flag is window-local.  Bit-exact with the reference
+// for every reducer (Welford included); throughput is one row per lane-step, which is what the
+// mode is for: parity and small / many-window series, not the 1B-row scan.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SeqJoinRed {
+    bool seen = false, done = false;
+    T v = 0, j = 0;
+    uint64_t n = 0;
+    double mean = 0, m2 = 0;
+
+    __device__ inline void welford(int func, T x) {
+        n++;
+        const double d = (double)x - mean;
+        mean += d / (double)n;
+        if (func != 5 && func != 13) m2 += d * ((double)x - mean);
+    }
+    __device__ inline void push_join(int func, T x, bool join) {
+        if (func == 10) { seen = true; v = join ? (T)(v + x) : x; return; }          // LastJoin :476-483
+        if (!seen) { seen = true; if (func == 9) v = x; else j = x; return; }        // r.t.IsZero()
+        switch (func) {
+        case 9: if (join && !done) v = (T)(v + x); else done = true; break;          // FirstJoin :447-457
+        case 12: if (join) j = (T)(j + x); else { if (v < j) v = j; j = x; } break;  // MaxJoin :504-518
+        case 11: if (join) j = (T)(j + x); else { if (j < v) v = j; j = x; } break;  // MinJoin :541-555
+        default: if (join) j = (T)(j + x); else { welford(func, j); j = x; } break;  // Mean/Var/StdJoin :578-731
+        }
+    }
+    __device__ inline void push(int func, T x) {
+        switch (func) {
+        case 8: v = (T)(v + 1); break;
+        case 0: v = (T)(v + x); break;
+        case 1: if (!seen) v = x; break;
+        case 2: v = x; break;
+        case 4: if (!seen || v < x) v = x; break;
+        case 3: if (!seen || v > x) v = x; break;
+        default: welford(func, x); break;
+        }
+        seen = true;
+    }
+    // Reducer.Value(): the join reducers flush the pending group first
+    __device__ inline T value(int func, bool *ok) {
+        if (func >= 11 && seen) push_join(func, func == 11 ? j : (T)0, false);
+        const bool mom = func == 5 || func == 6 || func == 7 || func >= 13;
+        *ok = mom ? n > 0 : seen;
+        switch (func) {
+        case 5: case 13: return (T)mean;
+        case 6: case 14: return n < 2 ? (T)__builtin_nan("") : (T)(m2 / (double)(n - 1));
+        case 7: case 15: return n < 2 ? (T)__builtin_nan("") : (T)__builtin_sqrt(m2 / (double)(n - 1));
+        default: return v;
+        }
+    }
+};
+
+template <typename T>
+__global__ void bucket_seq_kernel(int func, const int64_t *__restrict__ time, const T *__restrict__ src, const uint8_t *__restrict__ bits,
+                                  const uint64_t *__restrict__ start, uint32_t n_buckets, T *__restrict__ out_v, uint8_t *__restrict__ out_seen) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    SeqJoinRed<T> r;
+    bool have_prev = false;
+    int64_t prev = 0;
+    const uint64_t e = start[k + 1];
+    for (uint64_t i = start[k]; i < e; i++) {
+        if (bits != nullptr && !((bits[i >> 3] >> (i & 7)) & 1)) continue;
+        const T x = src[i];
+        if (func >= 9) {
+            const int64_t t = time[i];
+            r.push_join(func, x, have_prev && t == prev);
+            prev = t;
+            have_prev = true;
+        } else
+            r.push(func, x);
+    }
+    bool ok;
+    out_v[k] = r.value(func, &ok);
+    out_seen[k] = ok ? 1 : 0;
+}
+
+hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
+                                    const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen) {
+    const int tpb = 64;
+    const int grid = (int)((n_buckets + tpb - 1) / tpb);
+#define KNOX_BSEQ(T) hipLaunchKernelGGL((bucket_seq_kernel<T>), dim3(grid), dim3(tpb), 0, s, func, time, (const T *)col, mask, start, n_buckets, (T *)out_v, out_seen); break
+    switch (dtype) {
+    case 1: KNOX_BSEQ(int64_t);
+    case 2: KNOX_BSEQ(int32_t);
+    case 3: KNOX_BSEQ(int16_t);
+    case 4: KNOX_BSEQ(int8_t);
+    case 5: KNOX_BSEQ(uint64_t);
+    case 6: KNOX_BSEQ(uint32_t);
+    case 7: KNOX_BSEQ(uint16_t);
+    case 8: KNOX_BSEQ(uint8_t);
+    case 9: KNOX_BSEQ(double);
+    case 10: KNOX_BSEQ(float);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_BSEQ
+    return hipGetLastError();
+}
+
+
+}  // namespace knox
