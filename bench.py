@@ -129,6 +129,177 @@ def in_run_parity(ctx, col_seed, n_rows, pack_rows, a, b, bits, res, row_seed_fi
             "sum_equals_cpu": bool(gsum == sum_cpu), "sample_sum_mod_2^64": ssum % (1 << 64)}
 
 
+def _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup, pack_skip=None):
+    """`steps` software-pipelined passes (scan i+1 enqueued before scan i is collected, like the headline loop) after
+    `warmup` untimed ones: wall clock per step + the dominant kernel's mean duration (the library's HIP events on its
+    own stream, knox_prof_*).  Every pass produces and collects the bitset, the per-pack counts and the aggregates."""
+    def run(k):
+        ctx.scan_async(plan, bits_out=bits, pack_counts=True, pack_skip=pack_skip)
+        last = None
+        for i in range(k):
+            if i + 1 < k:
+                ctx.scan_async(plan, bits_out=bits, pack_counts=True, pack_skip=pack_skip)
+            last = ctx.scan_collect(plan, n_packs)
+        return last
+    run(max(1, warmup))
+    ctx.L.knox_prof_enable(ctx.h, 1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    res = run(steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ms, k = C.c_double(), C.c_int()
+    ctx.L.knox_prof_read(ctx.h, C.byref(ms), C.byref(k))
+    ctx.L.knox_prof_enable(ctx.h, 0)
+    return res, dt / steps * 1e3, ms.value / max(1, k.value), k.value
+
+
+def _cfg_line(n_rows, bytes_per_row, step_ms, kernel_ms, launches, kernel):
+    gbs = n_rows * bytes_per_row / kernel_ms / 1e6 if kernel_ms > 0 else 0.0
+    return {"rows": n_rows, "bytes_per_row": bytes_per_row, "algorithmic_bytes_per_launch": n_rows * bytes_per_row, "kernel": kernel,
+            "kernel_ms": kernel_ms, "launches_timed": launches, "ms_per_step": step_ms, "rows_per_s": n_rows / step_ms * 1e3,
+            "achieved_gb_per_s": gbs, "frac": gbs / HBM_PEAK_GBS, "whole_step_gb_per_s": n_rows * bytes_per_row / step_ms / 1e6}
+
+
+def secondary_configs(K, device_index, n_rows, pack_rows, steps, warmup, parity=True):
+    """BASELINE configs[2] and configs[3] at the same size as the headline, after its timed region (each in a fresh
+    context whose arena places its own columns): kernel time from HIP events, achieved GB/s against the 8 TB/s peak with
+    SURVEY.md 8(d)'s algorithmic bytes per row, and an in-run parity verdict (the oracle on sampled packs + whole-run
+    invariants).  Reported under "configs" in the one JSON line; the headline fields do not depend on any of this."""
+    import ctypes as C
+    import numpy as np
+    from knoxdb_amd import And, Leaf
+    from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc as R
+    O = None
+    if parity:
+        from oracle import oracle as O   # the checker, outside every timed region
+    n_packs = n_rows // pack_rows
+    sample = sorted(set(int(p) for p in np.linspace(0, n_packs - 1, 16)))
+    pb = pack_rows >> 3
+    out = {}
+
+    def note(msg):
+        print("[configs] " + msg, file=sys.stderr, flush=True)
+
+    # ---- configs[2]: two float64 columns, `A >= 256 AND B < 0.5`, min / max / mean(A) (+ sum, count) ---------------
+    t0 = time.perf_counter()
+    with K.Context(device_index) as ctx:
+        ctx.set_arena(64 << 30)
+        A = ctx.generate(BlockType.Float64, 1, 3, n_rows, pack_rows=pack_rows)   # k * 2^-10 grid: every summation order is exact
+        B = ctx.generate(BlockType.Float64, 2, 4, n_rows, pack_rows=pack_rows)   # uniform [0, 1)
+        bits = ctx.bits(n_rows, for_col=A)
+        tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
+        plan = ctx.plan(tree, [A, B], aggs=[(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Sum, 0), (R.Count, 0)])
+        res, step_ms, kms, kn = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
+        line = _cfg_line(n_rows, 16.125, step_ms, kms, kn, "knox::scan_kernel<8,2,FSUM|MINMAX|FIRSTLAST,float> (2 leaves, truth table, min/max/mean)")
+        vmin, vmax, vmean, vsum = (float(res.value(i)[0]) for i in range(4))
+        line.update({"workload": "BASELINE configs[2]: 2^%d float64 rows x 2 columns, A >= 256 AND B < 0.5, min/max/mean(A) + sum + count, bitset + per-pack counts"
+                                 % (n_rows.bit_length() - 1), "selected_rows": int(res.count), "min": vmin, "max": vmax, "mean": vmean, "sum": vsum,
+                     "bitset_pair_check_at_allocation": bits.pair_check[0]})
+        if parity:
+            got = bits.bytes()
+            ok_bits = ok_cnt = True
+            for p in sample:
+                xa = O.generate(O.F64, 1, 3, p * pack_rows, pack_rows)
+                xb = O.generate(O.F64, 2, 4, p * pack_rows, pack_rows)
+                wa, _ = O.cmp(O.F64, O.GE, xa, 256.0, 0.0)
+                wb, _ = O.cmp(O.F64, O.LT, xb, 0.5, 0.0)
+                want = O.bits_op("and", wa, wb, pack_rows)
+                ok_bits = ok_bits and bool((got[p * pb:(p + 1) * pb] == want).all())
+                ok_cnt = ok_cnt and int(res.pack_counts[p]) == int(O.popcount(want, pack_rows))
+            line["parity_in_run"] = {
+                "sample_packs": len(sample), "sample_bitsets_equal_oracle": ok_bits, "sample_pack_counts_equal": ok_cnt,
+                "pack_counts_sum_to_count": bool(int(res.pack_counts.sum()) == int(res.count)),
+                "bitset_popcount_equals_count": bool(bits.count() == int(res.count)),
+                # on the grid every partial sum is exact: the sum is THE sum, and the mean must be its one IEEE division
+                "mean_equals_sum_over_count": bool(res.count > 0 and vmean == vsum / int(res.count)),
+                "min_max_are_the_grid_ends": bool(vmin == 256.0 and vmax == ((1 << 20) - 1) / 1024.0) if n_rows >= (1 << 26) else None}
+        for o in (A, B, bits):
+            o.free()
+    line["setup_and_run_s"] = time.perf_counter() - t0
+    out["cfg3"] = line
+    note("cfg3: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
+
+    # ---- configs[3]: uint64 id + 32-byte []byte addr (one StringPool per pack), per-pack bloom -> EQ -> count ---------
+    def bloom_then_eq(ctx, col, key, hash_of_key, bytes_per_row, kernel, oracle_pack_bits):
+        bits = ctx.bits(n_rows, for_col=col)
+        tb = time.perf_counter()
+        bloom = ctx.bloom_build(col, 2)      # FilterTypeBloom2b: factor 2, built on the device
+        ctx.sync()
+        t_build = time.perf_counter() - tb
+        maybe = bloom.probe(hash_of_key)
+        plan = ctx.plan(And(Leaf(0, FilterMode.Equal, key)), [col], aggs=[(R.Count, 0)] if col.dtype != BlockType.Bytes else [])
+        full, step_ms, kms, kn = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
+        line = _cfg_line(n_rows, bytes_per_row, step_ms, kms, kn, kernel)
+        got = bits.bytes() if parity else None
+        skip = (1 - maybe).astype(np.uint8)
+        pruned, pstep_ms, pkms, pkn = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup, pack_skip=skip)
+        scanned = int(maybe.sum())
+        line.update({"selected_rows": int(full.count), "bloom_build_s": t_build, "bloom_filter_bytes": int(ctx.L.knox_bloom_bytes(bloom.h)),
+                     "bitset_pair_check_at_allocation": bits.pair_check[0],
+                     # packs the filter rejects cost 0 B/row: the roofline fraction above is over SCANNED packs (the full scan);
+                     # this is the separately labelled figure with pruning (SURVEY.md 8d)
+                     "bloom_pruned": {"packs_scanned": scanned, "packs": n_packs, "rows_scanned": int(pruned.rows_scanned), "kernel_ms": pkms,
+                                      "ms_per_step": pstep_ms, "effective_rows_per_s_incl_pruned_packs": n_rows / pstep_ms * 1e3,
+                                      "gb_per_s_over_scanned_packs": scanned * pack_rows * bytes_per_row / pkms / 1e6 if scanned and pkms > 0 else None,
+                                      "selected_rows": int(pruned.count)}})
+        if parity:
+            ok_bits = ok_cnt = True
+            for p in sorted(set(sample + [int(x) for x in np.flatnonzero(maybe)[:4]])):
+                want, wc = oracle_pack_bits(p)
+                ok_bits = ok_bits and bool((got[p * pb:(p + 1) * pb] == want).all())
+                ok_cnt = ok_cnt and int(full.pack_counts[p]) == int(wc)
+            line["parity_in_run"] = {
+                "sample_packs": len(sample), "sample_bitsets_equal_oracle": ok_bits, "sample_pack_counts_equal": ok_cnt,
+                "pack_counts_sum_to_count": bool(int(full.pack_counts.sum()) == int(full.count)),
+                "pruned_equals_full": bool(pruned.count == full.count and (pruned.pack_counts == full.pack_counts).all()),
+                "every_pruned_pack_is_empty_in_the_full_scan": bool((full.pack_counts[skip != 0] == 0).all()),
+                "present_key_found": bool(full.count >= 1)}
+        bloom.free()
+        bits.free()
+        return line
+
+    t0 = time.perf_counter()
+    with K.Context(device_index) as ctx:
+        ctx.set_arena(64 << 30)
+        ids = ctx.generate(BlockType.Uint64, 0, 5, n_rows, lo=0, span=0, pack_rows=pack_rows)   # unique-in-practice 64-bit ids
+        present = int(ids.download(min(777, n_packs - 1) * pack_rows + 12345 % pack_rows, 1)[0])
+
+        def want_u64(p):
+            x = O.generate(O.U64, 0, 5, p * pack_rows, pack_rows, lo=0, span=0)
+            return O.cmp(O.U64, O.EQ, x, present)
+        line = bloom_then_eq(ctx, ids, present, K.hash_value(BlockType.Uint64, np.uint64(present)), 8.125,
+                             "knox::scan_kernel<8,1,0> (uint64 EQ, count)", want_u64)
+        line["workload"] = "BASELINE configs[3], uint64 leg: 2^%d ids, per-pack bloom (factor 2) probe, EQ present key, count" % (n_rows.bit_length() - 1)
+        ids.free()
+    line["setup_and_run_s"] = time.perf_counter() - t0
+    out["cfg4_u64"] = line
+    note("cfg4_u64: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
+
+    t0 = time.perf_counter()
+    with K.Context(device_index) as ctx:
+        ctx.set_arena(128 << 30)
+        key_len, wbits, ppw = 32, 16, 4
+        addr = ctx.generate_bytes(6, n_rows, pack_rows, key_len, wbits, ppw)   # 2^24 keys, every key inside one window of 4 packs
+        ptr, buf = ctx.download_bytes_pack(addr, min(777, n_packs - 1))
+        r = 12345 % pack_rows
+        present = bytes(buf[r * key_len:(r + 1) * key_len])
+
+        def want_bytes(p):
+            wp, wbuf, _ = O.generate_bytes_pack(6, p, pack_rows, pack_rows, key_len, wbits, ppw)
+            return O.bytes_match(O.EQ, wp, wbuf, present)
+        line = bloom_then_eq(ctx, addr, present, K.hash_bytes(present), 8 + key_len + 0.125,
+                             "knox::bytes_eq_kernel (8 B pointer + 32 B payload per row)", want_bytes)
+        line["workload"] = ("BASELINE configs[3], []byte leg: 2^%d rows of 32-byte addr values from 2^24 keys, one StringPool per pack, per-pack bloom "
+                            "(factor 2, XXH3-64 on the device) probe, EQ present key, count") % (n_rows.bit_length() - 1)
+        line["pool_bytes"] = int(ctx.L.knox_col_pool_bytes(addr.h))
+        addr.free()
+    line["setup_and_run_s"] = time.perf_counter() - t0
+    out["cfg4_bytes"] = line
+    note("cfg4_bytes: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
+    return out
+
+
 def launch_ranks(n):
     """`bench.py --gpus N` without a launcher around it: start N rank processes (one per GPU, RCCL over xGMI between
     them) and wait.  They are FRESH interpreters -- this parent has not touched the GPU and never does (a process
@@ -168,7 +339,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows-log2", type=int, default=30, help="rows per GPU = 2^k (default 2^30 = the 1B-row config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and every oracle-backed parity check")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip BASELINE configs[2] / configs[3] after the timed region")
     ap.add_argument("--cpu-sample-log2", type=int, default=29)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
@@ -423,15 +595,25 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/traffic.json (%s; rocprofv3 --pmc passes of this command, tools/profile_round.sh)" % tj.get("measured", "round 1")
         except Exception:
             pass
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sample = min(n_rows, 1 << args.cpu_sample_log2)
-        out["cpu_baseline"] = cpu_baseline(sample, pack_rows, a, b, res.pack_counts)
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    pack_counts_host = res.pack_counts
     col.free()
     bits.free()
     ctx.close()
+    # BASELINE configs[2] / configs[3] at the same size, each in a context of its own (the headline's memory is back with the
+    # driver by now); one extra key of the same JSON line, nothing above depends on it
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            out["configs"] = secondary_configs(K, local_rank, n_rows, pack_rows, args.steps, args.warmup, parity=not args.no_cpu_baseline)
+        except Exception as e:   # a secondary config must never cost the headline its line
+            import traceback
+            traceback.print_exc()
+            out["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = min(n_rows, 1 << args.cpu_sample_log2)
+        out["cpu_baseline"] = cpu_baseline(sample, pack_rows, a, b, pack_counts_host)
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
