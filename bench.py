@@ -141,23 +141,27 @@ def _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup, pack_skip=None):
                 ctx.scan_async(plan, bits_out=bits, pack_counts=True, pack_skip=pack_skip)
             last = ctx.scan_collect(plan, n_packs)
         return last
-    run(max(1, warmup))
+    # the first ~10 launches after the device sat idle (generation, bloom build, host-side checks) run at a lower clock
+    # (DESIGN.md 7 "clock ramp"): at least 12 untimed passes, whatever --warmup says
+    run(max(12, warmup))
     ctx.L.knox_prof_enable(ctx.h, 1)
     ctx.sync()
     t0 = time.perf_counter()
     res = run(steps)
     ctx.sync()
     dt = time.perf_counter() - t0
-    ms, k = C.c_double(), C.c_int()
-    ctx.L.knox_prof_read(ctx.h, C.byref(ms), C.byref(k))
+    each = (C.c_float * 512)()
+    k = C.c_int()
+    ctx.L.knox_prof_read_each(ctx.h, each, 512, C.byref(k))
     ctx.L.knox_prof_enable(ctx.h, 0)
-    return res, dt / steps * 1e3, ms.value / max(1, k.value), k.value
+    v = [each[i] for i in range(k.value)]
+    return res, dt / steps * 1e3, (sum(v) / len(v) if v else 0.0), len(v), (min(v) if v else 0.0, max(v) if v else 0.0)
 
 
-def _cfg_line(n_rows, bytes_per_row, step_ms, kernel_ms, launches, kernel):
+def _cfg_line(n_rows, bytes_per_row, step_ms, kernel_ms, launches, kernel, spread=None):
     gbs = n_rows * bytes_per_row / kernel_ms / 1e6 if kernel_ms > 0 else 0.0
     return {"rows": n_rows, "bytes_per_row": bytes_per_row, "algorithmic_bytes_per_launch": n_rows * bytes_per_row, "kernel": kernel,
-            "kernel_ms": kernel_ms, "launches_timed": launches, "ms_per_step": step_ms, "rows_per_s": n_rows / step_ms * 1e3,
+            "kernel_ms": kernel_ms, "kernel_ms_min_max": list(spread) if spread else None, "launches_timed": launches, "ms_per_step": step_ms, "rows_per_s": n_rows / step_ms * 1e3,
             "achieved_gb_per_s": gbs, "frac": gbs / HBM_PEAK_GBS, "whole_step_gb_per_s": n_rows * bytes_per_row / step_ms / 1e6}
 
 
@@ -190,8 +194,8 @@ def secondary_configs(K, device_index, n_rows, pack_rows, steps, warmup, parity=
         bits = ctx.bits(n_rows, for_col=A)
         tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
         plan = ctx.plan(tree, [A, B], aggs=[(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Sum, 0), (R.Count, 0)])
-        res, step_ms, kms, kn = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
-        line = _cfg_line(n_rows, 16.125, step_ms, kms, kn, "knox::scan_kernel<8,2,FSUM|MINMAX|FIRSTLAST,float> (2 leaves, truth table, min/max/mean)")
+        res, step_ms, kms, kn, spread = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
+        line = _cfg_line(n_rows, 16.125, step_ms, kms, kn, "knox::scan_kernel<8,2,FSUM|MINMAX|FIRSTLAST,float> (2 leaves, truth table, min/max/mean)", spread)
         vmin, vmax, vmean, vsum = (float(res.value(i)[0]) for i in range(4))
         line.update({"workload": "BASELINE configs[2]: 2^%d float64 rows x 2 columns, A >= 256 AND B < 0.5, min/max/mean(A) + sum + count, bitset + per-pack counts"
                                  % (n_rows.bit_length() - 1), "selected_rows": int(res.count), "min": vmin, "max": vmax, "mean": vmean, "sum": vsum,
@@ -229,11 +233,11 @@ def secondary_configs(K, device_index, n_rows, pack_rows, steps, warmup, parity=
         t_build = time.perf_counter() - tb
         maybe = bloom.probe(hash_of_key)
         plan = ctx.plan(And(Leaf(0, FilterMode.Equal, key)), [col], aggs=[(R.Count, 0)] if col.dtype != BlockType.Bytes else [])
-        full, step_ms, kms, kn = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
-        line = _cfg_line(n_rows, bytes_per_row, step_ms, kms, kn, kernel)
+        full, step_ms, kms, kn, spread = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
+        line = _cfg_line(n_rows, bytes_per_row, step_ms, kms, kn, kernel, spread)
         got = bits.bytes() if parity else None
         skip = (1 - maybe).astype(np.uint8)
-        pruned, pstep_ms, pkms, pkn = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup, pack_skip=skip)
+        pruned, pstep_ms, pkms, pkn, _ = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup, pack_skip=skip)
         scanned = int(maybe.sum())
         line.update({"selected_rows": int(full.count), "bloom_build_s": t_build, "bloom_filter_bytes": int(ctx.L.knox_bloom_bytes(bloom.h)),
                      "bitset_pair_check_at_allocation": bits.pair_check[0],

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KNOX_ABI_VERSION 4
+#define KNOX_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------------------- */
 enum knox_err {
@@ -166,6 +166,28 @@ int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, size_t n, co
  * be short).  Upload goes host -> pinned ring -> hipMemcpyAsync.                           */
 int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, size_t pack_rows,
                     knox_col **out);
+/* Ingest that overlaps the scans -- the device form of the reference's load / match interleave
+ * (internal/pack/table/reader.go:329-334 calls loadPack, :484, then filter.Match, pack by pack).  Here a RUN of packs is
+ * copied host -> HBM on the context's copy stream while the scan of the previous run is in flight on the scan stream:
+ *   knox_col_create        an empty numeric column with room for capacity_rows rows (n_rows = 0)
+ *   knox_col_append_async  enqueue the copy of n_rows more rows behind the ones present and return.  A page-locked source
+ *                          (knox_host_alloc) is read in place by the DMA engine and must stay untouched until
+ *                          knox_col_wait / knox_col_ready says so; any other source is copied through a pinned ring
+ *                          inside the call and is not referenced after return (cgo rule)
+ *   knox_col_reset         n_rows = 0, to refill the column with the next run.  The copies enqueued afterwards wait for
+ *                          every scan enqueued SO FAR (they may still read the old rows) and for nothing enqueued later:
+ *                          call it before enqueueing the scan of the other buffer
+ *   knox_col_upload_async  create + append in one call
+ *   knox_col_wait / knox_col_ready   block until / ask whether (1 / 0) the column's uploads have landed
+ * Every entry point that reads a column orders its kernels behind the column's pending upload ON THE DEVICE
+ * (hipStreamWaitEvent), so `append_async(B); scan_async(A); collect(A)` overlaps B's copy with A's scan and
+ * `append_async(A); scan_async(A)` is simply correct.  KNOX_E_RANGE: more rows than the capacity.                      */
+int knox_col_create(knox_ctx *ctx, int dtype, size_t capacity_rows, size_t pack_rows, knox_col **out);
+int knox_col_append_async(knox_ctx *ctx, knox_col *col, const void *host, size_t n_rows);
+int knox_col_reset(knox_ctx *ctx, knox_col *col);
+int knox_col_upload_async(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, size_t pack_rows, knox_col **out);
+int knox_col_wait(knox_ctx *ctx, knox_col *col);
+int knox_col_ready(const knox_col *col);
 /* Bytes column in StringPool layout (pkg/stringx/pool.go:45-58): ptr[i] = off<<32 | len.  */
 int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf,
                           size_t buf_len, size_t pack_rows, knox_col **out);

@@ -80,6 +80,12 @@ SIGNATURES = {
     "knox_prof_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
     "knox_cmp": (_i64, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "knox_col_upload": (_i, [_vp, _i, _vp, _sz, _sz, _pp]),
+    "knox_col_create": (_i, [_vp, _i, _sz, _sz, _pp]),
+    "knox_col_append_async": (_i, [_vp, _vp, _vp, _sz]),
+    "knox_col_reset": (_i, [_vp, _vp]),
+    "knox_col_upload_async": (_i, [_vp, _i, _vp, _sz, _sz, _pp]),
+    "knox_col_wait": (_i, [_vp, _vp]),
+    "knox_col_ready": (_i, [_vp]),
     "knox_col_upload_bytes": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _pp]),
     "knox_col_bytes_create": (_i, [_vp, _sz, _sz, _sz, _pp]),
     "knox_col_bytes_append_pack": (_i, [_vp, _vp, _vp, _sz, _vp, _sz]),

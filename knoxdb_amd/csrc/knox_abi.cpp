@@ -93,6 +93,7 @@ KNOX_API int knox_ctx_open_stream(int device, void *hip_stream, knox_ctx **out) 
 KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     if (!ctx) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
@@ -115,6 +116,12 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
         if (r.h_packs) hipHostFree(r.h_packs);
         if (r.done) hipEventDestroy(r.done);
     }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->cstage[i]) hipHostFree(ctx->cstage[i]);
+        if (ctx->cstage_ev[i]) hipEventDestroy(ctx->cstage_ev[i]);
+    }
+    if (ctx->fence_ev) hipEventDestroy(ctx->fence_ev);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -124,6 +131,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
 
 KNOX_API int knox_ctx_sync(knox_ctx *ctx) {
     if (!ctx) return KNOX_E_INVALID;
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KNOX_OK;
 }
@@ -461,6 +469,125 @@ KNOX_API int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t 
     return rc;
 }
 
+// ---- ingest that overlaps the scans ----------------------------------------------------------------------
+// The reference interleaves loadPack and filter.Match pack by pack (internal/pack/table/reader.go:329-334, loadPack :484).
+// Here a RUN of packs is uploaded on the context's copy stream while the scan of the previous run is in flight on the
+// scan stream; the only coupling is the column's `ready` event, which every reader waits for on the device (col_acquire).
+static int copy_stream_init(knox_ctx *ctx) {
+    if (ctx->copy_stream) return KNOX_OK;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fence_ev, hipEventDisableTiming));
+    return KNOX_OK;
+}
+
+// host -> HBM on the copy stream, enqueue only.  Page-locked sources are read in place by the DMA engine and must stay
+// valid until the column's upload has completed (knox_col_wait / knox_col_ready); pageable sources are copied into the
+// copy stream's own pinned ring here and are not referenced after return.
+static int upload_async(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return KNOX_OK;
+    if (is_pinned_host(src)) {
+        // one DMA per 256 MiB: a single multi-GiB hipMemcpyAsync is not faster and delays the first byte
+        const size_t piece = (size_t)256 << 20;
+        for (size_t off = 0; off < bytes; off += piece)
+            HIPCHK(ctx, hipMemcpyAsync((char *)dst + off, (const char *)src + off, std::min(piece, bytes - off), hipMemcpyHostToDevice, ctx->copy_stream));
+        return KNOX_OK;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->cstage[i]) {
+            const hipError_t e = hipHostMalloc(&ctx->cstage[i], knox_ctx::kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                ctx->last_hip = (int)e;
+                ctx->cstage[i] = nullptr;
+                return KNOX_E_NOMEM;
+            }
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->cstage_ev[i], hipEventDisableTiming));
+        }
+    }
+    for (size_t off = 0; off < bytes;) {
+        const int slot = ctx->cstage_slot;
+        const size_t n = std::min(bytes - off, knox_ctx::kStageBytes);
+        if (ctx->cstage_used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->cstage_ev[slot]));  // the DMA that last read this slot
+        memcpy(ctx->cstage[slot], (const char *)src + off, n);
+        HIPCHK(ctx, hipMemcpyAsync((char *)dst + off, ctx->cstage[slot], n, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->cstage_ev[slot], ctx->copy_stream));
+        ctx->cstage_used[slot] = true;
+        ctx->cstage_slot ^= 1;
+        off += n;
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_create(knox_ctx *ctx, int dtype, size_t capacity_rows, size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || dtype == KNOX_BYTES || capacity_rows == 0) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = col_new(ctx, dtype, capacity_rows, pack_rows, true, out);
+    if (rc) return rc;
+    (*out)->rows_cap = capacity_rows;
+    (*out)->n_rows = 0;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_append_async(knox_ctx *ctx, knox_col *col, const void *host, size_t n_rows) {
+    if (!ctx || !col || col->ctx != ctx || col->dtype == KNOX_BYTES || !col->owned || col->rows_cap == 0 || (n_rows && !host)) return KNOX_E_INVALID;
+    if (n_rows > col->rows_cap - col->n_rows) return KNOX_E_RANGE;
+    if (n_rows == 0) return KNOX_OK;
+    hipSetDevice(ctx->device);
+    int rc = copy_stream_init(ctx);
+    if (rc) return rc;
+    rc = upload_async(ctx, (char *)col->dev + col->n_rows * (size_t)col->width, host, n_rows * (size_t)col->width);
+    if (rc) return rc;
+    if (!col->ready_ev) HIPCHK(ctx, hipEventCreateWithFlags(&col->ready_ev, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(col->ready_ev, ctx->copy_stream));
+    col->ready_pending = true;
+    col->n_rows += n_rows;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_reset(knox_ctx *ctx, knox_col *col) {
+    if (!ctx || !col || col->ctx != ctx || col->rows_cap == 0 || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = copy_stream_init(ctx);
+    if (rc) return rc;
+    // the next upload overwrites rows that scans enqueued so far may still be reading: the copy stream waits for them (and
+    // for nothing enqueued later -- so refill a column BEFORE enqueueing the scan of the other one)
+    HIPCHK(ctx, hipEventRecord(ctx->fence_ev, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
+    col->n_rows = 0;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_upload_async(knox_ctx *ctx, int dtype, const void *host, size_t n_rows, size_t pack_rows, knox_col **out) {
+    if (!ctx || !out || !host || n_rows == 0 || dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    int rc = knox_col_create(ctx, dtype, n_rows, pack_rows, out);
+    if (rc) return rc;
+    rc = knox_col_append_async(ctx, *out, host, n_rows);
+    if (rc) {
+        knox_col_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+KNOX_API int knox_col_wait(knox_ctx *ctx, knox_col *col) {
+    if (!ctx || !col) return KNOX_E_INVALID;
+    if (col->ready_pending) {
+        HIPCHK(ctx, hipEventSynchronize(col->ready_ev));
+        col->ready_pending = false;
+    }
+    return KNOX_OK;
+}
+
+KNOX_API int knox_col_ready(const knox_col *col) {
+    if (!col) return KNOX_E_INVALID;
+    if (!col->ready_pending) return 1;
+    if (hipEventQuery(col->ready_ev) == hipSuccess) {
+        col->ready_pending = false;
+        return 1;
+    }
+    (void)hipGetLastError();
+    return 0;
+}
+
 KNOX_API int knox_col_upload_bytes(knox_ctx *ctx, const uint64_t *ptr, size_t n_rows, const uint8_t *buf, size_t buf_len,
                                    size_t pack_rows, knox_col **out) {
     if (!ctx || !out || (n_rows && !ptr) || (buf_len && !buf)) return KNOX_E_INVALID;
@@ -630,12 +757,15 @@ KNOX_API int knox_col_download(knox_ctx *ctx, const knox_col *col, size_t first_
     if (!ctx || !col || (n_rows && !host)) return KNOX_E_INVALID;
     if (first_row + n_rows > col->n_rows) return KNOX_E_RANGE;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }
     return download(ctx, host, (const char *)col->dev + first_row * (size_t)col->width, n_rows * (size_t)col->width);
 }
 
 KNOX_API int knox_col_free(knox_col *col) {
     if (!col) return KNOX_E_INVALID;
     hipSetDevice(col->ctx->device);
+    if (col->ready_pending) hipEventSynchronize(col->ready_ev);
+    if (col->ready_ev) hipEventDestroy(col->ready_ev);
     hipStreamSynchronize(col->ctx->stream);
     if (col->owned) dev_free(col->ctx, col->dev);
     dev_free(col->ctx, col->buf);
@@ -724,6 +854,7 @@ KNOX_API int knox_bits_alloc(knox_ctx *ctx, size_t size_bits, knox_bits **out) {
 
 KNOX_API int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, knox_bits **out) {
     if (!col || col->ctx != ctx) return KNOX_E_INVALID;
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }  // the verification probes read the column
     return bits_alloc(ctx, size_bits, col, out);
 }
 
@@ -956,6 +1087,7 @@ KNOX_API int knox_match_wide(knox_ctx *ctx, knox_col *const *limbs, int n_limbs,
     if (bits->size != n_rows || (mask && mask->size != n_rows)) return KNOX_E_INVALID;
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    for (int i_ = 0; i_ < n_limbs; i_++) { const int rc_ = col_acquire(ctx, limbs[i_]); if (rc_) return rc_; }
     int rc = ensure(ctx, ctx->misc, 256);
     if (rc) return rc;
     unsigned long long *d_cnt = (unsigned long long *)((char *)ctx->misc.p + 64);
@@ -997,6 +1129,7 @@ KNOX_API int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_li
     if (bits->size != n_rows || (mask && mask->size != n_rows)) return KNOX_E_INVALID;
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    for (int i_ = 0; i_ < n_limbs; i_++) { const int rc_ = col_acquire(ctx, limbs[i_]); if (rc_) return rc_; }
     // sorted unique keys in the kernel's order: unsigned lexicographic with the top limb's sign bit flipped
     const size_t L = (size_t)n_limbs;
     std::vector<size_t> idx(n_set);
@@ -1555,6 +1688,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                              int want_pack_counts) {
     if (!ctx || !nodes || n_nodes <= 0 || !cols || n_cols <= 0 || n_aggs < 0 || n_aggs > 14 || (n_aggs && !aggs)) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
+    for (int i_ = 0; i_ < n_cols; i_++) { const int rc_ = col_acquire(ctx, cols[i_]); if (rc_) return rc_; }  // behind the columns' asynchronous uploads
     if (ctx->res_head - ctx->res_tail >= (uint64_t)knox_ctx::kResRing) return KNOX_E_BUSY;  // collect first
     knox_ctx::ResSlot &slot = ctx->res[ctx->res_head % knox_ctx::kResRing];
     slot.kind = 0;
@@ -1991,6 +2125,7 @@ KNOX_API int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *ma
     if (!ctx || !col || !state || col->dtype == KNOX_BYTES) return KNOX_E_INVALID;
     if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }
     const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8));
     int rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
@@ -2007,6 +2142,7 @@ KNOX_API int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_
     if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }
     const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 4));
     int rc = ensure(ctx, ctx->mom_partials, (size_t)(grid + 1) * 4 * sizeof(double) + 64);
     if (!rc) rc = ensure(ctx, ctx->misc, 256);

@@ -93,6 +93,7 @@ KNOX_API int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint
 KNOX_API int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out) {
     if (!ctx || !col || !out || factor <= 0 || col->pack_rows == 0) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }
     const size_t n_packs = (col->n_rows + col->pack_rows - 1) / col->pack_rows;
     std::vector<uint64_t> offsets(n_packs + 1);
     uint64_t off = 0;

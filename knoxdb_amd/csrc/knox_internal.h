@@ -51,6 +51,14 @@ struct knox_ctx {
     static constexpr size_t kStageBytes = 32u << 20;
     void *stage[2] = {nullptr, nullptr};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // ingest that overlaps the scans (knox_col_append_async & co.): a second stream for the H2D copies and a pinned ring of
+    // its own for pageable sources; the scan stream waits on a column's `ready` event, never on the copy stream as a whole
+    hipStream_t copy_stream = nullptr;
+    void *cstage[2] = {nullptr, nullptr};
+    hipEvent_t cstage_ev[2] = {nullptr, nullptr};
+    bool cstage_used[2] = {false, false};
+    int cstage_slot = 0;
+    hipEvent_t fence_ev = nullptr;  // "every scan enqueued so far" for the copy stream (knox_col_reset)
     // grow-only device scratch
     DevBuf partials;     // AggPartial[(grid+1) * slots]
     DevBuf states;       // AggStateDev[slots] + int64 count
@@ -132,7 +140,27 @@ struct knox_col {
     uint64_t *h_pool_base = nullptr;
     size_t n_packs = 0;                               // packs present
     size_t packs_cap = 0, rows_cap = 0, buf_cap = 0;  // capacity of an appendable column
+    // asynchronous ingest (knox_col_create / _append_async / _upload_async): the last copy into this column as an event on the
+    // context's copy stream; every reader makes the scan stream wait for it (col_acquire) until the host has seen it complete
+    mutable hipEvent_t ready_ev = nullptr;
+    mutable bool ready_pending = false;
 };
+
+// a kernel on ctx->stream is about to read `col`: order it behind the column's last asynchronous upload
+static inline int col_acquire(knox_ctx *ctx, const knox_col *col) {
+    if (!col || !col->ready_pending) return KNOX_OK;
+    if (hipEventQuery(col->ready_ev) == hipSuccess) {
+        col->ready_pending = false;
+        return KNOX_OK;
+    }
+    (void)hipGetLastError();  // hipErrorNotReady
+    const hipError_t e = hipStreamWaitEvent(ctx->stream, col->ready_ev, 0);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_HIP;
+    }
+    return KNOX_OK;
+}
 
 struct knox_bits {
     knox_ctx *ctx;

@@ -62,6 +62,7 @@ KNOX_API int knox_match_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t
     if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }
     int rc = run_regexp(ctx, col, pattern, pattern_len, mask ? (const uint8_t *)mask->dev : nullptr, (uint8_t *)bits->dev);
     if (rc) return rc;
     if (count) return knox_bits_popcount(ctx, bits, count);

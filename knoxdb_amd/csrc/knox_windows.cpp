@@ -134,6 +134,8 @@ static int reduce_buckets_dev(knox_ctx *ctx, const knox_col *time_col, const kno
     if ((__int128)t_from + (__int128)step * (__int128)n_buckets > (__int128)INT64_MAX) return KNOX_E_RANGE;
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, time_col); if (rc_) return rc_; }
+    { const int rc_ = col_acquire(ctx, value_col); if (rc_) return rc_; }
     const size_t n_rows = value_col->n_rows;
     int rc = ensure(ctx, ctx->misc, 256);
     if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + 64);
@@ -219,6 +221,8 @@ KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_
     if ((__int128)t_from + (__int128)step * (__int128)n_buckets > (__int128)INT64_MAX) return KNOX_E_RANGE;
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, time_col); if (rc_) return rc_; }
+    { const int rc_ = col_acquire(ctx, value_col); if (rc_) return rc_; }
     const size_t n_rows = value_col->n_rows;
     const size_t off_vals = ((n_buckets + 2) * 8 + 63) & ~(size_t)63;
     const size_t off_seen = off_vals + ((n_buckets * 8 + 63) & ~(size_t)63);
@@ -257,6 +261,7 @@ KNOX_API int knox_reduce_sequential(knox_ctx *ctx, const knox_col *col, const kn
     if (mask && mask->size != col->n_rows) return KNOX_E_INVALID;
     if (func < 0 || func > 8) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }
     int rc = ensure(ctx, ctx->misc, 256);
     if (rc) return rc;
     uint64_t *d = (uint64_t *)((char *)ctx->misc.p + 192);

@@ -89,6 +89,21 @@ class Column:
         check(_lib.lib().knox_col_download(self.ctx.h, self.h, first, n, _ptr(out)))
         return out
 
+    def append_async(self, arr):
+        """enqueue the copy of `arr` behind the rows present (knox_col_append_async); see Context.upload_async for lifetimes"""
+        assert arr.flags.c_contiguous and FROM_NP[arr.dtype] == self.dtype
+        check(_lib.lib().knox_col_append_async(self.ctx.h, self.h, _ptr(arr), arr.size), "knox_col_append_async")
+
+    def reset(self):
+        check(_lib.lib().knox_col_reset(self.ctx.h, self.h), "knox_col_reset")
+
+    def wait(self):
+        check(_lib.lib().knox_col_wait(self.ctx.h, self.h), "knox_col_wait")
+
+    @property
+    def ready(self):
+        return _lib.lib().knox_col_ready(self.h) == 1
+
     def free(self):
         if self.h:
             _lib.lib().knox_col_free(self.h)
@@ -371,6 +386,22 @@ class Context:
         h = C.c_void_p()
         check(self.L.knox_col_upload(self.h, int(dtype), _ptr(arr) if arr.size else None, arr.size, pack_rows, C.byref(h)))
         return Column(self, h, dtype, pack_rows=pack_rows)
+
+    # -- ingest that overlaps the scans (include/knoxgpu.h knox_col_create ... knox_col_ready)
+    def col_create(self, dtype, capacity_rows, pack_rows=0):
+        """an empty numeric column with room for capacity_rows rows, filled by Column.append_async"""
+        h = C.c_void_p()
+        check(self.L.knox_col_create(self.h, int(dtype), capacity_rows, pack_rows, C.byref(h)), "knox_col_create")
+        return Column(self, h, dtype, pack_rows=pack_rows or capacity_rows)
+
+    def upload_async(self, arr, pack_rows=0):
+        """knox_col_upload_async: the copy runs on the context's copy stream; `arr` must stay alive (and, if page-locked,
+        untouched) until Column.wait()"""
+        assert arr.flags.c_contiguous
+        dtype = FROM_NP[arr.dtype]
+        h = C.c_void_p()
+        check(self.L.knox_col_upload_async(self.h, int(dtype), _ptr(arr), arr.size, pack_rows, C.byref(h)), "knox_col_upload_async")
+        return Column(self, h, dtype, keep=arr, pack_rows=pack_rows or arr.size)
 
     def upload_bytes(self, ptr, buf, pack_rows=0):
         ptr = np.ascontiguousarray(ptr, dtype=np.uint64)

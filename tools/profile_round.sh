@@ -5,7 +5,7 @@
 # usage: tools/profile_round.sh r02   (writes gpurun_out/prof_r02/, gpurun_out/r02_rocprof_summary.txt, gpurun_out/traffic.json:
 # copy the last two into profiles/ -- gpurun only merges gpurun_out/ back)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 bash tools/prof.sh $TAG > gpurun_out/prof_$TAG.files 2>&1
 python3 tools/prof_summary.py gpurun_out/prof_$TAG gpurun_out/traffic.json > gpurun_out/${TAG}_rocprof_summary.txt
