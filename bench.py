@@ -10,7 +10,7 @@ timed region starts.  For N > 1 each rank owns a contiguous pack range (no data-
 collective); only the 144-byte partial aggregate state crosses xGMI (RCCL all-gather) each step.
 
 Setup, outside the timed region and reported under "placement" in the JSON line: the context's
-device-memory arena gets an explicit budget (KNOX_BENCH_ARENA_GIB, default 64), the column is generated into it, the
+device-memory arena gets an explicit budget (KNOX_BENCH_ARENA_GIB, default 160: the headline maps ~13-17 GiB of it, the secondary configs the rest), the column is generated into it, the
 bitset is allocated FOR that column (a write buffer verified against it, knox_bits_alloc_for) and the pair is checked ONCE with
 the real kernel against its own read-only form (a second look after 2.5 s only when the device was evidently still
 busy with somebody else's freed memory).  The timed region contains only the K steps.
@@ -165,11 +165,13 @@ def _cfg_line(n_rows, bytes_per_row, step_ms, kernel_ms, launches, kernel, sprea
             "achieved_gb_per_s": gbs, "frac": gbs / HBM_PEAK_GBS, "whole_step_gb_per_s": n_rows * bytes_per_row / step_ms / 1e6}
 
 
-def secondary_configs(K, device_index, n_rows, pack_rows, steps, warmup, parity=True):
-    """BASELINE configs[2] and configs[3] at the same size as the headline, after its timed region (each in a fresh
-    context whose arena places its own columns): kernel time from HIP events, achieved GB/s against the 8 TB/s peak with
-    SURVEY.md 8(d)'s algorithmic bytes per row, and an in-run parity verdict (the oracle on sampled packs + whole-run
-    invariants).  Reported under "configs" in the one JSON line; the headline fields do not depend on any of this."""
+def secondary_configs(K, ctx, n_rows, pack_rows, steps, warmup, parity=True):
+    """BASELINE configs[2] and configs[3] at the same size as the headline, after its timed region and in the SAME context
+    (its arena places the new columns; nothing goes back to the driver in between -- the driver clearing freed memory
+    slows every scan on the device for seconds): kernel time from HIP events, achieved GB/s against the
+    8 TB/s peak with SURVEY.md 8(d)'s algorithmic bytes per row, and an in-run parity verdict (the oracle on sampled
+    packs + whole-run invariants).  Reported under "configs" in the one JSON line; the headline fields do not depend on
+    any of this."""
     import ctypes as C
     import numpy as np
     from knoxdb_amd import And, Leaf
@@ -187,39 +189,37 @@ def secondary_configs(K, device_index, n_rows, pack_rows, steps, warmup, parity=
 
     # ---- configs[2]: two float64 columns, `A >= 256 AND B < 0.5`, min / max / mean(A) (+ sum, count) ---------------
     t0 = time.perf_counter()
-    with K.Context(device_index) as ctx:
-        ctx.set_arena(64 << 30)
-        A = ctx.generate(BlockType.Float64, 1, 3, n_rows, pack_rows=pack_rows)   # k * 2^-10 grid: every summation order is exact
-        B = ctx.generate(BlockType.Float64, 2, 4, n_rows, pack_rows=pack_rows)   # uniform [0, 1)
-        bits = ctx.bits(n_rows, for_col=A)
-        tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
-        plan = ctx.plan(tree, [A, B], aggs=[(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Sum, 0), (R.Count, 0)])
-        res, step_ms, kms, kn, spread = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
-        line = _cfg_line(n_rows, 16.125, step_ms, kms, kn, "knox::scan_kernel<8,2,FSUM|MINMAX|FIRSTLAST,float> (2 leaves, truth table, min/max/mean)", spread)
-        vmin, vmax, vmean, vsum = (float(res.value(i)[0]) for i in range(4))
-        line.update({"workload": "BASELINE configs[2]: 2^%d float64 rows x 2 columns, A >= 256 AND B < 0.5, min/max/mean(A) + sum + count, bitset + per-pack counts"
-                                 % (n_rows.bit_length() - 1), "selected_rows": int(res.count), "min": vmin, "max": vmax, "mean": vmean, "sum": vsum,
-                     "bitset_pair_check_at_allocation": bits.pair_check[0]})
-        if parity:
-            got = bits.bytes()
-            ok_bits = ok_cnt = True
-            for p in sample:
-                xa = O.generate(O.F64, 1, 3, p * pack_rows, pack_rows)
-                xb = O.generate(O.F64, 2, 4, p * pack_rows, pack_rows)
-                wa, _ = O.cmp(O.F64, O.GE, xa, 256.0, 0.0)
-                wb, _ = O.cmp(O.F64, O.LT, xb, 0.5, 0.0)
-                want = O.bits_op("and", wa, wb, pack_rows)
-                ok_bits = ok_bits and bool((got[p * pb:(p + 1) * pb] == want).all())
-                ok_cnt = ok_cnt and int(res.pack_counts[p]) == int(O.popcount(want, pack_rows))
-            line["parity_in_run"] = {
-                "sample_packs": len(sample), "sample_bitsets_equal_oracle": ok_bits, "sample_pack_counts_equal": ok_cnt,
-                "pack_counts_sum_to_count": bool(int(res.pack_counts.sum()) == int(res.count)),
-                "bitset_popcount_equals_count": bool(bits.count() == int(res.count)),
-                # on the grid every partial sum is exact: the sum is THE sum, and the mean must be its one IEEE division
-                "mean_equals_sum_over_count": bool(res.count > 0 and vmean == vsum / int(res.count)),
-                "min_max_are_the_grid_ends": bool(vmin == 256.0 and vmax == ((1 << 20) - 1) / 1024.0) if n_rows >= (1 << 26) else None}
-        for o in (A, B, bits):
-            o.free()
+    A = ctx.generate(BlockType.Float64, 1, 3, n_rows, pack_rows=pack_rows)   # k * 2^-10 grid: every summation order is exact
+    B = ctx.generate(BlockType.Float64, 2, 4, n_rows, pack_rows=pack_rows)   # uniform [0, 1)
+    bits = ctx.bits(n_rows, for_col=[A, B])   # verified against both read streams (knox_bits_alloc_for_cols)
+    tree = And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5))
+    plan = ctx.plan(tree, [A, B], aggs=[(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Sum, 0), (R.Count, 0)])
+    res, step_ms, kms, kn, spread = _timed_steps(ctx, C, plan, bits, n_packs, steps, warmup)
+    line = _cfg_line(n_rows, 16.125, step_ms, kms, kn, "knox::scan_kernel<8,2,FSUM|MINMAX|FIRSTLAST,float> (2 leaves, truth table, min/max/mean)", spread)
+    vmin, vmax, vmean, vsum = (float(res.value(i)[0]) for i in range(4))
+    line.update({"workload": "BASELINE configs[2]: 2^%d float64 rows x 2 columns, A >= 256 AND B < 0.5, min/max/mean(A) + sum + count, bitset + per-pack counts"
+                             % (n_rows.bit_length() - 1), "selected_rows": int(res.count), "min": vmin, "max": vmax, "mean": vmean, "sum": vsum,
+                 "bitset_pair_check_at_allocation": bits.pair_check[0]})
+    if parity:
+        got = bits.bytes()
+        ok_bits = ok_cnt = True
+        for p in sample:
+            xa = O.generate(O.F64, 1, 3, p * pack_rows, pack_rows)
+            xb = O.generate(O.F64, 2, 4, p * pack_rows, pack_rows)
+            wa, _ = O.cmp(O.F64, O.GE, xa, 256.0, 0.0)
+            wb, _ = O.cmp(O.F64, O.LT, xb, 0.5, 0.0)
+            want = O.bits_op("and", wa, wb, pack_rows)
+            ok_bits = ok_bits and bool((got[p * pb:(p + 1) * pb] == want).all())
+            ok_cnt = ok_cnt and int(res.pack_counts[p]) == int(O.popcount(want, pack_rows))
+        line["parity_in_run"] = {
+            "sample_packs": len(sample), "sample_bitsets_equal_oracle": ok_bits, "sample_pack_counts_equal": ok_cnt,
+            "pack_counts_sum_to_count": bool(int(res.pack_counts.sum()) == int(res.count)),
+            "bitset_popcount_equals_count": bool(bits.count() == int(res.count)),
+            # on the grid every partial sum is exact: the sum is THE sum, and the mean must be its one IEEE division
+            "mean_equals_sum_over_count": bool(res.count > 0 and vmean == vsum / int(res.count)),
+            "min_max_are_the_grid_ends": bool(vmin == 256.0 and vmax == ((1 << 20) - 1) / 1024.0) if n_rows >= (1 << 26) else None}
+    for o in (A, B, bits):
+        o.free()
     line["setup_and_run_s"] = time.perf_counter() - t0
     out["cfg3"] = line
     note("cfg3: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
@@ -264,40 +264,36 @@ def secondary_configs(K, device_index, n_rows, pack_rows, steps, warmup, parity=
         return line
 
     t0 = time.perf_counter()
-    with K.Context(device_index) as ctx:
-        ctx.set_arena(64 << 30)
-        ids = ctx.generate(BlockType.Uint64, 0, 5, n_rows, lo=0, span=0, pack_rows=pack_rows)   # unique-in-practice 64-bit ids
-        present = int(ids.download(min(777, n_packs - 1) * pack_rows + 12345 % pack_rows, 1)[0])
+    ids = ctx.generate(BlockType.Uint64, 0, 5, n_rows, lo=0, span=0, pack_rows=pack_rows)   # unique-in-practice 64-bit ids
+    present = int(ids.download(min(777, n_packs - 1) * pack_rows + 12345 % pack_rows, 1)[0])
 
-        def want_u64(p):
-            x = O.generate(O.U64, 0, 5, p * pack_rows, pack_rows, lo=0, span=0)
-            return O.cmp(O.U64, O.EQ, x, present)
-        line = bloom_then_eq(ctx, ids, present, K.hash_value(BlockType.Uint64, np.uint64(present)), 8.125,
-                             "knox::scan_kernel<8,1,0> (uint64 EQ, count)", want_u64)
-        line["workload"] = "BASELINE configs[3], uint64 leg: 2^%d ids, per-pack bloom (factor 2) probe, EQ present key, count" % (n_rows.bit_length() - 1)
-        ids.free()
+    def want_u64(p):
+        x = O.generate(O.U64, 0, 5, p * pack_rows, pack_rows, lo=0, span=0)
+        return O.cmp(O.U64, O.EQ, x, present)
+    line = bloom_then_eq(ctx, ids, present, K.hash_value(BlockType.Uint64, np.uint64(present)), 8.125,
+                         "knox::scan_kernel<8,1,0> (uint64 EQ, count)", want_u64)
+    line["workload"] = "BASELINE configs[3], uint64 leg: 2^%d ids, per-pack bloom (factor 2) probe, EQ present key, count" % (n_rows.bit_length() - 1)
+    ids.free()
     line["setup_and_run_s"] = time.perf_counter() - t0
     out["cfg4_u64"] = line
     note("cfg4_u64: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
 
     t0 = time.perf_counter()
-    with K.Context(device_index) as ctx:
-        ctx.set_arena(128 << 30)
-        key_len, wbits, ppw = 32, 16, 4
-        addr = ctx.generate_bytes(6, n_rows, pack_rows, key_len, wbits, ppw)   # 2^24 keys, every key inside one window of 4 packs
-        ptr, buf = ctx.download_bytes_pack(addr, min(777, n_packs - 1))
-        r = 12345 % pack_rows
-        present = bytes(buf[r * key_len:(r + 1) * key_len])
+    key_len, wbits, ppw = 32, 16, 4
+    addr = ctx.generate_bytes(6, n_rows, pack_rows, key_len, wbits, ppw)   # 2^24 keys, every key inside one window of 4 packs
+    ptr, buf = ctx.download_bytes_pack(addr, min(777, n_packs - 1))
+    r = 12345 % pack_rows
+    present = bytes(buf[r * key_len:(r + 1) * key_len])
 
-        def want_bytes(p):
-            wp, wbuf, _ = O.generate_bytes_pack(6, p, pack_rows, pack_rows, key_len, wbits, ppw)
-            return O.bytes_match(O.EQ, wp, wbuf, present)
-        line = bloom_then_eq(ctx, addr, present, K.hash_bytes(present), 8 + key_len + 0.125,
-                             "knox::bytes_eq_kernel (8 B pointer + 32 B payload per row)", want_bytes)
-        line["workload"] = ("BASELINE configs[3], []byte leg: 2^%d rows of 32-byte addr values from 2^24 keys, one StringPool per pack, per-pack bloom "
-                            "(factor 2, XXH3-64 on the device) probe, EQ present key, count") % (n_rows.bit_length() - 1)
-        line["pool_bytes"] = int(ctx.L.knox_col_pool_bytes(addr.h))
-        addr.free()
+    def want_bytes(p):
+        wp, wbuf, _ = O.generate_bytes_pack(6, p, pack_rows, pack_rows, key_len, wbits, ppw)
+        return O.bytes_match(O.EQ, wp, wbuf, present)
+    line = bloom_then_eq(ctx, addr, present, K.hash_bytes(present), 8 + key_len + 0.125,
+                         "knox::bytes_eq_kernel (8 B pointer + 32 B payload per row)", want_bytes)
+    line["workload"] = ("BASELINE configs[3], []byte leg: 2^%d rows of 32-byte addr values from 2^24 keys, one StringPool per pack, per-pack bloom "
+                        "(factor 2, XXH3-64 on the device) probe, EQ present key, count") % (n_rows.bit_length() - 1)
+    line["pool_bytes"] = int(ctx.L.knox_col_pool_bytes(addr.h))
+    addr.free()
     line["setup_and_run_s"] = time.perf_counter() - t0
     out["cfg4_bytes"] = line
     note("cfg4_bytes: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
@@ -347,6 +343,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip BASELINE configs[2] / configs[3] after the timed region")
     ap.add_argument("--cpu-sample-log2", type=int, default=29)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--collective", choices=["abi", "torch"], default=None,
+                    help="who runs the per-step exchange at N > 1: the library's own RCCL calls (knox_comm_*, what a Go host uses; default "
+                         "for the nccl backend) or torch.distributed (default for the gloo rehearsal)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -380,6 +379,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         print("[rank %d] process group up: backend %s, %d rank(s)" % (rank, backend, dist.get_world_size()), file=sys.stderr, flush=True)
+        collective = args.collective or ("abi" if backend == "nccl" else "torch")
+        if collective == "abi":
+            # the library's own communicator: rank 0 makes the ncclUniqueId, the process group only carries its 128 bytes
+            from knoxdb_amd import dist as kdist0
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = kdist0.comm_unique_id()
+                except RuntimeError as e:
+                    if backend == "nccl":
+                        raise
+                    box[0] = bytes(128)   # gloo rehearsal on a box without a GPU: the exchange itself is what is rehearsed
+                    print("[rank 0] abi collective: %s -- rehearsal id" % e, file=sys.stderr, flush=True)
+            dist.broadcast_object_list(box, src=0)
+            comm_id = box[0]
+            print("[rank %d] abi collective: unique id exchanged (%d bytes)" % (rank, len(comm_id)), file=sys.stderr, flush=True)
         if args.gpus > 1 and dist.get_world_size() != args.gpus:
             print("[rank %d] note: --gpus %d but the launcher started %d rank(s)" % (rank, args.gpus, dist.get_world_size()), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -409,7 +424,7 @@ def main():
     row_base = first_pack * pack_rows
     import ctypes as C
 
-    arena_gib = float(os.environ.get("KNOX_BENCH_ARENA_GIB", "64"))
+    arena_gib = float(os.environ.get("KNOX_BENCH_ARENA_GIB", "160"))   # headline 8 GiB; configs[2] 16 GiB; configs[3] 8 + 42 GiB + 2 x 2 GiB of filters
     ctx.set_arena(int(arena_gib * 2**30))   # explicit budget of the context's device-memory arena (include/knoxgpu.h)
 
     def kernel_ms(p, out_bits, reps):
@@ -450,8 +465,16 @@ def main():
     # (backend nccl = ncclAllReduce over xGMI); the all-gather of the full 144-byte states (what min / max / first /
     # last / float sums need) runs in the warmup and must give the same answer
     tdev = torch.device("cuda", local_rank) if backend == "nccl" else None
-    gather = kdist.StateGather(2, tdev) if dist is not None else None
-    reduce_sc = kdist.SumCountReduce(tdev) if dist is not None else None
+    gather = reduce_sc = None
+    ranks_in_comm = None
+    if dist is not None and collective == "abi":
+        # knox_comm_init = ncclCommInitRank on this rank's device; every step's exchange is then
+        # knox_comm_allreduce_sum_count_start / _finish (ONE ncclAllReduce(int64 x 3) on the context's collective stream)
+        ranks_in_comm = kdist.comm_init(ctx, dist.get_world_size(), rank, comm_id)
+        gather, reduce_sc = kdist.AbiStateGather(ctx, 2), kdist.AbiSumCountReduce(ctx)
+        print("[rank %d] abi collective: communicator up, ncclCommCount = %d" % (rank, ranks_in_comm), file=sys.stderr, flush=True)
+    elif dist is not None:
+        gather, reduce_sc = kdist.StateGather(2, tdev), kdist.SumCountReduce(tdev)
 
     def enqueue():
         ctx.scan_async(plan, bits_out=bits, pack_counts=True, row_base=row_base)
@@ -537,6 +560,11 @@ def main():
     assert ro_res.count == res.count
 
     scan_ms = kms.value / max(1, kn.value)
+    scan_ms_ranks = [scan_ms, scan_ms]
+    if dist is not None:
+        t = torch.tensor([scan_ms, -scan_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        scan_ms_ranks = [-float(t[1].item()), float(t[0].item())]   # [fastest rank, slowest rank]
     achieved = n_rows * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     total_rows = n_rows * world * args.steps
     value = total_rows / elapsed
@@ -572,11 +600,15 @@ def main():
                                "+ sum + count, bitset + per-pack counts emitted" % (1 if world == 1 else 4, "%d GPU" % world, args.rows_log2),
                    "rows_per_gpu": n_rows, "pack_rows": pack_rows, "parallelism": "pack-sharded x%d" % world,
                    "ranks_in_process_group": dist.get_world_size() if dist is not None else 1,
-                   "collective": ("all_reduce(int64 x3, sum) over %s every step; all_gather of the states agrees: %s" % (backend, collectives_agree)) if dist is not None else None,
+                   "ranks_in_rccl_communicator": ranks_in_comm,   # ncclCommCount of the library's own communicator (--collective abi)
+                   "collective": ("%s every step; all-gather of the states + knox_agg_combine agrees: %s" %
+                                  ("knox_comm_allreduce_sum_count_start/_finish = ncclAllReduce(int64 x3, sum) on the library's communicator" if collective == "abi"
+                                   else "torch.distributed all_reduce(int64 x3, sum) over %s" % backend, collectives_agree)) if dist is not None else None,
                    "selected_rows": int(total), "sum_mod_2^64": sum_val},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": scan_ms,
+                     "kernel_ms_min_max_over_ranks": scan_ms_ranks,
                      "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW,
                      "read_only_ceiling_gb_per_s": read_only_gbs,
                      "frac_of_read_only_ceiling": achieved / read_only_gbs if read_only_gbs > 0 else None},
@@ -600,19 +632,20 @@ def main():
         except Exception:
             pass
     pack_counts_host = res.pack_counts
-    col.free()
+    col.free()      # back to the arena's free lists, not to the driver
     bits.free()
-    ctx.close()
-    # BASELINE configs[2] / configs[3] at the same size, each in a context of its own (the headline's memory is back with the
-    # driver by now); one extra key of the same JSON line, nothing above depends on it
+    # BASELINE configs[2] / configs[3] at the same size, in the same context; one extra key of the same JSON line, nothing
+    # above depends on it
     if rank == 0 and world == 1 and not args.no_configs:
         try:
-            out["configs"] = secondary_configs(K, local_rank, n_rows, pack_rows, args.steps, args.warmup, parity=not args.no_cpu_baseline)
+            out["configs"] = secondary_configs(K, ctx, n_rows, pack_rows, args.steps, args.warmup, parity=not args.no_cpu_baseline)
         except Exception as e:   # a secondary config must never cost the headline its line
             import traceback
             traceback.print_exc()
             out["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    ctx.close()
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 only, after the timed region and its closing barrier (the other ranks are done and wait in destroy)
         sample = min(n_rows, 1 << args.cpu_sample_log2)
         out["cpu_baseline"] = cpu_baseline(sample, pack_rows, a, b, pack_counts_host)
     if rank == 0:

@@ -271,7 +271,10 @@ int knox_bits_wrap(knox_ctx *ctx, void *device_ptr, size_t size_bits, knox_bits 
 /* As knox_bits_alloc, but for scans over `col`: for columns of >= 1 GiB the buffer is a physical allocation of its own,
  * chosen among candidates by scanning samples of `col` into it (knox_bits_pair_check reports the measurement); works
  * for borrowed columns (knox_col_wrap) too.  Plain knox_bits_alloc takes ordinary arena memory, unverified.       */
-int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, knox_bits **out); /* zeroed           */
+int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col *col, knox_bits **out);
+/* The same for a scan whose tree reads SEVERAL columns (<= 4: the leaves of one fused pass): the buffer is verified against
+ * samples of every one of them and taken from a placement class none of them lies in when there is one.             */
+int knox_bits_alloc_for_cols(knox_ctx *ctx, size_t size_bits, const knox_col *const *cols, int n_cols, knox_bits **out); /* zeroed           */
 int knox_bits_free(knox_bits *b);
 size_t knox_bits_size(const knox_bits *b);
 void *knox_bits_device_ptr(const knox_bits *b);
@@ -584,6 +587,14 @@ int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *mine, int n_
  * the result is exactly the sum mod 2^64 for any reduction order -- bit-identical to the all-gather + combine above.
  * min / max / first / last and float sums need rank order and take knox_comm_allgather_states.                   */
 int knox_comm_allreduce_sum_count(knox_ctx *ctx, uint64_t *isum_inout, int64_t *count_inout);
+/* The same exchange, enqueue only: _start puts {sum mod 2^64, count} on the context's collective stream (page-locked
+ * slot -> ncclAllReduce -> page-locked slot) and returns; _finish blocks for the OLDEST exchange in flight (FIFO, up to
+ * 4; a 5th _start returns KNOX_E_BUSY).  The exchange waits for nothing on the scan stream, so a host keeps step i's
+ * collective in flight behind step i + 1's scan.  The blocking call above is _start + _finish on an empty FIFO.       */
+int knox_comm_allreduce_sum_count_start(knox_ctx *ctx, uint64_t isum, int64_t count);
+int knox_comm_allreduce_sum_count_finish(knox_ctx *ctx, uint64_t *isum_out, int64_t *count_out);
+/* The communicator's own size (ncclCommCount) and this context's rank.                                                 */
+int knox_comm_ranks(knox_ctx *ctx, int *n_ranks, int *rank);
 int knox_comm_destroy(knox_ctx *ctx);
 
 #ifdef __cplusplus

@@ -109,6 +109,7 @@ SIGNATURES = {
     "knox_col_dtype": (_i, [_vp]),
     "knox_col_device_ptr": (_vp, [_vp]),
     "knox_bits_alloc": (_i, [_vp, _sz, _pp]),
+    "knox_bits_alloc_for_cols": (_i, [_vp, _sz, _vp, _i, _pp]),
     "knox_bits_free": (_i, [_vp]),
     "knox_bits_size": (_sz, [_vp]),
     "knox_bits_device_ptr": (_vp, [_vp]),
@@ -177,6 +178,9 @@ SIGNATURES = {
     "knox_comm_init": (_i, [_vp, _i, _i, _vp]),
     "knox_comm_allgather_states": (_i, [_vp, C.POINTER(AggState), _i, C.POINTER(AggState), C.POINTER(_i64)]),
     "knox_comm_allreduce_sum_count": (_i, [_vp, C.POINTER(_u64), C.POINTER(_i64)]),
+    "knox_comm_allreduce_sum_count_start": (_i, [_vp, _u64, _i64]),
+    "knox_comm_allreduce_sum_count_finish": (_i, [_vp, C.POINTER(_u64), C.POINTER(_i64)]),
+    "knox_comm_ranks": (_i, [_vp, _pi, _pi]),
     "knox_comm_destroy": (_i, [_vp]),
 }
 

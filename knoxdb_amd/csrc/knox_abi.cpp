@@ -815,7 +815,10 @@ int ensure_for(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col) {
     return KNOX_OK;
 }
 
-int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, knox_bits **out) {
+static int bits_alloc_cols(knox_ctx *ctx, size_t size_bits, const knox_col *const *for_cols, int n_cols, knox_bits **out);
+int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, knox_bits **out) { return bits_alloc_cols(ctx, size_bits, &for_col, for_col ? 1 : 0, out); }
+
+static int bits_alloc_cols(knox_ctx *ctx, size_t size_bits, const knox_col *const *for_cols, int n_cols, knox_bits **out) {
     if (!ctx || !out) return KNOX_E_INVALID;
     *out = nullptr;
     hipSetDevice(ctx->device);
@@ -825,13 +828,19 @@ int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, knox_bi
     b->size = size_bits;
     b->cap_bytes = bits_padded(size_bits) + 64;
     hipError_t e = hipErrorNotSupported;
-    if (for_col && ctx->placement && for_col->n_rows) {
-        // a write buffer of its own, verified against the column itself (knox_arena.h)
+    if (n_cols > 0 && ctx->placement) {
+        // a write buffer of its own, verified against the column(s) themselves (knox_arena.h)
         (void)hipStreamSynchronize(ctx->stream);
-        const void *cp;
-        size_t cb;
-        col_stream(for_col, &cp, &cb);
-        e = ctx->arena.alloc_write_for((void **)&b->dev, b->cap_bytes, cp, cb, (double)cb / (double)for_col->n_rows, &b->pair_ratio, &b->pair_tried);
+        Arena::ColRef refs[kMaxLeaves];
+        int n = 0;
+        for (int i = 0; i < n_cols && n < kMaxLeaves; i++) {
+            if (!for_cols[i] || !for_cols[i]->n_rows) continue;
+            const void *cp;
+            size_t cb;
+            col_stream(for_cols[i], &cp, &cb);
+            refs[n++] = Arena::ColRef{cp, cb, (double)cb / (double)for_cols[i]->n_rows};
+        }
+        if (n) e = ctx->arena.alloc_write_for((void **)&b->dev, b->cap_bytes, refs, n, &b->pair_ratio, &b->pair_tried);
     }
     if (e == hipErrorNotSupported) e = dev_malloc(ctx, (void **)&b->dev, b->cap_bytes, ARENA_WRITE);
     if (e != hipSuccess) {
@@ -856,6 +865,16 @@ KNOX_API int knox_bits_alloc_for(knox_ctx *ctx, size_t size_bits, const knox_col
     if (!col || col->ctx != ctx) return KNOX_E_INVALID;
     { const int rc_ = col_acquire(ctx, col); if (rc_) return rc_; }  // the verification probes read the column
     return bits_alloc(ctx, size_bits, col, out);
+}
+
+KNOX_API int knox_bits_alloc_for_cols(knox_ctx *ctx, size_t size_bits, const knox_col *const *cols, int n_cols, knox_bits **out) {
+    if (!cols || n_cols <= 0 || n_cols > kMaxLeaves) return KNOX_E_INVALID;
+    for (int i = 0; i < n_cols; i++) {
+        if (!cols[i] || cols[i]->ctx != ctx) return KNOX_E_INVALID;
+        const int rc_ = col_acquire(ctx, cols[i]);
+        if (rc_) return rc_;
+    }
+    return bits_alloc_cols(ctx, size_bits, cols, n_cols, out);
 }
 
 KNOX_API int knox_bits_pair_check(const knox_bits *b, double *scan_over_read_only, int *candidates) {

@@ -131,34 +131,57 @@ class Arena {
         return heap_alloc(out, bytes);
     }
 
-    // A write buffer FOR a column: a physical allocation of its own, verified against the column (see the header comment).
-    // *ratio_out: scan / read-only of the worst sample with the buffer that was taken (0 = not measured); *tried_out:
-    // candidates looked at.  bytes_per_row: column bytes per bit of the buffer.
+    // A write buffer FOR a column (or for the columns of one multi-leaf scan): a physical allocation of its own, verified
+    // against every one of them (see the header comment).  *ratio_out: scan / read-only of the worst sample with the buffer
+    // that was taken (0 = not measured); *tried_out: candidates looked at.  bytes_per_row: column bytes per bit of the buffer.
+    struct ColRef {
+        const void *p;
+        size_t bytes;
+        double bytes_per_row;
+    };
     hipError_t alloc_write_for(void **out, size_t bytes, const void *col, size_t col_bytes, double bytes_per_row, double *ratio_out,
                                int *tried_out) {
+        const ColRef c{col, col_bytes, bytes_per_row};
+        return alloc_write_for(out, bytes, &c, 1, ratio_out, tried_out);
+    }
+    hipError_t alloc_write_for(void **out, size_t bytes, const ColRef *cols, int n_cols, double *ratio_out, int *tried_out) {
         *out = nullptr;
         if (ratio_out) *ratio_out = 0.0;
         if (tried_out) *tried_out = 0;
         bytes = round_up(bytes);
         if (!init_once()) return hipErrorNotSupported;
         const size_t sample = kProbeRows * 8, wrote = kProbeRows / 8;
-        if (!probe || !col || col_bytes < sample || bytes < std::max(kSmallWrite, wrote + 64) || bytes_per_row <= 0.0) return alloc(out, bytes, ARENA_WRITE);
-        const size_t wb_bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         constexpr int kMaxSamples = 16;  // every GiB of a column up to 16 GiB (a small write buffer can be made of fragments of several classes)
-        const int n_s = (int)std::min<size_t>(kMaxSamples, col_bytes / sample);
-        size_t offs[kMaxSamples] = {0}, boffs[kMaxSamples] = {0};
-        for (int i = 0; i < n_s; i++) {
-            offs[i] = n_s > 1 ? (((col_bytes - sample) / (size_t)(n_s - 1) * (size_t)i) & ~(size_t)0xffff) : 0;
-            boffs[i] = ((size_t)((double)offs[i] / bytes_per_row) >> 3) & ~(size_t)255;
-            if (boffs[i] + wrote + 64 > bytes) boffs[i] = (bytes - wrote - 64) & ~(size_t)255;
+        struct Sample { const char *col; size_t boff; };
+        Sample samples[kMaxSamples];
+        int n_s = 0;
+        bool in_zone[kMaxClasses] = {false, false, false, false};
+        bool any_zone = false;
+        if (probe && bytes >= std::max(kSmallWrite, wrote + 64)) {
+            int usable_cols = 0;
+            for (int c = 0; c < n_cols; c++) usable_cols += cols[c].p && cols[c].bytes >= sample && cols[c].bytes_per_row > 0.0;
+            for (int c = 0; c < n_cols && usable_cols; c++) {
+                if (!cols[c].p || cols[c].bytes < sample || cols[c].bytes_per_row <= 0.0) continue;
+                const int want = (int)std::min<size_t>((size_t)std::max(2, kMaxSamples / usable_cols), cols[c].bytes / sample);
+                for (int i = 0; i < want && n_s < kMaxSamples; i++) {
+                    const size_t off = want > 1 ? (((cols[c].bytes - sample) / (size_t)(want - 1) * (size_t)i) & ~(size_t)0xffff) : 0;
+                    size_t boff = ((size_t)((double)off / cols[c].bytes_per_row) >> 3) & ~(size_t)255;
+                    if (boff + wrote + 64 > bytes) boff = (bytes - wrote - 64) & ~(size_t)255;
+                    samples[n_s++] = Sample{(const char *)cols[c].p + off, boff};
+                }
+                const int z = zone_of(cols[c].p);
+                if (z >= 0) { in_zone[z] = true; any_zone = true; }
+            }
         }
+        if (n_s == 0) return alloc(out, bytes, ARENA_WRITE);
+        const size_t wb_bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         auto measure = [&](char *va) {
             double worst = 2.0;
             for (int i = 0; i < n_s; i++) {
-                const double r = probe(user, (const char *)col + offs[i], kProbeRows, va + boffs[i]);
+                const double r = probe(user, samples[i].col, kProbeRows, va + samples[i].boff);
                 probes_run++;
                 if (r <= 0.0) return -1.0;
-                if (r < kFastAbove) dbg("  sample %d of %d (column GiB %zu): %.3f", i, n_s, offs[i] >> 30, r);
+                if (r < kFastAbove) dbg("  sample %d of %d: %.3f", i, n_s, r);
                 worst = std::min(worst, r);
                 if (worst < kFastAbove - 0.03) break;  // out already
             }
@@ -178,19 +201,18 @@ class Arena {
         };
         // 0. memory of a KNOWN other class, if some has been met: column chunks are labelled by class (grow_zone), so a range
         //    at the top of another class's zone is fast with this column by construction -- verified like every candidate
-        const int zc = zone_of(col);
         bool zone_failed[kMaxClasses] = {false, false, false, false};
         auto try_zones = [&]() {
             // every other class with room is measured: class pairs differ (0.97 against 1.00 of the read-only rate), the
             // best one is taken; the first at >= 0.99 ends the search
             char *zbest = nullptr;
             double zbest_r = -1.0;
-            for (int zi = 0; zi < kMaxClasses && zc >= 0; zi++) {
-                if (zi == zc || zone_failed[zi]) continue;
+            for (int zi = 0; zi < kMaxClasses && any_zone; zi++) {
+                if (in_zone[zi] || zone_failed[zi]) continue;
                 char *va = nullptr;
                 if (!zone_take_top(zi, wb_bytes, &va)) continue;
                 const double r = measure(va);
-                dbg("write buffer (%zu MiB) at the top of zone %d vs the column in zone %d: %.3f", wb_bytes >> 20, zi, zc, r);
+                dbg("write buffer (%zu MiB) at the top of zone %d vs the column(s): %.3f", wb_bytes >> 20, zi, r);
                 if (r < kFastAbove) zone_failed[zi] = true;  // its label says "another class" and the pair is slow all the same: leave that zone alone
                 if (r > zbest_r) {
                     if (zbest) (void)release(zbest);
@@ -251,7 +273,7 @@ class Arena {
         if (hit) return hipSuccess;
         // 3. no other class met yet (or its zone is full): take a few more chunks -- they stay as column space of their
         //    class -- and look again
-        for (int grown = 0; zc >= 0 && grown < kMaxGrowForWrite && grown_for_write < 2 * kMaxGrowForWrite; grown++) {
+        for (int grown = 0; any_zone && grown < kMaxGrowForWrite && grown_for_write < 2 * kMaxGrowForWrite; grown++) {
             if (grow_zone() < 0) break;
             grown_for_write++;  // over the arena's life: a device whose free memory is one long run of one class is not mapped chunk by chunk in vain
             if (try_zones()) return hipSuccess;

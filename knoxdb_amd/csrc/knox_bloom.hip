@@ -136,6 +136,292 @@ __global__ void __launch_bounds__(kBlock) bloom_build_bytes_kernel(BytesView v, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Partitioned build (the product path for packs of >= 4096 rows and filters of <= 2 MiB): no global atomics per row.
+// The atomic kernels above are bound by device-scope atomicOr into a 2 MiB filter (4 per row: 2^30 rows 0.16 s =
+// 54 GB/s of column data).  Here every probe location is binned by FILTER SEGMENT (2^16 bits = 8 KiB), each segment's
+// bits are OR-ed into an LDS bitmap and stored once, coalesced.  Per batch of packs:
+//   bloom_count_kernel  one workgroup per tile of 4096 rows: hash every row, LDS histogram of the 4 locations
+//                       (h0 + i*h1) & mask by segment (loc >> 16), added to the pack's 256 segment counts (<= 256 global
+//                       atomics per tile).  8 B read per row
+//   bloom_scan_kernel   one wave per pack: exclusive prefix of the 256 counts = where each segment's entries start
+//   bloom_bin_kernel    the same tiles again: counting sort of the tile's 16384 locations by segment in LDS, one range
+//                       reserved per (tile, segment) behind the pack's segment cursor, 16-bit in-segment offsets written as
+//                       contiguous runs.  8 B read + 8 B written per row; the entries of one segment end up contiguous,
+//                       whatever the data looks like (exact counts: a column of one repeated value works like any other)
+//   bloom_fill_kernel   one workgroup per (pack, 8 consecutive segments = 64 KiB of filter): stream each segment's entries,
+//                       ds_or them into the LDS bitmap, write the 64 KiB out (the bit array starts at byte offset 1 of the
+//                       filter: aligned dwords via v_alignbyte, head / tail bytes one by one).  8 B read + 2 B written per row
+// Same bytes as the reference's addUnroll4 (bloom.go:162-169): OR is order independent.  tests/test_gpu_misc.py and
+// tests/test_gpu_fullsize.py compare the filters byte for byte with the oracle's.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBinTileRows = 4096;                     // rows per tile: 16 per thread
+constexpr int kBinRowsPerThread = kBinTileRows / kBlock;
+constexpr int kBinSlots = kBinTileRows * 4;            // locations per tile
+constexpr int kSegShift = 16;                          // 2^16 bits per segment: in-segment offsets fit 16 bits
+constexpr int kFillSegs = 8;                           // segments per fill workgroup (64 KiB of LDS)
+
+struct HashNumeric {
+    const void *col;
+    template <int W> __device__ __forceinline__ uint64_t at(uint64_t row, uint64_t) const { return xxh3_value<W>((uint64_t)load_elem<W>(col, row)); }
+};
+struct HashBytes {
+    const uint64_t *ptr;
+    const uint8_t *buf;
+    const uint64_t *pool_base;
+    template <int W> __device__ __forceinline__ uint64_t at(uint64_t row, uint64_t pack) const {
+        const uint8_t *pool = pool_base ? buf + pool_base[pack] : buf;
+        const uint64_t pr = ptr[row];
+        return knox_xxh3::hash(pool + (uint32_t)(pr >> 32), (uint64_t)(uint32_t)pr);
+    }
+};
+
+// the tile's row hashes into registers; -> bit i set = row i of this thread exists
+template <int W, typename H>
+__device__ __forceinline__ uint32_t bloom_tile_hashes(const H &hasher, uint64_t p, uint64_t pack_rows, uint64_t n_rows, uint32_t tile,
+                                                      uint64_t (&h)[kBinRowsPerThread]) {
+    uint64_t r1 = (p + 1) * pack_rows;
+    if (r1 > n_rows) r1 = n_rows;
+    const uint64_t r0 = p * pack_rows + (uint64_t)tile * kBinTileRows;
+    uint32_t valid = 0;
+#pragma unroll
+    for (int i = 0; i < kBinRowsPerThread; i++) {
+        const uint64_t r = r0 + (uint64_t)i * kBlock + threadIdx.x;
+        h[i] = 0;
+        if (r < r1) {
+            h[i] = hasher.template at<W>(r, p);
+            valid |= 1u << i;
+        }
+    }
+    return valid;
+}
+
+template <int W, typename H>
+__global__ void __launch_bounds__(kBlock) bloom_count_kernel(H hasher, uint64_t n_rows, uint64_t pack_rows, uint64_t p0, uint32_t tiles_pp,
+                                                             const uint64_t *offsets, uint32_t *seg_counts) {
+    __shared__ uint32_t hist[256];
+    const uint32_t tile = blockIdx.x % tiles_pp;
+    const uint64_t pl = blockIdx.x / tiles_pp, p = p0 + pl;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    const uint32_t mask = (uint32_t)((o1 - o0 - 1) * 8 - 1);
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t h[kBinRowsPerThread];
+    const uint32_t valid = bloom_tile_hashes<W>(hasher, p, pack_rows, n_rows, tile, h);
+#pragma unroll
+    for (int i = 0; i < kBinRowsPerThread; i++) {
+        if (valid & (1u << i)) {
+            uint32_t h0 = (uint32_t)h[i];
+            const uint32_t h1 = (uint32_t)(h[i] >> 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&hist[(h0 & mask) >> kSegShift], 1u);
+                h0 += h1;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t c = hist[threadIdx.x];
+    if (c) atomicAdd(&seg_counts[pl * 256 + threadIdx.x], c);
+}
+
+// one wave per pack: seg_base[pl][0..256] = exclusive prefix of the counts; the counts become the bin kernel's cursors (= the bases)
+__global__ void __launch_bounds__(kBlock) bloom_scan_kernel(uint64_t np, uint32_t *seg_counts, uint32_t *seg_base) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t pl = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (pl >= np) return;
+    uint32_t carry = 0;
+    for (int b = 0; b < 4; b++) {
+        const uint32_t c = seg_counts[pl * 256 + b * 64 + lane];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t excl = carry + incl - c;
+        seg_base[pl * 257 + b * 64 + lane] = excl;
+        seg_counts[pl * 256 + b * 64 + lane] = excl;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) seg_base[pl * 257 + 256] = carry;
+}
+
+template <int W, typename H>
+__global__ void __launch_bounds__(kBlock) bloom_bin_kernel(H hasher, uint64_t n_rows, uint64_t pack_rows, uint64_t p0, uint32_t tiles_pp,
+                                                           const uint64_t *offsets, uint32_t *seg_cursor, uint16_t *entries, uint64_t entries_pp) {
+    __shared__ uint32_t hist[256];    // counts, then the bin's LDS cursor
+    __shared__ uint32_t lstart[256];  // the bin's start inside the tile's sorted run
+    __shared__ uint32_t gpos[256];    // where the tile's run of this bin goes inside the pack's entries
+    __shared__ uint32_t wsum[kBlock / 64];
+    __shared__ uint16_t sorted[kBinSlots];
+    __shared__ uint8_t segof[kBinSlots];
+    const uint32_t tile = blockIdx.x % tiles_pp;
+    const uint64_t pl = blockIdx.x / tiles_pp, p = p0 + pl;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    const uint32_t mask = (uint32_t)((o1 - o0 - 1) * 8 - 1);
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t h[kBinRowsPerThread];
+    const uint32_t valid = bloom_tile_hashes<W>(hasher, p, pack_rows, n_rows, tile, h);
+#pragma unroll
+    for (int i = 0; i < kBinRowsPerThread; i++) {
+        if (valid & (1u << i)) {
+            uint32_t h0 = (uint32_t)h[i];
+            const uint32_t h1 = (uint32_t)(h[i] >> 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&hist[(h0 & mask) >> kSegShift], 1u);
+                h0 += h1;
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 256 bins (thread t owns bin t) + the bin's range behind the pack's cursor
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = hist[threadIdx.x];
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    const uint32_t excl = base + incl - c;
+    lstart[threadIdx.x] = excl;
+    gpos[threadIdx.x] = c ? atomicAdd(&seg_cursor[pl * 256 + threadIdx.x], c) : 0u;
+    __syncthreads();
+    hist[threadIdx.x] = excl;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBinRowsPerThread; i++) {
+        if (valid & (1u << i)) {
+            uint32_t h0 = (uint32_t)h[i];
+            const uint32_t h1 = (uint32_t)(h[i] >> 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t loc = h0 & mask;
+                const uint32_t pos = atomicAdd(&hist[loc >> kSegShift], 1u);
+                sorted[pos] = (uint16_t)loc;
+                segof[pos] = (uint8_t)(loc >> kSegShift);
+                h0 += h1;
+            }
+        }
+    }
+    __syncthreads();
+    // consecutive lanes write consecutive entries of a bin's run: a few destination runs per wave store
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint16_t *dst = entries + pl * entries_pp;
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const uint32_t sg = segof[i];
+        dst[gpos[sg] + (i - lstart[sg])] = sorted[i];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bloom_fill_kernel(uint64_t p0, uint32_t groups_pp, uint8_t *filters, const uint64_t *offsets,
+                                                            const uint16_t *entries, uint64_t entries_pp, const uint32_t *seg_base) {
+    __shared__ uint32_t bm[kFillSegs * 2048 + 4];
+    const uint32_t g = blockIdx.x % groups_pp;
+    const uint64_t pl = blockIdx.x / groups_pp, p = p0 + pl;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    const uint64_t fbytes = o1 - o0 - 1;                      // m / 8
+    const uint32_t n_seg = (uint32_t)((fbytes * 8 + (1u << kSegShift) - 1) >> kSegShift);
+    const uint32_t seg0 = g * kFillSegs;
+    if (seg0 >= n_seg) return;
+    if (g == 0 && threadIdx.x == 0) filters[o0] = 4;          // k (bloom.go:48-60)
+    for (int i = threadIdx.x; i < kFillSegs * 2048 + 4; i += kBlock) bm[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint16_t *pe = entries + pl * entries_pp;
+    const uint32_t *pb = seg_base + pl * 257;
+    for (uint32_t sl = wave; sl < kFillSegs && seg0 + sl < n_seg; sl += kBlock / 64) {
+        uint32_t *seg_bm = bm + sl * 2048;
+        const uint32_t e0 = pb[seg0 + sl], e1 = pb[seg0 + sl + 1];
+        uint32_t i = e0 + lane;
+        for (; i + 7 * 64 < e1; i += 8 * 64) {               // 8 independent loads in flight per lane
+            uint32_t off[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) off[u] = pe[i + u * 64];
+#pragma unroll
+            for (int u = 0; u < 8; u++) atomicOr(&seg_bm[off[u] >> 5], 1u << (off[u] & 31));
+        }
+        for (; i < e1; i += 64) {
+            const uint32_t off = pe[i];
+            atomicOr(&seg_bm[off >> 5], 1u << (off & 31));
+        }
+    }
+    __syncthreads();
+    // write out: the bit array starts at filters + o0 + 1 (any byte alignment)
+    uint64_t nbytes = fbytes - (uint64_t)seg0 * 8192;
+    if (nbytes > (uint64_t)kFillSegs * 8192) nbytes = (uint64_t)kFillSegs * 8192;
+    uint8_t *dst = filters + o0 + 1 + (uint64_t)seg0 * 8192;
+    const uint8_t *bmb = (const uint8_t *)bm;
+    uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (head > nbytes) head = (uint32_t)nbytes;
+    const uint32_t nd = (uint32_t)((nbytes - head) >> 2);     // aligned dwords
+    const uint32_t tail0 = head + nd * 4;
+    if (threadIdx.x < head) dst[threadIdx.x] = bmb[threadIdx.x];
+    if (threadIdx.x >= 8 && threadIdx.x - 8 < nbytes - tail0) dst[tail0 + threadIdx.x - 8] = bmb[tail0 + threadIdx.x - 8];
+    uint32_t *dw = (uint32_t *)(dst + head);
+    for (uint32_t j = threadIdx.x; j < nd; j += kBlock) {
+        const uint32_t b = head + 4 * j;                      // byte offset inside the bitmap
+        const uint32_t w0 = bm[b >> 2], w1 = bm[(b >> 2) + 1];
+        dw[j] = __builtin_amdgcn_alignbyte(w1, w0, b & 3);
+    }
+}
+
+uint32_t bloom_part_tiles(uint64_t pack_rows) { return (uint32_t)((pack_rows + kBinTileRows - 1) / kBinTileRows); }
+static uint64_t bloom_entries_pp(uint64_t pack_rows) { return (pack_rows * 4 + 127) & ~(uint64_t)127; }
+// scratch of a batch: the 16-bit entries (8 B per row), the segment counts / cursors and the segment bases of every pack
+size_t bloom_part_scratch_bytes(uint64_t packs, uint64_t pack_rows) { return (size_t)packs * (bloom_entries_pp(pack_rows) * 2 + 256 * 4 + 260 * 4) + 256; }
+
+// packs [p0, p0 + np) of the column through the partitioned build; scratch = bloom_part_scratch_bytes(np, pack_rows) bytes, max_fbytes
+// = the largest filter (bit array bytes) among them.  width 0 = bytes column (v), else numeric (col)
+hipError_t launch_bloom_build_part(hipStream_t s, int width, const void *col, const BytesView *v, uint64_t n_rows, uint64_t pack_rows, uint64_t p0,
+                                   uint64_t np, uint64_t max_fbytes, uint8_t *filters, const uint64_t *offsets, void *scratch) {
+    if (np == 0) return hipSuccess;
+    const uint32_t tiles_pp = bloom_part_tiles(pack_rows);
+    const uint64_t epp = bloom_entries_pp(pack_rows);
+    uint16_t *entries = (uint16_t *)scratch;
+    uint32_t *seg_counts = (uint32_t *)(entries + np * epp);
+    uint32_t *seg_base = seg_counts + np * 256;
+    hipError_t e = hipMemsetAsync(seg_counts, 0, np * 256 * 4, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid1((unsigned)(np * tiles_pp)), block(kBlock);
+#define KNOX_BLOOM_PASS(KERN, ...)                                                                                                       \
+    do {                                                                                                                                 \
+        if (width == 0) {                                                                                                                \
+            HashBytes hb{v->ptr, v->buf, v->pool_base};                                                                                  \
+            hipLaunchKernelGGL((KERN<8, HashBytes>), grid1, block, 0, s, hb, n_rows, pack_rows, p0, tiles_pp, offsets, __VA_ARGS__);   \
+        } else {                                                                                                                         \
+            HashNumeric hn{col};                                                                                                         \
+            switch (width) {                                                                                                             \
+            case 8: hipLaunchKernelGGL((KERN<8, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERN<4, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERN<2, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, __VA_ARGS__); break; \
+            case 1: hipLaunchKernelGGL((KERN<1, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, __VA_ARGS__); break; \
+            default: return hipErrorInvalidValue;                                                                                        \
+            }                                                                                                                            \
+        }                                                                                                                                \
+        e = hipGetLastError();                                                                                                           \
+        if (e != hipSuccess) return e;                                                                                                   \
+    } while (0)
+    KNOX_BLOOM_PASS(bloom_count_kernel, seg_counts);
+    hipLaunchKernelGGL(bloom_scan_kernel, dim3((unsigned)((np + kBlock / 64 - 1) / (kBlock / 64))), block, 0, s, np, seg_counts, seg_base);
+    KNOX_BLOOM_PASS(bloom_bin_kernel, seg_counts, entries, epp);
+#undef KNOX_BLOOM_PASS
+    const uint32_t n_seg = (uint32_t)((max_fbytes * 8 + (1u << kSegShift) - 1) >> kSegShift);
+    const uint32_t groups_pp = (n_seg + kFillSegs - 1) / kFillSegs;
+    hipLaunchKernelGGL(bloom_fill_kernel, dim3((unsigned)(np * groups_pp)), block, 0, s, p0, groups_pp, filters, offsets, entries, epp, seg_base);
+    return hipGetLastError();
+}
+
 hipError_t launch_bloom_build_bytes(hipStream_t s, const BytesView &v, uint8_t *filters, const uint64_t *offsets) {
     const uint64_t n_packs = (v.n_rows + v.pack_rows - 1) / v.pack_rows;
     if (n_packs == 0) return hipSuccess;

@@ -108,11 +108,31 @@ KNOX_API int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, kn
     int rc = bloom_alloc(ctx, offsets.data(), n_packs, out);
     if (rc) return rc;
     knox_bloom *b = *out;
-    hipError_t e = hipMemsetAsync(b->d_filters, 0, b->bytes, ctx->stream);
-    if (e == hipSuccess)
-        e = col->dtype == KNOX_BYTES
-                ? launch_bloom_build_bytes(ctx->stream, bytes_view(col, col->n_rows), b->d_filters, b->d_offsets)
-                : launch_bloom_build(ctx->stream, col->width, col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
+    hipError_t e = hipSuccess;
+    const uint64_t max_fbytes = n_packs ? offsets[1] - offsets[0] - 1 : 0;   // pack 0 is a full pack: the largest filter
+    static const bool part_on = !(getenv("KNOX_BLOOM_ATOMIC") && atoi(getenv("KNOX_BLOOM_ATOMIC")) != 0);  // 1: the atomic kernels (A/B runs)
+    if (part_on && col->pack_rows >= 4096 && max_fbytes <= ((size_t)2 << 20)) {
+        // partitioned build (knox_bloom.hip): probe locations binned by filter segment, every segment OR-ed together in LDS
+        // and stored once.  Batches of packs bound the scratch (8 B per row + 2 KiB per pack) to ~1 GiB
+        const BytesView bv = col->dtype == KNOX_BYTES ? bytes_view(col, col->n_rows) : BytesView();
+        size_t batch = std::max<size_t>(1, ((size_t)1 << 30) / bloom_part_scratch_bytes(1, col->pack_rows));
+        batch = std::min(batch, n_packs);
+        rc = ensure(ctx, ctx->sort_buf, bloom_part_scratch_bytes(batch, col->pack_rows) + 256, ARENA_WRITE);
+        if (rc) {
+            knox_bloom_free(b);
+            *out = nullptr;
+            return rc;
+        }
+        for (size_t p0 = 0; p0 < n_packs && e == hipSuccess; p0 += batch)
+            e = launch_bloom_build_part(ctx->stream, col->dtype == KNOX_BYTES ? 0 : col->width, col->dev, &bv, col->n_rows, col->pack_rows, p0,
+                                        std::min(batch, n_packs - p0), max_fbytes, b->d_filters, b->d_offsets, ctx->sort_buf.p);
+    } else {
+        e = hipMemsetAsync(b->d_filters, 0, b->bytes, ctx->stream);
+        if (e == hipSuccess)
+            e = col->dtype == KNOX_BYTES
+                    ? launch_bloom_build_bytes(ctx->stream, bytes_view(col, col->n_rows), b->d_filters, b->d_offsets)
+                    : launch_bloom_build(ctx->stream, col->width, col->dev, col->n_rows, col->pack_rows, b->d_filters, b->d_offsets);
+    }
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
         knox_bloom_free(b);

@@ -12,6 +12,7 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
 };
 static RcclApi g_rccl;
 
@@ -26,6 +27,7 @@ static int rccl_load() {
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(lib, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.CommDestroy) return KNOX_E_COMM;
     g_rccl.lib = lib;
     return KNOX_OK;
@@ -104,26 +106,87 @@ KNOX_API int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *min
 // aggregates {SumReducer (wrapping, reducer.go:168-178), CountReducer / CountResult}.  The 64-bit wrapping sum travels
 // as two 32-bit halves in int64 lanes, so no lane can overflow for any number of ranks a node has and the result is
 // exactly the sum mod 2^64 whatever the reduction order: bit-identical to knox_comm_allgather_states + combine.
+//
+// The exchange has nothing to wait for on the device (its input is the host's copy of a collected scan), so it runs on a
+// stream of its own behind page-locked slots: _start enqueues {H2D, ncclAllReduce, D2H, event} and returns, _finish
+// reads the oldest one -- a host keeps the collective of step i in flight behind the scan of step i + 1.
+static int comm_ring_init(knox_ctx *ctx) {
+    if (ctx->comm_stream) return KNOX_OK;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->comm_h, sizeof(int64_t) * 4 * knox_ctx::kCommRing, hipHostMallocDefault));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->comm_d, sizeof(int64_t) * 4 * knox_ctx::kCommRing));
+    for (int i = 0; i < knox_ctx::kCommRing; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->comm_ev[i], hipEventDisableTiming));
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_allreduce_sum_count_start(knox_ctx *ctx, uint64_t isum, int64_t count) {
+    if (!ctx) return KNOX_E_INVALID;
+    if (!ctx->comm) return KNOX_E_COMM;
+    if (ctx->comm_head - ctx->comm_tail >= (uint64_t)knox_ctx::kCommRing) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    int rc = comm_ring_init(ctx);
+    if (rc) return rc;
+    const int k = (int)(ctx->comm_head % knox_ctx::kCommRing);
+    int64_t *h = ctx->comm_h + 4 * k, *d = ctx->comm_d + 4 * k;
+    h[0] = (int64_t)(isum & 0xffffffffull);
+    h[1] = (int64_t)(isum >> 32);
+    h[2] = count;
+    HIPCHK(ctx, hipMemcpyAsync(d, h, 3 * sizeof(int64_t), hipMemcpyHostToDevice, ctx->comm_stream));
+    if (g_rccl.AllReduce(d, d, 3, ncclInt64, ncclSum, ctx->comm, ctx->comm_stream) != ncclSuccess) return KNOX_E_COMM;
+    HIPCHK(ctx, hipMemcpyAsync(h, d, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->comm_stream));
+    HIPCHK(ctx, hipEventRecord(ctx->comm_ev[k], ctx->comm_stream));
+    ctx->comm_head++;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_comm_allreduce_sum_count_finish(knox_ctx *ctx, uint64_t *isum_out, int64_t *count_out) {
+    if (!ctx || !isum_out || !count_out) return KNOX_E_INVALID;
+    if (ctx->comm_head == ctx->comm_tail) return KNOX_E_INVALID;  // nothing in flight
+    const int k = (int)(ctx->comm_tail % knox_ctx::kCommRing);
+    HIPCHK(ctx, hipEventSynchronize(ctx->comm_ev[k]));
+    const int64_t *h = ctx->comm_h + 4 * k;
+    *isum_out = (uint64_t)h[0] + ((uint64_t)h[1] << 32);
+    *count_out = h[2];
+    ctx->comm_tail++;
+    return KNOX_OK;
+}
+
 KNOX_API int knox_comm_allreduce_sum_count(knox_ctx *ctx, uint64_t *isum_inout, int64_t *count_inout) {
     if (!ctx || !isum_inout || !count_inout) return KNOX_E_INVALID;
     if (!ctx->comm) return KNOX_E_COMM;
-    hipSetDevice(ctx->device);
-    int rc = ensure_plain(ctx, ctx->comm_buf, 64);
+    if (ctx->comm_head != ctx->comm_tail) return KNOX_E_BUSY;  // finish the exchanges in flight first
+    const int rc = knox_comm_allreduce_sum_count_start(ctx, *isum_inout, *count_inout);
     if (rc) return rc;
-    int64_t h[3] = {(int64_t)(*isum_inout & 0xffffffffull), (int64_t)(*isum_inout >> 32), *count_inout};
-    int64_t *d = (int64_t *)ctx->comm_buf.p;
-    HIPCHK(ctx, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
-    if (g_rccl.AllReduce(d, d, 3, ncclInt64, ncclSum, ctx->comm, ctx->stream) != ncclSuccess) return KNOX_E_COMM;
-    HIPCHK(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *isum_inout = (uint64_t)h[0] + ((uint64_t)h[1] << 32);
-    *count_inout = h[2];
+    return knox_comm_allreduce_sum_count_finish(ctx, isum_inout, count_inout);
+}
+
+// the communicator's own view of its size (ncclCommCount) and this context's rank in it
+KNOX_API int knox_comm_ranks(knox_ctx *ctx, int *n_ranks, int *rank) {
+    if (!ctx || !n_ranks) return KNOX_E_INVALID;
+    if (!ctx->comm || !g_rccl.CommCount) return KNOX_E_COMM;
+    if (g_rccl.CommCount(ctx->comm, n_ranks) != ncclSuccess) return KNOX_E_COMM;
+    if (rank) *rank = ctx->rank;
     return KNOX_OK;
 }
 
 KNOX_API int knox_comm_destroy(knox_ctx *ctx) {
     if (!ctx) return KNOX_E_INVALID;
+    if (ctx->comm_stream) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->comm_stream);
+    }
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    if (ctx->comm_stream) {
+        for (hipEvent_t &e : ctx->comm_ev)
+            if (e) { hipEventDestroy(e); e = nullptr; }
+        if (ctx->comm_h) hipHostFree(ctx->comm_h);
+        if (ctx->comm_d) hipFree(ctx->comm_d);
+        hipStreamDestroy(ctx->comm_stream);
+        ctx->comm_h = nullptr;
+        ctx->comm_d = nullptr;
+        ctx->comm_stream = nullptr;
+        ctx->comm_head = ctx->comm_tail = 0;
+    }
     ctx->comm = nullptr;
     ctx->n_ranks = 1;
     ctx->rank = 0;

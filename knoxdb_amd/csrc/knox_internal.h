@@ -121,6 +121,12 @@ struct knox_ctx {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     DevBuf comm_buf;
+    // the sum / count all-reduce runs on a stream of its own behind a small ring of page-locked slots (knox_comm.cpp)
+    static constexpr int kCommRing = 4;
+    hipStream_t comm_stream = nullptr;
+    int64_t *comm_h = nullptr, *comm_d = nullptr;  // 4 int64 per slot
+    hipEvent_t comm_ev[kCommRing] = {};
+    uint64_t comm_head = 0, comm_tail = 0;
 };
 
 struct knox_col {

@@ -140,3 +140,58 @@ class SumCountReduce:
 
     def __call__(self, isum, count):
         return self.finish(self.start(isum, count))
+
+
+# ---- the library's own RCCL exchange (knox_comm_*): what a Go host calls, no torch in the data path ----------------
+def comm_unique_id():
+    """ncclGetUniqueId through the ABI (rank 0 creates it, every rank passes the same bytes to comm_init)"""
+    buf = (C.c_uint8 * 128)()
+    rc = _lib.lib().knox_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError("knox_comm_unique_id: %s" % _lib.lib().knox_strerror(rc).decode())
+    return bytes(buf)
+
+
+def comm_init(ctx, n_ranks, rank, unique_id):
+    """ncclCommInitRank on the context's device; returns the communicator's own size (ncclCommCount)"""
+    buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+    _lib.check(ctx.L.knox_comm_init(ctx.h, n_ranks, rank, buf), "knox_comm_init")
+    n, r = C.c_int(), C.c_int()
+    _lib.check(ctx.L.knox_comm_ranks(ctx.h, C.byref(n), C.byref(r)), "knox_comm_ranks")
+    return n.value
+
+
+class AbiSumCountReduce:
+    """SumCountReduce over knox_comm_allreduce_sum_count_start / _finish: ONE ncclAllReduce(int64 x 3, sum) per exchange on
+    the context's collective stream, up to 4 in flight (FIFO)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def start(self, isum, count):
+        _lib.check(self.ctx.L.knox_comm_allreduce_sum_count_start(self.ctx.h, isum & ((1 << 64) - 1), count), "knox_comm_allreduce_sum_count_start")
+        return 0
+
+    def finish(self, _k=0):
+        s, c = C.c_uint64(), C.c_int64()
+        _lib.check(self.ctx.L.knox_comm_allreduce_sum_count_finish(self.ctx.h, C.byref(s), C.byref(c)), "knox_comm_allreduce_sum_count_finish")
+        return int(s.value), int(c.value)
+
+    def __call__(self, isum, count):
+        self.start(isum, count)
+        return self.finish()
+
+
+class AbiStateGather:
+    """StateGather over knox_comm_allgather_states: ncclAllGather of every rank's states + the same deterministic
+    knox_agg_combine in rank order on every rank."""
+
+    def __init__(self, ctx, n_states):
+        self.ctx, self.n_states = ctx, n_states
+
+    def __call__(self, states, count):
+        mine = (AggState * self.n_states)(*states)
+        merged = (AggState * self.n_states)()
+        c = C.c_int64(count)
+        _lib.check(self.ctx.L.knox_comm_allgather_states(self.ctx.h, mine, self.n_states, merged, C.byref(c)), "knox_comm_allgather_states")
+        return [merged[i] for i in range(self.n_states)], int(c.value)

@@ -120,6 +120,9 @@ class Bits:
             check(_lib.lib().knox_bits_wrap(ctx.h, C.c_void_p(wrap_ptr), size, C.byref(h)), "knox_bits_wrap")
         elif for_col is None:
             check(_lib.lib().knox_bits_alloc(ctx.h, size, C.byref(h)))
+        elif isinstance(for_col, (list, tuple)):  # verified against every column of a multi-leaf scan
+            arr = (C.c_void_p * len(for_col))(*[c.h for c in for_col])
+            check(_lib.lib().knox_bits_alloc_for_cols(ctx.h, size, arr, len(for_col), C.byref(h)), "knox_bits_alloc_for_cols")
         else:  # placement class matched to scans of that column (include/knoxgpu.h knox_bits_alloc_for)
             check(_lib.lib().knox_bits_alloc_for(ctx.h, size, for_col.h, C.byref(h)), "knox_bits_alloc_for")
         self.h = h

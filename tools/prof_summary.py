@@ -33,10 +33,15 @@ TRAFFIC_KERNELS = {
     "headline": "scan_kernel<8, 1, 1u, false, false, 0u>",        # int64 Between + sum (BASELINE configs[1])
     "cfg3": "scan_kernel<8, 2, 14u, false, true, 2u>",             # 2 x float64, AND, min / max / mean (configs[2])
     "cfg4_bytes": "bytes_eq_kernel",                                # []byte EQ over per-pack StringPools (configs[3])
-    "bloom_build_u64": "bloom_build_kernel<8>",
-    "bloom_build_bytes": "bloom_build_bytes_kernel",
+    "bloom_count_u64": "bloom_count_kernel<8, HashNumeric>",
+    "bloom_bin_u64": "bloom_bin_kernel<8, HashNumeric>",
+    "bloom_count_bytes": "bloom_count_kernel<8, HashBytes>",
+    "bloom_bin_bytes": "bloom_bin_kernel<8, HashBytes>",
+    "bloom_fill": "bloom_fill_kernel",
+    "bloom_build_atomic_u64": "bloom_build_kernel<8>",
+    "bloom_build_atomic_bytes": "bloom_build_bytes_kernel",
 }
-SHOW = ("scan_kernel", "popcount_seg", "bytes_eq_kernel", "bloom_build", "finalize_packs")
+SHOW = ("scan_kernel", "popcount_seg", "bytes_eq_kernel", "bloom_", "finalize_packs")
 traffic = defaultdict(dict)
 for sub in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(sub):
