@@ -8,6 +8,8 @@ next best thing and runs in the CPU test suite (tests/test_go_boundary.py):
   * finds every `C.knox_*(...)` call in the Go sources, splits its arguments, infers the cgo type of each argument
     from the conversions / declarations in the enclosing function (`C.int(x)`, `(*C.uint8_t)(p)`, `unsafe.Pointer(p)`,
     `var out C.knox_scan_out` ... `&out`, struct fields `c.p`, `nil`) and compares arity and types with the header;
+  * checks that every call that reaches a context (first parameter knox_ctx*, or the free of a column / bitset / filter)
+    in the cgo package sits behind that context's mutex: the library's contexts are not re-entrant;
   * checks the struct fields the Go code touches (`cn[i].val_len`, `out.rows_scanned`, `ca[i]._func` ...) exist in the
     header's structs, and that the enum constants restated in Go have the header's values.
 
@@ -144,6 +146,9 @@ class Scope:
         # parameters of cgo types: `rc C.int`
         for nm, ty in re.findall(r"(\w+)\s+(\*{0,2}C\.\w+)", header_line):
             self.vars[nm] = go_ctype(ty)
+        # the owning context of a wrapper object: `c := col.c`
+        for nm in re.findall(r"\b(\w+)\s*:=\s*\w+\.c\b(?!\.)", body):
+            self.objs[nm] = "Ctx"
         # locals of wrapper types: `var out State`
         for nm, ty in re.findall(r"\bvar\s+(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State)\b", body):
             self.objs[nm] = ty
@@ -228,6 +233,8 @@ def find_calls(body):
         yield m.group(1), split_top(body[m.end():i - 1]), body.count("\n", 0, m.start())
 
 
+LOCKED_FREES = {"knox_col_free", "knox_bits_free", "knox_bloom_free", "knox_packed_free"}
+
 GO_ENUMS = {  # Go constant name -> header enum name (restated values must agree)
     "blockInt64": "KNOX_INT64", "blockInt32": "KNOX_INT32", "blockInt16": "KNOX_INT16", "blockInt8": "KNOX_INT8",
     "blockUint64": "KNOX_UINT64", "blockUint32": "KNOX_UINT32", "blockUint16": "KNOX_UINT16", "blockUint8": "KNOX_UINT8",
@@ -280,6 +287,14 @@ def check(verbose=False):
                     elif not compatible(t, p):
                         errors.append(f"{rel}: {name}: argument {i + 1} `{a}` is {t}, header takes {p}")
                 checked += 1
+                # the context is not re-entrant (include/knoxgpu.h "Conventions"; one goroutine per query in the reference):
+                # every call that reaches a knox_ctx -- through its first parameter, or by freeing an object whose free
+                # synchronises the context's stream -- must sit behind the context's mutex
+                needs_lock = (params[:1] == ["knox_ctx*"] and name not in ("knox_ctx_open", "knox_ctx_open_stream")) or name in LOCKED_FREES
+                if needs_lock and os.path.basename(path) == "knoxgpu.go":
+                    head = "\n".join(body.split("\n")[:line + 1])
+                    if not re.search(r"\bmu\.Lock\(\)", head):
+                        errors.append(f"{rel}: {name}: called without the context's lock (c.mu.Lock() must precede it in the same function)")
                 if verbose:
                     print(f"ok  {rel}: {name}({', '.join(params)}) -> {ret}")
             # field accesses on C structs: name[i].field / name.field for variables of header struct types

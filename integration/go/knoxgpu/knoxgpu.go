@@ -20,6 +20,7 @@ import "C"
 
 import (
 	"errors"
+	"math"
 	"os"
 	"strconv"
 	"sync"
@@ -42,8 +43,9 @@ type Number interface {
 }
 
 // Ctx is one device + one HIP stream.  The library's contexts are not re-entrant; the reference runs many queries
-// concurrently (one goroutine per query, pack/table/query.go:195-219), so calls are serialised per Ctx.  A host that
-// wants parallel scans opens one Ctx per worker.
+// concurrently (one goroutine per query, pack/table/query.go:195-219), so EVERY call that reaches the context -- also
+// the Free of a column / bitset / filter, which synchronises the context's stream -- takes c.mu
+// (integration/check_go_calls.py enforces it).  A host that wants parallel scans opens one Ctx per worker.
 type Ctx struct {
 	p  *C.knox_ctx
 	mu sync.Mutex
@@ -64,11 +66,65 @@ func Open(device int) (*Ctx, error) {
 	return &Ctx{p: c}, nil
 }
 
-func (c *Ctx) Close() { C.knox_ctx_close(c.p) }
+func (c *Ctx) Close() {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	C.knox_ctx_close(c.p)
+}
 
 // SetArena sets the budget of the context's device-memory arena (the pack cache on the device).
 func (c *Ctx) SetArena(bytes uint64) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	return errOf(C.knox_ctx_set_arena(c.p, C.size_t(bytes)))
+}
+
+// ProfEnable / ProfRead: the library's HIP-event stopwatch around the dominant kernel of every scan (knox_prof_*):
+// total milliseconds and launches since the last read -- what the run reader writes into QueryStats.
+func (c *Ctx) ProfEnable(on bool) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	v := 0
+	if on {
+		v = 1
+	}
+	C.knox_prof_enable(c.p, C.int(v))
+}
+
+func (c *Ctx) ProfRead() (ms float64, launches int) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var total C.double
+	var k C.int
+	C.knox_prof_read(c.p, &total, &k)
+	return float64(total), int(k)
+}
+
+// ValueBits: the raw bits of a filter value of the column type, zero-extended -- what knox_pred.a / .b carry.
+func ValueBits(v any) (uint64, bool) {
+	switch x := v.(type) {
+	case int64:
+		return uint64(x), true
+	case int32:
+		return uint64(uint32(x)), true
+	case int16:
+		return uint64(uint16(x)), true
+	case int8:
+		return uint64(uint8(x)), true
+	case uint64:
+		return x, true
+	case uint32:
+		return uint64(x), true
+	case uint16:
+		return uint64(x), true
+	case uint8:
+		return uint64(x), true
+	case float64:
+		return math.Float64bits(x), true
+	case float32:
+		return uint64(math.Float32bits(x)), true
+	}
+	return 0, false
 }
 
 // AsU64 reinterprets the signed top limb slice of an Int128Stride / Int256Stride (X0 []int64) as raw 64-bit words.
@@ -93,29 +149,114 @@ func Cmp[T Number](c *Ctx, dtype, mode int, src []T, a, b T, bits []byte) (int64
 type Column struct {
 	p *C.knox_col
 	n int
+	c *Ctx
 }
 
 func Upload[T Number](c *Ctx, dtype int, vals []T, packRows int) (*Column, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	var col *C.knox_col
 	rc := C.knox_col_upload(c.p, C.int(dtype), unsafe.Pointer(unsafe.SliceData(vals)), C.size_t(len(vals)), C.size_t(packRows), &col)
 	if rc != 0 {
 		return nil, errOf(rc)
 	}
-	return &Column{col, len(vals)}, nil
+	return &Column{col, len(vals), c}, nil
+}
+
+// NewColumn / AppendAsync / Reset / Wait: the ingest that overlaps the scans (include/knoxgpu.h knox_col_create ...):
+// an empty numeric column with room for capacityRows rows; AppendAsync enqueues the copy of one pack's vector behind
+// the rows present on the context's copy stream and returns (vals is a Go slice: it is copied into the library's pinned
+// ring inside the call and not referenced afterwards -- cgo rule); every scan that reads the column waits for the
+// copies ON THE DEVICE.  Reset empties the column for the next run (call it before enqueueing the other buffer's scan).
+func NewColumn(c *Ctx, dtype, capacityRows, packRows int) (*Column, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var col *C.knox_col
+	rc := C.knox_col_create(c.p, C.int(dtype), C.size_t(capacityRows), C.size_t(packRows), &col)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Column{col, 0, c}, nil
+}
+
+func AppendAsync[T Number](col *Column, vals []T) error {
+	c := col.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	rc := C.knox_col_append_async(c.p, col.p, unsafe.Pointer(unsafe.SliceData(vals)), C.size_t(len(vals)))
+	if rc == 0 {
+		col.n += len(vals)
+	}
+	return errOf(rc)
+}
+
+func (col *Column) Reset() error {
+	c := col.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	rc := C.knox_col_reset(c.p, col.p)
+	if rc == 0 {
+		col.n = 0
+	}
+	return errOf(rc)
+}
+
+func (col *Column) Wait() error {
+	c := col.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	return errOf(C.knox_col_wait(c.p, col.p))
+}
+
+// UploadRawContainers: one column from the ENCODED blocks of consecutive packs (the bytes NumberContainer.Store writes,
+// internal/encode/container.go:84): headers are parsed on the host, payloads expanded on the device -- no host decode.
+// The Go buffers are copied into C memory first (a C array of pointers must not point into Go memory).
+func UploadRawContainers(c *Ctx, dtype int, bufs [][]byte, packRows int) (*Column, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	n := len(bufs)
+	ptrs := C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0))))
+	lens := C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(C.size_t(0))))
+	pv := unsafe.Slice((**C.uint8_t)(ptrs), n)
+	lv := unsafe.Slice((*C.size_t)(lens), n)
+	defer func() {
+		for _, q := range pv {
+			C.free(unsafe.Pointer(q))
+		}
+		C.free(ptrs)
+		C.free(lens)
+	}()
+	rows := 0
+	for i, b := range bufs {
+		pv[i] = (*C.uint8_t)(C.CBytes(b))
+		lv[i] = C.size_t(len(b))
+	}
+	var col *C.knox_col
+	rc := C.knox_col_upload_raw_containers(c.p, C.int(dtype), (**C.uint8_t)(ptrs), (*C.size_t)(lens), C.size_t(n), C.size_t(packRows), &col)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	rows = int(C.knox_col_rows(col))
+	return &Column{col, rows, c}, nil
 }
 
 // NewBytesColumn / AppendPack: a []byte column held as ONE StringPool per pack (pkg/stringx/pool.go:45-58):
 // ptr[i] = off<<32 | len relative to that pack's own buffer.
 func NewBytesColumn(c *Ctx, packRows, maxPacks int, maxPoolBytes uint64) (*Column, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	var col *C.knox_col
 	rc := C.knox_col_bytes_create(c.p, C.size_t(packRows), C.size_t(maxPacks), C.size_t(maxPoolBytes), &col)
 	if rc != 0 {
 		return nil, errOf(rc)
 	}
-	return &Column{col, 0}, nil
+	return &Column{col, 0, c}, nil
 }
 
-func (col *Column) AppendPack(c *Ctx, ptr []uint64, buf []byte) error {
+func (col *Column) AppendPack(ptr []uint64, buf []byte) error {
+	c := col.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	rc := C.knox_col_bytes_append_pack(c.p, col.p, (*C.uint64_t)(unsafe.SliceData(ptr)), C.size_t(len(ptr)),
 		(*C.uint8_t)(unsafe.SliceData(buf)), C.size_t(len(buf)))
 	if rc == 0 {
@@ -125,44 +266,72 @@ func (col *Column) AppendPack(c *Ctx, ptr []uint64, buf []byte) error {
 }
 
 func (col *Column) Rows() int { return col.n }
-func (col *Column) Free()     { C.knox_col_free(col.p) }
+
+// Free synchronises the context's stream before the memory goes back to the arena: under the context's lock.
+func (col *Column) Free() {
+	c := col.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	C.knox_col_free(col.p)
+}
 
 // Bits is a device-resident bitset.Bitset.
 type Bits struct {
 	p    *C.knox_bits
 	size int
+	c    *Ctx
 }
 
 func NewBits(c *Ctx, size int) (*Bits, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	var b *C.knox_bits
 	if rc := C.knox_bits_alloc(c.p, C.size_t(size), &b); rc != 0 {
 		return nil, errOf(rc)
 	}
-	return &Bits{b, size}, nil
+	return &Bits{b, size, c}, nil
 }
 
 // NewBitsFor: the selection bitset of scans over col (a write buffer verified against that column).
 func NewBitsFor(c *Ctx, size int, col *Column) (*Bits, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	var b *C.knox_bits
 	if rc := C.knox_bits_alloc_for(c.p, C.size_t(size), col.p, &b); rc != 0 {
 		return nil, errOf(rc)
 	}
-	return &Bits{b, size}, nil
+	return &Bits{b, size, c}, nil
 }
 
-func (b *Bits) Free() { C.knox_bits_free(b.p) }
+func (b *Bits) Size() int { return b.size }
 
-func (b *Bits) Upload(c *Ctx, host []byte) error {
+func (b *Bits) Free() {
+	c := b.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	C.knox_bits_free(b.p)
+}
+
+func (b *Bits) Upload(host []byte) error {
+	c := b.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	return errOf(C.knox_bits_upload(c.p, b.p, (*C.uint8_t)(unsafe.SliceData(host))))
 }
 
 // Download fills host ((size+7)/8 bytes) -- what bitset.Bitset.Bytes() holds.
-func (b *Bits) Download(c *Ctx, host []byte) error {
+func (b *Bits) Download(host []byte) error {
+	c := b.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	return errOf(C.knox_bits_download(c.p, b.p, (*C.uint8_t)(unsafe.SliceData(host))))
 }
 
 // Indexes = Bitset.Indexes (internal/bitset/iterator.go:269-290): ascending row ids of the set bits.
-func (b *Bits) Indexes(c *Ctx, dst []uint32) ([]uint32, error) {
+func (b *Bits) Indexes(dst []uint32) ([]uint32, error) {
+	c := b.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	var n C.size_t
 	rc := C.knox_bits_indexes(c.p, b.p, (*C.uint32_t)(unsafe.SliceData(dst)), C.size_t(cap(dst)), &n)
 	if rc != 0 {
@@ -334,43 +503,93 @@ func Combine(states []State) State {
 
 // ---- per-pack bloom pre-filter (internal/filter/bloom/bloom.go:136-150) ------------------------------------------
 
-type Bloom struct{ p *C.knox_bloom }
+type Bloom struct {
+	p *C.knox_bloom
+	c *Ctx
+}
 
 func BuildBloom(c *Ctx, col *Column, factor int) (*Bloom, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	var b *C.knox_bloom
 	if rc := C.knox_bloom_build(c.p, col.p, C.int(factor), &b); rc != 0 {
 		return nil, errOf(rc)
 	}
-	return &Bloom{b}, nil
+	return &Bloom{b, c}, nil
 }
 
 // Probe = Filter.Contains(h) for every pack: maybe[p] == 1 when pack p may hold hash h.
-func (b *Bloom) Probe(c *Ctx, h uint64, maybe []byte) error {
+func (b *Bloom) Probe(h uint64, maybe []byte) error {
+	c := b.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	return errOf(C.knox_bloom_probe(c.p, b.p, C.uint64_t(h), (*C.uint8_t)(unsafe.SliceData(maybe))))
 }
 
-func (b *Bloom) Free() { C.knox_bloom_free(b.p) }
+func (b *Bloom) Free() {
+	c := b.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	C.knox_bloom_free(b.p)
+}
 
-// HashBytes = hash.Hash (internal/hash/hash.go:26, zeebo/xxh3): the probe value of a bytes matcher.
+// HashBytes = hash.Hash (internal/hash/hash.go:26, zeebo/xxh3): the probe value of a bytes matcher.  Pure host code.
 func HashBytes(v []byte) uint64 {
 	return uint64(C.knox_hash_bytes((*C.uint8_t)(unsafe.SliceData(v)), C.size_t(len(v))))
 }
 
 // ---- multi-GPU: the final aggregate only (one process per GPU, RCCL over xGMI) -----------------------------------
 
+// CommUniqueID: rank 0 makes the ncclUniqueId; the host's own rendezvous carries the 128 bytes to every rank.
+func CommUniqueID() (id [128]byte, err error) {
+	rc := C.knox_comm_unique_id((*C.uint8_t)(unsafe.Pointer(&id[0])))
+	return id, errOf(rc)
+}
+
 func (c *Ctx) CommInit(nRanks, rank int, id [128]byte) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	return errOf(C.knox_comm_init(c.p, C.int(nRanks), C.int(rank), (*C.uint8_t)(unsafe.Pointer(&id[0]))))
+}
+
+// CommRanks: the communicator's own size (ncclCommCount).
+func (c *Ctx) CommRanks() (int, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var n, r C.int
+	rc := C.knox_comm_ranks(c.p, &n, &r)
+	return int(n), errOf(rc)
 }
 
 // AllReduceSumCount: ONE ncclAllReduce(int64, sum) of {wrapping sum, count} over all ranks.
 func (c *Ctx) AllReduceSumCount(isum uint64, count int64) (uint64, int64, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	s, n := C.uint64_t(isum), C.int64_t(count)
 	rc := C.knox_comm_allreduce_sum_count(c.p, &s, &n)
 	return uint64(s), int64(n), errOf(rc)
 }
 
+// AllReduceSumCountStart / Finish: the same exchange kept in flight behind the next run's scan (FIFO, up to 4).
+func (c *Ctx) AllReduceSumCountStart(isum uint64, count int64) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	return errOf(C.knox_comm_allreduce_sum_count_start(c.p, C.uint64_t(isum), C.int64_t(count)))
+}
+
+func (c *Ctx) AllReduceSumCountFinish() (uint64, int64, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var s C.uint64_t
+	var n C.int64_t
+	rc := C.knox_comm_allreduce_sum_count_finish(c.p, &s, &n)
+	return uint64(s), int64(n), errOf(rc)
+}
+
 // AllGatherStates: what min / max / first / last / float sums need (rank order = row order).
 func (c *Ctx) AllGatherStates(mine []State, count int64) ([]State, int64, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	merged := make([]State, len(mine))
 	n := C.int64_t(count)
 	rc := C.knox_comm_allgather_states(c.p, (*C.knox_agg_state)(unsafe.Pointer(unsafe.SliceData(mine))), C.int(len(mine)),

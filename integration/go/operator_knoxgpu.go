@@ -11,17 +11,19 @@
 //                       it is handed; states merge exactly (knox_agg_combine), Value() finalises.
 //
 // Columns of a package are uploaded once and kept on the device keyed by (pack key, version, field): the second query
-// over the same pack reads HBM only.  Packages with non-materialized blocks, or trees with leaf kinds the device
-// plan does not take, fall back to the CPU operator.
+// over the same pack reads HBM only.  Encoded (non-materialized) blocks cross PCIe in their container form and are
+// decoded on the device (knox_col_upload_raw_containers).  Trees with leaf kinds the device plan does not take fall
+// back to the CPU operator.  This operator works package by package, as the PushOperator interface hands them out; the
+// run-level reader (many packs resident, ONE scan, per-pack results served) is run_knoxgpu.go.
 // Not compiled in the knoxdb_amd repository (no Go toolchain there); see integration/check_go_calls.py.
 package operator
 
 import (
 	"context"
-	"math"
 
 	"blockwatch.cc/knoxdb/internal/bitset"
 	"blockwatch.cc/knoxdb/internal/block"
+	"blockwatch.cc/knoxdb/internal/encode"
 	"blockwatch.cc/knoxdb/internal/knoxgpu"
 	"blockwatch.cc/knoxdb/internal/operator/filter"
 	"blockwatch.cc/knoxdb/internal/pack"
@@ -38,7 +40,10 @@ type colKey struct {
 }
 
 // deviceCols is the device-resident pack cache of one operator: bounded by the context's arena budget
-// (knoxgpu.Ctx.SetArena); a failing upload drops the oldest half and retries once.
+// (knoxgpu.Ctx.SetArena).  A failing upload evicts the oldest columns of OTHER packages and retries once: columns of the
+// package being planned are pinned for the duration of the plan (an earlier leaf's handle is already in the scan's
+// column list -- freeing it would hand a dangling knox_col to C); when nothing evictable is left the caller falls back
+// to the CPU operator.
 type deviceCols struct {
 	gpu   *knoxgpu.Ctx
 	cols  map[colKey]*knoxgpu.Column
@@ -51,12 +56,14 @@ func (d *deviceCols) get(pkg *pack.Package, field int) (*knoxgpu.Column, bool) {
 		return c, true
 	}
 	b := pkg.Block(field)
-	if b == nil || !b.IsMaterialized() {
+	if b == nil {
 		return nil, false
 	}
 	c, err := uploadBlock(d.gpu, b)
 	if err != nil {
-		d.evict(len(d.order) / 2)
+		if d.evictOthers(k.pack, k.version, (len(d.order)+1)/2) == 0 {
+			return nil, false // everything resident belongs to this package: nothing to give up
+		}
 		if c, err = uploadBlock(d.gpu, b); err != nil {
 			return nil, false
 		}
@@ -66,66 +73,76 @@ func (d *deviceCols) get(pkg *pack.Package, field int) (*knoxgpu.Column, bool) {
 	return c, true
 }
 
-func (d *deviceCols) evict(n int) {
-	for _, k := range d.order[:n] {
+// evictOthers frees up to n of the oldest columns that do NOT belong to (pack, version); returns how many went.
+func (d *deviceCols) evictOthers(pack, version uint32, n int) int {
+	kept := d.order[:0]
+	freed := 0
+	for _, k := range d.order {
+		if freed < n && (k.pack != pack || k.version != version) {
+			d.cols[k].Free()
+			delete(d.cols, k)
+			freed++
+			continue
+		}
+		kept = append(kept, k)
+	}
+	d.order = kept
+	return freed
+}
+
+func (d *deviceCols) evictAll() {
+	for _, k := range d.order {
 		d.cols[k].Free()
 		delete(d.cols, k)
 	}
-	d.order = d.order[n:]
+	d.order = d.order[:0]
+}
+
+// containerBytes re-serialises the encoded container of a non-materialized block (NumberContainer.Store,
+// internal/encode/container.go:84): the wire form knox_col_upload_raw_containers parses -- the device decodes it.
+func containerBytes[T knoxgpu.Number](b *block.Block) ([]byte, bool) {
+	c, ok := b.Container().(encode.NumberContainer[T])
+	if !ok {
+		return nil, false
+	}
+	return c.Store(make([]byte, 0, c.Size())), true
+}
+
+func uploadVector[T knoxgpu.Number](g *knoxgpu.Ctx, b *block.Block) (*knoxgpu.Column, error) {
+	if b.IsMaterialized() {
+		return knoxgpu.Upload(g, int(b.Type()), block.NewAccessor[T](b).Slice(), 0)
+	}
+	buf, ok := containerBytes[T](b)
+	if !ok {
+		return nil, ErrTodo
+	}
+	return knoxgpu.UploadRawContainers(g, int(b.Type()), [][]byte{buf}, 0)
 }
 
 func uploadBlock(g *knoxgpu.Ctx, b *block.Block) (*knoxgpu.Column, error) {
-	t := int(b.Type())
 	switch b.Type() {
 	case types.BlockInt64:
-		return knoxgpu.Upload(g, t, block.NewAccessor[int64](b).Slice(), 0)
+		return uploadVector[int64](g, b)
 	case types.BlockInt32:
-		return knoxgpu.Upload(g, t, block.NewAccessor[int32](b).Slice(), 0)
+		return uploadVector[int32](g, b)
 	case types.BlockInt16:
-		return knoxgpu.Upload(g, t, block.NewAccessor[int16](b).Slice(), 0)
+		return uploadVector[int16](g, b)
 	case types.BlockInt8:
-		return knoxgpu.Upload(g, t, block.NewAccessor[int8](b).Slice(), 0)
+		return uploadVector[int8](g, b)
 	case types.BlockUint64:
-		return knoxgpu.Upload(g, t, block.NewAccessor[uint64](b).Slice(), 0)
+		return uploadVector[uint64](g, b)
 	case types.BlockUint32:
-		return knoxgpu.Upload(g, t, block.NewAccessor[uint32](b).Slice(), 0)
+		return uploadVector[uint32](g, b)
 	case types.BlockUint16:
-		return knoxgpu.Upload(g, t, block.NewAccessor[uint16](b).Slice(), 0)
+		return uploadVector[uint16](g, b)
 	case types.BlockUint8:
-		return knoxgpu.Upload(g, t, block.NewAccessor[uint8](b).Slice(), 0)
+		return uploadVector[uint8](g, b)
 	case types.BlockFloat64:
-		return knoxgpu.Upload(g, t, block.NewAccessor[float64](b).Slice(), 0)
+		return uploadVector[float64](g, b)
 	case types.BlockFloat32:
-		return knoxgpu.Upload(g, t, block.NewAccessor[float32](b).Slice(), 0)
+		return uploadVector[float32](g, b)
 	}
 	return nil, ErrTodo
-}
-
-// valueBits: the raw bits of a filter value of the column type, zero-extended (knox_pred.a / .b).
-func valueBits(v any) (uint64, bool) {
-	switch x := v.(type) {
-	case int64:
-		return uint64(x), true
-	case int32:
-		return uint64(uint32(x)), true
-	case int16:
-		return uint64(uint16(x)), true
-	case int8:
-		return uint64(uint8(x)), true
-	case uint64:
-		return x, true
-	case uint32:
-		return uint64(x), true
-	case uint16:
-		return uint64(x), true
-	case uint8:
-		return uint64(x), true
-	case float64:
-		return math.Float64bits(x), true
-	case float32:
-		return uint64(math.Float32bits(x)), true
-	}
-	return 0, false
 }
 
 // plan flattens a filter.Node tree (node.go:29-37) into the postfix form knox_scan takes: operands first, then one
@@ -142,7 +159,7 @@ func (op *PhysicalGpuFilter) plan(n *filter.Node, pkg *pack.Package, nodes []kno
 		switch f.Mode {
 		case types.FilterModeEqual, types.FilterModeNotEqual, types.FilterModeGt, types.FilterModeGe,
 			types.FilterModeLt, types.FilterModeLe:
-			if p.A, ok = valueBits(f.Value); !ok {
+			if p.A, ok = knoxgpu.ValueBits(f.Value); !ok {
 				return nodes, cols, false
 			}
 		case types.FilterModeRange:
@@ -151,8 +168,8 @@ func (op *PhysicalGpuFilter) plan(n *filter.Node, pkg *pack.Package, nodes []kno
 				return nodes, cols, false
 			}
 			var okA, okB bool
-			p.A, okA = valueBits(rg[0])
-			p.B, okB = valueBits(rg[1])
+			p.A, okA = knoxgpu.ValueBits(rg[0])
+			p.B, okB = knoxgpu.ValueBits(rg[1])
 			if !okA || !okB {
 				return nodes, cols, false
 			}
@@ -217,7 +234,7 @@ func (op *PhysicalGpuFilter) Process(ctx context.Context, src *pack.Package) (*p
 	case res.Count == int64(src.Len()):
 		src.WithSelection(nil) // PhysicalFilter: `if op.bits.All()` (filter.go:31-32)
 	default:
-		sel, err := dbits.Indexes(op.gpu, make([]uint32, 0, res.Count))
+		sel, err := dbits.Indexes(make([]uint32, 0, res.Count))
 		if err != nil {
 			return op.cpu.Process(ctx, src)
 		}
@@ -230,7 +247,7 @@ func (op *PhysicalGpuFilter) Finalize(ctx context.Context) error { return nil }
 func (op *PhysicalGpuFilter) Err() error                         { return op.err }
 
 func (op *PhysicalGpuFilter) Close() {
-	op.dev.evict(len(op.dev.order))
+	op.dev.evictAll()
 	op.cpu.Close()
 	op.node = nil
 	op.bits.Close()
@@ -260,11 +277,11 @@ func NewGpuAggregateResult(gpu *knoxgpu.Ctx, node *filter.Node, aggs []knoxgpu.A
 func (r *GpuAggregateResult) Append(ctx context.Context, src *pack.Package) error {
 	nodes, cols, ok := r.filter.plan(r.node, src, nil, nil)
 	if !ok {
-		return ErrTodo
+		return ErrTodo // a leaf kind the device plan does not take (the caller keeps its CPU consumer for such plans)
 	}
 	aggs := make([]knoxgpu.Agg, len(r.aggs))
 	for i, a := range r.aggs {
-		c, ok := r.filter.dev.get(src, a.Col)
+		c, ok := r.filter.dev.get(src, a.Col) // materialized vector or encoded container: both upload (uploadVector)
 		if !ok {
 			return ErrTodo
 		}

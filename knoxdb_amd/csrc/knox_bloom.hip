@@ -176,22 +176,22 @@ struct HashBytes {
     }
 };
 
-// the tile's row hashes into registers; -> bit i set = row i of this thread exists
+// the tile's row hashes into registers, branch free: a row beyond the pack's end re-hashes the pack's last row (its
+// locations are dropped by the `valid` bit at the LDS operations) -- predicating the hash itself makes the compiler keep
+// the whole array in flux across 16 branches (4000 register moves per tile in the first version of these kernels)
 template <int W, typename H>
 __device__ __forceinline__ uint32_t bloom_tile_hashes(const H &hasher, uint64_t p, uint64_t pack_rows, uint64_t n_rows, uint32_t tile,
                                                       uint64_t (&h)[kBinRowsPerThread]) {
     uint64_t r1 = (p + 1) * pack_rows;
     if (r1 > n_rows) r1 = n_rows;
-    const uint64_t r0 = p * pack_rows + (uint64_t)tile * kBinTileRows;
+    const uint64_t r0 = p * pack_rows + (uint64_t)tile * kBinTileRows + threadIdx.x;
+    const uint64_t left = r1 > r0 ? r1 - r0 : 0;              // rows of this thread: i * kBlock < left
     uint32_t valid = 0;
 #pragma unroll
     for (int i = 0; i < kBinRowsPerThread; i++) {
-        const uint64_t r = r0 + (uint64_t)i * kBlock + threadIdx.x;
-        h[i] = 0;
-        if (r < r1) {
-            h[i] = hasher.template at<W>(r, p);
-            valid |= 1u << i;
-        }
+        const bool ok = (uint64_t)i * kBlock < left;
+        h[i] = hasher.template at<W>(ok ? r0 + (uint64_t)i * kBlock : r1 - 1, p);
+        valid |= ok ? 1u << i : 0u;
     }
     return valid;
 }

@@ -4,6 +4,8 @@
 // the Go side expects, on the GPU).  Expected values come from a scalar loop over the same data -- the semantics of
 // internal/cmp/generic.go and internal/reducer/reducer.go.
 // Build: g++ tests/cpp/test_go_entries.cpp -Iinclude -Lknoxdb_amd -lknoxgpu
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -109,6 +111,209 @@ static void go_MatchWide(knox_ctx *ctx, int n_limbs, size_t n, bool with_mask) {
         if (dmask) knox_bits_free(dmask);
         for (auto c : cols) knox_col_free(c);
     }
+}
+
+// pkg/num/varint.go:161-197 (SQLite4-style prefix varint), the ranges a container header of this test needs
+static void put_uvarint(std::vector<uint8_t> &out, uint64_t v) {
+    if (v <= 240) {
+        out.push_back((uint8_t)v);
+    } else if (v <= 2287) {
+        out.push_back((uint8_t)((v - 240) / 256 + 241));
+        out.push_back((uint8_t)((v - 240) % 256));
+    } else if (v <= 67823) {
+        out.push_back(249);
+        out.push_back((uint8_t)((v - 2288) / 256));
+        out.push_back((uint8_t)((v - 2288) % 256));
+    } else {
+        out.push_back(250);
+        out.push_back((uint8_t)(v >> 16)), out.push_back((uint8_t)(v >> 8)), out.push_back((uint8_t)v);
+    }
+}
+
+// run_knoxgpu.go (GpuRun): the run-level reader's C calls in its order -- NewColumn per filter column, AppendAsync pack by
+// pack, NewBits, ProfEnable, ONE Scan over the run with per-pack counts (+ fused reducers), ProfRead, ONE Download, the
+// per-pack slices served; Reset and the next run; then a run whose blocks arrive ENCODED (UploadRawContainers).
+static void go_RunReader(knox_ctx *ctx) {
+    const size_t pack = 4096, max_packs = 8;
+    knox_col *ca = nullptr, *cb = nullptr;
+    EXPECT(knox_col_create(ctx, KNOX_INT64, max_packs * pack, pack, &ca) == 0);
+    EXPECT(knox_col_create(ctx, KNOX_INT32, max_packs * pack, pack, &cb) == 0);
+    // (a BETWEEN -500 AND 500) AND (b >= 10); reducers sum(a), max(b) fused into the run's scan
+    knox_pred nodes[3];
+    std::memset(nodes, 0, sizeof nodes);
+    nodes[0].kind = KNOX_NODE_LEAF, nodes[0].col = 0, nodes[0].op = KNOX_RANGE, nodes[0].a = (uint64_t)(int64_t)-500, nodes[0].b = 500;
+    nodes[1].kind = KNOX_NODE_LEAF, nodes[1].col = 1, nodes[1].op = KNOX_GE, nodes[1].a = 10;
+    nodes[2].kind = KNOX_NODE_AND, nodes[2].nchild = 2;
+    knox_agg aggs[2] = {{KNOX_R_SUM, 0}, {KNOX_R_MAX, 1}};
+    std::vector<knox_agg_state> run_sum, run_max;
+    uint64_t row_base = 0;
+    int64_t want_total = 0, got_total = 0;
+    uint64_t want_sum = 0;
+    int32_t want_max = INT32_MIN;
+    const size_t run_packs[3] = {8, 5, 3};  // a full run, a shorter one, one whose last pack is short
+    for (int run = 0; run < 3; run++) {
+        const size_t np = run_packs[run];
+        std::vector<std::vector<int64_t>> va(np);
+        std::vector<std::vector<int32_t>> vb(np);
+        EXPECT(knox_col_reset(ctx, ca) == 0 && knox_col_reset(ctx, cb) == 0);  // the copy stream waits for the previous run's scan
+        size_t rows = 0;
+        for (size_t p = 0; p < np; p++) {
+            const size_t n = (run == 2 && p + 1 == np) ? pack - 1000 : pack;
+            va[p].resize(n), vb[p].resize(n);
+            for (size_t i = 0; i < n; i++) va[p][i] = (int64_t)(rnd() % 4001) - 2000, vb[p][i] = (int32_t)(rnd() % 41) - 20;
+            if (p == 2)  // one pack without a match: the reference's false positive metadata match
+                for (size_t i = 0; i < n; i++) va[p][i] = 100000;
+            EXPECT(knox_col_append_async(ctx, ca, va[p].data(), n) == 0);  // pageable Go slices: copied inside the call
+            EXPECT(knox_col_append_async(ctx, cb, vb[p].data(), n) == 0);
+            std::fill(va[p].begin(), va[p].begin() + 1, va[p][0]);  // the caller's memory is its own again after return
+            rows += n;
+        }
+        EXPECT(knox_col_rows(ca) == rows && knox_col_rows(cb) == rows);
+        knox_bits *bits = nullptr;
+        EXPECT(knox_bits_alloc(ctx, rows, &bits) == 0);
+        EXPECT(knox_prof_enable(ctx, 1) == 0);
+        knox_col *cols[2] = {ca, cb};
+        knox_agg_state st[2];
+        std::vector<int64_t> pc(np, -1);
+        knox_scan_out out;
+        EXPECT(knox_scan(ctx, nodes, 3, cols, 2, aggs, 2, row_base, nullptr, bits, pc.data(), st, &out) == 0);
+        double ms = -1;
+        int launches = -1;
+        EXPECT(knox_prof_read(ctx, &ms, &launches) == 0 && launches >= 1 && ms > 0);
+        std::vector<uint8_t> host((rows + 7) / 8);
+        EXPECT(knox_bits_download(ctx, bits, host.data()) == 0);
+        // serve: pack p's bitset is the slice starting at byte p * pack / 8; its count is pc[p]
+        size_t first = 0;
+        for (size_t p = 0; p < np; p++) {
+            int64_t cnt = 0;
+            bool same = true;
+            for (size_t i = 0; i < va[p].size(); i++) {
+                const bool h = va[p][i] >= -500 && va[p][i] <= 500 && vb[p][i] >= 10;
+                cnt += h;
+                same &= (((host[(first + i) >> 3] >> ((first + i) & 7)) & 1) != 0) == h;
+                if (h) want_sum += (uint64_t)va[p][i], want_max = std::max(want_max, vb[p][i]);
+            }
+            EXPECT(same);
+            EXPECT(pc[p] == cnt);
+            if (p == 2) EXPECT(pc[p] == 0);
+            want_total += cnt;
+            first += va[p].size();
+        }
+        got_total += out.count;
+        run_sum.push_back(st[0]), run_max.push_back(st[1]);
+        row_base += rows;
+        knox_bits_free(bits);
+    }
+    EXPECT(got_total == want_total);
+    // GpuRun.Value: Combine of the runs' states in run order, then Reducer.Value()
+    knox_agg_state ms_, mm_;
+    EXPECT(knox_agg_combine(run_sum.data(), (int)run_sum.size(), &ms_) == 0 && knox_agg_combine(run_max.data(), (int)run_max.size(), &mm_) == 0);
+    uint64_t v = 0;
+    int32_t mx = 0;
+    int seen = 0;
+    int64_t row = -1;
+    EXPECT(knox_agg_value(&ms_, KNOX_R_SUM, &v, &seen, &row) == 0 && seen && v == want_sum);
+    EXPECT(knox_agg_value(&mm_, KNOX_R_MAX, &mx, &seen, &row) == 0 && seen && mx == want_max && row >= 0 && (uint64_t)row < row_base);
+    // over capacity: KNOX_E_RANGE, the column stays as it was
+    {
+        std::vector<int64_t> big(max_packs * pack + 1, 1);
+        EXPECT(knox_col_reset(ctx, ca) == 0);
+        EXPECT(knox_col_append_async(ctx, ca, big.data(), big.size()) == KNOX_E_RANGE && knox_col_rows(ca) == 0);
+    }
+    knox_col_free(ca), knox_col_free(cb);
+
+    // an ENCODED run: every pack's block arrives as its raw container [7][uvarint n][LE values] (int_raw.go:73-94) and the
+    // run's column is made by ONE knox_col_upload_raw_containers (UploadRawContainers: C copies of the Go buffers + a C
+    // array of pointers)
+    {
+        const size_t np = 4;
+        std::vector<std::vector<uint8_t>> bufs(np);
+        std::vector<std::vector<int64_t>> vals(np);
+        for (size_t p = 0; p < np; p++) {
+            vals[p].resize(pack);
+            for (auto &x : vals[p]) x = (int64_t)(rnd() % 2001) - 1000;
+            bufs[p].push_back(7);
+            put_uvarint(bufs[p], pack);
+            const uint8_t *raw = (const uint8_t *)vals[p].data();
+            bufs[p].insert(bufs[p].end(), raw, raw + pack * 8);
+        }
+        uint8_t **ptrs = (uint8_t **)std::malloc(np * sizeof(uint8_t *));
+        size_t *lens = (size_t *)std::malloc(np * sizeof(size_t));
+        for (size_t p = 0; p < np; p++) {
+            ptrs[p] = (uint8_t *)std::malloc(bufs[p].size());  // C.CBytes
+            std::memcpy(ptrs[p], bufs[p].data(), bufs[p].size());
+            lens[p] = bufs[p].size();
+        }
+        knox_col *col = nullptr;
+        EXPECT(knox_col_upload_raw_containers(ctx, KNOX_INT64, ptrs, lens, np, pack, &col) == 0);
+        for (size_t p = 0; p < np; p++) std::free(ptrs[p]);
+        std::free(ptrs), std::free(lens);
+        EXPECT(col && knox_col_rows(col) == np * pack);
+        knox_pred leaf;
+        std::memset(&leaf, 0, sizeof leaf);
+        leaf.kind = KNOX_NODE_LEAF, leaf.op = KNOX_LT, leaf.a = (uint64_t)(int64_t)-900;
+        knox_bits *bits = nullptr;
+        EXPECT(knox_bits_alloc(ctx, np * pack, &bits) == 0);
+        knox_col *cols[1] = {col};
+        knox_agg none[1] = {{0, 0}};
+        std::vector<int64_t> pc(np, -1);
+        knox_scan_out out;
+        EXPECT(knox_scan(ctx, &leaf, 1, cols, 1, none, 0, 0, nullptr, bits, pc.data(), nullptr, &out) == 0);
+        for (size_t p = 0; p < np; p++) {
+            int64_t cnt = 0;
+            for (auto x : vals[p]) cnt += x < -900;
+            EXPECT(pc[p] == cnt);
+        }
+        knox_bits_free(bits), knox_col_free(col);
+    }
+}
+
+// operator_knoxgpu.go (deviceCols.get / evictOthers): under a tiny arena budget an upload fails with KNOX_E_NOMEM; the
+// cache frees columns of OTHER packages only and retries; the handles of the package being planned stay valid.
+static void go_EvictOthers() {
+    knox_ctx *ctx = nullptr;
+    if (knox_ctx_open(0, &ctx) != 0) return;
+    EXPECT(knox_ctx_set_arena(ctx, (size_t)3 << 30) == 0);  // room for two 1 GiB columns beside the arena's own heap chunk
+    const size_t n = (size_t)1 << 27;                       // 1 GiB of int64 per column
+    std::vector<int64_t> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = (int64_t)(i & 1023);
+    std::vector<knox_col *> resident;   // d.order: columns of earlier packages
+    std::vector<knox_col *> mine;       // columns of the package being planned
+    int failures = 0;
+    for (int k = 0; k < 6; k++) {
+        knox_col *c = nullptr;
+        int rc = knox_col_upload(ctx, KNOX_INT64, v.data(), n, 0, &c);
+        if (rc == KNOX_E_NOMEM) {
+            failures++;
+            // evictOthers: the oldest columns that do not belong to this package
+            EXPECT(!resident.empty());
+            if (resident.empty()) break;
+            const size_t drop = (resident.size() + 1) / 2;
+            for (size_t i = 0; i < drop; i++) knox_col_free(resident[i]);
+            resident.erase(resident.begin(), resident.begin() + (long)drop);
+            rc = knox_col_upload(ctx, KNOX_INT64, v.data(), n, 0, &c);
+        }
+        EXPECT(rc == 0 && c != nullptr);
+        if (!c) break;
+        if (k < 4) resident.push_back(c);  // earlier packages
+        else mine.push_back(c);            // two leaves of the current package: both handles must survive the evictions
+    }
+    EXPECT(failures >= 1);                 // the budget really was too small for everything
+    EXPECT(mine.size() == 2);
+    if (mine.size() == 2) {
+        knox_pred nodes[3];
+        std::memset(nodes, 0, sizeof nodes);
+        nodes[0].kind = KNOX_NODE_LEAF, nodes[0].col = 0, nodes[0].op = KNOX_LT, nodes[0].a = 8;
+        nodes[1].kind = KNOX_NODE_LEAF, nodes[1].col = 1, nodes[1].op = KNOX_GE, nodes[1].a = 4;
+        nodes[2].kind = KNOX_NODE_AND, nodes[2].nchild = 2;
+        knox_agg none[1] = {{0, 0}};
+        knox_scan_out out;
+        EXPECT(knox_scan(ctx, nodes, 3, mine.data(), 2, none, 0, 0, nullptr, nullptr, nullptr, nullptr, &out) == 0);
+        EXPECT(out.count == (int64_t)(n / 1024 * 4));
+    }
+    for (auto c : resident) knox_col_free(c);
+    for (auto c : mine) knox_col_free(c);
+    knox_ctx_close(ctx);
 }
 
 int main() {
@@ -268,10 +473,22 @@ int main() {
             int64_t cnt = 3;
             EXPECT(knox_comm_allgather_states(ctx, &mine, 1, &merged, &cnt) == 0);
             EXPECT(cnt == 3 && merged.isum == 42 && merged.count == 3);
+            // AllReduceSumCountStart / Finish (FIFO of 4 on the collective stream) and CommRanks = ncclCommCount
+            for (int k = 0; k < 4; k++) EXPECT(knox_comm_allreduce_sum_count_start(ctx, 1000ull + (uint64_t)k, 10 + k) == 0);
+            EXPECT(knox_comm_allreduce_sum_count_start(ctx, 1, 1) == KNOX_E_BUSY);
+            for (int k = 0; k < 4; k++) {
+                uint64_t s2 = 0;
+                int64_t c2 = 0;
+                EXPECT(knox_comm_allreduce_sum_count_finish(ctx, &s2, &c2) == 0 && s2 == 1000ull + (uint64_t)k && c2 == 10 + k);
+            }
+            int nr = 0, rk = -1;
+            EXPECT(knox_comm_ranks(ctx, &nr, &rk) == 0 && nr == 1 && rk == 0);
             knox_comm_destroy(ctx);
         }
     }
+    go_RunReader(ctx);
     knox_ctx_close(ctx);
+    go_EvictOthers();
     std::printf(fails ? "FAILED: %d\n" : "go entries ok\n", fails);
     return fails ? 1 : 0;
 }

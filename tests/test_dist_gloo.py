@@ -106,3 +106,21 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "no HIP device visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_abi_collective_reaches_the_id_exchange_in_every_rank():
+    """`bench.py --gpus 2 --collective abi`: the per-step exchange is the library's own RCCL communicator (knox_comm_*, what
+    a Go host calls).  Rank 0 makes the ncclUniqueId, the process group carries its 128 bytes to every rank, then each rank
+    calls knox_comm_init on its device.  Here (gloo rehearsal, possibly no GPU) both children must get as far as holding
+    the id; on a box without a device they then refuse to run (no CPU fallback), with one they bring the communicator up."""
+    import subprocess
+    env = dict(os.environ, KNOX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--collective", "abi", "--steps", "1", "--warmup", "1",
+                        "--rows-log2", "20", "--no-cpu-baseline", "--no-configs"], env=env, capture_output=True, text=True, timeout=300)
+    for rank in (0, 1):
+        assert "[rank %d] abi collective: unique id exchanged (128 bytes)" % rank in r.stderr, r.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no HIP device visible" in r.stderr and r.stdout.strip() == ""
