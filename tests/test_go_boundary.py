@@ -76,3 +76,41 @@ def test_matcher_and_operator_files_implement_the_reference_interfaces():
                 r"func \(r \*GpuAggregateResult\) Append\(ctx context\.Context, src \*pack\.Package\) error",
                 r"func \(r \*GpuAggregateResult\) Len\(\) int"):
         assert re.search(sig, op), sig
+
+
+def test_run_level_reader_is_committed_source_with_the_readers_contract():
+    """integration/go/run_knoxgpu.go: many packs resident, ONE scan per run, per-pack results served to the unchanged tail of
+    the reference's loop (reader.go:288-450); QueryStats gets the device's share (internal/query/stats.go:58-74)"""
+    run = open(os.path.join(GO, "run_knoxgpu.go")).read()
+    assert re.search(r"^package table$", run, flags=re.M)
+    assert re.search(r"func \(r \*Reader\) nextQueryMatchGpu\(ctx context\.Context\) \(\*pack\.Package, error\)", run)
+    assert re.search(r"func \(g \*GpuRun\) WithQuery\(n \*filter\.Node, aggs \[\]knoxgpu\.Agg\) bool", run)
+    body = run[run.index("func (g *GpuRun) scan("):run.index("// nextQueryMatchGpu has nextQueryMatch's contract")]
+    assert body.count("g.gpu.Scan(") == 1 and "true, len(g.packs))" in body          # ONE scan per run, with per-pack counts
+    assert body.count("bits.Download(") == 1                                           # ONE copy of the run's bitset
+    assert "UploadRawContainers" in body and "knoxgpu.AppendAsync(" in run             # encoded and materialized blocks
+    for key in ("GPU_RUNS_KEY", "GPU_ROWS_SCANNED_KEY", "GPU_SCAN_USEC_KEY", "GPU_INGEST_USEC_KEY", "PACKS_SCHEDULED_KEY"):
+        assert "Count(%s" % key in run, key
+    assert "r.finishMatch(ctx, pk.key, pk.ver, pk.n)" in run and "ResetCount(int(pk.count))" in run
+    op = open(os.path.join(GO, "operator_knoxgpu.go")).read()
+    assert "evictOthers(k.pack, k.version" in op and "func (d *deviceCols) evict(" not in op   # no eviction of the package being planned
+
+
+def test_the_checker_rejects_a_context_call_outside_the_lock(tmp_path):
+    mod = _checker()
+    work = tmp_path / "go"
+    shutil.copytree(GO, work)
+    path = work / "knoxgpu" / "knoxgpu.go"
+    src = path.read_text()
+    i = src.index("func (b *Bits) Free() {")
+    j = src.index("}", i)
+    bad = src[:i] + "func (b *Bits) Free() {\n\tC.knox_bits_free(b.p)\n" + src[j:]
+    k = bad.index("func NewBits(c *Ctx, size int) (*Bits, error) {")
+    bad = bad[:k] + bad[k:].replace("\tc.mu.Lock()\n\tdefer c.mu.Unlock()\n", "", 1)
+    assert bad != src
+    path.write_text(bad)
+    mod.GO_DIR = str(work)
+    errors, _, _, _ = mod.check()
+    text = "\n".join(errors)
+    assert "knox_bits_free: called without the context's lock" in text
+    assert "knox_bits_alloc: called without the context's lock" in text
