@@ -619,7 +619,7 @@ def main():
         # bitset is a write buffer chosen by running the scan on the (column, buffer) pair; nothing is held outside it
         "placement": {"arena_enabled": ai["enabled"], "arena_budget_gib": ai["budget_gib"], "arena_mapped_gib": ai["mapped_gib"],
                       "arena_used_gib": ai["used_gib"], "write_buffers_created": ai["write_buffers"], "spare_write_buffer_gib": ai["spare_write_buffer_gib"],
-                      "chunks_created": ai["chunks"], "probe_measurements": ai["probes"], "transient_spacer_gib": ai["transient_spacer_gib"],
+                      "chunks_created": ai["chunks"], "probe_measurements": ai["probes"], "mixed_zone_gib": ai["mixed_zone_gib"],
                       "bitset_pair_check_at_allocation": {"scan_over_read_only": bits.pair_check[0], "candidate_windows": bits.pair_check[1]},
                       "held_outside_arena_bytes": ctx.placement_info()["held_bytes"], "setup_checks": checks, "setup_s": t_setup},
     }

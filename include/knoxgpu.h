@@ -125,8 +125,9 @@ typedef struct knox_arena_info {
     uint64_t used_bytes;       /* handed out to columns / bitsets / scratch right now       */
     uint64_t peak_used_bytes;
     uint64_t spare_write_buffer_bytes; /* write buffers that were candidates or were freed: the first candidates of the next request */
-    uint64_t transient_spacer_bytes;   /* always 0 since ABI 4 (an earlier search skipped ahead in the driver's allocation
-                                          order with transient allocations; the field keeps the struct layout)       */
+    uint64_t mixed_zone_bytes;         /* chunks moved out of their class zones into one mixed-class region: columns that fit
+                                          no single class zone although the arena had the room (classes interleaving every
+                                          few GiB); 0 on every device seen so far                                        */
     int32_t write_buffers, chunks, probes; /* write buffers created, 1 GiB chunks created, probe measurements taken */
     int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
 } knox_arena_info;

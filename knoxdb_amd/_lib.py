@@ -50,7 +50,7 @@ class AggState(C.Structure):
 class ArenaInfo(C.Structure):
     """knox_arena_info -- the context's device-memory arena."""
     _fields_ = [("budget_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64), ("used_bytes", C.c_uint64), ("peak_used_bytes", C.c_uint64),
-                ("spare_write_buffer_bytes", C.c_uint64), ("transient_spacer_bytes", C.c_uint64), ("write_buffers", C.c_int32),
+                ("spare_write_buffer_bytes", C.c_uint64), ("mixed_zone_bytes", C.c_uint64), ("write_buffers", C.c_int32),
                 ("chunks", C.c_int32), ("probes", C.c_int32), ("enabled", C.c_int32)]
 
 

@@ -82,7 +82,7 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
     size_t budget = total_b / 4 * 3;
     env = getenv("KNOX_ARENA_GIB");
     if (env && atof(env) > 0) budget = (size_t)(atof(env) * (double)((size_t)1 << 30));
-    c->arena.configure(device, budget, arena_probe, c);
+    c->arena.configure(device, budget, arena_probe, c, arena_probe_multi);
     *out = c;
     return KNOX_OK;
 }
@@ -97,7 +97,8 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
-                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->sort_buf, &ctx->bytes_val, &ctx->ring_dev};
+                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->sort_buf, &ctx->bytes_val, &ctx->ring_dev,
+                      &ctx->tmp_bits_parked[0], &ctx->tmp_bits_parked[1]};
     for (DevBuf *b : bufs) dev_free(ctx, b->p);
     if (ctx->comm_buf.p) hipFree(ctx->comm_buf.p);
     if (ctx->probe_partials) hipFree(ctx->probe_partials);
@@ -213,7 +214,7 @@ KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
     out->spare_write_buffer_bytes = ctx->arena.spare_bytes();
     out->chunks = ctx->arena.chunks_created;
     out->probes = ctx->arena.probes_run;
-    out->transient_spacer_bytes = ctx->arena.spacer_bytes_used;
+    out->mixed_zone_bytes = ctx->arena.mixed_bytes;
     out->enabled = ctx->placement && ctx->arena.usable;
     return KNOX_OK;
 }
@@ -424,6 +425,64 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
     return ((double)ro[n_ro / 2] / 8.0) / ((double)mix[n_mix / 2] / 8.125);
 }
 double arena_probe(void *user, const void *col, uint64_t rows, void *bits) { return probe_pair((knox_ctx *)user, col, rows, bits); }
+
+// The short form for labelling a new chunk once two or more classes are known: ONE launch sequence measures the region
+// against every class's reference window -- 2 ramp launches, then read-only, scan(ref 0) .. scan(ref n-1), scan(ref n-1) ..
+// scan(ref 0), read-only (the mirrored order cancels a linear clock drift) = 2 + 2 (n + 1) launches: 8 for two classes
+// instead of 20-40 per class.  A reading near the threshold is taken again by the caller with the long form.
+static int probe_multi(knox_ctx *ctx, const void *p, uint64_t rows, void *const *bits, int n, double *ratios) {
+    const uint32_t iters = 2;
+    const uint64_t tr = (uint64_t)tile_rows(8) * iters;
+    if (rows < tr || rows % tr || n < 1 || n > 4) return -1;
+    const int grid = ctx->n_cus * 2;
+    if (!ctx->probe_partials && hipMalloc(&ctx->probe_partials, sizeof(AggPartial) * (size_t)(grid + 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->probe_partials = nullptr;
+        return -1;
+    }
+    const int n_l = 2 + 2 * (n + 1);
+    for (int i = 0; i <= n_l; i++)
+        if (!ctx->probe_ev[i] && hipEventCreate(&ctx->probe_ev[i]) != hipSuccess) return -1;
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.leaf[0].col = p;
+    a.leaf[0].diff = ~0ull >> 2;
+    a.tt = 2;
+    a.agg_col = p;
+    a.agg_flavor = FL_SIGNED;
+    a.iters = iters;
+    a.n_tiles = rows / tr;
+    a.n_rows = rows;
+    a.tail_first_row = rows;
+    a.pack_shift = 255;
+    a.partials = (AggPartial *)ctx->probe_partials;
+    const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
+    // which buffer launch i writes: -1 = read-only
+    int which[2 + 2 * (4 + 1)];
+    int k = 0;
+    which[k++] = -1, which[k++] = 0;                       // ramp
+    which[k++] = -1;
+    for (int c = 0; c < n; c++) which[k++] = c;
+    for (int c = n - 1; c >= 0; c--) which[k++] = c;
+    which[k++] = -1;
+    if (hipEventRecord(ctx->probe_ev[0], ctx->stream) != hipSuccess) return -1;
+    for (int i = 0; i < n_l; i++) {
+        a.bits = which[i] < 0 ? nullptr : (uint32_t *)bits[which[i]];
+        if (launch_probe_scan(ctx->stream, g, a) != hipSuccess || hipEventRecord(ctx->probe_ev[i + 1], ctx->stream) != hipSuccess) return -1;
+    }
+    if (hipEventSynchronize(ctx->probe_ev[n_l]) != hipSuccess) return -1;
+    double ro = 0.0, mix[4] = {0, 0, 0, 0};
+    for (int i = 2; i < n_l; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->probe_ev[i], ctx->probe_ev[i + 1]) != hipSuccess || ms <= 0.f) return -1;
+        if (which[i] < 0) ro += ms; else mix[which[i]] += ms;
+    }
+    for (int c = 0; c < n; c++) ratios[c] = (ro / 8.0) / (mix[c] / 8.125);
+    return 0;
+}
+int arena_probe_multi(void *user, const void *col, uint64_t rows, void *const *bits, int n, double *ratios) {
+    return probe_multi((knox_ctx *)user, col, rows, bits, n, ratios);
+}
 
 int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bool alloc, knox_col **out) {
     if (!ctx || !out) return KNOX_E_INVALID;
@@ -795,14 +854,36 @@ int ensure_for(knox_ctx *ctx, DevBuf &b, size_t bytes, const knox_col *col) {
     if (col && col->n_rows) col_stream(col, &cp, &cb);
     if (!ctx->placement || !cp || cb < ((size_t)1 << 30) || bytes < ((size_t)16 << 20)) return ensure(ctx, b, bytes, ARENA_WRITE);
     if (b.cap >= bytes && b.for_col == cp) return KNOX_OK;
+    // A workload that alternates between columns keeps its verified buffers: the one in use is parked (keyed by the
+    // column region it was verified against -- a verdict is about physical memory, so it survives the column object) and a
+    // parked one that fits comes back without a single probe launch.  Two are kept; the oldest goes when a third arrives.
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the stream may still be using b
+    if (&b == &ctx->tmp_bits) {
+        for (DevBuf &pk : ctx->tmp_bits_parked) {
+            if (pk.p && pk.for_col == cp && pk.cap >= bytes) {
+                std::swap(b, pk);
+                return KNOX_OK;
+            }
+        }
+        if (b.p && b.for_col) {
+            DevBuf *slot = nullptr;
+            for (DevBuf &pk : ctx->tmp_bits_parked)
+                if (!pk.p) { slot = &pk; break; }
+            if (!slot) {
+                slot = &ctx->tmp_bits_parked[ctx->tmp_bits_park_next];
+                ctx->tmp_bits_park_next = (ctx->tmp_bits_park_next + 1) % (int)(sizeof ctx->tmp_bits_parked / sizeof ctx->tmp_bits_parked[0]);
+                dev_free(ctx, slot->p);
+            }
+            *slot = b;
+            b = DevBuf();
+        }
+    }
     if (b.p) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         dev_free(ctx, b.p);
         b.p = nullptr;
         b.cap = 0;
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t cap = (std::max(bytes, b.cap) + 255) & ~(size_t)255;
+    const size_t cap = (bytes + 255) & ~(size_t)255;
     hipError_t e = ctx->arena.alloc_write_for(&b.p, cap, cp, cb, (double)cb / (double)col->n_rows, nullptr, nullptr);
     if (e == hipErrorNotSupported) return ensure(ctx, b, bytes, ARENA_WRITE);
     if (e != hipSuccess) {
@@ -1514,9 +1595,9 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // 2 no store, 3 plain store, 4 write-through store
 #endif
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
-    if (slot != 15) prof_mark(ctx, 0);
+    prof_mark(ctx, 0);  // also the leaf passes of a multi-pass plan (slot 15): knox_prof_read then sums a scan's leaf kernels
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, a);
-    if (slot != 15) prof_mark(ctx, 1);
+    prof_mark(ctx, 1);
     const bool has_tail = a.tail_first_row < a.n_rows;
     if (e == hipSuccess && has_tail) e = launch_scan_tail(ctx->stream, width, n_leaves, agg, g, a);
     char *res = ctx->res_dst ? ctx->res_dst : (char *)ctx->states.p;

@@ -50,6 +50,8 @@ enum ArenaKind { ARENA_READ = 0, ARENA_WRITE = 1 };
 // read-only form of the same scan, measured with ALTERNATING launches (whatever else disturbs the device -- the driver
 // clearing freshly taken or released memory costs bandwidth for seconds -- hits both alike); <= 0 = failed
 typedef double (*ArenaProbeFn)(void *user, const void *col, uint64_t rows, void *bits);
+// the same region against n write buffers in ONE short launch sequence (labelling a chunk once >= 2 classes are known): 0 = ok
+typedef int (*ArenaProbeMultiFn)(void *user, const void *col, uint64_t rows, void *const *bits, int n, double *ratios);
 
 // Three facts about the HIP virtual-memory API on this stack (ROCm 7.2), all measured (tools/vmm_remap_check*.py):
 //  1. a virtual address that has been mapped to one physical allocation must never be mapped to another: after
@@ -104,12 +106,13 @@ class Arena {
     bool usable = false;
     size_t budget = 0, mapped_total = 0, peak_used = 0;
     int chunks_created = 0, probes_run = 0, write_buffers = 0;
-    size_t spacer_bytes_used = 0;  // always 0 (the transient spacers of earlier versions are gone; kept for the info struct)
+    size_t mixed_bytes = 0;  // chunks moved out of their class zones into the mixed region (columns no single class could hold)
 
-    void configure(int device_, size_t budget_, ArenaProbeFn fn, void *user_) {
+    void configure(int device_, size_t budget_, ArenaProbeFn fn, void *user_, ArenaProbeMultiFn multi_ = nullptr) {
         device = device_;
         budget = budget_;
         probe = fn;
+        probe_multi = multi_;
         user = user_;
     }
     size_t used_bytes() const { return used; }
@@ -382,6 +385,7 @@ class Arena {
 
     int device = 0;
     ArenaProbeFn probe = nullptr;
+    ArenaProbeMultiFn probe_multi = nullptr;
     void *user = nullptr;
     bool inited = false;
     size_t used = 0;
@@ -389,7 +393,8 @@ class Arena {
     char *ref_va[kMaxClasses] = {nullptr, nullptr, nullptr, nullptr};  // class c's reference window; c >= 1: the first 32 MiB of zone c
     int n_refs = 0;
     int grown_for_write = 0;
-    Zone zones[kMaxClasses];
+    Zone zones[kMaxClasses + 1];  // [kMaxClasses]: the mixed region (chunks of several classes, see mixed_alloc)
+    bool fake_labels = false;     // test hook (KNOX_ARENA_FAKE_LABELS=1): chunks are labelled class 0, 1, 0, 1 ... without probing
     std::vector<Extent> heap;
     std::vector<WBuf> spares;
     std::map<char *, Small> smalls;
@@ -412,6 +417,7 @@ class Arena {
     }
     static void drop_extent(Extent &e) {  // mapping by mapping, as they were made
         for (size_t i = 0; i < e.chunks.size(); i++) {
+            if (!e.chunks[i]) continue;  // moved into the mixed region (mixed_alloc): unmapped there, released there
             (void)hipMemUnmap(e.va + i * kChunk, kChunk);
             (void)hipMemRelease(e.chunks[i]);
         }
@@ -526,6 +532,7 @@ class Arena {
     bool init_once() {
         if (inited) return usable;
         inited = true;
+        fake_labels = getenv("KNOX_ARENA_FAKE_LABELS") != nullptr && atoi(getenv("KNOX_ARENA_FAKE_LABELS")) != 0;
         usable = grow_heap();  // no virtual-memory API, or not even one chunk: the caller falls back to plain hipMalloc
         return usable;
     }
@@ -571,7 +578,9 @@ class Arena {
         chunks_created++;
         int label = 1;
         bool founder = false;  // the first chunk of a class not met before: its first 32 MiB become that class's reference window
-        if (probe) {
+        if (fake_labels) {
+            label = 1 + (chunks_created & 1);  // tests: classes that interleave chunk by chunk, the worst case for class-pure zones
+        } else if (probe) {
             if (!ref.va) {
                 if (!new_wbuf(kRefBytes, &ref)) {
                     (void)hipMemRelease(h);
@@ -595,9 +604,23 @@ class Arena {
             // them = a class of its own
             int cls = -1, closest = 0;
             double lowest = 2.0;
+            // two or more classes known: all of them in ONE short launch sequence (8 launches for two classes); only a
+            // reading near the threshold goes through the long form below
+            double quick[kMaxClasses] = {0, 0, 0, 0};
+            bool have_quick = false;
+            if (probe_multi && n_refs >= 2) {
+                void *refs[kMaxClasses];
+                for (int c = 0; c < n_refs; c++) refs[c] = ref_va[c];
+                have_quick = probe_multi(user, pva, kProbeRows, refs, n_refs, quick) == 0;
+                if (have_quick) probes_run++;
+            }
             for (int c = 0; c < n_refs && cls < 0; c++) {
                 double r = 0.0;
                 for (int rep = 0; rep < 2; rep++) {  // a reading near the threshold is taken again and averaged
+                    if (rep == 0 && have_quick && (quick[c] < 0.90 || quick[c] > 0.975)) {
+                        r = quick[c];
+                        break;
+                    }
                     const double x = probe(user, pva, kProbeRows, ref_va[c]);
                     probes_run++;
                     if (x <= 0.0) { r = 0.0; break; }
@@ -660,9 +683,85 @@ class Arena {
         }
         return label - 1;
     }
+    // A column that fits no single class zone although the arena has the room (classes that interleave every few GiB
+    // strand free chunks in every zone): wholly free chunks are taken OUT of their zones -- unmapped there, the hole in the
+    // zone's address range is never used again (VMM fact 1) -- and mapped back to back into a fresh reservation of the mixed
+    // region.  Such a column is not class pure; the write buffers of its scans are verified per (column, buffer) pair like
+    // all others, they just cannot rely on "another class's zone" being fast by construction.
+    hipError_t mixed_alloc(void **out, size_t bytes) {
+        const size_t need = (bytes + kChunk - 1) / kChunk;
+        struct Loc { int zi; size_t ei, ci; };
+        std::vector<Loc> found;
+        for (int zi = 0; zi < kMaxClasses && found.size() < need; zi++)
+            for (size_t ei = 0; ei < zones[zi].extents.size() && found.size() < need; ei++) {
+                Extent &e = zones[zi].extents[ei];
+                for (auto &fr : e.free) {
+                    size_t c0 = (fr.first + kChunk - 1) / kChunk, c1 = (fr.first + fr.second) / kChunk;
+                    for (size_t ci = c0; ci < c1 && found.size() < need; ci++)
+                        if (e.chunks[ci]) found.push_back(Loc{zi, ei, ci});
+                }
+            }
+        // what the free chunks do not cover comes fresh from the driver (labelled or not, it ends up in the mixed region)
+        std::vector<hipMemGenericAllocationHandle_t> fresh;
+        while (found.size() + fresh.size() < need) {
+            hipMemGenericAllocationHandle_t h;
+            if (!create(kChunk, &h)) break;
+            chunks_created++;
+            fresh.push_back(h);
+        }
+        if (found.size() + fresh.size() < need) {
+            for (auto h : fresh) {
+                (void)hipMemRelease(h);
+                mapped_total -= kChunk;
+            }
+            return hipErrorOutOfMemory;
+        }
+        char *va = VaBump::take(need * kChunk);
+        if (!va) {
+            for (auto h : fresh) {
+                (void)hipMemRelease(h);
+                mapped_total -= kChunk;
+            }
+            return hipErrorOutOfMemory;
+        }
+        Zone &mz = zones[kMaxClasses];
+        mz.regions.push_back({va, need * kChunk});
+        Extent me;
+        me.va = va;
+        size_t k = 0;
+        for (const Loc &l : found) {
+            Extent &e = zones[l.zi].extents[l.ei];
+            if (!take_at(e.free, l.ci * kChunk, kChunk)) continue;  // cannot happen: the range was free a moment ago
+            (void)hipMemUnmap(e.va + l.ci * kChunk, kChunk);
+            const hipMemGenericAllocationHandle_t h = e.chunks[l.ci];
+            e.chunks[l.ci] = nullptr;
+            zones[l.zi].mapped -= kChunk;
+            if (!map_at(va + k * kChunk, h, kChunk)) return hipErrorOutOfMemory;
+            me.chunks.push_back(h);
+            k++;
+        }
+        for (auto h : fresh) {
+            if (!map_at(va + k * kChunk, h, kChunk)) return hipErrorOutOfMemory;
+            me.chunks.push_back(h);
+            k++;
+        }
+        me.len = k * kChunk;
+        me.free[0] = me.len;
+        mz.mapped += me.len;
+        mixed_bytes += me.len;
+        mz.extents.push_back(me);
+        dbg("mixed region: %zu chunks (%zu out of class zones, %zu fresh) for a request of %zu bytes", k, found.size(), fresh.size(), bytes);
+        size_t off = 0;
+        Extent &ne = mz.extents.back();
+        if (!take(ne.free, bytes, &off)) return hipErrorOutOfMemory;
+        smalls[ne.va + off] = Small{kMaxClasses, (int)(mz.extents.size() - 1), off, bytes};
+        account(bytes);
+        *out = ne.va + off;
+        return hipSuccess;
+    }
     hipError_t zone_alloc(void **out, size_t bytes) {
         for (;;) {
-            for (int zi = 0; zi < kMaxClasses; zi++)
+            for (int zi = 0; zi <= kMaxClasses; zi++)
                 for (size_t ei = 0; ei < zones[zi].extents.size(); ei++) {
                     size_t off = 0;
                     if (!take(zones[zi].extents[ei].free, bytes, &off)) continue;
@@ -671,9 +770,12 @@ class Arena {
                     *out = zones[zi].extents[ei].va + off;
                     return hipSuccess;
                 }
-            if (grow_zone() < 0) {
-                dbg("zone_alloc: %zu bytes do not fit (mapped %zu of %zu)", bytes, mapped_total, budget);
-                return hipErrorOutOfMemory;
+            // one more chunk while the budget allows it AND a class zone can still come to hold the request; otherwise the
+            // free chunks of all zones together (mixed region)
+            if (mapped_total + kChunk > budget || grow_zone() < 0) {
+                const hipError_t e = mixed_alloc(out, bytes);
+                if (e != hipSuccess) dbg("zone_alloc: %zu bytes do not fit (mapped %zu of %zu)", bytes, mapped_total, budget);
+                return e;
             }
         }
     }

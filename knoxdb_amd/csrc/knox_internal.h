@@ -64,6 +64,8 @@ struct knox_ctx {
     DevBuf states;       // AggStateDev[slots] + int64 count
     DevBuf tmp_vals;     // knox_cmp: staged values
     DevBuf tmp_bits;     // scratch bitset(s)
+    DevBuf tmp_bits_parked[2];  // verified scratch of the columns scanned before (ensure_for): switching back costs no probes
+    int tmp_bits_park_next = 0;
     DevBuf pack_skip;    // device copy of the caller's pack_skip bytes
     DevBuf pack_counts;  // int64 per pack
     DevBuf misc;         // flags / counters / small outputs
@@ -204,6 +206,7 @@ static inline bool dtype_is_signed(int dtype) { return dtype >= KNOX_INT64 && dt
 static inline uint32_t dtype_flavor(int dtype) { return dtype_is_float(dtype) ? FL_FLOAT : dtype_is_signed(dtype) ? FL_SIGNED : FL_UNSIGNED; }
 
 double arena_probe(void *user, const void *col, uint64_t rows, void *bits);
+int arena_probe_multi(void *user, const void *col, uint64_t rows, void *const *bits, int n, double *ratios);
 
 // Device memory of a context: the arena when placement is on (kind READ = columns / payloads the scans stream through,
 // kind WRITE = bitsets / scratch they write), plain hipMalloc when it is off or the device has no virtual-memory API.

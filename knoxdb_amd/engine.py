@@ -345,7 +345,7 @@ class Context:
         check(self.L.knox_ctx_arena_info(self.h, C.byref(a)))
         return {"budget_gib": a.budget_bytes / 2**30, "mapped_gib": a.mapped_bytes / 2**30, "used_gib": a.used_bytes / 2**30,
                 "peak_used_gib": a.peak_used_bytes / 2**30, "write_buffers": a.write_buffers, "chunks": a.chunks, "probes": a.probes,
-                "enabled": bool(a.enabled), "transient_spacer_gib": a.transient_spacer_bytes / 2**30,
+                "enabled": bool(a.enabled), "mixed_zone_gib": a.mixed_zone_bytes / 2**30,
                 "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30}
 
     def arena_trim(self):

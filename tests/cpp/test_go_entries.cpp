@@ -273,7 +273,9 @@ static void go_RunReader(knox_ctx *ctx) {
 static void go_EvictOthers() {
     knox_ctx *ctx = nullptr;
     if (knox_ctx_open(0, &ctx) != 0) return;
-    EXPECT(knox_ctx_set_arena(ctx, (size_t)3 << 30) == 0);  // room for two 1 GiB columns beside the arena's own heap chunk
+    // 6 GiB: the arena's own 1 GiB heap chunk + a 32 MiB reference window + two columns (a 1 GiB column with its
+    // padding takes two 1 GiB chunks of one class zone); the third upload does not fit
+    EXPECT(knox_ctx_set_arena(ctx, (size_t)6 << 30) == 0);
     const size_t n = (size_t)1 << 27;                       // 1 GiB of int64 per column
     std::vector<int64_t> v(n);
     for (size_t i = 0; i < n; i++) v[i] = (int64_t)(i & 1023);
