@@ -98,18 +98,21 @@ def test_interleaved_classes_fall_back_to_the_mixed_region():
 
 
 def test_no_memory_of_another_class_within_the_budget_is_reported_not_hidden():
-    """a budget that leaves room for one candidate write buffer only: the allocation succeeds with the best there is and
-    knox_bits_pair_check says what the pair measured (a host can see a degraded placement instead of guessing)"""
+    """once the column is placed the budget is lowered to what is mapped + room for ONE candidate write buffer: the search
+    cannot reach further (no second candidate, no more chunks), the allocation still succeeds with the best there is, and
+    knox_bits_pair_check says what the pair measured -- a host sees a degraded placement instead of guessing"""
     with K.Context(0) as ctx:
         n = (1 << 28) - (1 << 17)                 # 2 GiB - 1 MiB: two chunks
-        ctx.set_arena(3 * GIB + (96 << 20))       # heap chunk + the column's two + reference window + ONE 32 MiB candidate
+        ctx.set_arena(8 * GIB)
         col = ctx.generate(BlockType.Int64, 3, 0, n, lo=5, pack_rows=1 << 20)
+        mapped = int(ctx.arena_info()["mapped_gib"] * GIB)
+        ctx.set_arena(mapped + (48 << 20))        # a 34 MiB candidate fits once
         bits = ctx.bits(n, for_col=col)
         ratio, tried = bits.pair_check
         assert tried >= 1 and 0.5 < ratio < 1.1, (ratio, tried)
         r = ctx.scan(And(Leaf(0, FilterMode.Le, 104)), [col], aggs=[(R.Sum, 0)], bits_out=bits)
         assert r.count == 100 and int(r.value(0)[0]) == sum(range(5, 105)) and bits.count() == 100
-        assert ctx.arena_info()["mapped_gib"] * GIB <= 3 * GIB + (96 << 20)
+        assert ctx.arena_info()["mapped_gib"] * GIB <= mapped + (48 << 20)
         col.free()
         bits.free()
 
