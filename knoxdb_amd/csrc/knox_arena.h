@@ -276,7 +276,12 @@ class Arena {
         if (hit) return hipSuccess;
         // 3. no other class met yet (or its zone is full): take a few more chunks -- they stay as column space of their
         //    class -- and look again
-        for (int grown = 0; any_zone && grown < kMaxGrowForWrite && grown_for_write < 2 * kMaxGrowForWrite; grown++) {
+        // (columns in TWO classes -- a multi-leaf scan -- need memory of a third one: classes come in runs of 5-40 GiB of the
+        //  driver's allocation order, so that search may look four times as far)
+        int col_classes = 0;
+        for (bool z : in_zone) col_classes += z;
+        const int max_grow = col_classes >= 2 ? 4 * kMaxGrowForWrite : kMaxGrowForWrite;
+        for (int grown = 0; any_zone && grown < max_grow && grown_for_write < 2 * max_grow; grown++) {
             if (grow_zone() < 0) break;
             grown_for_write++;  // over the arena's life: a device whose free memory is one long run of one class is not mapped chunk by chunk in vain
             if (try_zones()) return hipSuccess;

@@ -745,6 +745,60 @@ template <int W, bool SUM> __device__ __forceinline__ uint32_t swar_load(const S
     return qq;
 }
 
+// The same contract as swar_load with the wave's compare unit instead of SWAR arithmetic (measured against it with
+// -DKNOX_NARROW_SWAR): per element ONE subtract that wraps at the element width (2-byte: v_pk_sub_u16 does both halves of
+// a dword at once; 1-byte: v_sub_u32_sdwa picks the byte, subtracts and keeps the low 8 bits), ONE compare against the
+// range width straight into an SGPR pair (SDWA selects the half word) and ONE add-with-carry that shifts the lane's bit
+// of that mask into the row-order word, highest element first: qq = 2 qq + hit.  2.5 (2-byte) / 3 (1-byte) VALU
+// operations per row where the SWAR form takes 8 / 5.5; the selected values' sum takes the 0/1 element masks
+// v_dot2 / v_dot4 want from the result bits with one 24-bit multiply (the partial products do not collide) and one AND.
+// lo_rep: the range's low end, in both halves of the dword (2-byte) / in the low byte (1-byte); vdiff: the range width,
+// clamped to the element's range.
+template <int W, bool SUM>
+__device__ __forceinline__ uint32_t narrow_load(const u32x4 &r, uint32_t lo_rep, uint32_t vdiff, uint32_t m1, uint32_t m0, uint32_t &sum32) {
+    static_assert(W == 1 || W == 2, "1- and 2-byte columns");
+    const uint32_t d[4] = {r.x, r.y, r.z, r.w};
+    uint32_t qq = 0;
+#pragma unroll
+    for (int w = 3; w >= 0; w--) {
+        if constexpr (W == 2) {
+            uint32_t t;
+            uint64_t m;
+            asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(d[w]), "v"(lo_rep));
+            asm("v_cmp_le_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0" : "=s"(m) : "v"(t), "v"(vdiff));
+            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(qq), "+s"(m));
+            asm("v_cmp_le_u16_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(m) : "v"(t), "v"(vdiff));
+            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(qq), "+s"(m));
+        } else {
+#define KNOX_BYTE_STEP(SEL)                                                                                                                        \
+    {                                                                                                                                              \
+        uint32_t t;                                                                                                                                \
+        uint64_t m;                                                                                                                                \
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD" : "=v"(t) : "v"(d[w]), "v"(lo_rep)); \
+        asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(t), "v"(vdiff));                                                                        \
+        asm("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(qq), "+s"(m));                                                                          \
+    }
+            KNOX_BYTE_STEP("BYTE_3") KNOX_BYTE_STEP("BYTE_2") KNOX_BYTE_STEP("BYTE_1") KNOX_BYTE_STEP("BYTE_0")
+#undef KNOX_BYTE_STEP
+        }
+    }
+    qq = (qq & m1) | (~qq & m0);  // hit / negated / constant (m1, m0: all ones or zero over the K result bits)
+    if constexpr (SUM) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if constexpr (W == 1) {
+                // bits b0..b3 of the nibble -> bytes 0x01 at 0, 8, 16, 24: nib * (1 + 2^7 + 2^14 + 2^21), all 16 partial products distinct
+                const uint32_t m4 = __umul24((qq >> (4 * w)) & 0xfu, 0x00204081u) & 0x01010101u;
+                sum32 = __builtin_amdgcn_udot4(d[w], m4, sum32, false);
+            } else {
+                const uint32_t m2 = __umul24((qq >> (2 * w)) & 0x3u, 0x00008001u) & 0x00010001u;
+                sum32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d[w]), __builtin_bit_cast(u16x2, m2), sum32, false);
+            }
+        }
+    }
+    return qq;
+}
+
 // One wave iteration of a 1- / 2-byte column with ANY aggregate class, whole 32-bit words at a time (the per-value
 // form above costs ~14 VALU operations per value: 24 % / 42 % of the HBM peak for int8 / int16 with all aggregates).
 // Per word of 4 (2) values:

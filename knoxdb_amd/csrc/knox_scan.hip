@@ -45,6 +45,12 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     const uint32_t m1 = (tt & 2u) ? QMASK : 0u, m0 = (tt & 1u) ? QMASK : 0u;
     Swar<(W <= 2 ? W : 1)> sw;
     if constexpr (W <= 2 && NL == 1) sw.init((uint32_t)lo[0], (uint32_t)diff[0], (tt & 2u) != 0, (tt & 1u) != 0);
+    // narrow_load's constants: the low end replicated the way the subtract wants it, the width clamped to the element range
+    uint32_t nlo = 0, ndiff = 0;
+    if constexpr (W <= 2 && NL == 1) {
+        nlo = W == 2 ? (((uint32_t)lo[0] & 0xffffu) * 0x00010001u) : ((uint32_t)lo[0] & 0xffu);
+        ndiff = (uint32_t)(diff[0] > (U)WT<W>::MASK ? (U)WT<W>::MASK : diff[0]);
+    }
     const int qshift = K * (lane & (G - 1));
     // order-key range the selected values of a plain single-leaf range predicate can take (narrow integer types): the
     // leaf's [lo, lo + diff] in key space when it does not wrap, the whole type otherwise
@@ -118,7 +124,11 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             uint32_t sum32 = 0;  // <= 64 values x 255 resp. 32 x 65535 per iteration
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
+#ifdef KNOX_NARROW_SWAR  // A/B builds: the SWAR form
                 q[u] = swar_load<W, AGG == A_ISUM>(sw, r[0][u], sum32);
+#else
+                q[u] = narrow_load<W, AGG == A_ISUM>(r[0][u], nlo, ndiff, m1, m0, sum32);
+#endif
                 cnt32 += __builtin_popcount(q[u]);
             }
             if constexpr (AGG == A_ISUM) acc.isum += sum32;
