@@ -613,7 +613,8 @@ class Arena {
             // reading near the threshold goes through the long form below
             double quick[kMaxClasses] = {0, 0, 0, 0};
             bool have_quick = false;
-            if (probe_multi && n_refs >= 2) {
+            static const bool quick_on = !(getenv("KNOX_ARENA_QUICK") && atoi(getenv("KNOX_ARENA_QUICK")) == 0);  // 0: long form only (A/B)
+            if (probe_multi && n_refs >= 2 && quick_on) {
                 void *refs[kMaxClasses];
                 for (int c = 0; c < n_refs; c++) refs[c] = ref_va[c];
                 have_quick = probe_multi(user, pva, kProbeRows, refs, n_refs, quick) == 0;
@@ -622,7 +623,7 @@ class Arena {
             for (int c = 0; c < n_refs && cls < 0; c++) {
                 double r = 0.0;
                 for (int rep = 0; rep < 2; rep++) {  // a reading near the threshold is taken again and averaged
-                    if (rep == 0 && have_quick && (quick[c] < 0.90 || quick[c] > 0.975)) {
+                    if (rep == 0 && have_quick && (quick[c] < 0.91 || quick[c] > 0.96)) {  // same class reads 0.86-0.90, another one 0.97-1.02
                         r = quick[c];
                         break;
                     }
@@ -632,7 +633,7 @@ class Arena {
                     r = rep == 0 ? x : 0.5 * (r + x);
                     if (r < 0.915 || r > 0.965) break;
                 }
-                dbg("chunk %d vs the reference window of class %d: %.3f", chunks_created, c, r);
+                dbg("chunk %d vs the reference window of class %d: %.3f%s", chunks_created, c, r, have_quick ? (r == quick[c] ? " (quick)" : " (long form after a quick reading near the threshold)") : "");
                 if (r > 0.0 && r < lowest) { lowest = r; closest = c; }
                 if (r > 0.0 && r < 0.94) cls = c;
             }
