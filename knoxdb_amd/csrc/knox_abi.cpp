@@ -1568,8 +1568,11 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     // auto occupancy: the pure streaming passes run best at 2 workgroups per CU, VALU-heavier ones at 3
     // (profiles/r01_sweep_blocks_per_cu.txt): 8-byte / 4-byte integer streaming 2 WG/CU; float or min-max
     // aggregates, several leaves, 2-byte types 3; 1-byte types and float32 sums (VALU bound) 8
-    const bool heavy = n_leaves > 1 || (agg_col && (agg & ~A_ISUM) != 0) || width == 2;
-    const bool very_heavy = width == 1 || (width == 4 && agg_col && (agg & A_FSUM) != 0);
+    // (round 3, tools/sweep_narrow.py with the compare-unit predicate of narrow_load: 2-byte filter / filter + sum scans run
+    //  best at 2 like the wider ones -- 6.69 vs 6.32 TB/s at 3 --, 1-byte ones at 3 -- 6.0 vs 5.5-5.8 TB/s at 8)
+    const bool plain = !agg_col || (agg & ~A_ISUM) == 0;  // filter or filter + wrapping sum
+    const bool heavy = n_leaves > 1 || !plain || (width == 1 && plain);
+    const bool very_heavy = (width == 1 && !plain) || (width == 4 && agg_col && (agg & A_FSUM) != 0);
     const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (very_heavy ? 8 : heavy ? 3 : 2);
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
     // per-pack counts for free: when packs are whole numbers of tiles, nothing is pruned and nothing is
