@@ -7,17 +7,21 @@ evaluates `Between(-2^38, 2^38)` on 2^30 int64 rows (1024 packs of 2^20), writes
 selection bitset, the per-pack popcounts and the wrapping int64 sum + count.  Inputs are
 generated on the device (counter-based generator) and are resident in HBM when the
 timed region starts.  For N > 1 each rank owns a contiguous pack range (no data-path
-collective); only the 144-byte partial aggregate state crosses xGMI (RCCL all-gather) each step.
+collective); only {sum, count} cross xGMI each step: ONE ncclAllReduce(int64 x 3) on the library's own
+communicator (knox_comm_*, `--collective abi`, the default) or through torch.distributed (`--collective torch`).
 
 Setup, outside the timed region and reported under "placement" in the JSON line: the context's
-device-memory arena gets an explicit budget (KNOX_BENCH_ARENA_GIB, default 160: the headline maps ~13-17 GiB of it, the secondary configs the rest), the column is generated into it, the
-bitset is allocated FOR that column (a write buffer verified against it, knox_bits_alloc_for) and the pair is checked ONCE with
-the real kernel against its own read-only form (a second look after 2.5 s only when the device was evidently still
-busy with somebody else's freed memory).  The timed region contains only the K steps.
+device-memory arena gets an explicit budget (KNOX_BENCH_ARENA_GIB, default 160: the headline maps ~13-17 GiB of it, the
+secondary configs the rest), the column is generated into it, the bitset is allocated FOR that column (a write buffer
+verified against it, knox_bits_alloc_for) and the pair is checked ONCE with the real kernel against its own read-only
+form (a second look after 2.5 s only when the device was evidently still busy with somebody else's freed memory).  The
+timed region contains only the K steps.
 
 After the timed region (all outside it): the read-only ceiling, the 0 % / 100 % selectivity runs of the same scan, the
 in-run parity against the oracle (bitset memcmp on a 64-pack sample, XOR checksum of ALL bitset words, count and
-wrapping sum of the whole run), and the CPU baseline (scalar port @ 1 thread, AVX2 @ 1 thread, AVX2 @ all cores).
+wrapping sum of the whole run), BASELINE configs[2] and configs[3] at the same size in the same context ("configs":
+cfg3 = 2 x float64 AND + min / max / mean, cfg4_u64 / cfg4_bytes = per-pack bloom -> EQ -> count; each with kernel_ms,
+GB/s, frac and its own parity verdict), and the CPU baseline (scalar port @ 1 thread, AVX2 @ 1 thread, AVX2 @ all cores).
 
 Environment (diagnostics, none needed): KNOX_PLACEMENT=0 plain hipMalloc; KNOX_BENCH_DEPTH scans queued ahead;
 KNOX_BENCH_FORCE_DIST=1 / KNOX_BENCH_BACKEND=gloo rehearsal modes of the multi-rank path on a 1-GPU box.
@@ -629,6 +633,7 @@ def main():
             tj = json.load(open(tr))
             out["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
             out["roofline"]["traffic_source"] = "profiles/traffic.json (%s; rocprofv3 --pmc passes of this command, tools/profile_round.sh)" % tj.get("measured", "round 1")
+            out["_traffic_kernels"] = tj.get("kernels", {})
         except Exception:
             pass
     pack_counts_host = res.pack_counts
@@ -639,6 +644,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs:
         try:
             out["configs"] = secondary_configs(K, ctx, n_rows, pack_rows, args.steps, args.warmup, parity=not args.no_cpu_baseline)
+            for name, t in out.pop("_traffic_kernels", {}).items():   # PMC-measured HBM bytes per launch of the same kernels (profiles/traffic.json)
+                if name in out["configs"]:
+                    out["configs"][name]["traffic"] = t.get("hbm_bytes_per_launch")
         except Exception as e:   # a secondary config must never cost the headline its line
             import traceback
             traceback.print_exc()
@@ -648,6 +656,7 @@ def main():
         # rank 0 only, after the timed region and its closing barrier (the other ranks are done and wait in destroy)
         sample = min(n_rows, 1 << args.cpu_sample_log2)
         out["cpu_baseline"] = cpu_baseline(sample, pack_rows, a, b, pack_counts_host)
+    out.pop("_traffic_kernels", None)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -456,7 +456,11 @@ __device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl,
             imin = (uint32_t)fkey<W>(__float_as_uint(fmn));
             imax = (uint32_t)fkey<W>(__float_as_uint(fmx));
         }
-        if (__any((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax)) {
+        // (a lane that selected nothing holds the neutral elements, which compare "better" than the wave's initial bounds:
+        //  without the `any` term every iteration of a scan that selects nothing -- 0 % selectivity -- took the exact path)
+        const bool any = (q[0] | q[1] | q[2] | q[3]) != 0;
+        static_assert(kUnroll == 4, "the `any` term above names four loads");
+        if (__any(any && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax))) {
 #pragma unroll 1
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
@@ -612,7 +616,7 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
                     imax = kmax > imax ? kmax : imax;
                 }
             }
-            trig = (uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax;
+            trig = (q[0] | q[1] | q[2] | q[3]) != 0 && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax);  // nothing selected: nothing to adopt
         } else {
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
@@ -874,8 +878,10 @@ __device__ __forceinline__ void agg_iter_swar(Acc &acc, WaveMM &wm, FirstLast &f
         const uint32_t imax = pmax.x > pmax.y ? pmax.x : pmax.y;
         const uint32_t iminc = pminc.x > pminc.y ? pminc.x : pminc.y;
         const uint32_t imin = EMAX - iminc;  // nothing selected: iminc = 0 -> EMAX, the neutral element (a selected EMAX is no news either)
-        // okey_raw of these types IS the W-byte key zero-extended: comparable with the wave-wide 64-bit bounds
-        if (__any((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax)) {
+        // okey_raw of these types IS the W-byte key zero-extended: comparable with the wave-wide 64-bit bounds; a lane
+        // that selected nothing has nothing to adopt (its neutral elements would "beat" the initial bounds)
+        const bool any = (q[0] | q[1] | q[2] | q[3]) != 0;
+        if (__any(any && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax))) {
 #pragma unroll 1
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;

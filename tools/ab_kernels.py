@@ -49,6 +49,8 @@ cases = [
     ("i32 Between+ALL", ["i32"], lambda: And(Leaf(0, F.Range, -(1 << 28), 1 << 28)), ALLA, 4.125),
     ("i16 Between+sum", ["i16"], lambda: And(Leaf(0, F.Range, -(1 << 13), 1 << 13)), [(R.Sum, 0)], 2.125),
     ("i16 Between+ALL", ["i16"], lambda: And(Leaf(0, F.Range, -(1 << 13), 1 << 13)), ALLA, 2.125),
+    ("i32 0 % selected + ALL", ["i32"], lambda: And(Leaf(0, F.Range, (1 << 30) + 5, (1 << 30) + 6)), ALLA, 4.125),   # min / max pre-filter with nothing to adopt
+    ("i16 0 % selected + ALL", ["i16"], lambda: And(Leaf(0, F.Range, 1 << 14, (1 << 14) - 1)), ALLA, 2.125),
     ("i16 Between (count)", ["i16"], lambda: And(Leaf(0, F.Range, -(1 << 13), 1 << 13)), [], 2.125),
     ("u8 Between (count)", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), [], 1.125),
     ("u8 Between+sum", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), [(R.Sum, 0)], 1.125),
