@@ -774,6 +774,7 @@ class Arena {
                     smalls[zones[zi].extents[ei].va + off] = Small{zi, (int)ei, off, bytes};
                     account(bytes);
                     *out = zones[zi].extents[ei].va + off;
+                    dbg("%zu MiB in zone %d at offset %zu MiB (zone: %zu MiB mapped)", bytes >> 20, zi, off >> 20, zones[zi].mapped >> 20);
                     return hipSuccess;
                 }
             // one more chunk while the budget allows it AND a class zone can still come to hold the request; otherwise the

@@ -1,5 +1,6 @@
 // knox_bytes.hip -- bytes (StringPool) column matchers: EQ / NE streaming form, ordered modes, IN / NOT IN, REGEXP.
 #include "knox_bytes_dev.h"
+#include <stdlib.h>
 #define KNOX_HD __host__ __device__
 #include "knox_regex.h"
 
@@ -101,6 +102,20 @@ __global__ void __launch_bounds__(kBlock) bytes_eq_kernel(int negate, BytesView 
     if (lane == 0 && cnt && count_out) atomicAdd(count_out, (unsigned long long)cnt);
 }
 
+// Workgroups of the ordered-mode and REGEXP kernels: beyond the cap they walk the column grid-stride.  Measured on 2^28 x
+// 32-byte keys (tools/bench_bytes.py with KNOX_BYTES_CAP_LOG2 = 13 / 16 / 20, profiles/r03_bytes_grid.txt): unlike bytes EQ
+// -- which gained 10 points from "one group per wave, launch order" -- the ordered modes LOSE with it (LT 5.58 -> 5.32,
+// RANGE 4.91 -> 4.49 TB/s of 40.125 B/row accounting; a random key is decided by its first 8 bytes, so these kernels are
+// pointer-chasing latency, not payload streaming) and are best at 2^16 workgroups (LT 5.75, RANGE 4.96); REGEXP stages its
+// DFA in LDS per workgroup and wants few of them (2^13: 6.1 ms, 2^20: 8.7 ms); IN (binary search per row) does not care.
+static uint64_t bytes_grid_cap(int dflt_log2) {
+    static const int forced = [] {
+        const char *e = getenv("KNOX_BYTES_CAP_LOG2");
+        return e && atoi(e) >= 8 && atoi(e) <= 24 ? atoi(e) : 0;
+    }();
+    return (uint64_t)1 << (forced ? forced : dflt_log2);
+}
+
 hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const uint8_t *val, uint32_t vlen, const uint8_t *val2, uint32_t vlen2,
                               uint8_t *bits, const uint8_t *mask, unsigned long long *count_out) {
     const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
@@ -115,7 +130,7 @@ hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const
         KNOX_LAUNCH(bytes_eq_kernel, (int)g, mode == 2 ? 1 : 0, v, val, vlen, bits, mask, count_out);
     }
     uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g > 2048 * 4) g = 2048 * 4;  // the ordered modes walk grid-stride: measured best (tools/bench_bytes.py: LT 5.5 TB/s, RANGE 4.8 TB/s)
+    if (g > bytes_grid_cap(16)) g = bytes_grid_cap(16);
     KNOX_LAUNCH(bytes_match_kernel, (int)g, mode, v, val, vlen, val2, vlen2, bits, mask, count_out);
 }
 
@@ -318,7 +333,7 @@ hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t imag
     const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
     if (ngroups == 0) return hipSuccess;
     uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g > 2048 * 4) g = 2048 * 4;
+    if (g > bytes_grid_cap(13)) g = bytes_grid_cap(13);
     const uint32_t lds_bytes = ((image_bytes + 3u) & ~3u) + 96u * 5u + 16u;  // image + (<= 96) staged class intervals
     if (pg.direct != nullptr)  // host guarantees: the image with the direct table fits the LDS budget
         hipLaunchKernelGGL((regexp_match_kernel<true, true>), dim3((unsigned)g), dim3(kBlock), lds_bytes, s, pg, v, bits, mask);
