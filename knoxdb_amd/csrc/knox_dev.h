@@ -900,6 +900,94 @@ __device__ __forceinline__ void agg_iter_swar(Acc &acc, WaveMM &wm, FirstLast &f
     }
 }
 
+// agg_iter_swar with narrow_load's predicate (round 3): the same sums / min-max pre-filter / first-last bookkeeping, fed by the
+// result bits instead of SWAR hit masks.  Results are identical (tests/test_gpu_scan.py: all types x all aggregates).
+template <int W, unsigned AGG, unsigned FLV>
+__device__ __forceinline__ void agg_iter_narrow(Acc &acc, WaveMM &wm, FirstLast &fl, uint32_t nlo, uint32_t ndiff, uint32_t m1, uint32_t m0, const u32x4 (&r)[kUnroll],
+                                              uint32_t (&q)[kUnroll], uint32_t &cnt32, uint64_t row0, uint64_t row_base, int lane) {
+    static_assert(W <= 2 && FLV != FL_FLOAT, "SWAR aggregates: 1- and 2-byte integer columns");
+    constexpr int K = WT<W>::K;
+    constexpr int RPL = 64 * K;
+    constexpr uint32_t H = Swar<W>::H;
+    constexpr uint32_t XS = FLV == FL_SIGNED ? H : 0u;
+    uint32_t sum32 = 0, neg = 0;
+    u16x2 pmax = {0, 0}, pminc = {0, 0};
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+        const uint32_t d[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+        // the predicate through the compare unit (narrow_load), then the 0/1 element masks the sums and the min / max
+        // pre-filter want from the result bits: one 24-bit multiply + AND per word
+        uint32_t unused = 0;
+        const uint32_t qq = narrow_load<W, false>(r[u], nlo, ndiff, m1, m0, unused);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t m;
+            if constexpr (W == 1) m = __umul24((qq >> (4 * w)) & 0xfu, 0x00204081u) & 0x01010101u;
+            else m = __umul24((qq >> (2 * w)) & 0x3u, 0x00008001u) & 0x00010001u;
+            const uint32_t g = m << (8 * W - 1);
+            if constexpr (W == 1) {
+                if constexpr ((AGG & (A_ISUM | A_FSUM)) != 0) sum32 = __builtin_amdgcn_udot4(d[w], m, sum32, false);
+            } else {
+                if constexpr ((AGG & (A_ISUM | A_FSUM)) != 0)
+                    sum32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d[w]), __builtin_bit_cast(u16x2, m), sum32, false);
+            }
+            if constexpr ((AGG & A_FSUM) != 0 && FLV == FL_SIGNED) neg += (uint32_t)__builtin_popcount(d[w] & g);
+            if constexpr ((AGG & A_MINMAX) != 0) {
+                // element-wide mask of the selected elements: 2-byte elements by one full-rate 24-bit multiply (m <= 0x00010001)
+                const uint32_t mfull = W == 2 ? __umul24(m, 0xffffu) : ((g - m) | g);
+                const uint32_t key = d[w] ^ XS;
+                const uint32_t kmax = key & mfull, kminc = kmax ^ mfull;  // = ~key & mfull
+                if constexpr (W == 2) {
+                    pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(u16x2, kmax));
+                    pminc = __builtin_elementwise_max(pminc, __builtin_bit_cast(u16x2, kminc));
+                } else {
+                    // bytes 0,1 and 2,3 zero-extended to 16-bit lanes: selector 0x0c = constant 0x00
+                    pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(kmax, kmax, 0x0c010c00u)));
+                    pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(kmax, kmax, 0x0c030c02u)));
+                    pminc = __builtin_elementwise_max(pminc, __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(kminc, kminc, 0x0c010c00u)));
+                    pminc = __builtin_elementwise_max(pminc, __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(kminc, kminc, 0x0c030c02u)));
+                }
+            }
+        }
+        q[u] = qq;
+        cnt32 += (uint32_t)__builtin_popcount(qq);
+    }
+    if constexpr ((AGG & A_ISUM) != 0) acc.isum += sum32;  // the raw (zero-extended) values: SumReducer mod 2^64 is formed by finalize
+    if constexpr ((AGG & A_FSUM) != 0) {
+        if constexpr (FLV == FL_UNSIGNED) {
+            acc.add128(sum32, 0);
+        } else {
+            const int64_t it = (int64_t)sum32 - ((int64_t)neg << (8 * W));
+            acc.add128((uint64_t)it, it >> 63);
+        }
+    }
+    if constexpr ((AGG & A_MINMAX) != 0) {
+        constexpr uint32_t EMAX = W == 1 ? 0xffu : 0xffffu;
+        const uint32_t imax = pmax.x > pmax.y ? pmax.x : pmax.y;
+        const uint32_t iminc = pminc.x > pminc.y ? pminc.x : pminc.y;
+        const uint32_t imin = EMAX - iminc;  // nothing selected: iminc = 0 -> EMAX, the neutral element (a selected EMAX is no news either)
+        // okey_raw of these types IS the W-byte key zero-extended: comparable with the wave-wide 64-bit bounds; a lane
+        // that selected nothing has nothing to adopt (its neutral elements would "beat" the initial bounds)
+        const bool any = (q[0] | q[1] | q[2] | q[3]) != 0;
+        if (__any(any && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax))) {
+#pragma unroll 1
+            for (int u = 0; u < kUnroll; u++) {
+                const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
+#pragma unroll
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+            }
+            wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
+            wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
+        }
+    }
+    if constexpr ((AGG & A_FIRSTLAST) != 0) {
+        uint64_t qq = 0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) qq |= (uint64_t)q[u] << (u * K);
+        fl.update(row0, qq);
+    }
+}
+
 
 // one element of a column by row (tail kernels, finalisers, gathers)
 template <int W> __device__ __forceinline__ typename WT<W>::U load_elem(const void *col, uint64_t row) {

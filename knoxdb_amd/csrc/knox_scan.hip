@@ -116,10 +116,17 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             // Every selected value lies inside the predicate's own range, so once the wave holds a value AT both ends of
             // that range (strict compares: first occurrence wins) no later row can change its min / max: the min / max
             // work is dropped for the rest of the wave's rows (wave-uniform branch; low-cardinality columns get there fast)
+#ifdef KNOX_NARROW_SWAR  // A/B builds: the SWAR form
             if ((AGG & A_MINMAX) != 0 && wm.smin <= mm_lo && wm.smax >= mm_hi)
                 agg_iter_swar<WS, (AGG & ~A_MINMAX), FS>(acc, wm, fl, sw, r[0], q, cnt32, row0, a.row_base, lane);
             else
                 agg_iter_swar<WS, AGG, FS>(acc, wm, fl, sw, r[0], q, cnt32, row0, a.row_base, lane);
+#else
+            if ((AGG & A_MINMAX) != 0 && wm.smin <= mm_lo && wm.smax >= mm_hi)
+                agg_iter_narrow<WS, (AGG & ~A_MINMAX), FS>(acc, wm, fl, nlo, ndiff, m1, m0, r[0], q, cnt32, row0, a.row_base, lane);
+            else
+                agg_iter_narrow<WS, AGG, FS>(acc, wm, fl, nlo, ndiff, m1, m0, r[0], q, cnt32, row0, a.row_base, lane);
+#endif
         } else if constexpr (kSwar) {
             uint32_t sum32 = 0;  // <= 64 values x 255 resp. 32 x 65535 per iteration
 #pragma unroll

@@ -25,6 +25,21 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
     print("%-92s %7s %12s %12s %8s" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
     for r in csv.DictReader(open(f)):
         print("%-92s %7s %12s %12s %8s" % (short(r["Name"]), r["Calls"], r["AverageNs"], r["TotalDurationNs"], r["Percentage"]))
+# Kernels that run both over the whole column and over the few packs a bloom probe leaves (configs[3]): the kernel-stats
+# average mixes them; the full-size launches are the dispatches whose duration is at least half of the longest one.
+SPLIT = {"bytes_eq_kernel": "configs[3] []byte leg, full scans", "scan_kernel<8, 1, 0u, false, false, 0u>": "uint64 EQ / read-only form, full scans"}
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        nm = short(r["Kernel_Name"])
+        for k in SPLIT:
+            if k in nm:
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if dur:
+        print("\n## full-size launches only (duration >= 1/2 of the longest dispatch of that kernel)")
+    for k, v in dur.items():
+        big = [x for x in v if x >= max(v) / 2]
+        print("%-60s %4d of %4d launches, avg_ns %12.1f  (%s)" % (k, len(big), len(v), sum(big) / len(big), SPLIT[k]))
 tj = os.path.join(root, "trace_bench.json")
 if os.path.exists(tj):
     print("\n## bench line under the profiler\n" + open(tj).read().strip())
@@ -33,6 +48,7 @@ TRAFFIC_KERNELS = {
     "headline": "scan_kernel<8, 1, 1u, false, false, 0u>",        # int64 Between + sum (BASELINE configs[1])
     "cfg3": "scan_kernel<8, 2, 14u, false, true, 2u>",             # 2 x float64, AND, min / max / mean (configs[2])
     "cfg4_bytes": "bytes_eq_kernel",                                # []byte EQ over per-pack StringPools (configs[3])
+    "cfg4_u64": "scan_kernel<8, 1, 0u, false, false, 0u>",         # uint64 EQ + count (also the read-only form: full-size dispatches)
     "bloom_count_u64": "bloom_count_kernel<8, HashNumeric>",
     "bloom_bin_u64": "bloom_bin_kernel<8, HashNumeric>",
     "bloom_count_bytes": "bloom_count_kernel<8, HashBytes>",
@@ -60,7 +76,11 @@ for sub in sorted(glob.glob(os.path.join(root, "pmc_*"))):
                 if c in ("FETCH_SIZE", "WRITE_SIZE"):
                     for label, sub_name in TRAFFIC_KERNELS.items():
                         if sub_name in k:
-                            traffic[label][c] = sum(vals) / len(vals)
+                            use = vals
+                            if any(sp in k for sp in SPLIT):   # full-size dispatches only
+                                use = [x for x in vals if x >= max(vals) / 2]
+                                print("    %-24s n=%-4d mean=%.6g   (full-size dispatches)" % (c, len(use), sum(use) / len(use)))
+                            traffic[label][c] = sum(use) / len(use)
 
 import json
 import time
