@@ -1469,9 +1469,9 @@ uint32_t pack_shift_for(size_t pack_rows, int width) {
 // {1,2,4,8,16} x {2,3} workgroups/CU (tools/placement_matrix.py, profiles/r01_placement_matrix.txt):
 // iters = 2 is the fastest everywhere (7.0 TB/s typical, 5.9 TB/s on the slow placements, vs
 // 6.7 / 5.5 TB/s at iters = 1).  Short inputs keep tiles small so every CU gets work.
-uint32_t pick_iters(knox_ctx *ctx, size_t n_rows, int width, size_t pack_rows_or_0) {
+uint32_t pick_iters(knox_ctx *ctx, size_t n_rows, int width, size_t pack_rows_or_0, uint32_t dflt) {
     const char *env = getenv("KNOX_ITERS");
-    uint32_t it = env && atoi(env) > 0 ? (uint32_t)atoi(env) : 2u;
+    uint32_t it = env && atoi(env) > 0 ? (uint32_t)atoi(env) : dflt;
     if (it > (uint32_t)kMaxIters) it = kMaxIters;
     const uint64_t base = (uint64_t)tile_rows(width);
     const uint64_t want_tiles = (uint64_t)ctx->n_cus * 8;
@@ -1525,7 +1525,11 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
         sep = agg_col->dev != lcols[0]->dev;
     }
     const bool want_skip = skip && skip->d_skip && skip->d_live && pack_rows && !(pack_rows & (pack_rows - 1)) && n_rows % pack_rows == 0;
-    a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0);
+    // aggregate-heavy single-leaf scans (the software-pipelined instantiations) run 1.5-3.5 % faster with 4 wave iterations
+    // per tile than with 2 (tools/sweep_narrow.py all, round 3: int64 ALL 6.48 -> 6.64, int32 ALL 6.33 -> 6.51, int8 ALL 5.30 ->
+    // 5.65 TB/s together with the occupancy below); the plain filter (+ sum) scans keep 2
+    const bool plain_scan = !agg_col || (agg & ~A_ISUM) == 0;
+    a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0, (!plain_scan && n_leaves == 1) ? 4u : 2u);
     const uint64_t tr = (uint64_t)tile_rows(width) * a.iters;
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;
@@ -1570,10 +1574,16 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     // aggregates, several leaves, 2-byte types 3; 1-byte types and float32 sums (VALU bound) 8
     // (round 3, tools/sweep_narrow.py with the compare-unit predicate of narrow_load: 2-byte filter / filter + sum scans run
     //  best at 2 like the wider ones -- 6.69 vs 6.32 TB/s at 3 --, 1-byte ones at 3 -- 6.0 vs 5.5-5.8 TB/s at 8)
-    const bool plain = !agg_col || (agg & ~A_ISUM) == 0;  // filter or filter + wrapping sum
-    const bool heavy = n_leaves > 1 || !plain || (width == 1 && plain);
-    const bool very_heavy = (width == 1 && !plain) || (width == 4 && agg_col && (agg & A_FSUM) != 0);
-    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * (very_heavy ? 8 : heavy ? 3 : 2);
+    //  aggregate-heavy single-leaf scans, same sweep: 2 workgroups / CU for 8-, 4- and 1-byte columns (3 is the worst choice
+    //  for int32: 6.00 against 6.33-6.51 TB/s at 2 and 4), 3 for 2-byte ones, 8 for float32 sums)
+    const bool plain = plain_scan;  // filter or filter + wrapping sum
+    const bool f32sum = width == 4 && agg_col && (agg & A_FSUM) != 0 && a.agg_flavor == FL_FLOAT;
+    int per_cu;
+    if (n_leaves > 1) per_cu = 3;
+    else if (plain) per_cu = width == 1 ? 3 : 2;
+    else if (f32sum) per_cu = 8;
+    else per_cu = width == 2 ? 3 : 2;
+    const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * per_cu;
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
     // per-pack counts for free: when packs are whole numbers of tiles, nothing is pruned and nothing is
     // left for the tail kernel, every wave records the popcount of its bursts (one 128-byte line per 32 tiles)

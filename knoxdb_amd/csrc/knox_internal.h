@@ -345,7 +345,7 @@ int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, knox_bi
 int make_leaf(int dtype, int op, uint64_t a, uint64_t b, LeafHost &out);
 BytesView bytes_view(const knox_col *c, size_t n_rows, SkipPlan *skip = nullptr);
 uint32_t pack_shift_for(size_t pack_rows, int width);
-uint32_t pick_iters(knox_ctx *ctx, size_t n_rows, int width, size_t pack_rows_or_0);
+uint32_t pick_iters(knox_ctx *ctx, size_t n_rows, int width, size_t pack_rows_or_0, uint32_t dflt = 2);
 int run_reduce(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, unsigned agg, size_t n_rows, uint64_t row_base, int slot, int grid);
 int run_moments(knox_ctx *ctx, const knox_col *col, const uint32_t *mask, size_t n_rows, int slot, int grid);
 int run_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pat, uint64_t pat_len, const uint8_t *mask, uint8_t *bits,

@@ -26,7 +26,8 @@ def rate(plan, bits, bpr, steps=14):
     return n * bpr / statistics.median(v[len(v) // 2:]) / 1e6
 
 
-for bt, w, lo, span, a, b in ((B.Uint8, 1, 0, 256, 64, 127), (B.Int8, 1, -128, 256, -32, 31), (B.Int16, 2, -(1 << 15), 1 << 16, -(1 << 13), 1 << 13), (B.Int32, 4, -(1 << 30), 1 << 31, -(1 << 28), 1 << 28)):
+NARROW = ((B.Uint8, 1, 0, 256, 64, 127), (B.Int8, 1, -128, 256, -32, 31), (B.Int16, 2, -(1 << 15), 1 << 16, -(1 << 13), 1 << 13), (B.Int32, 4, -(1 << 30), 1 << 31, -(1 << 28), 1 << 28))
+for bt, w, lo, span, a, b in (NARROW if "wide" not in sys.argv[2:] else ()):
     col = ctx.generate(bt, 0, 2, n, lo=lo, span=span, pack_rows=pack)
     bits = ctx.bits(n, for_col=col)
     plan = ctx.plan(And(Leaf(0, F.Range, a, b)), [col], aggs=AGGS)
@@ -43,3 +44,21 @@ for bt, w, lo, span, a, b in ((B.Uint8, 1, 0, 256, 64, 127), (B.Int8, 1, -128, 2
     ctx.set_tuning(0)
     os.environ.pop("KNOX_ITERS", None)
     col.free(); bits.free()
+if "all" in sys.argv[2:]:   # the wide aggregate-heavy instantiations beside them
+    FL = [(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0)]
+    for bt, w, kind, tree, aggs in ((B.Int64, 8, 0, And(Leaf(0, F.Range, -(1 << 38), 1 << 38)), AGGS), (B.Float64, 8, 2, And(Leaf(0, F.Lt, 0.25)), FL),
+                                    (B.Float32, 4, 2, And(Leaf(0, F.Lt, 0.25)), FL)):
+        col = ctx.generate(bt, kind, 2, n, lo=-(1 << 40) if kind == 0 else 0, span=(1 << 41) if kind == 0 else 0, pack_rows=pack)
+        bits = ctx.bits(n, for_col=col)
+        plan = ctx.plan(tree, [col], aggs=aggs)
+        rate(plan, bits, w + .125, 40)
+        for it in (2, 4, 8):
+            os.environ["KNOX_ITERS"] = str(it)
+            full = []
+            for bpc in (2, 3, 4, 6, 8, 12):
+                ctx.set_tuning(bpc)
+                full.append(rate(plan, bits, w + .125))
+            print("%-7s iters %2d  scan      " % (bt.name, it) + " ".join("b%d:%5.0f" % (b_, r) for b_, r in zip((2, 3, 4, 6, 8, 12), full)), flush=True)
+        ctx.set_tuning(0)
+        os.environ.pop("KNOX_ITERS", None)
+        col.free(); bits.free()
