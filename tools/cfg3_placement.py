@@ -39,3 +39,12 @@ for name, mk in (("for [A, B]", lambda: ctx.bits(n, for_col=[A, Bc])), ("for A",
     t = ms(plan, b)
     print("%-18s pair check %-22s scan %.4f ms = %.0f GB/s = %.3f of peak" % (name, b.pair_check, t, n * 16.125 / t / 1e6, n * 16.125 / t / 8e9), flush=True)
 print(ctx.arena_info())
+# occupancy x burst iterations for the two-leaf float scan, on the bitset verified against both columns
+b = ctx.bits(n, for_col=[A, Bc])
+for it in (1, 2, 4, 8):
+    os.environ["KNOX_ITERS"] = str(it)
+    row = []
+    for bpc in (2, 3, 4, 6, 8):
+        ctx.set_tuning(bpc)
+        row.append(n * 16.125 / ms(plan, b) / 1e6)
+    print("cfg3 iters %d  " % it + " ".join("b%d:%5.0f" % (x, r) for x, r in zip((2, 3, 4, 6, 8), row)), flush=True)
