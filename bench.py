@@ -193,6 +193,7 @@ def secondary_configs(K, ctx, n_rows, pack_rows, steps, warmup, parity=True):
 
     # ---- configs[2]: two float64 columns, `A >= 256 AND B < 0.5`, min / max / mean(A) (+ sum, count) ---------------
     t0 = time.perf_counter()
+    ctx.reserve(2 * (n_rows * 8 + (1 << 20)))   # both columns of the tree in ONE placement class (knox_ctx_reserve), the bitset in another
     A = ctx.generate(BlockType.Float64, 1, 3, n_rows, pack_rows=pack_rows)   # k * 2^-10 grid: every summation order is exact
     B = ctx.generate(BlockType.Float64, 2, 4, n_rows, pack_rows=pack_rows)   # uniform [0, 1)
     bits = ctx.bits(n_rows, for_col=[A, B])   # verified against both read streams (knox_bits_alloc_for_cols)

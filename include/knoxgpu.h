@@ -132,6 +132,15 @@ typedef struct knox_arena_info {
     int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
 } knox_arena_info;
 int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out);
+/* Room for columns that will be SCANNED TOGETHER (the columns of one table run, the leaves of one filter tree): grows the
+ * arena until one placement class has `bytes` contiguous free and makes that class the preferred one of the following
+ * column allocations.  Two read streams of one scan run 4-5 % faster when they lie in ONE class (the bitset they write in
+ * ANOTHER one: knox_bits_alloc_for_cols).  Allocates nothing; without it columns simply follow the previous column's class
+ * while it has room.  KNOX_E_NOMEM: the budget cannot hold that much in one class (allocations still work, anywhere).    */
+int knox_ctx_reserve(knox_ctx *ctx, size_t bytes);
+/* The placement class (0 .. 3) the column's values (which = 0; a bytes column: its pointer array) or its bytes pool
+ * (which = 1) lie in; -1: small allocations, the mixed region, borrowed memory, placement off.  Diagnostics.            */
+int knox_col_placement_class(const knox_col *col, int which);
 /* Returns every FREE column chunk and every spare write buffer to the driver.  Explicit only: returning multi-GiB blocks
  * slows live neighbours for a second or two (the driver clears them).                                             */
 int knox_ctx_arena_trim(knox_ctx *ctx, size_t *freed_bytes /* nullable */);

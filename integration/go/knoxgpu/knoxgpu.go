@@ -79,6 +79,14 @@ func (c *Ctx) SetArena(bytes uint64) error {
 	return errOf(C.knox_ctx_set_arena(c.p, C.size_t(bytes)))
 }
 
+// Reserve makes room, in ONE placement class of the device memory, for columns that will be scanned together (the filter
+// columns of a run): two read streams of one scan run 4-5 % faster there (include/knoxgpu.h knox_ctx_reserve).  Best effort.
+func (c *Ctx) Reserve(bytes uint64) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	return errOf(C.knox_ctx_reserve(c.p, C.size_t(bytes)))
+}
+
 // ProfEnable / ProfRead: the library's HIP-event stopwatch around the dominant kernel of every scan (knox_prof_*):
 // total milliseconds and launches since the last read -- what the run reader writes into QueryStats.
 func (c *Ctx) ProfEnable(on bool) {

@@ -80,6 +80,7 @@ type GpuRun struct {
 	next    int
 	pending *gpuRunPack // a pack that was loaded but belongs to the next run
 	done    bool
+	reserved bool
 
 	// fused reducer states of the runs seen so far (rank order = row order); valid while fusable stays true
 	States  [][]knoxgpu.State
@@ -175,6 +176,10 @@ func appendTyped[T knoxgpu.Number](g *GpuRun, i int, b *block.Block) error {
 		return nil
 	}
 	if g.cols[i] == nil {
+		if !g.reserved { // all of the run's columns in ONE placement class (they are read by one scan); best effort
+			g.gpu.Reserve(uint64(len(g.fields)) * uint64(g.maxPacks*g.packRows) * 8)
+			g.reserved = true
+		}
 		col, err := knoxgpu.NewColumn(g.gpu, int(b.Type()), g.maxPacks*g.packRows, g.packRows)
 		if err != nil {
 			return err

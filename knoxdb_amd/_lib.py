@@ -146,6 +146,8 @@ SIGNATURES = {
     "knox_ctx_set_placement": (_i, [_vp, _i]),
     "knox_ctx_placement_info": (_i, [_vp, C.POINTER(_i64), _pi]),
     "knox_ctx_set_arena": (_i, [_vp, _sz]),
+    "knox_ctx_reserve": (_i, [_vp, _sz]),
+    "knox_col_placement_class": (_i, [_vp, _i]),
     "knox_ctx_arena_info": (_i, [_vp, C.POINTER(ArenaInfo)]),
     "knox_ctx_arena_trim": (_i, [_vp, C.POINTER(_sz)]),
     "knox_bits_pair_check": (_i, [_vp, C.POINTER(C.c_double), _pi]),

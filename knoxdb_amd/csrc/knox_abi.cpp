@@ -203,6 +203,20 @@ KNOX_API int knox_ctx_set_arena(knox_ctx *ctx, size_t budget_bytes) {
     return KNOX_OK;
 }
 
+KNOX_API int knox_ctx_reserve(knox_ctx *ctx, size_t bytes) {
+    if (!ctx) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    if (!ctx->placement) return KNOX_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // growing the arena probes new chunks on the context's stream
+    const hipError_t e = ctx->arena.reserve(bytes);
+    if (e == hipErrorNotSupported) return KNOX_OK;
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        return KNOX_E_NOMEM;
+    }
+    return KNOX_OK;
+}
+
 KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
     if (!ctx || !out) return KNOX_E_INVALID;
     memset(out, 0, sizeof *out);
@@ -682,6 +696,12 @@ static int bytes_col_alloc(knox_ctx *ctx, size_t pack_rows, size_t max_packs, si
     if (max_packs > ((size_t)1 << 40) / pack_rows) return KNOX_E_RANGE;
     hipSetDevice(ctx->device);
     const size_t rows_cap = pack_rows * max_packs;
+    // the pointer array and the pools are read together by every bytes kernel: one placement class for both when the arena
+    // can find the room (best effort: a failure only means they may end up in two classes)
+    if (ctx->placement) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)ctx->arena.reserve(rows_cap * 8 + max_pool_bytes + 64 * max_packs + ((size_t)4 << 20));
+    }
     int rc = col_new(ctx, KNOX_BYTES, rows_cap, pack_rows, true, out);
     if (rc) return rc;
     knox_col *c = *out;
@@ -832,6 +852,12 @@ KNOX_API int knox_col_free(knox_col *col) {
     free(col->h_pool_base);
     delete col;
     return KNOX_OK;
+}
+
+KNOX_API int knox_col_placement_class(const knox_col *col, int which) {
+    if (!col || !col->ctx) return -1;
+    const void *p = which == 1 ? (const void *)col->buf : (const void *)col->dev;
+    return p ? col->ctx->arena.class_of(p) : -1;
 }
 
 KNOX_API size_t knox_col_rows(const knox_col *col) { return col ? col->n_rows : 0; }

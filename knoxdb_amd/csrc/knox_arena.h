@@ -123,6 +123,7 @@ class Arena {
     }
     size_t zone_bytes(int label) const { return label >= 1 && label <= kMaxClasses ? zones[label - 1].mapped : 0; }
     int classes_seen() const { return n_refs; }
+    int class_of(const void *p) const { return zone_of(p); }  // the placement class (zone index) an address lies in, -1 = heap / mixed region / not the arena's
 
     // Columns / payloads of >= 1 GiB: a range of ONE zone (chunks of one label, mapped back to back).  Everything else: the heap.
     hipError_t alloc(void **out, size_t bytes, int kind) {
@@ -132,6 +133,29 @@ class Arena {
         (void)kind;  // large buffers of either kind live in a zone; write buffers that matter are verified (alloc_write_for)
         if (bytes >= kChunk) return zone_alloc(out, bytes);
         return heap_alloc(out, bytes);
+    }
+
+    // Room for columns that will be scanned together: grows the arena until ONE class zone has `bytes` contiguous free and
+    // makes that zone the preferred one of the next large allocations (zone_alloc), so that e.g. both columns of a two-leaf
+    // scan, or the pointer array and the pool of a bytes column, land in one placement class.  Nothing is allocated.
+    hipError_t reserve(size_t bytes) {
+        bytes = round_up(bytes);
+        if (!init_once()) return hipErrorNotSupported;
+        if (bytes < kChunk) return hipSuccess;
+        for (;;) {
+            for (int k = 0; k <= kMaxClasses; k++) {
+                const int zi = k == 0 ? last_zone : k - 1;
+                if (zi < 0 || (k > 0 && zi == last_zone)) continue;
+                for (auto &e : zones[zi].extents)
+                    for (auto &fr : e.free)
+                        if (fr.second >= bytes) {
+                            last_zone = zi;
+                            dbg("reserve: zone %d has %zu MiB contiguous for a request of %zu MiB", zi, fr.second >> 20, bytes >> 20);
+                            return hipSuccess;
+                        }
+            }
+            if (mapped_total + kChunk > budget || grow_zone() < 0) return hipErrorOutOfMemory;
+        }
     }
 
     // A write buffer FOR a column (or for the columns of one multi-leaf scan): a physical allocation of its own, verified
@@ -337,6 +361,7 @@ class Arena {
                 z = Zone();
             }
             for (int c = 1; c < kMaxClasses; c++) ref_va[c] = nullptr;
+            last_zone = -1;
             if (n_refs > 1) {
                 used -= (size_t)(n_refs - 1) * kRefBytes;
                 n_refs = 1;
@@ -367,6 +392,7 @@ class Arena {
             z = Zone();
         }
         smalls.clear();
+        last_zone = -1;
         for (auto &r : ref_va) r = nullptr;
         n_refs = 0;
         mapped_total = used = 0;
@@ -405,6 +431,7 @@ class Arena {
     char *ref_va[kMaxClasses] = {nullptr, nullptr, nullptr, nullptr};  // class c's reference window; c >= 1: the first 32 MiB of zone c
     int n_refs = 0;
     int grown_for_write = 0;
+    int last_zone = -1;  // the class zone of the latest column (or reserve()): the next column tries it first
     Zone zones[kMaxClasses + 1];  // [kMaxClasses]: the mixed region (chunks of several classes, see mixed_alloc)
     bool fake_labels = false;     // test hook (KNOX_ARENA_FAKE_LABELS=1): chunks are labelled class 0, 1, 0, 1 ... without probing
     std::vector<Extent> heap;
@@ -774,16 +801,23 @@ class Arena {
     }
     hipError_t zone_alloc(void **out, size_t bytes) {
         for (;;) {
-            for (int zi = 0; zi <= kMaxClasses; zi++)
+            // the zone of the previous column first: columns that are scanned TOGETHER (the leaves of one tree, the pointer
+            // array and the pool of a bytes column) read 4-5 % faster when they lie in ONE placement class (two 8 GiB float64
+            // columns, read-only two-leaf scan: 6.88-6.93 TB/s in one zone, 6.60-6.64 TB/s in two; tools/two_stream_skew.py)
+            for (int k = 0; k <= kMaxClasses + 1; k++) {
+                const int zi = k == 0 ? last_zone : k - 1;
+                if (zi < 0 || (k > 0 && zi == last_zone)) continue;
                 for (size_t ei = 0; ei < zones[zi].extents.size(); ei++) {
                     size_t off = 0;
                     if (!take(zones[zi].extents[ei].free, bytes, &off)) continue;
+                    if (zi < kMaxClasses) last_zone = zi;
                     smalls[zones[zi].extents[ei].va + off] = Small{zi, (int)ei, off, bytes};
                     account(bytes);
                     *out = zones[zi].extents[ei].va + off;
                     dbg("%zu MiB in zone %d at offset %zu MiB (zone: %zu MiB mapped)", bytes >> 20, zi, off >> 20, zones[zi].mapped >> 20);
                     return hipSuccess;
                 }
+            }
             // one more chunk while the budget allows it AND a class zone can still come to hold the request; otherwise the
             // free chunks of all zones together (mixed region)
             if (mapped_total + kChunk > budget || grow_zone() < 0) {

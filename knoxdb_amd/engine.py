@@ -89,6 +89,10 @@ class Column:
         check(_lib.lib().knox_col_download(self.ctx.h, self.h, first, n, _ptr(out)))
         return out
 
+    def placement_class(self, pool=False):
+        """the arena's placement class of the values / pointer array (pool=True: of a bytes column's pools), -1 = none"""
+        return _lib.lib().knox_col_placement_class(self.h, 1 if pool else 0)
+
     def append_async(self, arr):
         """enqueue the copy of `arr` behind the rows present (knox_col_append_async); see Context.upload_async for lifetimes"""
         assert arr.flags.c_contiguous and FROM_NP[arr.dtype] == self.dtype
@@ -339,6 +343,11 @@ class Context:
 
     def set_arena(self, budget_bytes):
         check(self.L.knox_ctx_set_arena(self.h, budget_bytes), "knox_ctx_set_arena")
+
+    def reserve(self, nbytes):
+        """room for columns that will be scanned together, in ONE placement class (include/knoxgpu.h knox_ctx_reserve);
+        -> True when such room exists now"""
+        return self.L.knox_ctx_reserve(self.h, int(nbytes)) == 0
 
     def arena_info(self):
         a = _lib.ArenaInfo()

@@ -138,3 +138,27 @@ def test_alternating_multi_pass_scans_keep_their_verified_scratch():
         assert ctx.arena_info()["probes"] == probes
         for o in (a64, b64, a32, bits):
             o.free()
+
+
+def test_columns_scanned_together_share_a_placement_class():
+    """knox_ctx_reserve + the arena's "previous column's class first" rule: the two columns of a two-leaf scan and the
+    pointer array / pools of a bytes column land in ONE placement class (two read streams of one scan run 4-5 % faster
+    there), the bitset verified against both in ANOTHER one when the device offers one"""
+    with K.Context(0) as ctx:
+        ctx.set_arena(48 * GIB)
+        n = 3 << 27                                # 3 GiB per float64 column
+        assert ctx.reserve(2 * (n * 8 + (1 << 20)))
+        a = ctx.generate(BlockType.Float64, 1, 3, n, pack_rows=1 << 20)
+        b = ctx.generate(BlockType.Float64, 2, 4, n, pack_rows=1 << 20)
+        assert a.placement_class() >= 0 and a.placement_class() == b.placement_class()
+        bits = ctx.bits(n, for_col=[a, b])
+        r = ctx.scan(And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5)), [a, b], aggs=[(R.Count, 0)], bits_out=bits)
+        assert r.count == bits.count() and abs(r.count / n - 0.375) < 1e-3
+        c = ctx.generate(BlockType.Int64, 3, 0, 1 << 27, lo=0, pack_rows=1 << 20)     # the next column follows while there is room
+        addr = ctx.generate_bytes(6, 1 << 26, 1 << 20, 32, 16, 4)                    # 0.5 GiB of pointers + 2 GiB of pools
+        assert addr.placement_class(pool=True) >= 0
+        assert addr.placement_class() in (-1, addr.placement_class(pool=True))        # a sub-GiB pointer array lives in the heap
+        big = ctx.generate_bytes(7, 1 << 28, 1 << 20, 32, 16, 4)                     # 2 GiB of pointers + 8 GiB of pools: one class
+        assert big.placement_class() == big.placement_class(pool=True) >= 0
+        for o in (a, b, c, addr, big, bits):
+            o.free()
