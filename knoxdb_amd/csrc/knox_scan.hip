@@ -255,11 +255,8 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // once per iteration is what these instantiations were bound by (measured: float32 +4 %, int16 ALL +7 %, int32 ALL
     // +2 %).  The plain filter / filter+sum kernels do so little between loads that the extra loads in flight only
     // disturb the read / write mix at the memory controllers (int64 headline -10 %): they keep the simple loop.
-#ifdef KNOX_PIPE_NARROW  // A/B builds: the plain 1- / 2-byte scans pipelined as well
-    constexpr bool kPipe = NL == 1 && !SEP && ((AGG & ~A_ISUM) != 0 || W <= 2);
-#else
+    // (round 3 A/B, the plain 1- / 2-byte scans pipelined too: int16 -1.4 ... -2.7 %, uint8 +1.5 % -- left as they are)
     constexpr bool kPipe = NL == 1 && !SEP && (AGG & ~A_ISUM) != 0;
-#endif
     if (kPipe && (iters & 1u) == 0) {
         u32x4 ra[kUnroll];
         u32x4 ra_a[NL][kUnroll], rb[NL][kUnroll];
