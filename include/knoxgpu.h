@@ -442,6 +442,17 @@ int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_limbs /* 2 
 typedef struct knox_packed knox_packed;
 int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
                        size_t pack_rows, knox_packed **out);
+/* A packed column filled on the context's COPY stream (the cold-scan form: bit-packed data crosses PCIe at log2 / 64 of the
+ * bytes of the decoded vectors, so a table that is not resident scans 64 / log2 times faster than knox_col_append_async can
+ * feed it): knox_packed_create reserves room for max_packs packs and max_payload_bytes of packed words;
+ * knox_packed_append_async enqueues the containers of the NEXT packs (same rules as knox_packed_upload: every pack but the
+ * column's last holds pack_rows values; page-locked sources are read in place and must stay untouched until
+ * knox_packed_wait, others are copied inside the call); knox_packed_scan orders itself behind pending appends on the
+ * device; knox_packed_reset empties the column for the next run (call it before enqueueing the other buffer's scan).     */
+int knox_packed_create(knox_ctx *ctx, int dtype, size_t pack_rows, size_t max_packs, size_t max_payload_bytes, knox_packed **out);
+int knox_packed_append_async(knox_ctx *ctx, knox_packed *p, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs);
+int knox_packed_reset(knox_ctx *ctx, knox_packed *p);
+int knox_packed_wait(knox_ctx *ctx, knox_packed *p);
 int knox_packed_free(knox_packed *p);
 size_t knox_packed_rows(const knox_packed *p);
 size_t knox_packed_bytes(const knox_packed *p); /* packed payload resident in HBM */

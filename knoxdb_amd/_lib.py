@@ -93,6 +93,10 @@ SIGNATURES = {
     "knox_col_pool_bytes": (_sz, [_vp]),
     "knox_col_generate_bytes": (_i, [_vp, _u64, _sz, _sz, C.c_uint32, C.c_uint32, C.c_uint32, _pp]),
     "knox_packed_upload": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _pp]),
+    "knox_packed_create": (_i, [_vp, _i, _sz, _sz, _sz, _pp]),
+    "knox_packed_append_async": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "knox_packed_reset": (_i, [_vp, _vp]),
+    "knox_packed_wait": (_i, [_vp, _vp]),
     "knox_packed_free": (_i, [_vp]),
     "knox_packed_rows": (_sz, [_vp]),
     "knox_packed_bytes": (_sz, [_vp]),

@@ -546,7 +546,7 @@ KNOX_API int knox_col_upload(knox_ctx *ctx, int dtype, const void *host, size_t 
 // The reference interleaves loadPack and filter.Match pack by pack (internal/pack/table/reader.go:329-334, loadPack :484).
 // Here a RUN of packs is uploaded on the context's copy stream while the scan of the previous run is in flight on the
 // scan stream; the only coupling is the column's `ready` event, which every reader waits for on the device (col_acquire).
-static int copy_stream_init(knox_ctx *ctx) {
+int copy_stream_init(knox_ctx *ctx) {
     if (ctx->copy_stream) return KNOX_OK;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fence_ev, hipEventDisableTiming));
@@ -556,7 +556,7 @@ static int copy_stream_init(knox_ctx *ctx) {
 // host -> HBM on the copy stream, enqueue only.  Page-locked sources are read in place by the DMA engine and must stay
 // valid until the column's upload has completed (knox_col_wait / knox_col_ready); pageable sources are copied into the
 // copy stream's own pinned ring here and are not referenced after return.
-static int upload_async(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
+int upload_async(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return KNOX_OK;
     if (is_pinned_host(src)) {
         // one DMA per 256 MiB: a single multi-GiB hipMemcpyAsync is not faster and delays the first byte

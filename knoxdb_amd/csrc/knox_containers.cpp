@@ -651,7 +651,117 @@ struct knox_packed {
     uint64_t *d_words;
     PackedPack *d_packs;
     size_t words_bytes;
+    // appendable packed columns (knox_packed_create / _append_async): capacities and the last copy's event
+    size_t packs_cap = 0, words_cap = 0;
+    hipEvent_t ready_ev = nullptr;
+    bool ready_pending = false;
 };
+
+// [4][uvarint For][uvarint log2][uvarint N][packed bits] (int_bitpack.go:93-133): header fields + where the payload lies
+static int parse_bitpack_header(const uint8_t *buf, size_t len, uint64_t *minv, uint64_t *l2, uint64_t *n, size_t *payload_off, size_t *payload_len) {
+    if (!buf || len < 2) return KNOX_E_INVALID;
+    if (buf[0] != 4) return KNOX_E_UNSUPPORTED;  // only bit-packed containers stay packed
+    size_t o = 1;
+    int k = knox_uvarint(buf + o, len - o, minv);
+    if (k == 0) return KNOX_E_INVALID;
+    o += (size_t)k;
+    k = knox_uvarint(buf + o, len - o, l2);
+    if (k == 0 || *l2 > 64) return KNOX_E_INVALID;
+    o += (size_t)k;
+    k = knox_uvarint(buf + o, len - o, n);
+    if (k == 0) return KNOX_E_INVALID;
+    o += (size_t)k;
+    const uint64_t sz = ((*l2 * *n + 63) & ~63ull) / 8;
+    if (o + sz > len) return KNOX_E_RANGE;
+    *payload_off = o;
+    *payload_len = (size_t)sz;
+    return KNOX_OK;
+}
+
+// ---- packed columns filled on the copy stream: a cold scan of bit-packed data crosses PCIe at log2 / 64 of the bytes ------
+KNOX_API int knox_packed_create(knox_ctx *ctx, int dtype, size_t pack_rows, size_t max_packs, size_t max_payload_bytes, knox_packed **out) {
+    if (!ctx || !out || dtype_width(dtype) == 0 || dtype_is_float(dtype) || dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    if (pack_rows == 0 || (pack_rows & 4095) || max_packs == 0 || max_packs > 0xffffffffull || max_payload_bytes == 0) return KNOX_E_INVALID;
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    knox_packed *p = new (std::nothrow) knox_packed();
+    if (!p) return KNOX_E_NOMEM;
+    p->ctx = ctx;
+    p->dtype = dtype;
+    p->n_rows = p->n_packs = p->words_bytes = 0;
+    p->pack_rows = pack_rows;
+    p->d_words = nullptr;
+    p->d_packs = nullptr;
+    p->packs_cap = max_packs;
+    p->words_cap = (max_payload_bytes + 7) / 8;
+    if (dev_malloc(ctx, (void **)&p->d_words, p->words_cap * 8 + 64) != hipSuccess ||
+        dev_malloc(ctx, (void **)&p->d_packs, max_packs * sizeof(PackedPack) + 64) != hipSuccess) {
+        if (p->d_words) dev_free(ctx, p->d_words);
+        delete p;
+        return KNOX_E_NOMEM;
+    }
+    // the kernel reads one word past a field's word unconditionally: the tail is defined once
+    if (hipMemsetAsync((char *)p->d_words + p->words_cap * 8, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        knox_packed_free(p);
+        return KNOX_E_HIP;
+    }
+    *out = p;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_packed_append_async(knox_ctx *ctx, knox_packed *p, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs) {
+    if (!ctx || !p || p->ctx != ctx || p->packs_cap == 0 || !bufs || !lens) return KNOX_E_INVALID;
+    if (n_bufs == 0) return KNOX_OK;
+    if (n_bufs > p->packs_cap - p->n_packs) return KNOX_E_RANGE;
+    if (p->n_packs && p->n_rows != p->n_packs * p->pack_rows) return KNOX_E_INVALID;  // a short pack can only be the last one
+    hipSetDevice(ctx->device);
+    int rc = copy_stream_init(ctx);
+    if (rc) return rc;
+    std::vector<PackedPack> packs(n_bufs);
+    std::vector<size_t> off(n_bufs), plen(n_bufs);
+    size_t words = p->words_bytes / 8, rows = 0;
+    for (size_t i = 0; i < n_bufs; i++) {
+        uint64_t minv = 0, l2 = 0, n = 0;
+        rc = parse_bitpack_header(bufs[i], lens[i], &minv, &l2, &n, &off[i], &plen[i]);
+        if (rc) return rc;
+        if (n > p->pack_rows || (i + 1 < n_bufs && n != p->pack_rows) || n == 0) return KNOX_E_INVALID;
+        if (words + plen[i] / 8 > p->words_cap) return KNOX_E_RANGE;
+        packs[i] = {words, minv, (uint32_t)n, (uint32_t)l2};
+        words += plen[i] / 8;
+        rows += (size_t)n;
+    }
+    // payloads (page-locked sources in place, others through the copy stream's ring), then the pack descriptors
+    for (size_t i = 0; i < n_bufs && !rc; i++) rc = upload_async(ctx, p->d_words + packs[i].word_off, bufs[i] + off[i], plen[i]);
+    if (!rc) rc = upload_async(ctx, p->d_packs + p->n_packs, packs.data(), n_bufs * sizeof(PackedPack));
+    if (rc) return rc;
+    if (!p->ready_ev) HIPCHK(ctx, hipEventCreateWithFlags(&p->ready_ev, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(p->ready_ev, ctx->copy_stream));
+    p->ready_pending = true;
+    p->n_packs += n_bufs;
+    p->n_rows += rows;
+    p->words_bytes = words * 8;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_packed_reset(knox_ctx *ctx, knox_packed *p) {
+    if (!ctx || !p || p->ctx != ctx || p->packs_cap == 0) return KNOX_E_INVALID;
+    hipSetDevice(ctx->device);
+    int rc = copy_stream_init(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->fence_ev, ctx->stream));   // the scans enqueued so far may still read the old words
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
+    p->n_packs = p->n_rows = p->words_bytes = 0;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_packed_wait(knox_ctx *ctx, knox_packed *p) {
+    if (!ctx || !p) return KNOX_E_INVALID;
+    if (p->ready_pending) {
+        HIPCHK(ctx, hipEventSynchronize(p->ready_ev));
+        p->ready_pending = false;
+    }
+    return KNOX_OK;
+}
 
 KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs, size_t pack_rows,
                                 knox_packed **out) {
@@ -664,21 +774,10 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
     std::vector<size_t> payload_len(n_bufs);
     size_t words = 0, rows = 0;
     for (size_t i = 0; i < n_bufs; i++) {
-        if (!bufs[i] || lens[i] < 2) return KNOX_E_INVALID;
-        if (bufs[i][0] != 4) return KNOX_E_UNSUPPORTED;  // only bit-packed containers stay packed
-        size_t o = 1;
         uint64_t minv = 0, l2 = 0, n = 0;
-        int k = knox_uvarint(bufs[i] + o, lens[i] - o, &minv);
-        if (k == 0) return KNOX_E_INVALID;
-        o += (size_t)k;
-        k = knox_uvarint(bufs[i] + o, lens[i] - o, &l2);
-        if (k == 0 || l2 > 64) return KNOX_E_INVALID;
-        o += (size_t)k;
-        k = knox_uvarint(bufs[i] + o, lens[i] - o, &n);
-        if (k == 0) return KNOX_E_INVALID;
-        o += (size_t)k;
-        const uint64_t sz = ((l2 * n + 63) & ~63ull) / 8;
-        if (o + sz > lens[i]) return KNOX_E_RANGE;
+        size_t o = 0, sz = 0;
+        const int prc = parse_bitpack_header(bufs[i], lens[i], &minv, &l2, &n, &o, &sz);
+        if (prc) return prc;
         if (n > pack_rows || (i + 1 < n_bufs && n != pack_rows) || n == 0) return KNOX_E_INVALID;  // only the last pack may be short
         packs[i] = {words, minv, (uint32_t)n, (uint32_t)l2};
         payload[i] = bufs[i] + o;
@@ -719,6 +818,8 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
 KNOX_API int knox_packed_free(knox_packed *p) {
     if (!p) return KNOX_E_INVALID;
     hipSetDevice(p->ctx->device);
+    if (p->ready_pending) hipEventSynchronize(p->ready_ev);
+    if (p->ready_ev) hipEventDestroy(p->ready_ev);
     hipStreamSynchronize(p->ctx->stream);
     if (p->d_words) dev_free(p->ctx, p->d_words);
     if (p->d_packs) dev_free(p->ctx, p->d_packs);
@@ -737,6 +838,7 @@ KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint6
     if (pack_counts && !bits_out) return KNOX_E_INVALID;  // per-pack counts come from the bitset
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
+    if (p->ready_pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, p->ready_ev, 0));  // behind the column's asynchronous appends
     LeafHost lh;
     int rc = make_leaf(p->dtype, op, a, b, lh);
     if (rc) return rc;

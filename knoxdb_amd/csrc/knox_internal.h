@@ -340,6 +340,8 @@ struct SkipPlan {
 void prof_mark(knox_ctx *ctx, int which);                                       // knox_prof_*: event before / after the timed kernel
 int upload(knox_ctx *ctx, void *dst, const void *src, size_t bytes);            // host -> HBM through the pinned ring (in place from page-locked memory)
 int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes);
+int copy_stream_init(knox_ctx *ctx);                                            // the context's copy stream (ingest that overlaps the scans)
+int upload_async(knox_ctx *ctx, void *dst, const void *src, size_t bytes);      // enqueue only, on the copy stream
 int col_new(knox_ctx *ctx, int dtype, size_t n_rows, size_t pack_rows, bool alloc, knox_col **out);
 int bits_alloc(knox_ctx *ctx, size_t size_bits, const knox_col *for_col, knox_bits **out);
 int make_leaf(int dtype, int op, uint64_t a, uint64_t b, LeafHost &out);

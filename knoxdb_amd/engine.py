@@ -471,6 +471,12 @@ class Context:
         check(self.L.knox_packed_upload(self.h, int(dtype), ptrs, lens, len(bufs), pack_rows, C.byref(h)), "knox_packed_upload")
         return Packed(self, h, BlockType(dtype), len(bufs))
 
+    def packed_create(self, dtype, pack_rows, max_packs, max_payload_bytes):
+        """an empty packed column filled by Packed.append_async on the copy stream (knox_packed_create)"""
+        h = C.c_void_p()
+        check(self.L.knox_packed_create(self.h, int(dtype), pack_rows, max_packs, max_payload_bytes, C.byref(h)), "knox_packed_create")
+        return Packed(self, h, BlockType(dtype), 0)
+
     def upload_wide_containers(self, n_limbs, containers, pack_rows=0):
         """Int128 / Int256 containers -> limb columns (most significant first) for match_wide"""
         bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
@@ -694,6 +700,23 @@ class Packed:
     @property
     def nbytes(self):
         return _lib.lib().knox_packed_bytes(self.h)
+
+    def append_async(self, containers):
+        """enqueue the bit-packed containers of the next packs (numpy uint8 arrays -- page-locked ones are read in place and must
+        stay untouched until wait() -- or bytes)"""
+        bufs = [c if isinstance(c, np.ndarray) else np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(1, len(bufs)))(*[b.size for b in bufs])
+        check(_lib.lib().knox_packed_append_async(self.ctx.h, self.h, ptrs, lens, len(bufs)), "knox_packed_append_async")
+        self.n_packs += len(bufs)
+        self._keep = bufs
+
+    def reset(self):
+        check(_lib.lib().knox_packed_reset(self.ctx.h, self.h), "knox_packed_reset")
+        self.n_packs = 0
+
+    def wait(self):
+        check(_lib.lib().knox_packed_wait(self.ctx.h, self.h), "knox_packed_wait")
 
     def scan(self, mode, a, b=None, want_sum=False, bits_out=None, pack_counts=False):
         """-> (count, sum state or None, per-pack counts or None)"""

@@ -141,3 +141,58 @@ def test_append_pack_by_pack_and_capacity(ctx):
     assert ctx.L.knox_col_append_async(ctx.h, plain.h, y.ctypes.data_as(C.c_void_p), 1) == -1
     for o in (col, bits, b2, plain):
         o.free()
+
+
+def test_packed_columns_streamed_on_the_copy_stream(ctx):
+    """bit-packed containers appended asynchronously to two packed columns in turn (the cold-scan form: the data crosses PCIe
+    packed), scanned as they are: every run's bitset, per-pack counts, count and wrapping sum equal knox_packed_upload +
+    knox_packed_scan of the same containers and the oracle's evaluation of the decoded values"""
+    rng = np.random.default_rng(21)
+    pack, bits_per = 8192, 13
+    base = 1_700_000_000_000
+    runs = []
+    for n_packs, last in ((6, pack), (3, pack), (5, pack - 1000)):          # the third run ends in a short pack
+        vals = [base + rng.integers(0, 1 << bits_per, size=(last if p + 1 == n_packs else pack), dtype=np.int64) for p in range(n_packs)]
+        runs.append((vals, [O.bitpack_container_store(O.I64, v) for v in vals]))
+    a, b = base + 1000, base + 5000
+    cols = [ctx.packed_create(BlockType.Int64, pack, 8, 8 * pack * 2), ctx.packed_create(BlockType.Int64, pack, 8, 8 * pack * 2)]
+    pins = []
+    def pinned(conts):                                                       # containers in page-locked memory: DMA'd in place
+        out = []
+        for c in conts:
+            h = ctx.host_array(len(c), np.uint8)
+            h[:] = np.frombuffer(c, dtype=np.uint8)
+            pins.append(h)
+            out.append(h)
+        return out
+    cols[0].append_async(pinned(runs[0][1]))
+    for i, (vals, conts) in enumerate(runs):
+        cur, nxt = cols[i & 1], cols[(i + 1) & 1]
+        if i + 1 < len(runs):
+            nxt.reset()
+            nxt.append_async(pinned(runs[i + 1][1]) if i == 0 else runs[i + 1][1])   # page-locked and pageable sources
+        x = np.concatenate(vals)
+        assert cur.rows == x.size
+        bits = ctx.bits(x.size)
+        cnt, st, pc = cur.scan(FilterMode.Range, a, b, want_sum=True, bits_out=bits, pack_counts=True)
+        ref = ctx.packed_upload(BlockType.Int64, conts, pack)
+        rbits = ctx.bits(x.size)
+        rcnt, rst, rpc = ref.scan(FilterMode.Range, a, b, want_sum=True, bits_out=rbits, pack_counts=True)
+        wb, wc = O.cmp(O.I64, O.RG, x, a, b)
+        assert cnt == rcnt == wc and (pc == rpc).all() and int(pc.sum()) == wc
+        assert (bits.bytes(poison=32) == wb).all() and (rbits.bytes(poison=32) == wb).all()
+        assert int(K.agg_value(st, R.Sum)[0]) == int(K.agg_value(rst, R.Sum)[0]) == int(x[(x >= a) & (x <= b)].sum())
+        for o in (bits, rbits, ref):
+            o.free()
+    # capacity: a ninth pack does not fit
+    cols[0].reset()
+    cols[0].append_async(runs[0][1] + runs[1][1][:2])
+    import ctypes as C
+    one = np.frombuffer(runs[0][1][0], dtype=np.uint8)
+    ptrs, lens = (C.c_void_p * 1)(one.ctypes.data), (C.c_size_t * 1)(one.size)
+    assert ctx.L.knox_packed_append_async(ctx.h, cols[0].h, ptrs, lens, 1) == -7       # KNOX_E_RANGE
+    for c in cols:
+        c.wait()
+        c.free()
+    for h in pins:
+        ctx.host_free(h)
