@@ -305,6 +305,50 @@ def secondary_configs(K, ctx, n_rows, pack_rows, steps, warmup, parity=True):
     return out
 
 
+def measure_traffic_live(rows_log2, timeout_s=90):
+    """roofline.traffic measured in THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate
+    passes, as MI355X_MICROARCH.md prescribes; no trace flags) run the headline scan a few times (`bench.py --pmc-child`), the
+    per-dispatch counters of scan_kernel<8,1,ISUM> are read back from the CSVs.  Called after this process has closed its
+    context; the children are ordinary child processes (nothing is exec'ed over a process that touched the GPU).  Returns
+    (hbm_bytes_per_launch, detail) or (None, reason): the caller then falls back to profiles/traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="knox_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--rows-log2", str(rows_log2), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-configs"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 pass %s timed out" % ctr
+            if r.returncode != 0:
+                return None, "rocprofv3 pass %s failed (rc %d): %s" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            got = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "scan_kernel<8, 1, 1u, false, false, 0u>" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "no %s rows for the headline kernel" % ctr
+            vals[ctr] = (sum(got) / len(got), len(got))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a 16 B/lane streaming read (the guide's
+    # gfx950 correction): doubled.  WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+    fetch_b, write_b = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return fetch_b + write_b, {"FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"][0], "WRITE_SIZE_KiB_raw": vals["WRITE_SIZE"][0],
+                               "dispatches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]], "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b}
+
+
 def launch_ranks(n):
     """`bench.py --gpus N` without a launcher around it: start N rank processes (one per GPU, RCCL over xGMI between
     them) and wait.  They are FRESH interpreters -- this parent has not touched the GPU and never does (a process
@@ -346,6 +390,8 @@ def main():
     ap.add_argument("--rows-log2", type=int, default=30, help="rows per GPU = 2^k (default 2^30 = the 1B-row config)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and every oracle-backed parity check")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip BASELINE configs[2] / configs[3] after the timed region")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc child passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child of measure_traffic_live: headline scans only, no output
     ap.add_argument("--cpu-sample-log2", type=int, default=29)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--collective", choices=["abi", "torch"], default=None,
@@ -524,6 +570,13 @@ def main():
         return last
 
     wres, wsum, wtotal = run(max(1, args.warmup))
+    if args.pmc_child:   # under rocprofv3 --pmc: a few more scans for the counters, then out (no JSON line, no baselines)
+        run(args.steps)
+        ctx.sync()
+        col.free()
+        bits.free()
+        ctx.close()
+        return
     collectives_agree = None
     if dist is not None:
         merged, gtotal = gather(wres.states, wres.count)
@@ -653,6 +706,17 @@ def main():
             traceback.print_exc()
             out["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
     ctx.close()
+    if rank == 0 and world == 1 and args.rows_log2 == 30 and not args.no_live_traffic and not args.no_cpu_baseline:
+        t_pmc = time.perf_counter()
+        live, detail = measure_traffic_live(args.rows_log2)
+        if live is not None:
+            out["roofline"]["traffic"] = live
+            out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over the same scan (bench.py "
+                                                 "--pmc-child), FETCH x 2 (gfx950) + WRITE, %.1f s" % (time.perf_counter() - t_pmc))
+            out["roofline"]["traffic_detail"] = detail
+        else:
+            out["roofline"]["traffic_live_failed"] = detail
+        print("[traffic] %s" % (("%.4g B per launch = %.4f x algorithmic" % (live, live / (n_rows * BYTES_PER_ROW))) if live is not None else detail), file=sys.stderr, flush=True)
     if rank == 0 and not args.no_cpu_baseline:
         # rank 0 only, after the timed region and its closing barrier (the other ranks are done and wait in destroy)
         sample = min(n_rows, 1 << args.cpu_sample_log2)
