@@ -138,9 +138,9 @@ class Scope:
         self.vars = {}
         self.structs_go = structs_go  # Go struct name -> {field: cgo type}
         self.objs = {}  # Go variable -> Go struct name (receivers / params of wrapper types)
-        for nm, ty in re.findall(r"(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State)\b", header_line):
+        for nm, ty in re.findall(r"(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed)\b", header_line):
             self.objs[nm] = ty
-        for names, ty in re.findall(r"\b([\w, ]+?)\s+\*?(Ctx|Column|Bits|Bloom|State)\b", header_line):
+        for names, ty in re.findall(r"\b([\w, ]+?)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed)\b", header_line):
             for nm in names.split(","):
                 self.objs[nm.strip()] = ty
         # parameters of cgo types: `rc C.int`
@@ -150,7 +150,7 @@ class Scope:
         for nm in re.findall(r"\b(\w+)\s*:=\s*\w+\.c\b(?!\.)", body):
             self.objs[nm] = "Ctx"
         # locals of wrapper types: `var out State`
-        for nm, ty in re.findall(r"\bvar\s+(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State)\b", body):
+        for nm, ty in re.findall(r"\bvar\s+(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed)\b", body):
             self.objs[nm] = ty
         # var a, b C.type / var a *C.type
         for names, ty in re.findall(r"\bvar\s+([\w, ]+?)\s+(\*{0,2}C\.\w+)", body):

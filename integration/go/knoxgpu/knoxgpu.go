@@ -509,6 +509,95 @@ func Combine(states []State) State {
 	return out
 }
 
+// ---- bit-packed columns scanned as they are (internal/encode/int_bitpack.go, bitpack/cmp_*.go) ----------------------
+
+// Packed is a column whose packs stay bit-packed in HBM: BitpackContainer.MatchEqual ... MatchBetween (+ count, sum, per-pack
+// counts) for a whole run in one call, and the form in which a table that is NOT resident crosses PCIe (log2 / 64 of the bytes).
+type Packed struct {
+	p *C.knox_packed
+	c *Ctx
+}
+
+// cBufs copies Go buffers into C memory and builds the C arrays knox_* container entry points take (a C array of pointers
+// must not point into Go memory); free() releases everything.
+func cBufs(bufs [][]byte) (ptrs unsafe.Pointer, lens unsafe.Pointer, free func()) {
+	n := len(bufs)
+	ptrs = C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0))))
+	lens = C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(C.size_t(0))))
+	pv := unsafe.Slice((**C.uint8_t)(ptrs), n)
+	lv := unsafe.Slice((*C.size_t)(lens), n)
+	for i, b := range bufs {
+		pv[i] = (*C.uint8_t)(C.CBytes(b))
+		lv[i] = C.size_t(len(b))
+	}
+	return ptrs, lens, func() {
+		for _, q := range pv {
+			C.free(unsafe.Pointer(q))
+		}
+		C.free(ptrs)
+		C.free(lens)
+	}
+}
+
+// NewPacked: room for maxPacks packs / maxPayloadBytes of packed words; filled by AppendAsync on the context's copy stream.
+func NewPacked(c *Ctx, dtype, packRows, maxPacks int, maxPayloadBytes uint64) (*Packed, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var p *C.knox_packed
+	rc := C.knox_packed_create(c.p, C.int(dtype), C.size_t(packRows), C.size_t(maxPacks), C.size_t(maxPayloadBytes), &p)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Packed{p, c}, nil
+}
+
+// AppendAsync enqueues the [4] containers of the next packs (NumberContainer.Store bytes) and returns.
+func (pk *Packed) AppendAsync(bufs [][]byte) error {
+	c := pk.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	ptrs, lens, free := cBufs(bufs)
+	defer free()
+	return errOf(C.knox_packed_append_async(c.p, pk.p, (**C.uint8_t)(ptrs), (*C.size_t)(lens), C.size_t(len(bufs))))
+}
+
+func (pk *Packed) Reset() error {
+	c := pk.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	return errOf(C.knox_packed_reset(c.p, pk.p))
+}
+
+// Scan: one numeric leaf on the packed words: count, wrapping sum state, selection bitset (nullable), per-pack counts.
+func (pk *Packed) Scan(mode int, a, b uint64, wantSum bool, bitsOut *Bits, packCounts []int64) (int64, State, error) {
+	c := pk.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var bo *C.knox_bits
+	if bitsOut != nil {
+		bo = bitsOut.p
+	}
+	var pc *C.int64_t
+	if packCounts != nil {
+		pc = (*C.int64_t)(unsafe.SliceData(packCounts))
+	}
+	ws := 0
+	if wantSum {
+		ws = 1
+	}
+	var cnt C.int64_t
+	var st State
+	rc := C.knox_packed_scan(c.p, pk.p, C.int(mode), C.uint64_t(a), C.uint64_t(b), C.int(ws), bo, pc, &cnt, &st.c)
+	return int64(cnt), st, errOf(rc)
+}
+
+func (pk *Packed) Free() {
+	c := pk.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	C.knox_packed_free(pk.p)
+}
+
 // ---- per-pack bloom pre-filter (internal/filter/bloom/bloom.go:136-150) ------------------------------------------
 
 type Bloom struct {

@@ -22,7 +22,7 @@ for name, (res, args) in LL.SIGNATURES.items():
     fn.restype, fn.argtypes = res, args
 
 ctxA = K.Context(0)
-spec = {"i64": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "i64b": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "f64": (B.Float64, 8, 0, 0, 2),
+spec = {"i64": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "i64b": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "f64": (B.Float64, 8, 0, 0, 2), "f64b": (B.Float64, 8, 0, 0, 2),
         "i32": (B.Int32, 4, -(1 << 30), 1 << 31, 0), "f32": (B.Float32, 4, 0, 0, 2), "i16": (B.Int16, 2, -(1 << 15), 1 << 16, 0),
         "u8": (B.Uint8, 1, 0, 256, 0)}
 colsA = {k: ctxA.generate(bt, kind, 2 + i, n, lo=lo, span=span, pack_rows=pack) for i, (k, (bt, w, lo, span, kind)) in enumerate(spec.items())}
@@ -43,6 +43,7 @@ cases = [
     ("i64 Between+sum", ["i64"], lambda: And(Leaf(0, F.Range, -(1 << 38), 1 << 38)), [(R.Sum, 0)], 8.125),
     ("i64 Between+ALL", ["i64"], lambda: And(Leaf(0, F.Range, -(1 << 38), 1 << 38)), ALLA, 8.125),
     ("f64 Lt+sum/min/max/mean", ["f64"], lambda: And(Leaf(0, F.Lt, 0.25)), [(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0)], 8.125),
+    ("f64 x2 AND + min/max/mean (cfg 3)", ["f64", "f64b"], lambda: And(Leaf(0, F.Ge, 0.25), Leaf(1, F.Lt, 0.5)), [(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Sum, 0), (R.Count, 0)], 16.125),
     ("i64 x2 AND + sum", ["i64", "i64b"], lambda: And(Leaf(0, F.Gt, 0), Leaf(1, F.Lt, 0)), [(R.Sum, 0)], 16.125),
     ("i32 Between+sum", ["i32"], lambda: And(Leaf(0, F.Range, -(1 << 28), 1 << 28)), [(R.Sum, 0)], 4.125),
     ("f32 Lt+sum/min/max/mean", ["f32"], lambda: And(Leaf(0, F.Lt, 0.25)), [(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0)], 4.125),
