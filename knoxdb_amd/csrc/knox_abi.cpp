@@ -1605,7 +1605,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     const bool plain = plain_scan;  // filter or filter + wrapping sum
     const bool f32sum = width == 4 && agg_col && (agg & A_FSUM) != 0 && a.agg_flavor == FL_FLOAT;
     int per_cu;
-    if (n_leaves > 1) per_cu = 3;
+    if (n_leaves > 1) per_cu = (n_leaves == 2 && !plain) ? 2 : 3;  // the pipelined two-leaf aggregate kernels hold 2 workgroups per CU (177 VGPRs)
     else if (plain) per_cu = width == 1 ? 3 : 2;
     else if (f32sum) per_cu = 8;
     else per_cu = width == 2 ? 3 : 2;

@@ -256,11 +256,8 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // +2 %).  The plain filter / filter+sum kernels do so little between loads that the extra loads in flight only
     // disturb the read / write mix at the memory controllers (int64 headline -10 %): they keep the simple loop.
     // (round 3 A/B, the plain 1- / 2-byte scans pipelined too: int16 -1.4 ... -2.7 %, uint8 +1.5 % -- left as they are)
-#ifdef KNOX_PIPE_NL2  // A/B builds: two-leaf aggregate-heavy scans (BASELINE configs[2]) pipelined as well
+    // (round 3: two-leaf aggregate-heavy scans too -- BASELINE configs[2]: +1.4 % on identical buffers, tools/ab_kernels.py)
     constexpr bool kPipe = NL <= 2 && !SEP && (AGG & ~A_ISUM) != 0;
-#else
-    constexpr bool kPipe = NL == 1 && !SEP && (AGG & ~A_ISUM) != 0;
-#endif
     if (kPipe && (iters & 1u) == 0) {
         u32x4 ra[kUnroll];
         u32x4 ra_a[NL][kUnroll], rb[NL][kUnroll];
