@@ -327,7 +327,9 @@ def measure_traffic_live(rows_log2, timeout_s=90):
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--rows-log2", str(rows_log2), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-configs"]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KNOX_BENCH_FORCE_DIST", "KNOX_BENCH_BACKEND")}
+                env["TMPDIR"] = "/tmp"   # the child is a plain single-process run whatever launched this one
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
             except subprocess.TimeoutExpired:
                 return None, "rocprofv3 pass %s timed out" % ctr
             if r.returncode != 0:
