@@ -49,6 +49,8 @@ TRAFFIC_KERNELS = {
     "cfg3": "scan_kernel<8, 2, 14u, false, true, 2u>",             # 2 x float64, AND, min / max / mean (configs[2])
     "cfg4_bytes": "bytes_eq_kernel",                                # []byte EQ over per-pack StringPools (configs[3])
     "cfg4_u64": "scan_kernel<8, 1, 0u, false, false, 0u>",         # uint64 EQ + count (also the read-only form: full-size dispatches)
+    "u8_filter_sum": "scan_kernel<1, 1, 1u, false, false, 0u>",     # tools/bench_narrow.py: 1- / 2-byte filter + sum
+    "i16_filter_sum": "scan_kernel<2, 1, 1u, false, false, 0u>",
     "bloom_count_u64": "bloom_count_kernel<8, HashNumeric>",
     "bloom_bin_u64": "bloom_bin_kernel<8, HashNumeric>",
     "bloom_count_bytes": "bloom_count_kernel<8, HashBytes>",
