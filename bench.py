@@ -327,7 +327,7 @@ def measure_traffic_live(rows_log2, timeout_s=90):
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--rows-log2", str(rows_log2), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-configs"]
             try:
-                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KNOX_BENCH_FORCE_DIST", "KNOX_BENCH_BACKEND")}
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KNOX_BENCH_FORCE_DIST", "KNOX_BENCH_BACKEND", "KNOX_ARENA_LOG")}
                 env["TMPDIR"] = "/tmp"   # the child is a plain single-process run whatever launched this one
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
             except subprocess.TimeoutExpired:
@@ -459,6 +459,15 @@ def main():
     local_rank = device_index
 
     import numpy as np
+    # the arena's decisions (chunk labels, every write-buffer candidate and what it measured) of THIS run, kept beside the
+    # other outputs: a placement that went wrong on some box can be read afterwards (knox_arena.h dbg)
+    if "KNOX_ARENA_LOG" not in os.environ and not args.pmc_child:
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            os.environ["KNOX_ARENA_LOG"] = os.path.join(ROOT, "gpurun_out", "arena_rank%d.log" % rank)
+            open(os.environ["KNOX_ARENA_LOG"], "w").close()
+        except OSError:
+            os.environ.pop("KNOX_ARENA_LOG", None)
     import knoxdb_amd as K
     from knoxdb_amd import And, Leaf
     from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc
@@ -651,6 +660,7 @@ def main():
         assert parity["sample_bitsets_equal_oracle"] and parity["xor_equals_cpu"] and parity["count_equals_cpu"] and parity["sum_equals_cpu"], parity
 
     ai = ctx.arena_info()
+    class_gib, classes_seen = ctx.arena_classes()
     out = {
         "metric": "scanned rows/sec + achieved HBM GB/s, 1B-row int64 range filter+sum",
         "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -680,6 +690,7 @@ def main():
         "placement": {"arena_enabled": ai["enabled"], "arena_budget_gib": ai["budget_gib"], "arena_mapped_gib": ai["mapped_gib"],
                       "arena_used_gib": ai["used_gib"], "write_buffers_created": ai["write_buffers"], "spare_write_buffer_gib": ai["spare_write_buffer_gib"],
                       "chunks_created": ai["chunks"], "probe_measurements": ai["probes"], "mixed_zone_gib": ai["mixed_zone_gib"],
+                      "classes_seen": classes_seen, "column_space_gib_per_class": class_gib,
                       "bitset_pair_check_at_allocation": {"scan_over_read_only": bits.pair_check[0], "candidate_windows": bits.pair_check[1]},
                       "held_outside_arena_bytes": ctx.placement_info()["held_bytes"], "setup_checks": checks, "setup_s": t_setup},
     }

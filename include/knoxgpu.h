@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KNOX_ABI_VERSION 5
+#define KNOX_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------------------- */
 enum knox_err {
@@ -132,6 +132,9 @@ typedef struct knox_arena_info {
     int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
 } knox_arena_info;
 int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out);
+/* Column space mapped per placement class (chunks labelled so far, used or free) and the number of classes met.
+ * Diagnostics: a context whose classes_seen stays 1 while bitsets are placed has found one class of memory only.        */
+int knox_ctx_arena_classes(knox_ctx *ctx, uint64_t class_bytes[4], int *classes_seen /* nullable */);
 /* Room for columns that will be SCANNED TOGETHER (the columns of one table run, the leaves of one filter tree): grows the
  * arena until one placement class has `bytes` contiguous free and makes that class the preferred one of the following
  * column allocations.  Two read streams of one scan run 4-5 % faster when they lie in ONE class (the bitset they write in

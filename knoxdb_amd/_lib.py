@@ -153,6 +153,7 @@ SIGNATURES = {
     "knox_ctx_reserve": (_i, [_vp, _sz]),
     "knox_col_placement_class": (_i, [_vp, _i]),
     "knox_ctx_arena_info": (_i, [_vp, C.POINTER(ArenaInfo)]),
+    "knox_ctx_arena_classes": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "knox_ctx_arena_trim": (_i, [_vp, C.POINTER(_sz)]),
     "knox_bits_pair_check": (_i, [_vp, C.POINTER(C.c_double), _pi]),
     "knox_bits_wrap": (_i, [_vp, _vp, _sz, _pp]),

@@ -233,6 +233,13 @@ KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
     return KNOX_OK;
 }
 
+KNOX_API int knox_ctx_arena_classes(knox_ctx *ctx, uint64_t class_bytes[4], int *classes_seen) {
+    if (!ctx || !class_bytes) return KNOX_E_INVALID;
+    for (int c = 0; c < 4; c++) class_bytes[c] = ctx->arena.zone_bytes(c + 1);
+    if (classes_seen) *classes_seen = ctx->arena.classes_seen();
+    return KNOX_OK;
+}
+
 KNOX_API int knox_ctx_arena_trim(knox_ctx *ctx, size_t *freed_bytes) {
     if (!ctx) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);

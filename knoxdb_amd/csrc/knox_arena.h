@@ -100,9 +100,10 @@ class Arena {
     static constexpr int kNearCandidates = 6;                  // new write buffers looked at before reaching further
     static constexpr int kMaxClasses = 4;                      // placement classes told apart (three were ever seen on one device)
     static constexpr size_t kRefBytes = (size_t)32 << 20;      // a class's reference window
-    static constexpr int kMaxGrowForWrite = 24;                // chunks taken at most while looking for memory of another class (round 2: 8; the
-                                                               // driver's free memory comes in runs of 5-40 GiB of one class, and a profiled bench run
-                                                               // that found none within 8 ran the headline scan at 0.72 instead of 0.87 of peak)
+    static constexpr int kMaxGrowForWrite = 96;                // chunks taken at most while looking for memory of another class (round 2: 8; the
+                                                               // driver's free memory comes in runs of one class: a profiled bench run that found none
+                                                               // within 8 ran the headline scan at 0.72 instead of 0.87 of peak, and so did one that
+                                                               // found none within 24 -- its run was > 40 GiB long; a chunk costs ~10 ms to take and label)
     static constexpr size_t kMaxSpareBytes = (size_t)6 << 30;  // spare write buffers kept (beyond: returned to the driver; they are small)
 
     bool usable = false;
@@ -314,11 +315,52 @@ class Arena {
         int col_classes = 0;
         for (bool z : in_zone) col_classes += z;
         const int max_grow = col_classes >= 2 ? 2 * kMaxGrowForWrite : kMaxGrowForWrite;
+        // Labels are a shortcut, not the decision: a chunk whose label says "the column's class" (or whose zone failed above)
+        // is still measured against the column directly, once, at the moment it arrives -- a label that a noisy reading got
+        // wrong, or a column that is not class pure, must not make the search walk past the memory it is looking for.
+        char *zcand = nullptr;
+        double zcand_r = -1.0;
         for (int grown = 0; any_zone && grown < max_grow && grown_for_write < 2 * max_grow; grown++) {
-            if (grow_zone() < 0) break;
+            const int zi = grow_zone();
+            if (zi < 0) break;
             grown_for_write++;  // over the arena's life: a device whose free memory is one long run of one class is not mapped chunk by chunk in vain
-            if (try_zones()) return hipSuccess;
+            if (!in_zone[zi] && !zone_failed[zi]) {
+                if (try_zones()) {
+                    if (zcand) (void)release(zcand);
+                    return hipSuccess;
+                }
+                continue;
+            }
+            char *va = nullptr;
+            if (!zone_take_top(zi, wb_bytes, &va)) continue;
+            const double r = measure(va);
+            dbg("write buffer (%zu MiB) in the chunk just taken (zone %d%s) vs the column(s): %.3f", wb_bytes >> 20, zi,
+                in_zone[zi] ? ", the column's own label" : ", a zone that failed before", r);
+            if (r >= kFastAbove) {
+                if (zcand) (void)release(zcand);
+                if (best.va) add_spare(best);
+                best.va = nullptr;
+                *out = va;
+                if (ratio_out) *ratio_out = r;
+                return hipSuccess;
+            }
+            if (r > zcand_r) {
+                if (zcand) (void)release(zcand);
+                zcand = va;
+                zcand_r = r;
+            } else {
+                (void)release(va);
+            }
         }
+        if (zcand && zcand_r > best_r) {  // the best there is lies in a zone
+            if (best.va) add_spare(best);
+            *out = zcand;
+            if (ratio_out) *ratio_out = zcand_r;
+            dbg("nothing fast within reach: the best candidate (%.3f, in a zone)", zcand_r);
+            return hipSuccess;
+        }
+        if (zcand) (void)release(zcand);
+        dbg("nothing fast within reach: the best candidate (%.3f)", best_r);
         // Nothing fast within reach (the free memory around is all of the column's class, a run longer than what was
         // looked at): the best candidate there is.  An earlier version then skipped ahead in the driver's allocation order
         // with transient 24 GiB spacers; measured on a box in exactly this state it found nothing in 144 GiB, and handing
@@ -447,13 +489,19 @@ class Arena {
         return (bytes + align - 1) & ~(align - 1);
     }
     static void dbg(const char *fmt, ...) __attribute__((format(printf, 1, 2))) {
-        static const bool debug = getenv("KNOX_ARENA_DEBUG") != nullptr;
-        if (!debug) return;
+        // KNOX_ARENA_LOG=<path>: every decision appended to that file (bench.py keeps one per run); KNOX_ARENA_DEBUG: to stderr
+        static FILE *const sink = [] {
+            const char *path = getenv("KNOX_ARENA_LOG");
+            FILE *f = path && *path ? fopen(path, "a") : nullptr;
+            return f ? f : (getenv("KNOX_ARENA_DEBUG") != nullptr ? stderr : nullptr);
+        }();
+        if (!sink) return;
         va_list ap;
         va_start(ap, fmt);
-        fprintf(stderr, "[arena] ");
-        vfprintf(stderr, fmt, ap);
-        fprintf(stderr, "\n");
+        fprintf(sink, "[arena] ");
+        vfprintf(sink, fmt, ap);
+        fprintf(sink, "\n");
+        if (sink != stderr) fflush(sink);
         va_end(ap);
     }
     static void drop_extent(Extent &e) {  // mapping by mapping, as they were made

@@ -357,6 +357,13 @@ class Context:
                 "enabled": bool(a.enabled), "mixed_zone_gib": a.mixed_zone_bytes / 2**30,
                 "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30}
 
+    def arena_classes(self):
+        """-> (GiB of column space per placement class, classes met); include/knoxgpu.h knox_ctx_arena_classes"""
+        b = (C.c_uint64 * 4)()
+        n = C.c_int()
+        check(self.L.knox_ctx_arena_classes(self.h, b, C.byref(n)))
+        return [x / 2**30 for x in b], n.value
+
     def arena_trim(self):
         f = C.c_size_t()
         check(self.L.knox_ctx_arena_trim(self.h, C.byref(f)))
