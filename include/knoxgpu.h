@@ -485,14 +485,19 @@ int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins, const kn
  * the rows are walked one per lane, decoding runes exactly as Go does (invalid byte = U+FFFD, width 1).
  * bits: overwritten when mask is NULL; with a mask only masked rows are evaluated and their hits OR-ed in
  * (the reference's bits.Set(i) loop).  Syntax: Go's regexp/syntax (RE2) -- literals, escapes, classes,
- * Perl and POSIX classes, . * + ? {n,m} (lazy forms too), groups and named groups, | , ^ $ \A \z \b \B,
- * flags i m s U.  KNOX_E_UNSUPPORTED = outside that subset (\p{..}, case folding of non-ASCII runes, a DFA
- * above 4096 states): the caller keeps regexp.Match for that condition.  The same program serves a
- * KNOX_REGEXP leaf of knox_scan (val/val_len = pattern).                                       */
+ * Perl and POSIX classes, \pN \p{Name} \P{Name} (general categories and their aliases, scripts, Any / Assigned /
+ * ASCII), . * + ? {n,m} (lazy forms too), groups and named groups, | , ^ $ \A \z \b \B, flags i m s U ((?i) =
+ * Unicode simple case folding, unicode.SimpleFold).  KNOX_E_UNSUPPORTED = outside that subset (a construct
+ * regexp.Compile rejects, a DFA above 4096 states or 255 rune classes): the caller keeps regexp.Match for that
+ * condition.  The same program serves a KNOX_REGEXP leaf of knox_scan (val/val_len = pattern).          */
 int knox_match_regexp(knox_ctx *ctx, const knox_col *col, const uint8_t *pattern, uint64_t pattern_len,
                       const knox_bits *mask /* nullable */, knox_bits *bits, int64_t *count /* nullable */);
 /* MatchValue (match_bytes.go:578-580) for one value, host only: 1 match, 0 no match, <0 error.  */
 int knox_regexp_match_value(const uint8_t *pattern, uint64_t pattern_len, const uint8_t *value, uint64_t value_len);
+/* The Unicode version of the tables behind \p{..} and (?i) ("17.0.0").  A host whose own tables differ (Go:
+ * unicode.Version) keeps patterns that use \p{..} or fold non-ASCII runes on its own regexp: code points assigned or
+ * re-categorised between the two versions would match differently.                                         */
+const char *knox_regexp_unicode_version(void);
 
 /* Masked reduction of one column by an existing bitset (reduce_* kernels of the plan).      */
 int knox_reduce(knox_ctx *ctx, const knox_col *col, const knox_bits *mask /*nullable = all rows*/,

@@ -23,7 +23,9 @@ import (
 	"math"
 	"os"
 	"strconv"
+	"strings"
 	"sync"
+	"unicode"
 	"unsafe"
 )
 
@@ -281,6 +283,87 @@ func (col *Column) Free() {
 	c.mu.Lock()
 	defer c.mu.Unlock()
 	C.knox_col_free(col.p)
+}
+
+// UploadPool puts ONE StringPool (pkg/stringx/pool.go:45-58: ptr[i] = off<<32 | len into buf) on the device as a bytes
+// column of one pack.
+func UploadPool(c *Ctx, ptr []uint64, buf []byte) (*Column, error) {
+	col, err := NewBytesColumn(c, (len(ptr)+63)&^63, 1, uint64(len(buf))) // pack sizes are multiples of 64 rows; the only pack may be short
+	if err != nil {
+		return nil, err
+	}
+	if err = col.AppendPack(ptr, buf); err != nil {
+		col.Free()
+		return nil, err
+	}
+	return col, nil
+}
+
+// RegexpUnicodeVersion: the Unicode version of the tables behind \p{..} and (?i) in the library's regexp compiler.
+func RegexpUnicodeVersion() string {
+	return C.GoString(C.knox_regexp_unicode_version())
+}
+
+// RegexpOnDevice reports whether the library's matcher returns what THIS binary's regexp package returns for the
+// pattern.  With equal Unicode versions: always (anything else the compiler refuses with KNOX_E_UNSUPPORTED and the
+// caller keeps re.Match).  With different versions a pattern that consults the tables stays on the host: \p / \P
+// classes, and case folding in a pattern that is not plain ASCII (the orbits of the ASCII letters -- K k U+212A,
+// S s U+017F -- have not changed since Unicode 5.1).
+func RegexpOnDevice(pattern string) bool {
+	if unicode.Version == RegexpUnicodeVersion() {
+		return true
+	}
+	if strings.Contains(pattern, `\p`) || strings.Contains(pattern, `\P`) {
+		return false
+	}
+	fold := false
+	for i := 0; i+2 < len(pattern); i++ {
+		if pattern[i] == '(' && pattern[i+1] == '?' {
+			for j := i + 2; j < len(pattern) && pattern[j] != ':' && pattern[j] != ')' && pattern[j] != '-'; j++ {
+				fold = fold || pattern[j] == 'i'
+			}
+		}
+	}
+	if !fold {
+		return true
+	}
+	for i := 0; i < len(pattern); i++ {
+		if pattern[i] >= 0x80 {
+			return false
+		}
+	}
+	return !strings.Contains(pattern, `\x`) // an escaped rune may be anything
+}
+
+// MatchRegexp = bytesRegexpMatcher.MatchVector (operator/filter/match_bytes.go:587-609) over a bytes column: bits.Set(i)
+// for every (masked) row the pattern matches; returns the popcount of bits afterwards.
+func MatchRegexp(c *Ctx, col *Column, pattern string, mask, bits *Bits) (int64, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	pat := C.CBytes([]byte(pattern))
+	defer C.free(pat)
+	var mp *C.knox_bits
+	if mask != nil {
+		mp = mask.p
+	}
+	var n C.int64_t
+	rc := C.knox_match_regexp(c.p, col.p, (*C.uint8_t)(pat), C.uint64_t(len(pattern)), mp, bits.p, &n)
+	return int64(n), errOf(rc)
+}
+
+// ArenaClasses: column space mapped per placement class and the number of classes met (diagnostics).
+func (c *Ctx) ArenaClasses() (classBytes [4]uint64, seen int) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	cb := make([]C.uint64_t, 4)
+	var n C.int
+	if C.knox_ctx_arena_classes(c.p, &cb[0], &n) != 0 {
+		return classBytes, 0
+	}
+	for i := range cb {
+		classBytes[i] = uint64(cb[i])
+	}
+	return classBytes, int(n)
 }
 
 // Bits is a device-resident bitset.Bitset.

@@ -166,6 +166,7 @@ SIGNATURES = {
     "knox_reduce_buckets_values": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "knox_match_regexp": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, C.POINTER(_i64)]),
     "knox_regexp_match_value": (_i, [_vp, _u64, _vp, _u64]),
+    "knox_regexp_unicode_version": (C.c_char_p, []),
     "knox_reduce_buckets_sequential": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _sz, _i, _i, _vp, _vp]),
     "knox_reduce_sequential": (_i, [_vp, _vp, _vp, _i, _vp, _pi, C.POINTER(_i64)]),
     "knox_agg_value": (_i, [C.POINTER(AggState), _i, _vp, _pi, C.POINTER(_i64)]),

@@ -1833,6 +1833,8 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                              const knox_agg *aggs, int n_aggs, uint64_t row_base, const uint8_t *pack_skip, knox_bits *bits_out,
                              int want_pack_counts) {
     if (!ctx || !nodes || n_nodes <= 0 || !cols || n_cols <= 0 || n_aggs < 0 || n_aggs > 14 || (n_aggs && !aggs)) return KNOX_E_INVALID;
+    for (int i = 0; i < n_cols; i++)
+        if (!cols[i] || cols[i]->ctx != ctx) return KNOX_E_INVALID;
     hipSetDevice(ctx->device);
     for (int i_ = 0; i_ < n_cols; i_++) { const int rc_ = col_acquire(ctx, cols[i_]); if (rc_) return rc_; }  // behind the columns' asynchronous uploads
     if (ctx->res_head - ctx->res_tail >= (uint64_t)knox_ctx::kResRing) return KNOX_E_BUSY;  // collect first

@@ -6,12 +6,20 @@
 //   * the input is decoded rune by rune exactly as utf8.DecodeRune does; an invalid byte is one rune
 //     U+FFFD of width 1 (regexp/regexp.go inputBytes.step),
 //   * ^ $ are text anchors unless (?m); \b \B are ASCII word boundaries; \d \s \w and the POSIX
-//     classes are ASCII; `.` excludes \n unless (?s); (?i) uses Unicode simple folding, of which
-//     the ASCII letters (with their two non-ASCII partners U+212A KELVIN SIGN and U+017F LONG S) are
-//     implemented -- a folded non-ASCII literal or class is refused (the host keeps regexp.Match then),
+//     classes are ASCII; `.` excludes \n unless (?s); (?i) closes every literal and class under the
+//     orbits of Unicode simple case folding (unicode.SimpleFold: K k U+212A, S s U+017F, the Greek
+//     theta's four forms ...), as regexp/syntax's appendFoldedRange does,
+//   * \pN \p{Name} \P{Name} \p{^Name}, alone or inside [...]: the general categories (one- and
+//     two-letter names, LC, Cn, and the long aliases such as Letter / Uppercase_Letter / punct), the
+//     scripts by their long names, and Any / Assigned / ASCII; names are matched ignoring case,
+//     spaces, underscores and hyphens (regexp/syntax unicodeTable since Go 1.25; earlier releases
+//     accept the exact names only and reject the rest at Compile, before this code is reached);
+//     under (?i) the class is the table together with its fold-equivalents, THEN negated,
 //   * greediness / (?U) / captures do not change whether a match exists and are parsed and ignored.
-// Anything this parser does not know (\p{..} Unicode classes, a construct Go rejects) is refused
-// with `unsupported`, never approximated.
+// The Unicode data is knox_unicode_tables.h: Unicode 17.0.0 (knox_unicode::kVersion, exported as
+// knox_regexp_unicode_version so that a host whose unicode.Version differs keeps \p{..} and folded
+// non-ASCII patterns on its own regexp).  Anything this parser does not know (a construct Go rejects)
+// is refused with `unsupported`, never approximated.
 //
 // Output: a DFA over RUNE CLASSES (the partition of [0, 0x10FFFF] induced by every range endpoint of
 // the pattern).  DFA state = (set of NFA states, kind of the previous rune); the empty-width
@@ -26,6 +34,8 @@
 #include <map>
 #include <string>
 #include <vector>
+
+#include "knox_unicode_tables.h"
 
 namespace knox_regex {
 
@@ -64,29 +74,93 @@ inline bool contains(const Set &s, uint32_t r) {
     return false;
 }
 
-// Unicode simple case folding restricted to what is implemented: returns false when the set holds a
-// rune outside ASCII other than the two partners of k and s (its fold orbit is not tabulated here).
-inline bool fold_ascii(Set &s) {
+// Unicode simple case folding: the set closed under unicode.SimpleFold orbits (regexp/syntax appendFoldedRange)
+inline void fold_set(Set &s) {
+    using knox_unicode::kFolds;
+    using knox_unicode::kNumFolds;
     Set add;
     for (const Range &r : s) {
-        if (r.hi >= 0x80) {
-            // only the exact runes U+017F / U+212A are understood above ASCII
-            for (uint32_t c = std::max<uint32_t>(r.lo, 0x80); c <= r.hi; c++) {
-                if (c == 0x17F) { add.push_back({'s', 's'}); add.push_back({'S', 'S'}); }
-                else if (c == 0x212A) { add.push_back({'k', 'k'}); add.push_back({'K', 'K'}); }
-                else return false;
-                if (c - r.lo > 4096) return false;
-            }
+        // the folding entries whose rune lies in [r.lo, r.hi]
+        int lo = 0, hi = kNumFolds;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (kFolds[mid].rune < r.lo) lo = mid + 1; else hi = mid;
         }
-        for (uint32_t c = r.lo; c <= std::min<uint32_t>(r.hi, 0x7f); c++) {
-            if (c >= 'a' && c <= 'z') add.push_back({c - 32, c - 32});
-            if (c >= 'A' && c <= 'Z') add.push_back({c + 32, c + 32});
-            if (c == 'k' || c == 'K') add.push_back({0x212A, 0x212A});
-            if (c == 's' || c == 'S') add.push_back({0x17F, 0x17F});
+        for (int i = lo; i < kNumFolds && kFolds[i].rune <= r.hi; i++) {
+            uint32_t c = kFolds[i].next;
+            for (int guard = 0; c != kFolds[i].rune && guard < 8; guard++) {
+                add.push_back({c, c});
+                int a = 0, b = kNumFolds;  // next of c
+                while (a < b) {
+                    const int mid = (a + b) >> 1;
+                    if (kFolds[mid].rune < c) a = mid + 1; else b = mid;
+                }
+                if (a >= kNumFolds || kFolds[a].rune != c) break;
+                c = kFolds[a].next;
+            }
         }
     }
     s.insert(s.end(), add.begin(), add.end());
     normalize(s);
+}
+
+// \p{name}: canonical form of a property name (upper case; spaces, underscores and hyphens dropped)
+inline std::string canonical_name(const uint8_t *p, size_t n) {
+    std::string out;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t c = p[i];
+        if (c == '_' || c == ' ' || c == '-') continue;
+        out.push_back((char)(c >= 'a' && c <= 'z' ? c - 32 : c));
+    }
+    return out;
+}
+
+// the table a \p name stands for (regexp/syntax unicodeTable): false = unknown name.  negate: the name means the complement.
+inline bool unicode_table(const std::string &name, Set &out, bool &neg) {
+    using namespace knox_unicode;
+    neg = false;
+    out.clear();
+    if (name == "ANY") { out = {{0, kMaxRune}}; return true; }
+    if (name == "ASCII") { out = {{0, 0x7f}}; return true; }
+    std::string cat = name;
+    if (name == "ASSIGNED") { cat = "CN"; neg = true; }
+    static const struct { const char *alias, *cat; } kAliases[] = {
+        {"OTHER", "C"}, {"CONTROL", "CC"}, {"CNTRL", "CC"}, {"FORMAT", "CF"}, {"UNASSIGNED", "CN"}, {"PRIVATEUSE", "CO"}, {"SURROGATE", "CS"},
+        {"LETTER", "L"}, {"CASEDLETTER", "LC"}, {"LOWERCASELETTER", "LL"}, {"MODIFIERLETTER", "LM"}, {"OTHERLETTER", "LO"},
+        {"TITLECASELETTER", "LT"}, {"UPPERCASELETTER", "LU"}, {"MARK", "M"}, {"COMBININGMARK", "M"}, {"SPACINGMARK", "MC"},
+        {"ENCLOSINGMARK", "ME"}, {"NONSPACINGMARK", "MN"}, {"NUMBER", "N"}, {"DECIMALNUMBER", "ND"}, {"DIGIT", "ND"},
+        {"LETTERNUMBER", "NL"}, {"OTHERNUMBER", "NO"}, {"PUNCTUATION", "P"}, {"PUNCT", "P"}, {"CONNECTORPUNCTUATION", "PC"},
+        {"DASHPUNCTUATION", "PD"}, {"CLOSEPUNCTUATION", "PE"}, {"FINALPUNCTUATION", "PF"}, {"INITIALPUNCTUATION", "PI"},
+        {"OTHERPUNCTUATION", "PO"}, {"OPENPUNCTUATION", "PS"}, {"SYMBOL", "S"}, {"CURRENCYSYMBOL", "SC"}, {"MODIFIERSYMBOL", "SK"},
+        {"MATHSYMBOL", "SM"}, {"OTHERSYMBOL", "SO"}, {"SEPARATOR", "Z"}, {"LINESEPARATOR", "ZL"}, {"PARAGRAPHSEPARATOR", "ZP"},
+        {"SPACESEPARATOR", "ZS"}};
+    // categories first (one letter = every category of that group, C with Cn as in unicode.C since Go 1.25; LC = Lu | Ll | Lt)
+    auto cat_mask = [&](const std::string &c, uint64_t &mask) {
+        mask = 0;
+        for (int i = 0; i < kNumCategories; i++) {
+            const char a = kCategoryNames[i][0], b = (char)(kCategoryNames[i][1] - 32);
+            const bool hit = c.size() == 1 ? c[0] == a : c == "LC" ? (a == 'L' && (b == 'U' || b == 'L' || b == 'T')) : (c.size() == 2 && c[0] == a && c[1] == b);
+            if (hit) mask |= (uint64_t)1 << i;
+        }
+        return mask != 0;
+    };
+    uint64_t mask = 0;
+    bool is_cat = cat.size() <= 2 && cat_mask(cat, mask);
+    if (!is_cat) {
+        for (int si = 0; si < kNumScripts; si++)
+            if (name == kScriptNames[si]) {
+                for (int i = 0; i < kNumScriptRuns; i++)
+                    if (kScriptRuns[i].id == si) out.push_back({kScriptRuns[i].lo, kScriptRuns[i].hi});
+                normalize(out);
+                return true;
+            }
+        for (const auto &al : kAliases)
+            if (name == al.alias) { is_cat = cat_mask(al.cat, mask); break; }
+    }
+    if (!is_cat) return false;
+    for (int i = 0; i < kNumCategoryRuns; i++)
+        if ((mask >> kCategoryRuns[i].id) & 1) out.push_back({kCategoryRuns[i].lo, kCategoryRuns[i].hi});
+    normalize(out);
     return true;
 }
 
@@ -218,8 +292,34 @@ struct Parser {
         }
     }
 
+    // after "\\" at 'p' or 'P': \pN, \p{Name}, \P{..}, \p{^Name} (regexp/syntax parseUnicodeClass).  The class is the
+    // table, with its fold-equivalents under (?i), negated last.
+    bool unicode_class(const Flags &f, Set &out) {
+        bool neg = *p == 'P';
+        p++;
+        if (p >= e) return false;
+        const uint8_t *st, *en;
+        if (*p != '{') {  // single-letter name (one rune)
+            st = p;
+            uint32_t r;
+            if (!rune(r)) return false;
+            en = p;
+        } else {
+            st = ++p;
+            while (p < e && *p != '}') p++;
+            if (p >= e) return false;
+            en = p++;
+        }
+        if (st < en && *st == '^') { neg = !neg; st++; }
+        bool tneg = false;
+        if (!unicode_table(canonical_name(st, (size_t)(en - st)), out, tneg)) return false;
+        if (f.fold) fold_set(out);
+        if (neg != tneg) out = negate(out);
+        return true;
+    }
+
     int make_set(Set s, const Flags &f) {
-        if (f.fold && !fold_ascii(s)) return fail();
+        if (f.fold) fold_set(s);
         normalize(s);
         const int n = node(OP_SET);
         ast[n].set = s;
@@ -244,7 +344,7 @@ struct Parser {
                 if (q + 1 >= e || q[1] != ']') return fail();
                 Set c;
                 if (!posix_class(std::string((const char *)st, (size_t)(q - st)), c)) return fail();
-                if (f.fold && !fold_ascii(c)) return fail();
+                if (f.fold) fold_set(c);
                 if (cneg) c = negate(c);
                 s.insert(s.end(), c.begin(), c.end());
                 p = q + 2;
@@ -257,10 +357,16 @@ struct Parser {
                 if (*p == 'd' || *p == 's' || *p == 'w' || *p == 'D' || *p == 'S' || *p == 'W') {
                     Set c;
                     perl_class((char)(*p | 0x20), c);
-                    if (f.fold && !fold_ascii(c)) return fail();
+                    if (f.fold) fold_set(c);
                     if (*p < 'a') c = negate(c);
                     s.insert(s.end(), c.begin(), c.end());
                     p++;
+                    continue;
+                }
+                if (*p == 'p' || *p == 'P') {
+                    Set c;
+                    if (!unicode_class(f, c)) return fail();
+                    s.insert(s.end(), c.begin(), c.end());
                     continue;
                 }
                 if (!escape_rune(lo)) return fail();
@@ -275,7 +381,7 @@ struct Parser {
                 if (hi < lo) return fail();
             }
             Set c = {{lo, hi}};
-            if (f.fold && !fold_ascii(c)) return fail();
+            if (f.fold) fold_set(c);
             s.insert(s.end(), c.begin(), c.end());
         }
         normalize(s);
@@ -375,7 +481,7 @@ struct Parser {
             if (d == 'd' || d == 's' || d == 'w' || d == 'D' || d == 'S' || d == 'W') {
                 Set s;
                 perl_class((char)(d | 0x20), s);
-                if (f.fold && !fold_ascii(s)) return fail();
+                if (f.fold) fold_set(s);
                 if (d < 'a') s = negate(s);
                 p++;
                 const int n = node(OP_SET);
@@ -397,8 +503,15 @@ struct Parser {
                 if (p < e && (*p == '*' || *p == '+' || *p == '?' || *p == '{')) return fail();
                 return cat;
             }
+            if (d == 'p' || d == 'P') {
+                Set s;
+                if (!unicode_class(f, s)) return fail();
+                const int n = node(OP_SET);
+                ast[n].set = s;
+                return n;
+            }
             uint32_t r;
-            if (!escape_rune(r)) return fail();  // \p{..}, \C, backreferences, unknown escapes
+            if (!escape_rune(r)) return fail();  // \C, backreferences, unknown escapes
             return make_set({{r, r}}, f);
         }
         default: {

@@ -77,3 +77,5 @@ KNOX_API int knox_regexp_match_value(const uint8_t *pattern, uint64_t pattern_le
     return knox_regex::match_host(pg, value, (size_t)value_len) ? 1 : 0;
 }
 
+
+KNOX_API const char *knox_regexp_unicode_version(void) { return knox_unicode::kVersion; }

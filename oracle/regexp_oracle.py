@@ -16,6 +16,13 @@ are restated here on top of an INDEPENDENT engine, CPython's `re`:
 Known gaps of this checker, avoided by the generators: Python's \\s includes \\v (Go's does not); under
 re.ASCII|re.I `k`/`s` do not match U+212A / U+017F (Go's simple folding does).
 
+Patterns with \\p{..} classes or non-ASCII case folding go through `regexp_match_unicode`: the same translation onto
+the third-party `regex` module (Unicode 17.0 tables; CPython's `re` has neither \\p nor tables newer than 13.0), with
+\\d \\s \\w \\b spelled out as ASCII sets because that module has no way to keep them ASCII while folding case by
+Unicode rules.  Two places where that module differs from Go and that the generators avoid / the model below handles:
+it folds i / I with the Turkic U+0130 / U+0131 (Go's SimpleFold does not), and under IGNORECASE it reads \\p{Lu} as
+"any cased letter" (Go: the table plus the runes whose fold orbit enters it, `fold_class_model`).
+
 Pinned by: the reference's only regexp vector (operator/filter/match_test.go:244-283: "Hel.*" matches
 "Hello", not "World") and the hand-worked cases in tests/test_regexp.py taken from the RE2 syntax page.
 """
@@ -55,9 +62,12 @@ def go_decode(b):
     return "".join(out)
 
 
-def translate(pat):
-    """Go regexp syntax -> (Python pattern, flags)."""
-    flags = re.ASCII
+ASCII_PERL = {"d": "0-9", "w": "0-9A-Za-z_", "s": "\\t\\n\\f\\r "}
+
+
+def translate(pat, uni=False):
+    """Go regexp syntax -> (Python pattern, flags); uni: for the `regex` module with Unicode folding (see the module text)."""
+    flags = 0 if uni else re.ASCII
     multi = False
     m = re.match(r"\(\?([imsU]+)\)", pat)
     if m:
@@ -85,9 +95,16 @@ def translate(pat):
                 ch, i = hex_escape(i + 2)
                 out.append(re.escape(ch))
             elif d == "b":   # spelled out: CPython's \b / \B never match in an empty text, Go's \B does
-                out.append("(?:(?<=\\w)(?!\\w)|(?<!\\w)(?=\\w))"); i += 2
+                W = "(?-i:[0-9A-Za-z_])" if uni else "\\w"   # word boundaries are ASCII and never folded (syntax.IsWordChar)
+                out.append("(?:(?<=%s)(?!%s)|(?<!%s)(?=%s))" % (W, W, W, W)); i += 2
             elif d == "B":
-                out.append("(?:(?<=\\w)(?=\\w)|(?<!\\w)(?!\\w))"); i += 2
+                W = "(?-i:[0-9A-Za-z_])" if uni else "\\w"   # word boundaries are ASCII and never folded (syntax.IsWordChar)
+                out.append("(?:(?<=%s)(?=%s)|(?<!%s)(?!%s))" % (W, W, W, W)); i += 2
+            elif d in "pP" and uni:
+                k = pat.index("}", i) + 1 if pat[i + 2] == "{" else i + 3
+                out.append(pat[i:k]); i = k
+            elif uni and d in "dwsDWS":
+                out.append("[%s%s]" % ("^" if d.isupper() else "", ASCII_PERL[d.lower()])); i += 2
             elif d in "QEpPC":
                 raise NotImplementedError("\\" + d)
             else:
@@ -111,6 +128,13 @@ def translate(pat):
                 elif pat[j] == "\\" and pat[j + 1] == "x":
                     ch, j = hex_escape(j + 2)
                     body.append(re.escape(ch))
+                elif pat[j] == "\\" and pat[j + 1] in "pP" and uni:
+                    k = pat.index("}", j) + 1 if pat[j + 2] == "{" else j + 3
+                    body.append(pat[j:k]); j = k
+                elif pat[j] == "\\" and uni and pat[j + 1] in "dws":
+                    body.append(ASCII_PERL[pat[j + 1]]); j += 2
+                elif pat[j] == "\\" and uni and pat[j + 1] in "DWS":
+                    raise NotImplementedError("negated Perl class inside a class")
                 elif pat[j] == "\\":
                     body.append(pat[j:j + 2]); j += 2
                 elif pat[j] == "[":
@@ -139,3 +163,35 @@ def regexp_match(pattern, rows):
     py, flags = translate(pattern)
     rx = re.compile(py, flags)
     return [rx.search(go_decode(bytes(r))) is not None for r in rows]
+
+
+def regexp_match_unicode(pattern, rows):
+    """[bool] per row for patterns with \\p{..} classes / non-ASCII folding, on the `regex` module (Unicode 17.0)."""
+    import regex
+    if isinstance(pattern, bytes):
+        pattern = pattern.decode("utf-8")
+    py, flags = translate(pattern, uni=True)
+    rflags = 0
+    for f_re, f_rx in ((re.I, regex.I), (re.M, regex.M), (re.S, regex.S)):
+        if flags & f_re:
+            rflags |= f_rx
+    rx = regex.compile(py, rflags | regex.V0)
+    return [rx.search(go_decode(bytes(r))) is not None for r in rows]
+
+
+def fold_orbit(cp):
+    """unicode.SimpleFold's orbit of a code point (CaseFolding.txt C + S: the `regex` module's cases without the Turkic pair)."""
+    import regex
+    import regex._regex as R
+    if cp in (0x130, 0x131):
+        return {cp}
+    return set(R.get_all_cases(regex.I | regex.U, cp)) - {0x130, 0x131}
+
+
+def fold_class_model(name, cp, negated=False):
+    """Is rune cp in (?i)\\p{name} (negated: \\P{name}) the way regexp/syntax builds it: the table together with every rune
+    whose fold orbit enters the table, negated LAST."""
+    import regex
+    rx = regex.compile(r"\p{%s}" % name)
+    inside = any(rx.match(chr(o)) is not None for o in fold_orbit(cp))
+    return inside != negated

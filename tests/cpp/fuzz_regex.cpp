@@ -8,7 +8,8 @@ int main(int argc, char **argv) {
     const long iters = argc > 1 ? atol(argv[1]) : 100000;
     std::mt19937_64 rng(argc > 2 ? atol(argv[2]) : 1);
     const char *frag[] = {"a","b","c","0","9"," ","-","_",".","*","+","?","|","(",")","(?:","(?i)","(?s)","(?m)","(?U)","(?P<n>","(?<n>","[","]","[^","^","$","\\","\\d","\\w","\\s","\\D","\\W","\\S",
-        "\\b","\\B","\\A","\\z","\\Q","\\E","\\x","\\x{","}","{","{2}","{1,3}","{2,}","{,2}","{1001}","[:alpha:]","[:^digit:]","[:bogus:]","\\p{L}","\\1","\\07","\\0","\xc3\xa9","\xe2\x82\xac","\xf0\x9f\x98\x80","\xff","\x80","-","a-z","z-a","\\n","\\t","(?-i)","(?i:","(?z)","\\xZZ","\\x{110000}","\\x{10FFFF}","{1000}","(a|b)","[ab]*a[ab]{8}"};
+        "\\b","\\B","\\A","\\z","\\Q","\\E","\\x","\\x{","}","{","{2}","{1,3}","{2,}","{,2}","{1001}","[:alpha:]","[:^digit:]","[:bogus:]","\\p{L}","\\1","\\07","\\0","\xc3\xa9","\xe2\x82\xac","\xf0\x9f\x98\x80","\xff","\x80","-","a-z","z-a","\\n","\\t","(?-i)","(?i:","(?z)","\\xZZ","\\x{110000}","\\x{10FFFF}","{1000}","(a|b)","[ab]*a[ab]{8}",
+        "\\pL","\\PN","\\p{Greek}","\\P{Lu}","\\p{^Han}","\\p{Any}","\\p{Cn}","\\p{old italic}","\\p{Nope}","\\p{","\\p","\\p{^}","\xcf\x89","\xc3\x9f","\xd0\xb2-\xd1\x8f","\xe1\xba\x9e"};
     const int nf = sizeof frag / sizeof frag[0];
     const char *text[] = {"", "a", "abc", "aAbB09 _-", "\n", "a\nb", "\xc3\xa9\xe2\x82\xac", "\xff\xfe", "\xe2\x82", "\xf0\x9f\x98\x80x", "zzzzabababababab"};
     long ok = 0, unsup = 0, big = 0;

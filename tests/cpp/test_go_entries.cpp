@@ -455,6 +455,99 @@ int main() {
         knox_bloom_free(bl), knox_col_free(col);
     }
 
+    // gpuBytesMatcher.MatchVector (integration/go/bytes_knoxgpu.go): UploadPool = NewBytesColumn(n, 1, len(buf)) + AppendPack,
+    // NewBits, Scan with ONE bytes leaf (compare modes: val / val2; REGEXP: the pattern), Download, ResetCount(res.Count),
+    // bits.And(mask) on the host; RegexpUnicodeVersion; MatchRegexp with a device mask; ArenaClasses
+    {
+        const size_t n = 70000;
+        const char *words[] = {"stra\xc3\x9f" "e", "STRA\xe1\xba\x9e" "E", "\xcf\x89\xce\xbc\xce\xad\xce\xb3\xce\xb1", "\xce\xa9\xce\x9c", "key-17", "KEY-17", "\xe6\xbc\xa2\xe5\xad\x97", "\xff\xfe", "", "x9"};
+        std::vector<uint64_t> ptr(n);
+        std::vector<uint8_t> buf;
+        std::vector<std::string> rows(n);
+        for (size_t i = 0; i < n; i++) {
+            std::string r = words[rnd() % 10];
+            if (rnd() % 3 == 0) r += words[rnd() % 10];
+            rows[i] = r;
+            ptr[i] = ((uint64_t)buf.size() << 32) | r.size();
+            buf.insert(buf.end(), r.begin(), r.end());
+        }
+        buf.resize(buf.size() + 8);
+        EXPECT(std::strcmp(knox_regexp_unicode_version(), "17.0.0") == 0);
+        knox_col *col = nullptr;
+        EXPECT(knox_col_bytes_create(ctx, n, 1, buf.size(), &col) == KNOX_E_INVALID && col == nullptr);  // pack sizes are multiples of 64 rows
+        {
+            knox_pred lf;
+            std::memset(&lf, 0, sizeof lf);
+            knox_col *none_cols[1] = {nullptr};
+            knox_agg na[1] = {{0, 0}};
+            knox_scan_out o;
+            EXPECT(knox_scan(ctx, &lf, 1, none_cols, 1, na, 0, 0, nullptr, nullptr, nullptr, nullptr, &o) == KNOX_E_INVALID);  // a nil column is refused, not followed
+        }
+        EXPECT(knox_col_bytes_create(ctx, (n + 63) & ~(size_t)63, 1, buf.size(), &col) == 0);
+        EXPECT(knox_col_bytes_append_pack(ctx, col, ptr.data(), n, buf.data(), buf.size()) == 0);
+        knox_bits *dbits = nullptr;
+        EXPECT(knox_bits_alloc(ctx, n, &dbits) == 0);
+        std::vector<uint8_t> mask((n + 7) / 8), host((n + 7) / 8);
+        for (auto &b : mask) b = (uint8_t)rnd();
+        mask.back() &= (uint8_t)(0xff >> ((8 - n % 8) % 8));
+        struct Case { int op; const char *val, *val2; } cases[] = {
+            {KNOX_EQ, "key-17", nullptr}, {KNOX_NE, "key-17", nullptr}, {KNOX_LT, "key-17", nullptr}, {KNOX_GE, "\xce\xa9", nullptr},
+            {KNOX_RANGE, "KEY", "stra\xc3\x9f" "e"}, {KNOX_REGEXP, "(?i)^stra\xc3\x9f" "e$", nullptr}, {KNOX_REGEXP, "^\\p{Greek}+$", nullptr},
+            {KNOX_REGEXP, "\\p{Han}{2}|\\p{Nd}$", nullptr}, {KNOX_REGEXP, "(?i)\xcf\x89\xce\xbc", nullptr}};
+        for (const Case &c : cases) {
+            const std::string v = c.val, v2 = c.val2 ? c.val2 : "";
+            knox_pred leaf;
+            std::memset(&leaf, 0, sizeof leaf);
+            leaf.kind = KNOX_NODE_LEAF, leaf.op = c.op, leaf.val = (const uint8_t *)v.data(), leaf.val_len = v.size();
+            if (c.val2) leaf.val2 = (const uint8_t *)v2.data(), leaf.val2_len = v2.size();
+            knox_col *cols[1] = {col};
+            knox_agg none[1] = {{0, 0}};
+            knox_scan_out out;
+            EXPECT(knox_scan(ctx, &leaf, 1, cols, 1, none, 0, 0, nullptr, dbits, nullptr, nullptr, &out) == 0);
+            EXPECT(knox_bits_download(ctx, dbits, host.data()) == 0);
+            int64_t want = 0, got = 0;
+            bool same = true;
+            for (size_t i = 0; i < n; i++) {
+                const std::string &r = rows[i];
+                bool w;
+                switch (c.op) {
+                case KNOX_EQ: w = r == v; break;
+                case KNOX_NE: w = r != v; break;
+                case KNOX_LT: w = r < v; break;   // std::string compares bytes as unsigned chars, like bytes.Compare
+                case KNOX_GE: w = r >= v; break;
+                case KNOX_RANGE: w = r >= v && r <= v2; break;
+                default: w = knox_regexp_match_value((const uint8_t *)v.data(), v.size(), (const uint8_t *)r.data(), r.size()) == 1; break;
+                }
+                const bool g = (host[i >> 3] >> (i & 7)) & 1;
+                same = same && g == w;
+                want += w, got += g;
+            }
+            EXPECT(same && got == want && out.count == want);
+            if (c.op == KNOX_REGEXP) {  // MatchRegexp with a device mask: only masked rows are set
+                knox_bits *dm = nullptr, *d2 = nullptr;
+                EXPECT(knox_bits_alloc(ctx, n, &dm) == 0 && knox_bits_alloc(ctx, n, &d2) == 0);
+                EXPECT(knox_bits_upload(ctx, dm, mask.data()) == 0);
+                std::vector<uint8_t> zero((n + 7) / 8, 0), h2((n + 7) / 8);
+                EXPECT(knox_bits_upload(ctx, d2, zero.data()) == 0);
+                int64_t cnt = -1;
+                EXPECT(knox_match_regexp(ctx, col, (const uint8_t *)v.data(), v.size(), dm, d2, &cnt) == 0);
+                EXPECT(knox_bits_download(ctx, d2, h2.data()) == 0);
+                int64_t pm = 0;
+                bool ok = true;
+                for (size_t b = 0; b < h2.size(); b++) {
+                    ok = ok && h2[b] == (uint8_t)(host[b] & mask[b]);  // = bits.And(mask) of the Go matcher
+                    pm += __builtin_popcount(h2[b]);
+                }
+                EXPECT(ok && cnt == pm);
+                knox_bits_free(dm), knox_bits_free(d2);
+            }
+        }
+        uint64_t cb[4];
+        int seen = -1;
+        EXPECT(knox_ctx_arena_classes(ctx, cb, &seen) == 0 && seen >= 0 && seen <= 4);
+        knox_bits_free(dbits), knox_col_free(col);
+    }
+
     // CommInit / AllReduceSumCount / AllGatherStates with one rank (the N-rank form runs under bench.py --gpus N)
     {
         uint8_t id[KNOX_COMM_ID_BYTES];

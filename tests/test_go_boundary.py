@@ -69,6 +69,16 @@ def test_matcher_and_operator_files_implement_the_reference_interfaces():
     flt = open(os.path.join(GO, "filter_knoxgpu.go")).read()
     assert "type gpuNumMatcher[T Number] struct" in flt
     assert re.search(r"func \(m \*gpuNumMatcher\[T\]\) MatchVector\(b \*block\.Block, bits, mask \*bitset\.Bitset\)", flt)
+    byt = open(os.path.join(GO, "bytes_knoxgpu.go")).read()
+    assert re.search(r"^package filter$", byt, flags=re.M) and "type gpuBytesMatcher struct" in byt
+    assert re.search(r"func \(m \*gpuBytesMatcher\) MatchVector\(b \*block\.Block, bits, mask \*bitset\.Bitset\)", byt)
+    assert re.search(r"func \(f gpuBytesMatcherFactory\) New\(m FilterMode\) Matcher", byt)
+    # every knoxgpu.* name the matcher uses exists in the cgo package; table-dependent patterns are guarded by the version check
+    lib = open(os.path.join(GO, "knoxgpu", "knoxgpu.go")).read()
+    for name in set(re.findall(r"knoxgpu\.([A-Z]\w+)", byt)):
+        assert re.search(r"^(func %s\b|type %s\b|\t%s\b)" % (name, name, name), lib, flags=re.M) or re.search(r"\b%s\b.*=" % name, lib), name
+    assert "knoxgpu.RegexpOnDevice(v)" in byt and "unicode.Version == RegexpUnicodeVersion()" in lib
+    assert byt.count("m.Matcher.MatchVector(b, bits, mask)") >= 5      # every failure path ends in the CPU matcher
     op = open(os.path.join(GO, "operator_knoxgpu.go")).read()
     for sig in (r"func \(op \*PhysicalGpuFilter\) Process\(ctx context\.Context, src \*pack\.Package\) \(\*pack\.Package, Result\)",
                 r"func \(op \*PhysicalGpuFilter\) Finalize\(ctx context\.Context\) error",

@@ -41,8 +41,8 @@ HAND = [
     (r"\Qa.b\E", b"a.b", True), (r"\Qa.b\E", b"axb", False), (r"\Q+", b"+", True),
     ("(?P<x>a)(?<y>b)", b"ab", True), ("(?U)a+", b"a", True), ("a+?b*?c??", b"a", True), ("(?:a*)*b", b"aab", True), ("(a*)+$", b"b", True),
     ("a|", b"zzz", True), ("(|a)b", b"b", True), ("()", b"", True), ("a**", None, "unsupported"), ("a*?*", None, "unsupported"), ("*", None, "unsupported"),
-    ("(", None, "unsupported"), (")", None, "unsupported"), ("[a", None, "unsupported"), (r"\pL", None, "unsupported"), (r"\1", None, "unsupported"),
-    ("(?i)é", None, "unsupported"), ("a{1001}", None, "unsupported"), ("[b-a]", None, "unsupported"), (r"\8", None, "unsupported"), ("(?z)", None, "unsupported"),
+    ("(", None, "unsupported"), (")", None, "unsupported"), ("[a", None, "unsupported"), (r"\p{Nope}", None, "unsupported"), (r"\1", None, "unsupported"),
+    (r"\C", None, "unsupported"), ("a{1001}", None, "unsupported"), ("[b-a]", None, "unsupported"), (r"\8", None, "unsupported"), ("(?z)", None, "unsupported"),
 ]
 
 
@@ -117,7 +117,7 @@ def gen_cases(seed, n_patterns):
         prefix = rng.choice(["", "", "", "(?i)", "(?s)", "(?m)", "(?is)", "(?ms)"])
         pat = prefix + gen_pattern(rng)
         if "i" in prefix and (any(ord(ch) >= 0x80 for ch in pat) or "\\x{e9}" in pat):
-            continue   # folding of non-ASCII runes: refused by the device (hand cases cover it)
+            continue   # folding of non-ASCII runes: CPython's re.ASCII cannot express it (tests/test_regexp_unicode.py does)
         out.append(pat)
     return out
 
@@ -206,7 +206,7 @@ def test_gpu_regexp_rows_match_the_oracle():
         assert int(K.agg_value(res.states[1], ReducerFunc.Sum)[0]) == int(ids[want].sum())
         # refusals: syntax outside the subset, and regexp on a numeric column
         with pytest.raises(K.KnoxError) as e:
-            ctx.match_regexp(col, r"\pL+")
+            ctx.match_regexp(col, r"\p{Nope}+")
         assert e.value.code == -5
         with pytest.raises(K.KnoxError):
             ctx.match_regexp(idc, "a")
