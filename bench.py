@@ -54,7 +54,8 @@ def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts, min_seconds=10.0
     on the first `sample_rows` rows of the same workload, repeated until >= min_seconds of CPU
     work have been timed; beside it the AVX2 port of the compare kernel with the masked sum fused
     (the strategy of internal/cmp/avx2/int64_AVX2_amd64.s:1154-1330) on ONE thread -- the figure
-    closest to the reference's published 1.8-2.8 G rows/s per core -- and on every host core."""
+    closest to the reference's published 1.8-2.8 G rows/s per core --, the AVX-512 form (k-mask compare,
+    internal/cmp/avx512/int64_AVX512_amd64.s:655) on one thread where the host has it, and the best of them on every host core."""
     import numpy as np
     from oracle import oracle as O
     cores = host_cores()
@@ -70,24 +71,31 @@ def cpu_baseline(sample_rows, pack_rows, a, b, gpu_pack_counts, min_seconds=10.0
         ok = int(gpu_pack_counts[: sample_rows // pack_rows].sum()) == int(cnt)
     rows = sample_rows * passes
 
-    def simd(threads, seconds):
+    best = O.simd_best_level()
+
+    def simd(threads, seconds, level):
         try:
+            level = min(level, best)
             sbits = np.zeros((sample_rows + 7) >> 3, dtype=np.uint8)
-            O.simd_scan_i64_bw_sum(x, pack_rows, a, b, threads, sbits)  # warm the pages
+            O.simd_scan_i64_bw_sum(x, pack_rows, a, b, threads, sbits, level)  # warm the pages
             sp, sdt = 0, 0.0
             while sdt < seconds and sp < 64:
                 t0 = time.perf_counter()
-                _, scnt, ssum = O.simd_scan_i64_bw_sum(x, pack_rows, a, b, threads, sbits)
+                _, scnt, ssum = O.simd_scan_i64_bw_sum(x, pack_rows, a, b, threads, sbits, level)
                 sdt += time.perf_counter() - t0
                 sp += 1
-            return {"value": sample_rows * sp / sdt, "unit": "rows/s", "cores": threads, "avx2": bool(O.lib().ko_simd_has_avx2()),
+            how = {3: "AVX-512 compare into a k-mask (8 lanes = one bitset byte), POPCNT per 64 rows, masked add (the strategy of internal/cmp/avx512/int64_AVX512_amd64.s:655)",
+                   2: "AVX2 cmp + movemask + popcnt with the masked sum fused (internal/cmp/avx2/int64_AVX2_amd64.s:1154-1330)", 1: "scalar"}[level]
+            return {"value": sample_rows * sp / sdt, "unit": "rows/s", "cores": threads, "isa": O.SIMD_LEVELS[level],
                     "gb_per_s": sample_rows * sp * BYTES_PER_ROW / sdt / 1e9,
                     "matches_port": bool(scnt == cnt and ssum == s and (sbits == bits).all()),
-                    "note": "AVX2 cmp + movemask + popcnt with the masked sum fused (oracle/knox_cpu_simd.c), pack-parallel over %d thread(s)" % threads}
+                    "note": "%s; oracle/knox_cpu_simd.c, pack-parallel over %d thread(s)" % (how, threads)}
         except Exception as e:  # the baseline must never break the bench line
             return {"error": str(e)}
 
-    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "simd_1_thread": simd(1, 4.0), "simd_all_cores": simd(cores, 3.0),
+    # AVX2 on one thread (rounds 1-2's figure), the best ISA of the host on one thread (AVX-512 where it exists), the best on every core
+    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "simd_1_thread": simd(1, 3.0, 2),
+            "simd_best_isa_1_thread": simd(1, 3.0, 3) if best >= 3 else None, "simd_all_cores": simd(cores, 3.0, 3),
             "sample": "first %d rows (%d packs of 2^20) of the same workload x %d passes, oracle/knox_oracle.c "
                       "ko_scan_i64_bw_sum (cmp_bw -> Indexes -> SumReducer per row), %.1f s timed, gcc -O2, 1 thread"
                       % (sample_rows, sample_rows // pack_rows, passes, dt),
@@ -121,7 +129,7 @@ def in_run_parity(ctx, col_seed, n_rows, pack_rows, a, b, bits, res, row_seed_fi
     xor_cpu, cnt_cpu, sum_cpu = np.uint64(0), 0, 0
     for r0 in range(0, n_rows, chunk):
         O.generate_mt(O.I64, 0, col_seed, r0, chunk, lo=-(1 << 40), span=1 << 41, threads=cores, out=xbuf)
-        _, c, s_ = O.simd_scan_i64_bw_sum(xbuf, pack_rows, a, b, cores, cbits)
+        _, c, s_ = O.simd_scan_i64_bw_sum(xbuf, pack_rows, a, b, cores, cbits, 0)   # the host's best ISA
         xor_cpu ^= np.bitwise_xor.reduce(cbits.view(np.uint64))
         cnt_cpu += int(c)
         sum_cpu = (sum_cpu + int(s_)) % (1 << 64)

@@ -99,6 +99,9 @@ def lib():
         L.ko_simd_scan_i64_bw_sum.restype = i64
         L.ko_simd_scan_i64_bw_sum.argtypes = [vp, i64, i64, i64, i64, vp, i32, C.POINTER(i64)]
         L.ko_simd_has_avx2.restype = i32
+        L.ko_simd_scan_i64_bw_sum_level.restype = i64
+        L.ko_simd_scan_i64_bw_sum_level.argtypes = [vp, i64, i64, i64, i64, vp, i32, i32, C.POINTER(i64)]
+        L.ko_simd_best_level.restype = i32
         L.ko_scan_i64_bw_sum.restype = i64
         L.ko_scan_i64_bw_sum.argtypes = [vp, i64, i64, i64, i64, vp, vp, C.POINTER(i64)]
         _lib = L
@@ -363,13 +366,22 @@ def scan_i64_bw_sum(src, pack_rows, a, b):
     return bits, cnt, s.value
 
 
-def simd_scan_i64_bw_sum(src, pack_rows, a, b, threads, bits=None):
-    """AVX2 pack-parallel CPU baseline (knox_cpu_simd.c): returns (bits, count, sum)."""
+SIMD_LEVELS = {1: "scalar", 2: "AVX2", 3: "AVX-512"}
+
+
+def simd_best_level():
+    """1 = scalar, 2 = AVX2, 3 = AVX-512: the best form of the SIMD baseline this CPU runs"""
+    return int(lib().ko_simd_best_level())
+
+
+def simd_scan_i64_bw_sum(src, pack_rows, a, b, threads, bits=None, level=2):
+    """SIMD pack-parallel CPU baseline (knox_cpu_simd.c; level 2 = AVX2, 3 = AVX-512, 0 = the best available): returns
+    (bits, count, sum)."""
     src = np.ascontiguousarray(src, dtype=np.int64)
     if bits is None:
         bits = np.zeros(bitfield_len(src.size), dtype=np.uint8)
     s = C.c_int64()
-    cnt = lib().ko_simd_scan_i64_bw_sum(_p(src), src.size, pack_rows, a, b, _p(bits), threads, C.byref(s))
+    cnt = lib().ko_simd_scan_i64_bw_sum_level(_p(src), src.size, pack_rows, a, b, _p(bits), threads, level, C.byref(s))
     return bits, cnt, s.value
 
 

@@ -144,5 +144,13 @@ def test_simd_cpu_baseline_equals_literal_port():
     x = O.generate(O.I64, 0, 2, 0, 5 * 4096 + 100, lo=-(1 << 40), span=1 << 41)
     b0, c0, s0 = O.scan_i64_bw_sum(x, 4096, -(1 << 38), 1 << 38)
     for threads in (1, 3, 8):
-        b1, c1, s1 = O.simd_scan_i64_bw_sum(x, 4096, -(1 << 38), 1 << 38, threads)
-        assert c1 == c0 and s1 == s0 and (b1 == b0).all()
+        for level in (0, 1, 2, 3):   # best available / scalar / AVX2 / AVX-512 (a level the CPU lacks runs its best)
+            b1, c1, s1 = O.simd_scan_i64_bw_sum(x, 4096, -(1 << 38), 1 << 38, threads, level=level)
+            assert c1 == c0 and s1 == s0 and (b1 == b0).all(), (threads, level)
+    # ragged lengths and the wrapped range (a > b) the reference's cmp_bw accepts (internal/cmp/number.go:211-243)
+    for m in (1, 7, 8, 9, 63, 64, 65, 1000, 4097):
+        for a, b in ((-(1 << 38), 1 << 38), (5, -5), (0, 0)):
+            w = O.scan_i64_bw_sum(x[:m], 4096, a, b)
+            for level in (2, 3):
+                r = O.simd_scan_i64_bw_sum(x[:m], 4096, a, b, 1, level=level)
+                assert r[1] == w[1] and r[2] == w[2] and (r[0] == w[0]).all(), (m, a, b, level)
