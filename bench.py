@@ -540,10 +540,20 @@ def main():
     if dist is not None and collective == "abi":
         # knox_comm_init = ncclCommInitRank on this rank's device; every step's exchange is then
         # knox_comm_allreduce_sum_count_start / _finish (ONE ncclAllReduce(int64 x 3) on the context's collective stream)
-        ranks_in_comm = kdist.comm_init(ctx, dist.get_world_size(), rank, comm_id)
-        gather, reduce_sc = kdist.AbiStateGather(ctx, 2), kdist.AbiSumCountReduce(ctx)
-        print("[rank %d] abi collective: communicator up, ncclCommCount = %d" % (rank, ranks_in_comm), file=sys.stderr, flush=True)
-    elif dist is not None:
+        up, why = 1, ""
+        try:
+            ranks_in_comm = kdist.comm_init(ctx, dist.get_world_size(), rank, comm_id)
+        except Exception as e:   # no RCCL library to dlopen, ncclCommInitRank refused ...: every rank must take the same way out
+            up, why = 0, str(e)
+        flag = torch.tensor([up], dtype=torch.int32, device=tdev if tdev is not None else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gather, reduce_sc = kdist.AbiStateGather(ctx, 2), kdist.AbiSumCountReduce(ctx)
+            print("[rank %d] abi collective: communicator up, ncclCommCount = %d" % (rank, ranks_in_comm), file=sys.stderr, flush=True)
+        else:
+            print("[rank %d] abi collective unavailable on some rank (%s): torch.distributed carries the exchange" % (rank, why or "another rank failed"), file=sys.stderr, flush=True)
+            collective, ranks_in_comm = "torch", None
+    if dist is not None and collective != "abi":
         gather, reduce_sc = kdist.StateGather(2, tdev), kdist.SumCountReduce(tdev)
 
     def enqueue():
@@ -601,9 +611,15 @@ def main():
         merged, gtotal = gather(wres.states, wres.count)
         collectives_agree = bool(gtotal == wtotal and int(merged[0].isum) == wsum and int(merged[1].count) == wtotal)
         assert collectives_agree, "all-reduce {sum,count} != all-gather + combine"
-    ctx.L.knox_prof_enable(ctx.h, 1)
     if dist is not None:
         dist.barrier()
+        # The barrier (and the all-gather check before it) leaves the device idle for milliseconds, and the first ~10 scans
+        # after such a pause run up to 15 % slower (per-launch times of a 1-rank rehearsal: 1.26 1.33 1.41 1.44 1.40 1.38 1.33
+        # 1.31 1.29 1.27 ... 1.245 ms; DESIGN.md 7 "clock ramp") -- with one rank and no barrier the W warm-up steps absorb
+        # that.  So the untimed passes that bring the clocks back run AFTER the barrier; every rank does the same 12, the
+        # synchronize below drains them, and the timed region is still K steps between barrier + synchronize on both sides.
+        run(12)
+    ctx.L.knox_prof_enable(ctx.h, 1)
     torch.cuda.synchronize()
     ctx.sync()
     t0 = time.perf_counter()
@@ -613,9 +629,13 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kms, kn = C.c_double(), C.c_int()
-    ctx.L.knox_prof_read(ctx.h, C.byref(kms), C.byref(kn))
+    each, kn = (C.c_float * 512)(), C.c_int()
+    ctx.L.knox_prof_read_each(ctx.h, each, 512, C.byref(kn))   # every timed launch of the scan kernel, in order
     ctx.L.knox_prof_enable(ctx.h, 0)
+    per_launch_ms = [float(each[i]) for i in range(kn.value)]
+    kms = C.c_double(sum(per_launch_ms))
+    if os.environ.get("KNOX_BENCH_VERBOSE") == "1":
+        print("[rank %d] scan kernel per launch (ms): %s" % (rank, " ".join("%.4f" % x for x in per_launch_ms)), file=sys.stderr, flush=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -687,6 +707,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "knox::scan_kernel<8,1,ISUM> (int64 Between + sum)", "kernel_ms": scan_ms,
                      "kernel_ms_min_max_over_ranks": scan_ms_ranks,
+                     "kernel_ms_min_max_over_launches": [min(per_launch_ms), max(per_launch_ms)] if per_launch_ms else None,
                      "launches_timed": kn.value, "algorithmic_bytes_per_launch": n_rows * BYTES_PER_ROW,
                      "read_only_ceiling_gb_per_s": read_only_gbs,
                      "frac_of_read_only_ceiling": achieved / read_only_gbs if read_only_gbs > 0 else None},
