@@ -12,14 +12,18 @@
 //
 // Columns of a package are uploaded once and kept on the device keyed by (pack key, version, field): the second query
 // over the same pack reads HBM only.  Encoded (non-materialized) blocks cross PCIe in their container form and are
-// decoded on the device (knox_col_upload_raw_containers).  Trees with leaf kinds the device plan does not take fall
-// back to the CPU operator.  This operator works package by package, as the PushOperator interface hands them out; the
+// decoded on the device (knox_col_upload_raw_containers); []byte / string blocks held as a plain StringPool go up as one
+// pack of a bytes column.  Leaves: the compare modes and RANGE on numeric and bytes columns, IN / NOT IN sets, REGEXP on
+// bytes columns.  Trees with anything else (wide integers, encoded string containers, empty sets) fall back to the CPU
+// operator.  This operator works package by package, as the PushOperator interface hands them out; the
 // run-level reader (many packs resident, ONE scan, per-pack results served) is run_knoxgpu.go.
 // Not compiled in the knoxdb_amd repository (no Go toolchain there); see integration/check_go_calls.py.
 package operator
 
 import (
 	"context"
+	"encoding/binary"
+	"unsafe"
 
 	"blockwatch.cc/knoxdb/internal/bitset"
 	"blockwatch.cc/knoxdb/internal/block"
@@ -28,6 +32,7 @@ import (
 	"blockwatch.cc/knoxdb/internal/operator/filter"
 	"blockwatch.cc/knoxdb/internal/pack"
 	"blockwatch.cc/knoxdb/internal/types"
+	"blockwatch.cc/knoxdb/pkg/stringx"
 )
 
 var (
@@ -141,8 +146,62 @@ func uploadBlock(g *knoxgpu.Ctx, b *block.Block) (*knoxgpu.Column, error) {
 		return uploadVector[float64](g, b)
 	case types.BlockFloat32:
 		return uploadVector[float32](g, b)
+	case types.BlockBytes:
+		// a plain StringPool goes up as it is (pointer array + buffer = one pack of a bytes column); the dictionary / fixed /
+		// compact string containers keep the reference's own matchers (the whole tree then runs on the CPU operator)
+		if pool, ok := b.Bytes().(*stringx.StringPool); ok {
+			ptr, buf := pool.Raw() // pkg/stringx accessor quoted in bytes_knoxgpu.go
+			return knoxgpu.UploadPool(g, ptr, buf)
+		}
 	}
 	return nil, ErrTodo
+}
+
+// setBytes marshals an IN / NOT IN set the way knox_pred.val takes it: the values of the column type back to back
+// (numInSetMatcher.Value() / floatInSetMatcher: a []T, match_num.go:602-615), or for a bytes column a packed list of
+// [uint32 little-endian length][bytes] entries (bytesInSetMatcher, match_bytes.go:300-540: a [][]byte).
+func setBytes(v any) ([]byte, bool) {
+	switch s := v.(type) {
+	case [][]byte:
+		n := 0
+		for _, e := range s {
+			n += 4 + len(e)
+		}
+		out := make([]byte, 0, n)
+		for _, e := range s {
+			out = binary.LittleEndian.AppendUint32(out, uint32(len(e)))
+			out = append(out, e...)
+		}
+		return out, true
+	case []int64:
+		return numSetBytes(s), true
+	case []int32:
+		return numSetBytes(s), true
+	case []int16:
+		return numSetBytes(s), true
+	case []int8:
+		return numSetBytes(s), true
+	case []uint64:
+		return numSetBytes(s), true
+	case []uint32:
+		return numSetBytes(s), true
+	case []uint16:
+		return numSetBytes(s), true
+	case []uint8:
+		return numSetBytes(s), true
+	case []float64:
+		return numSetBytes(s), true
+	case []float32:
+		return numSetBytes(s), true
+	}
+	return nil, false
+}
+
+func numSetBytes[T knoxgpu.Number](s []T) []byte {
+	if len(s) == 0 {
+		return nil
+	}
+	return unsafe.Slice((*byte)(unsafe.Pointer(unsafe.SliceData(s))), len(s)*int(unsafe.Sizeof(s[0])))
 }
 
 // plan flattens a filter.Node tree (node.go:29-37) into the postfix form knox_scan takes: operands first, then one
@@ -156,10 +215,15 @@ func (op *PhysicalGpuFilter) plan(n *filter.Node, pkg *pack.Package, nodes []kno
 			return nodes, cols, false
 		}
 		p := knoxgpu.Pred{Kind: knoxgpu.NodeLeaf, Col: len(cols), Op: int(f.Mode)}
+		isBytes := f.Type == types.BlockBytes
 		switch f.Mode {
 		case types.FilterModeEqual, types.FilterModeNotEqual, types.FilterModeGt, types.FilterModeGe,
 			types.FilterModeLt, types.FilterModeLe:
-			if p.A, ok = knoxgpu.ValueBits(f.Value); !ok {
+			if isBytes {
+				if p.Val, ok = f.Value.([]byte); !ok {
+					return nodes, cols, false
+				}
+			} else if p.A, ok = knoxgpu.ValueBits(f.Value); !ok {
 				return nodes, cols, false
 			}
 		case types.FilterModeRange:
@@ -168,13 +232,33 @@ func (op *PhysicalGpuFilter) plan(n *filter.Node, pkg *pack.Package, nodes []kno
 				return nodes, cols, false
 			}
 			var okA, okB bool
-			p.A, okA = knoxgpu.ValueBits(rg[0])
-			p.B, okB = knoxgpu.ValueBits(rg[1])
+			if isBytes {
+				p.Val, okA = rg[0].([]byte)
+				p.Val2, okB = rg[1].([]byte)
+			} else {
+				p.A, okA = knoxgpu.ValueBits(rg[0])
+				p.B, okB = knoxgpu.ValueBits(rg[1])
+			}
 			if !okA || !okB {
 				return nodes, cols, false
 			}
+		case types.FilterModeIn, types.FilterModeNotIn:
+			// the matcher's own view of the set (Value(): a []T / [][]byte whatever WithValue / WithSet was given); an empty
+			// set keeps the reference's short cuts on the CPU operator
+			if p.Val, ok = setBytes(f.Matcher.Value()); !ok || len(p.Val) == 0 {
+				return nodes, cols, false
+			}
+		case types.FilterModeRegexp:
+			// bytesRegexpMatcher.Value() = re.String() (match_bytes.go:549-554); a pattern whose result could depend on the
+			// Unicode tables of this binary stays on the CPU operator unless the versions agree (knoxgpu.RegexpOnDevice); a
+			// pattern outside the device's subset comes back from Scan as an error and takes the same way
+			pat, isStr := f.Matcher.Value().(string)
+			if !isBytes || !isStr || pat == "" || !knoxgpu.RegexpOnDevice(pat) {
+				return nodes, cols, false
+			}
+			p.Val = []byte(pat)
 		default:
-			return nodes, cols, false // IN / NOT IN / regexp leaves: host-side sets are marshalled by the caller
+			return nodes, cols, false
 		}
 		return append(nodes, p), append(cols, col), true
 	}

@@ -493,9 +493,18 @@ int main() {
         struct Case { int op; const char *val, *val2; } cases[] = {
             {KNOX_EQ, "key-17", nullptr}, {KNOX_NE, "key-17", nullptr}, {KNOX_LT, "key-17", nullptr}, {KNOX_GE, "\xce\xa9", nullptr},
             {KNOX_RANGE, "KEY", "stra\xc3\x9f" "e"}, {KNOX_REGEXP, "(?i)^stra\xc3\x9f" "e$", nullptr}, {KNOX_REGEXP, "^\\p{Greek}+$", nullptr},
-            {KNOX_REGEXP, "\\p{Han}{2}|\\p{Nd}$", nullptr}, {KNOX_REGEXP, "(?i)\xcf\x89\xce\xbc", nullptr}};
+            {KNOX_REGEXP, "\\p{Han}{2}|\\p{Nd}$", nullptr}, {KNOX_REGEXP, "(?i)\xcf\x89\xce\xbc", nullptr},
+            {KNOX_IN, nullptr, nullptr}, {KNOX_NOTIN, nullptr, nullptr}};
+        // setBytes([][]byte) of operator_knoxgpu.go: [uint32 little-endian length][bytes] entries, any order, duplicates allowed
+        const std::vector<std::string> set_members = {"key-17", "x9", "", "key-17", "\xff\xfe"};
+        std::string packed_set;
+        for (const std::string &m : set_members) {
+            const uint32_t l = (uint32_t)m.size();
+            packed_set.append((const char *)&l, 4);
+            packed_set += m;
+        }
         for (const Case &c : cases) {
-            const std::string v = c.val, v2 = c.val2 ? c.val2 : "";
+            const std::string v = c.val ? std::string(c.val) : packed_set, v2 = c.val2 ? c.val2 : "";
             knox_pred leaf;
             std::memset(&leaf, 0, sizeof leaf);
             leaf.kind = KNOX_NODE_LEAF, leaf.op = c.op, leaf.val = (const uint8_t *)v.data(), leaf.val_len = v.size();
@@ -516,6 +525,8 @@ int main() {
                 case KNOX_LT: w = r < v; break;   // std::string compares bytes as unsigned chars, like bytes.Compare
                 case KNOX_GE: w = r >= v; break;
                 case KNOX_RANGE: w = r >= v && r <= v2; break;
+                case KNOX_IN: w = std::find(set_members.begin(), set_members.end(), r) != set_members.end(); break;
+                case KNOX_NOTIN: w = std::find(set_members.begin(), set_members.end(), r) == set_members.end(); break;
                 default: w = knox_regexp_match_value((const uint8_t *)v.data(), v.size(), (const uint8_t *)r.data(), r.size()) == 1; break;
                 }
                 const bool g = (host[i >> 3] >> (i & 7)) & 1;

@@ -80,6 +80,13 @@ def test_matcher_and_operator_files_implement_the_reference_interfaces():
     assert "knoxgpu.RegexpOnDevice(v)" in byt and "unicode.Version == RegexpUnicodeVersion()" in lib
     assert byt.count("m.Matcher.MatchVector(b, bits, mask)") >= 5      # every failure path ends in the CPU matcher
     op = open(os.path.join(GO, "operator_knoxgpu.go")).read()
+    # the tree plan takes bytes blocks, bytes / regexp leaves and IN / NOT IN sets (types the reference really has: no BlockString)
+    for needle in ("case types.BlockBytes:", "knoxgpu.UploadPool(g, ptr, buf)", "case types.FilterModeIn, types.FilterModeNotIn:",
+                   "setBytes(f.Matcher.Value())", "case types.FilterModeRegexp:", "knoxgpu.RegexpOnDevice(pat)", "p.Val, okA = rg[0].([]byte)"):
+        assert needle in op, needle
+    ref_types = open(os.path.join(ROOT, "include", "knoxgpu.h")).read()
+    assert "KNOX_IN = 7, KNOX_NOTIN = 8" in ref_types and "KNOX_REGEXP = 10" in ref_types and "KNOX_BYTES = 12" in ref_types   # = FilterModeIn .. / BlockBytes
+    assert "BlockString" not in op
     for sig in (r"func \(op \*PhysicalGpuFilter\) Process\(ctx context\.Context, src \*pack\.Package\) \(\*pack\.Package, Result\)",
                 r"func \(op \*PhysicalGpuFilter\) Finalize\(ctx context\.Context\) error",
                 r"func \(op \*PhysicalGpuFilter\) Err\(\) error", r"func \(op \*PhysicalGpuFilter\) Close\(\)",
