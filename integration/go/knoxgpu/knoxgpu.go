@@ -19,6 +19,7 @@ package knoxgpu
 import "C"
 
 import (
+	"encoding/binary"
 	"errors"
 	"math"
 	"os"
@@ -497,6 +498,53 @@ type Pred struct {
 const (
 	NodeLeaf, NodeAnd, NodeOr = 0, 1, 2
 )
+
+// SetBytes marshals an IN / NOT IN set the way knox_pred.val takes it: the values of the column type back to back
+// (numInSetMatcher.Value() / floatInSetMatcher: a []T, match_num.go:602-615), or for a bytes column a packed list of
+// [uint32 little-endian length][bytes] entries (bytesInSetMatcher, match_bytes.go:300-540: a [][]byte).
+func SetBytes(v any) ([]byte, bool) {
+	switch s := v.(type) {
+	case [][]byte:
+		n := 0
+		for _, e := range s {
+			n += 4 + len(e)
+		}
+		out := make([]byte, 0, n)
+		for _, e := range s {
+			out = binary.LittleEndian.AppendUint32(out, uint32(len(e)))
+			out = append(out, e...)
+		}
+		return out, true
+	case []int64:
+		return numSetBytes(s), true
+	case []int32:
+		return numSetBytes(s), true
+	case []int16:
+		return numSetBytes(s), true
+	case []int8:
+		return numSetBytes(s), true
+	case []uint64:
+		return numSetBytes(s), true
+	case []uint32:
+		return numSetBytes(s), true
+	case []uint16:
+		return numSetBytes(s), true
+	case []uint8:
+		return numSetBytes(s), true
+	case []float64:
+		return numSetBytes(s), true
+	case []float32:
+		return numSetBytes(s), true
+	}
+	return nil, false
+}
+
+func numSetBytes[T Number](s []T) []byte {
+	if len(s) == 0 {
+		return nil
+	}
+	return unsafe.Slice((*byte)(unsafe.Pointer(unsafe.SliceData(s))), len(s)*int(unsafe.Sizeof(s[0])))
+}
 
 // Reducer codes follow internal/reducer/reducer.go:25-45.
 const (

@@ -22,8 +22,6 @@ package operator
 
 import (
 	"context"
-	"encoding/binary"
-	"unsafe"
 
 	"blockwatch.cc/knoxdb/internal/bitset"
 	"blockwatch.cc/knoxdb/internal/block"
@@ -157,53 +155,6 @@ func uploadBlock(g *knoxgpu.Ctx, b *block.Block) (*knoxgpu.Column, error) {
 	return nil, ErrTodo
 }
 
-// setBytes marshals an IN / NOT IN set the way knox_pred.val takes it: the values of the column type back to back
-// (numInSetMatcher.Value() / floatInSetMatcher: a []T, match_num.go:602-615), or for a bytes column a packed list of
-// [uint32 little-endian length][bytes] entries (bytesInSetMatcher, match_bytes.go:300-540: a [][]byte).
-func setBytes(v any) ([]byte, bool) {
-	switch s := v.(type) {
-	case [][]byte:
-		n := 0
-		for _, e := range s {
-			n += 4 + len(e)
-		}
-		out := make([]byte, 0, n)
-		for _, e := range s {
-			out = binary.LittleEndian.AppendUint32(out, uint32(len(e)))
-			out = append(out, e...)
-		}
-		return out, true
-	case []int64:
-		return numSetBytes(s), true
-	case []int32:
-		return numSetBytes(s), true
-	case []int16:
-		return numSetBytes(s), true
-	case []int8:
-		return numSetBytes(s), true
-	case []uint64:
-		return numSetBytes(s), true
-	case []uint32:
-		return numSetBytes(s), true
-	case []uint16:
-		return numSetBytes(s), true
-	case []uint8:
-		return numSetBytes(s), true
-	case []float64:
-		return numSetBytes(s), true
-	case []float32:
-		return numSetBytes(s), true
-	}
-	return nil, false
-}
-
-func numSetBytes[T knoxgpu.Number](s []T) []byte {
-	if len(s) == 0 {
-		return nil
-	}
-	return unsafe.Slice((*byte)(unsafe.Pointer(unsafe.SliceData(s))), len(s)*int(unsafe.Sizeof(s[0])))
-}
-
 // plan flattens a filter.Node tree (node.go:29-37) into the postfix form knox_scan takes: operands first, then one
 // AND / OR node popping nchild results.  cols receives the device columns in leaf order.  AnyMatch / Skip nodes are
 // dropped exactly where MatchAnd / MatchOr skip them (match_core.go:55-58, 129-135).
@@ -245,7 +196,7 @@ func (op *PhysicalGpuFilter) plan(n *filter.Node, pkg *pack.Package, nodes []kno
 		case types.FilterModeIn, types.FilterModeNotIn:
 			// the matcher's own view of the set (Value(): a []T / [][]byte whatever WithValue / WithSet was given); an empty
 			// set keeps the reference's short cuts on the CPU operator
-			if p.Val, ok = setBytes(f.Matcher.Value()); !ok || len(p.Val) == 0 {
+			if p.Val, ok = knoxgpu.SetBytes(f.Matcher.Value()); !ok || len(p.Val) == 0 {
 				return nodes, cols, false
 			}
 		case types.FilterModeRegexp:

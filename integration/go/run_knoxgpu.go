@@ -141,6 +141,14 @@ func (g *GpuRun) flatten(n *filter.Node, nodes []knoxgpu.Pred) ([]knoxgpu.Pred, 
 			if !ok || !okB {
 				return nodes, false
 			}
+		case types.FilterModeIn, types.FilterModeNotIn:
+			// numeric sets only (a run holds numeric vectors): the matcher's Value() is the []T of the set
+			if f.Type == types.BlockBytes {
+				return nodes, false
+			}
+			if p.Val, ok = knoxgpu.SetBytes(f.Matcher.Value()); !ok || len(p.Val) == 0 {
+				return nodes, false
+			}
 		default:
 			return nodes, false
 		}

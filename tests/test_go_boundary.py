@@ -82,7 +82,7 @@ def test_matcher_and_operator_files_implement_the_reference_interfaces():
     op = open(os.path.join(GO, "operator_knoxgpu.go")).read()
     # the tree plan takes bytes blocks, bytes / regexp leaves and IN / NOT IN sets (types the reference really has: no BlockString)
     for needle in ("case types.BlockBytes:", "knoxgpu.UploadPool(g, ptr, buf)", "case types.FilterModeIn, types.FilterModeNotIn:",
-                   "setBytes(f.Matcher.Value())", "case types.FilterModeRegexp:", "knoxgpu.RegexpOnDevice(pat)", "p.Val, okA = rg[0].([]byte)"):
+                   "knoxgpu.SetBytes(f.Matcher.Value())", "case types.FilterModeRegexp:", "knoxgpu.RegexpOnDevice(pat)", "p.Val, okA = rg[0].([]byte)"):
         assert needle in op, needle
     ref_types = open(os.path.join(ROOT, "include", "knoxgpu.h")).read()
     assert "KNOX_IN = 7, KNOX_NOTIN = 8" in ref_types and "KNOX_REGEXP = 10" in ref_types and "KNOX_BYTES = 12" in ref_types   # = FilterModeIn .. / BlockBytes
