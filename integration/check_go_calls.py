@@ -146,6 +146,9 @@ class Scope:
         # parameters of cgo types: `rc C.int`
         for nm, ty in re.findall(r"(\w+)\s+(\*{0,2}C\.\w+)", header_line):
             self.vars[nm] = go_ctype(ty)
+        # unsafe.Pointer parameters and locals are C's void*
+        for nm in re.findall(r"(\w+)\s+unsafe\.Pointer\b", header_line) + re.findall(r"\bvar\s+(\w+)\s+unsafe\.Pointer\b", body):
+            self.vars[nm] = "void*"
         # the owning context of a wrapper object: `c := col.c`
         for nm in re.findall(r"\b(\w+)\s*:=\s*\w+\.c\b(?!\.)", body):
             self.objs[nm] = "Ctx"

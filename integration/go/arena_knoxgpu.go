@@ -1,0 +1,115 @@
+//go:build knoxgpu && !with_assert
+
+// Drop into internal/arena/ of blockwatch-cc/knoxdb.  The allocation hook of SURVEY.md 8(b) "Ownership": block vectors
+// of the pack-sized classes come out of PAGE-LOCKED memory the library owns (knox_host_alloc = hipHostMalloc), so that
+// knoxgpu.Upload / AppendAsync of a materialized block is one DMA straight from the block (57 GB/s measured) instead of a
+// copy through the pinned ring (36 GB/s) -- the arena keeps handing out and taking back slices exactly as before
+// (arena.go:79-137, allocator.go:46-64), only where the bytes live changes.
+//
+// pinnedAllocator[T] wraps the stock allocator[T] (allocator.go:20-64): size classes 2^16 .. 2^22 elements (production
+// pack sizes; journal and tiny blocks stay in Go memory) are served from per-class free lists over page-locked slabs;
+// everything else is the embedded allocator's.  Slabs are never returned (the arena's pools never shrink either, and
+// page-locking is expensive); a class that cannot get a slab falls back to Go memory.  C memory is invisible to the
+// collector: slices over it are ordinary []T for every reader, and cgo may be handed their address without pinning.
+//
+// One rule comes with it: a block whose vector is page-locked is read by the DMA engine AFTER AppendAsync returns, so it
+// must not be recycled (arena.Free) before Column.Wait -- GpuRun holds its packages until the run is scanned.
+// Not compiled in the knoxdb_amd repository (no Go toolchain there); see integration/check_go_calls.py.
+package arena
+
+import (
+	"math/bits"
+	"sync"
+	"unsafe"
+
+	"blockwatch.cc/knoxdb/internal/knoxgpu"
+)
+
+const (
+	pinnedMinClass = 16 // 64 Ki elements: the smallest production pack
+	pinnedSlab     = 64 << 20
+)
+
+type pinnedAllocator[T any] struct {
+	inner *allocator[T]
+	gpu   *knoxgpu.Ctx
+	mu    sync.Mutex
+	free  [maxAllocClass - pinnedMinClass + 1][][]T
+	pin   map[unsafe.Pointer]struct{} // first element of every slice handed out from page-locked memory
+}
+
+func newPinnedAllocator[T any](gpu *knoxgpu.Ctx) *pinnedAllocator[T] {
+	return &pinnedAllocator[T]{inner: newAllocator[T](), gpu: gpu, pin: make(map[unsafe.Pointer]struct{})}
+}
+
+func classOf(sz int) int {
+	class := 63 - bits.LeadingZeros(uint(sz))
+	if bits.OnesCount(uint(sz)) > 1 {
+		class++
+	}
+	return class
+}
+
+func (a *pinnedAllocator[T]) Alloc(sz int) any {
+	class := classOf(sz)
+	if class < pinnedMinClass || class > maxAllocClass {
+		return a.inner.Alloc(sz)
+	}
+	a.mu.Lock()
+	defer a.mu.Unlock()
+	fl := &a.free[class-pinnedMinClass]
+	if len(*fl) == 0 {
+		// one slab = as many vectors of this class as fit 64 MiB (at least one)
+		var t T
+		each := (1 << class) * int(unsafe.Sizeof(t))
+		n := max(1, pinnedSlab/each)
+		p, err := a.gpu.HostAlloc(n * each)
+		if err != nil {
+			return a.inner.Alloc(sz)
+		}
+		for i := 0; i < n; i++ {
+			v := unsafe.Slice((*T)(unsafe.Add(p, i*each)), 1<<class)[:0]
+			a.pin[unsafe.Pointer(unsafe.SliceData(v))] = struct{}{}
+			*fl = append(*fl, v)
+		}
+	}
+	v := (*fl)[len(*fl)-1]
+	*fl = (*fl)[:len(*fl)-1]
+	return v
+}
+
+func (a *pinnedAllocator[T]) Free(val any, sz int) {
+	v, ok := val.([]T)
+	if !ok || cap(v) == 0 {
+		a.inner.Free(val, sz)
+		return
+	}
+	a.mu.Lock()
+	_, mine := a.pin[unsafe.Pointer(unsafe.SliceData(v[:1]))]
+	if mine {
+		class := classOf(cap(v))
+		a.free[class-pinnedMinClass] = append(a.free[class-pinnedMinClass], v[:0])
+	}
+	a.mu.Unlock()
+	if !mine {
+		a.inner.Free(val, sz)
+	}
+}
+
+func init() {
+	gpu := knoxgpu.Default()
+	if gpu == nil {
+		return
+	}
+	// the numeric vector types of block.Block (arena.go:17-29); [][]byte stays in Go memory (it holds Go pointers)
+	_arena.alloc[allocTypeInt64] = newPinnedAllocator[int64](gpu)
+	_arena.alloc[allocTypeInt32] = newPinnedAllocator[int32](gpu)
+	_arena.alloc[allocTypeInt16] = newPinnedAllocator[int16](gpu)
+	_arena.alloc[allocTypeInt8] = newPinnedAllocator[int8](gpu)
+	_arena.alloc[allocTypeUint64] = newPinnedAllocator[uint64](gpu)
+	_arena.alloc[allocTypeUint32] = newPinnedAllocator[uint32](gpu)
+	_arena.alloc[allocTypeUint16] = newPinnedAllocator[uint16](gpu)
+	_arena.alloc[allocTypeUint8] = newPinnedAllocator[uint8](gpu)
+	_arena.alloc[allocTypeFloat64] = newPinnedAllocator[float64](gpu)
+	_arena.alloc[allocTypeFloat32] = newPinnedAllocator[float32](gpu)
+}

@@ -18,12 +18,7 @@ import (
 var gpuCtx *knoxgpu.Ctx
 
 func init() {
-	if !knoxgpu.Enabled() {
-		return
-	}
-	if c, err := knoxgpu.Open(0); err == nil {
-		gpuCtx = c
-	}
+	gpuCtx = knoxgpu.Default() // nil: KNOX_NOGPU or no device -- every factory then returns the CPU matcher
 }
 
 type gpuNumMatcherFactory[T Number] struct {

@@ -286,6 +286,43 @@ func (col *Column) Free() {
 	C.knox_col_free(col.p)
 }
 
+var (
+	defaultOnce sync.Once
+	defaultCtx  *Ctx
+)
+
+// Default is the process-wide context on device 0 that the package-level hooks share (the Matcher shims, the arena's
+// page-locked allocator); nil when the GPU is switched off (KNOX_NOGPU) or cannot be opened.
+func Default() *Ctx {
+	defaultOnce.Do(func() {
+		if Enabled() {
+			if c, err := Open(0); err == nil {
+				defaultCtx = c
+			}
+		}
+	})
+	return defaultCtx
+}
+
+// HostAlloc hands out page-locked host memory (hipHostMalloc) owned by the library: block vectors built inside it are
+// read by the DMA engine in place (Upload / AppendAsync at PCIe rate, no staging copy).  C memory: the Go collector
+// neither moves nor frees it; HostFree gives it back.
+func (c *Ctx) HostAlloc(bytes int) (unsafe.Pointer, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var p unsafe.Pointer
+	if rc := C.knox_host_alloc(c.p, C.size_t(bytes), &p); rc != 0 {
+		return nil, errOf(rc)
+	}
+	return p, nil
+}
+
+func (c *Ctx) HostFree(p unsafe.Pointer) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	return errOf(C.knox_host_free(c.p, p))
+}
+
 // UploadPool puts ONE StringPool (pkg/stringx/pool.go:45-58: ptr[i] = off<<32 | len into buf) on the device as a bytes
 // column of one pack.
 func UploadPool(c *Ctx, ptr []uint64, buf []byte) (*Column, error) {

@@ -79,6 +79,12 @@ def test_matcher_and_operator_files_implement_the_reference_interfaces():
         assert re.search(r"^(func %s\b|type %s\b|\t%s\b)" % (name, name, name), lib, flags=re.M) or re.search(r"\b%s\b.*=" % name, lib), name
     assert "knoxgpu.RegexpOnDevice(v)" in byt and "unicode.Version == RegexpUnicodeVersion()" in lib
     assert byt.count("m.Matcher.MatchVector(b, bits, mask)") >= 5      # every failure path ends in the CPU matcher
+    # the arena hook: the reference's Allocator interface (internal/arena/allocator.go:14-17), page-locked slabs from the library
+    ar = open(os.path.join(GO, "arena_knoxgpu.go")).read()
+    assert re.search(r"^package arena$", ar, flags=re.M)
+    assert re.search(r"func \(a \*pinnedAllocator\[T\]\) Alloc\(sz int\) any", ar) and re.search(r"func \(a \*pinnedAllocator\[T\]\) Free\(val any, sz int\)", ar)
+    assert "a.gpu.HostAlloc(n * each)" in ar and ar.count("_arena.alloc[allocType") == 10 and "allocTypeBytesSlice" not in ar.split("func init()")[1]
+    assert "func (c *Ctx) HostAlloc(bytes int) (unsafe.Pointer, error)" in lib and "func Default() *Ctx" in lib
     op = open(os.path.join(GO, "operator_knoxgpu.go")).read()
     # the tree plan takes bytes blocks, bytes / regexp leaves and IN / NOT IN sets (types the reference really has: no BlockString)
     for needle in ("case types.BlockBytes:", "knoxgpu.UploadPool(g, ptr, buf)", "case types.FilterModeIn, types.FilterModeNotIn:",
