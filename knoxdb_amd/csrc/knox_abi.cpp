@@ -75,6 +75,8 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
 #endif
     env = getenv("KNOX_PLACEMENT");
     if (env) c->placement = atoi(env);
+    env = getenv("KNOX_DEFER");
+    c->defer_off = env && atoi(env) == 0;
     // arena budget: KNOX_ARENA_GIB, knox_ctx_set_arena, or three quarters of the device; physical memory is only taken
     // as allocations need it, 2 GiB at a time
     size_t free_b = 0, total_b = 0;
@@ -425,6 +427,7 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
     a.n_rows = rows;
     a.tail_first_row = rows;
     a.pack_shift = 255;
+    a.flags = 1;  // bursts tile by tile: the classes are told apart by the UNdeferred effect (knox_scan.hip kDefer)
     a.partials = (AggPartial *)ctx->probe_partials;
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
     if (hipEventRecord(ctx->probe_ev[0], ctx->stream) != hipSuccess) return 0.0;
@@ -476,6 +479,7 @@ static int probe_multi(knox_ctx *ctx, const void *p, uint64_t rows, void *const 
     a.n_rows = rows;
     a.tail_first_row = rows;
     a.pack_shift = 255;
+    a.flags = 1;  // bursts tile by tile: the classes are told apart by the UNdeferred effect (knox_scan.hip kDefer)
     a.partials = (AggPartial *)ctx->probe_partials;
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)grid);
     // which buffer launch i writes: -1 = read-only
@@ -1641,6 +1645,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // 2 no store, 3 plain store, 4 write-through store
 #endif
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
+    if (ctx->defer_off) a.flags |= 1u;  // KNOX_DEFER=0 when the context was opened (A/B): bitset bursts tile by tile
     prof_mark(ctx, 0);  // also the leaf passes of a multi-pass plan (slot 15): knox_prof_read then sums a scan's leaf kernels
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, a);
     prof_mark(ctx, 1);

@@ -20,8 +20,21 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    // the wave's bitset words of up to kMaxIters iterations, written out as one contiguous burst
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][kMaxIters * WAVE_ROWS / 32];
+    // The wave's bitset words, staged in LDS and written out as 16-byte-per-lane bursts of whole 128-byte lines.
+    // Plain filter (+ wrapping sum / count) scans -- the instantiations that run at 2 workgroups per CU and do nothing but
+    // stream -- DEFER their bursts: the words of as many consecutive tiles as 15 KiB per wave hold (120 tiles of an 8-byte
+    // column at 2 iterations) stay in LDS and leave together, every workgroup at the same rounds.  The memory controllers
+    // then see long read-only phases and short write-only ones instead of a write burst every 2.4 us per workgroup, and a
+    // bitset that lies in the column's OWN placement class costs 4 % instead of 16 % (round 3, on identical
+    // buffers: 0.727 -> 0.835 of peak at 120 tiles, 0.81 at 64, 0.77 at 32; another class: unchanged at 0.87).
+    // The same for the aggregate-heavy instantiations that run at 2 workgroups per CU anyway (knox_abi.cpp run_fused): one leaf
+    // on 8- and 1-byte columns, two leaves (BASELINE configs[2]: +1.9 % on identical buffers).  Not the 4-byte ones: int32 with
+    // all aggregates lost 1.7-2.4 % with parked bursts (tools/ab_kernels.py env:KNOX_DEFER=0), float32 sums want 8 workgroups per CU.
+    constexpr bool kHeavy = (AGG & ~A_ISUM) != 0;
+    constexpr bool kDefer = (NL == 1 && !kHeavy && W >= 2) || (NL == 1 && kHeavy && (W == 8 || W == 1)) || (NL == 2 && kHeavy);
+    constexpr uint32_t kTileWordsMax = kMaxIters * WAVE_ROWS / 32;
+    constexpr uint32_t kStageWords = kDefer ? (kTileWordsMax > 3840u ? kTileWordsMax : 3840u) : kTileWordsMax;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][kStageWords];
 
     Acc acc;
     acc.init();
@@ -31,6 +44,12 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     fl.init();
     uint32_t cnt32 = 0;
     const uint32_t iters = a.iters;
+    // tiles whose words are parked before one flush (1 = every tile, as the other instantiations do; the arena's probes ask
+    // for that too: they classify memory by the undeferred effect), the parked tiles so far, the first one's first row
+    const uint32_t tile_words = iters * (WAVE_ROWS / 32);
+    const uint32_t defer_tiles = (kDefer && a.live_packs == nullptr && (a.flags & 1u) == 0) ? kStageWords / tile_words : 1u;
+    uint32_t parked = 0;
+    uint64_t parked_row0 = 0;
 
     U lo[NL], diff[NL];
     bool isf[NL];
@@ -102,6 +121,28 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) ra[u] = ld16<true>(p + u * 64);
         }
+    };
+    // the parked tiles' words -> the bitset: tile j of the batch lies j rounds behind the first (live_packs == nullptr:
+    // a round is gridDim.x tiles further in the table); 16 bytes per lane, whole 128-byte lines, streaming (nt) stores
+    auto flush = [&]() {
+        const uint32_t nv = tile_words / 4;                     // 16-byte vectors per tile
+        const uint32_t total = parked * nv;
+        const uint64_t round_words = ((uint64_t)gridDim.x * kWavesPerBlock * iters * WAVE_ROWS) >> 5;
+        uint32_t *base = a.bits + (parked_row0 >> 5);
+        for (uint32_t v = lane; v < total; v += 64) {
+            const uint32_t j = defer_tiles == 1u ? 0u : v / nv;
+            const u32x4 x = ((const u32x4 *)stage[wave])[v];
+            u32x4 *dst = (u32x4 *)(base + (uint64_t)j * round_words) + (v - j * nv);
+#ifdef KNOX_DIAG
+            // diagnostics build only (make diag): debug bit0 = words are assembled but never leave the CU
+            if (a.debug & 2u) *dst = x;  // plain (L2 write-back) store
+            else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(x) : "memory");
+            else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst);
+#else
+            __builtin_nontemporal_store(x, dst);
+#endif
+        }
+        parked = 0;
     };
     // one wave iteration over loaded registers: predicate, bitset words into the LDS stage, aggregates; the last
     // iteration of a tile writes the wave's burst
@@ -202,7 +243,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             }
             if ((lane & (G - 1)) == 0) {
 #pragma unroll
-                for (int u = 0; u < kUnroll; u++) stage[wave][it * (WAVE_ROWS / 32) + u * (64 / G) + (lane / G)] = w[u];
+                for (int u = 0; u < kUnroll; u++) stage[wave][parked * tile_words + it * (WAVE_ROWS / 32) + u * (64 / G) + (lane / G)] = w[u];
             }
         }
         if constexpr (AGG != 0 && !kSwar && !kSwarAgg) {
@@ -211,26 +252,15 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
         }
         if (it + 1 == iters) {
         if (a.bits != nullptr) {
-            // LDS ops of one wave execute in order: the reads below see the words written above.
-            // One burst of iters * WAVE_ROWS/8 contiguous bytes per wave (1 KiB for 8-byte types at
-            // 16 iterations): whole 128-B lines, 16-byte-per-lane streaming (nt) stores.
-            const uint32_t nv = iters * (WAVE_ROWS / 128);  // 16-byte vectors
-            u32x4 *dst = (u32x4 *)(a.bits + (wrow0 >> 5));
+            // LDS ops of one wave execute in order: the flush reads see the words written above.
+            // One burst of iters * WAVE_ROWS/8 contiguous bytes per wave and tile (128 B for 8-byte types at 2 iterations):
+            // whole 128-B lines, 16-byte-per-lane streaming (nt) stores -- now, or with the tiles parked behind it
+            if (parked == 0) parked_row0 = wrow0;
+            if (++parked == defer_tiles) flush();
             // this lane's share of the burst's popcount is what its running count grew by (the wave total is all
             // the per-tile count needs): no popcounts over the staged words
             uint32_t tc = cnt32 - cnt_prev;
             cnt_prev = cnt32;
-            for (uint32_t v = lane; v < nv; v += 64) {
-                const u32x4 x = ((const u32x4 *)stage[wave])[v];
-#ifdef KNOX_DIAG
-                // diagnostics build only (make diag): debug bit0 = words are assembled but never leave the CU
-                if (a.debug & 2u) dst[v] = x;  // plain (L2 write-back) store
-                else if (a.debug & 4u) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + v), "v"(x) : "memory");
-                else if (!(a.debug & 1u) || x.x == 0x12345678u) __builtin_nontemporal_store(x, dst + v);
-#else
-                __builtin_nontemporal_store(x, dst + v);
-#endif
-            }
             if (tcbase != nullptr) {
                 // popcount of this wave tile's burst, once per tile.  The counts of 32 consecutive
                 // rounds are parked one per lane and leave as ONE full 128-byte line (no partial writes).
@@ -295,6 +325,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             }
         }
     }
+    if (a.bits != nullptr && parked != 0) flush();
     if (tcbase != nullptr && (round & 31u) != 0 && lane < (int)(round & 31u)) tcbase[(round & ~31u) + lane] = tcreg;
     acc.count = cnt32;
     if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);

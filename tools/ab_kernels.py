@@ -3,7 +3,9 @@
 and placed -- once by build A and borrowed by build B through knox_col_wrap / knox_bits_wrap), so
 that differences are kernel differences, not placement or box differences.  Alternates A/B `rounds`
 times per case and prints the per-build median GB/s.
-usage: ab_kernels.py <libB.so> [rows_log2=28] [rounds=3]      (A = the in-tree product library)"""
+usage: ab_kernels.py <libB.so> [rows_log2=28] [rounds=3]      (A = the in-tree product library)
+       ab_kernels.py env:NAME=VALUE [rows_log2] [rounds]      (B = the same library, its context opened with that environment
+                                                               variable set, e.g. env:KNOX_DEFER=0)"""
 import ctypes as C, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import knoxdb_amd as K
@@ -16,10 +18,15 @@ lg = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 n, pack = 1 << lg, 1 << 20
 A = LL.lib()
-Bl = C.CDLL(lib_b)
-for name, (res, args) in LL.SIGNATURES.items():
-    fn = getattr(Bl, name)
-    fn.restype, fn.argtypes = res, args
+env_b = None
+if lib_b.startswith("env:"):
+    env_b = lib_b[4:].split("=", 1)
+    Bl = A
+else:
+    Bl = C.CDLL(lib_b)
+    for name, (res, args) in LL.SIGNATURES.items():
+        fn = getattr(Bl, name)
+        fn.restype, fn.argtypes = res, args
 
 ctxA = K.Context(0)
 spec = {"i64": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "i64b": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "f64": (B.Float64, 8, 0, 0, 2), "f64b": (B.Float64, 8, 0, 0, 2),
@@ -29,7 +36,11 @@ colsA = {k: ctxA.generate(bt, kind, 2 + i, n, lo=lo, span=span, pack_rows=pack) 
 bitsA = ctxA.bits(n, for_col=colsA["i64"])
 ctxA.sync()
 LL._lib = Bl
+if env_b:
+    os.environ[env_b[0]] = env_b[1]
 ctxB = K.Context(0)
+if env_b:
+    os.environ.pop(env_b[0], None)
 ctxB.set_placement(False)
 colsB = {k: ctxB.wrap(spec[k][0], colsA[k].device_ptr, n, pack) for k in spec}
 LL._lib = A
