@@ -31,9 +31,14 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // on 8- and 1-byte columns, two leaves (BASELINE configs[2]: +1.9 % on identical buffers).  Not the 4-byte ones: int32 with
     // all aggregates lost 1.7-2.4 % with parked bursts (tools/ab_kernels.py env:KNOX_DEFER=0), float32 sums want 8 workgroups per CU.
     constexpr bool kHeavy = (AGG & ~A_ISUM) != 0;
-    constexpr bool kDefer = (NL == 1 && !kHeavy && W >= 2) || (NL == 1 && kHeavy && (W == 8 || W == 1)) || (NL == 2 && kHeavy);
+    constexpr bool kDefer2 = (NL == 1 && !kHeavy && W >= 2) || (NL == 1 && kHeavy && (W == 8 || W == 1)) || (NL == 2 && kHeavy);
+    // the instantiations that run at 3 workgroups per CU park 12 KiB per wave (96 tiles of an 8-byte column): 1-byte plain scans,
+    // 2-byte aggregate-heavy ones, trees of two plain or of three / four leaves
+    constexpr bool kDefer3 = (NL == 1 && !kHeavy && W == 1) || (NL == 1 && kHeavy && W == 2) || (NL == 2 && !kHeavy) || NL >= 3;
+    constexpr bool kDefer = kDefer2 || kDefer3;
     constexpr uint32_t kTileWordsMax = kMaxIters * WAVE_ROWS / 32;
-    constexpr uint32_t kStageWords = kDefer ? (kTileWordsMax > 3840u ? kTileWordsMax : 3840u) : kTileWordsMax;
+    constexpr uint32_t kParkWords = kDefer2 ? 3840u : kDefer3 ? 3072u : 0u;
+    constexpr uint32_t kStageWords = kTileWordsMax > kParkWords ? kTileWordsMax : kParkWords;
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][kStageWords];
 
     Acc acc;

@@ -67,6 +67,8 @@ cases = [
     ("u8 Between (count)", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), [], 1.125),
     ("u8 Between+sum", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), [(R.Sum, 0)], 1.125),
     ("u8 Between+ALL", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), ALLA, 1.125),
+    ("i64 x2 OR (count)", ["i64", "i64b"], lambda: Or(Leaf(0, F.Gt, 1 << 39), Leaf(1, F.Lt, -(1 << 39))), [], 16.125),
+    ("f64 x2 + i64 x1: 3 leaves + sum", ["f64", "f64b", "i64"], lambda: And(Leaf(0, F.Ge, 0.25), Leaf(1, F.Lt, 0.5), Leaf(2, F.Gt, 0)), [(R.Sum, 2)], 24.125),
 ]
 
 
