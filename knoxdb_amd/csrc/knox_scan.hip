@@ -292,7 +292,13 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // disturb the read / write mix at the memory controllers (int64 headline -10 %): they keep the simple loop.
     // (round 3 A/B, the plain 1- / 2-byte scans pipelined too: int16 -1.4 ... -2.7 %, uint8 +1.5 % -- left as they are)
     // (round 3: two-leaf aggregate-heavy scans too -- BASELINE configs[2]: +1.4 % on identical buffers, tools/ab_kernels.py)
-    constexpr bool kPipe = NL <= 2 && !SEP && (AGG & ~A_ISUM) != 0;
+    // (round 3, with the bursts deferred -- tools/ab_kernels.py against a build with every plain scan pipelined: two-leaf plain
+    //  trees +1.4 ... +1.9 %, uint8 filter + sum +5.5 %; int64 filter + sum -4.2 %, int16 -3 ... -7 %, int32 -1.5 %, uint8 count 0)
+#ifdef KNOX_PIPE_PLAIN  // experiment builds: every plain scan pipelined
+    constexpr bool kPipe = NL <= 2 && !SEP;
+#else
+    constexpr bool kPipe = NL <= 2 && !SEP && ((AGG & ~A_ISUM) != 0 || NL == 2 || (W == 1 && AGG == A_ISUM));
+#endif
     if (kPipe && (iters & 1u) == 0) {
         u32x4 ra[kUnroll];
         u32x4 ra_a[NL][kUnroll], rb[NL][kUnroll];
