@@ -76,7 +76,7 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
     env = getenv("KNOX_PLACEMENT");
     if (env) c->placement = atoi(env);
     env = getenv("KNOX_DEFER");
-    c->defer_off = env && atoi(env) == 0;
+    c->defer_flags = env && atoi(env) == 0 ? 1u : env && atoi(env) == 2 ? 2u : 0u;
     // arena budget: KNOX_ARENA_GIB, knox_ctx_set_arena, or three quarters of the device; physical memory is only taken
     // as allocations need it, 2 GiB at a time
     size_t free_b = 0, total_b = 0;
@@ -1645,7 +1645,7 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     a.debug = ctx->variant == 2 ? 1u : ctx->variant == 3 ? 2u : ctx->variant == 4 ? 4u : ctx->variant == 5 ? 8u : 0u;  // 2 no store, 3 plain store, 4 write-through store
 #endif
     a.partials = (AggPartial *)ctx->partials.p + (size_t)slot * (size_t)(grid + 1);
-    if (ctx->defer_off) a.flags |= 1u;  // KNOX_DEFER=0 when the context was opened (A/B): bitset bursts tile by tile
+    a.flags |= ctx->defer_flags;  // KNOX_DEFER=0 when the context was opened (A/B): bitset bursts tile by tile; =2: deferred but not aligned in time
     prof_mark(ctx, 0);  // also the leaf passes of a multi-pass plan (slot 15): knox_prof_read then sums a scan's leaf kernels
     hipError_t e = launch_scan(ctx->stream, width, n_leaves, agg_col ? agg : 0, sep, g, a);
     prof_mark(ctx, 1);

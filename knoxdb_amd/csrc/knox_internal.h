@@ -42,7 +42,7 @@ struct knox_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_hip = 0;
     int n_cus = 256;
-    bool defer_off = false; // KNOX_DEFER=0 at open: the plain scans write their bitset bursts tile by tile (A/B of knox_scan.hip kDefer)
+    uint32_t defer_flags = 0; // ScanArgs.flags of this context's scans: KNOX_DEFER=0 at open -> 1 (bitset bursts tile by tile), =2 -> 2 (deferred, flushes not aligned in time); A/B of knox_scan.hip kDefer
     int blocks_per_cu = 0;  // 0 = auto: 2 workgroups/CU for pure streaming passes, 3 when the pass carries
                             // float/min-max aggregates or several leaves (profiles/r01_sweep_blocks_per_cu.txt)
 #ifdef KNOX_DIAG

@@ -56,7 +56,7 @@ struct ScanArgs {
     uint32_t *bits;         // output bitset (nullable)
     const uint32_t *mask;   // reduce pass: input selection bitset (nullable = all rows)
     uint32_t debug;         // read by -DKNOX_DIAG builds only (make diag); the product kernels ignore it and the ABI leaves it 0
-    uint32_t flags;         // bit0: bitset bursts leave tile by tile (no deferral: the arena's placement probes, KNOX_DEFER=0)
+    uint32_t flags;         // bit0: bitset bursts leave tile by tile (no deferral: the arena's placement probes, KNOX_DEFER=0); bit1: deferred bursts are not aligned in time (KNOX_DEFER=2)
     uint32_t iters;         // wave iterations per tile (1..kMaxIters): tile = iters * tile_rows(width)
     uint32_t *tile_counts;  // nullable: [(workgroup * kWavesPerBlock + wave) * tc_rounds + round] = popcount of that wave tile's burst
     uint32_t tc_rounds;     // rounds per workgroup, padded to a multiple of 32 (one 128-byte line of counts)

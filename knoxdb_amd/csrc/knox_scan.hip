@@ -55,6 +55,18 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     const uint32_t defer_tiles = (kDefer && a.live_packs == nullptr && (a.flags & 1u) == 0) ? kStageWords / tile_words : 1u;
     uint32_t parked = 0;
     uint64_t parked_row0 = 0;
+    // The flushes are ALIGNED IN TIME across the chip: a phase lasts 2^phase_shift ticks of the 100 MHz real-time clock, the
+    // largest power of two below the time the stage takes to fill (a tile is 8 KiB per wave and column whatever the width:
+    // ~ gridDim.x * 15 / 32 ticks per tile and leaf at 7 TB/s, 240 for 512 workgroups; 120 tiles -> 2^14 ticks = 164 us).
+    // Measured on identical buffers (tools/ab_defer.py, phases of 2^11 ... 2^14 ticks): aligned flushes take a bitset in the
+    // column's own placement class from 0.846 (unaligned, 120 tiles) to 0.862 of peak, another class stays at 0.88; shorter
+    // phases lose (2^11: 0.844 / 0.872).  flags bit1 (KNOX_DEFER=2): unaligned, for the A/B.
+    uint32_t phase_shift = 0;
+    if (defer_tiles > 1u && (a.flags & 2u) == 0) {
+        const uint32_t fill_ticks = defer_tiles * ((gridDim.x * (uint32_t)NL * 15u) >> 5);
+        phase_shift = fill_ticks >= 64u ? 31u - (uint32_t)__builtin_clz(fill_ticks) : 0u;
+    }
+    uint32_t last_phase = phase_shift ? (uint32_t)(__builtin_amdgcn_s_memrealtime() >> phase_shift) : 0u;
 
     U lo[NL], diff[NL];
     bool isf[NL];
@@ -261,7 +273,16 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
             // One burst of iters * WAVE_ROWS/8 contiguous bytes per wave and tile (128 B for 8-byte types at 2 iterations):
             // whole 128-B lines, 16-byte-per-lane streaming (nt) stores -- now, or with the tiles parked behind it
             if (parked == 0) parked_row0 = wrow0;
-            if (++parked == defer_tiles) flush();
+            ++parked;
+            if (phase_shift != 0u) {
+                // every wave of every workgroup flushes when the constant 100 MHz clock enters a new phase: the write-only
+                // phases of the whole chip coincide (a full stage flushes too, which the phase length is chosen to avoid)
+                const uint32_t ph = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> phase_shift);
+                if (parked == defer_tiles || ph != last_phase) flush();
+                last_phase = ph;
+            } else if (parked == defer_tiles) {
+                flush();
+            }
             // this lane's share of the burst's popcount is what its running count grew by (the wave total is all
             // the per-tile count needs): no popcounts over the staged words
             uint32_t tc = cnt32 - cnt_prev;

@@ -17,7 +17,7 @@ from knoxdb_amd.types import BlockType as B, FilterMode as F, ReducerFunc as R  
 
 n, pack = 1 << 30, 1 << 20
 A = LL.lib()
-libs = [("bursts tile by tile", A), ("deferred (product)", A)]
+libs = [("bursts tile by tile", A), ("deferred, unaligned", A), ("deferred (product)", A)]
 for path in sys.argv[1:]:
     L = C.CDLL(path)
     for name, (res, args) in LL.SIGNATURES.items():
@@ -56,6 +56,8 @@ for name, L in libs:
     LL._lib = L
     if name == "bursts tile by tile":
         os.environ["KNOX_DEFER"] = "0"
+    elif name == "deferred, unaligned":
+        os.environ["KNOX_DEFER"] = "2"
     else:
         os.environ.pop("KNOX_DEFER", None)
     ctx = K.Context(0)
