@@ -52,7 +52,7 @@ type gpuBytesMatcher struct {
 }
 
 func (m *gpuBytesMatcher) MatchVector(b *block.Block, bits, mask *bitset.Bitset) {
-	pool, ok := b.Bytes().(*stringx.StringPool)
+	pool, ok := b.Container().(*stringx.StringPool) // Container() = the block's vector as `any` (block.go:188): no panic for encoded string containers
 	if !ok || pool.Len() < gpuBytesMinRows {
 		m.Matcher.MatchVector(b, bits, mask)
 		return
