@@ -147,7 +147,8 @@ func uploadBlock(g *knoxgpu.Ctx, b *block.Block) (*knoxgpu.Column, error) {
 	case types.BlockBytes:
 		// a plain StringPool goes up as it is (pointer array + buffer = one pack of a bytes column); the dictionary / fixed /
 		// compact string containers keep the reference's own matchers (the whole tree then runs on the CPU operator)
-		if pool, ok := b.Container().(*stringx.StringPool) // Container() = the block's vector as `any` (block.go:188): no panic for encoded string containers; ok {
+		// Container() = the block's vector as `any` (block.go:188): no panic for encoded string containers
+		if pool, ok := b.Container().(*stringx.StringPool); ok {
 			ptr, buf := pool.Raw() // pkg/stringx accessor quoted in bytes_knoxgpu.go
 			return knoxgpu.UploadPool(g, ptr, buf)
 		}
