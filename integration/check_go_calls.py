@@ -260,6 +260,52 @@ def go_consts(src):
     return out
 
 
+def structure_errors(text):
+    """What a missing toolchain still allows: brackets of a Go file balance outside strings, runes and comments, and no
+    statement opener (`if` / `for` / `switch` / `func` ... `{`) lost its brace to a trailing comment."""
+    errs, stack, i, n, line = [], [], 0, len(text), 1
+    pairs = {")": "(", "]": "[", "}": "{"}
+    while i < n:
+        c = text[i]
+        if c == "\n":
+            line += 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+            continue
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            line += text.count("\n", i, j if j >= 0 else n)
+            i = n if j < 0 else j + 2
+            continue
+        elif c == "`":
+            j = text.find("`", i + 1)
+            line += text.count("\n", i, j if j >= 0 else n)
+            i = n if j < 0 else j + 1
+            continue
+        elif c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            i = j + 1
+            continue
+        elif c in "([{":
+            stack.append((c, line))
+        elif c in ")]}":
+            if not stack or stack[-1][0] != pairs[c]:
+                errs.append("line %d: unbalanced `%s`" % (line, c))
+                return errs
+            stack.pop()
+        i += 1
+    if stack:
+        errs.append("line %d: `%s` is never closed" % (stack[-1][1], stack[-1][0]))
+    for ln, l in enumerate(text.split("\n"), 1):
+        code = l.split("//")[0].rstrip()
+        if re.match(r"^\s*(if|for|switch|func|} else if|} else)\b", code) and "//" in l and not code.endswith(("{", ",", "(", "||", "&&")) and l.split("//", 1)[1].rstrip().endswith("{"):
+            errs.append("line %d: the opening brace of this statement sits inside a comment" % ln)
+    return errs
+
+
 def check(verbose=False):
     funcs, structs, enums = parse_header(HEADER)
     errors, checked, bound = [], 0, set()
@@ -267,6 +313,8 @@ def check(verbose=False):
     for d, _, fs in os.walk(GO_DIR):
         go_files += [os.path.join(d, f) for f in fs if f.endswith(".go")]
     for path in sorted(go_files):
+        for e in structure_errors(open(path).read()):
+            errors.append(f"{os.path.relpath(path, ROOT)}: {e}")
         src = re.sub(r"//[^\n]*", "", open(path).read().replace("/*\n#cgo", "/*cgo"))
         src = re.sub(r"/\*cgo.*?\*/", "", src, flags=re.S)
         rel = os.path.relpath(path, ROOT)
