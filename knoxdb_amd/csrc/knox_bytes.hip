@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(kBlock) bytes_match_kernel(int mode, BytesView
 // [0, 16) and [min(16, vlen - 16), +16), which cover the whole value up to 32 bytes -- so 12 loads per lane are in
 // flight instead of a pointer -> first piece -> second piece chain.  Values above 32 bytes finish in bytes_equal for
 // the rows that still match (rare).  Per row: 8 B pointer + len B payload read, 1/8 B written.
+// (The payload pieces stay ordinary cached loads: as streaming (nt) loads -- round 3, same bench -- the kernel fell from 0.848 to
+// 0.78 of peak; the two pieces of a row and the rows of a 128-byte line share sectors, which only a cache can serve once.)
 constexpr int kEqGroups = 4;
 __global__ void __launch_bounds__(kBlock) bytes_eq_kernel(int negate, BytesView v, const uint8_t *val, uint32_t vlen, uint8_t *bits,
                                                           const uint8_t *mask, unsigned long long *count_out) {
