@@ -1566,7 +1566,12 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     // per tile than with 2 (tools/sweep_narrow.py all, round 3: int64 ALL 6.48 -> 6.64, int32 ALL 6.33 -> 6.51, int8 ALL 5.30 ->
     // 5.65 TB/s together with the occupancy below); the plain filter (+ sum) scans keep 2
     const bool plain_scan = !agg_col || (agg & ~A_ISUM) == 0;
-    a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0, (!plain_scan && n_leaves == 1) ? 4u : 2u);
+    // (round 3, with the bursts deferred: scans that also record per-tile counts for the per-pack counts run 1.5 % faster with 4
+    //  iterations -- half as many tiles, half as many count reductions: DPP chain + 4 readlanes per tile -- 8- and 4-byte columns;
+    //  without the counts 2 and 4 are equal, tools/sweep_iters.sh, tools/ab_kernels.py envrun:KNOX_ITERS=4; the count-only
+    //  form -- BASELINE configs[3]'s uint64 EQ -- loses 1-2 % with 4 and keeps 2)
+    const bool counted = per_pack_tiles != nullptr && bits != nullptr && width >= 4 && agg_col != nullptr && agg != 0;  // agg == 0: count only
+    a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0, ((!plain_scan && n_leaves == 1) || counted) ? 4u : 2u);
     const uint64_t tr = (uint64_t)tile_rows(width) * a.iters;
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;

@@ -56,14 +56,16 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     uint32_t parked = 0;
     uint64_t parked_row0 = 0;
     // The flushes are ALIGNED IN TIME across the chip: a phase lasts 2^phase_shift ticks of the 100 MHz real-time clock, the
-    // largest power of two below the time the stage takes to fill (a tile is 8 KiB per wave and column whatever the width:
-    // ~ gridDim.x * 15 / 32 ticks per tile and leaf at 7 TB/s, 240 for 512 workgroups; 120 tiles -> 2^14 ticks = 164 us).
+    // largest power of two below the time the stage takes to fill (a tile is iters * 4 KiB per wave and column whatever the
+    // width: ~ gridDim.x * iters * 15 / 64 ticks per tile and leaf at 7 TB/s, 240 for 512 workgroups at 2 iterations; 120 such
+    // tiles -> 2^14 ticks = 164 us).  (Writing the per-tile counts in the same phases instead of a 128-byte line every 32
+    // rounds was tried: no difference.)
     // Measured on identical buffers (tools/ab_defer.py, phases of 2^11 ... 2^14 ticks): aligned flushes take a bitset in the
     // column's own placement class from 0.846 (unaligned, 120 tiles) to 0.862 of peak, another class stays at 0.88; shorter
     // phases lose (2^11: 0.844 / 0.872).  flags bit1 (KNOX_DEFER=2): unaligned, for the A/B.
     uint32_t phase_shift = 0;
     if (defer_tiles > 1u && (a.flags & 2u) == 0) {
-        const uint32_t fill_ticks = defer_tiles * ((gridDim.x * (uint32_t)NL * 15u) >> 5);
+        const uint32_t fill_ticks = defer_tiles * ((gridDim.x * (uint32_t)NL * iters * 15u) >> 6);
         phase_shift = fill_ticks >= 64u ? 31u - (uint32_t)__builtin_clz(fill_ticks) : 0u;
     }
     uint32_t last_phase = phase_shift ? (uint32_t)(__builtin_amdgcn_s_memrealtime() >> phase_shift) : 0u;

@@ -5,7 +5,9 @@ that differences are kernel differences, not placement or box differences.  Alte
 times per case and prints the per-build median GB/s.
 usage: ab_kernels.py <libB.so> [rows_log2=28] [rounds=3]      (A = the in-tree product library)
        ab_kernels.py env:NAME=VALUE [rows_log2] [rounds]      (B = the same library, its context opened with that environment
-                                                               variable set, e.g. env:KNOX_DEFER=0)"""
+                                                               variable set, e.g. env:KNOX_DEFER=0)
+       ab_kernels.py envrun:NAME=VALUE [rows_log2] [rounds]   (B = the same library and context kind, the variable set while B's
+                                                               scans are enqueued, e.g. envrun:KNOX_ITERS=4)"""
 import ctypes as C, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import knoxdb_amd as K
@@ -18,9 +20,12 @@ lg = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 n, pack = 1 << lg, 1 << 20
 A = LL.lib()
-env_b = None
+env_b = envrun_b = None
 if lib_b.startswith("env:"):
     env_b = lib_b[4:].split("=", 1)
+    Bl = A
+elif lib_b.startswith("envrun:"):   # the variable is set while B's scans are enqueued (knobs the library reads per call, e.g. KNOX_ITERS)
+    envrun_b = lib_b[7:].split("=", 1)
     Bl = A
 else:
     Bl = C.CDLL(lib_b)
@@ -75,6 +80,8 @@ cases = [
 def run(lib, ctx, cols, bits, names, tree, aggs, bpr, steps=16):
     LL._lib = lib
     try:
+        if envrun_b and ctx is ctxB:
+            os.environ[envrun_b[0]] = envrun_b[1]
         plan = ctx.plan(tree(), [cols[k] for k in names], aggs=aggs)
         ctx.L.knox_prof_enable(ctx.h, 1)
         ctx.scan_async(plan, bits_out=bits)
@@ -89,6 +96,8 @@ def run(lib, ctx, cols, bits, names, tree, aggs, bpr, steps=16):
         v = [ms[i] for i in range(k.value)]
         return n * bpr / statistics.median(v[len(v) // 2:]) / 1e6, res.count
     finally:
+        if envrun_b:
+            os.environ.pop(envrun_b[0], None)
         LL._lib = A
 
 
