@@ -1572,6 +1572,8 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     //  form -- BASELINE configs[3]'s uint64 EQ -- loses 1-2 % with 4 and keeps 2)
     const bool counted = per_pack_tiles != nullptr && bits != nullptr && width >= 4 && agg_col != nullptr && agg != 0;  // agg == 0: count only
     a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0, ((!plain_scan && n_leaves == 1) || counted) ? 4u : 2u);
+    // packs must stay whole numbers of tiles for the per-tile counts (small packs: 4096 rows = one 2-iteration tile of an 8-byte column)
+    while (per_pack_tiles != nullptr && pack_rows && a.iters > 1 && pack_rows % ((size_t)tile_rows(width) * a.iters) != 0) a.iters >>= 1;
     const uint64_t tr = (uint64_t)tile_rows(width) * a.iters;
     a.n_tiles = n_rows / tr;
     a.n_rows = n_rows;
