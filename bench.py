@@ -525,7 +525,7 @@ def main():
         # A process that has just exited (the GPU tests, the smoke run, a previous bench) leaves the driver clearing the
         # memory it freed, which costs EVERY kernel on the device ~5 % for as long as it lasts (measured: three bench runs back
         # to back, the second and third read 6.82 instead of 7.16 TB/s for their whole 5 s).  The read-only form
-        # of the scan is sampled every 0.5 s until two consecutive samples agree within 1 %: setup, outside the
+        # of the scan is sampled every 0.5 s until two consecutive samples agree within 0.4 %: setup, outside the
         # timed region, reported as placement.device_quiet_ms.
         kernel_ms(ro_plan0, None, 12)                     # clock ramp
         quiet.append(kernel_ms(ro_plan0, None, 6))
@@ -538,7 +538,7 @@ def main():
             kernel_ms(ro_plan0, None, 6)                  # clock ramp after the pause
             quiet.append(kernel_ms(ro_plan0, None, 6))
             waited = time.perf_counter() - t_wait
-            stable = abs(quiet[-1] - quiet[-2]) <= 0.01 * quiet[-2]
+            stable = abs(quiet[-1] - quiet[-2]) <= 0.004 * quiet[-2]   # launch-to-launch noise is ~0.2 %; a device that is still getting faster keeps the wait going
             if (stable and (fast_enough(quiet[-1]) or waited > 10.0)) or waited > 15.0:
                 break
         for attempt in range(2):
