@@ -54,6 +54,11 @@ __global__ void __launch_bounds__(kBlock) bytes_match_kernel(int mode, BytesView
 // [0, 16) and [min(16, vlen - 16), +16), which cover the whole value up to 32 bytes -- so 12 loads per lane are in
 // flight instead of a pointer -> first piece -> second piece chain.  Values above 32 bytes finish in bytes_equal for
 // the rows that still match (rare).  Per row: 8 B pointer + len B payload read, 1/8 B written.
+// (Round 3 also tried the scan kernel's deferred, phase-aligned bursts here: a persistent kernel whose workgroups take chunks of
+// 8 x 1024 rows off a device counter in order, park the 128-byte bitset lines in LDS and flush on the clock's phases -- 0.79-0.80
+// of peak at 4 / 8 / 12 workgroups per CU against 0.843-0.845 for this one-workgroup-per-1024-rows form (one unit per dequeue: the
+// single counter word saturates at ~80 atomics per us, 0.39).  The pointer -> payload chain wants the parallelism of many short
+// workgroups more than it minds the trickle of bitset writes, which are 0.3 % of its traffic.)
 // (The payload pieces stay ordinary cached loads: as streaming (nt) loads -- round 3, same bench -- the kernel fell from 0.848 to
 // 0.78 of peak; the two pieces of a row and the rows of a 128-byte line share sectors, which only a cache can serve once.)
 constexpr int kEqGroups = 4;
