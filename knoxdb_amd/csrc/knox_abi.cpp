@@ -1567,10 +1567,10 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     // 5.65 TB/s together with the occupancy below); the plain filter (+ sum) scans keep 2
     const bool plain_scan = !agg_col || (agg & ~A_ISUM) == 0;
     // (round 3, with the bursts deferred: scans that also record per-tile counts for the per-pack counts run 1.5 % faster with 4
-    //  iterations -- half as many tiles, half as many count reductions: DPP chain + 4 readlanes per tile -- 8- and 4-byte columns;
+    //  iterations -- half as many tiles, half as many count reductions: DPP chain + 4 readlanes per tile -- 8-, 4- and 2-byte columns;
     //  without the counts 2 and 4 are equal, tools/sweep_iters.sh, tools/ab_kernels.py envrun:KNOX_ITERS=4; the count-only
     //  form -- BASELINE configs[3]'s uint64 EQ -- loses 1-2 % with 4 and keeps 2)
-    const bool counted = per_pack_tiles != nullptr && bits != nullptr && width >= 4 && agg_col != nullptr && agg != 0;  // agg == 0: count only
+    const bool counted = per_pack_tiles != nullptr && bits != nullptr && width >= 2 && agg_col != nullptr && agg != 0;  // agg == 0: count only; int32 85.4 -> 87.0, int16 78.8 -> 80.9 % of peak, uint8 no difference
     a.iters = pick_iters(ctx, n_rows, width, want_skip ? pack_rows : 0, ((!plain_scan && n_leaves == 1) || counted) ? 4u : 2u);
     // packs must stay whole numbers of tiles for the per-tile counts (small packs: 4096 rows = one 2-iteration tile of an 8-byte column)
     while (per_pack_tiles != nullptr && pack_rows && a.iters > 1 && pack_rows % ((size_t)tile_rows(width) * a.iters) != 0) a.iters >>= 1;
