@@ -28,10 +28,11 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // bitset that lies in the column's OWN placement class costs 4 % instead of 16 % (round 3, on identical
     // buffers: 0.727 -> 0.835 of peak at 120 tiles, 0.81 at 64, 0.77 at 32; another class: unchanged at 0.87).
     // The same for the aggregate-heavy instantiations that run at 2 workgroups per CU anyway (knox_abi.cpp run_fused): one leaf
-    // on 8- and 1-byte columns, two leaves (BASELINE configs[2]: +1.9 % on identical buffers).  Not the 4-byte ones: int32 with
-    // all aggregates lost 1.7-2.4 % with parked bursts (tools/ab_kernels.py env:KNOX_DEFER=0), float32 sums want 8 workgroups per CU.
+    // on 8-, 4- (integers) and 1-byte columns, two leaves (BASELINE configs[2]: +1.9 % on identical buffers).  int32 with all
+    // aggregates lost 1.7-2.4 % with unaligned parked bursts and gains 1.0-1.3 % with the aligned ones (tools/ab_kernels.py against
+    // a build without / with it); float32 sums want 8 workgroups per CU and keep their tile-by-tile bursts.
     constexpr bool kHeavy = (AGG & ~A_ISUM) != 0;
-    constexpr bool kDefer2 = (NL == 1 && !kHeavy && W >= 2) || (NL == 1 && kHeavy && (W == 8 || W == 1)) || (NL == 2 && kHeavy);
+    constexpr bool kDefer2 = (NL == 1 && !kHeavy && W >= 2) || (NL == 1 && kHeavy && (W == 8 || W == 1 || (W == 4 && FLV != FL_FLOAT))) || (NL == 2 && kHeavy);
     // the instantiations that run at 3 workgroups per CU park 12 KiB per wave (96 tiles of an 8-byte column): 1-byte plain scans,
     // 2-byte aggregate-heavy ones, trees of two plain or of three / four leaves
     constexpr bool kDefer3 = (NL == 1 && !kHeavy && W == 1) || (NL == 1 && kHeavy && W == 2) || (NL == 2 && !kHeavy) || NL >= 3;
