@@ -60,6 +60,18 @@ def test_tables_report_their_unicode_version():
     assert _lib.lib().knox_regexp_unicode_version() == b"17.0.0"
 
 
+def test_committed_tables_are_what_the_generator_writes(tmp_path):
+    """knox_unicode_tables.h is generated (tools/gen_unicode_tables.py from the regex module's Unicode 17.0 data): the committed
+    header must be byte for byte what the generator produces here"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "tables.h")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_unicode_tables.py"), out], stderr=subprocess.DEVNULL)
+    assert open(out, "rb").read() == open(os.path.join(root, "knoxdb_amd", "csrc", "knox_unicode_tables.h"), "rb").read()
+
+
 def test_hand_worked_unicode_cases():
     for pat, val, want in HAND:
         v = val if isinstance(val, bytes) else val.encode()
