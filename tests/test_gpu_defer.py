@@ -110,3 +110,51 @@ def test_a_scan_with_several_flush_phases_equals_the_oracle():
         assert int(res.count) == int(cnt) == int(res.pack_counts.sum())
         sel = (x >= lo) & (x <= hi)
         assert int(res.states[0].isum) == int(x[sel].sum(dtype=np.int64).view(np.uint64))
+
+
+def test_random_sizes_and_trees_match_the_tile_by_tile_form():
+    """60 random scans (every numeric type, 1 .. 2^25 rows incl. ragged ones, one to three leaves, with and without aggregates and
+    per-pack counts): the product context against a KNOX_DEFER=0 context on the same columns, bit for bit"""
+    import random
+    rng = random.Random(20261004)
+    types = [(BlockType.Int64, -(1 << 40), 1 << 41), (BlockType.Uint64, 0, 1 << 41), (BlockType.Int32, -(1 << 30), 1 << 31), (BlockType.Uint32, 0, 1 << 31),
+             (BlockType.Int16, -(1 << 15), 1 << 16), (BlockType.Uint16, 0, 1 << 16), (BlockType.Int8, -128, 256), (BlockType.Uint8, 0, 256),
+             (BlockType.Float64, 0, 0), (BlockType.Float32, 0, 0)]
+    ref_ctx, ctx = _ctx("0"), _ctx(None)
+    try:
+        for case in range(60):
+            dtype, lo, span = rng.choice(types)
+            is_f = dtype in (BlockType.Float64, BlockType.Float32)
+            n = rng.choice([rng.randrange(1, 5000), rng.randrange(5000, 1 << 20), rng.randrange(1 << 20, 1 << 25), 1 << rng.randrange(16, 26)])
+            pack = rng.choice([0, 4096, 1 << 16, 1 << 20])
+            if pack and n % pack and rng.random() < 0.5:
+                n = max(pack, n - n % pack)
+            n_leaves = rng.choice([1, 1, 1, 2, 3])
+            cols = [ref_ctx.generate(dtype, 2 if is_f else 0, 100 + case * 4 + k, n, lo=lo, span=span, pack_rows=pack) for k in range(n_leaves)]
+
+            def leaf(k):
+                if is_f:
+                    return Leaf(k, rng.choice([FilterMode.Lt, FilterMode.Ge]), rng.random())
+                a = lo + rng.randrange(span)
+                b = lo + rng.randrange(span)
+                return Leaf(k, FilterMode.Range, min(a, b), max(a, b)) if rng.random() < 0.7 else Leaf(k, rng.choice([FilterMode.Lt, FilterMode.Gt, FilterMode.NotEqual]), a)
+            leaves = [leaf(k) for k in range(n_leaves)]
+            tree = (And if rng.random() < 0.6 else Or)(*leaves)
+            aggs = rng.choice([[], [(R.Sum, 0)], [(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0)], [(R.Count, 0)], [(R.First, 0), (R.Last, 0)]])
+            want_packs = bool(pack) and n % pack == 0 and rng.random() < 0.7
+            got = []
+            for c in (ref_ctx, ctx):
+                cs = cols if c is ref_ctx else [c.wrap(dtype, x.device_ptr, n, pack) for x in cols]
+                bits = c.bits(n)
+                res = c.scan(tree, cs, aggs=aggs, bits_out=bits, pack_counts=want_packs)
+                got.append((bits.bytes().tobytes(), int(res.count), res.pack_counts.tobytes() if want_packs else None, [bytes(s) for s in res.states]))
+                bits.free()
+                if c is not ref_ctx:
+                    for x in cs:
+                        x.free()
+            assert got[0] == got[1], (case, dtype, n, pack, n_leaves, aggs)
+            for x in cols:
+                x.free()
+    finally:
+        ref_ctx.close()
+        ctx.close()
