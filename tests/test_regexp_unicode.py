@@ -51,6 +51,11 @@ HAND = [
     (r"^\p{Greek}$", "\u00b5", False), (r"^\p{Greek}$", "\u2126", True),   # OHM SIGN is Greek by script
     (r"(?i:é)x", "ÉX", False), (r"(?i:é)x", "Éx", True), (r"(?i)\x{e9}", "É", True),
     (r"(?i)\QÉ.\E", "é.", True), (r"(?i)[[:upper:]]", "ſ", True), (r"(?i)[[:upper:]]", "é", False),
+    # classes inside negated brackets, repeats, alternations, long script names
+    (r"(?i)^[^\p{Lu}]$", "a", False), (r"(?i)^[^\p{Lu}]$", "1", True), (r"^[^\P{L}]+$", "abcé", True), (r"^[^\P{L}]+$", "ab1", False),
+    (r"^\p{Lu}{2,3}$", "ÉÀ", True), (r"^(\p{Ll}|\p{Nd})+$", "a1é2", True), (r"^\P{Any}$", "a", False), (r"^[\p{Any}]$", "\n", True),
+    (r"(?i)^[k-l]$", "\u212a", True), (r"(?i)^[^k-l]$", "\u212a", False), (r"^\p{Braille}$", "\u283f", True),
+    (r"^\p{Egyptian_Hieroglyphs}$", "\U00013000", True), (r"^\p{Hangul}+$", "한글", True), (r"^\p{Thai}+$", "ไทย", True),
 ]
 
 REFUSED = [r"\p{Nope}", r"\p{", r"\p", r"\pq{", r"\p{Latn}", r"\p{}", r"[\p{Nope}]", r"\p{^}"]
