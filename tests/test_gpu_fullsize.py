@@ -310,3 +310,32 @@ def test_cfg3_semantics_dataset_at_scale(ctx):
             assert np.isposinf(xa[sel]).any() == np.isposinf(gsum) and gsum == lit_sum
     for o in (A, B, bits):
         o.free()
+
+
+def test_a_column_of_more_than_2_32_rows(ctx):
+    """uint8 column of 2^32 + 2^20 + 77 rows (4.3 GB): row and bitset offsets beyond 32 bits.  Properties over the whole column
+    (count == popcount == sum of pack counts, selectivity), and the rows around and beyond 2^32 against the oracle on rows
+    regenerated from the generator's spec (first_row offsets)"""
+    n = (1 << 32) + (1 << 20) + 77
+    col = ctx.generate(BlockType.Uint8, 0, 9, n, lo=0, span=256, pack_rows=PACK)
+    bits = ctx.bits(n)
+    res = ctx.scan(And(Leaf(0, FilterMode.Range, 64, 127)), [col], aggs=[(R.Sum, 0), (R.Count, 0)], bits_out=bits)
+    assert res.count == bits.count()
+    assert abs(res.count / n - 0.25) < 1e-4
+    got = bits.bytes()
+    assert got.size == (n + 7) // 8
+    assert (int(got[-1]) >> (n % 8)) == 0   # nothing set past row n in the last byte
+    for first, cnt in (((1 << 32) - (1 << 20), 1 << 21), ((1 << 32) + (1 << 20) - 4096, 4096 + 77), (0, 1 << 20)):
+        x = O.generate(O.U8, 0, 9, first, cnt, lo=0, span=256)
+        want, c = O.cmp(O.U8, O.RG, x, 64, 127)
+        assert first % 8 == 0
+        seg = got[first // 8:first // 8 + (cnt + 7) // 8]
+        assert seg.tobytes() == want.tobytes(), first
+    # per-pack counts need whole packs: the first 2^32 rows as their own scan
+    col2 = ctx.wrap(BlockType.Uint8, col.device_ptr, 1 << 32, PACK)
+    bits2 = ctx.bits(1 << 32)
+    res2 = ctx.scan(And(Leaf(0, FilterMode.Range, 64, 127)), [col2], aggs=[(R.Sum, 0)], bits_out=bits2, pack_counts=True)
+    assert int(res2.pack_counts.sum()) == res2.count == bits2.count() and res2.pack_counts.size == 4096
+    assert bits2.bytes().tobytes() == got[:(1 << 32) // 8].tobytes()
+    for o in (col2, bits2, bits, col):
+        o.free()
