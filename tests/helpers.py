@@ -69,3 +69,29 @@ def rand_col(bt, n, rng):
         ext = np.array([info.min, info.max, info.min + 1, info.max - 1, 0, 5], dtype=npdt)
         x[pos] = ext[rng.integers(0, ext.size, size=k)]
     return x
+
+
+# ---- the reference's StringPool matcher vectors (tests/golden/bytes_cases.json <- pkg/stringx/match_test.go) ----
+def bytes_golden_cases():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bytes_cases.json")))["cases"]
+
+
+def bytes_golden_pool(case, first=0, last=None, dedup=False):
+    """rows [first, last) of a golden case as one StringPool (ptr, buf): every row the 8-byte big-endian string
+    Uint64Bytes(v) (match_test.go:137-141), appended back to back as StringPool.Append does (pool.go:205-225);
+    dedup=True lets equal rows share the first occurrence's bytes (a layout Range / sub-pools produce)"""
+    import numpy as np
+    rows = case["rows_u64_be"][first:last]
+    buf, ptr, seen = bytearray(), [], {}
+    for v in rows:
+        s = int(v).to_bytes(8, "big")
+        if dedup and s in seen:
+            ptr.append(seen[s])
+            continue
+        p = (len(buf) << 32) | len(s)
+        seen[s] = p
+        ptr.append(p)
+        buf += s
+    return np.array(ptr, dtype=np.uint64), np.frombuffer(bytes(buf) + b"\x00" * 3, dtype=np.uint8)

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import helpers
 from oracle import oracle as O
 
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -225,3 +226,25 @@ def test_bytes_ordered_modes_vs_python_bytes_order():
             wm = want & mask
             wm[-1] &= 0xFF >> (8 - n % 8)
             assert (gm == wm).all()
+
+
+BYTES = helpers.bytes_golden_cases()
+
+
+@pytest.mark.parametrize("op", ["eq", "ne", "lt", "le", "gt", "ge", "bw"])
+def test_bytes_golden(op):
+    """pkg/stringx/match_test.go:25-33 (TestCompare) through the oracle's StringPool matchers: per case the count
+    (`set.Count()`), the exact result bytes and 32 untouched poison bytes behind them (match_test.go:73-76), for the
+    pool as Append lays it out and for a pool whose equal rows share their bytes"""
+    cases = [c for c in BYTES if c["op"] == op]
+    assert len(cases) == 15 and sorted(c["n"] for c in cases) == [0, 7, 15, 23, 31, 31, 32, 32, 32, 63, 64, 64, 64, 127, 128]
+    for c in cases:
+        for dedup in (False, True):
+            ptr, buf = helpers.bytes_golden_pool(c, dedup=dedup)
+            l = O.bitfield_len(c["n"])
+            bits = np.concatenate([np.zeros(l, np.uint8), np.full(32, 0xFA, np.uint8)])     # MakeBitsAndMaskPoison
+            got, cnt = O.bytes_match(O.OPNAME[op], ptr, buf, bytes.fromhex(c["match"]), bits=bits, val2=bytes.fromhex(c["match2"]))
+            tag = "%s/%s dedup=%s" % (op, c["name"], dedup)
+            assert cnt == c["count"], tag
+            assert got[:l].tobytes().hex() == c["result"], tag
+            assert (got[l:] == 0xFA).all(), tag
