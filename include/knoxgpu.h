@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KNOX_ABI_VERSION 6
+#define KNOX_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------------------- */
 enum knox_err {
@@ -161,6 +161,11 @@ int knox_prof_enable(knox_ctx *ctx, int on);
 int knox_prof_read(knox_ctx *ctx, double *total_ms, int *launches);
 /* Same, but returns each launch's duration (up to cap entries, in launch order).             */
 int knox_prof_read_each(knox_ctx *ctx, float *ms, int cap, int *launches);
+/* Scan-kernel instantiations launched so far (process-wide) whose resident workgroups per CU, as the HIP runtime
+ * reports them, are BELOW what the launch shape assumes (knox_kernels.h scan_shape: the deferred bitset bursts park LDS
+ * sized for exactly that many).  0 on gfx950 with the shipped build; anything else means a changed kernel, table or part
+ * and a measured loss (results stay correct).                                                                      */
+int knox_scan_occupancy_mismatches(void);
 
 /* ---- finest boundary: the cmp func vars --------------------------------------------- *
  * Replaces `func(src []T, val T, bits []byte) int64` / `func(src []T, a, b T, bits []byte)

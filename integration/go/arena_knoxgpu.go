@@ -30,16 +30,32 @@ const (
 	pinnedSlab     = 64 << 20
 )
 
+type pinnedSlabRange struct {
+	lo, hi uintptr // [lo, hi) of one page-locked slab
+}
+
 type pinnedAllocator[T any] struct {
 	inner *allocator[T]
 	gpu   *knoxgpu.Ctx
 	mu    sync.Mutex
 	free  [maxAllocClass - pinnedMinClass + 1][][]T
-	pin   map[unsafe.Pointer]struct{} // first element of every slice handed out from page-locked memory
+	pin   map[unsafe.Pointer]int // first element of every vector cut from page-locked memory -> its size class
+	slabs []pinnedSlabRange      // every slab ever taken (never returned): tells C memory from Go memory in Free
 }
 
 func newPinnedAllocator[T any](gpu *knoxgpu.Ctx) *pinnedAllocator[T] {
-	return &pinnedAllocator[T]{inner: newAllocator[T](), gpu: gpu, pin: make(map[unsafe.Pointer]struct{})}
+	return &pinnedAllocator[T]{inner: newAllocator[T](), gpu: gpu, pin: make(map[unsafe.Pointer]int)}
+}
+
+// inSlab reports whether p points into page-locked memory of this allocator (a.mu held).
+func (a *pinnedAllocator[T]) inSlab(p unsafe.Pointer) bool {
+	u := uintptr(p)
+	for _, r := range a.slabs {
+		if u >= r.lo && u < r.hi {
+			return true
+		}
+	}
+	return false
 }
 
 func classOf(sz int) int {
@@ -67,9 +83,10 @@ func (a *pinnedAllocator[T]) Alloc(sz int) any {
 		if err != nil {
 			return a.inner.Alloc(sz)
 		}
+		a.slabs = append(a.slabs, pinnedSlabRange{uintptr(p), uintptr(p) + uintptr(n*each)})
 		for i := 0; i < n; i++ {
 			v := unsafe.Slice((*T)(unsafe.Add(p, i*each)), 1<<class)[:0]
-			a.pin[unsafe.Pointer(unsafe.SliceData(v))] = struct{}{}
+			a.pin[unsafe.Pointer(unsafe.SliceData(v))] = class
 			*fl = append(*fl, v)
 		}
 	}
@@ -78,20 +95,27 @@ func (a *pinnedAllocator[T]) Alloc(sz int) any {
 	return v
 }
 
+// Free recycles exactly what Alloc handed out: a vector that still starts at its first element AND still has its full
+// class capacity (cap == 1<<class, the stock allocator's rule, allocator.go:57-64: "don't recycle out of bounds or
+// non-power of 2 slices").  A page-locked vector that comes back resliced -- a reduced cap (3-index slice) or a start
+// past element 0 -- is DROPPED, never filed under another class and never handed to the embedded allocator: C memory
+// must not enter a sync.Pool (the collector would treat its backing array as Go memory when the pool is cleared).
+// The dropped vector's bytes stay in their slab, lost to this allocator; that is the price of a caller's reslice.
 func (a *pinnedAllocator[T]) Free(val any, sz int) {
 	v, ok := val.([]T)
 	if !ok || cap(v) == 0 {
 		a.inner.Free(val, sz)
 		return
 	}
+	p := unsafe.Pointer(unsafe.SliceData(v))
 	a.mu.Lock()
-	_, mine := a.pin[unsafe.Pointer(unsafe.SliceData(v[:1]))]
-	if mine {
-		class := classOf(cap(v))
+	class, mine := a.pin[p]
+	pinned := mine || a.inSlab(p)
+	if mine && cap(v) == 1<<class && class >= pinnedMinClass && class <= maxAllocClass {
 		a.free[class-pinnedMinClass] = append(a.free[class-pinnedMinClass], v[:0])
 	}
 	a.mu.Unlock()
-	if !mine {
+	if !pinned {
 		a.inner.Free(val, sz)
 	}
 }

@@ -17,6 +17,11 @@
 //           metadata match"), every other pack is handed to the unchanged tail of the reference's loop (exclude mask,
 //           snapshot isolation, loadPack(resFields), Indexes -> WithSelection) with its slice of the run's bitset.
 //
+// Fallback: a block the device path does not take (errGpuBlock: a type or container outside appendBlock's switch) does
+// not fail the query -- the packs already loaded are matched by filter.Match as they are served (GPU_FALLBACK_KEY counts
+// them) and the reader continues on nextQueryMatch.  Any other error releases every package the run holds, after the copy
+// stream is done with their blocks.
+//
 // Reader changes this file needs (both mechanical, in reader.go):
 //   1. the tail of nextQueryMatch's loop body -- from `if r.bits.None()` (reader.go:337) to `return r.pack, nil`
 //      (reader.go:443) -- becomes the method  finishMatch(ctx, k, v, n) (*pack.Package, error)  (nil package = no match
@@ -56,6 +61,7 @@ type gpuRunPack struct {
 	n        int
 	pkg      *pack.Package
 	count    int64
+	cpu      bool // fallback: this pack is matched by the reference's filter.Match when it is served
 }
 
 // GpuRun holds one run of consecutive candidate packs on the device and serves the reference's per-pack loop from it.
@@ -81,6 +87,7 @@ type GpuRun struct {
 	pending *gpuRunPack // a pack that was loaded but belongs to the next run
 	done    bool
 	reserved bool
+	fallback bool // a block the device path does not take was met: the loaded packs are served by the CPU matcher, then the reader drops the run
 
 	// fused reducer states of the runs seen so far (rank order = row order); valid while fusable stays true
 	States  [][]knoxgpu.State
@@ -265,9 +272,53 @@ func (g *GpuRun) reset() error {
 	return nil
 }
 
+// waitCols blocks until the copy stream is done with every block handed to AppendAsync: a page-locked block vector is
+// read by the DMA engine AFTER AppendAsync returns (arena_knoxgpu.go), so no package of the run may be released before.
+func (g *GpuRun) waitCols() {
+	for _, c := range g.cols {
+		if c != nil {
+			c.Wait()
+		}
+	}
+}
+
+// abort is the error exit of fill: nothing of the run is served, so every package the run holds -- the packs appended so
+// far, the one just loaded, a pending one -- goes back (Release), after the device is done reading them.
+func (g *GpuRun) abort(cur *gpuRunPack) {
+	g.waitCols()
+	for i := range g.packs {
+		if g.packs[i].pkg != nil {
+			g.packs[i].pkg.Release()
+		}
+	}
+	if cur != nil && cur.pkg != nil {
+		cur.pkg.Release()
+	}
+	if g.pending != nil && g.pending.pkg != nil {
+		g.pending.pkg.Release()
+	}
+	g.packs, g.next, g.pending = g.packs[:0], 0, nil
+}
+
+// toCpu is the exit for errGpuBlock (a block type or container the run reader does not take): the query does not fail,
+// the packs loaded so far and the one that did not fit the device path are served by the reference's own matcher
+// (filter.Match per pack, reader.go:334) and counted under GPU_FALLBACK_KEY; nextQueryMatchGpu then hands the rest of the
+// query to nextQueryMatch.  The fused reducer states no longer cover every row, so the consumer's own fold counts.
+func (g *GpuRun) toCpu(r *Reader, cur *gpuRunPack) {
+	g.waitCols()
+	g.packs = append(g.packs, *cur)
+	for i := range g.packs {
+		g.packs[i].cpu = true
+	}
+	g.fallback, g.fusable = true, false
+	r.query.Stats.Count(GPU_FALLBACK_KEY, len(g.packs))
+	r.query.Stats.Count(PACKS_SCHEDULED_KEY, len(g.packs))
+}
+
 // fill loads the next run and scans it.  false: the stats iterator is exhausted and nothing is left to serve.
 func (g *GpuRun) fill(ctx context.Context, r *Reader) (bool, error) {
 	if err := g.reset(); err != nil {
+		g.abort(nil)
 		return false, err
 	}
 	t0 := time.Now()
@@ -288,6 +339,9 @@ func (g *GpuRun) fill(ctx context.Context, r *Reader) (bool, error) {
 			k, v, n := r.it.PackInfo()
 			r.pack = nil // loadPack prepares a fresh package (reader.go:487-493): the run keeps every one it loads
 			if err := r.loadPack(ctx, k, v, n, r.reqFields); err != nil {
+				cur := &gpuRunPack{pkg: r.pack}
+				r.pack = nil
+				g.abort(cur)
 				return false, err
 			}
 			pk = &gpuRunPack{key: k, ver: v, n: n, pkg: r.pack}
@@ -298,6 +352,12 @@ func (g *GpuRun) fill(ctx context.Context, r *Reader) (bool, error) {
 		}
 		for i, f := range g.fields {
 			if err := g.appendBlock(i, pk.pkg.Block(f)); err != nil {
+				r.pack = nil
+				if errors.Is(err, errGpuBlock) {
+					g.toCpu(r, pk)
+					return true, nil
+				}
+				g.abort(pk)
 				return false, err
 			}
 		}
@@ -308,7 +368,11 @@ func (g *GpuRun) fill(ctx context.Context, r *Reader) (bool, error) {
 		return false, nil
 	}
 	r.query.Stats.Count(GPU_INGEST_USEC_KEY, int(time.Since(t0).Microseconds()))
-	return true, g.scan(r)
+	if err := g.scan(r); err != nil {
+		g.abort(nil)
+		return false, err
+	}
+	return true, nil
 }
 
 func (g *GpuRun) scan(r *Reader) error {
@@ -384,6 +448,13 @@ func (g *GpuRun) scan(r *Reader) error {
 func (r *Reader) nextQueryMatchGpu(ctx context.Context) (*pack.Package, error) {
 	g := r.gpu
 	for {
+		if g.next == len(g.packs) && g.fallback {
+			// every pack the run had loaded is served: the rest of the query is the reference's own loop (same iterator)
+			g.packs, g.next = g.packs[:0], 0
+			g.Close()
+			r.gpu = nil
+			return r.nextQueryMatch(ctx)
+		}
 		if g.next == len(g.packs) {
 			more, err := g.fill(ctx, r)
 			if err != nil {
@@ -399,14 +470,26 @@ func (r *Reader) nextQueryMatchGpu(ctx context.Context) (*pack.Package, error) {
 			first += g.packs[i].n
 		}
 		g.next++
-		if pk.count == 0 {
-			continue
+		if pk.cpu {
+			// fallback pack: the reference's matcher, without the zone-map shortcut (the stats iterator has moved on;
+			// filter.Match takes a nil StatsReader, match_core.go:66) -- same bits, a little more work
+			r.pack = pk.pkg
+			filter.Match(r.query.Filters, r.pack, nil, r.bits.Resize(pk.n).Zero())
+			if r.bits.None() { // false positive metadata match (reader.go:337-341)
+				r.pack.Release()
+				r.pack, pk.pkg = nil, nil
+				continue
+			}
+		} else {
+			if pk.count == 0 {
+				continue
+			}
+			// this pack's slice of the run's bitset: packs start at multiples of packRows rows = whole bytes
+			r.pack = pk.pkg
+			r.bits.Resize(pk.n).Zero()
+			copy(r.bits.Bytes(), g.host[first/8:first/8+(pk.n+7)/8])
+			r.bits.ResetCount(int(pk.count))
 		}
-		// this pack's slice of the run's bitset: packs start at multiples of packRows rows = whole bytes
-		r.pack = pk.pkg
-		r.bits.Resize(pk.n).Zero()
-		copy(r.bits.Bytes(), g.host[first/8:first/8+(pk.n+7)/8])
-		r.bits.ResetCount(int(pk.count))
 		// the unchanged tail of the reference's loop: mask, snapshot isolation, remaining columns, selection vector
 		pkg, err := r.finishMatch(ctx, pk.key, pk.ver, pk.n)
 		if err != nil {
@@ -432,6 +515,7 @@ func (g *GpuRun) Value(i int) (uint64, bool) {
 func (g *GpuRun) Fused() bool { return g.fusable && len(g.aggs) > 0 }
 
 func (g *GpuRun) Close() {
+	g.waitCols() // queued DMAs may still read page-locked blocks of the packs released below
 	for _, c := range g.cols {
 		if c != nil {
 			c.Free()
@@ -452,4 +536,5 @@ func (g *GpuRun) Close() {
 		g.pending.pkg.Release()
 	}
 	g.cols, g.encCols, g.bits, g.packs, g.pending = nil, nil, nil, nil, nil
+	g.next = 0
 }

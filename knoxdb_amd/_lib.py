@@ -78,6 +78,7 @@ SIGNATURES = {
     "knox_prof_enable": (_i, [_vp, _i]),
     "knox_prof_read": (_i, [_vp, C.POINTER(C.c_double), _pi]),
     "knox_prof_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
+    "knox_scan_occupancy_mismatches": (_i, []),
     "knox_cmp": (_i64, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "knox_col_upload": (_i, [_vp, _i, _vp, _sz, _sz, _pp]),
     "knox_col_create": (_i, [_vp, _i, _sz, _sz, _pp]),

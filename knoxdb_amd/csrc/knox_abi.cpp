@@ -14,6 +14,7 @@
 // library / context
 // ------------------------------------------------------------------------------------------------
 KNOX_API int knox_abi_version(void) { return KNOX_ABI_VERSION; }
+KNOX_API int knox_scan_occupancy_mismatches(void) { return g_scan_occupancy_mismatches.load(); }
 
 KNOX_API const char *knox_strerror(int err) {
     switch (err) {
@@ -411,9 +412,12 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
         return 0.0;
     }
     constexpr int kLaunches = 20;  // alternating read-only / scan; the first 4 of each are the clock ramp
-    if (!ctx->probe_ev[0])
-        for (int i = 0; i <= kLaunches; i++)
-            if (hipEventCreate(&ctx->probe_ev[i]) != hipSuccess) return 0.0;
+    // every event on demand: probe_multi may have run first on this context and made only the first few
+    for (int i = 0; i <= kLaunches; i++)
+        if (!ctx->probe_ev[i] && hipEventCreate(&ctx->probe_ev[i]) != hipSuccess) {
+            ctx->probe_ev[i] = nullptr;
+            return 0.0;
+        }
     ScanArgs a;
     memset(&a, 0, sizeof a);
     a.leaf[0].col = p;
@@ -1620,13 +1624,11 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
     //  best at 2 like the wider ones -- 6.69 vs 6.32 TB/s at 3 --, 1-byte ones at 3 -- 6.0 vs 5.5-5.8 TB/s at 8)
     //  aggregate-heavy single-leaf scans, same sweep: 2 workgroups / CU for 8-, 4- and 1-byte columns (3 is the worst choice
     //  for int32: 6.00 against 6.33-6.51 TB/s at 2 and 4), 3 for 2-byte ones, 8 for float32 sums)
-    const bool plain = plain_scan;  // filter or filter + wrapping sum
-    const bool f32sum = width == 4 && agg_col && (agg & A_FSUM) != 0 && a.agg_flavor == FL_FLOAT;
-    int per_cu;
-    if (n_leaves > 1) per_cu = (n_leaves == 2 && !plain) ? 2 : 3;  // the pipelined two-leaf aggregate kernels hold 2 workgroups per CU (177 VGPRs)
-    else if (plain) per_cu = width == 1 ? 3 : 2;
-    else if (f32sum) per_cu = 8;
-    else per_cu = width == 2 ? 3 : 2;
+    //  The table itself is scan_shape (knox_kernels.h), shared with the kernel, whose parked LDS words assume exactly this many
+    //  workgroups per CU.
+    const bool heavy = !plain_scan;  // plain = filter or filter + wrapping sum
+    const int per_cu = scan_shape(width, n_leaves, heavy, a.agg_flavor == FL_FLOAT && agg_col != nullptr,
+                                  agg_col != nullptr && (agg & A_FSUM) != 0).per_cu;
     const int want = ctx->blocks_per_cu > 0 ? grid : ctx->n_cus * per_cu;
     const int g = (int)std::min<uint64_t>(a.n_tiles, (uint64_t)std::min(grid, want));
     // per-pack counts for free: when packs are whole numbers of tiles, nothing is pruned and nothing is

@@ -199,6 +199,8 @@ hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32
     KNOX_LAUNCH(pack_counts_kernel, (int)((n_packs + kBlock / 64 - 1) / (kBlock / 64)), tile_counts, grid, rounds, tiles_per_pack, n_packs, counts);
 }
 
+std::atomic<int> g_scan_occupancy_mismatches{0};
+
 // the scan kernel's instantiations live in knox_scan.hip, one object per width
 template <int W> hipError_t scan_nl(hipStream_t s, int nl, unsigned agg, bool sep, int grid, const ScanArgs &a);
 

@@ -110,12 +110,33 @@ KNOX_API int knox_comm_allgather_states(knox_ctx *ctx, const knox_agg_state *min
 // The exchange has nothing to wait for on the device (its input is the host's copy of a collected scan), so it runs on a
 // stream of its own behind page-locked slots: _start enqueues {H2D, ncclAllReduce, D2H, event} and returns, _finish
 // reads the oldest one -- a host keeps the collective of step i in flight behind the scan of step i + 1.
+static void comm_ring_drop(knox_ctx *ctx) {
+    for (hipEvent_t &e : ctx->comm_ev)
+        if (e) { hipEventDestroy(e); e = nullptr; }
+    if (ctx->comm_h) hipHostFree(ctx->comm_h);
+    if (ctx->comm_d) hipFree(ctx->comm_d);
+    if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_h = nullptr;
+    ctx->comm_d = nullptr;
+    ctx->comm_stream = nullptr;
+    ctx->comm_head = ctx->comm_tail = 0;
+}
+
+// All or nothing: `comm_stream` doubles as the "ring is ready" flag, so a failure half way (page-locked slots, device
+// slots, an event) tears the partial state down again and the next call starts over instead of writing through a null
+// slot pointer.
 static int comm_ring_init(knox_ctx *ctx) {
-    if (ctx->comm_stream) return KNOX_OK;
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->comm_h, sizeof(int64_t) * 4 * knox_ctx::kCommRing, hipHostMallocDefault));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->comm_d, sizeof(int64_t) * 4 * knox_ctx::kCommRing));
-    for (int i = 0; i < knox_ctx::kCommRing; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->comm_ev[i], hipEventDisableTiming));
+    if (ctx->comm_stream && ctx->comm_h && ctx->comm_d && ctx->comm_ev[knox_ctx::kCommRing - 1]) return KNOX_OK;
+    comm_ring_drop(ctx);
+    bool ok = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->comm_h, sizeof(int64_t) * 4 * knox_ctx::kCommRing, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->comm_d, sizeof(int64_t) * 4 * knox_ctx::kCommRing) == hipSuccess;
+    for (int i = 0; ok && i < knox_ctx::kCommRing; i++) ok = hipEventCreateWithFlags(&ctx->comm_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        ctx->last_hip = (int)hipGetLastError();
+        comm_ring_drop(ctx);
+        return KNOX_E_HIP;
+    }
     return KNOX_OK;
 }
 
@@ -176,17 +197,7 @@ KNOX_API int knox_comm_destroy(knox_ctx *ctx) {
         hipStreamSynchronize(ctx->comm_stream);
     }
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    if (ctx->comm_stream) {
-        for (hipEvent_t &e : ctx->comm_ev)
-            if (e) { hipEventDestroy(e); e = nullptr; }
-        if (ctx->comm_h) hipHostFree(ctx->comm_h);
-        if (ctx->comm_d) hipFree(ctx->comm_d);
-        hipStreamDestroy(ctx->comm_stream);
-        ctx->comm_h = nullptr;
-        ctx->comm_d = nullptr;
-        ctx->comm_stream = nullptr;
-        ctx->comm_head = ctx->comm_tail = 0;
-    }
+    comm_ring_drop(ctx);
     ctx->comm = nullptr;
     ctx->n_ranks = 1;
     ctx->rank = 0;

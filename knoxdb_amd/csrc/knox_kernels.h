@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace knox {
 
@@ -18,6 +19,41 @@ constexpr uint64_t kNoRow = ~0ull;
 enum : unsigned { A_ISUM = 1, A_FSUM = 2, A_MINMAX = 4, A_FIRSTLAST = 8, A_ALL = 15 };
 // value flavour of the aggregated column
 enum : unsigned { FL_SIGNED = 0, FL_UNSIGNED = 1, FL_FLOAT = 2 };
+
+// ONE table for the two sides that must agree on a scan instantiation's launch shape: the workgroups per CU run_fused
+// (knox_abi.cpp) launches and the LDS words per wave the kernel (knox_scan.hip) may park deferred bitset bursts in.  The
+// deferral's chip-wide phases only line up when the whole grid is resident, i.e. per_cu workgroups really fit a CU:
+// per_cu * kWavesPerBlock * park_words * 4 B must stay inside the CU's LDS (static_assert below, gfx950: 160 KiB), and
+// knox_scan_check_occupancy (knox_scan.hip) asks the runtime once per instantiation that it agrees.
+//   heavy  = aggregates beyond the wrapping integer sum (float sums, min / max, first / last)
+//   flt    = the aggregated column is float,  fsum = a float sum is among the aggregates
+// Measured choices (tools/sweep_narrow.py, profiles/r01_sweep_blocks_per_cu.txt, profiles/r03_narrow.txt):
+// streaming passes 2 per CU (1-byte columns 3); aggregate-heavy single leaves 2 (2-byte columns 3, float32 sums 8); two
+// aggregate-heavy leaves 2 (pipelined, 177 VGPRs); every other tree 3.
+struct ScanShape {
+    int per_cu;            // workgroups per CU the launch asks for
+    uint32_t park_words;   // bitset words per WAVE parked in LDS before one flush (0: bursts leave tile by tile)
+};
+constexpr uint32_t kLdsPerCu = 160u * 1024u;
+constexpr ScanShape scan_shape(int W, int NL, bool heavy, bool flt, bool fsum) {
+    int per_cu = 0;
+    if (NL >= 2) per_cu = (NL == 2 && heavy) ? 2 : 3;
+    else if (!heavy) per_cu = W == 1 ? 3 : 2;
+    else if (W == 4 && flt && fsum) per_cu = 8;
+    else per_cu = W == 2 ? 3 : 2;
+    // float32 aggregates keep their tile-by-tile bursts (the sums want 8 workgroups per CU)
+    const bool f32_heavy = NL == 1 && heavy && W == 4 && flt;
+    const uint32_t park = f32_heavy ? 0u : per_cu == 2 ? 3840u : per_cu == 3 ? 3072u : 0u;   // 15 KiB / 12 KiB per wave
+    return ScanShape{per_cu, park};
+}
+constexpr bool scan_shape_fits(int W, int NL, bool heavy, bool flt, bool fsum) {
+    return (uint32_t)scan_shape(W, NL, heavy, flt, fsum).per_cu * kWavesPerBlock * scan_shape(W, NL, heavy, flt, fsum).park_words * 4u <= kLdsPerCu;
+}
+// instantiations whose resident workgroups per CU (asked of the runtime at first launch) are below scan_shape's (knox_agg.hip)
+extern std::atomic<int> g_scan_occupancy_mismatches;
+static_assert(scan_shape_fits(8, 1, false, false, false) && scan_shape_fits(1, 1, false, false, false) && scan_shape_fits(2, 1, true, false, false) &&
+                  scan_shape_fits(8, 2, true, true, true) && scan_shape_fits(8, 2, false, false, false) && scan_shape_fits(4, 4, true, true, true),
+              "parked bitset words of per_cu workgroups exceed the CU's LDS");
 
 // One leaf in "key space": hit <=> U(key(x) - lo) <= diff, key = float order key or raw bits.
 struct LeafDev {

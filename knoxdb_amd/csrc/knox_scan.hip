@@ -2,6 +2,8 @@
 // the dominant kernel of the path.  Compiled once per column width (-DKNOX_SCAN_W=8|4|2|1 -> knox_scan_w8.o ...) so the
 // four families of instantiations build in parallel; launch_scan (knox_agg.hip) dispatches on the width.
 #include "knox_dev.h"
+#include <atomic>
+#include <cstdio>
 
 #ifndef KNOX_SCAN_W
 #error "compile with -DKNOX_SCAN_W=8|4|2|1"
@@ -32,13 +34,13 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     // aggregates lost 1.7-2.4 % with unaligned parked bursts and gains 1.0-1.3 % with the aligned ones (tools/ab_kernels.py against
     // a build without / with it); float32 sums want 8 workgroups per CU and keep their tile-by-tile bursts.
     constexpr bool kHeavy = (AGG & ~A_ISUM) != 0;
-    constexpr bool kDefer2 = (NL == 1 && !kHeavy && W >= 2) || (NL == 1 && kHeavy && (W == 8 || W == 1 || (W == 4 && FLV != FL_FLOAT))) || (NL == 2 && kHeavy);
-    // the instantiations that run at 3 workgroups per CU park 12 KiB per wave (96 tiles of an 8-byte column): 1-byte plain scans,
-    // 2-byte aggregate-heavy ones, trees of two plain or of three / four leaves
-    constexpr bool kDefer3 = (NL == 1 && !kHeavy && W == 1) || (NL == 1 && kHeavy && W == 2) || (NL == 2 && !kHeavy) || NL >= 3;
-    constexpr bool kDefer = kDefer2 || kDefer3;
+    // Which instantiations defer, and how many words a wave parks (15 KiB at 2 workgroups per CU: 120 tiles of an 8-byte column
+    // at 2 iterations; 12 KiB at 3: 1-byte plain scans, 2-byte aggregate-heavy ones, trees of two plain or of three / four
+    // leaves), comes from the SAME table run_fused takes its workgroups per CU from: scan_shape (knox_kernels.h).
+    constexpr ScanShape kShape = scan_shape(W, NL, kHeavy, FLV == FL_FLOAT, (AGG & A_FSUM) != 0);
+    constexpr uint32_t kParkWords = kShape.park_words;
+    constexpr bool kDefer = kParkWords != 0;
     constexpr uint32_t kTileWordsMax = kMaxIters * WAVE_ROWS / 32;
-    constexpr uint32_t kParkWords = kDefer2 ? 3840u : kDefer3 ? 3072u : 0u;
     constexpr uint32_t kStageWords = kTileWordsMax > kParkWords ? kTileWordsMax : kParkWords;
     __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock][kStageWords];
 
@@ -367,13 +369,42 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
     block_reduce_store(acc, a.partials + blockIdx.x);
 }
 
+// Once per instantiation that defers its bursts: does the runtime agree that scan_shape's workgroups per CU fit?  (Registers,
+// static LDS and launch bounds decide; a change to either side of the table, or a build for a part with less LDS, would
+// otherwise only show as a measured loss: the chip-wide phases of the deferral need the whole grid resident.)  A mismatch
+// is counted (knox_scan_occupancy_mismatches, asserted 0 by tests/test_gpu_defer.py) and reported once on stderr.
+template <int W, int NL, unsigned AGG, bool SEP, bool ANYF, unsigned FLV>
+static void scan_check_occupancy() {
+    constexpr ScanShape sh = scan_shape(W, NL, (AGG & ~A_ISUM) != 0, FLV == FL_FLOAT, (AGG & A_FSUM) != 0);
+    if constexpr (sh.park_words != 0) {
+        static const bool once = [] {
+            int fit = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, scan_kernel<W, NL, AGG, SEP, ANYF, FLV>, kBlock, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return true;
+            }
+            if (fit < sh.per_cu) {
+                g_scan_occupancy_mismatches.fetch_add(1);
+                fprintf(stderr, "knoxgpu: scan_kernel<%d,%d,%u,%d,%d,%u> fits %d workgroups per CU, its launch shape assumes %d\n", W, NL, AGG,
+                        (int)SEP, (int)ANYF, FLV, fit, sh.per_cu);
+            }
+            return true;
+        }();
+        (void)once;
+    }
+}
+
 template <int W, int NL, unsigned AGG, bool SEP, unsigned FLV>
 static hipError_t scan_anyf(hipStream_t s, int grid, const ScanArgs &a) {
     bool anyf = false;
     for (int l = 0; l < NL; l++) anyf = anyf || a.leaf[l].is_float != 0;
     if constexpr (W >= 4) {
-        if (anyf) KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true, FLV>), grid, a);
+        if (anyf) {
+            scan_check_occupancy<W, NL, AGG, SEP, true, FLV>();
+            KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, true, FLV>), grid, a);
+        }
     }
+    scan_check_occupancy<W, NL, AGG, SEP, false, FLV>();
     KNOX_LAUNCH((scan_kernel<W, NL, AGG, SEP, false, FLV>), grid, a);
 }
 

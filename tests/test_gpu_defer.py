@@ -158,3 +158,26 @@ def test_random_sizes_and_trees_match_the_tile_by_tile_form():
     finally:
         ref_ctx.close()
         ctx.close()
+
+
+def test_launch_shape_and_parked_lds_agree_with_the_runtime():
+    """knox_kernels.h scan_shape is the one table both the kernel's parked LDS words and run_fused's workgroups per CU come
+    from; every deferring instantiation asks the runtime at its first launch whether that many workgroups are resident per
+    CU.  Runs last in this file: the tests above have launched the plain, aggregate-heavy and multi-leaf forms of every
+    width.  (The single-leaf forms of all ten types with every aggregate: tests/test_gpu_scan.py, counted by the same
+    process-wide counter when the suite runs in one process, as the driver runs it.)"""
+    from knoxdb_amd import _lib
+    with K.Context(0) as c:
+        for dtype in (BlockType.Int64, BlockType.Int32, BlockType.Int16, BlockType.Int8, BlockType.Float64, BlockType.Float32):
+            is_f = dtype in (BlockType.Float64, BlockType.Float32)
+            n = 1 << 20
+            cols = [c.generate(dtype, 2 if is_f else 0, 7 + k, n, lo=0, span=100, pack_rows=1 << 16) for k in range(3)]
+            lf = (lambda k: Leaf(k, FilterMode.Lt, 0.5)) if is_f else (lambda k: Leaf(k, FilterMode.Lt, 50))
+            for nl in (1, 2, 3):
+                for aggs in ([], [(R.Sum, 0)], [(R.Sum, 0), (R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.First, 0)]):
+                    bits = c.bits(n)
+                    c.scan(And(*[lf(k) for k in range(nl)]), cols[:nl], aggs=aggs, bits_out=bits, pack_counts=True)
+                    bits.free()
+            for x in cols:
+                x.free()
+    assert _lib.lib().knox_scan_occupancy_mismatches() == 0
