@@ -524,7 +524,11 @@ int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mas
  * what the reference's reducer for that window saw.
  * states[k] is the window's mergeable state (count == 0: the reference created no reducer).
  * flags bit0: the caller guarantees the order, skip the verification pass.
- * flags bit1: also run the var/std second pass per window (states carry the m_* moments).    */
+ * flags bit1: also run the var/std second pass per window (states carry the m_* moments).
+ * flags bit4 (16): run the verification pass even when this column's order is already known.  (What the pass finds is
+ * kept with the column -- columns the library filled itself, until rows are appended or the column is reset; never for
+ * knox_col_wrap -- so a time column that is queried again and again is checked once: the pass reads 8 B per row, half of
+ * what an ordered window query reads.)                                                          */
 int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                         const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                         size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states);
@@ -549,7 +553,11 @@ int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const kn
  * and the join reducers KNOX_R_*_JOIN (reducer.go:432-731; join = the row's raw timestamp equals
  * the previous selected row's, pkg/series/series.go:200-203) included.  values_out holds
  * n_buckets values of the column's type, seen_out[k] = Value()'s ok (0: no reducer / no group).
- * Needs a non-decreasing time column (KNOX_E_UNSUPPORTED otherwise); flags bit0 as above.      */
+ * Needs a non-decreasing time column (KNOX_E_UNSUPPORTED otherwise); flags bit0 as above.
+ * The recurrence of a window is serial by definition; what varies is who fetches its rows: one lane per
+ * window when there are enough windows for every lane of the device, a whole wave per window below that
+ * (64 rows per coalesced fetch, handed to the SAME recurrence in row order -- identical results).  flags
+ * bit2 (4) forces the one-lane form, bit3 (8) the wave form (tests and A/B).                      */
 int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                                    const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                                    size_t n_buckets, int func, int flags, void *values_out, uint8_t *seen_out);

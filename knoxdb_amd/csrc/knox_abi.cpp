@@ -346,7 +346,7 @@ int upload(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
     while (off < bytes) {
         const size_t n = std::min(bytes - off, knox_ctx::kStageBytes);
         if (used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[slot]));
-        memcpy(ctx->stage[slot], (const char *)src + off, n);
+        CopyPool::get().copy(ctx->stage[slot], (const char *)src + off, n);
         HIPCHK(ctx, hipMemcpyAsync((char *)dst + off, ctx->stage[slot], n, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
         used[slot] = true;
@@ -369,7 +369,8 @@ int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
     int rc = stage_init(ctx);
     if (rc) return rc;
     // two ring slots: the DMA of chunk i+1 runs while chunk i is copied out to the caller's pageable memory
-    const size_t chunk = std::min<size_t>(knox_ctx::kStageBytes, (size_t)4 << 20);
+    // (4 MiB pieces for small results: the first copy-out starts early; 16 MiB ones once the copy pool shares them)
+    const size_t chunk = std::min<size_t>(knox_ctx::kStageBytes, bytes >= ((size_t)64 << 20) ? (size_t)16 << 20 : (size_t)4 << 20);
     size_t issued = 0, copied = 0;
     int slot = 0;
     size_t len[2] = {0, 0};
@@ -384,7 +385,7 @@ int download(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
         }
         const int done = len[slot] ? slot : slot ^ 1;  // the older of the slots in flight
         HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[done]));
-        memcpy((char *)dst + copied, ctx->stage[done], len[done]);
+        CopyPool::get().copy((char *)dst + copied, ctx->stage[done], len[done]);
         copied += len[done];
         len[done] = 0;
         slot = done;
@@ -595,7 +596,7 @@ int upload_async(knox_ctx *ctx, void *dst, const void *src, size_t bytes) {
         const int slot = ctx->cstage_slot;
         const size_t n = std::min(bytes - off, knox_ctx::kStageBytes);
         if (ctx->cstage_used[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->cstage_ev[slot]));  // the DMA that last read this slot
-        memcpy(ctx->cstage[slot], (const char *)src + off, n);
+        CopyPool::get().copy(ctx->cstage[slot], (const char *)src + off, n);
         HIPCHK(ctx, hipMemcpyAsync((char *)dst + off, ctx->cstage[slot], n, hipMemcpyHostToDevice, ctx->copy_stream));
         HIPCHK(ctx, hipEventRecord(ctx->cstage_ev[slot], ctx->copy_stream));
         ctx->cstage_used[slot] = true;
@@ -619,6 +620,7 @@ KNOX_API int knox_col_append_async(knox_ctx *ctx, knox_col *col, const void *hos
     if (!ctx || !col || col->ctx != ctx || col->dtype == KNOX_BYTES || !col->owned || col->rows_cap == 0 || (n_rows && !host)) return KNOX_E_INVALID;
     if (n_rows > col->rows_cap - col->n_rows) return KNOX_E_RANGE;
     if (n_rows == 0) return KNOX_OK;
+    col->sorted_state = -1;  // new rows: the order check runs again
     hipSetDevice(ctx->device);
     int rc = copy_stream_init(ctx);
     if (rc) return rc;
@@ -641,6 +643,7 @@ KNOX_API int knox_col_reset(knox_ctx *ctx, knox_col *col) {
     HIPCHK(ctx, hipEventRecord(ctx->fence_ev, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
     col->n_rows = 0;
+    col->sorted_state = -1;  // new content: what the order check found no longer holds
     return KNOX_OK;
 }
 
@@ -2115,7 +2118,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     }
 
     // ---- per-pack counts from the bitset
-    slot.has_pack_counts = false;
+    slot.has_pack_counts = want_pack_counts && n_packs == 0;  // an empty column has no packs: nothing to count, nothing to copy
     slot.n_packs = n_packs;
     if (want_pack_counts && n_packs && packs_done) {
         slot.has_pack_counts = true;

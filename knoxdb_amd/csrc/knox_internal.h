@@ -7,9 +7,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -25,6 +28,86 @@ using namespace knox;
 #define KNOX_API extern "C" __attribute__((visibility("default")))
 
 static_assert(sizeof(knox_agg_state) == sizeof(AggStateDev), "knox_agg_state layout");
+
+// ------------------------------------------------------------------------------------------------
+// Host copies between the caller's pageable memory and the page-locked staging ring, spread over a few threads: one core
+// moves 3-10 GB/s (less into memory it touches for the first time -- every 4 KiB page is a fault), the DMA engine 57 GB/s,
+// so a large result (2^20 window states = 151 MB) or a pageable upload is bound by this copy.  One process-wide pool,
+// started on first use; a copy below 1 MiB stays on the calling thread.  knox_copy_threads: KNOX_COPY_THREADS (default 8,
+// 1 = the calling thread only).
+// ------------------------------------------------------------------------------------------------
+class CopyPool {
+   public:
+    static CopyPool &get() {
+        static CopyPool pool;
+        return pool;
+    }
+    void copy(void *dst, const void *src, size_t bytes) {
+        if (bytes < ((size_t)1 << 20) || workers_.empty() || getpid() != pid_) {  // a forked child has no workers
+            memcpy(dst, src, bytes);
+            return;
+        }
+        std::lock_guard<std::mutex> one_at_a_time(call_mu_);
+        const size_t parts = workers_.size() + 1;
+        const size_t piece = ((bytes / parts) + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = (char *)dst, src_ = (const char *)src, bytes_ = bytes, piece_ = piece;
+            pending_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        run_piece(0);  // the caller takes the first piece
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+    }
+    int threads() const { return (int)workers_.size() + 1; }
+
+   private:
+    CopyPool() : pid_(getpid()) {
+        int n = 8;
+        if (const char *e = getenv("KNOX_COPY_THREADS")) n = atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)n > hw) n = (int)hw;
+        for (int i = 1; i < n; i++) workers_.emplace_back([this, i] { loop(i); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : workers_) t.join();
+    }
+    void run_piece(size_t i) {
+        const size_t off = i * piece_;
+        if (off < bytes_) memcpy(dst_ + off, src_ + off, std::min(piece_, bytes_ - off));
+    }
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            run_piece((size_t)id);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex call_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t bytes_ = 0, piece_ = 0;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    const pid_t pid_;
+};
 
 // ------------------------------------------------------------------------------------------------
 // handles
@@ -153,7 +236,18 @@ struct knox_col {
     // context's copy stream; every reader makes the scan stream wait for it (col_acquire) until the host has seen it complete
     mutable hipEvent_t ready_ev = nullptr;
     mutable bool ready_pending = false;
+    // time columns: what the order check of the window entry points found (-1 unknown, 0 out of order, 1 non-decreasing) for
+    // the first `sorted_rows` rows.  A property of the column's CONTENT: kept only for columns the library owns and wrote
+    // itself (never for knox_col_wrap), dropped by everything that writes into the column again (append, reset).
+    mutable int8_t sorted_state = -1;
+    mutable size_t sorted_rows = 0;
 };
+static inline int col_sorted_cached(const knox_col *c) { return (c->owned && c->sorted_state >= 0 && c->sorted_rows == c->n_rows) ? c->sorted_state : -1; }
+static inline void col_sorted_set(const knox_col *c, bool sorted) {
+    if (!c->owned) return;
+    c->sorted_state = sorted ? 1 : 0;
+    c->sorted_rows = c->n_rows;
+}
 
 // a kernel on ctx->stream is about to read `col`: order it behind the column's last asynchronous upload
 static inline int col_acquire(knox_ctx *ctx, const knox_col *col) {

@@ -342,7 +342,7 @@ struct RegexProg {
 };
 hipError_t launch_regexp_match(hipStream_t s, const RegexProg &pg, uint32_t image_bytes, const BytesView &v, uint8_t *bits, const uint8_t *mask);
 hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
-                                    const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen);
+                                    const uint64_t *start, uint32_t n_buckets, int wave_per_window, void *out_v, uint8_t *out_seen);
 hipError_t launch_reduce_sequential(hipStream_t s, int dtype, int func, const void *col, uint64_t n_rows,
                                     const uint8_t *mask, uint64_t *out3 /* value bits, seen, row */);
 

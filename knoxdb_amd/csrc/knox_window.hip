@@ -14,29 +14,45 @@ namespace knox {
 // partials of a window are merged in row order.  Out-of-order timestamps (which the reference
 // handles by inserting reducers, :123-141) are detected and refused: the caller keeps the host path.
 // ---------------------------------------------------------------------------------------------
+// One streaming pass over the time column, 8 B per row: four independent 16-byte loads per lane and loop iteration (the
+// first version had one, and a shuffle between it and the next: 92 % of its wave cycles were waits, 5.5 TB/s; round 4
+// profile profiles/r04_windows.txt).  A lane compares the two timestamps of each of its vectors with each other and the
+// second one with the first timestamp of the NEXT vector (the neighbour lane's; the wave's last lane reads it).
 __global__ void __launch_bounds__(kBlock) sorted_check_kernel(const int64_t *time, uint64_t n_rows, uint32_t *flag) {
+    constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     bool bad = false;
     const uint64_t npairs = n_rows >> 1;  // 16-byte vectors of two timestamps
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < ((npairs + 63) & ~63ull); v += (uint64_t)gridDim.x * blockDim.x) {
-        int64_t e0 = INT64_MIN, e1 = INT64_MIN;
-        const bool in = v < npairs;
-        if (in) {
-            const u32x4 r = ld16<true>((const u32x4 *)time + v);
-            e0 = (int64_t)(((uint64_t)r.y << 32) | r.x);
-            e1 = (int64_t)(((uint64_t)r.w << 32) | r.z);
-            bad = bad || e0 > e1;
+    const uint64_t per_iter = (uint64_t)gridDim.x * blockDim.x * U;
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) * U;  // this wave's first vector of the iteration
+    for (uint64_t base = wave_base; base < npairs; base += per_iter) {
+        int64_t e0[U], e1[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {   // vector v = base + u*64 + lane: consecutive lanes, consecutive vectors
+            const uint64_t v = base + (uint64_t)u * 64 + lane;
+            in[u] = v < npairs;
+            e0[u] = INT64_MIN, e1[u] = INT64_MIN;
+            if (in[u]) {
+                const u32x4 r = ld16<true>((const u32x4 *)time + v);
+                e0[u] = (int64_t)(((uint64_t)r.y << 32) | r.x);
+                e1[u] = (int64_t)(((uint64_t)r.w << 32) | r.z);
+            }
         }
-        int64_t nxt = (int64_t)__shfl_down((unsigned long long)e0, 1, 64);  // first timestamp of the next lane's pair
-        if (lane == 63 || v + 1 >= npairs) nxt = (2 * v + 2 < n_rows) ? time[2 * v + 2] : INT64_MAX;
-        if (in) bad = bad || e1 > nxt;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t v = base + (uint64_t)u * 64 + lane;
+            int64_t nxt = (int64_t)__shfl_down((unsigned long long)e0[u], 1, 64);  // first timestamp of the next lane's pair
+            if (lane == 63 || v + 1 >= npairs) nxt = (2 * v + 2 < n_rows) ? time[2 * v + 2] : INT64_MAX;
+            if (in[u]) bad = bad || e0[u] > e1[u] || e1[u] > nxt;
+        }
     }
     if (__any(bad) && lane == 0) atomicOr(flag, 1u);
 }
 
 hipError_t launch_sorted_check(hipStream_t s, const int64_t *time, uint64_t n_rows, uint32_t *flag) {
     if (n_rows < 2) return hipSuccess;
-    uint64_t g = ((n_rows >> 1) + kBlock - 1) / kBlock;
+    uint64_t g = ((n_rows >> 1) + kBlock * 4 - 1) / (kBlock * 4);
     if (g > 2048) g = 2048;
     if (g == 0) g = 1;
     KNOX_LAUNCH(sorted_check_kernel, (int)g, time, n_rows, flag);
@@ -116,22 +132,63 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_kernel(const ScanArgs a,
     }
 }
 
-// many small windows: one WAVE per work item -- no workgroup barrier and no LDS round per item (a window of a few hundred
-// rows costs a few loop iterations + one wave reduction); the rows are taken lane-strided, first / last ride in the Acc
+// many small windows: one WAVE per work item -- no workgroup barrier and no LDS round per item.  Round 4: the rows go
+// through the same vector path as the large items (agg_iter: 16-byte loads, the wave-uniform min / max shortcut, one
+// first / last update per iteration) instead of one exact per-row update per lane step (2.2 TB/s at 2^20 windows of 1024
+// rows, profiles/r04_windows.txt): the wave walks [rb & ~31, re) in steps of WAVE_ROWS rows -- a start on a multiple of
+// 32 rows keeps the 16-byte loads and the mask words lane aligned -- and rows outside [rb, re) are taken out of the
+// selection bits (a wave-uniform test skips that arithmetic for interior steps); lanes whose rows lie at or beyond `re`
+// do not load.
 template <int W, unsigned AGG, unsigned FLV>
 __global__ void __launch_bounds__(kBlock) bucket_reduce_wave_kernel(const ScanArgs a, const BucketItem *items, uint32_t n_items) {
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
+    constexpr uint32_t FULL = K == 32 ? 0xffffffffu : (1u << K) - 1u;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = gridDim.x * kWavesPerBlock;
-    const uint8_t *mask8 = (const uint8_t *)a.mask;
     for (uint32_t it = wave; it < n_items; it += n_waves) {
         const uint64_t rb = items[it].begin, re = items[it].end;
         Acc acc;
         acc.init();
-        for (uint64_t row = rb + lane; row < re; row += 64) {
-            const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
-            acc.count += hit;
-            acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+        WaveMM wm;
+        wm.init();
+        FirstLast fl;
+        fl.init();
+        uint32_t cnt32 = 0;
+        for (uint64_t row0 = rb & ~(uint64_t)31; row0 < re; row0 += WAVE_ROWS) {
+            u32x4 ra[kUnroll];
+            uint32_t q[kUnroll];
+            const bool edge = row0 < rb || row0 + WAVE_ROWS > re;  // wave uniform
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint64_t r = row0 + (uint64_t)u * RPL + (uint64_t)lane * K;  // this lane's K rows of load u
+                ra[u] = u32x4{0u, 0u, 0u, 0u};
+                q[u] = 0u;
+                if (r < re) {
+                    ra[u] = ld16<true>((const u32x4 *)a.agg_col + r / K);
+                    const uint32_t w = a.mask ? a.mask[r >> 5] : 0xffffffffu;
+                    q[u] = (w >> (K * (lane & (G - 1)))) & FULL;
+                }
+            }
+            if (edge) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+                    const uint64_t r = row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
+                    const uint64_t below = rb > r ? rb - r : 0;            // rows of this lane before the window
+                    const uint64_t left = re > r ? re - r : 0;             // rows of this lane before the window's end
+                    const uint32_t keep_hi = left >= (uint64_t)K ? FULL : (1u << (uint32_t)left) - 1u;
+                    const uint32_t drop_lo = below >= (uint64_t)K ? FULL : (1u << (uint32_t)below) - 1u;
+                    q[u] &= keep_hi & ~drop_lo;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) cnt32 += __builtin_popcount(q[u]);
+            agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
         }
+        acc.count += cnt32;
+        if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
         wave_reduce(acc);
         if (lane == 0) {
             AggPartial p;
@@ -417,11 +474,100 @@ __global__ void bucket_seq_kernel(int func, const int64_t *__restrict__ time, co
     out_seen[k] = ok ? 1 : 0;
 }
 
+// FEW windows (the 19 GB/s corner of round 3: `Mean` over 1024 windows keeps 1024 lanes = 16 waves of the whole chip
+// busy, each lane fetching its own cache line per row): one WAVE per window.  The recurrences are serial per window by
+// definition (Welford: mean += (x - mean) / n), so the wave does not split the ARITHMETIC -- every lane runs the same
+// recurrence on the same broadcast value, which costs nothing extra on a SIMD machine and keeps the results bit for bit
+// those of the one-lane kernel -- it splits the MEMORY side: 64 consecutive rows (value, selection bit, raw timestamp for
+// the join reducers) are fetched by the 64 lanes in one coalesced access, the next 64 are in flight while the current ones
+// are consumed, and the selected ones are handed to the recurrence in row order through v_readlane (the ballot of the
+// selection bits is walked with s_ff1: unselected rows cost nothing).
+template <typename T> __device__ __forceinline__ T readlane_any(T v, int j) {
+    if constexpr (sizeof(T) == 8) {
+        uint64_t u;
+        __builtin_memcpy(&u, &v, 8);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), j);
+        u = ((uint64_t)hi << 32) | lo;
+        T o;
+        __builtin_memcpy(&o, &u, 8);
+        return o;
+    } else {
+        uint32_t u = 0;
+        __builtin_memcpy(&u, &v, sizeof(T));
+        u = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
+        T o;
+        __builtin_memcpy(&o, &u, sizeof(T));
+        return o;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) bucket_seq_wave_kernel(int func, const int64_t *__restrict__ time, const T *__restrict__ src,
+                                                                 const uint8_t *__restrict__ bits, const uint64_t *__restrict__ start,
+                                                                 uint32_t n_buckets, T *__restrict__ out_v, uint8_t *__restrict__ out_seen) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);  // wave uniform
+    if (k >= n_buckets) return;
+    SeqJoinRed<T> r;
+    bool have_prev = false;
+    int64_t prev = 0;
+    const uint64_t b = start[k], e = start[k + 1];
+    const bool join = func >= 9;
+    // the chunk in flight: this lane's row of the NEXT 64
+    bool sel_n = false;
+    T x_n = 0;
+    int64_t t_n = 0;
+    auto fetch = [&](uint64_t base) {
+        const uint64_t i = base + (uint64_t)lane;
+        sel_n = i < e && (bits == nullptr || ((bits[i >> 3] >> (i & 7)) & 1));
+        x_n = 0;
+        t_n = 0;
+        if (sel_n) {
+            x_n = src[i];
+            if (join) t_n = time[i];
+        }
+    };
+    if (b < e) fetch(b);
+    for (uint64_t base = b; base < e; base += 64) {
+        const T x = x_n;
+        const int64_t t = t_n;
+        uint64_t m = __ballot(sel_n);
+        if (base + 64 < e) fetch(base + 64);
+        while (m) {  // wave uniform: every lane walks the same selected rows in row order
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const T xj = readlane_any<T>(x, j);
+            if (join) {
+                const int64_t tj = readlane_any<int64_t>(t, j);
+                r.push_join(func, xj, have_prev && tj == prev);
+                prev = tj;
+                have_prev = true;
+            } else
+                r.push(func, xj);
+        }
+    }
+    bool ok;
+    const T v = r.value(func, &ok);
+    if (lane == 0) {
+        out_v[k] = v;
+        out_seen[k] = ok ? 1 : 0;
+    }
+}
+
+// lanes per window: one (many windows: every lane of the chip has a window of its own) or a whole wave (few windows)
 hipError_t launch_bucket_sequential(hipStream_t s, int dtype, int func, const int64_t *time, const void *col, const uint8_t *mask,
-                                    const uint64_t *start, uint32_t n_buckets, void *out_v, uint8_t *out_seen) {
+                                    const uint64_t *start, uint32_t n_buckets, int wave_per_window, void *out_v, uint8_t *out_seen) {
     const int tpb = 64;
     const int grid = (int)((n_buckets + tpb - 1) / tpb);
-#define KNOX_BSEQ(T) hipLaunchKernelGGL((bucket_seq_kernel<T>), dim3(grid), dim3(tpb), 0, s, func, time, (const T *)col, mask, start, n_buckets, (T *)out_v, out_seen); break
+    const int wgrid = (int)((n_buckets + kWavesPerBlock - 1) / kWavesPerBlock);
+#define KNOX_BSEQ(T)                                                                                                                        \
+    if (wave_per_window)                                                                                                                    \
+        hipLaunchKernelGGL((bucket_seq_wave_kernel<T>), dim3(wgrid), dim3(kBlock), 0, s, func, time, (const T *)col, mask, start, n_buckets, \
+                           (T *)out_v, out_seen);                                                                                           \
+    else                                                                                                                                    \
+        hipLaunchKernelGGL((bucket_seq_kernel<T>), dim3(grid), dim3(tpb), 0, s, func, time, (const T *)col, mask, start, n_buckets,         \
+                           (T *)out_v, out_seen);                                                                                           \
+    break
     switch (dtype) {
     case 1: KNOX_BSEQ(int64_t);
     case 2: KNOX_BSEQ(int32_t);

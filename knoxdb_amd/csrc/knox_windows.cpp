@@ -141,9 +141,15 @@ static int reduce_buckets_dev(knox_ctx *ctx, const knox_col *time_col, const kno
     if (!rc) rc = ensure(ctx, ctx->idx_scratch, (n_buckets + 2) * 8 + 64);
     if (rc) return rc;
     // 1. order check (one streaming pass over the time column) unless the caller vouches for it
+    //    -- or the column was checked before: the answer is a property of its content and is kept with it (col_sorted_cached:
+    //    columns the library filled itself, until something writes into them again).  A time column is queried again and
+    //    again; the check is 8 B per row, half of what an ordered window query reads.  flags bit4 (16): check anyway.
     uint32_t *d_flag = (uint32_t *)((char *)ctx->misc.p + 32);
     uint32_t unsorted = 0;
-    if (!(flags & 1)) {
+    const int known = (flags & 16) ? -1 : col_sorted_cached(time_col);
+    const bool check = !(flags & 1) && known < 0;
+    if (known == 0 && !(flags & 1)) unsorted = 1;
+    if (check) {
         HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
         hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
@@ -153,7 +159,10 @@ static int reduce_buckets_dev(knox_ctx *ctx, const knox_col *time_col, const kno
     uint64_t *d_start = (uint64_t *)ctx->idx_scratch.p;
     hipError_t e = launch_bucket_bounds(ctx->stream, (const int64_t *)time_col->dev, n_rows, t_from, step, n_buckets, d_start);
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-    if (!(flags & 1)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (check) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        col_sorted_set(time_col, unsorted == 0);
+    }
     if (unsorted) return reduce_buckets_unordered(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, states_dev);
     // 3. reduce the windows' row ranges
     return reduce_windows(ctx, value_col->dev, value_col->dtype, mask ? (const uint32_t *)mask->dev : nullptr, n_rows, row_base, d_start, n_buckets,
@@ -230,7 +239,10 @@ KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_
     if (!rc) rc = ensure(ctx, ctx->idx_scratch, off_seen + n_buckets + 64);
     if (rc) return rc;
     uint32_t *d_flag = (uint32_t *)((char *)ctx->misc.p + 32);
-    if (!(flags & 1)) {
+    const int known = (flags & 16) ? -1 : col_sorted_cached(time_col);  // as in reduce_buckets_dev
+    if (known == 0 && !(flags & 1)) return KNOX_E_UNSUPPORTED;
+    const bool check = !(flags & 1) && known < 0;
+    if (check) {
         HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
         hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
@@ -239,15 +251,19 @@ KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_
     uint64_t *d_start = (uint64_t *)base;
     hipError_t e = launch_bucket_bounds(ctx->stream, (const int64_t *)time_col->dev, n_rows, t_from, step, n_buckets, d_start);
     // the window bounds never leave the device: the reducer lanes read them in place
+    // one lane per window when there are enough windows to give every lane of the chip one, a whole wave per window (coalesced
+    // fetches, the recurrence fed through v_readlane) below that; flags bit 2 / bit 3 force the one or the other (tests, A/B)
+    const bool wave_per_window = (flags & 8) != 0 || ((flags & 4) == 0 && n_buckets <= (size_t)ctx->n_cus * 256);
     if (e == hipSuccess)
         e = launch_bucket_sequential(ctx->stream, value_col->dtype, func, (const int64_t *)time_col->dev, value_col->dev,
-                                     mask ? (const uint8_t *)mask->dev : nullptr, d_start, (uint32_t)n_buckets, base + off_vals,
-                                     (uint8_t *)(base + off_seen));
+                                     mask ? (const uint8_t *)mask->dev : nullptr, d_start, (uint32_t)n_buckets, wave_per_window ? 1 : 0,
+                                     base + off_vals, (uint8_t *)(base + off_seen));
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     uint32_t unsorted = 0;
-    if (!(flags & 1)) {
+    if (check) {
         HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        col_sorted_set(time_col, unsorted == 0);
         if (unsorted) return KNOX_E_UNSUPPORTED;
     }
     rc = download(ctx, values_out, base + off_vals, n_buckets * (size_t)value_col->width);

@@ -622,12 +622,13 @@ class Context:
             check(self.L.knox_reduce_moments(self.h, col.h, mask.h if mask is not None else None, C.byref(st)), "knox_reduce_moments")
         return st
 
-    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False):
+    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False, out=None, recheck=False):
         """One mergeable state per time window [t_from + k*step, +step): NativeBucket semantics.
-        moments=True adds the var/std second pass per window."""
-        states = (AggState * n_buckets)()
+        moments=True adds the var/std second pass per window.  out: a (AggState * n_buckets) array to fill (a caller that
+        asks again and again keeps one; a fresh 144 B x n_buckets array is first-touch page faults on every call)."""
+        states = out if out is not None else (AggState * n_buckets)()
         check(self.L.knox_reduce_buckets(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
-                                         n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0), states), "knox_reduce_buckets")
+                                         n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0) | (16 if recheck else 0), states), "knox_reduce_buckets")
         return states   # ctypes array: indexable / iterable, no per-window Python objects until touched
 
     def reduce_buckets_view(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False):
@@ -639,12 +640,12 @@ class Context:
               "knox_reduce_buckets_view")
         return C.cast(p, C.POINTER(AggState * n_buckets)).contents
 
-    def reduce_buckets_values(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
+    def reduce_buckets_values(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False, recheck=False):
         """Reducer.Value() per window, finalised on the device -> (values[n_buckets] of the column's type, seen[n_buckets])
         as zero-copy views of the context's page-locked result buffer (valid until the next *_view / *_values call)."""
         pv, ps = C.c_void_p(), C.c_void_p()
         check(self.L.knox_reduce_buckets_values(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
-                                                n_buckets, int(func), 1 if assume_sorted else 0, C.byref(pv), C.byref(ps)),
+                                                n_buckets, int(func), (1 if assume_sorted else 0) | (16 if recheck else 0), C.byref(pv), C.byref(ps)),
               "knox_reduce_buckets_values")
         dt = np.dtype(NP_DTYPE[value_col.dtype])
         vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_uint8)), shape=(n_buckets * dt.itemsize,)).view(dt)
@@ -657,13 +658,14 @@ class Context:
         check(self.L.knox_bits_collect(self.h, C.byref(a), C.byref(l), C.byref(c)), "knox_bits_collect")
         return (None if a.value < 0 else bool(a.value), None if l.value < 0 else bool(l.value), None if c.value < 0 else c.value)
 
-    def reduce_buckets_sequential(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False):
+    def reduce_buckets_sequential(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False, form=None):
         """The reference's own reducer per window, row by row (bit-exact Value() for every reducer, join
         reducers included) -> (values[n_buckets], seen[n_buckets])."""
         vals = np.zeros(n_buckets, dtype=NP_DTYPE[value_col.dtype])
         seen = np.zeros(n_buckets, dtype=np.uint8)
         check(self.L.knox_reduce_buckets_sequential(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
-                                                    n_buckets, int(func), 1 if assume_sorted else 0, _ptr(vals), _ptr(seen)),
+                                                    n_buckets, int(func), (1 if assume_sorted else 0) | {None: 0, "lane": 4, "wave": 8}[form],
+                                                    _ptr(vals), _ptr(seen)),
               "knox_reduce_buckets_sequential")
         return vals, seen.astype(bool)
 

@@ -173,18 +173,21 @@ def test_gpu_sequential_windows_are_bit_exact_for_every_reducer():
                 isf = np.dtype(npdt).kind == "f"
                 for m, mh in ((None, None), (mask, bits_h)):
                     for f in PLAIN + JOIN:
-                        vals, seen = ctx.reduce_buckets_sequential(tcol, vcol, R(f), t_from, step, nb, mask=m)
-                        want_t, want_v = O.buckets(o, f, t, v, mh, t_from, step)
-                        ks = ((want_t - t_from) // step).astype(np.int64)
-                        # every window the reference created a reducer for is seen, and no other
-                        assert np.flatnonzero(seen).tolist() == ks.tolist(), (n, bt_k, f)
-                        got = vals[ks]
-                        if not isf and f in (O.R_VAR, O.R_STD, O.R_VAR_JOIN, O.R_STD_JOIN, O.R_MEAN, O.R_MEAN_JOIN):
-                            # T(NaN) / out-of-range float->int conversions are platform defined in Go: compare the
-                            # windows whose float result is representable in T
-                            ok = representable(f, t, v, mh, t_from, step, ks, npdt)
-                            got, want_v = got[ok], want_v[ok]
-                        assert got.tobytes() == want_v.tobytes(), (n, bt_k, f, got[:4], want_v[:4])
+                        want_t, want_v0 = O.buckets(o, f, t, v, mh, t_from, step)
+                        # both forms of the kernel: one lane per window, one wave per window (the default picks by window count)
+                        for form in ("lane", "wave"):
+                            want_v = want_v0
+                            vals, seen = ctx.reduce_buckets_sequential(tcol, vcol, R(f), t_from, step, nb, mask=m, form=form)
+                            ks = ((want_t - t_from) // step).astype(np.int64)
+                            # every window the reference created a reducer for is seen, and no other
+                            assert np.flatnonzero(seen).tolist() == ks.tolist(), (n, bt_k, f, form)
+                            got = vals[ks]
+                            if not isf and f in (O.R_VAR, O.R_STD, O.R_VAR_JOIN, O.R_STD_JOIN, O.R_MEAN, O.R_MEAN_JOIN):
+                                # T(NaN) / out-of-range float->int conversions are platform defined in Go: compare the
+                                # windows whose float result is representable in T
+                                ok = representable(f, t, v, mh, t_from, step, ks, npdt)
+                                got, want_v = got[ok], want_v[ok]
+                            assert got.tobytes() == want_v.tobytes(), (n, bt_k, f, form, got[:4], want_v[:4])
                 vcol.free()
             tcol.free(); mask.free()
         # out-of-order timestamps are refused here too
