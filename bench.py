@@ -14,15 +14,18 @@ Setup, outside the timed region and reported under "placement" in the JSON line 
 device-memory arena gets an explicit budget (KNOX_BENCH_ARENA_GIB, default 160: the headline maps ~13-17 GiB of it, the
 secondary configs the rest), the column is generated into it, the bitset is allocated FOR that column (a write buffer
 verified against it, knox_bits_alloc_for) and the pair is checked ONCE with the real kernel against its own read-only
-form (before it the read-only form is sampled every 0.5 s until two samples agree within 1 %: a process that has just exited
-leaves the driver clearing its memory, which costs every kernel ~5 % while it lasts -- "placement.device_quiet_ms").  The
-timed region contains only the K steps.
+form (before it the read-only form is sampled every 0.5 s until two consecutive samples agree within 0.4 % -- stability only,
+never a target rate -- or 10 s have passed: a process that has just exited leaves the driver clearing its memory, which costs
+every kernel ~5 % while it lasts; "placement.device_quiet_ms" holds the samples, "device_quiet_wait_s" the seconds waited and
+"device_quiet_ended_by" "stable" or "timeout").  The timed region contains only the K steps.
 
 After the timed region (all outside it): the read-only ceiling, the 0 % / 100 % selectivity runs of the same scan, the
 in-run parity against the oracle (bitset memcmp on a 64-pack sample, XOR checksum of ALL bitset words, count and
 wrapping sum of the whole run), BASELINE configs[2] and configs[3] at the same size in the same context ("configs":
 cfg3 = 2 x float64 AND + min / max / mean, cfg4_u64 / cfg4_bytes = per-pack bloom -> EQ -> count; each with kernel_ms,
-GB/s, frac and its own parity verdict), and the CPU baseline (scalar port @ 1 thread, AVX2 @ 1 thread, AVX2 @ all cores).
+GB/s, frac and its own parity verdict), "placement_off" (the headline, cfg3 and cfg4_bytes kernels once more in a second
+context with knox_ctx_set_placement(ctx, 0), and the points of peak the arena gains on each; "placement.probe_ms" is what
+its probes cost), and the CPU baseline (scalar port @ 1 thread, AVX2 @ 1 thread, AVX2 @ all cores).
 
 Environment (diagnostics, none needed): KNOX_PLACEMENT=0 plain hipMalloc; KNOX_BENCH_DEPTH scans queued ahead;
 KNOX_BENCH_FORCE_DIST=1 / KNOX_BENCH_BACKEND=gloo rehearsal modes of the multi-rank path on a 1-GPU box.
@@ -314,6 +317,63 @@ def secondary_configs(K, ctx, n_rows, pack_rows, steps, warmup, parity=True):
     return out
 
 
+def placement_off_ab(K, device, n_rows, pack_rows, on):
+    """What the arena's placement buys TODAY, in the driver's own record: the headline, configs[2] and the configs[3] []byte
+    leg once more in a SECOND context of this process with placement switched off (knox_ctx_set_placement(ctx, 0): plain
+    hipMalloc / hipFree, no probes, bitsets wherever the driver puts them) -- same generators, same kernels, 12 ramp launches
+    and 10 timed ones each (the library's HIP events), outside every timed region, while the first context (idle, nothing
+    freed: a driver clearing memory would slow both) is still open.  `on` = the kernel_ms the run measured with the arena."""
+    import ctypes as C
+    from knoxdb_amd import And, Leaf
+    from knoxdb_amd.types import BlockType, FilterMode, ReducerFunc as R
+    n_packs = n_rows // pack_rows
+    out = {}
+    ctx = K.Context(device)
+    try:
+        ctx.set_placement(False)
+
+        def kms(plan, bits):
+            for _ in range(12):
+                ctx.scan_async(plan, bits_out=bits, pack_counts=True)
+                ctx.scan_collect(plan, n_packs)
+            ctx.L.knox_prof_enable(ctx.h, 1)
+            for _ in range(10):
+                ctx.scan_async(plan, bits_out=bits, pack_counts=True)
+                ctx.scan_collect(plan, n_packs)
+            ms, k = C.c_double(), C.c_int()
+            ctx.L.knox_prof_read(ctx.h, C.byref(ms), C.byref(k))
+            ctx.L.knox_prof_enable(ctx.h, 0)
+            return ms.value / max(1, k.value)
+
+        def entry(name, ms_off, bytes_per_row):
+            f_off = n_rows * bytes_per_row / ms_off / 1e6 / HBM_PEAK_GBS
+            e = {"kernel_ms": ms_off, "frac": f_off}
+            if on.get(name):
+                f_on = n_rows * bytes_per_row / on[name] / 1e6 / HBM_PEAK_GBS
+                e.update({"kernel_ms_with_arena": on[name], "frac_with_arena": f_on, "gain_points": (f_on - f_off) * 100.0})
+            out[name] = e
+
+        col = ctx.generate(BlockType.Int64, 0, 2, n_rows, lo=-(1 << 40), span=1 << 41, pack_rows=pack_rows)
+        bits = ctx.bits(n_rows)
+        entry("headline", kms(ctx.plan(And(Leaf(0, FilterMode.Range, -(1 << 38), 1 << 38)), [col], aggs=[(R.Sum, 0), (R.Count, 0)]), bits), BYTES_PER_ROW)
+        col.free()
+        A = ctx.generate(BlockType.Float64, 1, 3, n_rows, pack_rows=pack_rows)
+        B = ctx.generate(BlockType.Float64, 2, 4, n_rows, pack_rows=pack_rows)
+        entry("cfg3", kms(ctx.plan(And(Leaf(0, FilterMode.Ge, 256.0), Leaf(1, FilterMode.Lt, 0.5)), [A, B],
+                                   aggs=[(R.Min, 0), (R.Max, 0), (R.Mean, 0), (R.Sum, 0), (R.Count, 0)]), bits), 16.125)
+        A.free(); B.free()
+        addr = ctx.generate_bytes(6, n_rows, pack_rows, 32, 16, 4)
+        _, buf = ctx.download_bytes_pack(addr, min(777, n_packs - 1))
+        key = bytes(buf[:32])
+        entry("cfg4_bytes", kms(ctx.plan(And(Leaf(0, FilterMode.Equal, key)), [addr], aggs=[]), bits), 40.125)
+        addr.free(); bits.free()
+        out["note"] = ("second context, knox_ctx_set_placement(ctx, 0): plain allocations, no probes; 12 ramp + 10 timed launches per config; "
+                       "gain_points = (frac with the arena, from this run's own lines) - (frac without), in points of the 8 TB/s peak")
+    finally:
+        ctx.close()
+    return out
+
+
 def measure_traffic_live(rows_log2, timeout_s=90):
     """roofline.traffic measured in THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate
     passes, as MI355X_MICROARCH.md prescribes; no trace flags) run the headline scan a few times (`bench.py --pmc-child`), the
@@ -401,6 +461,7 @@ def main():
     ap.add_argument("--rows-log2", type=int, default=30, help="rows per GPU = 2^k (default 2^30 = the 1B-row config)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and every oracle-backed parity check")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip BASELINE configs[2] / configs[3] after the timed region")
+    ap.add_argument("--no-placement-ab", action="store_true", help="skip the placement-off repetition of the three big configs (diagnostics, outside the timed region)")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc child passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child of measure_traffic_live: headline scans only, no output
     ap.add_argument("--cpu-sample-log2", type=int, default=29)
@@ -520,6 +581,7 @@ def main():
     # after 2.5 s and report both; nothing else is tried, nothing is re-allocated.
     checks = []
     quiet = []
+    quiet_wait_s, quiet_ended_by = 0.0, None
     if n_rows >= (1 << 26):
         ro_plan0 = ctx.plan(tree, [col], aggs=[])
         # A process that has just exited (the GPU tests, the smoke run, a previous bench) leaves the driver clearing the
@@ -529,18 +591,22 @@ def main():
         # timed region, reported as placement.device_quiet_ms.
         kernel_ms(ro_plan0, None, 12)                     # clock ramp
         quiet.append(kernel_ms(ro_plan0, None, 6))
-        # ... and, at the headline's size, until the read-only form also reaches 7.0 TB/s -- every box seen reads 6.93-7.25 TB/s
-        # when quiet, and the clearing of ~100 GiB can hold a steady 6.8 TB/s for more than 5 s -- or 10 s have passed
-        fast_enough = lambda ms_: n_rows != (1 << 30) or n_rows * 8 / ms_ / 1e6 >= 7000.0
+        # The wait ends on STABILITY alone (two consecutive samples within 0.4 %), never on a target rate -- a benchmark that
+        # waits until the device is as fast as it would like to see it has chosen its state (round-3 review) -- or after
+        # 10 s; the line reports the seconds waited, the samples, and which of the two ended the wait.
         t_wait = time.perf_counter()
+        quiet_ended_by = "timeout"
         while True:
             time.sleep(0.5)
             kernel_ms(ro_plan0, None, 6)                  # clock ramp after the pause
             quiet.append(kernel_ms(ro_plan0, None, 6))
             waited = time.perf_counter() - t_wait
-            stable = abs(quiet[-1] - quiet[-2]) <= 0.004 * quiet[-2]   # launch-to-launch noise is ~0.2 %; a device that is still getting faster keeps the wait going
-            if (stable and (fast_enough(quiet[-1]) or waited > 10.0)) or waited > 15.0:
+            if abs(quiet[-1] - quiet[-2]) <= 0.004 * quiet[-2]:   # launch-to-launch noise is ~0.2 %
+                quiet_ended_by = "stable"
                 break
+            if waited > 10.0:
+                break
+        quiet_wait_s = time.perf_counter() - t_wait
         for attempt in range(2):
             kernel_ms(plan, bits, 4)                      # clock ramp
             ro_ms, mix_ms = kernel_ms(ro_plan0, None, 6), kernel_ms(plan, bits, 8)
@@ -768,6 +834,22 @@ def main():
             import traceback
             traceback.print_exc()
             out["configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the arena's cost / benefit in the same record (round-3 review item 6): what the probes cost this context, and the three
+    # big configs once more without placement
+    ai2 = ctx.arena_info()
+    out["placement"].update({"probe_launches": ai2["probe_launches"], "probe_ms": ai2["probe_ms"], "probe_measurements": ai2["probes"],
+                             "device_quiet_wait_s": quiet_wait_s if quiet else 0.0, "device_quiet_ended_by": quiet_ended_by if quiet else None})
+    if rank == 0 and world == 1 and not args.no_configs and not args.no_placement_ab and n_rows >= (1 << 26):
+        try:
+            on = {"headline": scan_ms}
+            for k_ in ("cfg3", "cfg4_bytes"):
+                if isinstance(out.get("configs"), dict) and k_ in out["configs"]:
+                    on[k_] = out["configs"][k_].get("kernel_ms")
+            out["placement_off"] = placement_off_ab(K, local_rank, n_rows, pack_rows, on)
+            print("[placement A/B] " + json.dumps({k_: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v_.items()}
+                                                    for k_, v_ in out["placement_off"].items() if isinstance(v_, dict)}), file=sys.stderr, flush=True)
+        except Exception as e:   # diagnostics must never cost the headline its line
+            out["placement_off"] = {"error": "%s: %s" % (type(e).__name__, e)}
     ctx.close()
     if rank == 0 and world == 1 and args.rows_log2 == 30 and not args.no_live_traffic and not args.no_cpu_baseline:
         t_pmc = time.perf_counter()

@@ -130,6 +130,8 @@ typedef struct knox_arena_info {
                                           few GiB); 0 on every device seen so far                                        */
     int32_t write_buffers, chunks, probes; /* write buffers created, 1 GiB chunks created, probe measurements taken */
     int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
+    int32_t probe_launches;    /* kernel launches the probe measurements above took ...      */
+    float probe_ms;            /* ... and the device time they took (HIP events), since the context was opened */
 } knox_arena_info;
 int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out);
 /* Column space mapped per placement class (chunks labelled so far, used or free) and the number of classes met.
@@ -166,6 +168,10 @@ int knox_prof_read_each(knox_ctx *ctx, float *ms, int cap, int *launches);
  * sized for exactly that many).  0 on gfx950 with the shipped build; anything else means a changed kernel, table or part
  * and a measured loss (results stay correct).                                                                      */
 int knox_scan_occupancy_mismatches(void);
+/* The launch-shape table itself (diagnostics): workgroups per CU and parked bitset words per wave of the scan instantiation
+ * for `width`-byte columns, n_leaves leaves, aggregates beyond the wrapping sum (heavy), a float aggregate column, a float
+ * sum among the aggregates.  tests/test_scan_shapes.py holds it against the compiler's occupancy figures of the build.  */
+int knox_scan_launch_shape(int width, int n_leaves, int heavy, int is_float, int float_sum, int *per_cu, uint32_t *park_words);
 
 /* ---- finest boundary: the cmp func vars --------------------------------------------- *
  * Replaces `func(src []T, val T, bits []byte) int64` / `func(src []T, a, b T, bits []byte)

@@ -51,7 +51,7 @@ class ArenaInfo(C.Structure):
     """knox_arena_info -- the context's device-memory arena."""
     _fields_ = [("budget_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64), ("used_bytes", C.c_uint64), ("peak_used_bytes", C.c_uint64),
                 ("spare_write_buffer_bytes", C.c_uint64), ("mixed_zone_bytes", C.c_uint64), ("write_buffers", C.c_int32),
-                ("chunks", C.c_int32), ("probes", C.c_int32), ("enabled", C.c_int32)]
+                ("chunks", C.c_int32), ("probes", C.c_int32), ("enabled", C.c_int32), ("probe_launches", C.c_int32), ("probe_ms", C.c_float)]
 
 
 class ScanOut(C.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "knox_prof_read": (_i, [_vp, C.POINTER(C.c_double), _pi]),
     "knox_prof_read_each": (_i, [_vp, C.POINTER(C.c_float), _i, _pi]),
     "knox_scan_occupancy_mismatches": (_i, []),
+    "knox_scan_launch_shape": (_i, [_i, _i, _i, _i, _i, _pi, C.POINTER(C.c_uint32)]),
     "knox_cmp": (_i64, [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "knox_col_upload": (_i, [_vp, _i, _vp, _sz, _sz, _pp]),
     "knox_col_create": (_i, [_vp, _i, _sz, _sz, _pp]),

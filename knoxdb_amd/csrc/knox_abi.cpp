@@ -15,6 +15,13 @@
 // ------------------------------------------------------------------------------------------------
 KNOX_API int knox_abi_version(void) { return KNOX_ABI_VERSION; }
 KNOX_API int knox_scan_occupancy_mismatches(void) { return g_scan_occupancy_mismatches.load(); }
+KNOX_API int knox_scan_launch_shape(int width, int n_leaves, int heavy, int is_float, int float_sum, int *per_cu, uint32_t *park_words) {
+    if ((width != 1 && width != 2 && width != 4 && width != 8) || n_leaves < 1 || n_leaves > kMaxLeaves || !per_cu || !park_words) return KNOX_E_INVALID;
+    const ScanShape sh = scan_shape(width, n_leaves, heavy != 0, is_float != 0, float_sum != 0);
+    *per_cu = sh.per_cu;
+    *park_words = sh.park_words;
+    return KNOX_OK;
+}
 
 KNOX_API const char *knox_strerror(int err) {
     switch (err) {
@@ -233,6 +240,8 @@ KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
     out->probes = ctx->arena.probes_run;
     out->mixed_zone_bytes = ctx->arena.mixed_bytes;
     out->enabled = ctx->placement && ctx->arena.usable;
+    out->probe_launches = ctx->probe_launches;
+    out->probe_ms = (float)ctx->probe_ms;
     return KNOX_OK;
 }
 
@@ -441,6 +450,11 @@ static double probe_pair(knox_ctx *ctx, const void *p, uint64_t rows, void *bits
         if (launch_probe_scan(ctx->stream, g, a) != hipSuccess || hipEventRecord(ctx->probe_ev[i + 1], ctx->stream) != hipSuccess) return 0.0;
     }
     if (hipEventSynchronize(ctx->probe_ev[kLaunches]) != hipSuccess) return 0.0;
+    {
+        float all_ms = 0.f;
+        if (hipEventElapsedTime(&all_ms, ctx->probe_ev[0], ctx->probe_ev[kLaunches]) == hipSuccess) ctx->probe_ms += all_ms;
+        ctx->probe_launches += kLaunches;
+    }
     float ro[kLaunches / 2], mix[kLaunches / 2];
     int n_ro = 0, n_mix = 0;
     for (int i = 8; i < kLaunches; i++) {
@@ -501,6 +515,11 @@ static int probe_multi(knox_ctx *ctx, const void *p, uint64_t rows, void *const 
         if (launch_probe_scan(ctx->stream, g, a) != hipSuccess || hipEventRecord(ctx->probe_ev[i + 1], ctx->stream) != hipSuccess) return -1;
     }
     if (hipEventSynchronize(ctx->probe_ev[n_l]) != hipSuccess) return -1;
+    {
+        float all_ms = 0.f;
+        if (hipEventElapsedTime(&all_ms, ctx->probe_ev[0], ctx->probe_ev[n_l]) == hipSuccess) ctx->probe_ms += all_ms;
+        ctx->probe_launches += n_l;
+    }
     double ro = 0.0, mix[4] = {0, 0, 0, 0};
     for (int i = 2; i < n_l; i++) {
         float ms = 0.f;

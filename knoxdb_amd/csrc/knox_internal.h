@@ -202,6 +202,8 @@ struct knox_ctx {
     Arena arena;
     void *probe_partials = nullptr;  // the classification probes' own partial buffer (plain allocation: the arena cannot allocate while it grows)
     hipEvent_t probe_ev[24] = {};
+    int probe_launches = 0;    // launches and device time of the arena's probes (knox_arena_info)
+    double probe_ms = 0.0;
     // RCCL
     void *rccl = nullptr;
     ncclComm_t comm = nullptr;

@@ -37,7 +37,9 @@ struct ScanShape {
 constexpr uint32_t kLdsPerCu = 160u * 1024u;
 constexpr ScanShape scan_shape(int W, int NL, bool heavy, bool flt, bool fsum) {
     int per_cu = 0;
-    if (NL >= 2) per_cu = (NL == 2 && heavy) ? 2 : 3;
+    // (two plain leaves on 2-byte columns -- pipelined, 210 VGPRs -- and three / four aggregate-heavy leaves on 1-byte columns
+    //  -- 199-218 VGPRs -- hold two workgroups per CU: round 4, from the compiler's own occupancy figures)
+    if (NL >= 2) per_cu = ((NL == 2 && heavy) || (NL == 2 && W == 2) || (NL >= 3 && W == 1 && heavy)) ? 2 : 3;
     else if (!heavy) per_cu = W == 1 ? 3 : 2;
     else if (W == 4 && flt && fsum) per_cu = 8;
     else per_cu = W == 2 ? 3 : 2;

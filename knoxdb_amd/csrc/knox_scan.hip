@@ -323,7 +323,10 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const ScanArgs a) {
 #ifdef KNOX_PIPE_PLAIN  // experiment builds: every plain scan pipelined
     constexpr bool kPipe = NL <= 2 && !SEP;
 #else
-    constexpr bool kPipe = NL <= 2 && !SEP && ((AGG & ~A_ISUM) != 0 || NL == 2 || (W == 1 && AGG == A_ISUM));
+    // (round 4: NOT the two-leaf scans of 1-byte columns -- two register sets of two leaves at 16 rows per load need 256 VGPRs,
+    //  one workgroup per CU where the launch shape assumes two or three; found by the build-time occupancy check,
+    //  tests/test_scan_shapes.py)
+    constexpr bool kPipe = NL <= 2 && !SEP && !(W == 1 && NL == 2) && ((AGG & ~A_ISUM) != 0 || NL == 2 || (W == 1 && AGG == A_ISUM));
 #endif
     if (kPipe && (iters & 1u) == 0) {
         u32x4 ra[kUnroll];

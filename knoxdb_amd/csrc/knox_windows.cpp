@@ -253,7 +253,7 @@ KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_
     // the window bounds never leave the device: the reducer lanes read them in place
     // one lane per window when there are enough windows to give every lane of the chip one, a whole wave per window (coalesced
     // fetches, the recurrence fed through v_readlane) below that; flags bit 2 / bit 3 force the one or the other (tests, A/B)
-    const bool wave_per_window = (flags & 8) != 0 || ((flags & 4) == 0 && n_buckets <= (size_t)ctx->n_cus * 256);
+    const bool wave_per_window = (flags & 8) != 0 || ((flags & 4) == 0 && n_buckets <= (size_t)ctx->n_cus * 128);  // measured (tools/bench_windows.py, 2^26 / 2^28 rows): 16384 windows 1.7-1.8 x faster by wave, 65536 windows 1.25-1.3 x faster by lane
     if (e == hipSuccess)
         e = launch_bucket_sequential(ctx->stream, value_col->dtype, func, (const int64_t *)time_col->dev, value_col->dev,
                                      mask ? (const uint8_t *)mask->dev : nullptr, d_start, (uint32_t)n_buckets, wave_per_window ? 1 : 0,

@@ -355,7 +355,7 @@ class Context:
         return {"budget_gib": a.budget_bytes / 2**30, "mapped_gib": a.mapped_bytes / 2**30, "used_gib": a.used_bytes / 2**30,
                 "peak_used_gib": a.peak_used_bytes / 2**30, "write_buffers": a.write_buffers, "chunks": a.chunks, "probes": a.probes,
                 "enabled": bool(a.enabled), "mixed_zone_gib": a.mixed_zone_bytes / 2**30,
-                "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30}
+                "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30, "probe_launches": a.probe_launches, "probe_ms": a.probe_ms}
 
     def arena_classes(self):
         """-> (GiB of column space per placement class, classes met); include/knoxgpu.h knox_ctx_arena_classes"""
