@@ -838,6 +838,9 @@ def main():
     # big configs once more without placement
     ai2 = ctx.arena_info()
     out["placement"].update({"probe_launches": ai2["probe_launches"], "probe_ms": ai2["probe_ms"], "probe_measurements": ai2["probes"],
+                             "probe_budget": "200 launches / 50 ms per context (the library's default, knox_ctx_set_probe_budget)",
+                             "chunks_labelled_by_inheritance": ai2["unprobed_chunks"], "write_buffers_placed_by_label_only": ai2["unverified_write_buffers"],
+                             "chunks_created": ai2["chunks"], "arena_mapped_gib": ai2["mapped_gib"],
                              "device_quiet_wait_s": quiet_wait_s if quiet else 0.0, "device_quiet_ended_by": quiet_ended_by if quiet else None})
     if rank == 0 and world == 1 and not args.no_configs and not args.no_placement_ab and n_rows >= (1 << 26):
         try:

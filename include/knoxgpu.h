@@ -132,8 +132,16 @@ typedef struct knox_arena_info {
     int32_t enabled;           /* 0: plain allocations (mode 0 or no virtual-memory API)    */
     int32_t probe_launches;    /* kernel launches the probe measurements above took ...      */
     float probe_ms;            /* ... and the device time they took (HIP events), since the context was opened */
+    int32_t unprobed_chunks;   /* chunks that took the label of the chunk before them, and ...                  */
+    int32_t unverified_write_buffers; /* ... write buffers taken from another class's zone by label alone: the probe budget was spent */
 } knox_arena_info;
 int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out);
+/* What the arena may spend on probe measurements from now on: at most max_launches kernel launches and max_ms of device time
+ * (counted like probe_launches / probe_ms above).  A context starts with 200 launches / 50 ms -- placement buys 1-6 points of
+ * the HBM peak on multi-GiB scans and must not cost more than that by itself; a long-lived host grants more when it has idle
+ * time.  With the budget spent nothing is measured: new chunks inherit the previous chunk's class, write buffers are placed
+ * by label.  (0, 0) = measure nothing at all.                                                                        */
+int knox_ctx_set_probe_budget(knox_ctx *ctx, int max_launches, double max_ms);
 /* Column space mapped per placement class (chunks labelled so far, used or free) and the number of classes met.
  * Diagnostics: a context whose classes_seen stays 1 while bitsets are placed has found one class of memory only.        */
 int knox_ctx_arena_classes(knox_ctx *ctx, uint64_t class_bytes[4], int *classes_seen /* nullable */);

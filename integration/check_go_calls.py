@@ -356,6 +356,17 @@ def check(verbose=False):
                         f = fld[1:] if fld.startswith("_") else fld  # cgo spells C fields that are Go keywords `_func`
                         if f not in structs[base]:
                             errors.append(f"{rel}: {var}.{fld}: struct {base} has no such field")
+        # the context pool's rule (knoxgpu.Pool): a context taken with Get() goes back with a deferred Put() of the SAME
+        # variable in the same function, right after the Get -- otherwise an early return (every fallback path has one)
+        # leaks the context and the next Get blocks for good
+        for header_line, body in func_bodies(src):
+            for m in re.finditer(r"\b(\w+)\s*:=\s*(\w+)\.Get\(\)", body):
+                var, pool = m.group(1), m.group(2)
+                rest = body[m.end():]
+                nxt = rest.lstrip().split("\n", 1)[0].strip()
+                if nxt != f"defer {pool}.Put({var})":
+                    ln = body[:m.start()].count("\n") + 1
+                    errors.append(f"{rel}: `{var} := {pool}.Get()` (function line {ln}) is not followed by `defer {pool}.Put({var})`")
         for gname, val in go_consts(src).items():
             if gname in GO_ENUMS and enums.get(GO_ENUMS[gname]) != val:
                 errors.append(f"{rel}: const {gname} = {val}, header says {GO_ENUMS[gname]} = {enums.get(GO_ENUMS[gname])}")

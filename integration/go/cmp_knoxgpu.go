@@ -1,6 +1,6 @@
 //go:build knoxgpu
 
-// Drop into internal/cmp/ of blockwatch-cc/knoxdb.  Rebinds ALL 70 exported compare func vars (cmp.go:6-114) to the
+// Drop into internal/cmp/ of blockwatch-cc/knoxdb.  Rebinds ALL 84 exported compare func vars (cmp.go:6-114) to the
 // MI355X path, the same way cmp_amd64.go:14-218 rebinds them to AVX2 / AVX-512: 10 numeric types x 7 modes go through
 // knox_cmp (host slices in, host bitset out), Int128 / Int256 x 7 modes through knox_match_wide over the stride's limb
 // slices.  A failing GPU call falls back to the kernel that was installed before (the generic / SIMD one).
@@ -13,7 +13,9 @@ import (
 	"blockwatch.cc/knoxdb/pkg/num"
 )
 
-var gpu *knoxgpu.Ctx
+// the contexts the rebound kernels run on: a small pool, so that concurrent queries (one goroutine each) do not queue
+// behind one mutex (knoxgpu.Pool; KNOX_CMP_CONTEXTS, default 4)
+var gpus *knoxgpu.Pool
 
 // types.BlockType (internal/types/block.go:20-36) and types.FilterMode (internal/types/mode.go:13-27)
 const (
@@ -24,9 +26,16 @@ const (
 	modeRange                                           = 9
 )
 
-// one value / range kernel with its fallback
+// one value / range kernel with its fallback.  Below knoxgpu.CmpMinRows rows the call never leaves the CPU: the kernel
+// installed before (cmp_amd64.go's AVX2 / AVX-512 one) answers a production pack in a few microseconds, a device round
+// trip cannot (measured table: DESIGN.md 7, tools/cmp_latency.py).
 func bind1[T knoxgpu.Number](dtype, mode int, prev func([]T, T, []byte) int64) func([]T, T, []byte) int64 {
 	return func(src []T, val T, bits []byte) int64 {
+		if len(src) < knoxgpu.CmpMinRows {
+			return prev(src, val, bits)
+		}
+		gpu := gpus.Get()
+		defer gpus.Put(gpu)
 		if n, ok := knoxgpu.Cmp(gpu, dtype, mode, src, val, val, bits); ok {
 			return n
 		}
@@ -36,6 +45,11 @@ func bind1[T knoxgpu.Number](dtype, mode int, prev func([]T, T, []byte) int64) f
 
 func bind2[T knoxgpu.Number](dtype int, prev func([]T, T, T, []byte) int64) func([]T, T, T, []byte) int64 {
 	return func(src []T, a, b T, bits []byte) int64 {
+		if len(src) < knoxgpu.CmpMinRows {
+			return prev(src, a, b, bits)
+		}
+		gpu := gpus.Get()
+		defer gpus.Put(gpu)
 		if n, ok := knoxgpu.Cmp(gpu, dtype, modeRange, src, a, b, bits); ok {
 			return n
 		}
@@ -45,6 +59,11 @@ func bind2[T knoxgpu.Number](dtype int, prev func([]T, T, T, []byte) int64) func
 
 func bind128(mode int, prev func(*num.Int128Stride, num.Int128, []byte, []byte) int64) func(*num.Int128Stride, num.Int128, []byte, []byte) int64 {
 	return func(src *num.Int128Stride, val num.Int128, bits, mask []byte) int64 {
+		if src.Len() < knoxgpu.CmpMinRows {
+			return prev(src, val, bits, mask)
+		}
+		gpu := gpus.Get()
+		defer gpus.Put(gpu)
 		if n, ok := knoxgpu.MatchWide(gpu, [][]uint64{knoxgpu.AsU64(src.X0), src.X1}, mode, val[:], nil, mask, bits, src.Len()); ok {
 			return n
 		}
@@ -54,6 +73,11 @@ func bind128(mode int, prev func(*num.Int128Stride, num.Int128, []byte, []byte) 
 
 func bind256(mode int, prev func(*num.Int256Stride, num.Int256, []byte, []byte) int64) func(*num.Int256Stride, num.Int256, []byte, []byte) int64 {
 	return func(src *num.Int256Stride, val num.Int256, bits, mask []byte) int64 {
+		if src.Len() < knoxgpu.CmpMinRows {
+			return prev(src, val, bits, mask)
+		}
+		gpu := gpus.Get()
+		defer gpus.Put(gpu)
 		if n, ok := knoxgpu.MatchWide(gpu, [][]uint64{knoxgpu.AsU64(src.X0), src.X1, src.X2, src.X3}, mode, val[:], nil, mask, bits, src.Len()); ok {
 			return n
 		}
@@ -65,11 +89,11 @@ func init() {
 	if !knoxgpu.Enabled() { // KNOX_NOGPU=1: keep the CPU kernels (the switch of internal/cpu/avx.go:43-89)
 		return
 	}
-	ctx, err := knoxgpu.Open(0)
+	pool, err := knoxgpu.NewPool(0, knoxgpu.PoolSize())
 	if err != nil {
 		return // no device: keep the CPU kernels already installed by cmp_amd64.go
 	}
-	gpu = ctx
+	gpus = pool
 
 	// uint8
 	Uint8Equal = bind1[uint8](blockUint8, modeEq, Uint8Equal)
@@ -161,6 +185,11 @@ func init() {
 	{
 		prev := Int128Between
 		Int128Between = func(src *num.Int128Stride, a, b num.Int128, bits, mask []byte) int64 {
+			if src.Len() < knoxgpu.CmpMinRows {
+				return prev(src, a, b, bits, mask)
+			}
+			gpu := gpus.Get()
+			defer gpus.Put(gpu)
 			limbs := [][]uint64{knoxgpu.AsU64(src.X0), src.X1}
 			if n, ok := knoxgpu.MatchWide(gpu, limbs, modeRange, a[:], b[:], mask, bits, src.Len()); ok {
 				return n
@@ -178,6 +207,11 @@ func init() {
 	{
 		prev := Int256Between
 		Int256Between = func(src *num.Int256Stride, a, b num.Int256, bits, mask []byte) int64 {
+			if src.Len() < knoxgpu.CmpMinRows {
+				return prev(src, a, b, bits, mask)
+			}
+			gpu := gpus.Get()
+			defer gpus.Put(gpu)
 			limbs := [][]uint64{knoxgpu.AsU64(src.X0), src.X1, src.X2, src.X3}
 			if n, ok := knoxgpu.MatchWide(gpu, limbs, modeRange, a[:], b[:], mask, bits, src.Len()); ok {
 				return n

@@ -156,6 +156,72 @@ func Cmp[T Number](c *Ctx, dtype, mode int, src []T, a, b T, bits []byte) (int64
 	return int64(n), n >= 0
 }
 
+// CmpMinRows is the row floor of the rebound cmp func vars: a vector shorter than this stays on the kernel that was
+// installed before (AVX2 / AVX-512 / generic).  A cmp call is a synchronous round trip -- lock, launch, one stream
+// synchronisation, a copy of the bitset -- and below the floor one CPU core answers sooner: the reference's AVX2 kernel
+// takes 4.5-7.4 us for a 2^16-row pack (docs/bench/2020-10-d3f9115/Xeon-E-2176G/README.md:54,63), the device call ~25 us
+// plus the PCIe time of the vector.  Default = the crossover measured on the MI355X box with the vector in page-locked
+// memory (tools/cmp_latency.py, DESIGN.md 7): 2^21 rows.  KNOX_CMP_MIN_ROWS overrides it (0 = every call goes to the
+// device: tests).  The throughput path is not this one: runs of packs resident in HBM go through table.GpuRun.
+var CmpMinRows = func() int {
+	if v, err := strconv.Atoi(os.Getenv("KNOX_CMP_MIN_ROWS")); err == nil && v >= 0 {
+		return v
+	}
+	return 1 << 21
+}()
+
+// Pool hands out contexts to calls that would otherwise serialise on one: the reference runs many queries at once (one
+// goroutine per query, internal/tests/benchmarks/benchmark3_test.go:112-127 b.RunParallel), and a context is one HIP
+// stream plus one mutex.  Get blocks while every context is out; a context still takes its own c.mu inside every call (the
+// rule integration/check_go_calls.py enforces), Pool only decides WHICH context a call uses.  Every Get is paired with a
+// deferred Put in the same function (checked the same way).
+type Pool struct {
+	free chan *Ctx
+	all  []*Ctx
+}
+
+// NewPool opens n contexts on `device` (n < 1: one); fewer if the device refuses, an error if none opens.
+func NewPool(device, n int) (*Pool, error) {
+	if n < 1 {
+		n = 1
+	}
+	p := &Pool{free: make(chan *Ctx, n)}
+	var last error
+	for i := 0; i < n; i++ {
+		c, err := Open(device)
+		if err != nil {
+			last = err
+			break
+		}
+		p.all = append(p.all, c)
+		p.free <- c
+	}
+	if len(p.all) == 0 {
+		return nil, last
+	}
+	return p, nil
+}
+
+func (p *Pool) Get() *Ctx  { return <-p.free }
+func (p *Pool) Put(c *Ctx) { p.free <- c }
+func (p *Pool) Size() int  { return len(p.all) }
+
+// Close closes every context; the caller makes sure none is out.
+func (p *Pool) Close() {
+	for _, c := range p.all {
+		c.Close()
+	}
+	p.all = nil
+}
+
+// PoolSize: KNOX_CMP_CONTEXTS (default 4) contexts serve the rebound cmp func vars.
+func PoolSize() int {
+	if v, err := strconv.Atoi(os.Getenv("KNOX_CMP_CONTEXTS")); err == nil && v > 0 {
+		return v
+	}
+	return 4
+}
+
 // Column is the device image of one column of a run of consecutive packs.
 type Column struct {
 	p *C.knox_col

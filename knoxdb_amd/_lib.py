@@ -51,7 +51,7 @@ class ArenaInfo(C.Structure):
     """knox_arena_info -- the context's device-memory arena."""
     _fields_ = [("budget_bytes", C.c_uint64), ("mapped_bytes", C.c_uint64), ("used_bytes", C.c_uint64), ("peak_used_bytes", C.c_uint64),
                 ("spare_write_buffer_bytes", C.c_uint64), ("mixed_zone_bytes", C.c_uint64), ("write_buffers", C.c_int32),
-                ("chunks", C.c_int32), ("probes", C.c_int32), ("enabled", C.c_int32), ("probe_launches", C.c_int32), ("probe_ms", C.c_float)]
+                ("chunks", C.c_int32), ("probes", C.c_int32), ("enabled", C.c_int32), ("probe_launches", C.c_int32), ("probe_ms", C.c_float), ("unprobed_chunks", C.c_int32), ("unverified_write_buffers", C.c_int32)]
 
 
 class ScanOut(C.Structure):
@@ -154,6 +154,7 @@ SIGNATURES = {
     "knox_ctx_set_arena": (_i, [_vp, _sz]),
     "knox_ctx_reserve": (_i, [_vp, _sz]),
     "knox_col_placement_class": (_i, [_vp, _i]),
+    "knox_ctx_set_probe_budget": (_i, [_vp, _i, C.c_double]),
     "knox_ctx_arena_info": (_i, [_vp, C.POINTER(ArenaInfo)]),
     "knox_ctx_arena_classes": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "knox_ctx_arena_trim": (_i, [_vp, C.POINTER(_sz)]),

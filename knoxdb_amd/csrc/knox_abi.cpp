@@ -92,7 +92,7 @@ static int ctx_open(int device, void *ext_stream, bool use_ext, knox_ctx **out) 
     size_t budget = total_b / 4 * 3;
     env = getenv("KNOX_ARENA_GIB");
     if (env && atof(env) > 0) budget = (size_t)(atof(env) * (double)((size_t)1 << 30));
-    c->arena.configure(device, budget, arena_probe, c, arena_probe_multi);
+    c->arena.configure(device, budget, arena_probe, c, arena_probe_multi, &c->probe_launches, &c->probe_ms);
     *out = c;
     return KNOX_OK;
 }
@@ -124,6 +124,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     for (auto &r : ctx->res) {
         if (r.h_res) hipHostFree(r.h_res);
         if (ctx->h_view) { hipHostFree(ctx->h_view); ctx->h_view = nullptr; }
+        if (ctx->cmp_res) { hipHostFree(ctx->cmp_res); ctx->cmp_res = nullptr; }
         if (r.h_packs) hipHostFree(r.h_packs);
         if (r.done) hipEventDestroy(r.done);
     }
@@ -227,6 +228,12 @@ KNOX_API int knox_ctx_reserve(knox_ctx *ctx, size_t bytes) {
     return KNOX_OK;
 }
 
+KNOX_API int knox_ctx_set_probe_budget(knox_ctx *ctx, int max_launches, double max_ms) {
+    if (!ctx || max_launches < 0 || !(max_ms >= 0.0)) return KNOX_E_INVALID;
+    ctx->arena.grant(max_launches, max_ms);
+    return KNOX_OK;
+}
+
 KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
     if (!ctx || !out) return KNOX_E_INVALID;
     memset(out, 0, sizeof *out);
@@ -242,6 +249,8 @@ KNOX_API int knox_ctx_arena_info(knox_ctx *ctx, knox_arena_info *out) {
     out->enabled = ctx->placement && ctx->arena.usable;
     out->probe_launches = ctx->probe_launches;
     out->probe_ms = (float)ctx->probe_ms;
+    out->unprobed_chunks = ctx->arena.unprobed_chunks;
+    out->unverified_write_buffers = ctx->arena.unverified_write_buffers;
     return KNOX_OK;
 }
 
@@ -2268,11 +2277,21 @@ KNOX_API int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins,
 // ------------------------------------------------------------------------------------------------
 // knox_cmp: the finest boundary (host slices in, host bitset out)
 // ------------------------------------------------------------------------------------------------
+// Round 4: the call is latency, not bandwidth -- a cmp func var is called per vector (2^16 rows in production packs) and the
+// reference's AVX2 kernel answers in 4.5-7.4 us there.  So the fixed part is as short as the boundary allows:
+//   * a PAGE-LOCKED source (knox_host_alloc: the arena hook of a Go host) is not copied at all -- the scan kernel reads it
+//     in place over PCIe (page-locked host memory is device addressable at its own address);
+//   * a pageable source is staged as before (host copy into the pinned ring, DMA, scan from HBM);
+//   * the bitset is written by the kernel straight into page-locked memory (the staging ring's second slot) and the count
+//     and state block by the finalize launch into a page-locked result block (run_fused's res_dst), so the call ends in ONE
+//     stream synchronisation and one host memcpy of (n + 7) / 8 bytes -- no device-to-host copy commands.
+// tools/cmp_latency.py measures it against the AVX2 port; the table is in DESIGN.md 7 and sets the Go side's row floor.
 KNOX_API int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, size_t n, const void *a, const void *b, uint8_t *bits) {
     if (!ctx) return KNOX_E_INVALID;
     if (n == 0 || src == nullptr) return 0;  // cmp/tests/int64.go:212-213
     const int w = dtype_width(dtype);
     if (w == 0 || !bits || !a || (op == KNOX_RANGE && !b)) return KNOX_E_INVALID;
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;  // the result block below is the scans' too
     hipSetDevice(ctx->device);
     uint64_t av = 0, bv = 0;
     memcpy(&av, a, (size_t)w);
@@ -2280,26 +2299,45 @@ KNOX_API int64_t knox_cmp(knox_ctx *ctx, int dtype, int op, const void *src, siz
     LeafHost lh;
     int rc = make_leaf(dtype, op, av, bv, lh);
     if (rc) return rc;
-    rc = ensure(ctx, ctx->tmp_vals, n * (size_t)w + 512);
-    if (!rc) rc = ensure(ctx, ctx->tmp_bits, (bits_padded(n) + 64) * 8);
+    rc = stage_init(ctx);
+    if (rc) return rc;
+    const size_t res_bytes = sizeof(AggStateDev) * 16 + 8 * 16;
+    rc = ensure_host(ctx, ctx->cmp_res, ctx->cmp_res_cap, res_bytes);
+    if (rc) return rc;
+    const size_t out_bytes = (bits_padded(n) + 64) * 8;                 // what the kernel may touch (whole words + slack)
+    const bool bits_pinned = out_bytes <= knox_ctx::kStageBytes;        // 2^28 rows: the ring slot holds the bitset
+    const bool src_pinned = ((uintptr_t)src & 15) == 0 && is_pinned_host(src);
+    if (!src_pinned) rc = ensure(ctx, ctx->tmp_vals, n * (size_t)w + 512);
+    if (!rc && !bits_pinned) rc = ensure(ctx, ctx->tmp_bits, out_bytes);
     const int grid = std::max(1, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8));
     if (!rc) rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid + 1) * 16);
-    if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (!rc) rc = ensure(ctx, ctx->states, res_bytes);
     if (rc) return rc;
-    rc = upload(ctx, ctx->tmp_vals.p, src, n * (size_t)w);
-    if (rc) return rc;
+    if (!src_pinned) {
+        rc = upload(ctx, ctx->tmp_vals.p, src, n * (size_t)w);  // returns when the ring's DMAs are done: slot 1 is free again
+        if (rc) return rc;
+    }
     knox_col tmp;
-    tmp.ctx = ctx; tmp.dtype = dtype; tmp.width = w; tmp.n_rows = n; tmp.pack_rows = n; tmp.dev = ctx->tmp_vals.p;
+    tmp.ctx = ctx; tmp.dtype = dtype; tmp.width = w; tmp.n_rows = n; tmp.pack_rows = n; tmp.dev = src_pinned ? const_cast<void *>(src) : ctx->tmp_vals.p;
     tmp.buf = nullptr; tmp.buf_len = 0; tmp.owned = false;
     const knox_col *lc[1] = {&tmp};
     const uint64_t tt = lh.neg ? 0x1ull : 0x2ull;
-    rc = run_fused(ctx, w, &lh, lc, 1, tt, nullptr, 0, n, n, 0, nullptr, (uint32_t *)ctx->tmp_bits.p, 0, grid, dtype);
+    uint32_t *out = bits_pinned ? (uint32_t *)ctx->stage[1] : (uint32_t *)ctx->tmp_bits.p;
+    int64_t *h_cnt = (int64_t *)((AggStateDev *)ctx->cmp_res + 16);
+    h_cnt[0] = -1;
+    ctx->res_dst = (char *)ctx->cmp_res;
+    ctx->post_packs = 0;
+    rc = run_fused(ctx, w, &lh, lc, 1, tt, nullptr, 0, n, n, 0, nullptr, out, 0, grid, dtype);
+    ctx->res_dst = nullptr;
     if (rc) return rc;
-    int64_t cnt = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&cnt, (int64_t *)((AggStateDev *)ctx->states.p + 16), 8, hipMemcpyDeviceToHost, ctx->stream));
-    rc = download(ctx, bits, ctx->tmp_bits.p, bits_bytes(n));  // exactly (n+7)/8 bytes: poison tail untouched
-    if (rc) return rc;
-    return cnt;
+    if (bits_pinned) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        CopyPool::get().copy(bits, out, bits_bytes(n));  // exactly (n+7)/8 bytes: poison tail untouched
+    } else {
+        rc = download(ctx, bits, out, bits_bytes(n));    // synchronises the stream
+        if (rc) return rc;
+    }
+    return h_cnt[0];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,13 +111,38 @@ class Arena {
     int chunks_created = 0, probes_run = 0, write_buffers = 0;
     size_t mixed_bytes = 0;  // chunks moved out of their class zones into the mixed region (columns no single class could hold)
 
-    void configure(int device_, size_t budget_, ArenaProbeFn fn, void *user_, ArenaProbeMultiFn multi_ = nullptr) {
+    void configure(int device_, size_t budget_, ArenaProbeFn fn, void *user_, ArenaProbeMultiFn multi_ = nullptr,
+                   const int *spent_launches_ = nullptr, const double *spent_ms_ = nullptr) {
         device = device_;
         budget = budget_;
         probe = fn;
         probe_multi = multi_;
         user = user_;
+        spent_launches = spent_launches_;
+        spent_ms = spent_ms_;
     }
+    // Probe budget (round 4): what the arena may spend on measurements over the life of its context -- kernel launches and
+    // device time, as the context counts them (knox_arena_info.probe_launches / probe_ms).  Placement buys 1-6 points of HBM
+    // peak on multi-GiB scans (bench.py "placement_off"); it must not cost a context more than a few tens of milliseconds.
+    // Once the budget is spent nothing is measured any more: a new chunk inherits the label of the chunk before it (the
+    // driver hands memory out in runs of 5-40 GiB of one class) and a write buffer is taken from another class's zone by
+    // label alone.  knox_ctx_set_probe_budget grants a new budget (a host does so when it has idle time to spend).
+    int budget_launches = 200;
+    double budget_ms = 50.0;
+    int spent_base_launches = 0;
+    double spent_base_ms = 0.0;
+    void grant(int launches, double ms) {
+        budget_launches = launches;
+        budget_ms = ms;
+        spent_base_launches = spent_launches ? *spent_launches : 0;
+        spent_base_ms = spent_ms ? *spent_ms : 0.0;
+    }
+    bool may_probe() const {
+        if (!probe) return false;
+        if (!spent_launches || !spent_ms) return true;
+        return *spent_launches - spent_base_launches < budget_launches && *spent_ms - spent_base_ms < budget_ms;
+    }
+    int unprobed_chunks = 0, unverified_write_buffers = 0;  // decisions taken by inheritance / by label after the budget ran out
     size_t used_bytes() const { return used; }
     size_t spare_bytes() const {
         size_t n = 0;
@@ -181,7 +206,7 @@ class Arena {
         bytes = round_up(bytes);
         if (!init_once()) return hipErrorNotSupported;
         const size_t sample = kProbeRows * 8, wrote = kProbeRows / 8;
-        constexpr int kMaxSamples = 16;  // every GiB of a column up to 16 GiB (a small write buffer can be made of fragments of several classes)
+        constexpr int kMaxSamples = 4;   // up to four 1 GiB samples spread over the column(s) (round 3: 16 -- with the bursts deferred a mixed buffer costs 2 %, not 16)
         struct Sample { const char *col; size_t boff; };
         Sample samples[kMaxSamples];
         int n_s = 0;
@@ -205,9 +230,23 @@ class Arena {
         }
         if (n_s == 0) return alloc(out, bytes, ARENA_WRITE);
         const size_t wb_bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (!may_probe()) {
+            // budget spent: the top of a zone none of the columns lies in, by label alone; failing that, anywhere
+            for (int zi = 0; zi < kMaxClasses && any_zone; zi++) {
+                if (in_zone[zi]) continue;
+                char *va = nullptr;
+                if (!zone_take_top(zi, wb_bytes, &va)) continue;
+                unverified_write_buffers++;
+                dbg("write buffer (%zu MiB) at the top of zone %d by label (probe budget spent)", wb_bytes >> 20, zi);
+                *out = va;
+                return hipSuccess;
+            }
+            return alloc(out, bytes, ARENA_WRITE);
+        }
         auto measure = [&](char *va) {
             double worst = 2.0;
             for (int i = 0; i < n_s; i++) {
+                if (i > 0 && !may_probe()) break;  // the budget ran out between samples: what was measured so far decides
                 // the short launch sequence first (6 launches); a reading near the threshold is taken again with the long form (20)
                 double r = -1.0;
                 if (probe_multi) {
@@ -258,7 +297,7 @@ class Arena {
                 } else {
                     (void)release(va);
                 }
-                if (zbest_r >= 0.99) break;
+                if (zbest_r >= kFastAbove) break;  // round 4: the first fast class is taken (class pairs differ by 0.97 against 1.00; measuring them all cost more than it bought)
             }
             if (zbest && zbest_r >= kFastAbove) {
                 if (best.va) add_spare(best);
@@ -292,7 +331,7 @@ class Arena {
         // 2. a few new ones
         bool hit = false;
         auto try_new = [&](int n_tries) {
-            for (int k = 0; k < n_tries; k++) {
+            for (int k = 0; k < n_tries && may_probe(); k++) {
                 WBuf w;
                 if (!new_wbuf(wb_bytes, &w)) return false;
                 const double r = measure(w.va);
@@ -320,7 +359,7 @@ class Arena {
         // wrong, or a column that is not class pure, must not make the search walk past the memory it is looking for.
         char *zcand = nullptr;
         double zcand_r = -1.0;
-        for (int grown = 0; any_zone && grown < max_grow && grown_for_write < 2 * max_grow; grown++) {
+        for (int grown = 0; any_zone && may_probe() && grown < max_grow && grown_for_write < 2 * max_grow; grown++) {
             const int zi = grow_zone();
             if (zi < 0) break;
             grown_for_write++;  // over the arena's life: a device whose free memory is one long run of one class is not mapped chunk by chunk in vain
@@ -468,6 +507,9 @@ class Arena {
     int device = 0;
     ArenaProbeFn probe = nullptr;
     ArenaProbeMultiFn probe_multi = nullptr;
+    const int *spent_launches = nullptr;   // the context's probe counters (knox_arena_info): what the budget is held against
+    const double *spent_ms = nullptr;
+    int last_label = 1;                    // label of the chunk labelled last: inherited by chunks taken after the budget is spent
     void *user = nullptr;
     bool inited = false;
     size_t used = 0;
@@ -669,6 +711,10 @@ class Arena {
         bool founder = false;  // the first chunk of a class not met before: its first 32 MiB become that class's reference window
         if (fake_labels) {
             label = 1 + (chunks_created & 1);  // tests: classes that interleave chunk by chunk, the worst case for class-pure zones
+        } else if (probe && !may_probe()) {
+            label = last_label;  // budget spent: the class of the chunk before (memory comes in runs of one class)
+            unprobed_chunks++;
+            dbg("chunk %d takes the label of the chunk before it (class %d): probe budget spent", chunks_created, label - 1);
         } else if (probe) {
             if (!ref.va) {
                 if (!new_wbuf(kRefBytes, &ref)) {
@@ -698,7 +744,7 @@ class Arena {
             double quick[kMaxClasses] = {0, 0, 0, 0};
             bool have_quick = false;
             static const bool quick_on = !(getenv("KNOX_ARENA_QUICK") && atoi(getenv("KNOX_ARENA_QUICK")) == 0);  // 0: long form only (A/B)
-            if (probe_multi && n_refs >= 2 && quick_on) {
+            if (probe_multi && n_refs >= 1 && quick_on) {  // round 4: also while ONE class is known (6 launches instead of 20)
                 void *refs[kMaxClasses];
                 for (int c = 0; c < n_refs; c++) refs[c] = ref_va[c];
                 have_quick = probe_multi(user, pva, kProbeRows, refs, n_refs, quick) == 0;
@@ -726,6 +772,7 @@ class Arena {
                 else cls = closest;
             }
             label = cls + 1;
+            last_label = label;
             (void)hipDeviceSynchronize();
             (void)hipMemUnmap(pva, kChunk);
             VaBump::give_back(pva, kChunk);  // the probe mapping had a reservation of its own

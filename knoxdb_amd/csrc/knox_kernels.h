@@ -305,7 +305,7 @@ hipError_t launch_generate(hipStream_t s, int width, bool to_f32, int kind, uint
 
 // literal sequential reducer (one lane)
 // out-of-order time windows (knox_sort.hip): stable LSD radix sort of (window, row, value) triples, 1..4 passes of <= 8 bits
-constexpr int kWindowSortItems = 12;  // elements per thread and tile of the scatter kernel
+constexpr int kWindowSortItems = 16;  // round 4 sweep (2^28 shuffled rows, 1024 / 16384 / 2^20 windows): 6: 3.26 / 3.95 / 9.72 ms, 8: 2.99 / 3.83 / 11.8, 12: 2.95 / 3.59 / 9.34, 16: 2.88 / 3.50 / 9.13  // elements per thread and tile of the scatter kernel
 struct WindowSortGeom {
     uint32_t nb;         // workgroups
     uint64_t per_block;  // elements per workgroup (a multiple of the tile)

@@ -349,13 +349,18 @@ class Context:
         -> True when such room exists now"""
         return self.L.knox_ctx_reserve(self.h, int(nbytes)) == 0
 
+    def set_probe_budget(self, max_launches, max_ms):
+        """what the arena may spend on probe measurements from now on (include/knoxgpu.h knox_ctx_set_probe_budget)"""
+        check(self.L.knox_ctx_set_probe_budget(self.h, int(max_launches), float(max_ms)), "knox_ctx_set_probe_budget")
+
     def arena_info(self):
         a = _lib.ArenaInfo()
         check(self.L.knox_ctx_arena_info(self.h, C.byref(a)))
         return {"budget_gib": a.budget_bytes / 2**30, "mapped_gib": a.mapped_bytes / 2**30, "used_gib": a.used_bytes / 2**30,
                 "peak_used_gib": a.peak_used_bytes / 2**30, "write_buffers": a.write_buffers, "chunks": a.chunks, "probes": a.probes,
                 "enabled": bool(a.enabled), "mixed_zone_gib": a.mixed_zone_bytes / 2**30,
-                "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30, "probe_launches": a.probe_launches, "probe_ms": a.probe_ms}
+                "spare_write_buffer_gib": a.spare_write_buffer_bytes / 2**30, "probe_launches": a.probe_launches, "probe_ms": a.probe_ms,
+                "unprobed_chunks": a.unprobed_chunks, "unverified_write_buffers": a.unverified_write_buffers}
 
     def arena_classes(self):
         """-> (GiB of column space per placement class, classes met); include/knoxgpu.h knox_ctx_arena_classes"""

@@ -152,6 +152,12 @@ static int64_t simd_scan(const int64_t *src, int64_t n, int64_t pack_rows, int64
     const int64_t n_packs = (n + pack_rows - 1) / pack_rows;
     pthread_t tid[256];
     job_t jobs[256];
+    if (threads == 1) { /* on the calling thread: what a cmp call on one goroutine is (tools/cmp_latency.py times small vectors) */
+        jobs[0] = (job_t){src, n, pack_rows, a, b, bits, 0, n_packs, 0, 0, level};
+        worker(&jobs[0]);
+        *sum_out = jobs[0].sum;
+        return jobs[0].count;
+    }
     for (int t = 0; t < threads; t++) {
         jobs[t] = (job_t){src, n, pack_rows, a, b, bits, n_packs * t / threads, n_packs * (t + 1) / threads, 0, 0, level};
         pthread_create(&tid[t], NULL, worker, &jobs[t]);

@@ -137,3 +137,26 @@ def test_the_checker_rejects_a_context_call_outside_the_lock(tmp_path):
     text = "\n".join(errors)
     assert "knox_bits_free: called without the context's lock" in text
     assert "knox_bits_alloc: called without the context's lock" in text
+
+
+def test_cmp_rebinding_has_a_row_floor_and_a_context_pool(tmp_path):
+    """round-3 review item 5: a rebound cmp func var below knoxgpu.CmpMinRows rows calls the kernel installed before (a
+    device round trip cannot answer a 2^16-row pack in the 4.5-7.4 us the AVX2 kernel takes), and the calls above it take
+    a context from a pool instead of queueing behind one mutex; the checker enforces Get / deferred Put pairs."""
+    src = open(os.path.join(GO, "cmp_knoxgpu.go")).read()
+    lib = open(os.path.join(GO, "knoxgpu", "knoxgpu.go")).read()
+    assert "var CmpMinRows = func() int {" in lib and 'os.Getenv("KNOX_CMP_MIN_ROWS")' in lib and "type Pool struct" in lib
+    for fn in ("bind1", "bind2", "bind128", "bind256"):
+        body = src[src.index("func %s" % fn):]
+        body = body[:body.index("\n}\n")]
+        assert "knoxgpu.CmpMinRows" in body and "gpus.Get()" in body and "defer gpus.Put(gpu)" in body, fn
+        assert body.index("knoxgpu.CmpMinRows") < body.index("gpus.Get()"), fn     # the floor comes first: short vectors never wait for a context
+    assert src.count("gpus.Get()") == src.count("defer gpus.Put(gpu)") == 6         # + the two Between closures of Int128 / Int256
+    mod = _checker()
+    work = tmp_path / "go"
+    shutil.copytree(GO, work)
+    path = work / "cmp_knoxgpu.go"
+    path.write_text(path.read_text().replace("\t\tgpu := gpus.Get()\n\t\tdefer gpus.Put(gpu)\n", "\t\tgpu := gpus.Get()\n", 1))
+    mod.GO_DIR = str(work)
+    errors, _, _, _ = mod.check()
+    assert any("is not followed by `defer gpus.Put(gpu)`" in e for e in errors), errors
