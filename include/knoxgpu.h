@@ -616,6 +616,11 @@ int knox_bloom_upload(knox_ctx *ctx, const uint8_t *filters, const uint64_t *off
 int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out);
 int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor, knox_bloom **out);
 size_t knox_bloom_packs(const knox_bloom *b);
+/* How a built filter set came about (diagnostics): batches of packs the build ran in, and how many of them took the exact
+ * count / scan / bin / fill passes -- because a fixed entry region of the one-read build overflowed (heavy hitters in a
+ * column whose filters are sized for many distinct values) or the first batch said the column is of that kind.  The bytes
+ * are the same either way.                                                                                           */
+int knox_bloom_build_info(const knox_bloom *b, int *batches, int *exact_batches);
 size_t knox_bloom_bytes(const knox_bloom *b);
 int knox_bloom_download(knox_ctx *ctx, const knox_bloom *b, uint8_t *filters, size_t filters_cap,
                         uint64_t *offsets /* n_packs+1 */);

@@ -161,13 +161,14 @@ func Cmp[T Number](c *Ctx, dtype, mode int, src []T, a, b T, bits []byte) (int64
 // synchronisation, a copy of the bitset -- and below the floor one CPU core answers sooner: the reference's AVX2 kernel
 // takes 4.5-7.4 us for a 2^16-row pack (docs/bench/2020-10-d3f9115/Xeon-E-2176G/README.md:54,63), the device call ~25 us
 // plus the PCIe time of the vector.  Default = the crossover measured on the MI355X box with the vector in page-locked
-// memory (tools/cmp_latency.py, DESIGN.md 7): 2^21 rows.  KNOX_CMP_MIN_ROWS overrides it (0 = every call goes to the
+// memory (tools/cmp_latency.py, DESIGN.md 7): 2^23 rows -- below it one AVX2 core is 1.04-7 x faster, above it PCIe (~6 G
+// rows/s) and one core's memory stream (~5.7 G rows/s) are level, so the rebinding is plumbing, not a speed-up.  KNOX_CMP_MIN_ROWS overrides it (0 = every call goes to the
 // device: tests).  The throughput path is not this one: runs of packs resident in HBM go through table.GpuRun.
 var CmpMinRows = func() int {
 	if v, err := strconv.Atoi(os.Getenv("KNOX_CMP_MIN_ROWS")); err == nil && v >= 0 {
 		return v
 	}
-	return 1 << 21
+	return 1 << 23
 }()
 
 // Pool hands out contexts to calls that would otherwise serialise on one: the reference runs many queries at once (one

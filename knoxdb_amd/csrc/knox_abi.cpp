@@ -125,6 +125,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
         if (r.h_res) hipHostFree(r.h_res);
         if (ctx->h_view) { hipHostFree(ctx->h_view); ctx->h_view = nullptr; }
         if (ctx->cmp_res) { hipHostFree(ctx->cmp_res); ctx->cmp_res = nullptr; }
+        if (ctx->bloom_flags) { hipHostFree(ctx->bloom_flags); ctx->bloom_flags = nullptr; }
         if (r.h_packs) hipHostFree(r.h_packs);
         if (r.done) hipEventDestroy(r.done);
     }

@@ -278,6 +278,8 @@ class Arena {
         // 0. memory of a KNOWN other class, if some has been met: column chunks are labelled by class (grow_zone), so a range
         //    at the top of another class's zone is fast with this column by construction -- verified like every candidate
         bool zone_failed[kMaxClasses] = {false, false, false, false};
+        int zone_best_zi = -1;        // the best zone candidate seen that was NOT fast enough to end the search: still better than
+        double zone_best_r = -1.0;    // a slower fresh buffer when nothing fast turns up (round 4: a 0.933 zone was dropped for a 0.875 buffer)
         auto try_zones = [&]() {
             // every other class with room is measured: class pairs differ (0.97 against 1.00 of the read-only rate), the
             // best one is taken; the first at >= 0.99 ends the search
@@ -290,6 +292,7 @@ class Arena {
                 const double r = measure(va);
                 dbg("write buffer (%zu MiB) at the top of zone %d vs the column(s): %.3f", wb_bytes >> 20, zi, r);
                 if (r < kFastAbove) zone_failed[zi] = true;  // its label says "another class" and the pair is slow all the same: leave that zone alone
+                if (r < kFastAbove && r > zone_best_r) { zone_best_r = r; zone_best_zi = zi; }
                 if (r > zbest_r) {
                     if (zbest) (void)release(zbest);
                     zbest = va;
@@ -399,6 +402,16 @@ class Arena {
             return hipSuccess;
         }
         if (zcand) (void)release(zcand);
+        if (zone_best_zi >= 0 && zone_best_r > best_r) {  // a zone that measured below the bar earlier, but above everything else
+            char *va = nullptr;
+            if (zone_take_top(zone_best_zi, wb_bytes, &va)) {
+                if (best.va) add_spare(best);
+                *out = va;
+                if (ratio_out) *ratio_out = zone_best_r;
+                dbg("nothing fast within reach: the top of zone %d after all (%.3f)", zone_best_zi, zone_best_r);
+                return hipSuccess;
+            }
+        }
         dbg("nothing fast within reach: the best candidate (%.3f)", best_r);
         // Nothing fast within reach (the free memory around is all of the column's class, a run longer than what was
         // looked at): the best candidate there is.  An earlier version then skipped ahead in the driver's allocation order

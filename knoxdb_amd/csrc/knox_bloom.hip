@@ -376,6 +376,225 @@ __global__ void __launch_bounds__(kBlock) bloom_fill_kernel(uint64_t p0, uint32_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the build reads the column ONCE.  The count / scan passes above exist to give every (pack, segment) its exact
+// place in the entries; what they buy is exactness under any distribution, what they cost is a second read (and, for bytes
+// columns, a second XXH3) of every row.  Hashed locations are uniform, so a segment's entry count is known in advance up
+// to sqrt noise: every (pack, segment) gets a FIXED region of
+//     cap = mean + mean / 8 + 256 entries,      mean = 4 * pack_rows / segments   (2^20-row packs: 16384 -> 18688; 16 sigma)
+// and tiles reserve ranges in it with one atomicAdd per (tile, segment) on the segment's cursor -- no count pass, no scan.
+//   bloom_bin1_kernel   per tile of 4096 rows: hash (once), ONE LDS pass (atomicAdd with return: the entry's rank inside its
+//                       (tile, segment) run -- the count and the position pass of bloom_bin_kernel in one), scan of the 256
+//                       run lengths, one global atomicAdd per non-empty run, reorder through LDS (one 32-bit word per
+//                       entry: segment | offset, half the LDS operations of the two sub-dword arrays), contiguous 16-bit
+//                       runs out.  A run that does not fit its region any more sets the batch's overflow flag (and is cut).
+//   bloom_fill2_kernel  one workgroup per (pack, 8 segments): the regions start 16-byte aligned, so a lane takes eight
+//                       entries per load (the first version's 2-byte loads: 2.7 TB/s); ds_or; one coalesced store.
+// Heavy hitters (a value in a large share of a pack's rows while the filter is sized for many distinct values) overflow
+// their four segments.  OR is idempotent, but the regions are not sets: the host reads the flag after the batch and runs
+// the exact count / scan / bin / fill passes for that batch (and the rest of the column) -- same bytes either way
+// (tests/test_gpu_misc.py builds such a column).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t bloom_seg_count(uint64_t fbytes) { return (uint32_t)((fbytes * 8 + (1u << kSegShift) - 1) >> kSegShift); }
+__host__ __device__ inline uint32_t bloom_seg_cap(uint64_t pack_rows, uint32_t n_seg) {
+    const uint64_t mean = (pack_rows * 4 + n_seg - 1) / n_seg;
+    return (uint32_t)((mean + mean / 8 + 256 + 7) & ~7ull);  // a multiple of 8 entries: every region starts 16-byte aligned
+}
+
+template <int W, typename H>
+__global__ void __launch_bounds__(kBlock) bloom_bin1_kernel(H hasher, uint64_t n_rows, uint64_t pack_rows, uint64_t p0, uint32_t tiles_pp,
+                                                            const uint64_t *offsets, uint32_t *seg_cursor, uint16_t *entries, uint64_t entries_pp,
+                                                            uint32_t *overflow_flag) {
+    __shared__ uint32_t hist[256];    // the tile's run length per segment (filled by the ranking pass)
+    __shared__ uint32_t lstart[256];  // the run's start inside the tile's sorted order
+    __shared__ uint32_t gpos[256];    // where the run goes inside its segment's region
+    __shared__ uint32_t wsum[kBlock / 64];
+    __shared__ uint32_t sorted[kBinSlots];  // segment << 16 | in-segment offset
+    const uint32_t tile = blockIdx.x % tiles_pp;
+    const uint64_t pl = blockIdx.x / tiles_pp, p = p0 + pl;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    const uint64_t fbytes = o1 - o0 - 1;
+    const uint32_t mask = (uint32_t)(fbytes * 8 - 1);
+    const uint32_t cap = bloom_seg_cap(pack_rows, bloom_seg_count(fbytes));
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t h[kBinRowsPerThread];
+    const uint32_t valid = bloom_tile_hashes<W>(hasher, p, pack_rows, n_rows, tile, h);
+    // ranks of this thread's 64 locations inside their (tile, segment) runs, two per register
+    uint32_t rank2[kBinRowsPerThread * 2];
+#pragma unroll
+    for (int i = 0; i < kBinRowsPerThread; i++) {
+        uint32_t h0 = (uint32_t)h[i];
+        const uint32_t h1 = (uint32_t)(h[i] >> 32);
+        uint32_t r[4] = {0, 0, 0, 0};
+        if (valid & (1u << i)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[k] = atomicAdd(&hist[(h0 & mask) >> kSegShift], 1u);
+                h0 += h1;
+            }
+        }
+        rank2[2 * i] = r[0] | (r[1] << 16);      // a run holds at most 16384 entries
+        rank2[2 * i + 1] = r[2] | (r[3] << 16);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = hist[threadIdx.x];
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    lstart[threadIdx.x] = base + incl - c;
+    uint32_t g = 0;
+    if (c) {
+        g = atomicAdd(&seg_cursor[pl * 256 + threadIdx.x], c);
+        if (g + c > cap) atomicOr(overflow_flag, 1u);
+    }
+    gpos[threadIdx.x] = g;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBinRowsPerThread; i++) {
+        if (valid & (1u << i)) {
+            uint32_t h0 = (uint32_t)h[i];
+            const uint32_t h1 = (uint32_t)(h[i] >> 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t loc = h0 & mask;
+                const uint32_t rk = (rank2[2 * i + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu;
+                sorted[lstart[loc >> kSegShift] + rk] = loc;   // loc = segment << 16 | offset
+                h0 += h1;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint16_t *dst = entries + pl * entries_pp;
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+        const uint32_t e = sorted[i];
+        const uint32_t sg = e >> kSegShift;
+        const uint32_t at = gpos[sg] + (i - lstart[sg]);
+        if (at < cap) dst[(uint64_t)sg * cap + at] = (uint16_t)e;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bloom_fill2_kernel(uint64_t pack_rows, uint64_t p0, uint32_t groups_pp, uint8_t *filters, const uint64_t *offsets,
+                                                             const uint16_t *entries, uint64_t entries_pp, const uint32_t *seg_cursor) {
+    __shared__ uint32_t bm[kFillSegs * 2048 + 4];
+    const uint32_t g = blockIdx.x % groups_pp;
+    const uint64_t pl = blockIdx.x / groups_pp, p = p0 + pl;
+    const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
+    if (o1 <= o0 + 1) return;
+    const uint64_t fbytes = o1 - o0 - 1;
+    const uint32_t n_seg = bloom_seg_count(fbytes);
+    const uint32_t cap = bloom_seg_cap(pack_rows, n_seg);
+    const uint32_t seg0 = g * kFillSegs;
+    if (seg0 >= n_seg) return;
+    if (g == 0 && threadIdx.x == 0) filters[o0] = 4;          // k (bloom.go:48-60)
+    for (int i = threadIdx.x; i < kFillSegs * 2048 + 4; i += kBlock) bm[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint16_t *pe = entries + pl * entries_pp;
+    for (uint32_t sl = wave; sl < kFillSegs && seg0 + sl < n_seg; sl += kBlock / 64) {
+        uint32_t *seg_bm = bm + sl * 2048;
+        const uint32_t cur = seg_cursor[pl * 256 + seg0 + sl];
+        const uint32_t cnt = cur < cap ? cur : cap;
+        const u32x4 *src = (const u32x4 *)(pe + (uint64_t)(seg0 + sl) * cap);   // 16-byte aligned: cap and entries_pp are multiples of 8 entries
+        const uint32_t n_vec = (cnt + 7) >> 3;
+        constexpr int U = 4;                                  // 4 x 16 bytes in flight per lane
+        for (uint32_t v0 = lane; v0 < n_vec; v0 += 64 * U) {
+            u32x4 r[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t v = v0 + (uint32_t)u * 64;
+                r[u] = v < n_vec ? __builtin_nontemporal_load(src + v) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t v = v0 + (uint32_t)u * 64;
+                if (v >= n_vec) break;
+                const uint32_t left = cnt - v * 8;            // entries of this vector that exist (>= 1)
+                const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if ((uint32_t)j < left) {
+                        const uint32_t off = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                        atomicOr(&seg_bm[off >> 5], 1u << (off & 31));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // write out: the bit array starts at filters + o0 + 1 (any byte alignment)
+    uint64_t nbytes = fbytes - (uint64_t)seg0 * 8192;
+    if (nbytes > (uint64_t)kFillSegs * 8192) nbytes = (uint64_t)kFillSegs * 8192;
+    uint8_t *dst = filters + o0 + 1 + (uint64_t)seg0 * 8192;
+    const uint8_t *bmb = (const uint8_t *)bm;
+    uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (head > nbytes) head = (uint32_t)nbytes;
+    const uint32_t nd = (uint32_t)((nbytes - head) >> 2);     // aligned dwords
+    const uint32_t tail0 = head + nd * 4;
+    if (threadIdx.x < head) dst[threadIdx.x] = bmb[threadIdx.x];
+    if (threadIdx.x >= 8 && threadIdx.x - 8 < nbytes - tail0) dst[tail0 + threadIdx.x - 8] = bmb[tail0 + threadIdx.x - 8];
+    uint32_t *dw = (uint32_t *)(dst + head);
+    for (uint32_t j = threadIdx.x; j < nd; j += kBlock) {
+        const uint32_t b = head + 4 * j;                      // byte offset inside the bitmap
+        const uint32_t w0 = bm[b >> 2], w1 = bm[(b >> 2) + 1];
+        dw[j] = __builtin_amdgcn_alignbyte(w1, w0, b & 3);
+    }
+}
+
+// scratch of a one-read batch: fixed regions (n_seg x cap entries per pack, sized for the largest filter), the cursors, the flag
+static uint64_t bloom_one_entries_pp(uint64_t pack_rows, uint64_t max_fbytes) {
+    const uint32_t n_seg = bloom_seg_count(max_fbytes);
+    return (uint64_t)n_seg * bloom_seg_cap(pack_rows, n_seg) + 1024;  // + slack: a pack with a smaller filter has fewer, larger regions (rounding)
+}
+size_t bloom_one_scratch_bytes(uint64_t packs, uint64_t pack_rows, uint64_t max_fbytes) {
+    return (size_t)packs * (bloom_one_entries_pp(pack_rows, max_fbytes) * 2 + 256 * 4) + 512;
+}
+
+// packs [p0, p0 + np) through the one-read build.  *overflow_flag_dev (a device word inside scratch, zeroed here) is non-zero
+// afterwards when some region overflowed: the caller then rebuilds these packs with launch_bloom_build_part.
+hipError_t launch_bloom_build_one(hipStream_t s, int width, const void *col, const BytesView *v, uint64_t n_rows, uint64_t pack_rows, uint64_t p0,
+                                  uint64_t np, uint64_t max_fbytes, uint8_t *filters, const uint64_t *offsets, void *scratch, uint32_t **overflow_flag_dev) {
+    if (np == 0) return hipSuccess;
+    const uint32_t tiles_pp = bloom_part_tiles(pack_rows);
+    const uint64_t epp = bloom_one_entries_pp(pack_rows, max_fbytes);
+    uint16_t *entries = (uint16_t *)scratch;
+    uint32_t *seg_cursor = (uint32_t *)(entries + np * epp);
+    uint32_t *flag = seg_cursor + np * 256;
+    *overflow_flag_dev = flag;
+    hipError_t e = hipMemsetAsync(seg_cursor, 0, np * 256 * 4 + 64, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid1((unsigned)(np * tiles_pp)), block(kBlock);
+    if (width == 0) {
+        HashBytes hb{v->ptr, v->buf, v->pool_base};
+        hipLaunchKernelGGL((bloom_bin1_kernel<8, HashBytes>), grid1, block, 0, s, hb, n_rows, pack_rows, p0, tiles_pp, offsets, seg_cursor, entries, epp, flag);
+    } else {
+        HashNumeric hn{col};
+        switch (width) {
+        case 8: hipLaunchKernelGGL((bloom_bin1_kernel<8, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, seg_cursor, entries, epp, flag); break;
+        case 4: hipLaunchKernelGGL((bloom_bin1_kernel<4, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, seg_cursor, entries, epp, flag); break;
+        case 2: hipLaunchKernelGGL((bloom_bin1_kernel<2, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, seg_cursor, entries, epp, flag); break;
+        case 1: hipLaunchKernelGGL((bloom_bin1_kernel<1, HashNumeric>), grid1, block, 0, s, hn, n_rows, pack_rows, p0, tiles_pp, offsets, seg_cursor, entries, epp, flag); break;
+        default: return hipErrorInvalidValue;
+        }
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint32_t n_seg = bloom_seg_count(max_fbytes);
+    const uint32_t groups_pp = (n_seg + kFillSegs - 1) / kFillSegs;
+    hipLaunchKernelGGL(bloom_fill2_kernel, dim3((unsigned)(np * groups_pp)), block, 0, s, pack_rows, p0, groups_pp, filters, offsets, entries, epp, seg_cursor);
+    return hipGetLastError();
+}
+
 uint32_t bloom_part_tiles(uint64_t pack_rows) { return (uint32_t)((pack_rows + kBinTileRows - 1) / kBinTileRows); }
 static uint64_t bloom_entries_pp(uint64_t pack_rows) { return (pack_rows * 4 + 127) & ~(uint64_t)127; }
 // scratch of a batch: the 16-bit entries (8 B per row), the segment counts / cursors and the segment bases of every pack

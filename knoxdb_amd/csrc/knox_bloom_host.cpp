@@ -45,6 +45,7 @@ struct knox_bloom {
     uint64_t *d_offsets = nullptr;
     uint8_t *d_maybe = nullptr;
     size_t n_packs = 0, bytes = 0;
+    int batches = 0, exact_batches = 0;  // how the filters were built (knox_bloom_build_info)
     std::vector<uint64_t> h_offsets;
 };
 
@@ -115,17 +116,52 @@ KNOX_API int knox_bloom_build(knox_ctx *ctx, const knox_col *col, int factor, kn
         // partitioned build (knox_bloom.hip): probe locations binned by filter segment, every segment OR-ed together in LDS
         // and stored once.  Batches of packs bound the scratch (8 B per row + 2 KiB per pack) to ~1 GiB
         const BytesView bv = col->dtype == KNOX_BYTES ? bytes_view(col, col->n_rows) : BytesView();
-        size_t batch = std::max<size_t>(1, ((size_t)1 << 30) / bloom_part_scratch_bytes(1, col->pack_rows));
+        const int width = col->dtype == KNOX_BYTES ? 0 : col->width;
+        // Round 4: the one-read build (fixed entry regions, no count pass) first; a batch whose regions overflow -- heavy hitters
+        // in a column whose filters are sized for many distinct values -- is rebuilt with the exact count / scan / bin / fill
+        // passes, and if the FIRST batch overflows the rest of the column goes the exact way at once.  KNOX_BLOOM_EXACT=1: exact only.
+        static const bool one_on = !(getenv("KNOX_BLOOM_EXACT") && atoi(getenv("KNOX_BLOOM_EXACT")) != 0);
+        const size_t per_pack = std::max(bloom_part_scratch_bytes(1, col->pack_rows), bloom_one_scratch_bytes(1, col->pack_rows, max_fbytes));
+        size_t batch = std::max<size_t>(1, ((size_t)1 << 30) / per_pack);
         batch = std::min(batch, n_packs);
-        rc = ensure(ctx, ctx->sort_buf, bloom_part_scratch_bytes(batch, col->pack_rows) + 256, ARENA_WRITE);
+        const size_t n_batches = (n_packs + batch - 1) / batch;
+        rc = ensure(ctx, ctx->sort_buf, std::max(bloom_part_scratch_bytes(batch, col->pack_rows), bloom_one_scratch_bytes(batch, col->pack_rows, max_fbytes)) + 256,
+                    ARENA_WRITE);
+        if (!rc) rc = ensure_host(ctx, ctx->bloom_flags, ctx->bloom_flags_cap, n_batches * 4 + 64);
         if (rc) {
             knox_bloom_free(b);
             *out = nullptr;
             return rc;
         }
-        for (size_t p0 = 0; p0 < n_packs && e == hipSuccess; p0 += batch)
-            e = launch_bloom_build_part(ctx->stream, col->dtype == KNOX_BYTES ? 0 : col->width, col->dev, &bv, col->n_rows, col->pack_rows, p0,
-                                        std::min(batch, n_packs - p0), max_fbytes, b->d_filters, b->d_offsets, ctx->sort_buf.p);
+        uint32_t *h_flags = (uint32_t *)ctx->bloom_flags;   // page-locked: one word per batch, copied behind the batch, read after one sync
+        bool exact = !one_on;
+        for (size_t bi = 0, p0 = 0; p0 < n_packs && e == hipSuccess; p0 += batch, bi++) {
+            const size_t np = std::min(batch, n_packs - p0);
+            h_flags[bi] = exact ? 2u : 0u;             // 2: built exactly, nothing to check
+            b->batches++;
+            if (exact) {
+                b->exact_batches++;
+                e = launch_bloom_build_part(ctx->stream, width, col->dev, &bv, col->n_rows, col->pack_rows, p0, np, max_fbytes, b->d_filters, b->d_offsets,
+                                            ctx->sort_buf.p);
+                continue;
+            }
+            uint32_t *d_flag = nullptr;
+            e = launch_bloom_build_one(ctx->stream, width, col->dev, &bv, col->n_rows, col->pack_rows, p0, np, max_fbytes, b->d_filters, b->d_offsets,
+                                       ctx->sort_buf.p, &d_flag);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_flags[bi], d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess && bi == 0 && n_batches > 1) {
+                e = hipStreamSynchronize(ctx->stream);  // the first batch decides how the rest is built
+                exact = e == hipSuccess && h_flags[0] != 0;
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (size_t bi = 0, p0 = 0; p0 < n_packs && e == hipSuccess; p0 += batch, bi++) {
+            if (h_flags[bi] != 1u) continue;           // 1: a region of this batch overflowed
+            e = launch_bloom_build_part(ctx->stream, width, col->dev, &bv, col->n_rows, col->pack_rows, p0, std::min(batch, n_packs - p0), max_fbytes,
+                                        b->d_filters, b->d_offsets, ctx->sort_buf.p);
+            ctx->bloom_exact_batches++;
+            b->exact_batches++;
+        }
     } else {
         e = hipMemsetAsync(b->d_filters, 0, b->bytes, ctx->stream);
         if (e == hipSuccess)
@@ -148,6 +184,12 @@ KNOX_API int knox_bloom_build_u64(knox_ctx *ctx, const knox_col *col, int factor
 }
 
 KNOX_API size_t knox_bloom_packs(const knox_bloom *b) { return b ? b->n_packs : 0; }
+KNOX_API int knox_bloom_build_info(const knox_bloom *b, int *batches, int *exact_batches) {
+    if (!b || !batches || !exact_batches) return KNOX_E_INVALID;
+    *batches = b->batches;
+    *exact_batches = b->exact_batches;
+    return KNOX_OK;
+}
 KNOX_API size_t knox_bloom_bytes(const knox_bloom *b) { return b ? b->bytes : 0; }
 
 KNOX_API int knox_bloom_download(knox_ctx *ctx, const knox_bloom *b, uint8_t *filters, size_t filters_cap, uint64_t *offsets) {

@@ -184,6 +184,9 @@ struct knox_ctx {
     // whole follow-up work -- finalize + per-pack counts -- is ONE launch (post_packs): what a step costs beyond the scan
     // kernel is ~6.5 us of dispatch gap per dependent launch, so two launches and a copy become one launch
     char *res_dst = nullptr;
+    void *bloom_flags = nullptr;  // page-locked overflow flags of a bloom build's batches
+    size_t bloom_flags_cap = 0;
+    int bloom_exact_batches = 0;  // batches of bloom builds that overflowed the one-read regions and were rebuilt exactly (diagnostics)
     void *cmp_res = nullptr;     // knox_cmp's page-locked result block (same layout as a slot's mirror)
     size_t cmp_res_cap = 0;
     size_t post_packs = 0;       // != 0: run_fused also writes this many per-pack counts at res_dst + post_packs_off

@@ -240,6 +240,12 @@ hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint6
 hipError_t launch_bloom_build_bytes(hipStream_t s, const BytesView &v, uint8_t *filters, const uint64_t *offsets);
 // partitioned (atomic-free) build of packs [p0, p0 + np): packs of >= 4096 rows, filters of <= 2 MiB (256 segments of 2^16 bits)
 size_t bloom_part_scratch_bytes(uint64_t packs, uint64_t pack_rows);
+// the one-read build (round 4): fixed entry regions per (pack, segment), no count pass; *overflow_flag_dev != 0 afterwards =
+// a region overflowed (heavy hitters), rebuild the batch with launch_bloom_build_part
+size_t bloom_one_scratch_bytes(uint64_t packs, uint64_t pack_rows, uint64_t max_fbytes);
+hipError_t launch_bloom_build_one(hipStream_t s, int width /* 0 = bytes */, const void *col, const BytesView *v, uint64_t n_rows, uint64_t pack_rows,
+                                  uint64_t p0, uint64_t np, uint64_t max_fbytes, uint8_t *filters, const uint64_t *offsets, void *scratch,
+                                  uint32_t **overflow_flag_dev);
 uint32_t bloom_part_tiles(uint64_t pack_rows);
 hipError_t launch_bloom_build_part(hipStream_t s, int width /* 0 = bytes */, const void *col, const BytesView *v, uint64_t n_rows, uint64_t pack_rows,
                                    uint64_t p0, uint64_t np, uint64_t max_filter_bytes, uint8_t *filters, const uint64_t *offsets, void *scratch);

@@ -760,6 +760,12 @@ class Bloom:
     def packs(self):
         return _lib.lib().knox_bloom_packs(self.h)
 
+    def build_info(self):
+        """-> (batches the build ran in, batches that took the exact passes); include/knoxgpu.h knox_bloom_build_info"""
+        a, b = C.c_int(), C.c_int()
+        check(_lib.lib().knox_bloom_build_info(self.h, C.byref(a), C.byref(b)), "knox_bloom_build_info")
+        return a.value, b.value
+
     def download(self):
         nbytes = _lib.lib().knox_bloom_bytes(self.h)
         filters = np.zeros(nbytes, dtype=np.uint8)

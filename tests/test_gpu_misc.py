@@ -96,6 +96,40 @@ def test_bloom_build_every_width_matches_reference_hashes(ctx, bt):
     bloom.free()
 
 
+def _oracle_filters(x, pack, factor=2):
+    """per-pack filters as the reference builds them (bloom.go:48-60,162-169), one bloom.Add per DISTINCT value (OR is idempotent)"""
+    out = []
+    for p0 in range(0, len(x), pack):
+        vals = x[p0:p0 + pack]
+        f = O.bloom_new(len(vals), factor)
+        for v in np.unique(vals):
+            O.bloom_add(f, O.lib().ko_xxh3_u64(int(v)))
+        out.append(f)
+    return out
+
+
+def test_bloom_build_one_read_and_its_exact_fallback(ctx):
+    """Round 4: the build reads the column once, binning probe locations into FIXED regions per (pack, filter segment); a
+    heavy hitter overflows its four segments' regions and the batch is rebuilt with the exact count / scan / bin / fill
+    passes.  Both ways the filters are the reference's, byte for byte: a uniform column (one-read path, no exact batch), a
+    column where one value fills half of every pack (exact fallback), and one with a short last pack."""
+    rng = np.random.default_rng(17)
+    pack = 1 << 16
+    for name, n, hitter in (("uniform", 3 * pack, False), ("heavy hitter", 2 * pack, True), ("short last pack", 2 * pack + 5000, False)):
+        x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        if hitter:
+            x[rng.random(n) < 0.5] = np.uint64(0x1234567890ABCDEF)
+        col = ctx.upload(x, pack)
+        bloom = ctx.bloom_build(col, 2)
+        batches, exact = bloom.build_info()
+        assert batches >= 1 and (exact >= 1) == hitter, (name, batches, exact)
+        filters, offsets = bloom.download()
+        for p, f in enumerate(_oracle_filters(x, pack)):
+            got = filters[int(offsets[p]):int(offsets[p + 1])]
+            assert got.size == f.size and (got == f).all(), (name, p, int((got != f).sum()))
+        col.free(); bloom.free()
+
+
 def test_bloom_build_bytes_column(ctx):
     """device bloom build over a bytes (StringPool) column: XXH3-64 of every row on the device, filters
     byte-identical to the oracle's construction; lengths 0..300 cover every branch of the hash"""
