@@ -887,3 +887,190 @@ KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint6
     return KNOX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dictionary [5] and run-end [3] integer containers kept ENCODED in HBM and scanned as they are (round 4).  The reference
+// matches on these containers without materializing them (internal/encode/int_dict.go:181-380: the compare runs on the
+// uint16 codes; int_runend.go:224-330: on the run values, hit runs become row ranges); round 3 expanded them to full-width
+// vectors at upload.  Here the children are decoded on the device (any integer container the reference nests there: raw,
+// bit-packed, constant, delta, simple8) but the container itself is not: a dictionary column holds 2 B per row + its
+// dictionaries, a run-end column (W + 4) B per run.  The bytes that cross PCIe are the container's own.
+// ------------------------------------------------------------------------------------------------
+struct knox_enc {
+    knox_ctx *ctx;
+    int dtype, kind;           // kind = the container type: 5 dictionary, 3 run-end
+    size_t n_rows, pack_rows, n_packs;
+    void *d_vals = nullptr;    // dictionary entries / run values of all packs
+    uint16_t *d_codes = nullptr;
+    uint32_t *d_ends = nullptr;
+    EncPack *d_packs = nullptr;
+    size_t n_vals = 0, resident_bytes = 0, container_bytes = 0;
+};
+
+KNOX_API int knox_enc_free(knox_enc *e) {
+    if (!e) return KNOX_E_INVALID;
+    hipSetDevice(e->ctx->device);
+    hipStreamSynchronize(e->ctx->stream);
+    if (e->d_vals) dev_free(e->ctx, e->d_vals);
+    if (e->d_codes) dev_free(e->ctx, e->d_codes);
+    if (e->d_ends) dev_free(e->ctx, e->d_ends);
+    if (e->d_packs) dev_free(e->ctx, e->d_packs);
+    delete e;
+    return KNOX_OK;
+}
+KNOX_API size_t knox_enc_rows(const knox_enc *e) { return e ? e->n_rows : 0; }
+KNOX_API size_t knox_enc_bytes(const knox_enc *e) { return e ? e->resident_bytes : 0; }
+KNOX_API size_t knox_enc_container_bytes(const knox_enc *e) { return e ? e->container_bytes : 0; }
+KNOX_API int knox_enc_kind(const knox_enc *e) { return e ? e->kind : 0; }
+
+KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs, size_t pack_rows, knox_enc **out) {
+    if (!ctx || !out || !n_bufs || !bufs || !lens || dtype_width(dtype) == 0 || dtype == KNOX_BYTES) return KNOX_E_INVALID;
+    if (dtype_is_float(dtype)) return KNOX_E_UNSUPPORTED;  // float dictionaries / runs ([12] / [11]) take the decoding path
+    if (pack_rows == 0 || (pack_rows % kEncChunkRows) || n_bufs > 0xffffffffull) return KNOX_E_INVALID;  // whole 8192-row chunks
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    const int w = dtype_width(dtype);
+    // pass 1: headers -- kind, children, element counts
+    struct Child { size_t off1, len1, n1, off2, len2, n2; };
+    std::vector<Child> ch(n_bufs);
+    int kind = 0;
+    size_t total_vals = 0, total_bytes = 0;
+    for (size_t i = 0; i < n_bufs; i++) {
+        const uint8_t *b = bufs[i];
+        if (!b || lens[i] < 3) return KNOX_E_INVALID;
+        if (b[0] != 5 && b[0] != 3) return KNOX_E_UNSUPPORTED;
+        if (i == 0) kind = b[0];
+        if (b[0] != kind) return KNOX_E_UNSUPPORTED;  // one kind per column (a mixed run of packs takes the decoding path)
+        size_t n1 = 0, c1 = 0, n2 = 0, c2 = 0;
+        if (b[1] == 3 || b[1] == 5) return KNOX_E_UNSUPPORTED;  // a nested dictionary / run-end child reports its rows late
+        int rc = container_measure(b + 1, lens[i] - 1, w, false, &n1, &c1, 1);
+        if (rc) return rc;
+        if (1 + c1 >= lens[i]) return KNOX_E_RANGE;
+        if (b[1 + c1] == 3 || b[1 + c1] == 5) return KNOX_E_UNSUPPORTED;
+        rc = container_measure(b + 1 + c1, lens[i] - 1 - c1, kind == 5 ? 2 : 4, false, &n2, &c2, 1);
+        if (rc) return rc;
+        if (kind == 5) {
+            if (n1 == 0 || n1 > 65536 || n2 == 0 || n2 > pack_rows || (i + 1 < n_bufs && n2 != pack_rows)) return KNOX_E_INVALID;
+        } else {
+            if (n1 == 0 || n1 != n2 || n1 > pack_rows) return KNOX_E_INVALID;
+        }
+        ch[i] = Child{1, c1, n1, 1 + c1, c2, n2};
+        total_vals += n1;
+        total_bytes += lens[i];
+    }
+    knox_enc *e = new (std::nothrow) knox_enc();
+    if (!e) return KNOX_E_NOMEM;
+    e->ctx = ctx;
+    e->dtype = dtype;
+    e->kind = kind;
+    e->pack_rows = pack_rows;
+    e->n_packs = n_bufs;
+    e->n_vals = total_vals;
+    e->container_bytes = total_bytes;
+    hipError_t he = dev_malloc(ctx, &e->d_vals, total_vals * (size_t)w + 64);
+    if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_packs, n_bufs * sizeof(EncPack) + 64);
+    if (he == hipSuccess && kind == 5) he = dev_malloc(ctx, (void **)&e->d_codes, n_bufs * pack_rows * 2 + 256);
+    if (he == hipSuccess && kind == 3) he = dev_malloc(ctx, (void **)&e->d_ends, total_vals * 4 + 64);
+    if (he != hipSuccess) {
+        ctx->last_hip = (int)he;
+        knox_enc_free(e);
+        return KNOX_E_NOMEM;
+    }
+    // pass 2: children onto the device (decoded there), pack table
+    std::vector<EncPack> packs(n_bufs);
+    size_t voff = 0, rows = 0;
+    int rc = KNOX_OK;
+    for (size_t i = 0; i < n_bufs && !rc; i++) {
+        const Child &c = ch[i];
+        rc = container_decode(ctx, bufs[i] + c.off1, c.len1, w, false, (char *)e->d_vals + voff * (size_t)w, c.n1, 1);
+        uint32_t prows = 0;
+        if (!rc && kind == 5) {
+            rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 2, false, e->d_codes + i * pack_rows, c.n2, 1);
+            prows = (uint32_t)c.n2;
+        } else if (!rc) {
+            rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 4, false, e->d_ends + voff, c.n2, 1);
+            uint32_t last = 0;  // the pack's row count = its last inclusive end + 1 (int_runend.go:109)
+            if (!rc && (hipMemcpyAsync(&last, e->d_ends + voff + (c.n2 - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess))
+                rc = KNOX_E_HIP;
+            if (!rc && ((uint64_t)last + 1 > pack_rows || (i + 1 < n_bufs && (uint64_t)last + 1 != pack_rows))) rc = KNOX_E_INVALID;
+            prows = last + 1;
+        }
+        packs[i] = EncPack{(uint64_t)voff, (uint32_t)c.n1, prows};
+        voff += c.n1;
+        rows += prows;
+    }
+    if (!rc) rc = upload(ctx, e->d_packs, packs.data(), n_bufs * sizeof(EncPack));
+    if (rc) {
+        knox_enc_free(e);
+        return rc;
+    }
+    e->n_rows = rows;
+    e->resident_bytes = total_vals * (size_t)w + (kind == 5 ? rows * 2 : total_vals * 4) + n_bufs * sizeof(EncPack);
+    *out = e;
+    return KNOX_OK;
+}
+
+KNOX_API int knox_enc_scan(knox_ctx *ctx, const knox_enc *e, int op, uint64_t a, uint64_t b, int want_sum, knox_bits *bits_out, int64_t *pack_counts,
+                           int64_t *count, knox_agg_state *sum_state) {
+    if (!ctx || !e || e->ctx != ctx || (want_sum && !sum_state)) return KNOX_E_INVALID;
+    if (bits_out && bits_out->size != e->n_rows) return KNOX_E_INVALID;
+    if (pack_counts && !bits_out) return KNOX_E_INVALID;  // per-pack counts come from the bitset
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    hipSetDevice(ctx->device);
+    LeafHost lh;
+    int rc = make_leaf(e->dtype, op, a, b, lh);
+    if (rc) return rc;
+    const int grid_max = std::max(1, ctx->n_cus * 8);
+    rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid_max + 1) * 16);
+    if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
+    if (rc) return rc;
+    EncScanArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.vals = e->d_vals;
+    ea.codes = e->d_codes;
+    ea.ends = e->d_ends;
+    ea.packs = e->d_packs;
+    ea.n_packs = (uint32_t)e->n_packs;
+    ea.width = (uint32_t)dtype_width(e->dtype);
+    ea.pack_rows = e->pack_rows;
+    ea.n_rows = e->n_rows;
+    ea.lo = lh.lo;
+    ea.diff = lh.diff;
+    ea.wmask = wmask(dtype_width(e->dtype));
+    ea.negate = lh.neg ? 1u : 0u;
+    ea.want_sum = want_sum ? 1u : 0u;
+    ea.bits = bits_out ? bits_out->dev : nullptr;
+    ea.partials = (AggPartial *)ctx->partials.p;
+    hipError_t he = hipSuccess;
+    int grid = 1;
+    prof_mark(ctx, 0);
+    if (e->kind == 5) {
+        const uint64_t n_chunks = (uint64_t)e->n_packs * (e->pack_rows / kEncChunkRows);
+        grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)std::min(grid_max, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 4)));
+        he = launch_dict_scan(ctx->stream, grid, ea);
+    } else {
+        const uint64_t n_words = (uint64_t)e->n_packs * (e->pack_rows >> 6);
+        const int grid_bits = (int)std::min<uint64_t>((n_words + kBlock - 1) / kBlock, (uint64_t)ctx->n_cus * 16);
+        grid = (int)std::min<uint64_t>(e->n_packs, (uint64_t)grid_max);
+        he = launch_runend_scan(ctx->stream, grid_bits, grid, ea);
+    }
+    prof_mark(ctx, 1);
+    if (he == hipSuccess)
+        he = launch_finalize(ctx->stream, dtype_width(e->dtype), ea.partials, grid, nullptr, 0, e->dtype, (AggStateDev *)ctx->states.p,
+                             (int64_t *)((AggStateDev *)ctx->states.p + 16));
+    if (he != hipSuccess) { ctx->last_hip = (int)he; return KNOX_E_HIP; }
+    if (pack_counts) {
+        rc = ensure(ctx, ctx->pack_counts, e->n_packs * 8 + 64);
+        if (rc) return rc;
+        he = launch_popcount_segments(ctx->stream, bits_out->dev, e->n_rows, e->pack_rows, (int64_t *)ctx->pack_counts.p, e->n_packs);
+        if (he != hipSuccess) { ctx->last_hip = (int)he; return KNOX_E_HIP; }
+        rc = download(ctx, pack_counts, ctx->pack_counts.p, e->n_packs * 8);
+        if (rc) return rc;
+    }
+    AggStateDev st;
+    HIPCHK(ctx, hipMemcpyAsync(&st, ctx->states.p, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) *count = st.count;
+    if (sum_state) memcpy(sum_state, &st, sizeof st);
+    return KNOX_OK;
+}

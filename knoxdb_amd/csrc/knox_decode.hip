@@ -124,6 +124,206 @@ hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Scan on DICTIONARY containers without materializing them (round 4).  The reference matches on the codes too
+// (DictionaryContainer.Match*, internal/encode/int_dict.go:181-380: the value is looked up in the sorted dictionary, the
+// compare runs on the uint16 codes).  Here the predicate is evaluated on every dictionary entry of the pack -- a hit bitmap
+// of <= 2^16 bits in LDS, built when a workgroup enters a pack; no assumption about the dictionary's order -- and the codes
+// stream through it: one LDS bit lookup per row, 2 B + 1/8 B of HBM traffic per row for any value width.
+// Work shape: a workgroup owns a contiguous range of 8192-row chunks (so it changes packs rarely); per chunk a wave takes
+// 2048 rows = 4 loads of 16 B per lane (8 codes); a lane's 8 result bits are OR-ed with its quad's (DPP) into one bitset
+// word per 4 lanes, and lane 4q + j stores load j's word of quad q: 64 consecutive words = 256 B per wave and chunk.
+// Sum (wrapping, of the selected VALUES): dict[code] from LDS when the pack's dictionary fits 32 KiB, else through the L2.
+// ---------------------------------------------------------------------------------------------
+template <int W> __device__ __forceinline__ uint64_t enc_load_val(const void *vals, uint64_t i) {
+    if constexpr (W == 8) return ((const uint64_t *)vals)[i];
+    else if constexpr (W == 4) return ((const uint32_t *)vals)[i];
+    else if constexpr (W == 2) return ((const uint16_t *)vals)[i];
+    else return ((const uint8_t *)vals)[i];
+}
+
+template <int W, bool SUM>
+__global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, uint64_t chunks_per_wg) {
+    __shared__ uint32_t hitmap[2048];                                   // 2^16 bits
+    __shared__ __attribute__((aligned(16))) uint8_t dvals[SUM ? kEncDictLdsBytes : 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t chunks_pp = a.pack_rows / kEncChunkRows;
+    const uint64_t n_chunks = (uint64_t)a.n_packs * chunks_pp;
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunks_per_wg;
+    const uint64_t c1 = c0 + chunks_per_wg < n_chunks ? c0 + chunks_per_wg : n_chunks;
+    Acc acc;
+    acc.init();
+    uint64_t cnt = 0, sum = 0;
+    uint32_t cur_pack = 0xffffffffu;
+    EncPack hp = {0, 0, 0};
+    bool dict_in_lds = false;
+    for (uint64_t c = c0; c < c1; c++) {
+        const uint32_t pack = (uint32_t)(c / chunks_pp);
+        if (pack != cur_pack) {  // workgroup uniform
+            __syncthreads();     // everybody is done with the previous pack's tables
+            cur_pack = pack;
+            hp = a.packs[pack];
+            for (int i = threadIdx.x; i < 2048; i += kBlock) hitmap[i] = 0;
+            __syncthreads();
+            dict_in_lds = SUM && (uint64_t)hp.len * W <= (uint64_t)kEncDictLdsBytes;
+            for (uint32_t e = threadIdx.x; e < hp.len; e += kBlock) {
+                const uint64_t v = enc_load_val<W>(a.vals, hp.off + e);
+                const bool hit = (((v - a.lo) & a.wmask) <= a.diff) != (a.negate != 0);
+                if (hit) atomicOr(&hitmap[e >> 5], 1u << (e & 31));
+                if constexpr (SUM) {
+                    if (dict_in_lds) {
+                        if constexpr (W == 8) ((uint64_t *)dvals)[e] = v;
+                        else if constexpr (W == 4) ((uint32_t *)dvals)[e] = (uint32_t)v;
+                        else if constexpr (W == 2) ((uint16_t *)dvals)[e] = (uint16_t)v;
+                        else dvals[e] = (uint8_t)v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const uint64_t in_pack = (c % chunks_pp) * kEncChunkRows + (uint64_t)wave * 2048;  // this wave's first row inside the pack
+        if (in_pack >= hp.rows) continue;                                                   // a short last pack (wave uniform)
+        const uint64_t row0 = (uint64_t)pack * a.pack_rows + in_pack;
+        const u32x4 *src = (const u32x4 *)(a.codes + row0) + lane;
+        u32x4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = __builtin_nontemporal_load(src + u * 64);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+            const uint64_t lane_row = in_pack + (uint64_t)u * 512 + (uint64_t)lane * 8;
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t code = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                uint32_t hit = (hitmap[code >> 5] >> (code & 31)) & 1u;
+                hit = (lane_row + j < hp.rows && code < hp.len) ? hit : 0u;   // rows past a short pack's end; a code outside the dictionary never matches
+                m |= hit << j;
+                if constexpr (SUM) {
+                    if (hit) sum += dict_in_lds ? (W == 8   ? ((const uint64_t *)dvals)[code]
+                                                   : W == 4 ? (uint64_t)((const uint32_t *)dvals)[code]
+                                                   : W == 2 ? (uint64_t)((const uint16_t *)dvals)[code]
+                                                            : (uint64_t)dvals[code])
+                                                : enc_load_val<W>(a.vals, hp.off + code);
+                }
+            }
+            const uint32_t word = pack_word<8>(m, lane);   // the quad's 32 rows, in all four of its lanes
+            mine = (lane & 3) == u ? word : mine;
+        }
+        cnt += (uint64_t)__builtin_popcount(mine);
+        if (a.bits != nullptr) {
+            const uint64_t wi = (row0 >> 5) + (uint64_t)(lane & 3) * 16 + (uint64_t)(lane >> 2);  // load (lane & 3), quad (lane >> 2)
+            if (wi * 32 < ((a.n_rows + 63) & ~63ull)) __builtin_nontemporal_store(mine, (uint32_t *)a.bits + wi);
+        }
+    }
+    acc.count = cnt;
+    acc.isum = sum;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+hipError_t launch_dict_scan(hipStream_t s, int grid, const EncScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+    const uint64_t n_chunks = (uint64_t)a.n_packs * (a.pack_rows / kEncChunkRows);
+    const uint64_t per = (n_chunks + (uint64_t)grid - 1) / (uint64_t)grid;
+#define KNOX_DICT(W)                                                                       \
+    if (a.want_sum) KNOX_LAUNCH((dict_scan_kernel<W, true>), grid, a, per);                \
+    KNOX_LAUNCH((dict_scan_kernel<W, false>), grid, a, per)
+    switch (a.width) {
+    case 8: KNOX_DICT(8);
+    case 4: KNOX_DICT(4);
+    case 2: KNOX_DICT(2);
+    case 1: KNOX_DICT(1);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_DICT
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scan on RUN-END containers without materializing them (round 4).  The reference compares the run VALUES and translates
+// the matching runs into row ranges (RunEndContainer.Match* -> applyMatch, internal/encode/int_runend.go:224-330).  Here:
+//   runend_bits_kernel   one lane per 64-bit bitset word: lower_bound of the word's first row in the pack's ends, then the
+//                        runs that overlap the word are walked; a run's bit range is set when its value matches.  Reads
+//                        (W + 4) B per run (through the L2: neighbouring words share runs), writes 1/8 B per row.
+//   runend_sum_kernel    one lane per run: count += length, sum += value * length (wrapping) for matching runs.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kBlock) runend_bits_kernel(const EncScanArgs a) {
+    const uint64_t words_pp = a.pack_rows >> 6;
+    const uint64_t n_words = (uint64_t)a.n_packs * words_pp;
+    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t pack = (uint32_t)(wi / words_pp);
+        const EncPack hp = a.packs[pack];
+        const uint64_t r0 = (wi % words_pp) << 6;       // first row of the word inside its pack
+        if (r0 >= hp.rows) {
+            if (wi * 64 < ((a.n_rows + 63) & ~63ull)) a.bits[wi] = 0;
+            continue;
+        }
+        const uint32_t *ends = a.ends + hp.off;
+        uint32_t lo = 0, hi = hp.len;                    // first run whose inclusive end is >= r0
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((uint64_t)ends[mid] < r0) lo = mid + 1; else hi = mid;
+        }
+        uint64_t word = 0;
+        uint64_t row = r0;
+        const uint64_t stop = r0 + 64 < hp.rows ? r0 + 64 : hp.rows;
+        for (uint32_t r = lo; r < hp.len && row < stop; r++) {
+            const uint64_t end = (uint64_t)ends[r] + 1 < stop ? (uint64_t)ends[r] + 1 : stop;   // exclusive
+            const uint64_t v = enc_load_val<W>(a.vals, hp.off + r);
+            const bool hit = (((v - a.lo) & a.wmask) <= a.diff) != (a.negate != 0);
+            if (hit && end > row) {
+                const uint32_t b0 = (uint32_t)(row - r0), n = (uint32_t)(end - row);
+                word |= (n >= 64 ? ~0ull : ((1ull << n) - 1)) << b0;
+            }
+            row = end;
+        }
+        a.bits[wi] = word;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) runend_sum_kernel(const EncScanArgs a) {
+    Acc acc;
+    acc.init();
+    uint64_t cnt = 0, sum = 0;
+    // one lane per run, packs walked by the workgroups (a pack's runs are few: the container exists for long runs)
+    for (uint32_t pack = blockIdx.x; pack < a.n_packs; pack += gridDim.x) {
+        const EncPack hp = a.packs[pack];
+        const uint32_t *ends = a.ends + hp.off;
+        for (uint32_t r = threadIdx.x; r < hp.len; r += kBlock) {
+            const uint64_t first = r == 0 ? 0 : (uint64_t)ends[r - 1] + 1;
+            uint64_t last1 = (uint64_t)ends[r] + 1;
+            if (last1 > hp.rows) last1 = hp.rows;
+            const uint64_t v = enc_load_val<W>(a.vals, hp.off + r);
+            const bool hit = (((v - a.lo) & a.wmask) <= a.diff) != (a.negate != 0);
+            if (hit && last1 > first) {
+                cnt += last1 - first;
+                sum += v * (last1 - first);
+            }
+        }
+    }
+    acc.count = cnt;
+    acc.isum = sum;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+hipError_t launch_runend_scan(hipStream_t s, int grid_bits, int grid_runs, const EncScanArgs &a) {
+#define KNOX_RE(W)                                                                                              \
+    if (a.bits != nullptr && grid_bits > 0) hipLaunchKernelGGL((runend_bits_kernel<W>), dim3(grid_bits), dim3(kBlock), 0, s, a); \
+    hipLaunchKernelGGL((runend_sum_kernel<W>), dim3(grid_runs), dim3(kBlock), 0, s, a);                        \
+    break
+    switch (a.width) {
+    case 8: KNOX_RE(8);
+    case 4: KNOX_RE(4);
+    case 2: KNOX_RE(2);
+    case 1: KNOX_RE(1);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_RE
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Simple8 containers (internal/encode/int_s8b.go:87-115, s8b/generic/decode.go:15-80, unpack_for.go):
 // every 64-bit word carries a 4-bit selector (bits 60..63) and n values of b bits, LSB first;
 // selectors 0 / 1 are runs of 128 zeros / ones.  value = field + minv.  A word's position in the

@@ -277,6 +277,36 @@ struct PackedScanArgs {
 // one wave per 4096 values: lane l evaluates values l, l + 64, ...; a wave64 ballot IS the bitset word
 hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a);
 
+// ---- dictionary / run-end containers scanned as they are (round 4; knox_enc_*) -------------------------------------------
+// dictionary [5]: row i of pack p = dict[dict_off[p] + codes[p * pack_rows + i]] (int_dict.go:76-103); the predicate is
+// evaluated on the pack's dictionary once (a hit bitmap in LDS), then the uint16 codes stream: 2.125 B per row whatever
+// the value width.  run-end [3]: run r of pack p covers rows (ends[r-1], ends[r]] of the pack (int_runend.go:84-112); the
+// predicate is evaluated on the run values, hit runs are expanded into the bitset: (W + 4) B per run + 1/8 B per row.
+struct EncPack {
+    uint64_t off;      // first dictionary entry / first run of the pack inside the concatenated arrays
+    uint32_t len;      // dictionary entries / runs
+    uint32_t rows;     // rows of the pack (pack_rows except for the column's last)
+};
+struct EncScanArgs {
+    const void *vals;        // dictionary entries / run values, W bytes each, all packs back to back
+    const uint16_t *codes;   // dictionary: n_packs * pack_rows codes (pack p at p * pack_rows)
+    const uint32_t *ends;    // run-end: inclusive last row (inside its pack) of every run
+    const EncPack *packs;
+    uint32_t n_packs;
+    uint32_t width;          // W
+    uint64_t pack_rows;
+    uint64_t n_rows;
+    uint64_t lo, diff, wmask;  // hit = ((raw(v) - lo) & wmask) <= diff, negated when `negate` (integer leaves: the reference's unsigned-difference form)
+    uint32_t negate;
+    uint32_t want_sum;
+    uint64_t *bits;          // nullable
+    AggPartial *partials;    // [grid]
+};
+constexpr int kEncChunkRows = 8192;      // dictionary scan: rows per workgroup step (4 waves x 4 loads x 64 lanes x 8 codes)
+constexpr int kEncDictLdsBytes = 32768;  // dictionaries up to this size are staged in LDS for the sum (beyond: read through the L2)
+hipError_t launch_dict_scan(hipStream_t s, int grid, const EncScanArgs &a);
+hipError_t launch_runend_scan(hipStream_t s, int grid_bits, int grid_runs, const EncScanArgs &a);
+
 // bit-packed container payload -> materialized values: out[i] = T((stream >> i*log2) & mask) + minv
 hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,
                                  uint64_t n_values, void *dst);

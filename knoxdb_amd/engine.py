@@ -483,6 +483,15 @@ class Context:
         check(self.L.knox_packed_upload(self.h, int(dtype), ptrs, lens, len(bufs), pack_rows, C.byref(h)), "knox_packed_upload")
         return Packed(self, h, BlockType(dtype), len(bufs))
 
+    def enc_upload(self, dtype, containers, pack_rows):
+        """dictionary [5] / run-end [3] containers of consecutive packs, kept encoded in HBM (knox_enc_upload)"""
+        bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(1, len(bufs)))(*[b.size for b in bufs])
+        h = C.c_void_p()
+        check(self.L.knox_enc_upload(self.h, int(dtype), ptrs, lens, len(bufs), pack_rows, C.byref(h)), "knox_enc_upload")
+        return Encoded(self, h, BlockType(dtype), len(bufs))
+
     def packed_create(self, dtype, pack_rows, max_packs, max_payload_bytes):
         """an empty packed column filled by Packed.append_async on the copy stream (knox_packed_create)"""
         h = C.c_void_p()
@@ -747,6 +756,46 @@ class Packed:
     def free(self):
         if self.h:
             check(_lib.lib().knox_packed_free(self.h))
+            self.h = None
+
+
+class Encoded:
+    """A column of dictionary [5] or run-end [3] containers kept encoded in HBM and scanned as it is (knox_enc_*)."""
+
+    def __init__(self, ctx, handle, dtype, n_packs):
+        self.ctx, self.h, self.dtype, self.n_packs = ctx, handle, dtype, n_packs
+
+    @property
+    def rows(self):
+        return _lib.lib().knox_enc_rows(self.h)
+
+    @property
+    def nbytes(self):
+        return _lib.lib().knox_enc_bytes(self.h)
+
+    @property
+    def container_bytes(self):
+        return _lib.lib().knox_enc_container_bytes(self.h)
+
+    @property
+    def kind(self):
+        return _lib.lib().knox_enc_kind(self.h)
+
+    def scan(self, mode, a, b=None, want_sum=False, bits_out=None, pack_counts=False):
+        """-> (count, sum state or None, per-pack counts or None)"""
+        av = value_bits(self.dtype, a)
+        bv = value_bits(self.dtype, b) if b is not None else 0
+        cnt = C.c_int64()
+        st = AggState()
+        pc = np.zeros(self.n_packs, dtype=np.int64) if pack_counts else None
+        check(_lib.lib().knox_enc_scan(self.ctx.h, self.h, int(mode), av, bv, 1 if want_sum else 0, bits_out.h if bits_out is not None else None,
+                                       pc.ctypes.data_as(C.POINTER(C.c_int64)) if pc is not None else None, C.byref(cnt), C.byref(st)),
+              "knox_enc_scan")
+        return cnt.value, (st if want_sum else None), pc
+
+    def free(self):
+        if self.h:
+            check(_lib.lib().knox_enc_free(self.h))
             self.h = None
 
 
