@@ -524,6 +524,20 @@ int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const knox_col
 int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op,
                                    const uint8_t *val, uint64_t val_len, const uint8_t *val2, uint64_t val2_len,
                                    const knox_bits *mask /* nullable */, knox_bits *bits);
+/* numInSetMatcher.MatchRangeVectors (match_num.go:693-727), materialized statistics vectors: bits[p] = the set holds a
+ * member in [uint64(min[p]), uint64(max[p])] (Go's conversion: signed values sign-extend; the pair is swapped when reversed),
+ * and-ed with the mask.  set = n_set values of the (integer) column type, any order, duplicates allowed.  negate != 0 =
+ * numNotInSetMatcher: undecided, bits = mask or all ones (:810-817).  The reference's branch for COMPRESSED statistics
+ * blocks answers with the coarser range test [set min, set max]: knox_match_range_vectors(KNOX_RANGE).               */
+int knox_match_range_vectors_set(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int negate, const void *set,
+                                 size_t n_set, const knox_bits *mask /* nullable */, knox_bits *bits);
+/* The Int128 / Int256 forms (match_i128.go:78-375, match_i256.go:64-229) over the limb columns of the min / max statistics
+ * (most significant limb first, as knox_match_wide): EQ (min <= v) & (max >= v), RANGE (min <= to) & (max >= from) -- also
+ * what the IN matchers ask with [set min, set max] (:371-376) --, LT / LE on min, GT / GE on max, all and-ed with the mask
+ * (the wide compare kernels take one); NE / NOT IN: the mask, or all ones.                                          */
+int knox_match_range_vectors_wide(knox_ctx *ctx, knox_col *const *mins, knox_col *const *maxs, int n_limbs /* 2 | 4 */, int op,
+                                  const uint64_t *a, const uint64_t *b /* RANGE only */, const knox_bits *mask /* nullable */,
+                                  knox_bits *bits);
 
 /* bytesRegexpMatcher (operator/filter/match_bytes.go:543-609): MatchVector = regexp.Match(row) for every
  * (masked) row of a bytes column.  The pattern is compiled on the host into a DFA over rune classes and

@@ -152,6 +152,8 @@ SIGNATURES = {
     "knox_scan_async": (_i, [_vp, C.POINTER(Pred), _i, _pp, _i, C.POINTER(Agg), _i, _u64, _vp, _vp, _i]),
     "knox_scan_collect": (_i, [_vp, _vp, C.POINTER(AggState), _i, C.POINTER(ScanOut)]),
     "knox_match_range_vectors": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _vp, _vp]),
+    "knox_match_range_vectors_set": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
+    "knox_match_range_vectors_wide": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "knox_match_range_vectors_bytes": (_i, [_vp, _vp, _vp, _i, C.c_char_p, _u64, C.c_char_p, _u64, _vp, _vp]),
     "knox_reduce": (_i, [_vp, _vp, _vp, _u64, C.POINTER(AggState)]),
     "knox_host_alloc": (_i, [_vp, _sz, _pp]),

@@ -2237,6 +2237,68 @@ KNOX_API int knox_match_range_vectors(knox_ctx *ctx, const knox_col *mins, const
     return rc;
 }
 
+// numInSetMatcher.MatchRangeVectors (match_num.go:693-727) on materialized statistics vectors: which packs hold a member of the
+// set inside [min, max].  (The reference's other branch -- compressed statistics blocks -- answers with the coarser RANGE test
+// [set min, set max]: knox_match_range_vectors with KNOX_RANGE.)  NOT IN is "undecided, always true" (:810-817).
+KNOX_API int knox_match_range_vectors_set(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int negate, const void *set, size_t n_set,
+                                          const knox_bits *mask, knox_bits *bits) {
+    if (!ctx || !mins || !maxs || !bits || mins->n_rows != maxs->n_rows || mins->dtype != maxs->dtype || bits->size != mins->n_rows) return KNOX_E_INVALID;
+    if (mask && mask->size != bits->size) return KNOX_E_INVALID;
+    if (n_set && !set) return KNOX_E_INVALID;
+    if (mins->dtype == KNOX_BYTES || dtype_is_float(mins->dtype)) return KNOX_E_UNSUPPORTED;  // integer sets (xroar bitmaps of uint64(v))
+    if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
+    if (negate) return mask ? knox_bits_copy(ctx, bits, mask) : knox_bits_one(ctx, bits);
+    hipSetDevice(ctx->device);
+    { const int rc_ = col_acquire(ctx, mins); if (rc_) return rc_; }
+    { const int rc_ = col_acquire(ctx, maxs); if (rc_) return rc_; }
+    const int w = mins->width;
+    const bool is_signed = dtype_flavor(mins->dtype) == FL_SIGNED;
+    std::vector<uint64_t> keys(n_set);
+    for (size_t i = 0; i < n_set; i++) {
+        uint64_t v = 0;
+        memcpy(&v, (const char *)set + i * (size_t)w, (size_t)w);
+        if (is_signed && w < 8 && (v >> (8 * w - 1))) v |= ~0ull << (8 * w);  // Go's uint64(T(v)) sign-extends
+        keys[i] = v;
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    if (keys.size() > 0xffffffffull) return KNOX_E_RANGE;
+    int rc = ensure(ctx, ctx->bytes_val, keys.size() * 8 + 64);
+    if (!rc && !keys.empty()) rc = upload(ctx, ctx->bytes_val.p, keys.data(), keys.size() * 8);
+    if (rc) return rc;
+    hipError_t e = launch_range_set(ctx->stream, w, is_signed, mins->dev, maxs->dev, mins->n_rows, (const uint64_t *)ctx->bytes_val.p, (uint32_t)keys.size(),
+                                    bits->dev, mask ? mask->dev : nullptr);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    return KNOX_OK;
+}
+
+// The Int128 / Int256 matchers' MatchRangeVectors (match_i128.go:78-375, match_i256.go:64-229) over limb columns of the
+// min / max statistics: compositions of the wide compares, WITH the mask everywhere (cmp_i128_* take one):
+//   EQ     (min <= v) & (max >= v) & mask          RANGE  (min <= to) & (max >= from) & mask     (IN: RANGE [set min, set max], :371-376)
+//   LT/LE  (min < / <= v) & mask                   GT/GE  (max > / >= v) & mask                  NE / NOT IN: mask, or all ones
+KNOX_API int knox_match_range_vectors_wide(knox_ctx *ctx, knox_col *const *mins, knox_col *const *maxs, int n_limbs, int op, const uint64_t *a,
+                                           const uint64_t *b, const knox_bits *mask, knox_bits *bits) {
+    if (!ctx || !mins || !maxs || !bits || (n_limbs != 2 && n_limbs != 4)) return KNOX_E_INVALID;
+    if (mask && mask->size != bits->size) return KNOX_E_INVALID;
+    if (op == KNOX_NE || op == KNOX_NOTIN) return mask ? knox_bits_copy(ctx, bits, mask) : knox_bits_one(ctx, bits);
+    if (!a || (op == KNOX_RANGE && !b)) return KNOX_E_INVALID;
+    int64_t cnt = 0;
+    switch (op) {
+    case KNOX_LT: case KNOX_LE: return knox_match_wide(ctx, mins, n_limbs, op, a, nullptr, mask, bits, &cnt);
+    case KNOX_GT: case KNOX_GE: return knox_match_wide(ctx, maxs, n_limbs, op, a, nullptr, mask, bits, &cnt);
+    case KNOX_EQ: case KNOX_RANGE: {
+        knox_bits *t = nullptr;
+        int rc = knox_bits_alloc(ctx, bits->size, &t);
+        if (rc) return rc;
+        rc = knox_match_wide(ctx, mins, n_limbs, KNOX_LE, op == KNOX_RANGE ? b : a, nullptr, mask, t, &cnt);   // minBits = (min <= to) & mask
+        if (!rc) rc = knox_match_wide(ctx, maxs, n_limbs, KNOX_GE, a, nullptr, t, bits, &cnt);                     // bits = (max >= from) & minBits
+        knox_bits_free(t);
+        return rc;
+    }
+    default: return KNOX_E_UNSUPPORTED;
+    }
+}
+
 // the bytes forms (bytesEqualMatcher.. bytesRangeMatcher.MatchRangeVectors, match_bytes.go:97-299): same
 // shapes over StringPool statistics columns, bytes.Compare order
 KNOX_API int knox_match_range_vectors_bytes(knox_ctx *ctx, const knox_col *mins, const knox_col *maxs, int op, const uint8_t *val, uint64_t val_len,

@@ -1,6 +1,7 @@
 // knox_bitset.hip -- bitset combinators, popcounts, Indexes (bitset -> row ids), Int128 / Int256 compares and the numeric
 // IN / NOT IN matcher: kernels that read or write selection bitsets without touching the streaming scan.
 #include "knox_dev.h"
+#include <algorithm>
 
 namespace knox {
 
@@ -163,6 +164,60 @@ hipError_t launch_wide_inset(hipStream_t s, int n_limbs, bool negate, const uint
     if (n_limbs == 2) KNOX_LAUNCH(wide_inset_kernel<2>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], nullptr, nullptr, n_rows, keys, n_keys, bits, mask);
     if (n_limbs == 4) KNOX_LAUNCH(wide_inset_kernel<4>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], limbs[2], limbs[3], n_rows, keys, n_keys, bits, mask);
     return hipErrorInvalidValue;
+}
+
+// numInSetMatcher.MatchRangeVectors over materialized min / max statistics vectors (operator/filter/match_num.go:693-727): one
+// row per pack; minU64, maxU64 = uint64(min), uint64(max) -- Go's conversion sign-extends a signed T -- swapped when
+// minU64 > maxU64 ("source could contain negative integers"); the pack MAY match when the set holds a member in
+// [minU64, maxU64] (xroar ContainsRange).  keys = the set's members converted the same way, sorted ascending, unique.
+// bits are overwritten: hit, and-ed with the mask when there is one (the reference tests masked rows only and Sets).
+template <int W, bool SIGNED>
+__global__ void __launch_bounds__(kBlock) range_set_kernel(const void *mins, const void *maxs, uint64_t n_rows, const uint64_t *keys, uint32_t n_keys,
+                                                           uint64_t *bits, const uint64_t *mask) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves_total) {
+        const uint64_t row = (g << 6) + lane;
+        bool m = false;
+        if (row < n_rows) {
+            uint64_t lo_v, hi_v;
+            if constexpr (SIGNED) {
+                lo_v = sext_u64<W>(load_elem<W>(mins, row));
+                hi_v = sext_u64<W>(load_elem<W>(maxs, row));
+            } else {
+                lo_v = (uint64_t)load_elem<W>(mins, row);
+                hi_v = (uint64_t)load_elem<W>(maxs, row);
+            }
+            if (lo_v > hi_v) { const uint64_t t = lo_v; lo_v = hi_v; hi_v = t; }
+            uint32_t lo = 0, hi = n_keys;  // first key >= lo_v
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (keys[mid] < lo_v) lo = mid + 1; else hi = mid;
+            }
+            m = lo < n_keys && keys[lo] <= hi_v;
+        }
+        uint64_t word = __ballot(m);
+        if (mask != nullptr) word &= mask[g];
+        if (lane == 0) bits[g] = word;
+    }
+}
+
+hipError_t launch_range_set(hipStream_t s, int width, bool is_signed, const void *mins, const void *maxs, uint64_t n_rows, const uint64_t *keys,
+                            uint32_t n_keys, uint64_t *bits, const uint64_t *mask) {
+    if (n_rows == 0) return hipSuccess;
+    const int g = (int)std::min<uint64_t>((n_rows + kBlock - 1) / kBlock, 4096);
+#define KNOX_RS(W)                                                                                                \
+    if (is_signed) KNOX_LAUNCH((range_set_kernel<W, true>), g, mins, maxs, n_rows, keys, n_keys, bits, mask);    \
+    KNOX_LAUNCH((range_set_kernel<W, false>), g, mins, maxs, n_rows, keys, n_keys, bits, mask)
+    switch (width) {
+    case 8: KNOX_RS(8);
+    case 4: KNOX_RS(4);
+    case 2: KNOX_RS(2);
+    case 1: KNOX_RS(1);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_RS
 }
 
 hipError_t launch_wide_cmp(hipStream_t s, int n_limbs, int grid, const WideArgs &w) {

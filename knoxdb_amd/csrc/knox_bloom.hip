@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(kBlock) bloom_bin1_kernel(H hasher, uint64_t n
     __shared__ uint32_t lstart[256];  // the run's start inside the tile's sorted order
     __shared__ uint32_t gpos[256];    // where the run goes inside its segment's region
     __shared__ uint32_t wsum[kBlock / 64];
-    __shared__ uint32_t sorted[kBinSlots];  // segment << 16 | in-segment offset
+    __shared__ uint16_t sorted[kBinSlots];  // in-segment offsets, runs of one segment contiguous (32 KiB: four workgroups per CU)
     const uint32_t tile = blockIdx.x % tiles_pp;
     const uint64_t pl = blockIdx.x / tiles_pp, p = p0 + pl;
     const uint64_t o0 = offsets[p], o1 = offsets[p + 1];
@@ -441,6 +441,10 @@ __global__ void __launch_bounds__(kBlock) bloom_bin1_kernel(H hasher, uint64_t n
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = hist[threadIdx.x];
+    // the run's place in its segment's region: ONE device-scope atomic per non-empty run, issued now and consumed only after
+    // the LDS reorder below -- its round trip to the memory side (microseconds) is hidden behind that phase
+    uint32_t g = 0;
+    if (c) g = atomicAdd(&seg_cursor[pl * 256 + threadIdx.x], c);
     uint32_t incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -452,12 +456,6 @@ __global__ void __launch_bounds__(kBlock) bloom_bin1_kernel(H hasher, uint64_t n
     uint32_t base = 0;
     for (int w = 0; w < wave; w++) base += wsum[w];
     lstart[threadIdx.x] = base + incl - c;
-    uint32_t g = 0;
-    if (c) {
-        g = atomicAdd(&seg_cursor[pl * 256 + threadIdx.x], c);
-        if (g + c > cap) atomicOr(overflow_flag, 1u);
-    }
-    gpos[threadIdx.x] = g;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kBinRowsPerThread; i++) {
@@ -468,19 +466,24 @@ __global__ void __launch_bounds__(kBlock) bloom_bin1_kernel(H hasher, uint64_t n
             for (int k = 0; k < 4; k++) {
                 const uint32_t loc = h0 & mask;
                 const uint32_t rk = (rank2[2 * i + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu;
-                sorted[lstart[loc >> kSegShift] + rk] = loc;   // loc = segment << 16 | offset
+                sorted[lstart[loc >> kSegShift] + rk] = (uint16_t)loc;
                 h0 += h1;
             }
         }
     }
+    if (c && g + c > cap) atomicOr(overflow_flag, 1u);
+    gpos[threadIdx.x] = g;
     __syncthreads();
-    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // write-out by runs: wave w takes the segments w, w + 4, ...; the lanes copy a run's entries side by side (a run is ~64
+    // entries = one 128-byte store per wave)
     uint16_t *dst = entries + pl * entries_pp;
-    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
-        const uint32_t e = sorted[i];
-        const uint32_t sg = e >> kSegShift;
-        const uint32_t at = gpos[sg] + (i - lstart[sg]);
-        if (at < cap) dst[(uint64_t)sg * cap + at] = (uint16_t)e;
+    for (uint32_t sg = wave; sg < 256; sg += kBlock / 64) {
+        const uint32_t n = hist[sg];
+        if (n == 0) continue;
+        const uint32_t ls = lstart[sg], at0 = gpos[sg];
+        uint16_t *d = dst + (uint64_t)sg * cap;
+        for (uint32_t i = lane; i < n; i += 64)
+            if (at0 + i < cap) d[at0 + i] = sorted[ls + i];
     }
 }
 
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(kBlock) bloom_fill2_kernel(uint64_t pack_rows,
         const uint32_t cnt = cur < cap ? cur : cap;
         const u32x4 *src = (const u32x4 *)(pe + (uint64_t)(seg0 + sl) * cap);   // 16-byte aligned: cap and entries_pp are multiples of 8 entries
         const uint32_t n_vec = (cnt + 7) >> 3;
-        constexpr int U = 4;                                  // 4 x 16 bytes in flight per lane
+        constexpr int U = 8;                                  // 8 x 16 bytes in flight per lane
         for (uint32_t v0 = lane; v0 < n_vec; v0 += 64 * U) {
             u32x4 r[U];
 #pragma unroll

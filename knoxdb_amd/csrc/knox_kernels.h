@@ -227,6 +227,9 @@ hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const
 
 // IN / NOT IN: membership of the value's canonical order key in a sorted key set (binary search);
 // matching rows are OR-ed into bits (bits.Set), only mask-selected rows are tested when mask != null
+// numInSetMatcher.MatchRangeVectors: bits[row] = the sorted u64 key set holds a member in [uint64(min[row]), uint64(max[row])] (swapped if reversed), & mask
+hipError_t launch_range_set(hipStream_t s, int width, bool is_signed, const void *mins, const void *maxs, uint64_t n_rows, const uint64_t *keys,
+                            uint32_t n_keys, uint64_t *bits, const uint64_t *mask);
 hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
                         const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask);
 

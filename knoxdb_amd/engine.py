@@ -596,6 +596,26 @@ class Context:
                                                     mask.h if mask is not None else None, out.h), "knox_match_range_vectors_bytes")
         return out
 
+    def match_range_vectors_set(self, mins, maxs, values, negate=False, mask=None, bits=None):
+        """numInSetMatcher / numNotInSetMatcher.MatchRangeVectors over integer min / max statistics columns -> Bits"""
+        vals = np.ascontiguousarray(values, dtype=NP_DTYPE[mins.dtype])
+        out = bits if bits is not None else self.bits(mins.rows)
+        check(self.L.knox_match_range_vectors_set(self.h, mins.h, maxs.h, 1 if negate else 0, _ptr(vals) if vals.size else None, vals.size,
+                                                  mask.h if mask is not None else None, out.h), "knox_match_range_vectors_set")
+        return out
+
+    def match_range_vectors_wide(self, mins, maxs, mode, a, b=None, mask=None, bits=None):
+        """Int128 / Int256 MatchRangeVectors over the limb columns (most significant first) of the min / max statistics -> Bits"""
+        n = len(mins)
+        amin = (C.c_void_p * n)(*[c.h for c in mins])
+        amax = (C.c_void_p * n)(*[c.h for c in maxs])
+        av = (C.c_uint64 * n)(*[int(v) & (2**64 - 1) for v in a]) if a is not None else None
+        bv = (C.c_uint64 * n)(*[int(v) & (2**64 - 1) for v in b]) if b is not None else None
+        out = bits if bits is not None else self.bits(mins[0].rows)
+        check(self.L.knox_match_range_vectors_wide(self.h, amin, amax, n, int(mode), av, bv, mask.h if mask is not None else None, out.h),
+              "knox_match_range_vectors_wide")
+        return out
+
     def match_regexp(self, col, pattern, mask=None, bits=None):
         """bytesRegexpMatcher.MatchVector: Go regexp.Match per row of a bytes column -> (Bits, count)."""
         pat = pattern.encode() if isinstance(pattern, str) else bytes(pattern)

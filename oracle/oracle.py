@@ -281,6 +281,47 @@ def cmp_wide(op, limbs, a, b=None, mask=None):
     return out[:bitfield_len(n)].copy(), int(cnt)
 
 
+def range_vectors_set(dtype, mins, maxs, values, negate=False, mask=None):
+    """numInSetMatcher / numNotInSetMatcher.MatchRangeVectors on materialized statistics vectors
+    (internal/operator/filter/match_num.go:693-727, :810-817): row i may match when the set holds a member in
+    [uint64(min[i]), uint64(max[i])] -- Go's conversion sign-extends a signed T; the pair is swapped when reversed --,
+    masked rows only; NOT IN is undecided: the mask, or all ones.  Pure numpy (xroar's ContainsRange = a sorted search)."""
+    mins = np.ascontiguousarray(mins, dtype=NP[dtype])
+    maxs = np.ascontiguousarray(maxs, dtype=NP[dtype])
+    n = mins.size
+    m = np.unpackbits(np.ascontiguousarray(mask, dtype=np.uint8), bitorder="little")[:n].astype(bool) if mask is not None else np.ones(n, dtype=bool)
+    if negate:
+        return np.packbits(m, bitorder="little")
+    u64 = (lambda x: x.astype(np.int64).view(np.uint64)) if np.dtype(NP[dtype]).kind == "i" else (lambda x: x.astype(np.uint64))
+    lo, hi = u64(mins), u64(maxs)
+    lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
+    keys = np.unique(u64(np.ascontiguousarray(values, dtype=NP[dtype])))
+    idx = np.searchsorted(keys, lo, side="left")
+    hit = (idx < keys.size) & (keys[np.minimum(idx, max(keys.size - 1, 0))] <= hi) if keys.size else np.zeros(n, dtype=bool)
+    return np.packbits(hit & m, bitorder="little")
+
+
+def range_vectors_wide(op, mins, maxs, a, b=None, mask=None):
+    """The Int128 / Int256 matchers' MatchRangeVectors (match_i128.go:78-375, match_i256.go:64-229) over limb slices
+    (most significant first): EQ :78-91 = le(min) with the mask, and-ed with the mask, ge(max) under it, and-ed again; RANGE
+    :299-313 the same with (to, from); LT / LE :213-218,:243-248 on min, GT / GE :153-158,:183-188 on max (the wide compares
+    honour the mask); NE / NOT IN :111-118,:432-439 the mask or all ones."""
+    n = np.ascontiguousarray(mins[0]).size
+    full = np.packbits(np.ones(n, dtype=bool), bitorder="little")
+    if op in (NE, NIN):
+        return np.array(mask, dtype=np.uint8, copy=True) if mask is not None else full
+    if op in (LT, LE):
+        return cmp_wide(op, mins, a, mask=mask)[0]
+    if op in (GT, GE):
+        return cmp_wide(op, maxs, a, mask=mask)[0]
+    assert op in (EQ, RG)
+    min_bits = cmp_wide(LE, mins, b if op == RG else a, mask=mask)[0]
+    if mask is not None:
+        min_bits &= np.ascontiguousarray(mask, dtype=np.uint8)
+    bits = cmp_wide(GE, maxs, a, mask=min_bits)[0]
+    return bits & min_bits
+
+
 def inset(dtype, negate, src, values, mask=None, bits=None):
     src = np.ascontiguousarray(src, dtype=NP[dtype])
     vals = np.ascontiguousarray(values, dtype=NP[dtype])

@@ -280,3 +280,64 @@ def test_zone_map_match_range_vectors_bytes(ctx):
             got.free()
     for h in (mins, maxs, mask):
         h.free()
+
+
+def test_zone_map_range_vectors_for_sets_and_wide_integers(ctx):
+    """Round 4: the remaining MatchRangeVectors forms on the device.  numInSetMatcher (match_num.go:693-727: a set member inside
+    [uint64(min), uint64(max)], Go's sign-extending conversion, reversed pairs swapped) and numNotInSetMatcher (:810-817) for
+    integer statistics columns; the Int128 / Int256 matchers (match_i128.go:78-375, match_i256.go:64-229) over limb columns.
+    Against the oracle's restatements (oracle.range_vectors_set / range_vectors_wide), with and without a mask."""
+    rng = np.random.default_rng(23)
+    n = 1000 + 37                      # packs (rows of the statistics columns)
+    mask_h = rng.integers(0, 256, size=O.bitfield_len(n)).astype(np.uint8)
+    mask_h[-1] &= 0xFF >> (8 - n % 8)
+    mask = ctx.bits(n).upload(mask_h)
+    for bt, dt, npdt in ((BlockType.Int64, O.I64, np.int64), (BlockType.Uint64, O.U64, np.uint64), (BlockType.Int32, O.I32, np.int32),
+                         (BlockType.Int16, O.I16, np.int16), (BlockType.Uint8, O.U8, np.uint8)):
+        info = np.iinfo(npdt)
+        lo_v = max(int(info.min), -(1 << 40))
+        hi_v = min(int(info.max), 1 << 40)
+        a = rng.integers(lo_v, hi_v, size=n, endpoint=True)
+        w = rng.integers(0, max(1, (hi_v - lo_v) // 50), size=n)
+        mins_h = a.astype(npdt)
+        maxs_h = np.minimum(a + w, hi_v).astype(npdt)
+        mins, maxs = ctx.upload(mins_h), ctx.upload(maxs_h)
+        sets = [rng.integers(lo_v, hi_v, size=k, endpoint=True).astype(npdt) for k in (1, 7, 300)]
+        sets.append(np.array([mins_h[3], maxs_h[5], mins_h[3]], dtype=npdt))                # members that sit exactly on pack edges, a duplicate
+        if info.min < 0:
+            sets.append(np.array([-1, 0, info.min, info.max], dtype=npdt))                 # both sides of the sign change: uint64(-1) is the largest key
+        for vals in sets:
+            for neg in (False, True):
+                for m, mh in ((None, None), (mask, mask_h)):
+                    got = ctx.match_range_vectors_set(mins, maxs, vals, negate=neg, mask=m)
+                    want = O.range_vectors_set(dt, mins_h, maxs_h, vals, negate=neg, mask=mh)
+                    assert (got.bytes(poison=32) == want).all(), (bt, len(vals), neg, m is not None)
+                    got.free()
+        # an empty set matches nothing
+        got = ctx.match_range_vectors_set(mins, maxs, np.zeros(0, dtype=npdt))
+        assert got.count() == 0
+        got.free()
+        mins.free(); maxs.free()
+    # Int128 / Int256: limb columns of min / max (most significant first, top limb signed)
+    for nl in (2, 4):
+        top = rng.integers(-3, 4, size=n).astype(np.int64)
+        rest = [rng.integers(0, 1 << 62, size=n).astype(np.uint64) for _ in range(nl - 1)]
+        mins_h = [top] + rest
+        bump = rng.integers(0, 1 << 61, size=n).astype(np.uint64)
+        maxs_h = [top] + rest[:-1] + [rest[-1] + bump]                                      # max >= min: same upper limbs, a larger lowest limb
+        mins_c = [ctx.upload(x) for x in mins_h]
+        maxs_c = [ctx.upload(x) for x in maxs_h]
+        probes = [[int(mins_h[l][11]) for l in range(nl)], [int(maxs_h[l][500]) for l in range(nl)], [0] * nl, [-1 & (2**64 - 1)] + [5] * (nl - 1)]
+        for mode, om in ((FilterMode.Equal, O.EQ), (FilterMode.NotEqual, O.NE), (FilterMode.Lt, O.LT), (FilterMode.Le, O.LE), (FilterMode.Gt, O.GT),
+                         (FilterMode.Ge, O.GE), (FilterMode.Range, O.RG), (FilterMode.NotIn, O.NIN)):
+            for pa in probes:
+                pb = probes[1] if mode == FilterMode.Range else None
+                for m, mh in ((None, None), (mask, mask_h)):
+                    got = ctx.match_range_vectors_wide(mins_c, maxs_c, mode, pa, pb, mask=m)
+                    want = O.range_vectors_wide(om, mins_h, maxs_h, pa, pb, mask=mh)
+                    want[-1] &= 0xFF >> (8 - n % 8)
+                    assert (got.bytes(poison=32) == want).all(), (nl, mode, m is not None)
+                    got.free()
+        for c in mins_c + maxs_c:
+            c.free()
+    mask.free()
