@@ -474,16 +474,32 @@ __global__ void __launch_bounds__(kBlock) bloom_bin1_kernel(H hasher, uint64_t n
     if (c && g + c > cap) atomicOr(overflow_flag, 1u);
     gpos[threadIdx.x] = g;
     __syncthreads();
-    // write-out by runs: wave w takes the segments w, w + 4, ...; the lanes copy a run's entries side by side (a run is ~64
-    // entries = one 128-byte store per wave)
+    // write-out by runs: wave w takes the segments w, w + 4, ...: lane l first fetches the run (length, start in the tile, place in
+    // the region) of segment w + 4 l, then the wave walks its 64 runs with those three values broadcast from the owning lane
+    // (v_readlane: no LDS round trip per run for the bookkeeping), four runs per step so that four entry reads are in flight;
+    // the lanes copy a run's entries side by side (a run is ~64 entries = one 128-byte store per wave)
     uint16_t *dst = entries + pl * entries_pp;
-    for (uint32_t sg = wave; sg < 256; sg += kBlock / 64) {
-        const uint32_t n = hist[sg];
-        if (n == 0) continue;
-        const uint32_t ls = lstart[sg], at0 = gpos[sg];
-        uint16_t *d = dst + (uint64_t)sg * cap;
-        for (uint32_t i = lane; i < n; i += 64)
-            if (at0 + i < cap) d[at0 + i] = sorted[ls + i];
+    const uint32_t my_sg = (uint32_t)wave + 4u * (uint32_t)lane;
+    const uint32_t my_n = hist[my_sg], my_ls = lstart[my_sg], my_at = gpos[my_sg];
+#pragma unroll 1
+    for (int l0 = 0; l0 < 64; l0 += 4) {
+        uint32_t n[4], ls[4], at0[4];
+        uint16_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            n[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_n, l0 + k);
+            ls[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_ls, l0 + k);
+            at0[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_at, l0 + k);
+            e[k] = (uint32_t)lane < n[k] ? sorted[ls[k] + lane] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sg = (uint32_t)wave + 4u * (uint32_t)(l0 + k);
+            uint16_t *d = dst + (uint64_t)sg * cap;
+            if ((uint32_t)lane < n[k] && at0[k] + lane < cap) d[at0[k] + lane] = e[k];
+            for (uint32_t i = 64 + lane; i < n[k]; i += 64)   // runs longer than a wave (skewed tiles)
+                if (at0[k] + i < cap) d[at0[k] + i] = sorted[ls[k] + i];
+        }
     }
 }
 

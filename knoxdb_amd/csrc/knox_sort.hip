@@ -158,27 +158,44 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
     }
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < n ? begin + per_block : n;
-    for (uint64_t tile0 = begin; tile0 < end; tile0 += TILE) {
-#pragma unroll
-        for (int w = 0; w < kSortWaves; w++) cnt[w][tid] = 0;
-        __syncthreads();
-        uint32_t key[ITEMS], rank[ITEMS], row[ITEMS];
-        U val[ITEMS];
-        // phase 1: load + rank inside the wave's chunk
+    // The NEXT tile's elements are loaded before the current tile is ranked and reordered (round 4): a tile's phases are a chain
+    // of LDS passes and barriers during which nothing was in flight -- the kernel moved 3.0-3.5 TB/s with 53 % of its wave cycles
+    // waiting (profiles/r04_windows.txt) -- so the loads of tile t + 1 now overlap the four phases of tile t.
+    uint32_t nkey[ITEMS], nrow[ITEMS];
+    U nval[ITEMS];
+    auto load_tile = [&](uint64_t tile0) {
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             const uint64_t e = tile0 + (uint64_t)wave * (64 * ITEMS) + (uint64_t)j * 64 + lane;
-            key[j] = kNoKey;
+            nkey[j] = kNoKey;
+            nrow[j] = 0;
+            nval[j] = 0;
             if (e < end) {
-                key[j] = keys_in[e];
+                nkey[j] = keys_in[e];
                 if (FIRST) {
-                    row[j] = (uint32_t)e;
+                    nrow[j] = (uint32_t)e;
                 } else {
-                    row[j] = idx_in[e];
+                    nrow[j] = idx_in[e];
                 }
-                val[j] = val_in[e];
+                nval[j] = val_in[e];
             }
         }
+    };
+    if (begin < end) load_tile(begin);
+    for (uint64_t tile0 = begin; tile0 < end; tile0 += TILE) {
+#pragma unroll
+        for (int w = 0; w < kSortWaves; w++) cnt[w][tid] = 0;
+        uint32_t key[ITEMS], rank[ITEMS], row[ITEMS];
+        U val[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            key[j] = nkey[j];
+            row[j] = nrow[j];
+            val[j] = nval[j];
+        }
+        if (tile0 + TILE < end) load_tile(tile0 + TILE);
+        __syncthreads();
+        // phase 1: rank inside the wave's chunk
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             const bool active = key[j] != kNoKey;  // later passes: always true below `end` (kNoKey never survives pass 0)
