@@ -138,9 +138,9 @@ class Scope:
         self.vars = {}
         self.structs_go = structs_go  # Go struct name -> {field: cgo type}
         self.objs = {}  # Go variable -> Go struct name (receivers / params of wrapper types)
-        for nm, ty in re.findall(r"(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed)\b", header_line):
+        for nm, ty in re.findall(r"(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed|Encoded)\b", header_line):
             self.objs[nm] = ty
-        for names, ty in re.findall(r"\b([\w, ]+?)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed)\b", header_line):
+        for names, ty in re.findall(r"\b([\w, ]+?)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed|Encoded)\b", header_line):
             for nm in names.split(","):
                 self.objs[nm.strip()] = ty
         # parameters of cgo types: `rc C.int`
@@ -153,7 +153,7 @@ class Scope:
         for nm in re.findall(r"\b(\w+)\s*:=\s*\w+\.c\b(?!\.)", body):
             self.objs[nm] = "Ctx"
         # locals of wrapper types: `var out State`
-        for nm, ty in re.findall(r"\bvar\s+(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed)\b", body):
+        for nm, ty in re.findall(r"\bvar\s+(\w+)\s+\*?(Ctx|Column|Bits|Bloom|State|Packed|Encoded)\b", body):
             self.objs[nm] = ty
         # var a, b C.type / var a *C.type
         for names, ty in re.findall(r"\bvar\s+([\w, ]+?)\s+(\*{0,2}C\.\w+)", body):
@@ -236,7 +236,7 @@ def find_calls(body):
         yield m.group(1), split_top(body[m.end():i - 1]), body.count("\n", 0, m.start())
 
 
-LOCKED_FREES = {"knox_col_free", "knox_bits_free", "knox_bloom_free", "knox_packed_free"}
+LOCKED_FREES = {"knox_col_free", "knox_bits_free", "knox_bloom_free", "knox_packed_free", "knox_enc_free"}
 
 GO_ENUMS = {  # Go constant name -> header enum name (restated values must agree)
     "blockInt64": "KNOX_INT64", "blockInt32": "KNOX_INT32", "blockInt16": "KNOX_INT16", "blockInt8": "KNOX_INT8",

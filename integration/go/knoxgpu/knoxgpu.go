@@ -840,6 +840,68 @@ type Bloom struct {
 	c *Ctx
 }
 
+// ---- dictionary / run-end columns scanned as they are (internal/encode/int_dict.go:181-380, int_runend.go:224-330) ----
+
+// Encoded is a column whose packs stay dictionary- or run-end-encoded in HBM (encode.TIntDictionary / TIntRunEnd containers,
+// NumberContainer.Store bytes): the predicate runs on the dictionary / the run values, the codes / runs are never expanded.
+// A run of packs qualifies when every block of the column arrives as the same container kind (GpuRun keeps such a column
+// here instead of UploadRawContainers when the query has ONE numeric leaf on it).
+type Encoded struct {
+	p *C.knox_enc
+	c *Ctx
+}
+
+// UploadEncoded: the containers of consecutive packs (every pack but the last holds packRows rows; packRows a multiple of 8192).
+// errors.Is(err, ...) is not needed: any error means "take the decoding path" (UploadRawContainers).
+func UploadEncoded(c *Ctx, dtype int, bufs [][]byte, packRows int) (*Encoded, error) {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	ptrs, lens, free := cBufs(bufs)
+	defer free()
+	var e *C.knox_enc
+	rc := C.knox_enc_upload(c.p, C.int(dtype), (**C.uint8_t)(ptrs), (*C.size_t)(lens), C.size_t(len(bufs)), C.size_t(packRows), &e)
+	if rc != 0 {
+		return nil, errOf(rc)
+	}
+	return &Encoded{e, c}, nil
+}
+
+// Scan: one numeric leaf (mode = types.FilterMode, a / b = ValueBits): count, wrapping sum state, selection bitset (nullable),
+// per-pack counts (nullable; needs bitsOut) -- what DictionaryContainer / RunEndContainer.Match* + the reducers give per pack.
+func (e *Encoded) Scan(mode int, a, b uint64, wantSum bool, bitsOut *Bits, packCounts []int64) (int64, State, error) {
+	c := e.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var bo *C.knox_bits
+	if bitsOut != nil {
+		bo = bitsOut.p
+	}
+	var pc *C.int64_t
+	if packCounts != nil {
+		pc = (*C.int64_t)(unsafe.SliceData(packCounts))
+	}
+	ws := 0
+	if wantSum {
+		ws = 1
+	}
+	var cnt C.int64_t
+	var st State
+	rc := C.knox_enc_scan(c.p, e.p, C.int(mode), C.uint64_t(a), C.uint64_t(b), C.int(ws), bo, pc, &cnt, &st.c)
+	return int64(cnt), st, errOf(rc)
+}
+
+func (e *Encoded) Rows() int { return int(C.knox_enc_rows(e.p)) }
+
+func (e *Encoded) Free() {
+	c := e.c
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	if e.p != nil {
+		C.knox_enc_free(e.p)
+		e.p = nil
+	}
+}
+
 func BuildBloom(c *Ctx, col *Column, factor int) (*Bloom, error) {
 	c.mu.Lock()
 	defer c.mu.Unlock()

@@ -306,7 +306,7 @@ struct EncScanArgs {
     AggPartial *partials;    // [grid]
 };
 constexpr int kEncChunkRows = 8192;      // dictionary scan: rows per workgroup step (4 waves x 4 loads x 64 lanes x 8 codes)
-constexpr int kEncDictLdsBytes = 32768;  // dictionaries up to this size are staged in LDS for the sum (beyond: read through the L2)
+constexpr int kEncHistCodes = 8192;      // dictionaries up to this many entries count selected rows per code in LDS for the sum (beyond: dict[code] through the L2)
 hipError_t launch_dict_scan(hipStream_t s, int grid, const EncScanArgs &a);
 hipError_t launch_runend_scan(hipStream_t s, int grid_bits, int grid_runs, const EncScanArgs &a);
 

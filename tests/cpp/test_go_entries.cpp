@@ -273,9 +273,11 @@ static void go_RunReader(knox_ctx *ctx) {
 static void go_EvictOthers() {
     knox_ctx *ctx = nullptr;
     if (knox_ctx_open(0, &ctx) != 0) return;
-    // 6 GiB: the arena's own 1 GiB heap chunk + a 32 MiB reference window + two columns (a 1 GiB column with its
-    // padding takes two 1 GiB chunks of one class zone); the third upload does not fit
-    EXPECT(knox_ctx_set_arena(ctx, (size_t)6 << 30) == 0);
+    // 8 GiB: the arena's own 1 GiB heap chunk + a 32 MiB reference window + three columns (a 1 GiB column with its
+    // padding takes two 1 GiB chunks of ONE class zone); the fourth upload does not fit.  (6 GiB until round 4: on a box whose
+    // first four chunks fall into three or four placement classes -- each class's founder chunk carries its reference
+    // window -- the FIRST column found no two chunks of one class inside the budget and the test failed before it began.)
+    EXPECT(knox_ctx_set_arena(ctx, (size_t)8 << 30) == 0);
     const size_t n = (size_t)1 << 27;                       // 1 GiB of int64 per column
     std::vector<int64_t> v(n);
     for (size_t i = 0; i < n; i++) v[i] = (int64_t)(i & 1023);

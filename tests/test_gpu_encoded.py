@@ -100,8 +100,8 @@ def check_all_modes(ctx, enc, bt, dt, npdt, want, containers, tag):
 @pytest.mark.parametrize("bt,dt,npdt", TYPES)
 def test_dictionary_columns_scan_like_their_decoded_vectors(ctx, bt, dt, npdt):
     rng = np.random.default_rng(int(bt))
-    # three packs, the last one short; dictionaries of different sizes (the largest beyond the LDS staging limit of the sum for 8-byte values)
-    shapes = [(PACK, 300), (PACK, 6000 if npdt().itemsize >= 4 else 200), (PACK - 3001, 17)]
+    # three packs, the last one short; dictionaries of different sizes (the largest beyond the per-code counters of the sum (kEncHistCodes), so the L2 path runs too)
+    shapes = [(PACK, 300), (PACK, 9000 if npdt().itemsize >= 4 else 200), (PACK - 3001, 17)]
     packs = [dict_pack(rng, dt, npdt, n, d, sort=(i != 1), child="raw" if i == 2 else "bitpack") for i, (n, d) in enumerate(shapes)]
     containers = [p[0] for p in packs]
     want = np.concatenate([p[1] for p in packs])
