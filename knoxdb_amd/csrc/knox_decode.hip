@@ -150,6 +150,11 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
     // LDS copy per selected row -- 64-bit gathers, 2.9 x the time of the count-only scan.)  Dictionaries beyond
     // kEncHistCodes entries (the reference builds them up to 2^15, hashprobe.MAX_DICT_LIMIT) read dict[code] through the L2.
     __shared__ uint32_t chist[SUM ? kEncHistCodes : 1];
+    // the hit codes of a SORTED dictionary under a range predicate are one interval [first, last]: the per-code bitmap lookup
+    // (one LDS instruction per row: the count-only scan was LDS-issue bound at 63 % of the HBM peak) becomes a compare.  Found,
+    // not assumed: first / last / number of hit entries are collected while the bitmap is built; an unsorted dictionary, a NOT
+    // EQUAL (two intervals) or anything else that is not one interval keeps the bitmap.
+    __shared__ uint32_t s_first, s_last, s_hits;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t chunks_pp = a.pack_rows / kEncChunkRows;
     const uint64_t n_chunks = (uint64_t)a.n_packs * chunks_pp;
@@ -160,7 +165,8 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
     uint64_t cnt = 0, sum = 0;
     uint32_t cur_pack = 0xffffffffu;
     EncPack hp = {0, 0, 0};
-    bool use_hist = false;
+    bool use_hist = false, contig = false;
+    uint32_t c_lo = 0, c_diff = 0;
     auto flush_hist = [&]() {   // workgroup uniform; callers synchronise before and after
         if constexpr (SUM) {
             if (use_hist)
@@ -179,6 +185,7 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
             cur_pack = pack;
             hp = a.packs[pack];
             for (int i = threadIdx.x; i < 2048; i += kBlock) hitmap[i] = 0;
+            if (threadIdx.x == 0) { s_first = 0xffffffffu; s_last = 0; s_hits = 0; }
             use_hist = SUM && hp.len <= (uint32_t)kEncHistCodes;
             if constexpr (SUM) {
                 if (use_hist)
@@ -188,9 +195,19 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
             for (uint32_t e = threadIdx.x; e < hp.len; e += kBlock) {
                 const uint64_t v = enc_load_val<W>(a.vals, hp.off + e);
                 const bool hit = (((v - a.lo) & a.wmask) <= a.diff) != (a.negate != 0);
-                if (hit) atomicOr(&hitmap[e >> 5], 1u << (e & 31));
+                if (hit) {
+                    atomicOr(&hitmap[e >> 5], 1u << (e & 31));
+                    atomicMin(&s_first, e);
+                    atomicMax(&s_last, e);
+                    atomicAdd(&s_hits, 1u);
+                }
             }
             __syncthreads();
+            const uint32_t nh = s_hits;
+            contig = nh == 0 || s_last - s_first + 1 == nh;
+            c_lo = nh ? s_first : 1u;           // no hit at all: the empty interval [1, 0]
+            c_diff = nh ? s_last - s_first : 0xffffffffu;
+            if (nh == 0) c_diff = 0, c_lo = 0x10000u;  // (code - 0x10000) wraps above every 16-bit code: never <= 0
         }
         const uint64_t in_pack = (c % chunks_pp) * kEncChunkRows + (uint64_t)wave * 2048;  // this wave's first row inside the pack
         if (in_pack >= hp.rows) continue;                                                   // a short last pack (wave uniform)
@@ -208,7 +225,9 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const uint32_t code = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                uint32_t hit = (hitmap[code >> 5] >> (code & 31)) & 1u;
+                uint32_t hit;
+                if (contig) hit = (code - c_lo) <= c_diff ? 1u : 0u;          // workgroup uniform: hoisted out of the unrolled loops
+                else hit = (hitmap[code >> 5] >> (code & 31)) & 1u;
                 hit = (lane_row + j < hp.rows && code < hp.len) ? hit : 0u;   // rows past a short pack's end; a code outside the dictionary never matches
                 m |= hit << j;
                 if constexpr (SUM) {

@@ -15,7 +15,6 @@
 // reordered through LDS and written out as contiguous per-digit runs.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <cstring>
 
 #include "knox_finalize.h"
@@ -133,7 +132,7 @@ __global__ void __launch_bounds__(kSortBlock) hist_scan_kernel(uint32_t *__restr
 // rows dropped; otherwise the (key, row, value) triples of the previous pass.  ITEMS elements per thread and tile; wave w
 // of a tile owns the elements [w*64*ITEMS, (w+1)*64*ITEMS) of it, element (j, lane) at j*64 + lane (coalesced loads,
 // element order == offset order, which is what makes the ranking stable).
-template <typename U, bool FIRST, int ITEMS, bool DIRECT>
+template <typename U, bool FIRST, int ITEMS>
 __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ idx_in,
                                                                   const U *__restrict__ val_in, uint64_t n, uint64_t per_block, uint32_t shift,
                                                                   uint32_t nbits, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ tot,
@@ -145,12 +144,8 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
     __shared__ uint32_t tile_start[kRadix];          // first sorted position of the digit inside the tile
     __shared__ uint32_t gbase[kRadix];               // output slot of that position
     __shared__ uint32_t tmp[kSortWaves + 1];
-    // DIRECT (round 4): no reorder through LDS -- an element goes from its registers straight to its output slot.  The staged form
-    // holds 16 B of LDS per element (64 KiB per workgroup at 16 elements per thread: two workgroups per CU) and spends two more
-    // barrier-separated LDS passes per tile; what it buys is store coalescing.  With 7 KiB of LDS the CU holds as many workgroups
-    // as registers allow, and the chain of short phases of one tile overlaps with other workgroups' loads.
-    __shared__ uint32_t s_key[DIRECT ? 1 : TILE], s_idx[DIRECT ? 1 : TILE];
-    __shared__ U s_val[DIRECT ? 1 : TILE];
+    __shared__ uint32_t s_key[TILE], s_idx[TILE];
+    __shared__ U s_val[TILE];
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t dmask = (1u << nbits) - 1;
     {
@@ -163,9 +158,12 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
     }
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < n ? begin + per_block : n;
-    // (round 4: loading the NEXT tile's elements before the current tile's four phases -- two register sets -- was built and
-    //  measured: 2.94 / 3.71 / 11.5 ms against 2.88 / 3.50 / 9.13 ms at 1024 / 16384 / 2^20 windows of 2^28 shuffled rows; the kernel
-    //  is bound by its LDS passes and barriers, not by load latency -- dropped)
+    // Round 4, two restructurings of this loop built and measured at 1024 / 16384 / 2^20 windows of 2^28 shuffled rows (whole calls,
+    // this form: 2.79-2.88 / 3.38-3.50 / 9.1-9.7 ms), both dropped:
+    //   * the NEXT tile's elements loaded before the current tile's four phases (two register sets): 2.94 / 3.71 / 11.5 ms;
+    //   * no reorder through LDS, every element stored from its registers straight to its output slot (7 KiB of LDS, four
+    //     workgroups per CU instead of two): 3.63 / 4.90 / 12.1 ms -- the coalesced runs of the staged form are worth more than
+    //     the occupancy.
     for (uint64_t tile0 = begin; tile0 < end; tile0 += TILE) {
 #pragma unroll
         for (int w = 0; w < kSortWaves; w++) cnt[w][tid] = 0;
@@ -215,32 +213,14 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
                 cnt[w][tid] = total;
                 total += c;
             }
-            if constexpr (!DIRECT) {  // the digit's start inside the tile's sorted order: only the staged form reorders
-                uint32_t n_tile;
-                const uint32_t st = block_exclusive_scan(total, tmp, &n_tile);
-                tile_start[tid] = st;
-                if (tid == 0) tmp[kSortWaves] = n_tile;
-            }
+            uint32_t n_tile;
+            const uint32_t st = block_exclusive_scan(total, tmp, &n_tile);
+            tile_start[tid] = st;
             gbase[tid] = run_off[tid];
             run_off[tid] += total;
+            if (tid == 0) tmp[kSortWaves] = n_tile;
         }
         __syncthreads();
-        if constexpr (DIRECT) {
-            // straight to the output: slot = the digit's next free slot of this workgroup + the wave's offset inside the digit
-            // + the element's rank inside the wave -- the same slot the staged form computes, so the sort stays stable
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++) {
-                if (key[j] != kNoKey) {
-                    const uint32_t d = (key[j] >> shift) & dmask;
-                    const uint32_t dst = gbase[d] + cnt[wave][d] + rank[j];
-                    keys_out[dst] = key[j];
-                    idx_out[dst] = row[j];
-                    val_out[dst] = val[j];
-                }
-            }
-            __syncthreads();  // cnt / gbase are rewritten by the next tile
-            continue;
-        }
         // phase 3: into sorted position inside the tile
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
@@ -273,17 +253,12 @@ hipError_t scatter_launch(hipStream_t s, bool first, uint32_t nb, const uint32_t
                           uint64_t per_block, uint32_t shift, uint32_t nbits, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out,
                           uint32_t *idx_out, void *val_out) {
     constexpr int ITEMS = kWindowSortItems;
-    // KNOX_SORT_DIRECT=0: the staged form (reorder through LDS, coalesced runs out) for A/B runs
-    static const bool direct = !(getenv("KNOX_SORT_DIRECT") && atoi(getenv("KNOX_SORT_DIRECT")) == 0);
-#define KNOX_SCATTER(FIRST_, DIRECT_)                                                                                                        \
-    hipLaunchKernelGGL((sort_scatter_kernel<U, FIRST_, ITEMS, DIRECT_>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n, \
-                       per_block, shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out)
-    if (first) {
-        if (direct) KNOX_SCATTER(true, true); else KNOX_SCATTER(true, false);
-    } else {
-        if (direct) KNOX_SCATTER(false, true); else KNOX_SCATTER(false, false);
-    }
-#undef KNOX_SCATTER
+    if (first)
+        hipLaunchKernelGGL((sort_scatter_kernel<U, true, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n, per_block,
+                           shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
+    else
+        hipLaunchKernelGGL((sort_scatter_kernel<U, false, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n,
+                           per_block, shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
     return hipGetLastError();
 }
 
