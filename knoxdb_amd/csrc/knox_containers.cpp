@@ -1046,7 +1046,9 @@ KNOX_API int knox_enc_scan(knox_ctx *ctx, const knox_enc *e, int op, uint64_t a,
     prof_mark(ctx, 0);
     if (e->kind == 5) {
         const uint64_t n_chunks = (uint64_t)e->n_packs * (e->pack_rows / kEncChunkRows);
-        grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)std::min(grid_max, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 4)));
+        // latency bound (one 4 KiB wave iteration in flight per wave): the count / bitset form holds 8 KiB of LDS and runs 8 workgroups
+        // per CU; with the sum's per-code counters (40 KiB) 4 fit
+        grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)std::min(grid_max, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (want_sum ? 4 : 8))));
         he = launch_dict_scan(ctx->stream, grid, ea);
     } else {
         const uint64_t n_words = (uint64_t)e->n_packs * (e->pack_rows >> 6);

@@ -6,7 +6,9 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --no-cpu-baseline"   # the default run (20 steps, 3 warmup) minus the CPU leg
+BENCH="python3 $PWD/bench.py --no-cpu-baseline --no-placement-ab"   # the default run (20 steps, 3 warmup) minus the CPU leg and minus the
+# placement-off repetition (a second context without the arena runs the same kernels slower: its launches would be averaged into the
+# kernel-trace figures of the product path)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
