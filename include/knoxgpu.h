@@ -579,8 +579,6 @@ int knox_reduce_moments(knox_ctx *ctx, const knox_col *col, const knox_bits *mas
  * states[k] is the window's mergeable state (count == 0: the reference created no reducer).
  * flags bit0: the caller guarantees the order, skip the verification pass.
  * flags bit1: also run the var/std second pass per window (states carry the m_* moments).
- * flags bit5 (32): out-of-order time always goes through the sort (by default <= 1024 windows over an integer column without the
- * var / std pass are folded where the rows lie -- two streaming passes with LDS atomics, no sort; same states, bit for bit).
  * flags bit4 (16): run the verification pass even when this column's order is already known.  (What the pass finds is
  * kept with the column -- columns the library filled itself, until rows are appended or the column is reset; never for
  * knox_col_wrap -- so a time column that is queried again and again is checked once: the pass reads 8 B per row, half of

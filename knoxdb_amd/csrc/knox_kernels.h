@@ -362,12 +362,6 @@ hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *key
                                    uint32_t *idx_out, void *val_out);
 hipError_t launch_key_bounds(hipStream_t s, const uint32_t *keys, uint64_t n, uint32_t n_buckets, uint64_t *start);
 hipError_t launch_remap_rows(hipStream_t s, AggStateDev *states, uint32_t n_buckets, const uint32_t *idx, uint64_t row_base);
-// out-of-order time, few windows, integer values: states by LDS atomics in two streaming passes, no sort (knox_window.hip)
-constexpr uint32_t kHashWindows = 1024;   // the per-workgroup table: 8 fields x 8 B x windows of LDS (64 KiB: two workgroups per CU)
-size_t window_hash_scratch_bytes(uint32_t grid, uint32_t n_buckets);
-hipError_t launch_window_hash(hipStream_t s, int width, bool is_signed, int grid, const int64_t *time, const void *vals, const uint8_t *mask,
-                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t row_base, int dtype, void *scratch,
-                              AggStateDev *states_out);
 // per-window work items planned on the device: item_start[0..n_buckets] (last = item count), then the items
 uint32_t window_plan_blocks(uint32_t n_buckets, uint32_t *per_block);
 hipError_t launch_window_plan(hipStream_t s, const uint64_t *start, uint32_t n_buckets, uint32_t chunk_shift, uint32_t *block_sum,

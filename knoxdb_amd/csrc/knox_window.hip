@@ -392,199 +392,6 @@ hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Out-of-order time, FEW windows, integer values (round 4): no sort.  Every field of a window's state is an order-free fold
-// once "first" / "last" are read as the smallest / largest row id and the exact sum is split into two 64-bit adders -- so
-// the rows can be folded where they lie, with LDS atomics, into a per-workgroup table of <= 1024 windows:
-//   hash_agg1_kernel    one streaming pass (time 8 B + value W B + 1/8 B per row): window = (t - from) / step of every selected
-//                       row inside the range; ds_add (count, zero-extended wrapping sum, low / high half of the sign-correct
-//                       value), ds_min / ds_max (order key), ds_min / ds_max (row id).  The workgroup's table goes to memory.
-//   hash_merge_kernel   one lane per window folds the workgroups' tables.
-//   hash_agg2_kernel    "first occurrence wins" (reducer.go:256-296) needs the LOWEST row holding the window's min / max key, and
-//                       (key, row) does not fit one atomic: a second streaming pass, ds_min of the row id for the rows whose key
-//                       equals the merged min / max.
-//   hash_finalize       the workgroups' candidates folded, AggStateDev written as bucket_finalize_kernel writes it.
-// 2 x 16.1 B per row at streaming rate instead of the sort's ~5 passes (profiles/r04_windows.txt).  Floats keep the sort (their
-// double-double sums are not atomic), as do more than kHashWindows windows (the table is LDS) and the var / std second pass.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kHashFields = 8;  // count, isum, A (low 32 bits of the values), B (their upper bits), minkey, maxkey, firstrow, lastrow + 1
-struct HashAggArgs {
-    const int64_t *time;
-    const void *vals;
-    const uint8_t *mask;
-    uint64_t n_rows, per_block;
-    int64_t t_from, step;
-    uint32_t n_buckets;
-    uint64_t *partial;        // phase 1: [grid][kHashFields][n_buckets]; phase 2: [grid][2][n_buckets]
-    const uint64_t *merged;   // phase 2 / finalize: [kHashFields][n_buckets]
-};
-
-template <int W, bool SIGNED> __device__ __forceinline__ uint64_t hash_key(uint64_t raw) {
-    return SIGNED ? (raw ^ (uint64_t)WT<W>::SIGN) : raw;   // order key of the W-byte value, zero-extended (okey_raw)
-}
-
-template <int W, bool SIGNED, int PHASE>
-__global__ void __launch_bounds__(kBlock) hash_agg_kernel(const HashAggArgs a) {
-    extern __shared__ uint64_t tab[];   // PHASE 1: kHashFields x n_buckets; PHASE 2: minrow | maxrow | gmin | gmax, n_buckets each
-    const uint32_t nb = a.n_buckets;
-    if constexpr (PHASE == 1) {
-        for (uint32_t i = threadIdx.x; i < kHashFields * nb; i += kBlock) {
-            const uint32_t f = i / nb;
-            tab[i] = (f == 4 || f == 6) ? ~0ull : 0ull;      // minkey, firstrow start at the top
-        }
-    } else {
-        for (uint32_t i = threadIdx.x; i < 2 * nb; i += kBlock) tab[i] = ~0ull;
-        for (uint32_t i = threadIdx.x; i < nb; i += kBlock) {
-            tab[2 * nb + i] = a.merged[4 * (uint64_t)nb + i];
-            tab[3 * nb + i] = a.merged[5 * (uint64_t)nb + i];
-        }
-    }
-    __syncthreads();
-    const uint64_t begin = (uint64_t)blockIdx.x * a.per_block;
-    const uint64_t end = begin + a.per_block < a.n_rows ? begin + a.per_block : a.n_rows;
-    constexpr int U = 4;   // independent (timestamp, value, selection byte) loads per thread and step
-    for (uint64_t i0 = begin + threadIdx.x; i0 < end; i0 += (uint64_t)kBlock * U) {
-        int64_t t[U];
-        uint64_t v[U];
-        bool sel[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t i = i0 + (uint64_t)u * kBlock;
-            const bool in = i < end;
-            t[u] = in ? a.time[i] : 0;
-            v[u] = in ? (uint64_t)load_elem<W>(a.vals, i) : 0;
-            sel[u] = in && (a.mask == nullptr || ((a.mask[i >> 3] >> (i & 7)) & 1));
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t i = i0 + (uint64_t)u * kBlock;
-            if (!sel[u] || t[u] < a.t_from) continue;
-            const uint64_t q = (uint64_t)(t[u] - a.t_from) / (uint64_t)a.step;   // host checked: every window edge fits int64
-            if (q >= nb) continue;
-            const uint32_t w = (uint32_t)q;
-            const uint64_t key = hash_key<W, SIGNED>(v[u]);
-            if constexpr (PHASE == 1) {
-                const uint64_t sx = SIGNED ? sext_u64<W>((typename WT<W>::U)v[u]) : v[u];   // the value in 64-bit two's complement
-                atomicAdd((unsigned long long *)&tab[0 * nb + w], 1ull);
-                atomicAdd((unsigned long long *)&tab[1 * nb + w], (unsigned long long)v[u]);
-                atomicAdd((unsigned long long *)&tab[2 * nb + w], (unsigned long long)(sx & 0xffffffffull));
-                atomicAdd((unsigned long long *)&tab[3 * nb + w], (unsigned long long)(SIGNED ? (uint64_t)((int64_t)sx >> 32) : (sx >> 32)));
-                atomicMin((unsigned long long *)&tab[4 * nb + w], (unsigned long long)key);
-                atomicMax((unsigned long long *)&tab[5 * nb + w], (unsigned long long)key);
-                atomicMin((unsigned long long *)&tab[6 * nb + w], (unsigned long long)i);
-                atomicMax((unsigned long long *)&tab[7 * nb + w], (unsigned long long)(i + 1));
-            } else {
-                if (key == tab[2 * nb + w]) atomicMin((unsigned long long *)&tab[0 * nb + w], (unsigned long long)i);
-                if (key == tab[3 * nb + w]) atomicMin((unsigned long long *)&tab[1 * nb + w], (unsigned long long)i);
-            }
-        }
-    }
-    __syncthreads();
-    constexpr uint32_t NF = PHASE == 1 ? kHashFields : 2;
-    uint64_t *out = a.partial + (uint64_t)blockIdx.x * NF * nb;
-    for (uint32_t i = threadIdx.x; i < NF * nb; i += kBlock) out[i] = tab[i];
-}
-
-// one lane per window: the workgroups' tables folded field by field
-__global__ void __launch_bounds__(kBlock) hash_merge_kernel(const uint64_t *partial, uint32_t grid, uint32_t nb, uint64_t *merged) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nb) return;
-    uint64_t f[kHashFields] = {0, 0, 0, 0, ~0ull, 0, ~0ull, 0};
-    for (uint32_t b = 0; b < grid; b++) {
-        const uint64_t *p = partial + (uint64_t)b * kHashFields * nb + w;
-        f[0] += p[0];
-        f[1] += p[(uint64_t)nb];
-        f[2] += p[2 * (uint64_t)nb];
-        f[3] += p[3 * (uint64_t)nb];   // two's complement: the signed high parts add as unsigned words
-        const uint64_t mn = p[4 * (uint64_t)nb], mx = p[5 * (uint64_t)nb], fr = p[6 * (uint64_t)nb], la = p[7 * (uint64_t)nb];
-        f[4] = mn < f[4] ? mn : f[4];
-        f[5] = mx > f[5] ? mx : f[5];
-        f[6] = fr < f[6] ? fr : f[6];
-        f[7] = la > f[7] ? la : f[7];
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < kHashFields; k++) merged[(uint64_t)k * nb + w] = f[k];
-}
-
-template <int W, bool SIGNED>
-__global__ void __launch_bounds__(kBlock) hash_finalize_kernel(const uint64_t *merged, const uint64_t *partial2, uint32_t grid, uint32_t nb, const void *vals,
-                                                               uint64_t row_base, int dtype, AggStateDev *state_out) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nb) return;
-    uint64_t minrow = ~0ull, maxrow = ~0ull;
-    for (uint32_t b = 0; b < grid; b++) {
-        const uint64_t r0 = partial2[(uint64_t)b * 2 * nb + w], r1 = partial2[(uint64_t)b * 2 * nb + nb + w];
-        minrow = r0 < minrow ? r0 : minrow;
-        maxrow = r1 < maxrow ? r1 : maxrow;
-    }
-    const uint64_t count = merged[w], isum = merged[(uint64_t)nb + w], A = merged[2 * (uint64_t)nb + w], B = merged[3 * (uint64_t)nb + w];
-    const uint64_t minkey = merged[4 * (uint64_t)nb + w], maxkey = merged[5 * (uint64_t)nb + w];
-    const uint64_t firstrow = merged[6 * (uint64_t)nb + w], lastrow1 = merged[7 * (uint64_t)nb + w];
-    // S = A + B * 2^32 in 128 bits (B signed for signed columns)
-    const uint64_t blo = B << 32;
-    const int64_t bhi = SIGNED ? (int64_t)B >> 32 : (int64_t)(B >> 32);
-    const uint64_t xlo = A + blo;
-    const int64_t xhi = bhi + (int64_t)(xlo < A);
-    AggStateDev s;
-    s.dtype = dtype;
-    s.flags = 1u;
-    s.count = (int64_t)count;
-    s.isum = isum;
-    s.fsum_hi = 0.0;
-    s.fsum_lo = 0.0;
-    int128_to_dd(xlo, xhi, s.fsum_hi, s.fsum_lo);
-    const bool any = count != 0;
-    s.min_row = any ? (int64_t)(row_base + minrow) : -1;
-    s.max_row = any ? (int64_t)(row_base + maxrow) : -1;
-    s.first_row = any ? (int64_t)(row_base + firstrow) : -1;
-    s.last_row = any ? (int64_t)(row_base + lastrow1 - 1) : -1;
-    s.min_bits = any ? hash_key<W, SIGNED>(minkey) : 0;     // the key map is its own inverse
-    s.max_bits = any ? hash_key<W, SIGNED>(maxkey) : 0;
-    s.first_bits = any ? (uint64_t)load_elem<W>(vals, firstrow) : 0;
-    s.last_bits = any ? (uint64_t)load_elem<W>(vals, lastrow1 - 1) : 0;
-    s.m_shift = 0.0; s.m_dev_hi = 0.0; s.m_dev_lo = 0.0; s.m_sq_hi = 0.0; s.m_sq_lo = 0.0;
-    state_out[w] = s;
-}
-
-size_t window_hash_scratch_bytes(uint32_t grid, uint32_t n_buckets) {
-    return ((size_t)grid * kHashFields + kHashFields + (size_t)grid * 2) * n_buckets * 8 + 256;
-}
-
-// scratch: window_hash_scratch_bytes(grid, n_buckets); states_out: AggStateDev[n_buckets]
-hipError_t launch_window_hash(hipStream_t s, int width, bool is_signed, int grid, const int64_t *time, const void *vals, const uint8_t *mask,
-                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t row_base, int dtype, void *scratch,
-                              AggStateDev *states_out) {
-    if (grid < 1 || n_buckets == 0 || n_buckets > kHashWindows) return hipErrorInvalidValue;
-    HashAggArgs a;
-    a.time = time, a.vals = vals, a.mask = mask, a.n_rows = n_rows;
-    a.per_block = ((n_rows + (uint64_t)grid - 1) / (uint64_t)grid + 1023) & ~1023ull;
-    a.t_from = t_from, a.step = step, a.n_buckets = n_buckets;
-    uint64_t *p1 = (uint64_t *)scratch;
-    uint64_t *merged = p1 + (size_t)grid * kHashFields * n_buckets;
-    uint64_t *p2 = merged + (size_t)kHashFields * n_buckets;
-    const size_t lds1 = (size_t)kHashFields * n_buckets * 8, lds2 = (size_t)4 * n_buckets * 8;
-    const int gm = (int)((n_buckets + kBlock - 1) / kBlock);
-#define KNOX_HASH(W, S)                                                                                                          \
-    do {                                                                                                                         \
-        a.partial = p1, a.merged = nullptr;                                                                                      \
-        hipLaunchKernelGGL((hash_agg_kernel<W, S, 1>), dim3(grid), dim3(kBlock), lds1, s, a);                                    \
-        hipLaunchKernelGGL(hash_merge_kernel, dim3(gm), dim3(kBlock), 0, s, (const uint64_t *)p1, (uint32_t)grid, n_buckets, merged); \
-        a.partial = p2, a.merged = merged;                                                                                       \
-        hipLaunchKernelGGL((hash_agg_kernel<W, S, 2>), dim3(grid), dim3(kBlock), lds2, s, a);                                    \
-        hipLaunchKernelGGL((hash_finalize_kernel<W, S>), dim3(gm), dim3(kBlock), 0, s, (const uint64_t *)merged, (const uint64_t *)p2, \
-                           (uint32_t)grid, n_buckets, vals, row_base, dtype, states_out);                                       \
-    } while (0)
-    switch (width) {
-    case 8: if (is_signed) KNOX_HASH(8, true); else KNOX_HASH(8, false); break;
-    case 4: if (is_signed) KNOX_HASH(4, true); else KNOX_HASH(4, false); break;
-    case 2: if (is_signed) KNOX_HASH(2, true); else KNOX_HASH(2, false); break;
-    case 1: if (is_signed) KNOX_HASH(1, true); else KNOX_HASH(1, false); break;
-    default: return hipErrorInvalidValue;
-    }
-#undef KNOX_HASH
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
 // Literal reducers per time window: one lane owns one window [start[k], start[k+1]) and applies
 // the reference's reducer statement by statement in row order -- plain reducers (reducer.go:
 // 130-429) and the join reducers (reducer.go:432-731), whose `join` argument is "this row's raw

@@ -656,13 +656,13 @@ class Context:
             check(self.L.knox_reduce_moments(self.h, col.h, mask.h if mask is not None else None, C.byref(st)), "knox_reduce_moments")
         return st
 
-    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False, out=None, recheck=False, no_hash=False):
+    def reduce_buckets(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False, out=None, recheck=False):
         """One mergeable state per time window [t_from + k*step, +step): NativeBucket semantics.
         moments=True adds the var/std second pass per window.  out: a (AggState * n_buckets) array to fill (a caller that
         asks again and again keeps one; a fresh 144 B x n_buckets array is first-touch page faults on every call)."""
         states = out if out is not None else (AggState * n_buckets)()
         check(self.L.knox_reduce_buckets(self.h, time_col.h, value_col.h, mask.h if mask is not None else None, t_from, step,
-                                         n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0) | (16 if recheck else 0) | (32 if no_hash else 0), states), "knox_reduce_buckets")
+                                         n_buckets, row_base, (1 if assume_sorted else 0) | (2 if moments else 0) | (16 if recheck else 0), states), "knox_reduce_buckets")
         return states   # ctypes array: indexable / iterable, no per-window Python objects until touched
 
     def reduce_buckets_view(self, time_col, value_col, t_from, step, n_buckets, mask=None, row_base=0, assume_sorted=False, moments=False):

@@ -46,15 +46,12 @@ for lg, shuffled in ((28, False), (28, True)) if quick else ((30, False), (26, F
         ms_chk = timed(lambda: rb(recheck=True))
         ms = timed(lambda: rb())
         ms_v = timed(lambda: rb(moments=True))
-        ms_sort = timed(lambda: rb(no_hash=True)) if shuffled and nb <= 1024 else None
         ms_view = timed(lambda: ctx.reduce_buckets_view(clock, col, 1000, max(step, 1), nb, mask=bits))
         ms_sum_chk = timed(lambda: rv(R.Sum, recheck=True))
         ms_sum = timed(lambda: rv(R.Sum))
         ms_std = timed(lambda: rv(R.Std))
         print("2^%d rows, %s clock, %7d windows: states %7.2f ms checked (%.1f G rows/s), %7.2f ms order known (%.1f G rows/s), with var/std %7.2f ms, as a pinned view %7.2f ms | values: sum %7.2f ms checked (%.1f G rows/s), %7.2f ms order known (%.1f G rows/s), std %7.2f ms" % (
             lg, "shuffled" if shuffled else "ordered ", nb, ms_chk, n / ms_chk / 1e6, ms, n / ms / 1e6, ms_v, ms_view, ms_sum_chk, n / ms_sum_chk / 1e6, ms_sum, n / ms_sum / 1e6, ms_std), flush=True)
-        if ms_sort is not None:
-            print("    (the same through the sort, flags bit 5: states %7.2f ms order known = %.1f G rows/s)" % (ms_sort, n / ms_sort / 1e6), flush=True)
     if not shuffled and lg <= 28:
         # the literal reducers per window (knox_reduce_buckets_sequential): one lane per window against one wave per window
         for nb in (1024, 16384, 65536, 1 << 20):
