@@ -483,27 +483,32 @@ size_t knox_packed_bytes(const knox_packed *p); /* packed payload resident in HB
 int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint64_t a, uint64_t b, int want_sum,
                      knox_bits *bits_out, int64_t *pack_counts, int64_t *count, knox_agg_state *sum_state);
 
-/* ---- dictionary and run-end columns scanned as they are (round 4) ----------------------------- *
- * The reference matches on these containers without materializing them: DictionaryContainer.Match*
- * looks the value up in the sorted dictionary and compares the uint16 CODES (internal/encode/int_dict.go:181-380),
- * RunEndContainer.Match* compares the run VALUES and turns matching runs into row ranges
- * (int_runend.go:224-330).  So does the device: the integer containers [5] / [3] of consecutive packs stay
- * encoded in HBM -- a dictionary column is 2 B per row plus its dictionaries, a run-end column (W + 4) B per
- * run -- and knox_enc_scan evaluates one numeric leaf on them: selection bitset, count, wrapping sum, per-pack
- * counts.  The children (dictionary / codes, values / ends) may be any integer container the reference nests
- * there except another dictionary / run-end; they are decoded on the device, so what crosses PCIe is the
- * container's own bytes.  Any integer dtype; ONE kind per column (KNOX_E_UNSUPPORTED otherwise: upload the packs
- * with knox_col_upload_raw_containers instead); pack_rows a multiple of 8192; every pack but the last holds
- * exactly pack_rows rows.  Results are identical to knox_col_upload_raw_containers + knox_scan on the same
- * containers (tests/test_gpu_encoded.py).  op = KNOX_EQ .. KNOX_LE, KNOX_RANGE; a / b as in a knox_pred leaf.   */
+/* ---- integer columns kept ENCODED in HBM and scanned as they are (round 4) --------------------- *
+ * The reference matches on containers without materializing them: DictionaryContainer.Match* looks the value up
+ * in the sorted dictionary and compares the uint16 CODES (internal/encode/int_dict.go:181-380), RunEndContainer.Match*
+ * compares the run VALUES and turns matching runs into row ranges (int_runend.go:224-330), constant and delta
+ * containers answer from their header (int_const.go, int_delta.go).  So does the device, PACK BY PACK -- the
+ * reference's encoder picks the scheme per block, a run of packs is usually mixed:
+ *   dictionary [5]   2 B of codes per row + the dictionary (predicate evaluated on the dictionary once per pack)
+ *   run-end [3]      (W + 4) B per run (predicate on the run values, matching runs expanded into the bitset)
+ *   constant [1], delta [2]   nothing resident: row i = T(i * delta + base)
+ *   every other integer container (raw, bit-packed, simple8, nested dictionary / run-end): decoded on the device
+ *                    at upload, W B per row, compared there
+ * knox_enc_scan evaluates one numeric leaf on such a column: selection bitset, count, wrapping sum, per-pack counts.
+ * The children of dictionary / run-end containers are decoded on the device; what crosses PCIe is the containers'
+ * own bytes.  Any integer dtype (floats: KNOX_E_UNSUPPORTED, use knox_col_upload_raw_containers); pack_rows a
+ * multiple of 8192; every pack but the last holds exactly pack_rows rows.  Results are identical to
+ * knox_col_upload_raw_containers + knox_scan on the same containers (tests/test_gpu_encoded.py).
+ * op = KNOX_EQ .. KNOX_LE, KNOX_RANGE; a / b as in a knox_pred leaf.                                              */
 typedef struct knox_enc knox_enc;
 int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs,
                     size_t pack_rows, knox_enc **out);
 int knox_enc_free(knox_enc *e);
 size_t knox_enc_rows(const knox_enc *e);
-size_t knox_enc_bytes(const knox_enc *e);           /* bytes resident in HBM: codes + dictionaries, or run values + ends */
+size_t knox_enc_bytes(const knox_enc *e);           /* bytes resident in HBM (codes + dictionaries, run values + ends, decoded packs) */
 size_t knox_enc_container_bytes(const knox_enc *e); /* bytes of the containers as they came (what crossed PCIe)        */
-int knox_enc_kind(const knox_enc *e);               /* 5 = dictionary, 3 = run-end (encode.ContainerType)             */
+/* how many packs are scanned in which form (each pointer nullable) */
+int knox_enc_kinds(const knox_enc *e, size_t *n_dictionary, size_t *n_runend, size_t *n_const_delta, size_t *n_raw);
 /* bits_out nullable; pack_counts (host, n_packs) needs bits_out; sum_state (nullable unless want_sum) receives
  * count + isum (knox_agg_value: Sum, Count).                                                                  */
 int knox_enc_scan(knox_ctx *ctx, const knox_enc *e, int op, uint64_t a, uint64_t b, int want_sum,

@@ -842,10 +842,10 @@ type Bloom struct {
 
 // ---- dictionary / run-end columns scanned as they are (internal/encode/int_dict.go:181-380, int_runend.go:224-330) ----
 
-// Encoded is a column whose packs stay dictionary- or run-end-encoded in HBM (encode.TIntDictionary / TIntRunEnd containers,
-// NumberContainer.Store bytes): the predicate runs on the dictionary / the run values, the codes / runs are never expanded.
-// A run of packs qualifies when every block of the column arrives as the same container kind (GpuRun keeps such a column
-// here instead of UploadRawContainers when the query has ONE numeric leaf on it).
+// Encoded is an integer column whose packs stay ENCODED in HBM (NumberContainer.Store bytes, any scheme, mixed pack by pack as the
+// encoder chose them): dictionary and run-end packs are matched on their dictionary / run values (encode.TIntDictionary /
+// TIntRunEnd), constant and delta packs from their header, every other scheme is decoded on the device.  GpuRun keeps a column
+// here instead of UploadRawContainers when the query has ONE numeric leaf on it.
 type Encoded struct {
 	p *C.knox_enc
 	c *Ctx

@@ -108,7 +108,7 @@ SIGNATURES = {
     "knox_enc_rows": (_sz, [_vp]),
     "knox_enc_bytes": (_sz, [_vp]),
     "knox_enc_container_bytes": (_sz, [_vp]),
-    "knox_enc_kind": (_i, [_vp]),
+    "knox_enc_kinds": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "knox_enc_scan": (_i, [_vp, _vp, _i, _u64, _u64, _i, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AggState)]),
     "knox_col_upload_wide_containers": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _pp]),
     "knox_bits_upload_bitmap_container": (_i, [_vp, _vp, C.c_char_p, _sz]),

@@ -888,22 +888,28 @@ KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint6
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dictionary [5] and run-end [3] integer containers kept ENCODED in HBM and scanned as they are (round 4).  The reference
-// matches on these containers without materializing them (internal/encode/int_dict.go:181-380: the compare runs on the
-// uint16 codes; int_runend.go:224-330: on the run values, hit runs become row ranges); round 3 expanded them to full-width
-// vectors at upload.  Here the children are decoded on the device (any integer container the reference nests there: raw,
-// bit-packed, constant, delta, simple8) but the container itself is not: a dictionary column holds 2 B per row + its
-// dictionaries, a run-end column (W + 4) B per run.  The bytes that cross PCIe are the container's own.
+// Integer columns kept ENCODED in HBM and scanned as they are (round 4).  The reference matches on containers without
+// materializing them (internal/encode/int_dict.go:181-380: the compare runs on the uint16 codes; int_runend.go:224-330: on the run
+// values, hit runs become row ranges; int_const.go / int_delta.go: from the header alone); round 3 expanded everything but
+// bit-packed containers to full-width vectors at upload.  Here every pack keeps the form it is cheapest to scan in, pack by pack
+// (the reference's encoder chooses the scheme per block, so a run of packs is usually MIXED):
+//   dictionary [5]   2 B of codes per row + the dictionary        run-end [3]   (W + 4) B per run
+//   constant [1], delta [2]   nothing but the header             everything else (raw, bit-packed, simple8, nested containers): decoded on
+//   the device at upload into W B per row and compared there (kind 7).
+// The children of dictionary / run-end containers are decoded on the device too (any integer container the reference nests there but
+// another dictionary / run-end); what crosses PCIe is always the container's own bytes.
 // ------------------------------------------------------------------------------------------------
 struct knox_enc {
     knox_ctx *ctx;
-    int dtype, kind;           // kind = the container type: 5 dictionary, 3 run-end
+    int dtype;
     size_t n_rows, pack_rows, n_packs;
-    void *d_vals = nullptr;    // dictionary entries / run values of all packs
-    uint16_t *d_codes = nullptr;
-    uint32_t *d_ends = nullptr;
+    void *d_vals = nullptr;       // dictionary entries / run values / raw values of all packs
+    uint16_t *d_codes = nullptr;  // pack_rows codes per dictionary pack
+    uint32_t *d_ends = nullptr;   // indexed like d_vals (only run-end packs use their slots)
     EncPack *d_packs = nullptr;
-    size_t n_vals = 0, resident_bytes = 0, container_bytes = 0;
+    uint32_t *d_lists = nullptr;  // pack numbers by scanned kind: dictionary | run-end | constant + delta | raw
+    size_t n_dict = 0, n_run = 0, n_aff = 0, n_raw = 0;
+    size_t resident_bytes = 0, container_bytes = 0;
 };
 
 KNOX_API int knox_enc_free(knox_enc *e) {
@@ -914,98 +920,172 @@ KNOX_API int knox_enc_free(knox_enc *e) {
     if (e->d_codes) dev_free(e->ctx, e->d_codes);
     if (e->d_ends) dev_free(e->ctx, e->d_ends);
     if (e->d_packs) dev_free(e->ctx, e->d_packs);
+    if (e->d_lists) dev_free(e->ctx, e->d_lists);
     delete e;
     return KNOX_OK;
 }
 KNOX_API size_t knox_enc_rows(const knox_enc *e) { return e ? e->n_rows : 0; }
 KNOX_API size_t knox_enc_bytes(const knox_enc *e) { return e ? e->resident_bytes : 0; }
 KNOX_API size_t knox_enc_container_bytes(const knox_enc *e) { return e ? e->container_bytes : 0; }
-KNOX_API int knox_enc_kind(const knox_enc *e) { return e ? e->kind : 0; }
+KNOX_API int knox_enc_kinds(const knox_enc *e, size_t *n_dictionary, size_t *n_runend, size_t *n_const_delta, size_t *n_raw) {
+    if (!e) return KNOX_E_INVALID;
+    if (n_dictionary) *n_dictionary = e->n_dict;
+    if (n_runend) *n_runend = e->n_run;
+    if (n_const_delta) *n_const_delta = e->n_aff;
+    if (n_raw) *n_raw = e->n_raw;
+    return KNOX_OK;
+}
 
 KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *bufs, const size_t *lens, size_t n_bufs, size_t pack_rows, knox_enc **out) {
     if (!ctx || !out || !n_bufs || !bufs || !lens || dtype_width(dtype) == 0 || dtype == KNOX_BYTES) return KNOX_E_INVALID;
-    if (dtype_is_float(dtype)) return KNOX_E_UNSUPPORTED;  // float dictionaries / runs ([12] / [11]) take the decoding path
+    if (dtype_is_float(dtype)) return KNOX_E_UNSUPPORTED;  // float containers take the decoding path (knox_col_upload_raw_containers)
     if (pack_rows == 0 || (pack_rows % kEncChunkRows) || n_bufs > 0xffffffffull) return KNOX_E_INVALID;  // whole 8192-row chunks
     *out = nullptr;
     hipSetDevice(ctx->device);
     const int w = dtype_width(dtype);
-    // pass 1: headers -- kind, children, element counts
-    struct Child { size_t off1, len1, n1, off2, len2, n2; };
-    std::vector<Child> ch(n_bufs);
-    int kind = 0;
-    size_t total_vals = 0, total_bytes = 0;
+    // pass 1: headers -- how every pack will be scanned, element counts
+    struct Plan { uint32_t kind; size_t off1, len1, n1, off2, len2, n2; uint64_t base, delta; };
+    std::vector<Plan> pl(n_bufs);
+    size_t total_vals = 0, total_bytes = 0, n_dict = 0;
     for (size_t i = 0; i < n_bufs; i++) {
         const uint8_t *b = bufs[i];
-        if (!b || lens[i] < 3) return KNOX_E_INVALID;
-        if (b[0] != 5 && b[0] != 3) return KNOX_E_UNSUPPORTED;
-        if (i == 0) kind = b[0];
-        if (b[0] != kind) return KNOX_E_UNSUPPORTED;  // one kind per column (a mixed run of packs takes the decoding path)
-        size_t n1 = 0, c1 = 0, n2 = 0, c2 = 0;
-        if (b[1] == 3 || b[1] == 5) return KNOX_E_UNSUPPORTED;  // a nested dictionary / run-end child reports its rows late
-        int rc = container_measure(b + 1, lens[i] - 1, w, false, &n1, &c1, 1);
-        if (rc) return rc;
-        if (1 + c1 >= lens[i]) return KNOX_E_RANGE;
-        if (b[1 + c1] == 3 || b[1 + c1] == 5) return KNOX_E_UNSUPPORTED;
-        rc = container_measure(b + 1 + c1, lens[i] - 1 - c1, kind == 5 ? 2 : 4, false, &n2, &c2, 1);
-        if (rc) return rc;
-        if (kind == 5) {
-            if (n1 == 0 || n1 > 65536 || n2 == 0 || n2 > pack_rows || (i + 1 < n_bufs && n2 != pack_rows)) return KNOX_E_INVALID;
-        } else {
-            if (n1 == 0 || n1 != n2 || n1 > pack_rows) return KNOX_E_INVALID;
-        }
-        ch[i] = Child{1, c1, n1, 1 + c1, c2, n2};
-        total_vals += n1;
+        if (!b || lens[i] < 2) return KNOX_E_INVALID;
+        Plan &p = pl[i];
+        p = Plan{7, 0, lens[i], 0, 0, 0, 0, 0, 0};
         total_bytes += lens[i];
+        const bool nested = (b[0] == 5 || b[0] == 3) && lens[i] >= 3 && (b[1] == 3 || b[1] == 5);  // a dictionary / run-end child reports its rows late
+        if ((b[0] == 5 || b[0] == 3) && !nested) {
+            size_t n1 = 0, c1 = 0, n2 = 0, c2 = 0;
+            int rc = container_measure(b + 1, lens[i] - 1, w, false, &n1, &c1, 1);
+            if (rc) return rc;
+            if (1 + c1 >= lens[i]) return KNOX_E_RANGE;
+            const bool nested2 = b[1 + c1] == 3 || b[1 + c1] == 5;
+            if (!nested2) {
+                rc = container_measure(b + 1 + c1, lens[i] - 1 - c1, b[0] == 5 ? 2 : 4, false, &n2, &c2, 1);
+                if (rc) return rc;
+                if (b[0] == 5 && n1 >= 1 && n1 <= 65536 && n2 >= 1) {
+                    p = Plan{5, 1, c1, n1, 1 + c1, c2, n2, 0, 0};
+                    total_vals += n1;
+                    n_dict++;
+                    continue;
+                }
+                if (b[0] == 3 && n1 >= 1 && n1 == n2) {
+                    p = Plan{3, 1, c1, n1, 1 + c1, c2, n2, 0, 0};
+                    total_vals += n1;
+                    continue;
+                }
+            }
+        }
+        if (b[0] == 1 || b[0] == 2) {  // [1][base][N] / [2][For][Delta][N] (int_const.go:67-84, int_delta.go:70-95)
+            size_t o = 1;
+            uint64_t base = 0, delta = 0, n = 0;
+            int k = knox_uvarint(b + o, lens[i] - o, &base);
+            if (k == 0) return KNOX_E_INVALID;
+            o += (size_t)k;
+            if (b[0] == 2) {
+                k = knox_uvarint(b + o, lens[i] - o, &delta);
+                if (k == 0) return KNOX_E_INVALID;
+                o += (size_t)k;
+            }
+            k = knox_uvarint(b + o, lens[i] - o, &n);
+            if (k == 0 || n == 0) return KNOX_E_INVALID;
+            p = Plan{(uint32_t)b[0], 0, 0, 0, 0, 0, (size_t)n, base, delta};
+            continue;
+        }
+        // everything else: the container decoded on the device (W B per row), scanned as raw values
+        size_t n = 0, c = 0;
+        int rc = container_measure(b, lens[i], w, false, &n, &c, 0);
+        if (rc) return rc;
+        if (b[0] == 3) {  // a (nested) run-end container knows its row count only from its ends
+            rc = container_rows(ctx, b, lens[i], w, false, &n);
+            if (rc) return rc;
+        }
+        if (n == 0) return KNOX_E_INVALID;
+        p.n2 = n;
+        total_vals += n;
     }
     knox_enc *e = new (std::nothrow) knox_enc();
     if (!e) return KNOX_E_NOMEM;
     e->ctx = ctx;
     e->dtype = dtype;
-    e->kind = kind;
     e->pack_rows = pack_rows;
     e->n_packs = n_bufs;
-    e->n_vals = total_vals;
     e->container_bytes = total_bytes;
     hipError_t he = dev_malloc(ctx, &e->d_vals, total_vals * (size_t)w + 64);
     if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_packs, n_bufs * sizeof(EncPack) + 64);
-    if (he == hipSuccess && kind == 5) he = dev_malloc(ctx, (void **)&e->d_codes, n_bufs * pack_rows * 2 + 256);
-    if (he == hipSuccess && kind == 3) he = dev_malloc(ctx, (void **)&e->d_ends, total_vals * 4 + 64);
+    if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_lists, n_bufs * 4 + 64);
+    if (he == hipSuccess && n_dict) he = dev_malloc(ctx, (void **)&e->d_codes, n_dict * pack_rows * 2 + 256);
+    if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_ends, total_vals * 4 + 64);
     if (he != hipSuccess) {
         ctx->last_hip = (int)he;
         knox_enc_free(e);
         return KNOX_E_NOMEM;
     }
-    // pass 2: children onto the device (decoded there), pack table
+    // pass 2: payloads onto the device (children / whole containers decoded there), pack table
     std::vector<EncPack> packs(n_bufs);
-    size_t voff = 0, rows = 0;
+    std::vector<uint32_t> l_dict, l_run, l_aff, l_raw;
+    size_t voff = 0, coff = 0, rows = 0, resident = 0;
     int rc = KNOX_OK;
     for (size_t i = 0; i < n_bufs && !rc; i++) {
-        const Child &c = ch[i];
-        rc = container_decode(ctx, bufs[i] + c.off1, c.len1, w, false, (char *)e->d_vals + voff * (size_t)w, c.n1, 1);
+        const Plan &c = pl[i];
+        EncPack hp;
+        memset(&hp, 0, sizeof hp);
+        hp.kind = c.kind;
         uint32_t prows = 0;
-        if (!rc && kind == 5) {
-            rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 2, false, e->d_codes + i * pack_rows, c.n2, 1);
+        if (c.kind == 5) {
+            rc = container_decode(ctx, bufs[i] + c.off1, c.len1, w, false, (char *)e->d_vals + voff * (size_t)w, c.n1, 1);
+            if (!rc) rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 2, false, e->d_codes + coff, c.n2, 1);
+            hp.off = voff, hp.code_off = coff, hp.len = (uint32_t)c.n1;
             prows = (uint32_t)c.n2;
-        } else if (!rc) {
-            rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 4, false, e->d_ends + voff, c.n2, 1);
+            voff += c.n1;
+            coff += pack_rows;
+            resident += c.n1 * (size_t)w + c.n2 * 2;
+            l_dict.push_back((uint32_t)i);
+        } else if (c.kind == 3) {
+            rc = container_decode(ctx, bufs[i] + c.off1, c.len1, w, false, (char *)e->d_vals + voff * (size_t)w, c.n1, 1);
+            if (!rc) rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 4, false, e->d_ends + voff, c.n2, 1);
             uint32_t last = 0;  // the pack's row count = its last inclusive end + 1 (int_runend.go:109)
             if (!rc && (hipMemcpyAsync(&last, e->d_ends + voff + (c.n2 - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                         hipStreamSynchronize(ctx->stream) != hipSuccess))
                 rc = KNOX_E_HIP;
-            if (!rc && ((uint64_t)last + 1 > pack_rows || (i + 1 < n_bufs && (uint64_t)last + 1 != pack_rows))) rc = KNOX_E_INVALID;
+            hp.off = voff, hp.len = (uint32_t)c.n1;
             prows = last + 1;
+            voff += c.n1;
+            resident += c.n1 * ((size_t)w + 4);
+            l_run.push_back((uint32_t)i);
+        } else if (c.kind == 1 || c.kind == 2) {
+            hp.base = c.base, hp.delta = c.kind == 2 ? c.delta : 0;
+            prows = (uint32_t)c.n2;
+            l_aff.push_back((uint32_t)i);
+        } else {
+            rc = container_decode(ctx, bufs[i], lens[i], w, false, (char *)e->d_vals + voff * (size_t)w, c.n2, 0);
+            hp.off = voff, hp.len = (uint32_t)c.n2;
+            prows = (uint32_t)c.n2;
+            voff += c.n2;
+            resident += c.n2 * (size_t)w;
+            l_raw.push_back((uint32_t)i);
         }
-        packs[i] = EncPack{(uint64_t)voff, (uint32_t)c.n1, prows};
-        voff += c.n1;
+        if (!rc && ((uint64_t)prows > pack_rows || prows == 0 || (i + 1 < n_bufs && (uint64_t)prows != pack_rows))) rc = KNOX_E_INVALID;  // only the last pack may be short
+        hp.rows = prows;
+        packs[i] = hp;
         rows += prows;
     }
     if (!rc) rc = upload(ctx, e->d_packs, packs.data(), n_bufs * sizeof(EncPack));
+    if (!rc) {
+        std::vector<uint32_t> all;
+        all.insert(all.end(), l_dict.begin(), l_dict.end());
+        all.insert(all.end(), l_run.begin(), l_run.end());
+        all.insert(all.end(), l_aff.begin(), l_aff.end());
+        all.insert(all.end(), l_raw.begin(), l_raw.end());
+        rc = upload(ctx, e->d_lists, all.data(), all.size() * 4);
+    }
     if (rc) {
         knox_enc_free(e);
         return rc;
     }
+    e->n_dict = l_dict.size(), e->n_run = l_run.size(), e->n_aff = l_aff.size(), e->n_raw = l_raw.size();
     e->n_rows = rows;
-    e->resident_bytes = total_vals * (size_t)w + (kind == 5 ? rows * 2 : total_vals * 4) + n_bufs * sizeof(EncPack);
+    e->resident_bytes = resident + n_bufs * (sizeof(EncPack) + 4);
     *out = e;
     return KNOX_OK;
 }
@@ -1021,7 +1101,7 @@ KNOX_API int knox_enc_scan(knox_ctx *ctx, const knox_enc *e, int op, uint64_t a,
     int rc = make_leaf(e->dtype, op, a, b, lh);
     if (rc) return rc;
     const int grid_max = std::max(1, ctx->n_cus * 8);
-    rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(grid_max + 1) * 16);
+    rc = ensure(ctx, ctx->partials, sizeof(AggPartial) * (size_t)(4 * grid_max + 1) * 16);
     if (!rc) rc = ensure(ctx, ctx->states, sizeof(AggStateDev) * 16 + 8 * 16);
     if (rc) return rc;
     EncScanArgs ea;
@@ -1030,7 +1110,6 @@ KNOX_API int knox_enc_scan(knox_ctx *ctx, const knox_enc *e, int op, uint64_t a,
     ea.codes = e->d_codes;
     ea.ends = e->d_ends;
     ea.packs = e->d_packs;
-    ea.n_packs = (uint32_t)e->n_packs;
     ea.width = (uint32_t)dtype_width(e->dtype);
     ea.pack_rows = e->pack_rows;
     ea.n_rows = e->n_rows;
@@ -1040,25 +1119,40 @@ KNOX_API int knox_enc_scan(knox_ctx *ctx, const knox_enc *e, int op, uint64_t a,
     ea.negate = lh.neg ? 1u : 0u;
     ea.want_sum = want_sum ? 1u : 0u;
     ea.bits = bits_out ? bits_out->dev : nullptr;
-    ea.partials = (AggPartial *)ctx->partials.p;
+    AggPartial *part = (AggPartial *)ctx->partials.p;
+    int n_part = 0;                       // partials written so far: one launch after the other appends its workgroups
     hipError_t he = hipSuccess;
-    int grid = 1;
     prof_mark(ctx, 0);
-    if (e->kind == 5) {
-        const uint64_t n_chunks = (uint64_t)e->n_packs * (e->pack_rows / kEncChunkRows);
+    const uint32_t *lists = e->d_lists;
+    if (e->n_dict && he == hipSuccess) {  // the dominant kernel when there are dictionary packs
+        ea.list = lists, ea.n_list = (uint32_t)e->n_dict, ea.partials = part + n_part;
+        const uint64_t n_chunks = (uint64_t)e->n_dict * (e->pack_rows / kEncChunkRows);
         // latency bound (one 4 KiB wave iteration in flight per wave): the count / bitset form holds 8 KiB of LDS and runs 8 workgroups
         // per CU; with the sum's per-code counters (40 KiB) 4 fit
-        grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)std::min(grid_max, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (want_sum ? 4 : 8))));
+        const int grid = (int)std::min<uint64_t>(n_chunks, (uint64_t)std::min(grid_max, ctx->n_cus * (ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (want_sum ? 4 : 8))));
         he = launch_dict_scan(ctx->stream, grid, ea);
-    } else {
-        const uint64_t n_words = (uint64_t)e->n_packs * (e->pack_rows >> 6);
+        n_part += grid;
+    }
+    if (e->n_run && he == hipSuccess) {
+        ea.list = lists + e->n_dict, ea.n_list = (uint32_t)e->n_run, ea.partials = part + n_part;
+        const uint64_t n_words = (uint64_t)e->n_run * (e->pack_rows >> 6);
         const int grid_bits = (int)std::min<uint64_t>((n_words + kBlock - 1) / kBlock, (uint64_t)ctx->n_cus * 16);
-        grid = (int)std::min<uint64_t>(e->n_packs, (uint64_t)grid_max);
+        const int grid = (int)std::min<uint64_t>(e->n_run, (uint64_t)grid_max);
         he = launch_runend_scan(ctx->stream, grid_bits, grid, ea);
+        n_part += grid;
+    }
+    for (int raw = 0; raw < 2 && he == hipSuccess; raw++) {
+        const size_t n = raw ? e->n_raw : e->n_aff;
+        if (!n) continue;
+        ea.list = lists + e->n_dict + e->n_run + (raw ? e->n_aff : 0), ea.n_list = (uint32_t)n, ea.partials = part + n_part;
+        const uint64_t n_words = (uint64_t)n * (e->pack_rows >> 6);
+        const int grid = (int)std::min<uint64_t>((n_words + kWavesPerBlock - 1) / kWavesPerBlock, (uint64_t)grid_max);
+        he = launch_flat_scan(ctx->stream, grid, raw != 0, ea);
+        n_part += grid;
     }
     prof_mark(ctx, 1);
     if (he == hipSuccess)
-        he = launch_finalize(ctx->stream, dtype_width(e->dtype), ea.partials, grid, nullptr, 0, e->dtype, (AggStateDev *)ctx->states.p,
+        he = launch_finalize(ctx->stream, dtype_width(e->dtype), part, n_part, nullptr, 0, e->dtype, (AggStateDev *)ctx->states.p,
                              (int64_t *)((AggStateDev *)ctx->states.p + 16));
     if (he != hipSuccess) { ctx->last_hip = (int)he; return KNOX_E_HIP; }
     if (pack_counts) {

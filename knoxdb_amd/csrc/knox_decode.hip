@@ -157,14 +157,14 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
     __shared__ uint32_t s_first, s_last, s_hits;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t chunks_pp = a.pack_rows / kEncChunkRows;
-    const uint64_t n_chunks = (uint64_t)a.n_packs * chunks_pp;
+    const uint64_t n_chunks = (uint64_t)a.n_list * chunks_pp;
     const uint64_t c0 = (uint64_t)blockIdx.x * chunks_per_wg;
     const uint64_t c1 = c0 + chunks_per_wg < n_chunks ? c0 + chunks_per_wg : n_chunks;
     Acc acc;
     acc.init();
     uint64_t cnt = 0, sum = 0;
     uint32_t cur_pack = 0xffffffffu;
-    EncPack hp = {0, 0, 0};
+    EncPack hp = {0, 0, 0, 0, 0, 0, 0, 0};
     bool use_hist = false, contig = false;
     uint32_t c_lo = 0, c_diff = 0;
     auto flush_hist = [&]() {   // workgroup uniform; callers synchronise before and after
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
         }
     };
     for (uint64_t c = c0; c < c1; c++) {
-        const uint32_t pack = (uint32_t)(c / chunks_pp);
+        const uint32_t pack = a.list[c / chunks_pp];
         if (pack != cur_pack) {  // workgroup uniform
             __syncthreads();     // everybody is done with the previous pack's tables
             if (cur_pack != 0xffffffffu) flush_hist();
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
         const uint64_t in_pack = (c % chunks_pp) * kEncChunkRows + (uint64_t)wave * 2048;  // this wave's first row inside the pack
         if (in_pack >= hp.rows) continue;                                                   // a short last pack (wave uniform)
         const uint64_t row0 = (uint64_t)pack * a.pack_rows + in_pack;
-        const u32x4 *src = (const u32x4 *)(a.codes + row0) + lane;
+        const u32x4 *src = (const u32x4 *)(a.codes + hp.code_off + in_pack) + lane;
         u32x4 r[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) r[u] = __builtin_nontemporal_load(src + u * 64);
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
 
 hipError_t launch_dict_scan(hipStream_t s, int grid, const EncScanArgs &a) {
     if (grid <= 0) return hipSuccess;
-    const uint64_t n_chunks = (uint64_t)a.n_packs * (a.pack_rows / kEncChunkRows);
+    const uint64_t n_chunks = (uint64_t)a.n_list * (a.pack_rows / kEncChunkRows);
     const uint64_t per = (n_chunks + (uint64_t)grid - 1) / (uint64_t)grid;
 #define KNOX_DICT(W)                                                                       \
     if (a.want_sum) KNOX_LAUNCH((dict_scan_kernel<W, true>), grid, a, per);                \
@@ -281,11 +281,12 @@ hipError_t launch_dict_scan(hipStream_t s, int grid, const EncScanArgs &a) {
 template <int W>
 __global__ void __launch_bounds__(kBlock) runend_bits_kernel(const EncScanArgs a) {
     const uint64_t words_pp = a.pack_rows >> 6;
-    const uint64_t n_words = (uint64_t)a.n_packs * words_pp;
-    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t pack = (uint32_t)(wi / words_pp);
+    const uint64_t n_words = (uint64_t)a.n_list * words_pp;
+    for (uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; li < n_words; li += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t pack = a.list[li / words_pp];
+        const uint64_t wi = (uint64_t)pack * words_pp + li % words_pp;   // the word inside the column's bitset
         const EncPack hp = a.packs[pack];
-        const uint64_t r0 = (wi % words_pp) << 6;       // first row of the word inside its pack
+        const uint64_t r0 = (li % words_pp) << 6;       // first row of the word inside its pack
         if (r0 >= hp.rows) {
             if (wi * 64 < ((a.n_rows + 63) & ~63ull)) a.bits[wi] = 0;
             continue;
@@ -319,8 +320,8 @@ __global__ void __launch_bounds__(kBlock) runend_sum_kernel(const EncScanArgs a)
     acc.init();
     uint64_t cnt = 0, sum = 0;
     // one lane per run, packs walked by the workgroups (a pack's runs are few: the container exists for long runs)
-    for (uint32_t pack = blockIdx.x; pack < a.n_packs; pack += gridDim.x) {
-        const EncPack hp = a.packs[pack];
+    for (uint32_t li = blockIdx.x; li < a.n_list; li += gridDim.x) {
+        const EncPack hp = a.packs[a.list[li]];
         const uint32_t *ends = a.ends + hp.off;
         for (uint32_t r = threadIdx.x; r < hp.len; r += kBlock) {
             const uint64_t first = r == 0 ? 0 : (uint64_t)ends[r - 1] + 1;
@@ -353,6 +354,60 @@ hipError_t launch_runend_scan(hipStream_t s, int grid_bits, int grid_runs, const
     }
 #undef KNOX_RE
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The packs of an encoded column that are neither dictionary nor run-end (round 4): constant [1] and delta [2] containers are
+// scanned from their header alone -- row i is T(i * delta + base), wrapping in T exactly as ConstContainer / DeltaContainer.Get
+// compute it (internal/encode/int_const.go, int_delta.go:109-111), so the scan reads NOTHING and writes the bitset -- and every
+// other container kind (raw, bit-packed, simple8, nested ones) was decoded into the value pool at upload and is compared there.
+// One lane per row, 64 rows per wave step: the wave64 ballot of the hits IS the bitset word.
+// ---------------------------------------------------------------------------------------------
+template <int W, bool RAW>
+__global__ void __launch_bounds__(kBlock) flat_scan_kernel(const EncScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t words_pp = a.pack_rows >> 6;
+    const uint64_t n_words = (uint64_t)a.n_list * words_pp;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * kWavesPerBlock;
+    Acc acc;
+    acc.init();
+    uint64_t cnt = 0, sum = 0;
+    for (uint64_t li = wave0; li < n_words; li += n_waves) {
+        const uint32_t pack = a.list[li / words_pp];
+        const EncPack hp = a.packs[pack];
+        const uint64_t r0 = (li % words_pp) << 6;
+        const uint64_t wi = (uint64_t)pack * words_pp + (li % words_pp);
+        const uint64_t row = r0 + (uint64_t)lane;
+        bool hit = false;
+        uint64_t v = 0;
+        if (row < hp.rows) {
+            if constexpr (RAW) v = enc_load_val<W>(a.vals, hp.off + row);
+            else v = (row * hp.delta + hp.base) & a.wmask;
+            hit = (((v - a.lo) & a.wmask) <= a.diff) != (a.negate != 0);
+        }
+        const uint64_t word = __ballot(hit);
+        if (a.bits != nullptr && lane == 0 && wi * 64 < ((a.n_rows + 63) & ~63ull)) a.bits[wi] = word;
+        if (lane == 0) cnt += (uint64_t)__builtin_popcountll(word);
+        sum += hit ? v : 0ull;
+    }
+    acc.count = cnt;
+    acc.isum = sum;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+hipError_t launch_flat_scan(hipStream_t s, int grid, bool raw, const EncScanArgs &a) {
+    if (grid <= 0) return hipSuccess;
+#define KNOX_FLAT(W)                                                       \
+    if (raw) KNOX_LAUNCH((flat_scan_kernel<W, true>), grid, a);            \
+    KNOX_LAUNCH((flat_scan_kernel<W, false>), grid, a)
+    switch (a.width) {
+    case 8: KNOX_FLAT(8);
+    case 4: KNOX_FLAT(4);
+    case 2: KNOX_FLAT(2);
+    case 1: KNOX_FLAT(1);
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_FLAT
 }
 
 // ---------------------------------------------------------------------------------------------

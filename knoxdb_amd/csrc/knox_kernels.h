@@ -286,16 +286,22 @@ hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a);
 // the value width.  run-end [3]: run r of pack p covers rows (ends[r-1], ends[r]] of the pack (int_runend.go:84-112); the
 // predicate is evaluated on the run values, hit runs are expanded into the bitset: (W + 4) B per run + 1/8 B per row.
 struct EncPack {
-    uint64_t off;      // first dictionary entry / first run of the pack inside the concatenated arrays
-    uint32_t len;      // dictionary entries / runs
-    uint32_t rows;     // rows of the pack (pack_rows except for the column's last)
+    uint64_t off;       // dictionary: first entry; run-end: first run; raw: first value -- element index into the value pool
+    uint64_t code_off;  // dictionary: first code inside the code pool (a multiple of 8: 16-byte aligned loads)
+    uint64_t base, delta;  // constant / delta packs: row i = T(i * delta + base), wrapping in T (int_const.go, int_delta.go:109)
+    uint32_t len;       // dictionary entries / runs / raw rows
+    uint32_t rows;      // rows of the pack (pack_rows except for the column's last)
+    uint32_t kind;      // encode.ContainerType the pack is SCANNED as: 1 constant, 2 delta, 3 run-end, 5 dictionary, 7 raw (every other
+                        // container: decoded on the device at upload)
+    uint32_t _pad;
 };
 struct EncScanArgs {
-    const void *vals;        // dictionary entries / run values, W bytes each, all packs back to back
-    const uint16_t *codes;   // dictionary: n_packs * pack_rows codes (pack p at p * pack_rows)
-    const uint32_t *ends;    // run-end: inclusive last row (inside its pack) of every run
-    const EncPack *packs;
-    uint32_t n_packs;
+    const void *vals;        // dictionary entries / run values / raw values, W bytes each, one pool for all packs
+    const uint16_t *codes;   // dictionary packs: pack_rows codes per pack
+    const uint32_t *ends;    // run-end packs: inclusive last row (inside its pack) of every run, indexed like the values
+    const EncPack *packs;    // [n_packs], by pack number
+    const uint32_t *list;    // the packs THIS launch handles (all of one scanned kind), ascending
+    uint32_t n_list;
     uint32_t width;          // W
     uint64_t pack_rows;
     uint64_t n_rows;
@@ -303,12 +309,14 @@ struct EncScanArgs {
     uint32_t negate;
     uint32_t want_sum;
     uint64_t *bits;          // nullable
-    AggPartial *partials;    // [grid]
+    AggPartial *partials;    // [grid] of this launch
 };
 constexpr int kEncChunkRows = 8192;      // dictionary scan: rows per workgroup step (4 waves x 4 loads x 64 lanes x 8 codes)
 constexpr int kEncHistCodes = 8192;      // dictionaries up to this many entries count selected rows per code in LDS for the sum (beyond: dict[code] through the L2)
 hipError_t launch_dict_scan(hipStream_t s, int grid, const EncScanArgs &a);
 hipError_t launch_runend_scan(hipStream_t s, int grid_bits, int grid_runs, const EncScanArgs &a);
+// constant / delta packs (raw == false: values computed from the row number, nothing read) and raw packs (values read from the pool)
+hipError_t launch_flat_scan(hipStream_t s, int grid, bool raw, const EncScanArgs &a);
 
 // bit-packed container payload -> materialized values: out[i] = T((stream >> i*log2) & mask) + minv
 hipError_t launch_bitpack_decode(hipStream_t s, int width, const uint64_t *packed, uint64_t n_words, uint32_t log2, uint64_t minv,

@@ -484,7 +484,7 @@ class Context:
         return Packed(self, h, BlockType(dtype), len(bufs))
 
     def enc_upload(self, dtype, containers, pack_rows):
-        """dictionary [5] / run-end [3] containers of consecutive packs, kept encoded in HBM (knox_enc_upload)"""
+        """the integer containers of consecutive packs (any kinds, mixed), kept in the form they are cheapest to scan in (knox_enc_upload)"""
         bufs = [np.frombuffer(bytes(c), dtype=np.uint8) for c in containers]
         ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
         lens = (C.c_size_t * max(1, len(bufs)))(*[b.size for b in bufs])
@@ -780,7 +780,8 @@ class Packed:
 
 
 class Encoded:
-    """A column of dictionary [5] or run-end [3] containers kept encoded in HBM and scanned as it is (knox_enc_*)."""
+    """An integer column whose packs stay encoded in HBM -- dictionary / run-end / constant / delta as they are, everything else
+    decoded on the device -- and are scanned in that form (knox_enc_*)."""
 
     def __init__(self, ctx, handle, dtype, n_packs):
         self.ctx, self.h, self.dtype, self.n_packs = ctx, handle, dtype, n_packs
@@ -797,9 +798,11 @@ class Encoded:
     def container_bytes(self):
         return _lib.lib().knox_enc_container_bytes(self.h)
 
-    @property
-    def kind(self):
-        return _lib.lib().knox_enc_kind(self.h)
+    def kinds(self):
+        """-> packs scanned as (dictionary, run-end, constant / delta, raw)"""
+        n = [C.c_size_t() for _ in range(4)]
+        check(_lib.lib().knox_enc_kinds(self.h, *[C.byref(x) for x in n]), "knox_enc_kinds")
+        return tuple(x.value for x in n)
 
     def scan(self, mode, a, b=None, want_sum=False, bits_out=None, pack_counts=False):
         """-> (count, sum state or None, per-pack counts or None)"""

@@ -106,7 +106,7 @@ def test_dictionary_columns_scan_like_their_decoded_vectors(ctx, bt, dt, npdt):
     containers = [p[0] for p in packs]
     want = np.concatenate([p[1] for p in packs])
     enc = ctx.enc_upload(bt, containers, PACK)
-    assert enc.kind == 5 and enc.nbytes < want.nbytes or npdt().itemsize <= 2
+    assert enc.kinds() == (3, 0, 0, 0) and (enc.nbytes < want.nbytes or npdt().itemsize <= 2)
     check_all_modes(ctx, enc, bt, dt, npdt, want, containers, "dict %s" % bt)
     enc.free()
 
@@ -118,9 +118,49 @@ def test_runend_columns_scan_like_their_decoded_vectors(ctx, bt, dt, npdt):
     containers = [p[0] for p in packs]
     want = np.concatenate([p[1] for p in packs])
     enc = ctx.enc_upload(bt, containers, PACK)
-    assert enc.kind == 3
+    assert enc.kinds() == (0, 3, 0, 0)
     check_all_modes(ctx, enc, bt, dt, npdt, want, containers, "run-end %s" % bt)
     enc.free()
+
+
+def test_mixed_runs_of_packs_keep_every_pack_in_its_cheapest_form(ctx):
+    """the reference's encoder picks the scheme per block: one column, seven packs -- dictionary, run-end, constant, delta (positive
+    and wrapping negative step), raw, bit-packed, a run-end pack whose values child is a dictionary (nested: decoded) -- scanned in one
+    call, every mode, against the oracle on the decoded vector and against the decoding path of the same containers"""
+    rng = np.random.default_rng(77)
+    for bt, dt, npdt in ((BlockType.Int64, O.I64, np.int64), (BlockType.Uint32, O.U32, np.uint32), (BlockType.Int16, O.I16, np.int16)):
+        info = np.iinfo(npdt)
+        mask_w = (1 << (8 * npdt().itemsize)) - 1
+        d_c, d_v = dict_pack(rng, dt, npdt, PACK, 500)
+        r_c, r_v = runend_pack(rng, dt, npdt, PACK, 25)
+        cval = int(d_v[7])
+        c_c = bytes([1]) + bytes(O.put_uvarint(cval & mask_w)) + bytes(O.put_uvarint(PACK))
+        c_v = np.full(PACK, cval, dtype=npdt)
+        base, step = int(info.min) + 5 if info.min < 0 else 3, 3
+        de_c = bytes([2]) + bytes(O.put_uvarint(base & mask_w)) + bytes(O.put_uvarint(step)) + bytes(O.put_uvarint(PACK))
+        de_v = ((base + step * np.arange(PACK, dtype=object)) & mask_w).astype(np.uint64).astype(np.dtype("u%d" % npdt().itemsize)).view(npdt)
+        neg_step = mask_w            # T(-1): the sequence counts down and wraps
+        dn_c = bytes([2]) + bytes(O.put_uvarint(100)) + bytes(O.put_uvarint(neg_step)) + bytes(O.put_uvarint(PACK))
+        dn_v = ((100 + neg_step * np.arange(PACK, dtype=object)) & mask_w).astype(np.uint64).astype(np.dtype("u%d" % npdt().itemsize)).view(npdt)
+        raw_v = rng.integers(max(int(info.min), -(1 << 40)), min(int(info.max), 1 << 40), size=PACK, endpoint=True).astype(npdt)
+        raw_c = bytes(O.raw_container_store(dt, raw_v))
+        bp_v = (np.abs(raw_v.astype(np.int64)) % 1000).astype(npdt)
+        bp_c = bytes(O.bitpack_container_store(dt, bp_v))
+        # nested: run-end whose values child is a dictionary container -> no native form, decoded on the device (short last pack)
+        nd_c, nd_vals = dict_pack(rng, dt, npdt, 300, 40)           # 300 run values behind a 40-entry dictionary
+        runs = rng.integers(1, 40, size=300)
+        ends = (np.cumsum(runs) - 1).astype(np.uint32)
+        n_last = int(ends[-1]) + 1
+        assert n_last <= PACK
+        ne_c = bytes([3]) + nd_c + bytes(O.raw_container_store(O.U32, ends))
+        ne_v = np.repeat(nd_vals, runs)
+        containers = [d_c, r_c, c_c, de_c, dn_c, raw_c, bp_c, ne_c]
+        want = np.concatenate([d_v, r_v, c_v, de_v, dn_v, raw_v, bp_v, ne_v])
+        enc = ctx.enc_upload(bt, containers, PACK)
+        assert enc.kinds() == (1, 1, 3, 3), enc.kinds()
+        assert enc.container_bytes == sum(len(c) for c in containers)
+        check_all_modes(ctx, enc, bt, dt, npdt, want, containers, "mixed %s" % bt)
+        enc.free()
 
 
 def test_enc_upload_rules(ctx):
@@ -128,12 +168,12 @@ def test_enc_upload_rules(ctx):
     d, _ = dict_pack(rng, O.I64, np.int64, PACK, 50)
     r, _ = runend_pack(rng, O.I64, np.int64, PACK, 20)
     short, _ = dict_pack(rng, O.I64, np.int64, PACK - 5, 50)
-    for bad, code in (([d, r], -5),                 # one kind per column
-                      ([short, d], -1),             # only the last pack may be short
-                      ([O.raw_container_store(O.I64, np.arange(PACK, dtype=np.int64))], -5)):   # not a dictionary / run-end container
-        with pytest.raises(K.KnoxError) as e:
-            ctx.enc_upload(BlockType.Int64, bad, PACK)
-        assert e.value.code == code, (code, e.value.code)
+    with pytest.raises(K.KnoxError) as e:
+        ctx.enc_upload(BlockType.Int64, [short, d], PACK)          # only the last pack may be short
+    assert e.value.code == -1
+    mixed = ctx.enc_upload(BlockType.Int64, [d, r, bytes(O.raw_container_store(O.I64, np.arange(PACK, dtype=np.int64)))], PACK)
+    assert mixed.kinds() == (1, 1, 0, 1) and mixed.rows == 3 * PACK
+    mixed.free()
     with pytest.raises(K.KnoxError):
         ctx.enc_upload(BlockType.Int64, [d], 1000)  # pack_rows not a multiple of 8192
     with pytest.raises(K.KnoxError) as e:
