@@ -52,6 +52,7 @@ const (
 	GPU_SCAN_USEC_KEY    = "gpu_scan_usec"   // the scan kernels, HIP events (knox_prof_read)
 	GPU_INGEST_USEC_KEY  = "gpu_ingest_usec" // host time spent handing vectors / containers to the library
 	GPU_FALLBACK_KEY     = "gpu_fallback_packs"
+	GPU_ENCODED_RUNS_KEY = "gpu_encoded_runs" // runs scanned on their containers (knox_enc_scan), never expanded
 )
 
 var errGpuBlock = errors.New("knoxgpu: block type or container the run reader does not take")
@@ -380,6 +381,9 @@ func (g *GpuRun) scan(r *Reader) error {
 	for _, pk := range g.packs {
 		rows += pk.n
 	}
+	if ok, err := g.scanEncoded(r, rows); ok || err != nil { // one numeric leaf on an encoded integer column: the containers stay encoded
+		return err
+	}
 	cols := make([]*knoxgpu.Column, len(g.fields))
 	for i := range g.fields {
 		if !g.isEnc[i] {
@@ -441,6 +445,94 @@ func (g *GpuRun) scan(r *Reader) error {
 	st.Count(GPU_ROWS_SCANNED_KEY, rows)
 	st.Count(GPU_SCAN_USEC_KEY, int(ms*1000))
 	return nil
+}
+
+// reducer functions knox_enc_scan folds by itself (include/knoxgpu.h knox_reducer: KNOX_R_SUM = 0, KNOX_R_COUNT = 8)
+const (
+	gpuFuncSum   = 0
+	gpuFuncCount = 8
+)
+
+// scanEncoded: the run's ONE filter column arrived as containers (block.Decode, not materialized) and the plan is ONE numeric
+// compare leaf on it: the containers go to knoxgpu.UploadEncoded as they are -- dictionary and run-end packs are matched on their
+// dictionary / run values, constant / delta packs from their header, everything else is decoded on the device
+// (DictionaryContainer.Match*, RunEndContainer.Match*: internal/encode/int_dict.go:181-380, int_runend.go:224-330) -- and one
+// Encoded.Scan yields the run's bitset, per-pack counts and, when they may ride along, the Sum / Count reducers.  false: not this
+// shape (several columns or leaves, a materialized run, floats, other reducers) or the library declined: the caller takes the
+// decoding path.
+func (g *GpuRun) scanEncoded(r *Reader, rows int) (bool, error) {
+	if len(g.fields) != 1 || !g.isEnc[0] || len(g.nodes) != 2 || g.nodes[0].Kind != knoxgpu.NodeLeaf {
+		return false, nil
+	}
+	leaf := g.nodes[0]
+	switch types.FilterMode(leaf.Op) {
+	case types.FilterModeEqual, types.FilterModeNotEqual, types.FilterModeGt, types.FilterModeGe,
+		types.FilterModeLt, types.FilterModeLe, types.FilterModeRange:
+	default:
+		return false, nil
+	}
+	bt := g.packs[0].pkg.Block(g.fields[0]).Type()
+	switch bt {
+	case types.BlockInt64, types.BlockInt32, types.BlockInt16, types.BlockInt8,
+		types.BlockUint64, types.BlockUint32, types.BlockUint16, types.BlockUint8:
+	default:
+		return false, nil
+	}
+	fuse := g.fusable && len(g.aggs) > 0 && r.query.Snap.Safe && (r.mode != engine.ReadModeExcludeMask || r.mask == nil || r.mask.None())
+	for _, a := range g.aggs {
+		if fuse && a.Func != gpuFuncSum && a.Func != gpuFuncCount {
+			return false, nil
+		}
+	}
+	enc, err := knoxgpu.UploadEncoded(g.gpu, int(bt), g.encoded[0], g.packRows)
+	if err != nil {
+		return false, nil // e.g. a pack size that is not a multiple of 8192: the decoding path takes it
+	}
+	defer enc.Free()
+	bits := g.bits[rows]
+	if bits == nil {
+		if bits, err = knoxgpu.NewBits(g.gpu, rows); err != nil {
+			return false, err
+		}
+		g.bits[rows] = bits
+	}
+	g.fusable = g.fusable && (fuse || len(g.aggs) == 0)
+	counts := make([]int64, len(g.packs))
+	g.gpu.ProfEnable(true)
+	cnt, state, err := enc.Scan(leaf.Op, leaf.A, leaf.B, fuse, bits, counts)
+	if err != nil {
+		return false, err
+	}
+	ms, _ := g.gpu.ProfRead()
+	if need := (rows + 7) / 8; cap(g.host) < need {
+		g.host = make([]byte, need)
+	}
+	g.host = g.host[:(rows+7)/8]
+	if cnt > 0 {
+		if err := bits.Download(g.host); err != nil {
+			return false, err
+		}
+	}
+	for i := range g.packs {
+		g.packs[i].count = counts[i]
+		if counts[i] == 0 { // false positive metadata match (reader.go:337-341)
+			g.packs[i].pkg.Release()
+			g.packs[i].pkg = nil
+		}
+	}
+	if fuse {
+		for i := range g.aggs { // Sum and Count both finalise from the one state (knox_agg_value)
+			g.States[i] = append(g.States[i], state)
+		}
+	}
+	g.Rows += int64(rows)
+	st := r.query.Stats
+	st.Count(PACKS_SCHEDULED_KEY, len(g.packs))
+	st.Count(GPU_RUNS_KEY, 1)
+	st.Count(GPU_ROWS_SCANNED_KEY, rows)
+	st.Count(GPU_SCAN_USEC_KEY, int(ms*1000))
+	st.Count(GPU_ENCODED_RUNS_KEY, 1)
+	return true, nil
 }
 
 // nextQueryMatchGpu has nextQueryMatch's contract (reader.go:288): the next pack with real matches, its selection

@@ -268,6 +268,100 @@ static void go_RunReader(knox_ctx *ctx) {
     }
 }
 
+// run_knoxgpu.go (GpuRun.scanEncoded): a run whose one filter column arrived as containers and whose plan is one numeric leaf --
+// UploadEncoded (C copies of the Go buffers + a C pointer array, cBufs), NewBits, ONE (*Encoded).Scan with the bitset, the per-pack
+// counts and the Sum / Count state, ONE Download, Free.  The run mixes container schemes pack by pack, as the encoder would:
+// dictionary [5], delta [2], raw [7], constant [1]; a short last pack.
+static void go_EncodedRun(knox_ctx *ctx) {
+    const size_t pack = 8192, np = 4, last_rows = 5000;
+    std::vector<std::vector<uint8_t>> bufs(np);
+    std::vector<std::vector<int64_t>> vals(np);
+    auto put_raw = [&](std::vector<uint8_t> &out, const void *p, size_t n, size_t w) {   // [7][uvarint n][LE values]
+        out.push_back(7);
+        put_uvarint(out, n);
+        const uint8_t *b = (const uint8_t *)p;
+        out.insert(out.end(), b, b + n * w);
+    };
+    {   // pack 0: dictionary of 37 sorted values, uint16 codes
+        std::vector<int64_t> dict(37);
+        for (size_t i = 0; i < dict.size(); i++) dict[i] = -500 + (int64_t)i * 29;
+        std::vector<uint16_t> codes(pack);
+        vals[0].resize(pack);
+        for (size_t i = 0; i < pack; i++) codes[i] = (uint16_t)(rnd() % dict.size()), vals[0][i] = dict[codes[i]];
+        bufs[0].push_back(5);
+        put_raw(bufs[0], dict.data(), dict.size(), 8);
+        put_raw(bufs[0], codes.data(), pack, 2);
+    }
+    {   // pack 1: delta container, row i = -1000 + 3 i
+        bufs[1].push_back(2);
+        std::vector<uint8_t> &b = bufs[1];
+        // For = uint64(int64(-1000)) needs the 9-byte varint form: 255 + 8 big-endian bytes (pkg/num/varint.go:161-197)
+        const uint64_t f = (uint64_t)(int64_t)-1000;
+        b.push_back(255);
+        for (int k = 7; k >= 0; k--) b.push_back((uint8_t)(f >> (8 * k)));
+        put_uvarint(b, 3);
+        put_uvarint(b, pack);
+        vals[1].resize(pack);
+        for (size_t i = 0; i < pack; i++) vals[1][i] = -1000 + 3 * (int64_t)i;
+    }
+    {   // pack 2: raw
+        vals[2].resize(pack);
+        for (size_t i = 0; i < pack; i++) vals[2][i] = (int64_t)(rnd() % 4000) - 2000;
+        put_raw(bufs[2], vals[2].data(), pack, 8);
+    }
+    {   // pack 3 (short): constant 123
+        bufs[3].push_back(1);
+        put_uvarint(bufs[3], 123);
+        put_uvarint(bufs[3], last_rows);
+        vals[3].assign(last_rows, 123);
+    }
+    const uint8_t *ptrs[np];
+    size_t lens[np];
+    size_t rows = 0;
+    for (size_t p = 0; p < np; p++) ptrs[p] = bufs[p].data(), lens[p] = bufs[p].size(), rows += vals[p].size();
+    knox_enc *enc = nullptr;
+    EXPECT(knox_enc_upload(ctx, KNOX_INT64, ptrs, lens, np, pack, &enc) == 0);
+    if (!enc) return;
+    EXPECT(knox_enc_rows(enc) == rows);
+    size_t nd = 9, nr = 9, na = 9, nw = 9;
+    EXPECT(knox_enc_kinds(enc, &nd, &nr, &na, &nw) == 0 && nd == 1 && nr == 0 && na == 2 && nw == 1);
+    knox_bits *bits = nullptr;
+    EXPECT(knox_bits_alloc(ctx, rows, &bits) == 0);
+    std::vector<int64_t> pc(np, -1);
+    int64_t cnt = -1;
+    knox_agg_state st;
+    // leaf: v BETWEEN -300 AND 123 (ValueBits: the raw bits of the column type)
+    const int64_t lo = -300, hi = 123;
+    EXPECT(knox_enc_scan(ctx, enc, KNOX_RANGE, (uint64_t)lo, (uint64_t)hi, 1, bits, pc.data(), &cnt, &st) == 0);
+    std::vector<uint8_t> host((rows + 7) / 8);
+    EXPECT(knox_bits_download(ctx, bits, host.data()) == 0);
+    int64_t want = 0;
+    uint64_t want_sum = 0;
+    bool same = true;
+    size_t base = 0;
+    for (size_t p = 0; p < np; p++) {
+        int64_t c = 0;
+        for (size_t i = 0; i < vals[p].size(); i++) {
+            const bool h = vals[p][i] >= lo && vals[p][i] <= hi;
+            c += h;
+            if (h) want_sum += (uint64_t)vals[p][i];
+            const size_t r = base + i;
+            same &= (((host[r >> 3] >> (r & 7)) & 1) != 0) == h;
+        }
+        EXPECT(pc[p] == c);
+        want += c;
+        base += pack;   // packs start pack_rows apart on the device
+    }
+    EXPECT(cnt == want && same);
+    uint64_t vbits = 0;
+    int seen = 0;
+    int64_t row = 0;
+    EXPECT(knox_agg_value(&st, KNOX_R_SUM, &vbits, &seen, &row) == 0 && seen == 1 && vbits == want_sum);
+    EXPECT(knox_agg_value(&st, KNOX_R_COUNT, &vbits, &seen, &row) == 0 && (int64_t)vbits == want);
+    knox_bits_free(bits);
+    knox_enc_free(enc);
+}
+
 // operator_knoxgpu.go (deviceCols.get / evictOthers): under a tiny arena budget an upload fails with KNOX_E_NOMEM; the
 // cache frees columns of OTHER packages only and retries; the handles of the package being planned stay valid.
 static void go_EvictOthers() {
@@ -595,6 +689,7 @@ int main() {
         }
     }
     go_RunReader(ctx);
+    go_EncodedRun(ctx);
     knox_ctx_close(ctx);
     go_EvictOthers();
     std::printf(fails ? "FAILED: %d\n" : "go entries ok\n", fails);

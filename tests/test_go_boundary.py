@@ -108,13 +108,19 @@ def test_run_level_reader_is_committed_source_with_the_readers_contract():
     assert re.search(r"^package table$", run, flags=re.M)
     assert re.search(r"func \(r \*Reader\) nextQueryMatchGpu\(ctx context\.Context\) \(\*pack\.Package, error\)", run)
     assert re.search(r"func \(g \*GpuRun\) WithQuery\(n \*filter\.Node, aggs \[\]knoxgpu\.Agg\) bool", run)
-    body = run[run.index("func (g *GpuRun) scan("):run.index("// nextQueryMatchGpu has nextQueryMatch's contract")]
+    body = run[run.index("func (g *GpuRun) scan("):run.index("// reducer functions knox_enc_scan folds by itself")]
     assert body.count("g.gpu.Scan(") == 1 and "true, len(g.packs))" in body          # ONE scan per run, with per-pack counts
     assert body.count("bits.Download(") == 1                                           # ONE copy of the run's bitset
     assert "UploadRawContainers" in body and "knoxgpu.AppendAsync(" in run             # encoded and materialized blocks
     for key in ("GPU_RUNS_KEY", "GPU_ROWS_SCANNED_KEY", "GPU_SCAN_USEC_KEY", "GPU_INGEST_USEC_KEY", "PACKS_SCHEDULED_KEY"):
         assert "Count(%s" % key in run, key
     assert "r.finishMatch(ctx, pk.key, pk.ver, pk.n)" in run and "ResetCount(int(pk.count))" in run
+    # round 4: a run whose one filter column arrived as containers and whose plan is one numeric leaf stays encoded on the device
+    enc = run[run.index("func (g *GpuRun) scanEncoded("):run.index("// nextQueryMatchGpu has nextQueryMatch's contract")]
+    assert "knoxgpu.UploadEncoded(g.gpu, int(bt), g.encoded[0], g.packRows)" in enc and "defer enc.Free()" in enc
+    assert enc.count("enc.Scan(") == 1 and enc.count("bits.Download(") == 1 and "GPU_ENCODED_RUNS_KEY" in enc
+    assert "return false, nil" in enc                       # every shape it does not take goes to the decoding path
+    assert body.index("g.scanEncoded(r, rows)") < body.index("knoxgpu.UploadRawContainers(")
     op = open(os.path.join(GO, "operator_knoxgpu.go")).read()
     assert "evictOthers(k.pack, k.version" in op and "func (d *deviceCols) evict(" not in op   # no eviction of the package being planned
 
