@@ -946,7 +946,7 @@ KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *buf
     // pass 1: headers -- how every pack will be scanned, element counts
     struct Plan { uint32_t kind; size_t off1, len1, n1, off2, len2, n2; uint64_t base, delta; };
     std::vector<Plan> pl(n_bufs);
-    size_t total_vals = 0, total_bytes = 0, n_dict = 0;
+    size_t total_vals = 0, total_runs = 0, total_bytes = 0, n_dict = 0;
     for (size_t i = 0; i < n_bufs; i++) {
         const uint8_t *b = bufs[i];
         if (!b || lens[i] < 2) return KNOX_E_INVALID;
@@ -972,6 +972,7 @@ KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *buf
                 if (b[0] == 3 && n1 >= 1 && n1 == n2) {
                     p = Plan{3, 1, c1, n1, 1 + c1, c2, n2, 0, 0};
                     total_vals += n1;
+                    total_runs += n1;
                     continue;
                 }
             }
@@ -1015,7 +1016,7 @@ KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *buf
     if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_packs, n_bufs * sizeof(EncPack) + 64);
     if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_lists, n_bufs * 4 + 64);
     if (he == hipSuccess && n_dict) he = dev_malloc(ctx, (void **)&e->d_codes, n_dict * pack_rows * 2 + 256);
-    if (he == hipSuccess) he = dev_malloc(ctx, (void **)&e->d_ends, total_vals * 4 + 64);
+    if (he == hipSuccess && total_runs) he = dev_malloc(ctx, (void **)&e->d_ends, total_runs * 4 + 64);
     if (he != hipSuccess) {
         ctx->last_hip = (int)he;
         knox_enc_free(e);
@@ -1024,7 +1025,7 @@ KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *buf
     // pass 2: payloads onto the device (children / whole containers decoded there), pack table
     std::vector<EncPack> packs(n_bufs);
     std::vector<uint32_t> l_dict, l_run, l_aff, l_raw;
-    size_t voff = 0, coff = 0, rows = 0, resident = 0;
+    size_t voff = 0, coff = 0, eoff = 0, rows = 0, resident = 0;
     int rc = KNOX_OK;
     for (size_t i = 0; i < n_bufs && !rc; i++) {
         const Plan &c = pl[i];
@@ -1043,14 +1044,15 @@ KNOX_API int knox_enc_upload(knox_ctx *ctx, int dtype, const uint8_t *const *buf
             l_dict.push_back((uint32_t)i);
         } else if (c.kind == 3) {
             rc = container_decode(ctx, bufs[i] + c.off1, c.len1, w, false, (char *)e->d_vals + voff * (size_t)w, c.n1, 1);
-            if (!rc) rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 4, false, e->d_ends + voff, c.n2, 1);
+            if (!rc) rc = container_decode(ctx, bufs[i] + c.off2, c.len2, 4, false, e->d_ends + eoff, c.n2, 1);
             uint32_t last = 0;  // the pack's row count = its last inclusive end + 1 (int_runend.go:109)
-            if (!rc && (hipMemcpyAsync(&last, e->d_ends + voff + (c.n2 - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            if (!rc && (hipMemcpyAsync(&last, e->d_ends + eoff + (c.n2 - 1), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                         hipStreamSynchronize(ctx->stream) != hipSuccess))
                 rc = KNOX_E_HIP;
-            hp.off = voff, hp.len = (uint32_t)c.n1;
+            hp.off = voff, hp.code_off = eoff, hp.len = (uint32_t)c.n1;   // code_off of a run-end pack: its first end
             prows = last + 1;
             voff += c.n1;
+            eoff += c.n1;
             resident += c.n1 * ((size_t)w + 4);
             l_run.push_back((uint32_t)i);
         } else if (c.kind == 1 || c.kind == 2) {

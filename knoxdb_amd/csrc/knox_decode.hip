@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) runend_bits_kernel(const EncScanArgs a
             if (wi * 64 < ((a.n_rows + 63) & ~63ull)) a.bits[wi] = 0;
             continue;
         }
-        const uint32_t *ends = a.ends + hp.off;
+        const uint32_t *ends = a.ends + hp.code_off;   // a run-end pack's first end (its values: hp.off)
         uint32_t lo = 0, hi = hp.len;                    // first run whose inclusive end is >= r0
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(kBlock) runend_sum_kernel(const EncScanArgs a)
     // one lane per run, packs walked by the workgroups (a pack's runs are few: the container exists for long runs)
     for (uint32_t li = blockIdx.x; li < a.n_list; li += gridDim.x) {
         const EncPack hp = a.packs[a.list[li]];
-        const uint32_t *ends = a.ends + hp.off;
+        const uint32_t *ends = a.ends + hp.code_off;   // a run-end pack's first end (its values: hp.off)
         for (uint32_t r = threadIdx.x; r < hp.len; r += kBlock) {
             const uint64_t first = r == 0 ? 0 : (uint64_t)ends[r - 1] + 1;
             uint64_t last1 = (uint64_t)ends[r] + 1;

@@ -287,7 +287,7 @@ hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a);
 // predicate is evaluated on the run values, hit runs are expanded into the bitset: (W + 4) B per run + 1/8 B per row.
 struct EncPack {
     uint64_t off;       // dictionary: first entry; run-end: first run; raw: first value -- element index into the value pool
-    uint64_t code_off;  // dictionary: first code inside the code pool (a multiple of 8: 16-byte aligned loads)
+    uint64_t code_off;  // dictionary: first code inside the code pool (a multiple of 8: 16-byte aligned loads); run-end: first end inside the end pool
     uint64_t base, delta;  // constant / delta packs: row i = T(i * delta + base), wrapping in T (int_const.go, int_delta.go:109)
     uint32_t len;       // dictionary entries / runs / raw rows
     uint32_t rows;      // rows of the pack (pack_rows except for the column's last)
@@ -298,7 +298,7 @@ struct EncPack {
 struct EncScanArgs {
     const void *vals;        // dictionary entries / run values / raw values, W bytes each, one pool for all packs
     const uint16_t *codes;   // dictionary packs: pack_rows codes per pack
-    const uint32_t *ends;    // run-end packs: inclusive last row (inside its pack) of every run, indexed like the values
+    const uint32_t *ends;    // run-end packs: inclusive last row (inside its pack) of every run, a pool of their own (EncPack.code_off)
     const EncPack *packs;    // [n_packs], by pack number
     const uint32_t *list;    // the packs THIS launch handles (all of one scanned kind), ascending
     uint32_t n_list;
