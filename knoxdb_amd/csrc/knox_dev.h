@@ -704,6 +704,7 @@ __device__ __forceinline__ void block_reduce_store(Acc &acc, AggPartial *out) {
 // element masks, a v_dot4_u32_u8 / v_dot2_u32_u16 for the wrapping integer sum.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 template <int W> struct Swar {
     static constexpr uint32_t H = W == 1 ? 0x80808080u : 0x80008000u;
@@ -910,7 +911,7 @@ __device__ __forceinline__ void agg_iter_narrow(Acc &acc, WaveMM &wm, FirstLast 
     constexpr int RPL = 64 * K;
     constexpr uint32_t H = Swar<W>::H;
     constexpr uint32_t XS = FLV == FL_SIGNED ? H : 0u;
-    uint32_t sum32 = 0, neg = 0;
+    uint32_t sum32 = 0;
     u16x2 pmax = {0, 0}, pminc = {0, 0};
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
@@ -925,13 +926,14 @@ __device__ __forceinline__ void agg_iter_narrow(Acc &acc, WaveMM &wm, FirstLast 
             if constexpr (W == 1) m = __umul24((qq >> (4 * w)) & 0xfu, 0x00204081u) & 0x01010101u;
             else m = __umul24((qq >> (2 * w)) & 0x3u, 0x00008001u) & 0x00010001u;
             const uint32_t g = m << (8 * W - 1);
-            if constexpr (W == 1) {
-                if constexpr ((AGG & (A_ISUM | A_FSUM)) != 0) sum32 = __builtin_amdgcn_udot4(d[w], m, sum32, false);
-            } else {
-                if constexpr ((AGG & (A_ISUM | A_FSUM)) != 0)
-                    sum32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d[w]), __builtin_bit_cast(u16x2, m), sum32, false);
+            // signed columns: the signed dot product IS the exact sum of the selected values (64 values of <= 16 bits fit an
+            // int32), and the wrapping sum is that sum mod 2^(8W) -- no count of negative values (round 4)
+            if constexpr ((AGG & (A_ISUM | A_FSUM)) != 0) {
+                if constexpr (W == 1 && FLV == FL_SIGNED) sum32 = (uint32_t)__builtin_amdgcn_sdot4((int)d[w], (int)m, (int)sum32, false);
+                else if constexpr (W == 1) sum32 = __builtin_amdgcn_udot4(d[w], m, sum32, false);
+                else if constexpr (FLV == FL_SIGNED) sum32 = (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, d[w]), __builtin_bit_cast(s16x2, m), (int)sum32, false);
+                else sum32 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d[w]), __builtin_bit_cast(u16x2, m), sum32, false);
             }
-            if constexpr ((AGG & A_FSUM) != 0 && FLV == FL_SIGNED) neg += (uint32_t)__builtin_popcount(d[w] & g);
             if constexpr ((AGG & A_MINMAX) != 0) {
                 // element-wide mask of the selected elements: 2-byte elements by one full-rate 24-bit multiply (m <= 0x00010001)
                 const uint32_t mfull = W == 2 ? __umul24(m, 0xffffu) : ((g - m) | g);
@@ -952,12 +954,13 @@ __device__ __forceinline__ void agg_iter_narrow(Acc &acc, WaveMM &wm, FirstLast 
         q[u] = qq;
         cnt32 += (uint32_t)__builtin_popcount(qq);
     }
-    if constexpr ((AGG & A_ISUM) != 0) acc.isum += sum32;  // the raw (zero-extended) values: SumReducer mod 2^64 is formed by finalize
+    // the wrapping sum: finalize keeps the low 8W bits (knox_finalize.h: `isum & m`), where the zero-extended and the signed sum agree
+    if constexpr ((AGG & A_ISUM) != 0) acc.isum += FLV == FL_SIGNED ? (uint64_t)(int64_t)(int32_t)sum32 : (uint64_t)sum32;
     if constexpr ((AGG & A_FSUM) != 0) {
         if constexpr (FLV == FL_UNSIGNED) {
             acc.add128(sum32, 0);
         } else {
-            const int64_t it = (int64_t)sum32 - ((int64_t)neg << (8 * W));
+            const int64_t it = (int64_t)(int32_t)sum32;
             acc.add128((uint64_t)it, it >> 63);
         }
     }

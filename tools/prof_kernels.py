@@ -36,6 +36,7 @@ def mean(k, c):
 
 print("# rocprofv3 of `python3 %s` (%s): kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; one SQ pass" % (cmd, os.path.basename(root)))
 print("# hbm_MB = (FETCH_SIZE x 2 + WRITE_SIZE) KiB per launch (x2: gfx950 wide-read correction); TB/s = those bytes / avg duration")
+print('# caveat: the x2 is right for 16-byte-per-lane streaming reads (the scans: headline traffic = 1.0003 x algorithmic); kernels that load 4 or 8 bytes\n#   per lane (sort passes, histograms) are counted nearer their raw FETCH_SIZE -- read their hbm_MB as an upper bound; calls of several sizes share a row (averages per launch)')
 print("%-84s %6s %11s %6s %9s %9s %9s %6s %6s %6s %7s" % ("kernel", "calls", "avg_us", "pct", "fetchKiB", "writeKiB", "hbm_MB", "TB/s", "valu%", "wait%", "ldsst%"))
 for k, (calls, avg, tot, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
     fe, wr = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
