@@ -163,11 +163,13 @@ hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanAr
 // state_out[k] = ordered merge of partials[item_start[k] .. item_start[k+1])
 // the same with one wave per work item: many small windows
 hipError_t launch_bucket_reduce_waves(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items);
+hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items);
 hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
                                   const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out);
 
 // var/std per window (second pass over the same work items); partials: 4 doubles per work item
-hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask,
+// group_rows != 0: the 16-lanes-per-window form (grid = workgroups of 16 windows; group_rows = the column's rows, the bitset's bound)
+hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask, uint64_t group_rows,
                                  const BucketItem *items, uint32_t n_items, const uint32_t *item_start, uint32_t n_buckets,
                                  AggStateDev *states, double *partials);
 

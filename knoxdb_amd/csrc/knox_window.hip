@@ -200,6 +200,111 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_wave_kernel(const ScanAr
     }
 }
 
+// Very many very small windows (64 ... a few thousand rows: 2^20 windows of a 2^26 ... 2^30-row column): a wave per window spends
+// its time in the wave-wide reduction of the twelve accumulator fields (six shuffle steps through the LDS crossbar, ~1000
+// instructions per window; 1.6 TB/s at 1024 rows per window, latency bound below that -- profiles/r04_windows.txt).  Here a
+// window belongs to a GROUP OF 16 LANES, four windows per wave: every lane walks rows rb + sub, + 16, ... in ascending order
+// with the exact per-row update (four rows loaded ahead), and the group's accumulators meet in four DPP steps inside the
+// 16-lane row (lane ^ 1, lane ^ 2, mirror of 8, mirror of 16: no LDS, no out-of-range lane).  Acc::merge breaks ties by row id, so
+// the butterfly's order does not show in the result.
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_mov64(uint64_t v) {
+    return ((uint64_t)dpp_mov<CTRL>((uint32_t)(v >> 32)) << 32) | dpp_mov<CTRL>((uint32_t)v);
+}
+template <int CTRL> __device__ __forceinline__ void acc_merge_dpp(Acc &a) {
+    Acc b;
+    b.count = dpp_mov64<CTRL>(a.count);
+    b.isum = dpp_mov64<CTRL>(a.isum);
+    b.hi = __longlong_as_double((long long)dpp_mov64<CTRL>((uint64_t)__double_as_longlong(a.hi)));
+    b.lo = __longlong_as_double((long long)dpp_mov64<CTRL>((uint64_t)__double_as_longlong(a.lo)));
+    b.xlo = dpp_mov64<CTRL>(a.xlo);
+    b.xhi = (int64_t)dpp_mov64<CTRL>((uint64_t)a.xhi);
+    b.minkey = dpp_mov64<CTRL>(a.minkey);
+    b.minrow = dpp_mov64<CTRL>(a.minrow);
+    b.maxkey = dpp_mov64<CTRL>(a.maxkey);
+    b.maxrow = dpp_mov64<CTRL>(a.maxrow);
+    b.firstrow = dpp_mov64<CTRL>(a.firstrow);
+    b.lastrow1 = dpp_mov64<CTRL>(a.lastrow1);
+    a.merge(b);
+}
+
+template <int W, unsigned AGG, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_reduce_group_kernel(const ScanArgs a, const BucketItem *items, uint32_t n_items) {
+    using U = typename WT<W>::U;
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = gridDim.x * kWavesPerBlock;
+    const uint8_t *mask8 = (const uint8_t *)a.mask;
+    const uint64_t *mask64 = (const uint64_t *)a.mask;
+    const uint64_t last64 = ((a.n_rows + 63) >> 6) - 1;
+    for (uint32_t base = wave * 4u; base < n_items; base += n_waves * 4u) {  // wave uniform: the DPP steps below see all 64 lanes
+        const uint32_t it = base + (uint32_t)grp;
+        uint64_t rb = 0, re = 0;
+        if (it < n_items) { rb = items[it].begin; re = items[it].end; }
+        Acc acc;
+        acc.init();
+        uint64_t row = rb + (uint64_t)sub;
+        for (; row + 48 < re; row += 64) {
+            U e[4];
+            uint32_t h[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) e[j] = load_elem<W>(a.agg_col, row + 16u * j);
+            // the lane's four selection bits sit 16 apart: bits s, s + 16, s + 32, s + 48 of the 64-bit word that holds row `row`
+            // and, for s > 15, its successor -- two aligned 8-byte loads instead of four byte loads (a bitset is padded to whole
+            // 64-bit words, knox_internal.h bits_padded)
+            uint64_t m = ~0ull;
+            if (mask64) {
+                const uint64_t i = row >> 6;
+                const uint32_t sh = (uint32_t)row & 63u;
+                const uint64_t v0 = mask64[i];
+                const uint64_t v1 = (sh > 15u && i < last64) ? mask64[i + 1] : 0ull;
+                m = sh ? (v0 >> sh) | (v1 << (64u - sh)) : v0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) h[j] = (uint32_t)(m >> (16 * j)) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc.count += h[j];
+                acc_update<W, (AGG | A_FIRSTLAST)>(acc, e[j], h[j], a.row_base + row + 16u * j, FLV);
+            }
+        }
+        for (; row < re; row += 16) {
+            const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
+            acc.count += hit;
+            acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+        }
+        acc_merge_dpp<0xB1>(acc);   // quad_perm [1,0,3,2]
+        acc_merge_dpp<0x4E>(acc);   // quad_perm [2,3,0,1]
+        acc_merge_dpp<0x141>(acc);  // row_half_mirror
+        acc_merge_dpp<0x140>(acc);  // row_mirror
+        if (sub == 0 && it < n_items) {
+            AggPartial p;
+            p.count = acc.count; p.isum = acc.isum; p.hi = acc.hi; p.lo = acc.lo; p.xlo = acc.xlo; p.xhi = acc.xhi;
+            p.minkey = acc.minkey; p.minrow = acc.minrow; p.maxkey = acc.maxkey; p.maxrow = acc.maxrow;
+            p.firstrow = acc.firstrow; p.lastrow = acc.lastrow1;
+            a.partials[it] = p;
+        }
+    }
+}
+
+template <int W> static hipError_t bucket_reduce_groups_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
+    if constexpr (W >= 4) {
+        if (a.agg_flavor == FL_FLOAT) KNOX_LAUNCH((bucket_reduce_group_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+    }
+    if (a.agg_flavor == FL_SIGNED) KNOX_LAUNCH((bucket_reduce_group_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    KNOX_LAUNCH((bucket_reduce_group_kernel<W, A_ALL, FL_UNSIGNED>), grid, a, items, n_items);
+}
+
+hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+    if (n_items == 0 || grid <= 0) return hipSuccess;
+    switch (width) {
+    case 8: return bucket_reduce_groups_w<8>(s, grid, a, items, n_items);
+    case 4: return bucket_reduce_groups_w<4>(s, grid, a, items, n_items);
+    case 2: return bucket_reduce_groups_w<2>(s, grid, a, items, n_items);
+    case 1: return bucket_reduce_groups_w<1>(s, grid, a, items, n_items);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 template <int W> static hipError_t bucket_reduce_waves_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
     constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
     if constexpr (W >= 4) {
@@ -344,6 +449,67 @@ __global__ void __launch_bounds__(kBlock) bucket_moments_kernel(const void *col,
     }
 }
 
+// the 16-lanes-per-window form of the second pass (see bucket_reduce_group_kernel): the same rows in the same per-lane order,
+// the four running double-doubles met in four DPP steps
+template <int CTRL> __device__ __forceinline__ void mom_merge_dpp(Mom &m) {
+    Mom o;
+    o.qh = __longlong_as_double((long long)dpp_mov64<CTRL>((uint64_t)__double_as_longlong(m.qh)));
+    o.ql = __longlong_as_double((long long)dpp_mov64<CTRL>((uint64_t)__double_as_longlong(m.ql)));
+    o.dh = __longlong_as_double((long long)dpp_mov64<CTRL>((uint64_t)__double_as_longlong(m.dh)));
+    o.dl = __longlong_as_double((long long)dpp_mov64<CTRL>((uint64_t)__double_as_longlong(m.dl)));
+    m.merge(o);
+}
+
+template <int W, unsigned FLV>
+__global__ void __launch_bounds__(kBlock) bucket_moments_group_kernel(const void *col, const uint32_t *mask, uint64_t n_rows, const BucketItem *items,
+                                                                      uint32_t n_items, const AggStateDev *states, double *partials) {
+    using U = typename WT<W>::U;
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = gridDim.x * kWavesPerBlock;
+    const uint8_t *mask8 = (const uint8_t *)mask;
+    const uint64_t *mask64 = (const uint64_t *)mask;
+    const uint64_t last64 = ((n_rows + 63) >> 6) - 1;
+    for (uint32_t base = wave * 4u; base < n_items; base += n_waves * 4u) {
+        const uint32_t it = base + (uint32_t)grp;
+        uint64_t rb = 0, re = 0;
+        double k0 = 0.0;
+        if (it < n_items) {
+            rb = items[it].begin; re = items[it].end;
+            k0 = moments_shift(states + items[it].bucket, 0.0);
+        }
+        Mom m;
+        m.init();
+        uint64_t row = rb + (uint64_t)sub;
+        for (; row + 48 < re; row += 64) {
+            U e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) e[j] = load_elem<W>(col, row + 16u * j);
+            uint64_t mm = ~0ull;
+            if (mask64) {
+                const uint64_t i = row >> 6;
+                const uint32_t sh = (uint32_t)row & 63u;
+                const uint64_t v0 = mask64[i];
+                const uint64_t v1 = (sh > 15u && i < last64) ? mask64[i + 1] : 0ull;
+                mm = sh ? (v0 >> sh) | (v1 << (64u - sh)) : v0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) m.add(to_f64_c<W, FLV>(e[j]), k0, ((mm >> (16 * j)) & 1u) != 0);
+        }
+        for (; row < re; row += 16) {
+            const bool hit = mask8 ? ((mask8[row >> 3] >> (row & 7)) & 1u) != 0 : true;
+            m.add(to_f64_c<W, FLV>((U)load_elem<W>(col, row)), k0, hit);
+        }
+        mom_merge_dpp<0xB1>(m);
+        mom_merge_dpp<0x4E>(m);
+        mom_merge_dpp<0x141>(m);
+        mom_merge_dpp<0x140>(m);
+        if (sub == 0 && it < n_items) {
+            double *o = partials + 4 * (size_t)it;
+            o[0] = m.qh; o[1] = m.ql; o[2] = m.dh; o[3] = m.dl;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) bucket_moments_finalize_kernel(const double *partials, const uint32_t *item_start, uint32_t n_buckets,
                                                                          AggStateDev *states) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,8 +528,15 @@ __global__ void __launch_bounds__(kBlock) bucket_moments_finalize_kernel(const d
 }
 
 template <int W>
-static hipError_t bucket_moments_w(hipStream_t s, uint32_t flavor, int grid, const void *col, const uint32_t *mask, const BucketItem *items,
-                                   uint32_t n_items, const AggStateDev *states, double *partials) {
+static hipError_t bucket_moments_w(hipStream_t s, uint32_t flavor, int grid, const void *col, const uint32_t *mask, uint64_t group_rows,
+                                   const BucketItem *items, uint32_t n_items, const AggStateDev *states, double *partials) {
+    if (group_rows) {  // the 16-lanes-per-window form: grid counts workgroups of 16 windows
+        if constexpr (W >= 4) {
+            if (flavor == FL_FLOAT) KNOX_LAUNCH((bucket_moments_group_kernel<W, FL_FLOAT>), grid, col, mask, group_rows, items, n_items, states, partials);
+        }
+        if (flavor == FL_SIGNED) KNOX_LAUNCH((bucket_moments_group_kernel<W, FL_SIGNED>), grid, col, mask, group_rows, items, n_items, states, partials);
+        KNOX_LAUNCH((bucket_moments_group_kernel<W, FL_UNSIGNED>), grid, col, mask, group_rows, items, n_items, states, partials);
+    }
     if constexpr (W >= 4) {
         if (flavor == FL_FLOAT) KNOX_LAUNCH((bucket_moments_kernel<W, FL_FLOAT>), grid, col, mask, items, n_items, states, partials);
     }
@@ -371,17 +544,17 @@ static hipError_t bucket_moments_w(hipStream_t s, uint32_t flavor, int grid, con
     KNOX_LAUNCH((bucket_moments_kernel<W, FL_UNSIGNED>), grid, col, mask, items, n_items, states, partials);
 }
 
-hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask,
+hipError_t launch_bucket_moments(hipStream_t s, int width, uint32_t flavor, int grid, const void *col, const uint32_t *mask, uint64_t group_rows,
                                  const BucketItem *items, uint32_t n_items, const uint32_t *item_start, uint32_t n_buckets,
                                  AggStateDev *states, double *partials) {
     if (n_buckets == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     if (n_items != 0 && grid > 0) {
         switch (width) {
-        case 8: e = bucket_moments_w<8>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
-        case 4: e = bucket_moments_w<4>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
-        case 2: e = bucket_moments_w<2>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
-        case 1: e = bucket_moments_w<1>(s, flavor, grid, col, mask, items, n_items, states, partials); break;
+        case 8: e = bucket_moments_w<8>(s, flavor, grid, col, mask, group_rows, items, n_items, states, partials); break;
+        case 4: e = bucket_moments_w<4>(s, flavor, grid, col, mask, group_rows, items, n_items, states, partials); break;
+        case 2: e = bucket_moments_w<2>(s, flavor, grid, col, mask, group_rows, items, n_items, states, partials); break;
+        case 1: e = bucket_moments_w<1>(s, flavor, grid, col, mask, group_rows, items, n_items, states, partials); break;
         default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;

@@ -39,9 +39,21 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
     a.row_base = row_base;
     a.partials = (AggPartial *)(base + off_partials);
     const int grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cus * 8);
-    // many small windows (a few hundred rows each): one wave per item instead of one workgroup per item
-    const bool small_items = n_items > (size_t)ctx->n_cus * 8 && n_rows / n_items < 2048;
-    if (small_items)
+    // many small windows: one wave per item instead of one workgroup per item, or -- with enough windows to fill the chip four to a
+    // wave -- 16 lanes per window (knox_window.hip).  Measured on the same resident columns (tools/ab_window_forms.py, values path,
+    // 2^26 ... 2^30 rows): at 64 K rows per window the workgroup form wins, at 16 K the group form by a little, at 4 K and below wave < block and
+    // group < wave (2^20 windows: 2^26 rows 2.21 -> 0.75 ms, 2^28 rows 2.34 -> 1.10 ms, 2^30 rows 3.42 -> 2.35 ms).
+    // KNOX_WINDOW_FORM=block | wave | group pins the form (measurements, tests).
+    const bool small_items = n_items > (size_t)ctx->n_cus * 8 && n_rows / n_items < 32768;
+    const char *form_env = getenv("KNOX_WINDOW_FORM");
+    const bool pin_wave = form_env && !strcmp(form_env, "wave"), pin_group = form_env && !strcmp(form_env, "group");
+    const bool pin_block = form_env && !strcmp(form_env, "block");
+    const bool by_group = !pin_block && !pin_wave && (pin_group || (small_items && n_items >= (size_t)ctx->n_cus * 32));
+    const int group_grid = (int)std::min<size_t>((n_items + 15) / 16, (size_t)ctx->n_cus * 16);
+    if (by_group)
+        e = launch_bucket_reduce_groups(ctx->stream, width, group_grid, a,
+                                        (const BucketItem *)(base + off_items), (uint32_t)n_items);
+    else if (!pin_block && (pin_wave || small_items))
         e = launch_bucket_reduce_waves(ctx->stream, width, (int)std::min<size_t>((n_items + 3) / 4, (size_t)ctx->n_cus * 16), a,
                                        (const BucketItem *)(base + off_items), (uint32_t)n_items);
     else
@@ -53,7 +65,8 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
         // var/std: second pass over the same work items, each centred on its window's mean
         rc = ensure(ctx, ctx->mom_partials, (n_items + 1) * 4 * sizeof(double));
         if (rc) return rc;
-        e = launch_bucket_moments(ctx->stream, width, a.agg_flavor, grid, vals, a.mask, (const BucketItem *)(base + off_items), (uint32_t)n_items,
+        e = launch_bucket_moments(ctx->stream, width, a.agg_flavor, by_group ? group_grid : grid, vals, a.mask, by_group ? (uint64_t)n_rows : 0,
+                                  (const BucketItem *)(base + off_items), (uint32_t)n_items,
                                   (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, (AggStateDev *)(base + off_states),
                                   (double *)ctx->mom_partials.p);
     }

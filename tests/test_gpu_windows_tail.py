@@ -182,3 +182,69 @@ def test_out_of_order_windows_with_nothing_selected_or_nothing_inside():
         assert seen.sum() == 1 and seen[k] == 1 and vals[k] == v[777]
         for o in (tcol, vcol, none, one):
             o.free()
+
+
+def test_many_small_windows_three_launch_forms_agree_and_match_the_oracle():
+    """The reduce step has three launch forms (knox_windows.cpp reduce_windows): a workgroup per work item, a wave per item, and
+    -- for more windows than the chip has wave slots -- a 16-lane group per item, four windows per wave (knox_window.hip
+    bucket_reduce_group_kernel).  KNOX_WINDOW_FORM pins one; all three must return the same states, byte for byte, for every
+    width, with and without a selection, with empty windows, windows of 1 ... a few thousand rows and ragged ends; the default
+    choice (the group form at 40 000 windows) is checked against the oracle's literal NativeBucket.Push
+    (internal/reducer/bucket_native.go:104-159)."""
+    import os
+    from oracle import oracle as O
+    rng = np.random.default_rng(404)
+    OT = {B.Int64: O.I64, B.Float64: O.F64, B.Int16: O.I16, B.Uint8: O.U8, B.Uint32: O.U32}
+    OF = {R.Sum: O.R_SUM, R.Min: O.R_MIN, R.Max: O.R_MAX, R.First: O.R_FIRST, R.Last: O.R_LAST, R.Count: O.R_COUNT}
+    old = os.environ.pop("KNOX_WINDOW_FORM", None)
+    try:
+        with K.Context(0) as ctx:
+            for n, mean_rows in ((1 << 20, 26), (700_001, 5), (1 << 21, 900)):
+                dt = rng.integers(0, 3, n)
+                dt[rng.integers(0, n, n // 300)] += 50                      # gaps: runs of empty windows
+                t = (5_000_000 + np.cumsum(dt)).astype(np.int64)
+                step = mean_rows
+                t_from = int(t[0]) - 3
+                nb = int((t[-1] - t_from) // step) + 1
+                tcol = ctx.upload(t, 4096)
+                bits_h = np.packbits(rng.random(n) < 0.5, bitorder="little")
+                mask = ctx.bits(n).upload(bits_h)
+                for bt in (B.Int64, B.Float64, B.Int16, B.Uint8, B.Uint32):
+                    v = _values(rng, bt, n)
+                    if np.dtype(NP[bt]).kind == "f":
+                        v = np.where(np.isnan(v), 0.5, v).astype(NP[bt])   # the oracle comparison below wants comparable sums
+                    vcol = ctx.upload(v, 4096)
+                    for m, mh in ((None, None), (mask, bits_h)):
+                        got = {}
+                        for form in ("block", "wave", "group", None):
+                            if form is None:
+                                os.environ.pop("KNOX_WINDOW_FORM", None)
+                            else:
+                                os.environ["KNOX_WINDOW_FORM"] = form
+                            got[form] = bytes(ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=m))
+                            if bt in (B.Int16, B.Float64):
+                                # the var / std second pass has a workgroup and a group form: its double-double partial sums meet in
+                                # another order, which Value() must not show
+                                for f in (R.Var, R.Std):
+                                    vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                                    got[(form, f)] = (vals.tobytes(), seen.tobytes())
+                        assert got["wave"] == got["block"], (n, bt, "wave")
+                        assert got["group"] == got["block"], (n, bt, "group")
+                        assert got[None] == got["block"], (n, bt, "default")
+                        if bt in (B.Int16, B.Float64):
+                            for f in (R.Var, R.Std):
+                                assert got[("group", f)] == got[("block", f)] == got[(None, f)], (n, bt, f)
+                    if mean_rows == 26 and bt in OT:
+                        states = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=mask)
+                        for f, of in OF.items():
+                            want_t, want_v = O.buckets(OT[bt], of, t, v, bits_h, t_from, step)
+                            gt = [t_from + k * step for k, st in enumerate(states) if st.count > 0]
+                            assert gt == want_t.tolist(), (bt, f)
+                            gv = np.array([K.agg_value(st, f)[0] for st in states if st.count > 0], dtype=want_v.dtype)
+                            assert gv.tobytes() == want_v.tobytes(), (bt, f)
+                    vcol.free()
+                tcol.free(); mask.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_FORM", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_FORM"] = old
