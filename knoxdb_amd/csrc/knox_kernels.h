@@ -362,6 +362,7 @@ struct WindowSortGeom {
 WindowSortGeom window_sort_geom(uint64_t n, int n_cus);
 void window_sort_passes(unsigned key_bits, uint32_t bits[4], int *n_passes);
 // keys[n_rows] (0xffffffff = row not selected / outside every window); hist[nb*256] scanned, tot[256] = per-digit totals
+// idx_out == nullptr: the sort carries (key, value) pairs, no row ids
 hipError_t launch_window_sort_begin(hipStream_t s, const int64_t *time, uint64_t n_rows, const uint8_t *mask, int64_t t_from, int64_t step,
                                     uint32_t n_buckets, WindowSortGeom g, uint32_t bits0, uint32_t *keys, uint32_t *hist, uint32_t *tot);
 hipError_t launch_window_sort_first(hipStream_t s, int width, const uint32_t *keys, const void *value_col, uint64_t n_rows, WindowSortGeom g,

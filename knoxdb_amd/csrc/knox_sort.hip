@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kSortBlock) hist_scan_kernel(uint32_t *__restr
 // rows dropped; otherwise the (key, row, value) triples of the previous pass.  ITEMS elements per thread and tile; wave w
 // of a tile owns the elements [w*64*ITEMS, (w+1)*64*ITEMS) of it, element (j, lane) at j*64 + lane (coalesced loads,
 // element order == offset order, which is what makes the ranking stable).
-template <typename U, bool FIRST, int ITEMS>
+template <typename U, bool FIRST, bool IDX, int ITEMS>
 __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ idx_in,
                                                                   const U *__restrict__ val_in, uint64_t n, uint64_t per_block, uint32_t shift,
                                                                   uint32_t nbits, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ tot,
@@ -144,10 +144,16 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
     __shared__ uint32_t tile_start[kRadix];          // first sorted position of the digit inside the tile
     __shared__ uint32_t gbase[kRadix];               // output slot of that position
     __shared__ uint32_t tmp[kSortWaves + 1];
-    __shared__ uint32_t s_key[TILE], s_idx[TILE];
+    __shared__ uint32_t s_key[TILE], s_idx[IDX ? TILE : 1];
     __shared__ U s_val[TILE];
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t dmask = (1u << nbits) - 1;
+    // IDX = false (idx_out == nullptr at the launch): the caller wants no row ids (Value() per window never shows them:
+    // knox_reduce_buckets_values) -- the triples travel as (key, value) pairs, 4 of 16 bytes per element and pass less, and 16 KiB less
+    // of LDS.  (Round 4: window indexes as 2-byte keys in memory when n_buckets <= 65535 were built as well and measured on the same box,
+    // 2^28 shuffled rows, 25 % selected -> 1024 windows: 2.94 ms against 2.49 ms with 4-byte keys -- the 2-byte stores cost more than
+    // the bytes they save; dropped.)
+    constexpr bool with_idx = IDX;
     {
         tile_start[tid] = tot[tid];
         __syncthreads();
@@ -168,7 +174,10 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
 #pragma unroll
         for (int w = 0; w < kSortWaves; w++) cnt[w][tid] = 0;
         __syncthreads();
-        uint32_t key[ITEMS], rank[ITEMS], row[ITEMS];
+        uint32_t key[ITEMS], rank[ITEMS], row[ITEMS] = {};
+#ifndef KNOX_SORT_RMW_RANK
+        uint32_t held[ITEMS], lead[ITEMS];
+#endif
         U val[ITEMS];
         // phase 1: load + rank inside the wave's chunk
 #pragma unroll
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
                 key[j] = keys_in[e];
                 if (FIRST) {
                     row[j] = (uint32_t)e;
-                } else {
+                } else if (with_idx) {
                     row[j] = idx_in[e];
                 }
                 val[j] = val_in[e];
@@ -197,12 +206,27 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
             }
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
             const uint32_t group = (uint32_t)__popcll(peers);
+#ifdef KNOX_SORT_RMW_RANK  // A/B builds: read, then write by the group's last lane -- 16 dependent LDS round trips per wave and tile
             uint32_t c = 0;
             if (active) c = cnt[wave][d];
             // all lanes of the wave have read before any writes: LDS operations of one wave retire in order
             if (active && below == group - 1) cnt[wave][d] = c + group;
             rank[j] = c + below;
+#else
+            // the group's FIRST lane adds the group's size and takes the old count back (one returning LDS add per digit present);
+            // nothing here waits for the previous element's answer -- LDS operations of a wave execute in order, so the sixteen
+            // adds queue up behind each other and the sixteen answers are fetched afterwards (lead[j]: the lane that holds it)
+            uint32_t old = 0;
+            if (active && below == 0) old = atomicAdd(&cnt[wave][d], group);
+            rank[j] = below;
+            held[j] = old;
+            lead[j] = active ? (uint32_t)__builtin_ctzll(peers) : lane;
+#endif
         }
+#ifndef KNOX_SORT_RMW_RANK
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) rank[j] += (uint32_t)__shfl((int)held[j], (int)lead[j], 64);
+#endif
         __syncthreads();
         // phase 2: digit d (= tid): waves' offsets inside the digit, the digit's start inside the tile, its output slot
         {
@@ -228,7 +252,7 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
                 const uint32_t d = (key[j] >> shift) & dmask;
                 const uint32_t pos = tile_start[d] + cnt[wave][d] + rank[j];
                 s_key[pos] = key[j];
-                s_idx[pos] = row[j];
+                if (with_idx) s_idx[pos] = row[j];
                 s_val[pos] = val[j];
             }
         }
@@ -240,7 +264,7 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
             const uint32_t d = (k >> shift) & dmask;
             const uint32_t dst = gbase[d] + (i - tile_start[d]);
             keys_out[dst] = k;
-            idx_out[dst] = s_idx[i];
+            if (with_idx) idx_out[dst] = s_idx[i];
             val_out[dst] = s_val[i];
         }
         __syncthreads();
@@ -248,18 +272,26 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
 }
 
 namespace {
+template <typename U, bool IDX>
+hipError_t scatter_launch2(hipStream_t s, bool first, uint32_t nb, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
+                           uint64_t per_block, uint32_t shift, uint32_t nbits, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out,
+                           uint32_t *idx_out, void *val_out) {
+    constexpr int ITEMS = kWindowSortItems;
+    if (first)
+        hipLaunchKernelGGL((sort_scatter_kernel<U, true, IDX, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n, per_block,
+                           shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
+    else
+        hipLaunchKernelGGL((sort_scatter_kernel<U, false, IDX, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n,
+                           per_block, shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
+    return hipGetLastError();
+}
+
 template <typename U>
 hipError_t scatter_launch(hipStream_t s, bool first, uint32_t nb, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
                           uint64_t per_block, uint32_t shift, uint32_t nbits, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out,
                           uint32_t *idx_out, void *val_out) {
-    constexpr int ITEMS = kWindowSortItems;
-    if (first)
-        hipLaunchKernelGGL((sort_scatter_kernel<U, true, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n, per_block,
-                           shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
-    else
-        hipLaunchKernelGGL((sort_scatter_kernel<U, false, ITEMS>), dim3(nb), dim3(kSortBlock), 0, s, keys_in, idx_in, (const U *)val_in, n,
-                           per_block, shift, nbits, hist, tot, keys_out, idx_out, (U *)val_out);
-    return hipGetLastError();
+    return idx_out != nullptr ? scatter_launch2<U, true>(s, first, nb, keys_in, idx_in, val_in, n, per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out)
+                              : scatter_launch2<U, false>(s, first, nb, keys_in, idx_in, val_in, n, per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
 }
 
 hipError_t scatter_any(hipStream_t s, int width, bool first, uint32_t nb, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in,

@@ -2,6 +2,8 @@
 // NativeBucket.Emit's gap filling (pure host code).
 #include "knox_internal.h"
 
+static const int kWindowsNoRowIds = 1 << 20;  // internal flag (never from the ABI: callers' flags are masked): the states' row ids are not wanted
+
 // windows -> states on the device: each window's row range [d_start[k], d_start[k+1]) of `vals` is cut into work
 // items (planned on the device: no host round trip of the bounds), reduced, and merged per window in row order.
 // *states_dev = AggStateDev[n_buckets] inside ctx->tmp_vals.  n_rows bounds the item count.
@@ -108,16 +110,18 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     size_t n_sel = 0;
     for (uint32_t t : tot) n_sel += t;
-    // the triples: two sets when there is more than one pass
-    const size_t arr4 = (n_sel * 4 + 255) & ~(size_t)255, arrw = (n_sel * w + 255) & ~(size_t)255;
-    const size_t set = 2 * arr4 + arrw;
+    // the triples (key, row id, value) -- or pairs, when no row ids are wanted: two sets when there is more than one pass
+    const bool want_rows = (flags & kWindowsNoRowIds) == 0;  // Value() per window never shows a row id
+    const size_t arrk = (n_sel * 4 + 255) & ~(size_t)255, arr4 = want_rows ? arrk : 0;
+    const size_t arrw = (n_sel * w + 255) & ~(size_t)255;
+    const size_t set = arrk + arr4 + arrw;
     rc = ensure(ctx, ctx->sort_buf, (n_passes > 1 ? 2 : 1) * set + 256);
     if (rc) return rc;
     const char *sb = (const char *)ctx->idx_rows.p;
     char *cur = (char *)ctx->sort_buf.p, *oth = cur + set;
     auto K = [&](char *b) { return (uint32_t *)b; };
-    auto I = [&](char *b) { return (uint32_t *)(b + arr4); };
-    auto V = [&](char *b) { return (void *)(b + 2 * arr4); };
+    auto I = [&](char *b) { return want_rows ? (uint32_t *)(b + arrk) : (uint32_t *)nullptr; };
+    auto V = [&](char *b) { return (void *)(b + arrk + arr4); };
     e = launch_window_sort_first(ctx->stream, (int)w, (const uint32_t *)sb, value_col->dev, n_rows, g0, bits[0], d_hist, d_tot, K(cur), I(cur), V(cur));
     const WindowSortGeom g1 = window_sort_geom(n_sel, ctx->n_cus);  // never more workgroups than g0: the histogram fits
     uint32_t shift = bits[0];
@@ -131,7 +135,7 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
     char *st = nullptr;
     rc = reduce_windows(ctx, V(cur), value_col->dtype, nullptr, n_sel, 0, d_start, n_buckets, flags, &st);
     if (rc) return rc;
-    e = launch_remap_rows(ctx->stream, (AggStateDev *)st, (uint32_t)n_buckets, I(cur), row_base);
+    if (want_rows) e = launch_remap_rows(ctx->stream, (AggStateDev *)st, (uint32_t)n_buckets, I(cur), row_base);
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     *states_dev = st;
     return KNOX_OK;
@@ -190,7 +194,7 @@ KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const 
                                  int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {
     if (!states) return KNOX_E_INVALID;
     char *st = nullptr;
-    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, &st);
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags & 0xffff, &st);
     if (rc) return rc;
     return download(ctx, states, st, n_buckets * sizeof(AggStateDev));
 }
@@ -201,7 +205,7 @@ KNOX_API int knox_reduce_buckets_view(knox_ctx *ctx, const knox_col *time_col, c
                                       int64_t step, size_t n_buckets, uint64_t row_base, int flags, const knox_agg_state **states_view) {
     if (!states_view) return KNOX_E_INVALID;
     char *st = nullptr;
-    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, &st);
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags & 0xffff, &st);
     if (rc) return rc;
     const size_t bytes = n_buckets * sizeof(AggStateDev);
     rc = ensure_host(ctx, ctx->h_view, ctx->h_view_cap, bytes);
@@ -220,7 +224,7 @@ KNOX_API int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col,
     if (!values_view || !seen_view || func < KNOX_R_SUM || func > KNOX_R_COUNT) return KNOX_E_INVALID;
     if (func == KNOX_R_VAR || func == KNOX_R_STD) flags |= 2;
     char *st = nullptr;
-    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, flags, &st);
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, (flags & 0xffff) | kWindowsNoRowIds, &st);
     if (rc) return rc;
     const size_t w = (size_t)value_col->width;
     const size_t off_seen = (n_buckets * w + 63) & ~(size_t)63, bytes = off_seen + n_buckets;

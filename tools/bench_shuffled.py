@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Shuffled clock only (the stable radix sort path): 2^28 rows -> 1024 / 16384 windows, 25 % selected and unselected (mask=None),
+values path.  The command behind a per-kernel table of exactly this shape (tools/prof_cmd.sh <tag> shuffled tools/bench_shuffled.py).
+usage: bench_shuffled.py [rows_log2=28] [reps=5]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import knoxdb_amd as K
+from knoxdb_amd import And, Leaf
+from knoxdb_amd.types import BlockType as B, FilterMode as F, ReducerFunc as R
+
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ctx = K.Context(0)
+n = 1 << lg
+col = ctx.generate(B.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=1 << 20)
+clock = ctx.generate(B.Int64, 0, 9, n, lo=1000, span=1 << 20, pack_rows=1 << 20)
+bits = ctx.bits(n, for_col=col)
+ctx.scan(And(Leaf(0, F.Range, -(1 << 38), 1 << 38)), [col], bits_out=bits)
+
+
+def timed(fn):
+    fn(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+only = os.environ.get("KNOX_SHUFFLED_ONLY")   # "masked" | "all": one variant (a profile of one shape)
+for nb in (1024, 16384):
+    step = (1 << 20) // nb
+    for m, tag in ((bits, "25 % selected"), (None, "all rows")):
+        if only and not tag.startswith("25" if only == "masked" else "all"):
+            continue
+        ms = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Sum, 1000, step, nb, mask=m))
+        print("2^%d rows, shuffled clock, %6d windows, %-13s: %6.2f ms (%.1f G rows/s)" % (lg, nb, tag, ms, n / ms / 1e6), flush=True)
