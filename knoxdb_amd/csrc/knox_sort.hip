@@ -104,6 +104,8 @@ __global__ void __launch_bounds__(kSortBlock) key_hist_kernel(const uint32_t *__
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < n ? begin + per_block : n;
+    // (Round 4: lanes with equal digits found by match-any ballots, one add per group instead of one per lane, in both histogram kernels:
+    //  2^28 shuffled rows -> 1024 windows 2.75 ms against 2.51 ms with the plain adds -- dropped.)
     for (uint64_t i = begin + threadIdx.x; i < end; i += kSortBlock) atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
     __syncthreads();
     hist[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = h[threadIdx.x];
