@@ -15,5 +15,8 @@ if [ "${KNOX_PROFILE_FAMILIES:-1}" = "1" ]; then
   bash tools/prof_cmd.sh $TAG windows tools/bench_windows.py --profile > gpurun_out/prof_${TAG}_windows.log 2>&1
   bash tools/prof_cmd.sh $TAG bloom_build tools/bench_bloom_build.py > gpurun_out/prof_${TAG}_bloom.log 2>&1
   bash tools/prof_cmd.sh $TAG encoded tools/bench_encoded.py 28 > gpurun_out/prof_${TAG}_encoded.log 2>&1
+  export KNOX_SHUFFLED_ONLY=masked
+  bash tools/prof_cmd.sh $TAG shuffled tools/bench_shuffled.py > gpurun_out/prof_${TAG}_shuffled.log 2>&1
+  unset KNOX_SHUFFLED_ONLY
   ls -la gpurun_out/${TAG}_*.txt
 fi
