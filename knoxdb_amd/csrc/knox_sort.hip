@@ -232,17 +232,19 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
         __syncthreads();
         // phase 2: digit d (= tid): waves' offsets inside the digit, the digit's start inside the tile, its output slot
         {
-            uint32_t total = 0;
+            uint32_t total = 0, c[kSortWaves];
 #pragma unroll
             for (int w = 0; w < kSortWaves; w++) {
-                const uint32_t c = cnt[w][tid];
-                cnt[w][tid] = total;
-                total += c;
+                c[w] = total;
+                total += cnt[w][tid];
             }
             uint32_t n_tile;
             const uint32_t st = block_exclusive_scan(total, tmp, &n_tile);
-            tile_start[tid] = st;
-            gbase[tid] = run_off[tid];
+            // one LDS read per element in phase 3 (the wave's first slot of the digit inside the tile) and one in phase 4 (output slot
+            // minus tile position) instead of two each: the scatter is bound by its LDS operations, not by HBM
+#pragma unroll
+            for (int w = 0; w < kSortWaves; w++) cnt[w][tid] = st + c[w];
+            gbase[tid] = run_off[tid] - st;
             run_off[tid] += total;
             if (tid == 0) tmp[kSortWaves] = n_tile;
         }
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
         for (int j = 0; j < ITEMS; j++) {
             if (key[j] != kNoKey) {
                 const uint32_t d = (key[j] >> shift) & dmask;
-                const uint32_t pos = tile_start[d] + cnt[wave][d] + rank[j];
+                const uint32_t pos = cnt[wave][d] + rank[j];
                 s_key[pos] = key[j];
                 if (with_idx) s_idx[pos] = row[j];
                 s_val[pos] = val[j];
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
         for (uint32_t i = tid; i < n_tile; i += kSortBlock) {
             const uint32_t k = s_key[i];
             const uint32_t d = (k >> shift) & dmask;
-            const uint32_t dst = gbase[d] + (i - tile_start[d]);
+            const uint32_t dst = gbase[d] + i;  // gbase: the digit's output slot minus its first position inside the tile (wraps mod 2^32)
             keys_out[dst] = k;
             if (with_idx) idx_out[dst] = s_idx[i];
             val_out[dst] = s_val[i];
