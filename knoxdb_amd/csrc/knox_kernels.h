@@ -163,7 +163,7 @@ hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanAr
 // state_out[k] = ordered merge of partials[item_start[k] .. item_start[k+1])
 // the same with one wave per work item: many small windows
 hipError_t launch_bucket_reduce_waves(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items);
-hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items);
+hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items, bool sums_only);
 hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
                                   const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out);
 

@@ -263,13 +263,13 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_group_kernel(const ScanA
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 acc.count += h[j];
-                acc_update<W, (AGG | A_FIRSTLAST)>(acc, e[j], h[j], a.row_base + row + 16u * j, FLV);
+                acc_update<W, AGG>(acc, e[j], h[j], a.row_base + row + 16u * j, FLV);
             }
         }
         for (; row < re; row += 16) {
             const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
             acc.count += hit;
-            acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+            acc_update<W, AGG>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
         }
         acc_merge_dpp<0xB1>(acc);   // quad_perm [1,0,3,2]
         acc_merge_dpp<0x4E>(acc);   // quad_perm [2,3,0,1]
@@ -285,22 +285,31 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_group_kernel(const ScanA
     }
 }
 
-template <int W> static hipError_t bucket_reduce_groups_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+// sums_only: the caller wants Sum / Count / Mean (and the mean the var / std pass centres on) only -- knox_reduce_buckets_values knows its
+// reducer -- so the per-row update keeps two sums and the count; min / max / first / last stay at their initial "none"
+template <int W> static hipError_t bucket_reduce_groups_w(hipStream_t s, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items, bool sums_only) {
     constexpr unsigned FF = A_FSUM | A_MINMAX | A_FIRSTLAST;
     if constexpr (W >= 4) {
-        if (a.agg_flavor == FL_FLOAT) KNOX_LAUNCH((bucket_reduce_group_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+        if (a.agg_flavor == FL_FLOAT) {
+            if (sums_only) KNOX_LAUNCH((bucket_reduce_group_kernel<W, A_FSUM, FL_FLOAT>), grid, a, items, n_items);
+            KNOX_LAUNCH((bucket_reduce_group_kernel<W, FF, FL_FLOAT>), grid, a, items, n_items);
+        }
     }
-    if (a.agg_flavor == FL_SIGNED) KNOX_LAUNCH((bucket_reduce_group_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    if (a.agg_flavor == FL_SIGNED) {
+        if (sums_only) KNOX_LAUNCH((bucket_reduce_group_kernel<W, (A_ISUM | A_FSUM), FL_SIGNED>), grid, a, items, n_items);
+        KNOX_LAUNCH((bucket_reduce_group_kernel<W, A_ALL, FL_SIGNED>), grid, a, items, n_items);
+    }
+    if (sums_only) KNOX_LAUNCH((bucket_reduce_group_kernel<W, (A_ISUM | A_FSUM), FL_UNSIGNED>), grid, a, items, n_items);
     KNOX_LAUNCH((bucket_reduce_group_kernel<W, A_ALL, FL_UNSIGNED>), grid, a, items, n_items);
 }
 
-hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items) {
+hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items, bool sums_only) {
     if (n_items == 0 || grid <= 0) return hipSuccess;
     switch (width) {
-    case 8: return bucket_reduce_groups_w<8>(s, grid, a, items, n_items);
-    case 4: return bucket_reduce_groups_w<4>(s, grid, a, items, n_items);
-    case 2: return bucket_reduce_groups_w<2>(s, grid, a, items, n_items);
-    case 1: return bucket_reduce_groups_w<1>(s, grid, a, items, n_items);
+    case 8: return bucket_reduce_groups_w<8>(s, grid, a, items, n_items, sums_only);
+    case 4: return bucket_reduce_groups_w<4>(s, grid, a, items, n_items, sums_only);
+    case 2: return bucket_reduce_groups_w<2>(s, grid, a, items, n_items, sums_only);
+    case 1: return bucket_reduce_groups_w<1>(s, grid, a, items, n_items, sums_only);
     default: return hipErrorInvalidValue;
     }
 }

@@ -2,6 +2,7 @@
 // NativeBucket.Emit's gap filling (pure host code).
 #include "knox_internal.h"
 
+static const int kWindowsSumsOnly = 1 << 21;  // internal flag: only Sum / Count / Mean / Var / Std will be read from the states
 static const int kWindowsNoRowIds = 1 << 20;  // internal flag (never from the ABI: callers' flags are masked): the states' row ids are not wanted
 
 // windows -> states on the device: each window's row range [d_start[k], d_start[k+1]) of `vals` is cut into work
@@ -54,7 +55,7 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
     const int group_grid = (int)std::min<size_t>((n_items + 15) / 16, (size_t)ctx->n_cus * 16);
     if (by_group)
         e = launch_bucket_reduce_groups(ctx->stream, width, group_grid, a,
-                                        (const BucketItem *)(base + off_items), (uint32_t)n_items);
+                                        (const BucketItem *)(base + off_items), (uint32_t)n_items, (flags & kWindowsSumsOnly) != 0);
     else if (!pin_block && (pin_wave || small_items))
         e = launch_bucket_reduce_waves(ctx->stream, width, (int)std::min<size_t>((n_items + 3) / 4, (size_t)ctx->n_cus * 16), a,
                                        (const BucketItem *)(base + off_items), (uint32_t)n_items);
@@ -223,8 +224,9 @@ KNOX_API int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col,
                                         const uint8_t **seen_view) {
     if (!values_view || !seen_view || func < KNOX_R_SUM || func > KNOX_R_COUNT) return KNOX_E_INVALID;
     if (func == KNOX_R_VAR || func == KNOX_R_STD) flags |= 2;
+    const bool sums = func == KNOX_R_SUM || func == KNOX_R_COUNT || func == KNOX_R_MEAN || func == KNOX_R_VAR || func == KNOX_R_STD;
     char *st = nullptr;
-    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, (flags & 0xffff) | kWindowsNoRowIds, &st);
+    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, (flags & 0xffff) | kWindowsNoRowIds | (sums ? kWindowsSumsOnly : 0), &st);
     if (rc) return rc;
     const size_t w = (size_t)value_col->width;
     const size_t off_seen = (n_buckets * w + 63) & ~(size_t)63, bytes = off_seen + n_buckets;

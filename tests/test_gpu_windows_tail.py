@@ -228,6 +228,15 @@ def test_many_small_windows_three_launch_forms_agree_and_match_the_oracle():
                                 for f in (R.Var, R.Std):
                                     vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
                                     got[(form, f)] = (vals.tobytes(), seen.tobytes())
+                        # values of a known reducer: the group form then keeps only the sums (knox_reduce_buckets_values, Sum / Count / Mean /
+                        # Var / Std) -- the same values as the other forms, which always carry every field
+                        for form in ("block", "group"):
+                            os.environ["KNOX_WINDOW_FORM"] = form
+                            for f in (R.Sum, R.Count, R.Mean, R.Min, R.Last):
+                                vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                                got[(form, "v", f)] = (vals.tobytes(), seen.tobytes())
+                        for f in (R.Sum, R.Count, R.Mean, R.Min, R.Last):
+                            assert got[("group", "v", f)] == got[("block", "v", f)], (n, bt, f)
                         assert got["wave"] == got["block"], (n, bt, "wave")
                         assert got["group"] == got["block"], (n, bt, "group")
                         assert got[None] == got["block"], (n, bt, "default")
