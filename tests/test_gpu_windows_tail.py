@@ -209,7 +209,7 @@ def test_many_small_windows_three_launch_forms_agree_and_match_the_oracle():
                 tcol = ctx.upload(t, 4096)
                 bits_h = np.packbits(rng.random(n) < 0.5, bitorder="little")
                 mask = ctx.bits(n).upload(bits_h)
-                for bt in (B.Int64, B.Float64, B.Int16, B.Uint8, B.Uint32):
+                for bt in (B.Int64, B.Float64, B.Float32, B.Int16, B.Uint8, B.Uint32):
                     v = _values(rng, bt, n)
                     if np.dtype(NP[bt]).kind == "f":
                         v = np.where(np.isnan(v), 0.5, v).astype(NP[bt])   # the oracle comparison below wants comparable sums
