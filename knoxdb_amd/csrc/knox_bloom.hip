@@ -162,10 +162,12 @@ constexpr int kSegShift = 16;                          // 2^16 bits per segment:
 constexpr int kFillSegs = 8;                           // segments per fill workgroup (64 KiB of LDS)
 
 struct HashNumeric {
+    static constexpr bool kIsBytes = false;
     const void *col;
     template <int W> __device__ __forceinline__ uint64_t at(uint64_t row, uint64_t) const { return xxh3_value<W>((uint64_t)load_elem<W>(col, row)); }
 };
 struct HashBytes {
+    static constexpr bool kIsBytes = true;
     const uint64_t *ptr;
     const uint8_t *buf;
     const uint64_t *pool_base;
@@ -187,6 +189,47 @@ __device__ __forceinline__ uint32_t bloom_tile_hashes(const H &hasher, uint64_t 
     const uint64_t r0 = p * pack_rows + (uint64_t)tile * kBinTileRows + threadIdx.x;
     const uint64_t left = r1 > r0 ? r1 - r0 : 0;              // rows of this thread: i * kBlock < left
     uint32_t valid = 0;
+    if constexpr (H::kIsBytes) {
+        // bytes rows: knox_xxh3::hash is a CALL per row (it branches on the length eight ways), and every call waits for its own
+        // loads -- sixteen dependent round trips to memory per thread and tile (the bytes build: 71 % of the wave cycles waiting,
+        // profiles/r04_bloom_build.txt).  When no row of the wave's tile is longer than 32 bytes (hashes, addresses, UUIDs, names,
+        // tags: the branches of XXH3 that need at most four 8-byte words) the rows' words are loaded eight rows at a time before any
+        // arithmetic; the pools are allocated with 256 bytes of slack (knox_abi.cpp), so the first word of a short row may be read whole.
+        uint64_t pr[kBinRowsPerThread];
+        bool fast = true;
+#pragma unroll
+        for (int i = 0; i < kBinRowsPerThread; i++) {
+            const bool ok = (uint64_t)i * kBlock < left;
+            pr[i] = hasher.ptr[ok ? r0 + (uint64_t)i * kBlock : r1 - 1];
+            valid |= ok ? 1u << i : 0u;
+            fast = fast && (uint32_t)pr[i] <= 32u;
+        }
+        if (__all(fast)) {  // wave uniform
+            const uint8_t *pool = hasher.pool_base ? hasher.buf + hasher.pool_base[p] : hasher.buf;
+            static_assert(kBinRowsPerThread % 8 == 0, "halves of eight rows");
+#pragma unroll
+            for (int i0 = 0; i0 < kBinRowsPerThread; i0 += 8) {
+                uint64_t w[8][4];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint8_t *in = pool + (uint32_t)(pr[i0 + i] >> 32);
+                    const uint32_t len = (uint32_t)pr[i0 + i];
+                    w[i][0] = knox_xxh3::rd64(in);
+                    w[i][3] = knox_xxh3::rd64(in + (len > 8u ? len - 8u : 0u));
+                    w[i][1] = 0;
+                    w[i][2] = 0;
+                    if (len > 16u) {
+                        w[i][1] = knox_xxh3::rd64(in + 8);
+                        w[i][2] = knox_xxh3::rd64(in + len - 16);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) h[i0 + i] = knox_xxh3::hash_le32_words(w[i][0], w[i][1], w[i][2], w[i][3], (uint32_t)pr[i0 + i]);
+            }
+            return valid;
+        }
+        valid = 0;
+    }
 #pragma unroll
     for (int i = 0; i < kBinRowsPerThread; i++) {
         const bool ok = (uint64_t)i * kBlock < left;

@@ -83,6 +83,39 @@ KNOX_HD inline void accumulate_512(uint64_t *acc, const uint8_t *in, const uint8
     }
 }
 
+// XXH3_64bits of an input of 17 ... 32 bytes from its four words already in registers: a0 a1 = bytes [0, 16), b0 b1 = bytes
+// [len - 16, len) -- the same arithmetic as the 17..128 branch of hash() below; lets a kernel issue the loads of many rows
+// before any of the multiplies (knox_bloom.hip)
+KNOX_HD inline uint64_t hash_17_32_words(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1, uint64_t len) {
+    const uint8_t *s = kSecret;
+    uint64_t acc = len * P64_1;
+    acc += mul_fold(a0 ^ rd64(s), a1 ^ rd64(s + 8));
+    acc += mul_fold(b0 ^ rd64(s + 16), b1 ^ rd64(s + 24));
+    return avalanche3(acc);
+}
+
+// XXH3_64bits of an input of at most 32 bytes from words already in registers (every branch of hash() below up to 32 bytes, the
+// same arithmetic): w0 = the 8 bytes at in (read even when the input is shorter: the caller's buffer must be readable 7 bytes past
+// the input's end), w3 = the input's last 8 bytes (len >= 9), w1 = bytes [8, 16) and w2 = bytes [len - 16, len - 8) (len >= 17).
+KNOX_HD inline uint64_t hash_le32_words(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint32_t len) {
+    const uint8_t *s = kSecret;
+    if (len > 16) return hash_17_32_words(w0, w1, w2, w3, len);
+    if (len > 8) {
+        const uint64_t lo = w0 ^ (rd64(s + 24) ^ rd64(s + 32)), hi = w3 ^ (rd64(s + 40) ^ rd64(s + 48));
+        return avalanche3(len + bswap(lo) + hi + mul_fold(lo, hi));
+    }
+    if (len >= 4) {
+        const uint32_t i1 = (uint32_t)w0, i2 = (uint32_t)(w0 >> (8 * (len - 4)));
+        return rrmxmx(((uint64_t)i2 + ((uint64_t)i1 << 32)) ^ (rd64(s + 8) ^ rd64(s + 16)), len);
+    }
+    if (len > 0) {
+        const uint32_t c1 = (uint32_t)w0 & 0xffu, c2 = (uint32_t)(w0 >> (8 * (len >> 1))) & 0xffu, c3 = (uint32_t)(w0 >> (8 * (len - 1))) & 0xffu;
+        const uint32_t comb = (c1 << 16) | (c2 << 24) | c3 | (len << 8);
+        return avalanche64((uint64_t)comb ^ (uint64_t)(rd32(s) ^ rd32(s + 4)));
+    }
+    return avalanche64(rd64(s + 56) ^ rd64(s + 64));
+}
+
 // XXH3_64bits(in, len)
 KNOX_HD inline uint64_t hash(const uint8_t *in, uint64_t len) {
     const uint8_t *s = kSecret;

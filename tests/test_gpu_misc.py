@@ -160,6 +160,49 @@ def test_bloom_build_bytes_column(ctx):
     bloom.free()
 
 
+def test_bloom_build_bytes_rows_of_at_most_32_bytes(ctx):
+    """the bytes build's batched-load path (knox_bloom.hip bloom_tile_hashes: no row of a wave's tile longer than 32 bytes -- the
+    branches of XXH3 that need at most four 8-byte words, loaded for eight rows before any arithmetic): every length 0 ... 32,
+    byte-unaligned rows, a ragged last pack, a pack of 17 ... 32-byte rows only, and a pack with ONE longer row (its waves take
+    the general path) -- filters byte-identical to the oracle's construction either way; the last row ends at the pool's end"""
+    rng = np.random.default_rng(92)
+    pack, n_packs = 8192, 3
+    n = pack * n_packs - 1234
+    lens = rng.integers(0, 33, size=n)
+    lens[:33] = np.arange(0, 33)
+    lens[pack:2 * pack] = rng.integers(17, 33, size=pack)
+    lens[2 * pack + 77] = 40                  # third pack: one row beyond the fast path
+    lens[n - 1] = 3                           # the last row's first word reaches past the pool's end (device slack)
+    vals = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in lens]
+    buf = np.frombuffer(b"\x01" + b"".join(vals), dtype=np.uint8)   # + 1: rows start at odd addresses; no slack behind the last row
+    ln = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = (1 + np.concatenate([[0], np.cumsum(ln)[:-1]])).astype(np.uint64)
+    col = ctx.upload_bytes((offs << np.uint64(32)) | ln, buf, pack)
+    bloom = ctx.bloom_build(col, 2)
+    filters, offsets = bloom.download()
+    for p in range(n_packs):
+        vs = vals[p * pack:(p + 1) * pack]
+        f = O.bloom_new(len(vs), 2)
+        for v in vs:
+            O.bloom_add(f, O.xxh3_bytes(v))
+        assert (filters[int(offsets[p]):int(offsets[p + 1])] == f).all(), p
+    col.free()
+    bloom.free()
+    # the same rows as one pool per pack (knox_col_bytes_create / _append_pack: every pool on its own 64-byte boundary)
+    packs = []
+    for p in range(n_packs):
+        vs = vals[p * pack:(p + 1) * pack]
+        l = np.array([len(v) for v in vs], dtype=np.uint64)
+        o = np.concatenate([[0], np.cumsum(l)[:-1]]).astype(np.uint64)
+        packs.append(((o << np.uint64(32)) | l, np.frombuffer(b"".join(vs) or b"\x00", dtype=np.uint8)))
+    col = ctx.upload_bytes_packs(packs, pack)
+    bloom2 = ctx.bloom_build(col, 2)
+    f2, o2 = bloom2.download()
+    assert (o2 == offsets).all() and (f2 == filters).all()
+    col.free()
+    bloom2.free()
+
+
 def test_large_scan_properties(ctx):
     """2^26 rows (512 MiB): size-independent properties + sampled packs against the oracle."""
     n, pack = 1 << 26, 1 << 20
