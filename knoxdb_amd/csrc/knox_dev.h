@@ -461,11 +461,19 @@ __device__ __forceinline__ void agg_iter_w4(Acc &acc, WaveMM &wm, FirstLast &fl,
         const bool any = (q[0] | q[1] | q[2] | q[3]) != 0;
         static_assert(kUnroll == 4, "the `any` term above names four loads");
         if (__any(any && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax))) {
+            // the rare exact path walks the four loads in a rolled loop (code size) over COPIES of them: indexed in place, the loop
+            // variable made the compiler keep the whole r[NL][4] block of the three- and four-leaf instantiations in scratch memory,
+            // twelve / sixteen 16-byte scratch stores in EVERY iteration (knox_scan_w*.res: ScratchSize 208 / 272); the copies are
+            // made -- and, if at all, spilled -- only here
+            u32x4 rr[kUnroll];
+            uint32_t qr[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) { rr[u] = r[u]; qr[u] = q[u]; }
 #pragma unroll 1
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
 #pragma unroll
-                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(rr[u], j), (qr[u] >> j) & 1u, rbase + j, FLV);
             }
             wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
             wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
@@ -628,11 +636,19 @@ __device__ __forceinline__ void agg_iter(Acc &acc, WaveMM &wm, FirstLast &fl, co
             }
         }
         if (__any(trig)) {
+            // the rare exact path walks the four loads in a rolled loop (code size) over COPIES of them: indexed in place, the loop
+            // variable made the compiler keep the whole r[NL][4] block of the three- and four-leaf instantiations in scratch memory,
+            // twelve / sixteen 16-byte scratch stores in EVERY iteration (knox_scan_w*.res: ScratchSize 208 / 272); the copies are
+            // made -- and, if at all, spilled -- only here
+            u32x4 rr[kUnroll];
+            uint32_t qr[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) { rr[u] = r[u]; qr[u] = q[u]; }
 #pragma unroll 1
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
 #pragma unroll
-                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(rr[u], j), (qr[u] >> j) & 1u, rbase + j, FLV);
             }
             wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
             wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
@@ -883,11 +899,19 @@ __device__ __forceinline__ void agg_iter_swar(Acc &acc, WaveMM &wm, FirstLast &f
         // that selected nothing has nothing to adopt (its neutral elements would "beat" the initial bounds)
         const bool any = (q[0] | q[1] | q[2] | q[3]) != 0;
         if (__any(any && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax))) {
+            // the rare exact path walks the four loads in a rolled loop (code size) over COPIES of them: indexed in place, the loop
+            // variable made the compiler keep the whole r[NL][4] block of the three- and four-leaf instantiations in scratch memory,
+            // twelve / sixteen 16-byte scratch stores in EVERY iteration (knox_scan_w*.res: ScratchSize 208 / 272); the copies are
+            // made -- and, if at all, spilled -- only here
+            u32x4 rr[kUnroll];
+            uint32_t qr[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) { rr[u] = r[u]; qr[u] = q[u]; }
 #pragma unroll 1
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
 #pragma unroll
-                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(rr[u], j), (qr[u] >> j) & 1u, rbase + j, FLV);
             }
             wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
             wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));
@@ -973,11 +997,19 @@ __device__ __forceinline__ void agg_iter_narrow(Acc &acc, WaveMM &wm, FirstLast 
         // that selected nothing has nothing to adopt (its neutral elements would "beat" the initial bounds)
         const bool any = (q[0] | q[1] | q[2] | q[3]) != 0;
         if (__any(any && ((uint64_t)imin < wm.smin || (uint64_t)imax > wm.smax))) {
+            // the rare exact path walks the four loads in a rolled loop (code size) over COPIES of them: indexed in place, the loop
+            // variable made the compiler keep the whole r[NL][4] block of the three- and four-leaf instantiations in scratch memory,
+            // twelve / sixteen 16-byte scratch stores in EVERY iteration (knox_scan_w*.res: ScratchSize 208 / 272); the copies are
+            // made -- and, if at all, spilled -- only here
+            u32x4 rr[kUnroll];
+            uint32_t qr[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) { rr[u] = r[u]; qr[u] = q[u]; }
 #pragma unroll 1
             for (int u = 0; u < kUnroll; u++) {
                 const uint64_t rbase = row_base + row0 + (uint64_t)u * RPL + (uint64_t)lane * K;
 #pragma unroll
-                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(r[u], j), (q[u] >> j) & 1u, rbase + j, FLV);
+                for (int j = 0; j < K; j++) acc_update<W, A_MINMAX>(acc, elem<W>(rr[u], j), (qr[u] >> j) & 1u, rbase + j, FLV);
             }
             wm.smin = uniform_u64(wave_min_u64(acc.minrow != kNoRow ? acc.minkey : ~0ull));
             wm.smax = uniform_u64(wave_max_u64(acc.maxrow != kNoRow ? acc.maxkey : 0ull));

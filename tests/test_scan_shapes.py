@@ -66,3 +66,17 @@ def test_the_headline_kernels_do_not_spill():
     for key in ((1, 1, False, False, 0), (2, 14, False, True, 2), (1, 0, False, False, 0)):
         i = by[key]
         assert i["scratch"] == 0 and i["occ"] >= 2, i
+
+
+def test_no_scan_instantiation_keeps_anything_in_scratch_memory():
+    """Round 4: the three- and four-leaf aggregate-heavy instantiations kept their whole r[NL][4] block of loaded values in
+    scratch memory (ScratchSize 208 / 272 bytes per lane, twelve / sixteen 16-byte scratch stores in EVERY wave iteration) because
+    the rare exact min / max path indexed the array with a run-time loop variable; they ran at 0.55-0.59 of what they do now
+    (tools/ab_kernels.py on identical buffers: 3.6-3.8 -> 6.4-6.7 TB/s).  The build's resource remarks would have shown it:
+    hold every instantiation of every width to ScratchSize 0 and no spilled register."""
+    n = 0
+    for w in (8, 4, 2, 1):
+        for i in instantiations(w):
+            assert i["scratch"] == 0, i
+            n += 1
+    assert n >= 250

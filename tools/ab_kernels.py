@@ -34,7 +34,8 @@ else:
         fn.restype, fn.argtypes = res, args
 
 ctxA = K.Context(0)
-spec = {"i64": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "i64b": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "f64": (B.Float64, 8, 0, 0, 2), "f64b": (B.Float64, 8, 0, 0, 2),
+spec = {"i64": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "i64b": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "i64c": (B.Int64, 8, -(1 << 40), 1 << 41, 0),
+        "i64d": (B.Int64, 8, -(1 << 40), 1 << 41, 0), "f64": (B.Float64, 8, 0, 0, 2), "f64b": (B.Float64, 8, 0, 0, 2),
         "i32": (B.Int32, 4, -(1 << 30), 1 << 31, 0), "f32": (B.Float32, 4, 0, 0, 2), "i16": (B.Int16, 2, -(1 << 15), 1 << 16, 0),
         "u8": (B.Uint8, 1, 0, 256, 0)}
 colsA = {k: ctxA.generate(bt, kind, 2 + i, n, lo=lo, span=span, pack_rows=pack) for i, (k, (bt, w, lo, span, kind)) in enumerate(spec.items())}
@@ -74,6 +75,10 @@ cases = [
     ("u8 Between+ALL", ["u8"], lambda: And(Leaf(0, F.Range, 64, 127)), ALLA, 1.125),
     ("i64 x2 OR (count)", ["i64", "i64b"], lambda: Or(Leaf(0, F.Gt, 1 << 39), Leaf(1, F.Lt, -(1 << 39))), [], 16.125),
     ("f64 x2 + i64 x1: 3 leaves + sum", ["f64", "f64b", "i64"], lambda: And(Leaf(0, F.Ge, 0.25), Leaf(1, F.Lt, 0.5), Leaf(2, F.Gt, 0)), [(R.Sum, 2)], 24.125),
+    # three / four leaves with every aggregate (round 4: these instantiations kept their loads in scratch memory)
+    ("i64 x3: 3 leaves + ALL", ["i64", "i64b", "i64c"], lambda: And(Leaf(0, F.Gt, -(1 << 39)), Or(Leaf(1, F.Lt, 0), Leaf(2, F.Ge, 0))), ALLA, 24.125),
+    ("f64 x2 + i64 x1: 3 leaves + min/max/mean", ["f64", "f64b", "i64"], lambda: And(Leaf(0, F.Ge, 0.25), Leaf(1, F.Lt, 0.5), Leaf(2, F.Gt, 0)), [(R.Min, 0), (R.Max, 0), (R.Mean, 0)], 24.125),
+    ("i64 x4: 4 leaves + ALL", ["i64", "i64b", "i64c", "i64d"], lambda: And(Or(Leaf(0, F.Gt, 0), Leaf(1, F.Lt, 0)), Or(Leaf(2, F.Ge, 0), Leaf(3, F.Lt, 0))), ALLA, 32.125),
 ]
 
 
