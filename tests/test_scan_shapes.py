@@ -80,3 +80,17 @@ def test_no_scan_instantiation_keeps_anything_in_scratch_memory():
             assert i["scratch"] == 0, i
             n += 1
     assert n >= 250
+
+
+def test_no_kernel_of_any_family_keeps_anything_in_scratch_memory():
+    """the same figures for every other kernel family (knox_agg / window / bitset / bytes / bloom / decode / sort .res, left by the
+    build): no kernel spills a register or holds an array in scratch memory"""
+    seen = 0
+    for fam in ("knox_agg", "knox_window", "knox_bitset", "knox_bytes", "knox_bloom", "knox_decode", "knox_sort"):
+        path = os.path.join(CSRC, fam + ".res")
+        assert os.path.exists(path), "build first (__graft_entry__.build): %s.res" % fam
+        for b in open(path).read().split("Function Name: ")[1:]:
+            g = lambda k: int(re.search(k + r": (\d+)", b).group(1))
+            assert g(r"ScratchSize \[bytes/lane\]") == 0 and g("VGPRs Spill") == 0, (fam, b.split()[0])   # (SGPRs spill into VGPR lanes, not memory)
+            seen += 1
+    assert seen >= 250
