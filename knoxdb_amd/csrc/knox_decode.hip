@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
     uint32_t cur_pack = 0xffffffffu;
     EncPack hp = {0, 0, 0, 0, 0, 0, 0, 0};
     bool use_hist = false, contig = false;
-    uint32_t c_lo = 0, c_diff = 0;
+    uint32_t c_lo = 0, c_diff = 0, q_lo = 0, q_diff = 0, q_m1 = 0;
     auto flush_hist = [&]() {   // workgroup uniform; callers synchronise before and after
         if constexpr (SUM) {
             if (use_hist)
@@ -208,6 +208,10 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
             c_lo = nh ? s_first : 1u;           // no hit at all: the empty interval [1, 0]
             c_diff = nh ? s_last - s_first : 0xffffffffu;
             if (nh == 0) c_diff = 0, c_lo = 0x10000u;  // (code - 0x10000) wraps above every 16-bit code: never <= 0
+            // the same interval for narrow_load: the low end in both halves of a dword, the width, "no hit at all" as a constant
+            q_lo = (c_lo & 0xffffu) * 0x00010001u;
+            q_diff = nh ? s_last - s_first : 0u;
+            q_m1 = nh ? 0xffu : 0u;
         }
         const uint64_t in_pack = (c % chunks_pp) * kEncChunkRows + (uint64_t)wave * 2048;  // this wave's first row inside the pack
         if (in_pack >= hp.rows) continue;                                                   // a short last pack (wave uniform)
@@ -217,11 +221,30 @@ __global__ void __launch_bounds__(kBlock) dict_scan_kernel(const EncScanArgs a, 
 #pragma unroll
         for (int u = 0; u < 4; u++) r[u] = __builtin_nontemporal_load(src + u * 64);
         uint32_t mine = 0;
+        // one interval of hit codes and no pack end inside the wave's 2048 rows (wave uniform): the codes go through the 2-byte scans'
+        // predicate (knox_dev.h narrow_load: v_pk_sub_u16 + an SDWA compare per half word + add-with-carry, 2.5 operations per row
+        // where the general form below takes ~8 -- extract, subtract, compare, row bound, code bound, shift, or); a code beyond the
+        // dictionary cannot lie inside the interval, whose ends are dictionary entries
+        const bool quick = contig && in_pack + 2048 <= hp.rows;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
             const uint64_t lane_row = in_pack + (uint64_t)u * 512 + (uint64_t)lane * 8;
             uint32_t m = 0;
+            if (quick) {
+                uint32_t unused = 0;
+                m = narrow_load<2, false>(r[u], q_lo, q_diff, q_m1, 0u, unused);
+                if constexpr (SUM) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if ((m >> j) & 1u) {
+                            const uint32_t code = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                            if (use_hist) atomicAdd(&chist[code], 1u);
+                            else sum += enc_load_val<W>(a.vals, hp.off + code);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const uint32_t code = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
