@@ -655,6 +655,8 @@ struct knox_packed {
     size_t packs_cap = 0, words_cap = 0;
     hipEvent_t ready_ev = nullptr;
     bool ready_pending = false;
+    uint32_t max_log2 = 0;     // widest field of any pack
+    bool aligned16 = true;     // every pack's first word is 16-byte aligned (the LDS-staged scan loads 16 bytes per lane)
 };
 
 // [4][uvarint For][uvarint log2][uvarint N][packed bits] (int_bitpack.go:93-133): header fields + where the payload lies
@@ -727,6 +729,8 @@ KNOX_API int knox_packed_append_async(knox_ctx *ctx, knox_packed *p, const uint8
         if (n > p->pack_rows || (i + 1 < n_bufs && n != p->pack_rows) || n == 0) return KNOX_E_INVALID;
         if (words + plen[i] / 8 > p->words_cap) return KNOX_E_RANGE;
         packs[i] = {words, minv, (uint32_t)n, (uint32_t)l2};
+        p->max_log2 = std::max(p->max_log2, (uint32_t)l2);
+        p->aligned16 = p->aligned16 && (words & 1) == 0;
         words += plen[i] / 8;
         rows += (size_t)n;
     }
@@ -751,6 +755,8 @@ KNOX_API int knox_packed_reset(knox_ctx *ctx, knox_packed *p) {
     HIPCHK(ctx, hipEventRecord(ctx->fence_ev, ctx->stream));   // the scans enqueued so far may still read the old words
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
     p->n_packs = p->n_rows = p->words_bytes = 0;
+    p->max_log2 = 0;
+    p->aligned16 = true;
     return KNOX_OK;
 }
 
@@ -773,6 +779,8 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
     std::vector<const uint8_t *> payload(n_bufs);
     std::vector<size_t> payload_len(n_bufs);
     size_t words = 0, rows = 0;
+    uint32_t max_l2 = 0;
+    bool al16 = true;
     for (size_t i = 0; i < n_bufs; i++) {
         uint64_t minv = 0, l2 = 0, n = 0;
         size_t o = 0, sz = 0;
@@ -780,6 +788,8 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
         if (prc) return prc;
         if (n > pack_rows || (i + 1 < n_bufs && n != pack_rows) || n == 0) return KNOX_E_INVALID;  // only the last pack may be short
         packs[i] = {words, minv, (uint32_t)n, (uint32_t)l2};
+        max_l2 = std::max(max_l2, (uint32_t)l2);
+        al16 = al16 && (words & 1) == 0;
         payload[i] = bufs[i] + o;
         payload_len[i] = (size_t)sz;
         words += (size_t)sz / 8;
@@ -795,6 +805,8 @@ KNOX_API int knox_packed_upload(knox_ctx *ctx, int dtype, const uint8_t *const *
     p->d_words = nullptr;
     p->d_packs = nullptr;
     p->words_bytes = words * 8;
+    p->max_log2 = max_l2;
+    p->aligned16 = al16;
     // + 64 bytes: the kernel reads one word past a field's word unconditionally
     if (dev_malloc(ctx, (void **)&p->d_words, words * 8 + 64) != hipSuccess || dev_malloc(ctx, (void **)&p->d_packs, n_bufs * sizeof(PackedPack) + 64) != hipSuccess) {
         if (p->d_words) dev_free(p->ctx, p->d_words);
@@ -866,7 +878,10 @@ KNOX_API int knox_packed_scan(knox_ctx *ctx, const knox_packed *p, int op, uint6
     const int blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8;  // latency bound: 32 waves/CU (tools/bench_packed.py sweep)
     const int grid = (int)std::min<uint64_t>((n_chunks + kWavesPerBlock - 1) / kWavesPerBlock, (uint64_t)std::min(grid_max, ctx->n_cus * blocks_per_cu));
     prof_mark(ctx, 0);
-    hipError_t e = launch_packed_scan(ctx->stream, grid, pa);
+    // fields of at most 32 bits: chunks staged in LDS (knox_decode.hip); KNOX_PACKED_FORM=global pins the general form (measurements, tests)
+    const char *pf = getenv("KNOX_PACKED_FORM");
+    const bool staged = p->max_log2 <= 32 && p->aligned16 && !(pf && !strcmp(pf, "global"));
+    hipError_t e = staged ? launch_packed_scan_lds(ctx->stream, grid, pa, p->max_log2) : launch_packed_scan(ctx->stream, grid, pa);
     prof_mark(ctx, 1);
     if (e == hipSuccess)
         e = launch_finalize(ctx->stream, dtype_width(p->dtype), pa.partials, grid, nullptr, 0, p->dtype, (AggStateDev *)ctx->states.p, (int64_t *)((AggStateDev *)ctx->states.p + 16));

@@ -89,7 +89,11 @@ __global__ void __launch_bounds__(kBlock) packed_scan_kernel(const PackedScanArg
         for (uint32_t t0 = 0; t0 < 64; t0 += 8) {
             u64x2u w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = __builtin_nontemporal_load((const u64x2u *)(wp + (uint64_t)(t0 + k) * b));
+            for (int k = 0; k < 8; k++) {
+                // (a short last pack: the groups behind its values are not there -- the words buffer ends 64 bytes behind the payload)
+                const bool there = full || base + (uint64_t)(t0 + k) * 64 < hp.n;
+                w[k] = there ? __builtin_nontemporal_load((const u64x2u *)(wp + (uint64_t)(t0 + k) * b)) : u64x2u{0ull, 0ull};
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t t = t0 + k;
@@ -115,6 +119,154 @@ __global__ void __launch_bounds__(kBlock) packed_scan_kernel(const PackedScanArg
     }
     acc.count = cnt;
     block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+// Fields of at most 32 bits, the chunk staged in LDS (round 4).  The kernel above issues one 16-byte global load per lane and STEP
+// (64 values): 2^30 values are 16.8 M wave-level loads of which every 64 lanes want the same few cache lines -- the texture
+// addresser, not HBM and not the ALUs, bound it at 1.2 T rows/s whatever the width (0.83 ms per 2^30 rows at 9 and at 20 bits).  Here
+// a wave copies its chunk (4096 values = 512 b bytes) into its own LDS slice with coalesced 16-byte loads and the steps read two
+// dwords from there (ds_read2_b32).  The predicate in field space: key - lo = field + c0 (mod 2^w) walks up by one with the field,
+// so the fields that hit are ONE cyclic interval [x0, x0 + diff] mod 2^w cut to [0, 2^b): as a 32-bit test (field - s) <= d -- when
+// the interval wraps, its two pieces [s, 2^b) and [0, e] are one interval mod 2^32 again, because no field lies in between.  Per
+// value: funnel shift, mask, subtract, compare -- the compare's lane mask IS the bitset word -- and two v_writelane to park the word
+// in lane t.
+template <bool SUM>
+__global__ void __launch_bounds__(kBlock) packed_scan_lds_kernel(const PackedScanArgs a, uint32_t wave_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t packed_lds[];
+    const int lane = threadIdx.x & 63;
+    uint32_t *stage = (uint32_t *)(packed_lds + (size_t)(threadIdx.x >> 6) * wave_bytes);
+    const uint64_t n_chunks = (uint64_t)a.n_packs * a.groups_per_pack;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint64_t n_words_bits = (a.n_rows + 63) >> 6;
+    Acc acc;
+    acc.init();
+    uint64_t cnt = 0;
+    // a chunk's shape (wave uniform) and its words on their way: the NEXT chunk's 16-byte vectors are loaded into registers (at
+    // most 16 per lane: 512 * 32 bytes / 64 lanes) before the current chunk's steps run from LDS -- without that the global
+    // latency of every chunk is exposed, and the LDS slices leave room for two to five workgroups per CU only
+    struct Chunk {
+        PackedPack hp;
+        uint64_t base;
+        uint32_t pack, n_vec;
+        bool empty, full;
+    };
+    constexpr int kMaxVec = 16;
+    u32x4 pre[kMaxVec];
+    auto shape = [&](uint64_t wc) {
+        Chunk c;
+        c.pack = (uint32_t)(wc / a.groups_per_pack);
+        c.base = (wc % a.groups_per_pack) * 4096;  // first value of the chunk inside its pack
+        c.hp = a.packs[c.pack];
+        c.empty = c.base >= c.hp.n;                // a chunk behind a short last pack's values
+        c.full = c.base + 4096 <= c.hp.n;
+        const uint32_t groups = c.empty ? 0u : c.full ? 64u : (uint32_t)((c.hp.n - c.base + 63) >> 6);
+        c.n_vec = (groups * c.hp.log2 * 8u + 15u) >> 4;     // the chunk's valid words as 16-byte vectors
+        return c;
+    };
+    auto fetch = [&](const Chunk &c) {
+        const u32x4 *src = (const u32x4 *)(a.words + c.hp.word_off + (c.base >> 6) * c.hp.log2) + lane;
+#pragma unroll
+        for (int k = 0; k < kMaxVec; k++)
+            if ((uint32_t)(k * 64 + lane) < c.n_vec) pre[k] = __builtin_nontemporal_load(src + k * 64);
+    };
+    if (wave0 >= n_chunks) {
+        block_reduce_store(acc, a.partials + blockIdx.x);
+        return;
+    }
+    Chunk cur = shape(wave0);
+    fetch(cur);
+    for (uint64_t wc = wave0; wc < n_chunks; wc += n_waves) {
+        const PackedPack hp = cur.hp;
+        const uint64_t base = cur.base;
+        const uint32_t pack = cur.pack;
+        const bool full = cur.full, empty = cur.empty;
+#pragma unroll
+        for (int k = 0; k < kMaxVec; k++)
+            if ((uint32_t)(k * 64 + lane) < cur.n_vec) ((u32x4 *)stage)[k * 64 + lane] = pre[k];
+        if (wc + n_waves < n_chunks) {   // wave uniform
+            cur = shape(wc + n_waves);
+            fetch(cur);
+        }
+        const uint64_t wi = (((uint64_t)pack * a.pack_rows + base) >> 6) + (uint64_t)lane;
+        if (empty) {
+            if (a.bits != nullptr && wi < n_words_bits) __builtin_nontemporal_store(0ull, a.bits + wi);
+            continue;
+        }
+        const uint32_t b = hp.log2;                              // <= 32 (the host picks this kernel)
+        const uint64_t c0 = (hp.minv ^ a.key_xor) - a.lo;
+        const uint32_t m1 = b == 32u ? 0xffffffffu : (1u << b) - 1u;              // the largest field
+        const uint64_t wm = a.wmask, x0 = (0ull - c0) & wm;
+        bool none = false;
+        uint32_t s32 = 0, d32 = 0xffffffffu;                                       // diff == wm: every field
+        if (a.diff < wm) {
+            const uint64_t end = (x0 + a.diff) & wm;
+            if (end >= x0) {                                                       // one piece
+                none = x0 > (uint64_t)m1;
+                s32 = (uint32_t)x0;
+                d32 = (uint32_t)((end > (uint64_t)m1 ? (uint64_t)m1 : end) - x0);
+            } else if (x0 > (uint64_t)m1) {                                        // wrapped, only the piece [0, end] reaches the fields
+                s32 = 0;
+                d32 = end > (uint64_t)m1 ? m1 : (uint32_t)end;
+            } else {                                                               // [x0, m1] and [0, min(end, m1)], end < x0
+                s32 = (uint32_t)x0;
+                d32 = (end > (uint64_t)m1 ? m1 : (uint32_t)end) - s32;             // mod 2^32
+            }
+        }
+        const bool flip = a.negate != 0;
+        const uint32_t bitoff = (uint32_t)lane * b, sh32 = bitoff & 31u;
+        const uint32_t *mine = stage + (bitoff >> 5);                             // group t: 2 b dwords further on
+        uint32_t w_lo = 0, w_hi = 0;
+        uint64_t sum = 0;  // of the FIELDS of the hits; For is added once per chunk: + For * hits
+#pragma unroll 1   // (unrolled, all 128 LDS reads are hoisted: 172 VGPRs, two waves per SIMD)
+        for (int t0 = 0; t0 < 64; t0 += 8) {
+            uint32_t d0[8], d1[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                d0[k] = mine[(uint32_t)(t0 + k) * 2u * b];
+                d1[k] = mine[(uint32_t)(t0 + k) * 2u * b + 1u];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t field = __builtin_amdgcn_alignbit(d1[k], d0[k], sh32) & m1;
+                bool hit = (((field - s32) <= d32) && !none) != flip;
+                if (!full) hit = hit && (base + (uint32_t)(t0 + k) * 64 + (uint32_t)lane < hp.n);
+                const uint64_t word = __ballot(hit);
+                // lane t parks the ballot of step t (this compiler has no __builtin_amdgcn_writelane; m0 carries the lane select: two
+                // SGPR operands would exceed the constant bus)
+                asm("s_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                    : "+v"(w_lo), "+v"(w_hi)
+                    : "s"((uint32_t)word), "s"(t0 + k), "s"((uint32_t)(word >> 32))
+                    : "m0");
+                if constexpr (SUM) sum += hit ? (uint64_t)field : 0ull;
+            }
+        }
+        const uint64_t myword = ((uint64_t)w_hi << 32) | w_lo;
+        if (a.bits != nullptr && wi < n_words_bits) __builtin_nontemporal_store(myword, a.bits + wi);
+        const uint64_t hits = (uint64_t)__builtin_popcountll(myword);  // lane t: hits of step t
+        cnt += hits;
+        if constexpr (SUM) acc.isum += sum + hp.minv * hits;  // wrapping: sum over lanes = sum of fields + For * all hits
+    }
+    acc.count = cnt;
+    block_reduce_store(acc, a.partials + blockIdx.x);
+}
+
+// max_log2 <= 32 and every pack's words 16-byte aligned: the LDS-staged form; else the general one
+hipError_t launch_packed_scan_lds(hipStream_t s, int grid, const PackedScanArgs &a, uint32_t max_log2) {
+    if (grid <= 0) return hipSuccess;
+    const uint32_t wave_bytes = 512u * (max_log2 ? max_log2 : 1u) + 16u;   // + the dword a field's second read may touch behind the chunk
+    const size_t lds = (size_t)kWavesPerBlock * wave_bytes;
+    if (lds > 48 * 1024) {  // 32-bit fields: 64 KiB + 64 B per workgroup
+        static const bool raised = [] {
+            (void)hipFuncSetAttribute((const void *)packed_scan_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            (void)hipFuncSetAttribute((const void *)packed_scan_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            return true;
+        }();
+        (void)raised;
+    }
+    if (a.want_sum) hipLaunchKernelGGL(packed_scan_lds_kernel<true>, dim3(grid), dim3(kBlock), lds, s, a, wave_bytes);
+    else hipLaunchKernelGGL(packed_scan_lds_kernel<false>, dim3(grid), dim3(kBlock), lds, s, a, wave_bytes);
+    return hipGetLastError();
 }
 
 hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a) {

@@ -281,6 +281,8 @@ struct PackedScanArgs {
 };
 // one wave per 4096 values: lane l evaluates values l, l + 64, ...; a wave64 ballot IS the bitset word
 hipError_t launch_packed_scan(hipStream_t s, int grid, const PackedScanArgs &a);
+// the same for columns whose fields are at most 32 bits wide (and whose packs start 16-byte aligned): chunks staged in LDS
+hipError_t launch_packed_scan_lds(hipStream_t s, int grid, const PackedScanArgs &a, uint32_t max_log2);
 
 // ---- dictionary / run-end containers scanned as they are (round 4; knox_enc_*) -------------------------------------------
 // dictionary [5]: row i of pack p = dict[dict_off[p] + codes[p * pack_rows + i]] (int_dict.go:76-103); the predicate is

@@ -123,3 +123,35 @@ def test_packed_scan_narrow_types(ctx, bt, dt, npdt):
             bits_p.free()
         pk.free()
         col.free()
+
+
+@pytest.mark.parametrize("bits", [0, 5, 16, 31, 32])
+def test_packed_scan_general_form_for_narrow_fields(ctx, bits, monkeypatch):
+    """fields of at most 32 bits scan from LDS-staged chunks (packed_scan_lds_kernel: the default, exercised by every test
+    above); KNOX_PACKED_FORM=global keeps the general kernel on the same containers -- same bitset, count, sum"""
+    rng = np.random.default_rng(4000 + bits)
+    pack, n_packs, last = 8192, 3, 4096 + 64 + 1
+    packs = make_packs(rng, np.int64, bits, pack, n_packs, last)
+    conts = [O.bitpack_container_store(O.I64, p) for p in packs]
+    whole = np.concatenate(packs)
+    n = whole.size
+    pk = ctx.packed_upload(BlockType.Int64, conts, pack)
+    srt = np.sort(whole)
+    a, b = srt[n // 4].item(), srt[3 * n // 4].item()
+    for mode in MODES:
+        got = {}
+        for form in ("", "global"):
+            if form:
+                monkeypatch.setenv("KNOX_PACKED_FORM", form)
+            else:
+                monkeypatch.delenv("KNOX_PACKED_FORM", raising=False)
+            bits_p = ctx.bits(n)
+            bits_p.one()
+            cnt, st, pc = pk.scan(mode, a, b if mode == FilterMode.Range else None, want_sum=True, bits_out=bits_p, pack_counts=True)
+            got[form] = (bits_p.bytes(poison=32).tobytes(), cnt, K.agg_value(st, R.Sum)[0], pc.tobytes())
+            bits_p.free()
+        want, wcnt = O.cmp(O.I64, int(mode), whole, a, b if mode == FilterMode.Range else 0)
+        assert got[""] == got["global"], (bits, mode)
+        assert got[""][0] == want.tobytes() and got[""][1] == wcnt, (bits, mode)
+    monkeypatch.delenv("KNOX_PACKED_FORM", raising=False)
+    pk.free()
