@@ -107,7 +107,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm) knox_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->partials, &ctx->states, &ctx->tmp_vals, &ctx->tmp_bits, &ctx->pack_skip, &ctx->pack_counts,
-                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->sort_buf, &ctx->bytes_val, &ctx->ring_dev,
+                      &ctx->misc, &ctx->mom_partials, &ctx->tile_counts, &ctx->idx_scratch, &ctx->idx_rows, &ctx->sort_buf, &ctx->bytes_val, &ctx->inset_keys, &ctx->ring_dev,
                       &ctx->tmp_bits_parked[0], &ctx->tmp_bits_parked[1]};
     for (DevBuf *b : bufs) dev_free(ctx, b->p);
     if (ctx->comm_buf.p) hipFree(ctx->comm_buf.p);
@@ -1833,30 +1833,34 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
         if (p.val_len % w != 0 || (p.val_len && !p.val)) return KNOX_E_INVALID;
         const size_t cnt = (size_t)(p.val_len / w);
         if (cnt > 0xffffffffu) return KNOX_E_RANGE;
-        std::vector<uint64_t> keys;
-        keys.reserve(cnt);
-        const bool isf = dtype_is_float(col->dtype);
-        const uint64_t m = wmask((int)w), sign = 1ull << (8 * w - 1), expm = w == 8 ? 0x7ff0000000000000ull : 0x7f800000ull;
-        for (size_t i = 0; i < cnt; i++) {
-            uint64_t v = 0;
-            memcpy(&v, p.val + i * w, w);
-            if (isf) {
-                if ((v & (m ^ sign)) > expm) continue;
-                keys.push_back(order_key(col->dtype, v));
-            } else {
+        const bool same = ctx->inset_keys.p && ctx->inset_dtype == col->dtype && ctx->inset_raw.size() == (size_t)p.val_len &&
+                          (p.val_len == 0 || memcmp(ctx->inset_raw.data(), p.val, (size_t)p.val_len) == 0);
+        if (!same) {
+            std::vector<uint64_t> keys;
+            keys.reserve(cnt);
+            const bool isf = dtype_is_float(col->dtype);
+            const uint64_t m = wmask((int)w), sign = 1ull << (8 * w - 1), expm = w == 8 ? 0x7ff0000000000000ull : 0x7f800000ull;
+            for (size_t i = 0; i < cnt; i++) {
+                uint64_t v = 0;
+                memcpy(&v, p.val + i * w, w);
+                if (isf && (v & (m ^ sign)) > expm) continue;
                 keys.push_back(order_key(col->dtype, v));
             }
-        }
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-        int rc = ensure(ctx, ctx->bytes_val, keys.size() * 8 + 16);
-        if (rc) return rc;
-        if (!keys.empty()) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vector not retained
+            std::sort(keys.begin(), keys.end());
+            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+            ctx->inset_dtype = -1;   // not valid while it is being replaced
+            int rc = ensure(ctx, ctx->inset_keys, keys.size() * 8 + 16);
+            if (rc) return rc;
+            if (!keys.empty()) {
+                HIPCHK(ctx, hipMemcpyAsync(ctx->inset_keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vector not retained
+            }
+            ctx->inset_raw.assign(p.val, p.val + p.val_len);
+            ctx->inset_n = keys.size();
+            ctx->inset_dtype = col->dtype;
         }
         hipError_t e = launch_inset(ctx->stream, col->width, dtype_flavor(col->dtype), p.op == KNOX_NOTIN, col->dev, n_rows,
-                                    (const uint64_t *)ctx->bytes_val.p, (uint32_t)keys.size(), (uint8_t *)bits, nullptr);
+                                    (const uint64_t *)ctx->inset_keys.p, (uint32_t)ctx->inset_n, (uint8_t *)bits, nullptr);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return KNOX_E_HIP;

@@ -2,6 +2,8 @@
 // IN / NOT IN matcher: kernels that read or write selection bitsets without touching the streaming scan.
 #include "knox_dev.h"
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace knox {
 
@@ -516,16 +518,183 @@ __global__ void __launch_bounds__(kBlock) inset_kernel(uint32_t flavor, int nega
     }
 }
 
+// Round 4: the same matcher at streaming shape.  The kernel above (one row per lane, a binary search through global memory, result
+// BYTES read-modified-written) ran at 335 G rows/s for ONE key and 23 G rows/s for 64 Ki keys (tools/bench_inset.py, 2^28 int64
+// rows; a range scan of the same column: 900).  Here a wave takes whole tiles as the scans do -- four 16-byte loads per lane in
+// flight, K rows per load -- and the lookup depends on the set:
+//   1- / 2-byte columns    a 65 536-bit membership bitmap in LDS (built per workgroup from the keys): one bit test per row, any set size
+//   up to 8 keys           the keys in turn from scalar registers against all of the lane's rows (one compare per row and key)
+//   up to 4096 keys        the sorted keys in LDS, padded to a power of two: a branch-free binary search, the rows of a lane interleaved
+//   larger sets            every stride-th key as one of <= 4096 pivots in LDS: twelve steps there, the last log2(stride) through the L2
+// Result bits leave as 32-bit words (the DPP word assembly of the scans), OR-ed into the caller's bits as before.  The rows behind
+// the last whole tile go through the kernel above.
+constexpr uint32_t kInsetRegKeys = 8, kInsetLdsKeys = 4096;
+
+template <int W>
+__global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int negate, const void *col, uint64_t n_tiles, const uint64_t *keys,
+                                                            uint32_t n_keys, uint32_t *bits32, const uint32_t *mask32) {
+    using U = typename WT<W>::U;
+    constexpr int K = WT<W>::K;
+    constexpr int G = 32 / K;
+    constexpr int RPL = 64 * K;
+    constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
+    __shared__ uint64_t skeys[W >= 4 ? kInsetLdsKeys : 1];
+    __shared__ uint32_t sbm[W <= 2 ? 2048 : 1];
+    const int lane = threadIdx.x & 63;
+    uint32_t pow2 = 1, stride = 1, n_piv = 0;
+    while (pow2 < n_keys) pow2 <<= 1;
+    if constexpr (W <= 2) {
+        for (int i = threadIdx.x; i < 2048; i += kBlock) sbm[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_keys; i += kBlock) {
+            const uint64_t k = keys[i];
+            if (k < 65536) atomicOr(&sbm[k >> 5], 1u << (k & 31));
+        }
+        __syncthreads();
+    } else if (n_keys > kInsetRegKeys && n_keys <= kInsetLdsKeys) {
+        for (uint32_t i = threadIdx.x; i < pow2; i += kBlock) skeys[i] = i < n_keys ? keys[i] : ~0ull;
+        __syncthreads();
+    } else if (n_keys > kInsetLdsKeys) {
+        // every stride-th key as a pivot: the search runs its first 12 steps in LDS and only the last log2(stride) through the L2
+        stride = (n_keys + kInsetLdsKeys - 1) / kInsetLdsKeys;
+        n_piv = (n_keys + stride - 1) / stride;
+        pow2 = 1;
+        while (pow2 < n_piv) pow2 <<= 1;
+        for (uint32_t i = threadIdx.x; i < pow2; i += kBlock) skeys[i] = i < n_piv ? keys[(uint64_t)i * stride] : ~0ull;
+        __syncthreads();
+    }
+    const uint64_t wave0 = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * kWavesPerBlock;
+    for (uint64_t t = wave0; t < n_tiles; t += n_waves) {
+        const uint64_t row0 = t * WAVE_ROWS;
+        const u32x4 *p = (const u32x4 *)col + row0 / K + lane;
+        u32x4 r[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) r[u] = ld16<true>(p + u * 64);
+        uint32_t q[kUnroll] = {0, 0, 0, 0};
+        // the rows' canonical order keys (floats: -0 -> +0, NaN never a member), as the kernel above forms them
+        auto key_of = [&](U e, bool &isnan) -> uint64_t {
+            isnan = false;
+            if (flavor == FL_FLOAT) {
+                const U mag = e & (WT<W>::MASK ^ WT<W>::SIGN);
+                U expmask;
+                if constexpr (W == 8) expmask = 0x7ff0000000000000ull; else expmask = (U)0x7f800000u;
+                isnan = mag > expmask;
+                return (mag == 0) ? (uint64_t)WT<W>::SIGN : (uint64_t)fkey<W>(e);
+            }
+            return (flavor == FL_SIGNED) ? (uint64_t)(U)(e ^ WT<W>::SIGN) : (uint64_t)e;
+        };
+        if constexpr (W <= 2) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    bool nan_;
+                    const uint32_t k = (uint32_t)key_of(elem<W>(r[u], j), nan_);
+                    q[u] |= ((sbm[k >> 5] >> (k & 31)) & 1u) << j;
+                }
+            }
+        } else if (n_keys <= kInsetRegKeys) {  // workgroup uniform
+            U ek[kUnroll][K];
+            uint32_t nanq[kUnroll] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    bool nan_;
+                    ek[u][j] = (U)key_of(elem<W>(r[u], j), nan_);
+                    nanq[u] |= (nan_ ? 1u : 0u) << j;
+                }
+            }
+            for (uint32_t kk = 0; kk < n_keys; kk++) {
+                const uint64_t kv64 = keys[kk];                       // uniform address: a scalar load
+                const bool fits = kv64 <= (uint64_t)WT<W>::MASK;      // a key beyond the column type's range matches nothing
+                const U kv = (U)kv64;
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) q[u] |= ((fits && ek[u][j] == kv) ? 1u : 0u) << j;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) q[u] &= ~nanq[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    bool nan_;
+                    const uint64_t key = key_of(elem<W>(r[u], j), nan_);
+                    bool found;
+                    if (n_keys <= kInsetLdsKeys) {
+                        uint32_t pos = 0;
+                        for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += skeys[pos + step - 1] < key ? step : 0u;
+                        found = pos < n_keys && skeys[pos] == key;
+                    } else {
+                        uint32_t pos = 0;                                    // first pivot >= key
+                        for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += skeys[pos + step - 1] < key ? step : 0u;
+                        found = pos < n_piv && skeys[pos] == key;
+                        if (!found && pos > 0) {                             // strictly between pivot pos - 1 and pivot pos
+                            uint32_t lo = (pos - 1) * stride + 1, hi = pos * stride < n_keys ? pos * stride : n_keys;
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                            }
+                            found = lo < n_keys && keys[lo] == key;
+                        }
+                    }
+                    q[u] |= ((found && !nan_) ? 1u : 0u) << j;
+                }
+            }
+        }
+        constexpr uint32_t FULL = K == 32 ? 0xffffffffu : (1u << K) - 1u;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t hit = negate ? (~q[u] & FULL) : q[u];
+            uint32_t w = pack_word<K>(hit, lane);
+            if ((lane & (G - 1)) == 0) {
+                const uint64_t idx = ((row0 + (uint64_t)u * RPL) >> 5) + (uint64_t)(lane / G);
+                if (mask32 != nullptr) w &= mask32[idx];
+                if (w) bits32[idx] |= w;
+            }
+        }
+    }
+}
+
 hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
                         const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
     if (n_rows == 0) return hipSuccess;
-    uint64_t g = (n_rows + kBlock - 1) / kBlock;
+    // whole tiles through the streaming kernel (KNOX_INSET_FORM=rows pins the row-per-lane kernel: measurements, tests); the rest, and
+    // columns or bitsets that are not 16- / 4-byte aligned, through the row-per-lane kernel
+    const char *form = getenv("KNOX_INSET_FORM");
+    const uint64_t wave_rows = (uint64_t)64 * (16 / (uint64_t)width) * kUnroll;
+    uint64_t n_tiles = n_rows / wave_rows;
+    if ((form && !strcmp(form, "rows")) || ((uintptr_t)col & 15) || ((uintptr_t)bits & 3) || ((uintptr_t)mask & 3)) n_tiles = 0;
+    if (n_tiles) {
+        uint64_t g = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (g > 256 * 8) g = 256 * 8;
+        switch (width) {
+        case 8: hipLaunchKernelGGL((inset_tile_kernel<8>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
+        case 4: hipLaunchKernelGGL((inset_tile_kernel<4>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
+        case 2: hipLaunchKernelGGL((inset_tile_kernel<2>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
+        case 1: hipLaunchKernelGGL((inset_tile_kernel<1>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
+        default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const uint64_t done = n_tiles * wave_rows;   // a multiple of 1024 rows: byte aligned in the bitset
+    if (done == n_rows) return hipSuccess;
+    const uint64_t left = n_rows - done;
+    const void *tcol = (const uint8_t *)col + done * (uint64_t)width;
+    uint8_t *tbits = bits + (done >> 3);
+    const uint8_t *tmask = mask ? mask + (done >> 3) : nullptr;
+    uint64_t g = (left + kBlock - 1) / kBlock;
     if (g > 2048 * 4) g = 2048 * 4;
     switch (width) {
-    case 8: KNOX_LAUNCH((inset_kernel<8>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
-    case 4: KNOX_LAUNCH((inset_kernel<4>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
-    case 2: KNOX_LAUNCH((inset_kernel<2>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
-    case 1: KNOX_LAUNCH((inset_kernel<1>), (int)g, flavor, negate ? 1 : 0, col, n_rows, keys, n_keys, bits, mask);
+    case 8: KNOX_LAUNCH((inset_kernel<8>), (int)g, flavor, negate ? 1 : 0, tcol, left, keys, n_keys, tbits, tmask);
+    case 4: KNOX_LAUNCH((inset_kernel<4>), (int)g, flavor, negate ? 1 : 0, tcol, left, keys, n_keys, tbits, tmask);
+    case 2: KNOX_LAUNCH((inset_kernel<2>), (int)g, flavor, negate ? 1 : 0, tcol, left, keys, n_keys, tbits, tmask);
+    case 1: KNOX_LAUNCH((inset_kernel<1>), (int)g, flavor, negate ? 1 : 0, tcol, left, keys, n_keys, tbits, tmask);
     default: return hipErrorInvalidValue;
     }
 }

@@ -160,6 +160,12 @@ struct knox_ctx {
     DevBuf idx_rows;     // indexes: row ids; window sort: the keys of all rows
     DevBuf sort_buf;     // window sort: the (key, row, value) triples, one or two sets
     DevBuf bytes_val;    // bytes leaf value
+    // the last numeric IN / NOT IN set as the device wants it (sorted unique order keys): a query runs the same set against every
+    // run of its table, and sorting + uploading 64 Ki members took longer than matching 2^28 rows against them
+    DevBuf inset_keys;
+    std::vector<uint8_t> inset_raw;   // the caller's members as given: compared byte for byte before the prepared set is reused
+    size_t inset_n = 0;
+    int inset_dtype = -1;
     // ring of pinned result mirrors: up to kResRing scans may be in flight (software
     // pipelining: enqueue scan i+1 before collecting scan i keeps the device busy)
     struct ResSlot {

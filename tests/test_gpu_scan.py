@@ -383,3 +383,52 @@ def test_in_and_not_in_sets(ctx):
     a, b = rand_col(BlockType.Int64, n, rng), rand_col(BlockType.Float64, n, rng)
     tree = And(Leaf(0, FilterMode.In, np.array([5, 6, 7, -3, 0], dtype=np.int64)), Or(Leaf(1, FilterMode.Gt, 0.0), Leaf(0, FilterMode.NotIn, np.array([5], dtype=np.int64))))
     check_scan(ctx, tree, [a, b], [(R.Sum, 0), (R.Max, 1)], 2048, n)
+
+
+@pytest.mark.parametrize("bt", [BlockType.Int64, BlockType.Uint64, BlockType.Int32, BlockType.Float64, BlockType.Float32, BlockType.Int16, BlockType.Uint8])
+def test_in_sets_of_every_lookup_tier(ctx, bt, monkeypatch):
+    """the streaming IN / NOT IN kernel (knox_bitset.hip inset_tile_kernel) picks its lookup by the set: a bitmap in LDS for 1- / 2-byte
+    columns, <= 8 keys from scalar registers, <= 4096 keys by a branch-free binary search in LDS, larger sets through the L2 -- set sizes
+    on both sides of every threshold, members at the type's extremes, a ragged tail behind the last whole tile, and the
+    row-per-lane kernel (KNOX_INSET_FORM=rows) on the same input: same bits, both equal to the oracle"""
+    rng = np.random.default_rng(4100 + int(bt))
+    n = 9 * 8192 + 777
+    npdt = {BlockType.Int64: np.int64, BlockType.Uint64: np.uint64, BlockType.Int32: np.int32, BlockType.Float64: np.float64,
+            BlockType.Float32: np.float32, BlockType.Int16: np.int16, BlockType.Uint8: np.uint8}[bt]
+    if np.dtype(npdt).kind == "f":
+        x = (rng.integers(-20000, 20000, size=n) / 4.0).astype(npdt)
+        x[rng.integers(0, n, 20)] = np.nan
+        x[rng.integers(0, n, 20)] = -0.0
+        x[rng.integers(0, n, 5)] = np.inf
+        pool = np.unique(x[~np.isnan(x)])
+    else:
+        info = np.iinfo(npdt)
+        span = min(40000, int(info.max) - int(info.min))
+        x = rng.integers(int(info.min), int(info.min) + span, size=n, endpoint=True).astype(npdt)
+        x[:3] = [info.min, info.max, 0]
+        pool = np.unique(x)
+    col = ctx.upload(x, 8192)
+    for nk in (1, 8, 9, 100, 4096, 4097, 9000):
+        members = rng.choice(pool, size=min(nk, pool.size), replace=False)
+        if nk >= 9:
+            members = np.concatenate([members, members[:3]])                  # duplicates in the set
+        if np.dtype(npdt).kind == "f":
+            members = np.concatenate([members, np.array([np.nan, 12345.5], dtype=npdt)]).astype(npdt)
+        else:
+            members = np.concatenate([members, np.array([np.iinfo(npdt).max], dtype=npdt)]).astype(npdt)
+        for mode in (FilterMode.In, FilterMode.NotIn):
+            want = oracle_match(And(Leaf(0, mode, members)), [x], n)
+            got = {}
+            for form in ("", "rows"):
+                if form:
+                    monkeypatch.setenv("KNOX_INSET_FORM", form)
+                else:
+                    monkeypatch.delenv("KNOX_INSET_FORM", raising=False)
+                bits = ctx.bits(n)
+                res = ctx.scan(And(Leaf(0, mode, members)), [col], aggs=[(R.Count, 0)], bits_out=bits)
+                got[form] = bits.bytes(poison=32)
+                assert res.count == O.popcount(want, n), (bt, nk, mode, form)
+                bits.free()
+            assert (got[""] == want).all() and (got["rows"] == want).all(), (bt, nk, mode)
+    monkeypatch.delenv("KNOX_INSET_FORM", raising=False)
+    col.free()
