@@ -1789,14 +1789,26 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
             pool.insert(pool.end(), items[i].first, items[i].first + items[i].second);
         }
         pool.resize(pool.size() + 8);  // 8-byte compare loads may touch the padding
-        const size_t pool_off = (sp.size() * 8 + 63) & ~(size_t)63;
+        // the members' first 8 bytes as big-endian integers, zero padded: bytes.Compare order sorts by them first (knox_bytes.hip)
+        std::vector<uint64_t> pre(items.size());
+        for (size_t i = 0; i < items.size(); i++) {
+            uint64_t be = 0;
+            for (uint32_t k = 0; k < 8; k++) be = (be << 8) | (k < items[i].second ? items[i].first[k] : 0);
+            pre[i] = be;
+        }
+        const size_t pre_off = (sp.size() * 8 + 63) & ~(size_t)63;
+        const size_t pool_off = (pre_off + pre.size() * 8 + 63) & ~(size_t)63;
         int rc = ensure(ctx, ctx->bytes_val, pool_off + pool.size() + 64);
         if (rc) return rc;
-        if (!sp.empty()) HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, sp.data(), sp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (!sp.empty()) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, sp.data(), sp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->bytes_val.p + pre_off, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
         HIPCHK(ctx, hipMemcpyAsync((char *)ctx->bytes_val.p + pool_off, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors not retained
         hipError_t e = launch_bytes_inset(ctx->stream, p.op == KNOX_NOTIN, bytes_view(col, n_rows, skip), (const uint64_t *)ctx->bytes_val.p,
-                                          (uint32_t)sp.size(), (const uint8_t *)ctx->bytes_val.p + pool_off, (uint8_t *)bits, nullptr);
+                                          (uint32_t)sp.size(), (const uint8_t *)ctx->bytes_val.p + pool_off,
+                                          (const uint64_t *)((const char *)ctx->bytes_val.p + pre_off), (uint8_t *)bits, nullptr);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return KNOX_E_HIP;

@@ -1,6 +1,7 @@
 // knox_bytes.hip -- bytes (StringPool) column matchers: EQ / NE streaming form, ordered modes, IN / NOT IN, REGEXP.
 #include "knox_bytes_dev.h"
 #include <stdlib.h>
+#include <string.h>
 #define KNOX_HD __host__ __device__
 #include "knox_regex.h"
 
@@ -175,10 +176,81 @@ __global__ void __launch_bounds__(kBlock) bytes_inset_kernel(int negate, BytesVi
     }
 }
 
+// Round 4: the same membership test with the search in LDS.  The kernel above walks the sorted set with a full bytes.Compare per
+// step -- ten dependent (set pointer, set bytes, row bytes) fetches through the L2 per row for 583 members: 35 G rows/s on 32-byte
+// keys where EQ runs at 160 (tools/bench_bytes.py).  bytes.Compare order is the order of the 8-byte big-endian PREFIXES (zero
+// padded) first: the sets' prefixes sit in LDS (<= 4096 members), a branch-free binary search finds the first member whose prefix
+// is not below the row's, and only the members sharing the row's prefix (usually one or none) are compared in full.  Four groups of
+// 64 rows per wave iteration: the pointers, then the first 8 bytes of every row, are in flight together.  A row's first 8 bytes
+// are read even when the row is shorter (the pools end in 256 bytes of slack; knox_abi.cpp) and cut to its length.
+constexpr int kInGroups = 4;
+constexpr uint32_t kBytesInLdsKeys = 4096;
+
+__global__ void __launch_bounds__(kBlock) bytes_inset_prefix_kernel(int negate, BytesView v, const uint64_t *set_ptr, uint32_t n_set,
+                                                                    const uint8_t *set_buf, const uint64_t *set_prefix, uint8_t *bits,
+                                                                    const uint8_t *mask) {
+    __shared__ uint64_t spre[kBytesInLdsKeys];
+    uint32_t pow2 = 1;
+    while (pow2 < n_set) pow2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < pow2; i += kBlock) spre[i] = i < n_set ? set_prefix[i] : ~0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = bv_ngroups(v);
+    for (uint64_t g0 = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kInGroups; g0 < ngroups; g0 += nwaves_total * kInGroups) {
+        uint64_t row0[kInGroups], p[kInGroups], pre[kInGroups];
+        const uint8_t *x[kInGroups];
+#pragma unroll
+        for (int k = 0; k < kInGroups; k++) {
+            const bool there = g0 + k < ngroups;                         // wave uniform
+            row0[k] = there ? bv_group_row0(v, g0 + k) : 0;
+            const uint64_t row = row0[k] + lane;
+            p[k] = (there && row < v.n_rows) ? v.ptr[row] : ~0ull;      // len 0xffffffff: no row
+        }
+#pragma unroll
+        for (int k = 0; k < kInGroups; k++) {
+            const uint8_t *pool = g0 + k < ngroups ? bv_pool(v, row0[k]) : v.buf;
+            x[k] = pool + (uint32_t)(p[k] >> 32);
+            uint64_t raw = 0;
+            if (p[k] != ~0ull) __builtin_memcpy(&raw, x[k], 8);
+            const uint32_t len = (uint32_t)p[k];
+            if (len < 8) raw &= len ? (1ull << (8 * len)) - 1 : 0ull;    // the bytes behind a short row are not the row's
+            pre[k] = __builtin_bswap64(raw);
+        }
+#pragma unroll
+        for (int k = 0; k < kInGroups; k++) {
+            if (g0 + k >= ngroups) break;                                // wave uniform
+            bool m = false;
+            if (p[k] != ~0ull) {
+                const uint32_t len = (uint32_t)p[k];
+                uint32_t pos = 0;                                        // first member whose prefix is >= the row's
+                for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += spre[pos + step - 1] < pre[k] ? step : 0u;
+                bool found = false;
+                while (pos < n_set && spre[pos] == pre[k]) {
+                    const uint64_t sp = set_ptr[pos];
+                    if ((uint32_t)sp == len && bytes_equal(x[k], set_buf + (uint32_t)(sp >> 32), len)) { found = true; break; }
+                    pos++;
+                }
+                m = negate ? !found : found;
+            }
+            const uint64_t ballot = __ballot(m);
+            bv_store_group(ballot, row0[k], v.n_rows, lane, bits, mask, true);
+        }
+    }
+}
+
+// set_prefix: the members' first 8 bytes as big-endian integers, zero padded (same order as the sorted set); null or more than
+// 4096 members: the general kernel
 hipError_t launch_bytes_inset(hipStream_t s, bool negate, const BytesView &v, const uint64_t *set_ptr, uint32_t n_set, const uint8_t *set_buf,
-                              uint8_t *bits, const uint8_t *mask) {
+                              const uint64_t *set_prefix, uint8_t *bits, const uint8_t *mask) {
     const uint64_t ngroups = v.live ? (uint64_t)v.n_live * (v.pack_rows >> 6) : (v.n_rows + 63) >> 6;
     if (ngroups == 0) return hipSuccess;
+    const char *form = getenv("KNOX_BYTES_IN_FORM");
+    if (set_prefix != nullptr && n_set <= kBytesInLdsKeys && !(form && !strcmp(form, "general"))) {
+        uint64_t g = (ngroups + (uint64_t)kWavesPerBlock * kInGroups - 1) / ((uint64_t)kWavesPerBlock * kInGroups);
+        if (g > bytes_grid_cap(16)) g = bytes_grid_cap(16);
+        KNOX_LAUNCH(bytes_inset_prefix_kernel, (int)g, negate ? 1 : 0, v, set_ptr, n_set, set_buf, set_prefix, bits, mask);
+    }
     uint64_t g = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
     if (g > ((uint64_t)1 << 20)) g = (uint64_t)1 << 20;  // latency bound (binary search per row): one group per wave, +14 % over 8192 workgroups
     KNOX_LAUNCH(bytes_inset_kernel, (int)g, negate ? 1 : 0, v, set_ptr, n_set, set_buf, bits, mask);

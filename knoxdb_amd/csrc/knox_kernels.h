@@ -237,7 +237,7 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
 
 // bytes IN / NOT IN: the set sorted + unique in StringPool form (set_ptr[i] = off << 32 | len into set_buf)
 hipError_t launch_bytes_inset(hipStream_t s, bool negate, const BytesView &v, const uint64_t *set_ptr, uint32_t n_set,
-                              const uint8_t *set_buf, uint8_t *bits, const uint8_t *mask);
+                              const uint8_t *set_buf, const uint64_t *set_prefix, uint8_t *bits, const uint8_t *mask);
 
 // bloom probe / build
 hipError_t launch_bloom_probe(hipStream_t s, const uint8_t *filters, const uint64_t *offsets, uint64_t n_packs,

@@ -432,3 +432,35 @@ def test_in_sets_of_every_lookup_tier(ctx, bt, monkeypatch):
             assert (got[""] == want).all() and (got["rows"] == want).all(), (bt, nk, mode)
     monkeypatch.delenv("KNOX_INSET_FORM", raising=False)
     col.free()
+
+
+def test_bytes_in_sets_prefix_search_and_general_form_agree(ctx, monkeypatch):
+    """bytes IN / NOT IN searches the members' 8-byte prefixes in LDS and compares in full only the members that share the row's
+    prefix (knox_bytes.hip bytes_inset_prefix_kernel); KNOX_BYTES_IN_FORM=general keeps the full-compare binary search.  Members
+    and rows that share prefixes of 8 and more bytes, rows shorter than 8 bytes (their first word is cut to their length), the empty
+    string, zero bytes behind a prefix, a set beyond 4096 members (general form either way)"""
+    rng = np.random.default_rng(77)
+    n = 5 * 1024 + 123
+    stems = [b"", b"\x00", b"\x00\x00", b"a", b"ab", b"abcdefg", b"abcdefgh", b"abcdefgh\x00", b"abcdefghi", b"abcdefghij" * 3, b"\xff" * 8, b"\xff" * 9]
+    keys = stems + [bytes(rng.integers(0, 4, size=int(rng.integers(0, 20)), dtype=np.uint8)) for _ in range(400)]
+    vals = [keys[i] for i in rng.integers(0, len(keys), size=n)]
+    buf = np.frombuffer(b"".join(vals) + b"\x00" * 8, dtype=np.uint8)
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    col = ctx.upload_bytes(ptr, buf, 1024)
+    big = [bytes(rng.integers(0, 256, size=12, dtype=np.uint8)) for _ in range(5000)] + stems[:6]
+    for st in (stems, stems[:1], keys[5:200], [b"abcdefgh"], [b"abcdefghX", b"\x00\x00\x00"], big):
+        for mode in (FilterMode.In, FilterMode.NotIn):
+            want = oracle_match(And(Leaf(0, mode, st)), [(ptr, buf)], n)
+            for form in ("", "general"):
+                if form:
+                    monkeypatch.setenv("KNOX_BYTES_IN_FORM", form)
+                else:
+                    monkeypatch.delenv("KNOX_BYTES_IN_FORM", raising=False)
+                bits = ctx.bits(n)
+                ctx.scan(And(Leaf(0, mode, st)), [col], bits_out=bits)
+                assert (bits.bytes(poison=32) == want).all(), (len(st), mode, form)
+                bits.free()
+    monkeypatch.delenv("KNOX_BYTES_IN_FORM", raising=False)
+    col.free()
