@@ -1303,11 +1303,12 @@ KNOX_API int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_li
     if (ctx->res_head != ctx->res_tail) return KNOX_E_BUSY;
     hipSetDevice(ctx->device);
     for (int i_ = 0; i_ < n_limbs; i_++) { const int rc_ = col_acquire(ctx, limbs[i_]); if (rc_) return rc_; }
-    // sorted unique keys in the kernel's order: unsigned lexicographic with the top limb's sign bit flipped
+    // sorted unique keys in the kernels' order: unsigned lexicographic over the limbs LEAST significant first (membership needs no value
+    // order, and the low limb is the one that tells small values apart: knox_bitset.hip); the limb columns are passed in that order too
     const size_t L = (size_t)n_limbs;
     std::vector<size_t> idx(n_set);
     for (size_t i = 0; i < n_set; i++) idx[i] = i;
-    auto key = [&](size_t i, size_t l) { return l == 0 ? set[i * L] ^ (1ull << 63) : set[i * L + l]; };
+    auto key = [&](size_t i, size_t l) { return set[i * L + (L - 1 - l)]; };
     auto less = [&](size_t x, size_t y) {
         for (size_t l = 0; l < L; l++)
             if (key(x, l) != key(y, l)) return key(x, l) < key(y, l);
@@ -1325,7 +1326,7 @@ KNOX_API int knox_match_wide_set(knox_ctx *ctx, knox_col *const *limbs, int n_li
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vector not retained
     }
     const uint64_t *lp[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int l = 0; l < n_limbs; l++) lp[l] = (const uint64_t *)limbs[l]->dev;
+    for (int l = 0; l < n_limbs; l++) lp[l] = (const uint64_t *)limbs[n_limbs - 1 - l]->dev;
     hipError_t e = launch_wide_inset(ctx->stream, n_limbs, negate != 0, lp, n_rows, (const uint64_t *)ctx->bytes_val.p, (uint32_t)idx.size(),
                                      (uint8_t *)bits->dev, mask ? (const uint8_t *)mask->dev : nullptr);
     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }

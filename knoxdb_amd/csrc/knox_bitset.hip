@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(kBlock) wide_cmp_kernel(const WideArgs w) {
 }
 
 // Int128 / Int256 IN / NOT IN (i128InSetMatcher / i128NotInSetMatcher.MatchVector, match_i128.go:318-430 and
-// the i256 twins): membership in a sorted set; keys[k * L + l] = limb l (most significant first, top limb
+// the i256 twins): membership in a sorted set; keys[k * L + l] = limb l IN THE ORDER THE CALLER PASSES THE LIMB COLUMNS (round 4: least
+// significant first, no sign flip -- membership needs no value order; was: most significant first, top limb
 // already sign-flipped) of set value k.  One lane per row, bits.Set semantics (OR), mask-selected rows only.
 template <int L>
 __global__ void __launch_bounds__(kBlock) wide_inset_kernel(int negate, const uint64_t *l0, const uint64_t *l1, const uint64_t *l2,
@@ -130,7 +131,6 @@ __global__ void __launch_bounds__(kBlock) wide_inset_kernel(int negate, const ui
             uint64_t x[L];
 #pragma unroll
             for (int l = 0; l < L; l++) x[l] = limb[l][row];
-            x[0] ^= 1ull << 63;
             uint32_t lo = 0, hi = n_keys;
             bool found = false;
             while (lo < hi) {
@@ -158,11 +158,78 @@ __global__ void __launch_bounds__(kBlock) wide_inset_kernel(int negate, const ui
     }
 }
 
+// Round 4: the set's first compared limb in LDS (<= 4096 members): a branch-free binary search there, the other limbs of the members
+// that share it compared from the L2; four groups of 64 rows per wave iteration.  Membership needs no value order, so the set is
+// sorted -- and the limbs are compared -- LEAST significant limb first: that limb tells members apart where the top limbs of
+// small 128- / 256-bit values are all zero (the callers pass the limb columns in that order: knox_abi.cpp knox_match_wide_set).
+template <int L>
+__global__ void __launch_bounds__(kBlock) wide_inset_prefix_kernel(int negate, const uint64_t *l0, const uint64_t *l1, const uint64_t *l2,
+                                                                   const uint64_t *l3, uint64_t n_rows, const uint64_t *keys, uint32_t n_keys,
+                                                                   uint8_t *bits, const uint8_t *mask) {
+    constexpr int kG = 4;
+    __shared__ uint64_t spre[4096];
+    const uint64_t *limb[4] = {l0, l1, l2, l3};
+    uint32_t pow2 = 1;
+    while (pow2 < n_keys) pow2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < pow2; i += kBlock) spre[i] = i < n_keys ? keys[(uint64_t)i * L] : ~0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves_total = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t ngroups = (n_rows + 63) >> 6;
+    for (uint64_t g0 = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kG; g0 < ngroups; g0 += nwaves_total * kG) {
+        uint64_t x[kG][L];
+#pragma unroll
+        for (int k = 0; k < kG; k++) {
+            const uint64_t row = ((g0 + k) << 6) + lane;
+#pragma unroll
+            for (int l = 0; l < L; l++) x[k][l] = row < n_rows ? limb[l][row] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < kG; k++) {
+            if (g0 + k >= ngroups) break;  // wave uniform
+            const uint64_t row = ((g0 + k) << 6) + lane;
+            bool m = false;
+            if (row < n_rows) {
+                uint32_t pos = 0;          // first member whose first limb is >= the row's
+                for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += spre[pos + step - 1] < x[k][0] ? step : 0u;
+                bool found = false;
+                while (pos < n_keys && spre[pos] == x[k][0]) {
+                    const uint64_t *kk = keys + (uint64_t)pos * L;
+                    bool eq = true;
+#pragma unroll
+                    for (int l = 1; l < L; l++) eq = eq && kk[l] == x[k][l];
+                    if (eq) { found = true; break; }
+                    pos++;
+                }
+                m = negate ? !found : found;
+            }
+            const uint64_t ballot = __ballot(m);
+            if (lane < 8) {
+                const uint64_t r0 = ((g0 + k) << 6) + 8 * (uint64_t)lane;
+                if (r0 < n_rows) {
+                    uint8_t byte = (uint8_t)(ballot >> (8 * lane));
+                    const uint64_t bi = r0 >> 3;
+                    if (mask != nullptr) byte &= mask[bi];
+                    if (byte) bits[bi] |= byte;
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_wide_inset(hipStream_t s, int n_limbs, bool negate, const uint64_t *const *limbs, uint64_t n_rows, const uint64_t *keys,
                              uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
     if (n_rows == 0) return hipSuccess;
     uint64_t g = (n_rows + kBlock - 1) / kBlock;
     if (g > 2048 * 4) g = 2048 * 4;
+    const char *form = getenv("KNOX_WIDE_IN_FORM");
+    if (n_keys <= 4096 && !(form && !strcmp(form, "general"))) {
+        uint64_t gp = (n_rows + (uint64_t)kBlock * 4 - 1) / ((uint64_t)kBlock * 4);
+        if (gp > 2048 * 4) gp = 2048 * 4;
+        if (n_limbs == 2) KNOX_LAUNCH(wide_inset_prefix_kernel<2>, (int)gp, negate ? 1 : 0, limbs[0], limbs[1], nullptr, nullptr, n_rows, keys, n_keys, bits, mask);
+        if (n_limbs == 4) KNOX_LAUNCH(wide_inset_prefix_kernel<4>, (int)gp, negate ? 1 : 0, limbs[0], limbs[1], limbs[2], limbs[3], n_rows, keys, n_keys, bits, mask);
+        return hipErrorInvalidValue;
+    }
     if (n_limbs == 2) KNOX_LAUNCH(wide_inset_kernel<2>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], nullptr, nullptr, n_rows, keys, n_keys, bits, mask);
     if (n_limbs == 4) KNOX_LAUNCH(wide_inset_kernel<4>, (int)g, negate ? 1 : 0, limbs[0], limbs[1], limbs[2], limbs[3], n_rows, keys, n_keys, bits, mask);
     return hipErrorInvalidValue;

@@ -101,9 +101,15 @@ def test_wide_extremes_and_errors(ctx):
         ctx.match_wide(cols, FilterMode.In, [0, 0])
 
 
+@pytest.mark.parametrize("form", ["", "general"])
 @pytest.mark.parametrize("nl", [2, 4])
-def test_wide_in_not_in(ctx, nl):
-    """i128 / i256 InSet / NotInSet matchers (match_i128.go:318-430): membership, bits.Set semantics, mask"""
+def test_wide_in_not_in(ctx, nl, form, monkeypatch):
+    """i128 / i256 InSet / NotInSet matchers (match_i128.go:318-430): membership, bits.Set semantics, mask -- through the prefix
+    search in LDS (the default up to 4096 members) and through the full-compare binary search (KNOX_WIDE_IN_FORM=general)"""
+    if form:
+        monkeypatch.setenv("KNOX_WIDE_IN_FORM", form)
+    else:
+        monkeypatch.delenv("KNOX_WIDE_IN_FORM", raising=False)
     rng = np.random.default_rng(60 + nl)
     n = 5000 + 3
     limbs = [rng.integers(0, 3, size=n).astype(np.uint64) for _ in range(nl)]
