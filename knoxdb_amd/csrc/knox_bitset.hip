@@ -591,13 +591,16 @@ __global__ void __launch_bounds__(kBlock) inset_kernel(uint32_t flavor, int nega
 // flight, K rows per load -- and the lookup depends on the set:
 //   1- / 2-byte columns    a 65 536-bit membership bitmap in LDS (built per workgroup from the keys): one bit test per row, any set size
 //   up to 8 keys           the keys in turn from scalar registers against all of the lane's rows (one compare per row and key)
-//   up to 4096 keys        the sorted keys in LDS, padded to a power of two: a branch-free binary search, the rows of a lane interleaved
+//   up to 4096 keys        the sorted keys in LDS under radix buckets (top bits of key - smallest member): a row searches its bucket only
 //   larger sets            every stride-th key as one of <= 4096 pivots in LDS: twelve steps there, the last log2(stride) through the L2
 // Result bits leave as 32-bit words (the DPP word assembly of the scans), OR-ed into the caller's bits as before.  The rows behind
 // the last whole tile go through the kernel above.
-constexpr uint32_t kInsetRegKeys = 8, kInsetLdsKeys = 4096;
+constexpr uint32_t kInsetRegKeys = 8, kInsetBranchFree = 256, kInsetLdsKeys = 4096;
 
-template <int W>
+// TIER (the host picks it from the set's size, one instantiation each so that no lookup pays for another's registers and branches):
+// 0 = bitmap (1- / 2-byte columns) or scalar keys (<= 8), 1 = branch-free binary search in LDS (<= 256), 2 = radix buckets in LDS
+// (<= 4096), 3 = pivots in LDS + the L2
+template <int W, int TIER>
 __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int negate, const void *col, uint64_t n_tiles, const uint64_t *keys,
                                                             uint32_t n_keys, uint32_t *bits32, const uint32_t *mask32) {
     using U = typename WT<W>::U;
@@ -605,10 +608,12 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
     constexpr int G = 32 / K;
     constexpr int RPL = 64 * K;
     constexpr uint64_t WAVE_ROWS = (uint64_t)RPL * kUnroll;
-    __shared__ uint64_t skeys[W >= 4 ? kInsetLdsKeys : 1];
+    __shared__ uint64_t skeys[(W >= 4 && TIER >= 1) ? kInsetLdsKeys : 1];
+    __shared__ uint16_t bstart[(W >= 4 && TIER == 2) ? kInsetLdsKeys + 2 : 1];   // radix buckets over the sorted keys (see the LDS tier below)
     __shared__ uint32_t sbm[W <= 2 ? 2048 : 1];
     const int lane = threadIdx.x & 63;
-    uint32_t pow2 = 1, stride = 1, n_piv = 0;
+    uint32_t pow2 = 1, stride = 1, n_piv = 0, b_shift = 0;
+    uint64_t k_min = 0;
     while (pow2 < n_keys) pow2 <<= 1;
     if constexpr (W <= 2) {
         for (int i = threadIdx.x; i < 2048; i += kBlock) sbm[i] = 0;
@@ -618,10 +623,29 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
             if (k < 65536) atomicOr(&sbm[k >> 5], 1u << (k & 31));
         }
         __syncthreads();
-    } else if (n_keys > kInsetRegKeys && n_keys <= kInsetLdsKeys) {
+    } else if constexpr (TIER == 1 || TIER == 2) {
         for (uint32_t i = threadIdx.x; i < pow2; i += kBlock) skeys[i] = i < n_keys ? keys[i] : ~0ull;
         __syncthreads();
-    } else if (n_keys > kInsetLdsKeys) {
+      if constexpr (TIER == 2) {
+        // buckets by the top bits of (key - smallest member): bstart[b] = first member of bucket b.  A row reads its bucket's two
+        // bounds and searches between them -- one or two members when the set is spread evenly, the whole binary search at
+        // worst -- instead of log2(n) steps over the whole set (the LDS tier was bound by exactly those reads)
+        k_min = skeys[0];
+        const uint64_t range = skeys[n_keys - 1] - k_min;
+        b_shift = 0;
+        while ((range >> b_shift) >= (uint64_t)pow2) b_shift++;
+        for (uint32_t b = threadIdx.x; b <= pow2; b += kBlock) {
+            const uint64_t first = ((uint64_t)b << b_shift);         // the bucket's first offset; b == pow2: behind the last member
+            uint32_t lo = 0, hi = n_keys;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (skeys[mid] - k_min < first) lo = mid + 1; else hi = mid;
+            }
+            bstart[b] = (uint16_t)(b == pow2 ? n_keys : lo);
+        }
+        __syncthreads();
+      }
+    } else if constexpr (TIER == 3) {
         // every stride-th key as a pivot: the search runs its first 12 steps in LDS and only the last log2(stride) through the L2
         stride = (n_keys + kInsetLdsKeys - 1) / kInsetLdsKeys;
         n_piv = (n_keys + stride - 1) / stride;
@@ -660,7 +684,7 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
                     q[u] |= ((sbm[k >> 5] >> (k & 31)) & 1u) << j;
                 }
             }
-        } else if (n_keys <= kInsetRegKeys) {  // workgroup uniform
+        } else if constexpr (TIER == 0) {
             U ek[kUnroll][K];
             uint32_t nanq[kUnroll] = {0, 0, 0, 0};
 #pragma unroll
@@ -692,10 +716,23 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
                     bool nan_;
                     const uint64_t key = key_of(elem<W>(r[u], j), nan_);
                     bool found;
-                    if (n_keys <= kInsetLdsKeys) {
+                    if constexpr (TIER == 1) {                               // few steps: the branch-free search costs less than the bucket's two bounds and a divergent loop (measured: 16 keys 0.54 against 0.97 ms, 64 keys 0.66 against 0.83; 1024 keys 1.30 against 0.93)
                         uint32_t pos = 0;
                         for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += skeys[pos + step - 1] < key ? step : 0u;
                         found = pos < n_keys && skeys[pos] == key;
+                    } else if constexpr (TIER == 2) {
+                        const uint64_t off = key - k_min;                    // below the smallest member: wraps far above every bucket
+                        const uint64_t b = off >> b_shift;
+                        found = false;
+                        if (b < (uint64_t)pow2) {
+                            uint32_t lo = bstart[b], hi = bstart[b + 1];
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                const uint64_t km = skeys[mid];
+                                if (km == key) { found = true; break; }
+                                if (km < key) lo = mid + 1; else hi = mid;
+                            }
+                        }
                     } else {
                         uint32_t pos = 0;                                    // first pivot >= key
                         for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += skeys[pos + step - 1] < key ? step : 0u;
@@ -739,13 +776,26 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
     if (n_tiles) {
         uint64_t g = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         if (g > 256 * 8) g = 256 * 8;
+        const int tier = width <= 2 || n_keys <= kInsetRegKeys ? 0 : n_keys <= kInsetBranchFree ? 1 : n_keys <= kInsetLdsKeys ? 2 : 3;
+#define KNOX_INSET_T(W, T)                                                                                                                      \
+    hipLaunchKernelGGL((inset_tile_kernel<W, T>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, \
+                       (uint32_t *)bits, (const uint32_t *)mask)
+#define KNOX_INSET_W(W)                                                                        \
+    do {                                                                                       \
+        if (tier == 0) KNOX_INSET_T(W, 0);                                                     \
+        else if (tier == 1) KNOX_INSET_T(W, 1);                                                \
+        else if (tier == 2) KNOX_INSET_T(W, 2);                                                \
+        else KNOX_INSET_T(W, 3);                                                               \
+    } while (0)
         switch (width) {
-        case 8: hipLaunchKernelGGL((inset_tile_kernel<8>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
-        case 4: hipLaunchKernelGGL((inset_tile_kernel<4>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
-        case 2: hipLaunchKernelGGL((inset_tile_kernel<2>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
-        case 1: hipLaunchKernelGGL((inset_tile_kernel<1>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, (uint32_t *)bits, (const uint32_t *)mask); break;
+        case 8: KNOX_INSET_W(8); break;
+        case 4: KNOX_INSET_W(4); break;
+        case 2: KNOX_INSET_T(2, 0); break;
+        case 1: KNOX_INSET_T(1, 0); break;
         default: return hipErrorInvalidValue;
         }
+#undef KNOX_INSET_W
+#undef KNOX_INSET_T
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
