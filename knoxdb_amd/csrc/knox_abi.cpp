@@ -1862,18 +1862,42 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
             std::sort(keys.begin(), keys.end());
             keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
             ctx->inset_dtype = -1;   // not valid while it is being replaced
-            int rc = ensure(ctx, ctx->inset_keys, keys.size() * 8 + 16);
+            // large sets: radix buckets over the sorted keys (top bits of key - smallest member), two or three dependent L2 loads per
+            // row instead of a 16-step search (knox_bitset.hip)
+            std::vector<uint32_t> gstart;
+            uint32_t nb = 0, shift = 0;
+            if (keys.size() > 4096) {
+                nb = 1;
+                while (nb < keys.size() && nb < (1u << 24)) nb <<= 1;
+                const uint64_t range = keys.back() - keys.front();
+                while ((range >> shift) >= (uint64_t)nb) shift++;
+                gstart.assign((size_t)nb + 1, (uint32_t)keys.size());
+                size_t i = 0;
+                for (uint32_t b = 0; b <= nb; b++) {    // gstart[b] = first key whose bucket is >= b
+                    while (i < keys.size() && ((keys[i] - keys.front()) >> shift) < (uint64_t)b) i++;
+                    gstart[b] = (uint32_t)i;
+                }
+            }
+            const size_t goff = (keys.size() * 8 + 255) & ~(size_t)255;
+            int rc = ensure(ctx, ctx->inset_keys, goff + gstart.size() * 4 + 16);
             if (rc) return rc;
             if (!keys.empty()) {
                 HIPCHK(ctx, hipMemcpyAsync(ctx->inset_keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vector not retained
+                if (!gstart.empty())
+                    HIPCHK(ctx, hipMemcpyAsync((char *)ctx->inset_keys.p + goff, gstart.data(), gstart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors not retained
             }
+            ctx->inset_gstart_off = gstart.empty() ? 0 : goff;
+            ctx->inset_buckets = nb;
+            ctx->inset_shift = shift;
             ctx->inset_raw.assign(p.val, p.val + p.val_len);
             ctx->inset_n = keys.size();
             ctx->inset_dtype = col->dtype;
         }
+        const uint32_t *gst = ctx->inset_gstart_off ? (const uint32_t *)((const char *)ctx->inset_keys.p + ctx->inset_gstart_off) : nullptr;
         hipError_t e = launch_inset(ctx->stream, col->width, dtype_flavor(col->dtype), p.op == KNOX_NOTIN, col->dev, n_rows,
-                                    (const uint64_t *)ctx->inset_keys.p, (uint32_t)ctx->inset_n, (uint8_t *)bits, nullptr);
+                                    (const uint64_t *)ctx->inset_keys.p, (uint32_t)ctx->inset_n, gst, ctx->inset_buckets, ctx->inset_shift,
+                                    (uint8_t *)bits, nullptr);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return KNOX_E_HIP;

@@ -592,7 +592,8 @@ __global__ void __launch_bounds__(kBlock) inset_kernel(uint32_t flavor, int nega
 //   1- / 2-byte columns    a 65 536-bit membership bitmap in LDS (built per workgroup from the keys): one bit test per row, any set size
 //   up to 8 keys           the keys in turn from scalar registers against all of the lane's rows (one compare per row and key)
 //   up to 4096 keys        the sorted keys in LDS under radix buckets (top bits of key - smallest member): a row searches its bucket only
-//   larger sets            every stride-th key as one of <= 4096 pivots in LDS: twelve steps there, the last log2(stride) through the L2
+//   larger sets            the host's radix buckets over the whole set: bounds and members through the L2, two or three dependent loads
+//                          (without a bucket table from the caller: the row-per-lane kernel)
 // Result bits leave as 32-bit words (the DPP word assembly of the scans), OR-ed into the caller's bits as before.  The rows behind
 // the last whole tile go through the kernel above.
 constexpr uint32_t kInsetRegKeys = 8, kInsetBranchFree = 256, kInsetLdsKeys = 4096;
@@ -602,7 +603,8 @@ constexpr uint32_t kInsetRegKeys = 8, kInsetBranchFree = 256, kInsetLdsKeys = 40
 // (<= 4096), 3 = pivots in LDS + the L2
 template <int W, int TIER>
 __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int negate, const void *col, uint64_t n_tiles, const uint64_t *keys,
-                                                            uint32_t n_keys, uint32_t *bits32, const uint32_t *mask32) {
+                                                            uint32_t n_keys, const uint32_t *gstart, uint32_t g_buckets, uint32_t g_shift,
+                                                            uint32_t *bits32, const uint32_t *mask32) {
     using U = typename WT<W>::U;
     constexpr int K = WT<W>::K;
     constexpr int G = 32 / K;
@@ -612,7 +614,7 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
     __shared__ uint16_t bstart[(W >= 4 && TIER == 2) ? kInsetLdsKeys + 2 : 1];   // radix buckets over the sorted keys (see the LDS tier below)
     __shared__ uint32_t sbm[W <= 2 ? 2048 : 1];
     const int lane = threadIdx.x & 63;
-    uint32_t pow2 = 1, stride = 1, n_piv = 0, b_shift = 0;
+    uint32_t pow2 = 1, b_shift = 0;
     uint64_t k_min = 0;
     while (pow2 < n_keys) pow2 <<= 1;
     if constexpr (W <= 2) {
@@ -646,13 +648,7 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
         __syncthreads();
       }
     } else if constexpr (TIER == 3) {
-        // every stride-th key as a pivot: the search runs its first 12 steps in LDS and only the last log2(stride) through the L2
-        stride = (n_keys + kInsetLdsKeys - 1) / kInsetLdsKeys;
-        n_piv = (n_keys + stride - 1) / stride;
-        pow2 = 1;
-        while (pow2 < n_piv) pow2 <<= 1;
-        for (uint32_t i = threadIdx.x; i < pow2; i += kBlock) skeys[i] = i < n_piv ? keys[(uint64_t)i * stride] : ~0ull;
-        __syncthreads();
+        k_min = keys[0];
     }
     const uint64_t wave0 = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * kWavesPerBlock;
     for (uint64_t t = wave0; t < n_tiles; t += n_waves) {
@@ -733,17 +729,17 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
                                 if (km < key) lo = mid + 1; else hi = mid;
                             }
                         }
-                    } else {
-                        uint32_t pos = 0;                                    // first pivot >= key
-                        for (uint32_t step = pow2 >> 1; step >= 1; step >>= 1) pos += skeys[pos + step - 1] < key ? step : 0u;
-                        found = pos < n_piv && skeys[pos] == key;
-                        if (!found && pos > 0) {                             // strictly between pivot pos - 1 and pivot pos
-                            uint32_t lo = (pos - 1) * stride + 1, hi = pos * stride < n_keys ? pos * stride : n_keys;
+                    } else {                                                 // the host's radix buckets over the whole set, bounds and members through the L2
+                        const uint64_t b = (key - k_min) >> g_shift;
+                        found = false;
+                        if (b < (uint64_t)g_buckets) {
+                            uint32_t lo = gstart[b], hi = gstart[b + 1];
                             while (lo < hi) {
                                 const uint32_t mid = (lo + hi) >> 1;
-                                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                                const uint64_t km = keys[mid];
+                                if (km == key) { found = true; break; }
+                                if (km < key) lo = mid + 1; else hi = mid;
                             }
-                            found = lo < n_keys && keys[lo] == key;
                         }
                     }
                     q[u] |= ((found && !nan_) ? 1u : 0u) << j;
@@ -764,8 +760,11 @@ __global__ void __launch_bounds__(kBlock) inset_tile_kernel(uint32_t flavor, int
     }
 }
 
+// gstart (nullable): the host's radix buckets over a large set -- gstart[b] = first member with (member - keys[0]) >> g_shift >= b,
+// g_buckets + 1 entries
 hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
-                        const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask) {
+                        const uint64_t *keys, uint32_t n_keys, const uint32_t *gstart, uint32_t g_buckets, uint32_t g_shift, uint8_t *bits,
+                        const uint8_t *mask) {
     if (n_rows == 0) return hipSuccess;
     // whole tiles through the streaming kernel (KNOX_INSET_FORM=rows pins the row-per-lane kernel: measurements, tests); the rest, and
     // columns or bitsets that are not 16- / 4-byte aligned, through the row-per-lane kernel
@@ -773,13 +772,14 @@ hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, 
     const uint64_t wave_rows = (uint64_t)64 * (16 / (uint64_t)width) * kUnroll;
     uint64_t n_tiles = n_rows / wave_rows;
     if ((form && !strcmp(form, "rows")) || ((uintptr_t)col & 15) || ((uintptr_t)bits & 3) || ((uintptr_t)mask & 3)) n_tiles = 0;
+    if (width >= 4 && n_keys > kInsetLdsKeys && gstart == nullptr) n_tiles = 0;
     if (n_tiles) {
         uint64_t g = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         if (g > 256 * 8) g = 256 * 8;
         const int tier = width <= 2 || n_keys <= kInsetRegKeys ? 0 : n_keys <= kInsetBranchFree ? 1 : n_keys <= kInsetLdsKeys ? 2 : 3;
 #define KNOX_INSET_T(W, T)                                                                                                                      \
     hipLaunchKernelGGL((inset_tile_kernel<W, T>), dim3((unsigned)g), dim3(kBlock), 0, s, flavor, negate ? 1 : 0, col, n_tiles, keys, n_keys, \
-                       (uint32_t *)bits, (const uint32_t *)mask)
+                       gstart, g_buckets, g_shift, (uint32_t *)bits, (const uint32_t *)mask)
 #define KNOX_INSET_W(W)                                                                        \
     do {                                                                                       \
         if (tier == 0) KNOX_INSET_T(W, 0);                                                     \

@@ -166,6 +166,8 @@ struct knox_ctx {
     std::vector<uint8_t> inset_raw;   // the caller's members as given: compared byte for byte before the prepared set is reused
     size_t inset_n = 0;
     int inset_dtype = -1;
+    size_t inset_gstart_off = 0;      // byte offset of the radix bucket table behind the keys (0: none)
+    uint32_t inset_buckets = 0, inset_shift = 0;
     // ring of pinned result mirrors: up to kResRing scans may be in flight (software
     // pipelining: enqueue scan i+1 before collecting scan i keeps the device busy)
     struct ResSlot {

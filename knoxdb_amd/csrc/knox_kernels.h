@@ -233,7 +233,7 @@ hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const
 hipError_t launch_range_set(hipStream_t s, int width, bool is_signed, const void *mins, const void *maxs, uint64_t n_rows, const uint64_t *keys,
                             uint32_t n_keys, uint64_t *bits, const uint64_t *mask);
 hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
-                        const uint64_t *keys, uint32_t n_keys, uint8_t *bits, const uint8_t *mask);
+                        const uint64_t *keys, uint32_t n_keys, const uint32_t *gstart, uint32_t g_buckets, uint32_t g_shift, uint8_t *bits, const uint8_t *mask);
 
 // bytes IN / NOT IN: the set sorted + unique in StringPool form (set_ptr[i] = off << 32 | len into set_buf)
 hipError_t launch_bytes_inset(hipStream_t s, bool negate, const BytesView &v, const uint64_t *set_ptr, uint32_t n_set,
