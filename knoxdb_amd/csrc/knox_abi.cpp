@@ -127,6 +127,7 @@ KNOX_API int knox_ctx_close(knox_ctx *ctx) {
         if (ctx->cmp_res) { hipHostFree(ctx->cmp_res); ctx->cmp_res = nullptr; }
         if (ctx->bloom_flags) { hipHostFree(ctx->bloom_flags); ctx->bloom_flags = nullptr; }
         if (r.h_packs) hipHostFree(r.h_packs);
+        if (r.h_skip) hipHostFree(r.h_skip);
         if (r.done) hipEventDestroy(r.done);
     }
     for (int i = 0; i < 2; i++) {
@@ -2007,10 +2008,13 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         const size_t live_off = (n_packs + 15) & ~(size_t)15;
         rc = ensure(ctx, ctx->pack_skip, live_off + live.size() * 4 + 16);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->pack_skip.p, pack_skip, n_packs, hipMemcpyHostToDevice, ctx->stream));
-        if (!live.empty())
-            HIPCHK(ctx, hipMemcpyAsync((char *)ctx->pack_skip.p + live_off, live.data(), live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are not retained
+        // through the slot's page-locked staging: one copy, no stream synchronisation (the caller's array and `live` are not retained,
+        // the slot is -- until this scan is collected)
+        rc = ensure_host(ctx, slot.h_skip, slot.h_skip_cap, live_off + live.size() * 4 + 16);
+        if (rc) return rc;
+        memcpy(slot.h_skip, pack_skip, n_packs);
+        if (!live.empty()) memcpy((char *)slot.h_skip + live_off, live.data(), live.size() * 4);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pack_skip.p, slot.h_skip, live_off + live.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         skip.d_skip = (const uint8_t *)ctx->pack_skip.p;
         skip.d_live = (const uint32_t *)((const char *)ctx->pack_skip.p + live_off);
         skip.n_live = (uint32_t)live.size();

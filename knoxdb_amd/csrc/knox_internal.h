@@ -175,6 +175,8 @@ struct knox_ctx {
         size_t h_res_cap = 0;
         void *h_packs = nullptr;
         size_t h_packs_cap = 0;
+        void *h_skip = nullptr;   // page-locked copy of the caller's pack_skip bytes + the live-pack list: the H2D copy needs no
+        size_t h_skip_cap = 0;    // stream synchronisation (the slot outlives the scan), which a pruned point lookup would spend 30 us on
         hipEvent_t done = nullptr;
         int agg_slot[16];
         int n_aggs = 0;
