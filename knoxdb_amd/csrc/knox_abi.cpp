@@ -1631,21 +1631,8 @@ static int run_fused(knox_ctx *ctx, int width, const LeafHost *lh, const knox_co
             a.n_tiles = (uint64_t)skip->n_live << sh;
             skip->used = true;
             if (bits) {
-                size_t runs = 0;
-                for (size_t p = 0; p < skip->n_packs; p++)
-                    if (skip->h_skip[p] && (p == 0 || !skip->h_skip[p - 1])) runs++;
-                const size_t pack_bytes = pack_rows >> 3;
-                if (runs > 16) {
-                    HIPCHK(ctx, hipMemsetAsync(bits, 0, skip->n_packs * pack_bytes, ctx->stream));
-                } else {
-                    for (size_t p = 0; p < skip->n_packs;) {
-                        if (!skip->h_skip[p]) { p++; continue; }
-                        size_t e = p;
-                        while (e < skip->n_packs && skip->h_skip[e]) e++;
-                        HIPCHK(ctx, hipMemsetAsync((uint8_t *)bits + p * pack_bytes, 0, (e - p) * pack_bytes, ctx->stream));
-                        p = e;
-                    }
-                }
+                const hipError_t ze = launch_zero_pruned(ctx->stream, (uint8_t *)bits, skip->d_skip, (uint32_t)skip->n_packs, pack_rows, n_rows);
+                if (ze != hipSuccess) { ctx->last_hip = (int)ze; return KNOX_E_HIP; }
             }
         }
     } else {
@@ -2159,15 +2146,8 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         if (pack_skip && n_packs) {
             // "pruned = no row matches": leaves that were evaluated everywhere (or a NOT-style combination over
             // untouched ranges) may have left bits inside pruned packs -- clear those ranges of the result
-            const size_t pack_bytes = pack_rows >> 3;
-            for (size_t p0 = 0; p0 < n_packs;) {
-                if (!pack_skip[p0]) { p0++; continue; }
-                size_t e = p0;
-                while (e < n_packs && pack_skip[e]) e++;
-                const size_t b0 = p0 * pack_bytes, b1 = std::min(e * pack_bytes, bits_bytes(n_rows));
-                HIPCHK(ctx, hipMemsetAsync((uint8_t *)bits + b0, 0, b1 - b0, ctx->stream));
-                p0 = e;
-            }
+            const hipError_t ze = launch_zero_pruned(ctx->stream, (uint8_t *)bits, skip.d_skip, (uint32_t)n_packs, pack_rows, n_rows);
+            if (ze != hipSuccess) { ctx->last_hip = (int)ze; return KNOX_E_HIP; }
             if (all_leaves_skipped) slot.rows_scanned = n_rows - rows_pruned;
         }
         // total count (slot 0 count word) from the final bitset
@@ -2201,7 +2181,8 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         hipError_t e = per_pack_tiles
                            ? launch_pack_counts(ctx->stream, (const uint32_t *)ctx->tile_counts.p, ctx->tc_grid, ctx->tc_rounds, per_pack_tiles,
                                                 n_packs, (int64_t *)(res + res_base))
-                           : launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)(res + res_base), n_packs);
+                           : launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, (int64_t *)(res + res_base), n_packs,
+                                                      (pack_skip && n_packs) ? skip.d_skip : nullptr);   // pruned packs hold no bit (the contract, kept above)
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         slot.has_pack_counts = true;
     }

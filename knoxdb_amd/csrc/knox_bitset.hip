@@ -385,10 +385,16 @@ hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bi
 }
 
 // per-segment popcount: one workgroup per segment (seg_bits multiple of 64)
+// skip (nullable): segments whose bits are known to be zero (the pruned packs of a scan) -- their count is 0 without a read: a
+// bloom-pruned point lookup counted the whole 128 MiB bitset of 2^30 rows for its five surviving packs (42 of its ~100 us)
 __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
-                                                              uint64_t seg_words, int64_t *counts, uint64_t n_seg) {
+                                                              uint64_t seg_words, int64_t *counts, uint64_t n_seg, const uint8_t *skip) {
     __shared__ uint64_t sm[kBlock / 64];
     for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        if (skip != nullptr && skip[seg]) {   // workgroup uniform
+            if (threadIdx.x == 0) counts[seg] = 0;
+            continue;
+        }
         const uint64_t w0 = seg * seg_words;
         uint64_t w1 = w0 + seg_words;
         if (w1 > nwords) w1 = nwords;
@@ -415,11 +421,11 @@ __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bi
 }
 
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
-                                    int64_t *counts, uint64_t n_seg) {
+                                    int64_t *counts, uint64_t n_seg, const uint8_t *skip) {
     if (n_seg == 0) return hipSuccess;
     const uint64_t nwords = (size_bits + 63) >> 6;
     uint64_t g = n_seg > 65535 ? 65535 : n_seg;
-    KNOX_LAUNCH(popcount_seg_kernel, (int)g, bits, nwords, size_bits, seg_bits >> 6, counts, n_seg);
+    KNOX_LAUNCH(popcount_seg_kernel, (int)g, bits, nwords, size_bits, seg_bits >> 6, counts, n_seg, skip);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,6 +535,43 @@ hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bit
     hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, nblocks, n_out);
     hipLaunchKernelGGL(idx_write_kernel, dim3((unsigned)nblocks), dim3(kBlock), 0, s, bits, nwords, size_bits, scratch, rows_out,
                        capacity);
+    return hipGetLastError();
+}
+
+// The bitset ranges of PRUNED packs cleared in one launch ("pruned = no row matches" is part of a scan's contract).  The runtime's
+// fill kernel behind hipMemsetAsync writes ~2 TB/s (profiles/r04_*: __amd_rocclr_fillBufferAligned), and a pruned scan issued up to
+// sixteen of them: zeroing the 128 MiB bitset of 2^30 rows took 60 of the ~100 us a bloom-pruned point lookup cost, four times
+// its scan kernel.  One workgroup per 16 KiB slice of a pack's range; slices of surviving packs return at once.
+__global__ void __launch_bounds__(kBlock) zero_pruned_kernel(uint8_t *bits, const uint8_t *skip, uint32_t n_packs, uint64_t pack_bytes,
+                                                             uint64_t bits_bytes, uint32_t slices_per_pack) {
+    const uint32_t p = blockIdx.x / slices_per_pack, sl = blockIdx.x % slices_per_pack;
+    if (p >= n_packs || !skip[p]) return;
+    const uint64_t slice = (pack_bytes + slices_per_pack - 1) / slices_per_pack;
+    uint64_t b0 = (uint64_t)p * pack_bytes + (uint64_t)sl * slice;
+    uint64_t b1 = b0 + slice;
+    const uint64_t pend = (uint64_t)(p + 1) * pack_bytes;
+    if (b1 > pend) b1 = pend;
+    if (b1 > bits_bytes) b1 = bits_bytes;
+    if (b0 >= b1) return;
+    // pack_bytes is a multiple of 8 (pack_rows of 64), so b0 is: 16-byte stores in the aligned middle, 8-byte ones around it, single
+    // bytes only behind the last whole word of the bitset (nothing behind its (n + 7) / 8 bytes is touched)
+    const uint64_t w1 = b1 & ~7ull;
+    uint64_t a0 = (b0 + 15) & ~15ull, a1 = w1 & ~15ull;
+    if (a0 > a1) a0 = a1 = b0;
+    for (uint64_t b = b0 + 8ull * threadIdx.x; b < a0 && b < w1; b += 8ull * kBlock) *(uint64_t *)(bits + b) = 0ull;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (uint64_t b = a0 + 16ull * threadIdx.x; b < a1; b += 16ull * kBlock) __builtin_nontemporal_store(z, (u32x4 *)(bits + b));
+    for (uint64_t b = (a1 > b0 ? a1 : b0) + 8ull * threadIdx.x; b < w1; b += 8ull * kBlock) *(uint64_t *)(bits + b) = 0ull;
+    for (uint64_t b = (w1 > b0 ? w1 : b0) + threadIdx.x; b < b1; b += kBlock) bits[b] = 0;
+}
+
+hipError_t launch_zero_pruned(hipStream_t s, uint8_t *bits, const uint8_t *d_skip, uint32_t n_packs, uint64_t pack_rows, uint64_t n_rows) {
+    if (n_packs == 0) return hipSuccess;
+    const uint64_t pack_bytes = pack_rows >> 3, bits_bytes = (n_rows + 7) >> 3;
+    uint32_t slices = (uint32_t)((pack_bytes + 16383) / 16384);
+    if (slices == 0) slices = 1;
+    while ((uint64_t)n_packs * slices > 0x7fffffffull && slices > 1) slices >>= 1;
+    hipLaunchKernelGGL(zero_pruned_kernel, dim3(n_packs * slices), dim3(kBlock), 0, s, bits, d_skip, n_packs, pack_bytes, bits_bytes, slices);
     return hipGetLastError();
 }
 

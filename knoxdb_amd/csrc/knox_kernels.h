@@ -200,7 +200,7 @@ hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bi
 hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
                               uint64_t n_packs, int64_t *counts);
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
-                                    int64_t *counts, uint64_t n_seg);
+                                    int64_t *counts, uint64_t n_seg, const uint8_t *skip = nullptr);
 // bitset -> ascending uint32 row ids; scratch holds ceil(size/16384)+1 uint32 block offsets
 hipError_t launch_idx_scan(hipStream_t s, uint32_t *counts, uint64_t n, unsigned long long *n_out);  // in-place exclusive scan, one workgroup
 hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
@@ -232,6 +232,8 @@ hipError_t launch_bytes_match(hipStream_t s, int mode, const BytesView &v, const
 // numInSetMatcher.MatchRangeVectors: bits[row] = the sorted u64 key set holds a member in [uint64(min[row]), uint64(max[row])] (swapped if reversed), & mask
 hipError_t launch_range_set(hipStream_t s, int width, bool is_signed, const void *mins, const void *maxs, uint64_t n_rows, const uint64_t *keys,
                             uint32_t n_keys, uint64_t *bits, const uint64_t *mask);
+// zeroes the bitset ranges of the packs with skip[p] != 0 (pack_rows a multiple of 64), one launch
+hipError_t launch_zero_pruned(hipStream_t s, uint8_t *bits, const uint8_t *d_skip, uint32_t n_packs, uint64_t pack_rows, uint64_t n_rows);
 hipError_t launch_inset(hipStream_t s, int width, uint32_t flavor, bool negate, const void *col, uint64_t n_rows,
                         const uint64_t *keys, uint32_t n_keys, const uint32_t *gstart, uint32_t g_buckets, uint32_t g_shift, uint8_t *bits, const uint8_t *mask);
 
