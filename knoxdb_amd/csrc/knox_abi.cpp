@@ -2116,7 +2116,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
             if (p.kind == KNOX_NODE_LEAF) {
                 if (sp >= 7) return KNOX_E_UNSUPPORTED;
                 uint64_t *dst = slot_ptr(sp);
-                HIPCHK(ctx, hipMemsetAsync(dst, 0, bits_padded(n_rows) + 8, ctx->stream));
+                { const hipError_t ze = launch_zero_bytes(ctx->stream, dst, bits_padded(n_rows) + 8); if (ze != hipSuccess) { ctx->last_hip = (int)ze; return KNOX_E_HIP; } }
                 SkipPlan leaf_skip = skip;  // per leaf: `used` reports whether THIS leaf left the pruned packs unread
                 rc = run_leaf_to_bits(ctx, p, cols[p.col], n_rows, dst, grid, pack_skip ? &leaf_skip : nullptr);
                 if (rc) return rc;
@@ -2129,7 +2129,7 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
                     if (sp >= 7) return KNOX_E_UNSUPPORTED;
                     uint64_t *dst = slot_ptr(sp);
                     hipError_t e = p.kind == KNOX_NODE_AND ? launch_bitop(ctx->stream, BIT_ONE, dst, nullptr, n_rows, nullptr)
-                                                           : hipMemsetAsync(dst, 0, bits_padded(n_rows) + 8, ctx->stream);
+                                                           : launch_zero_bytes(ctx->stream, dst, bits_padded(n_rows) + 8);
                     if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
                     sp++;
                     continue;
@@ -2146,14 +2146,30 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
         if (pack_skip && n_packs) {
             // "pruned = no row matches": leaves that were evaluated everywhere (or a NOT-style combination over
             // untouched ranges) may have left bits inside pruned packs -- clear those ranges of the result
-            const hipError_t ze = launch_zero_pruned(ctx->stream, (uint8_t *)bits, skip.d_skip, (uint32_t)n_packs, pack_rows, n_rows);
-            if (ze != hipSuccess) { ctx->last_hip = (int)ze; return KNOX_E_HIP; }
+            // (every leaf wrote only the surviving packs of a cleared scratch bitset, and AND / OR keep zeros zero: nothing to clear then)
+            if (!all_leaves_skipped) {
+                const hipError_t ze = launch_zero_pruned(ctx->stream, (uint8_t *)bits, skip.d_skip, (uint32_t)n_packs, pack_rows, n_rows);
+                if (ze != hipSuccess) { ctx->last_hip = (int)ze; return KNOX_E_HIP; }
+            }
             if (all_leaves_skipped) slot.rows_scanned = n_rows - rows_pruned;
         }
-        // total count (slot 0 count word) from the final bitset
+        // total count (slot 0 count word) from the final bitset -- with pruned packs, from the surviving packs only and together with
+        // the per-pack counts (one pass over a few packs instead of two over the whole bitset)
         unsigned long long *d_cnt = (unsigned long long *)((int64_t *)((AggStateDev *)ctx->states.p + 16));
-        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-        hipError_t e = launch_popcount(ctx->stream, bits, n_rows, d_cnt);
+        hipError_t e = launch_zero_bytes(ctx->stream, d_cnt, 8);   // (the runtime's fill kernel takes 11 us for these 8 bytes)
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+        if (pack_skip && n_packs && pack_rows && !(pack_rows & 63)) {
+            int64_t *pc = (int64_t *)((char *)ctx->states.p + res_base);
+            if (!want_pack_counts) {
+                rc = ensure(ctx, ctx->pack_counts, n_packs * 8 + 64);
+                if (rc) return rc;
+                pc = (int64_t *)ctx->pack_counts.p;
+            }
+            e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, pc, n_packs, skip.d_skip, d_cnt);
+            packs_done = want_pack_counts;
+        } else {
+            e = launch_popcount(ctx->stream, bits, n_rows, d_cnt);
+        }
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         first_reduce_slot = 0;
     }

@@ -388,7 +388,8 @@ hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bi
 // skip (nullable): segments whose bits are known to be zero (the pruned packs of a scan) -- their count is 0 without a read: a
 // bloom-pruned point lookup counted the whole 128 MiB bitset of 2^30 rows for its five surviving packs (42 of its ~100 us)
 __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bits, uint64_t nwords, uint64_t size_bits,
-                                                              uint64_t seg_words, int64_t *counts, uint64_t n_seg, const uint8_t *skip) {
+                                                              uint64_t seg_words, int64_t *counts, uint64_t n_seg, const uint8_t *skip,
+                                                              unsigned long long *total) {
     __shared__ uint64_t sm[kBlock / 64];
     for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
         if (skip != nullptr && skip[seg]) {   // workgroup uniform
@@ -415,17 +416,43 @@ __global__ void __launch_bounds__(kBlock) popcount_seg_kernel(const uint64_t *bi
         for (int off = 32; off >= 1; off >>= 1) c += shfl_down_u64(c, off);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
         __syncthreads();
-        if (threadIdx.x == 0) counts[seg] = (int64_t)(sm[0] + sm[1] + sm[2] + sm[3]);
+        if (threadIdx.x == 0) {
+            const uint64_t c4 = sm[0] + sm[1] + sm[2] + sm[3];
+            counts[seg] = (int64_t)c4;
+            if (total != nullptr && c4) atomicAdd(total, (unsigned long long)c4);   // total (nullable): the bitset's popcount with the same pass
+        }
         __syncthreads();
     }
 }
 
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
-                                    int64_t *counts, uint64_t n_seg, const uint8_t *skip) {
+                                    int64_t *counts, uint64_t n_seg, const uint8_t *skip, unsigned long long *total) {
     if (n_seg == 0) return hipSuccess;
     const uint64_t nwords = (size_bits + 63) >> 6;
     uint64_t g = n_seg > 65535 ? 65535 : n_seg;
-    KNOX_LAUNCH(popcount_seg_kernel, (int)g, bits, nwords, size_bits, seg_bits >> 6, counts, n_seg, skip);
+    KNOX_LAUNCH(popcount_seg_kernel, (int)g, bits, nwords, size_bits, seg_bits >> 6, counts, n_seg, skip, total);
+}
+
+// bytes of device memory set to zero by one streaming kernel (16-byte nontemporal stores; ptr 8-byte aligned): the runtime's fill
+// kernel behind hipMemsetAsync writes ~2 TB/s, and the multi-pass plans clear a 128 MiB scratch bitset per leaf
+__global__ void __launch_bounds__(kBlock) zero_bytes_kernel(uint8_t *p, uint64_t bytes) {
+    const uint64_t head = ((16 - ((uintptr_t)p & 15)) & 15) < bytes ? ((16 - ((uintptr_t)p & 15)) & 15) : bytes;
+    const uint64_t nvec = (bytes - head) >> 4;
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x, nth = (uint64_t)gridDim.x * kBlock;
+    if (tid < head) p[tid] = 0;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4 *v = (u32x4 *)(p + head);
+    for (uint64_t i = tid; i < nvec; i += nth) __builtin_nontemporal_store(z, v + i);
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + tid < bytes) p[tail0 + tid] = 0;
+}
+
+hipError_t launch_zero_bytes(hipStream_t s, void *p, uint64_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    uint64_t g = (bytes / 16 + kBlock - 1) / kBlock;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g == 0) g = 1;
+    KNOX_LAUNCH(zero_bytes_kernel, (int)g, (uint8_t *)p, bytes);
 }
 
 // ---------------------------------------------------------------------------------------------

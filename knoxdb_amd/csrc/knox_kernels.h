@@ -200,7 +200,8 @@ hipError_t launch_popcount(hipStream_t s, const uint64_t *bits, uint64_t size_bi
 hipError_t launch_pack_counts(hipStream_t s, const uint32_t *tile_counts, uint32_t grid, uint32_t rounds, uint32_t tiles_per_pack,
                               uint64_t n_packs, int64_t *counts);
 hipError_t launch_popcount_segments(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint64_t seg_bits,
-                                    int64_t *counts, uint64_t n_seg, const uint8_t *skip = nullptr);
+                                    int64_t *counts, uint64_t n_seg, const uint8_t *skip = nullptr, unsigned long long *total = nullptr);
+hipError_t launch_zero_bytes(hipStream_t s, void *p, uint64_t bytes);
 // bitset -> ascending uint32 row ids; scratch holds ceil(size/16384)+1 uint32 block offsets
 hipError_t launch_idx_scan(hipStream_t s, uint32_t *counts, uint64_t n, unsigned long long *n_out);  // in-place exclusive scan, one workgroup
 hipError_t launch_indexes(hipStream_t s, const uint64_t *bits, uint64_t size_bits, uint32_t *scratch,
