@@ -168,7 +168,7 @@ static int reduce_buckets_dev(knox_ctx *ctx, const knox_col *time_col, const kno
     const bool check = !(flags & 1) && known < 0;
     if (known == 0 && !(flags & 1)) unsorted = 1;
     if (check) {
-        HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_flag, 4));
         hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         HIPCHK(ctx, hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -266,7 +266,7 @@ KNOX_API int knox_reduce_buckets_sequential(knox_ctx *ctx, const knox_col *time_
     if (known == 0 && !(flags & 1)) return KNOX_E_UNSUPPORTED;
     const bool check = !(flags & 1) && known < 0;
     if (check) {
-        HIPCHK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_flag, 4));
         hipError_t e = launch_sorted_check(ctx->stream, (const int64_t *)time_col->dev, n_rows, d_flag);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
     }
