@@ -1814,9 +1814,18 @@ static int run_leaf_to_bits(knox_ctx *ctx, const knox_pred &p, const knox_col *c
         const size_t off2 = ((size_t)p.val_len + 15) & ~(size_t)15;
         int rc = ensure(ctx, ctx->bytes_val, off2 + len2 + 16);
         if (rc) return rc;
-        if (p.val_len) HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, p.val, (size_t)p.val_len, hipMemcpyHostToDevice, ctx->stream));
-        if (len2) HIPCHK(ctx, hipMemcpyAsync((char *)ctx->bytes_val.p + off2, p.val2, len2, hipMemcpyHostToDevice, ctx->stream));
-        if (p.val_len || len2) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host values not retained
+        if (ctx->leaf_stage && ctx->leaf_stage_off + off2 + len2 <= ctx->leaf_stage_cap) {
+            // through the scan's page-locked staging: one copy, the host values need not outlive this call, no synchronisation
+            char *st = ctx->leaf_stage + ctx->leaf_stage_off;
+            if (p.val_len) memcpy(st, p.val, (size_t)p.val_len);
+            if (len2) memcpy(st + off2, p.val2, len2);
+            if (p.val_len || len2) HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, st, off2 + len2, hipMemcpyHostToDevice, ctx->stream));
+            ctx->leaf_stage_off += (off2 + len2 + 63) & ~(size_t)63;
+        } else {
+            if (p.val_len) HIPCHK(ctx, hipMemcpyAsync(ctx->bytes_val.p, p.val, (size_t)p.val_len, hipMemcpyHostToDevice, ctx->stream));
+            if (len2) HIPCHK(ctx, hipMemcpyAsync((char *)ctx->bytes_val.p + off2, p.val2, len2, hipMemcpyHostToDevice, ctx->stream));
+            if (p.val_len || len2) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host values not retained
+        }
         prof_mark(ctx, 0);  // the dominant kernel of a bytes-leaf plan: 8 B pointer + the value bytes per row
         hipError_t e = launch_bytes_match(ctx->stream, p.op, bytes_view(col, n_rows, skip), (const uint8_t *)ctx->bytes_val.p,
                                           (uint32_t)p.val_len, (const uint8_t *)ctx->bytes_val.p + off2, (uint32_t)len2, (uint8_t *)bits, nullptr,
@@ -1985,19 +1994,41 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
     if (rc) return rc;
     SkipPlan skip;
     uint64_t rows_pruned = 0;
+    // the slot's page-locked staging holds the skip list and, behind it, the value bytes of the bytes leaves (EQ / NE / ordered): their
+    // uploads need no stream synchronisation -- the callers' arrays are not retained, the slot is, until this scan is collected
+    struct StageGuard {
+        knox_ctx *c;
+        ~StageGuard() { c->leaf_stage = nullptr; }
+    } stage_guard{ctx};
+    size_t leaf_bytes = 0;
+    for (int l = 0; l < n_leaves; l++) {
+        const knox_pred &lp = nodes[leaf_nodes[l]];
+        if (cols[lp.col]->dtype == KNOX_BYTES && lp.op != KNOX_IN && lp.op != KNOX_NOTIN && lp.op != KNOX_REGEXP)
+            leaf_bytes += (((size_t)lp.val_len + 15) & ~(size_t)15) + (lp.op == KNOX_RANGE ? (size_t)lp.val2_len : 0) + 64;
+    }
+    if (leaf_bytes > ((size_t)1 << 20)) leaf_bytes = 0;   // huge values: the synchronising path
+    std::vector<uint32_t> live;
+    size_t skip_bytes = 0, live_off = 0;
     if (pack_skip && n_packs) {
-        std::vector<uint32_t> live;
         live.reserve(n_packs);
         for (size_t p = 0; p < n_packs; p++) {
             if (pack_skip[p]) rows_pruned += std::min(pack_rows, n_rows - p * pack_rows);
             else live.push_back((uint32_t)p);
         }
-        const size_t live_off = (n_packs + 15) & ~(size_t)15;
-        rc = ensure(ctx, ctx->pack_skip, live_off + live.size() * 4 + 16);
+        live_off = (n_packs + 15) & ~(size_t)15;
+        skip_bytes = (live_off + live.size() * 4 + 63) & ~(size_t)63;
+    }
+    if (skip_bytes + leaf_bytes) {
+        rc = ensure_host(ctx, slot.h_skip, slot.h_skip_cap, skip_bytes + leaf_bytes + 64);
         if (rc) return rc;
-        // through the slot's page-locked staging: one copy, no stream synchronisation (the caller's array and `live` are not retained,
-        // the slot is -- until this scan is collected)
-        rc = ensure_host(ctx, slot.h_skip, slot.h_skip_cap, live_off + live.size() * 4 + 16);
+        if (leaf_bytes) {
+            ctx->leaf_stage = (char *)slot.h_skip;
+            ctx->leaf_stage_off = skip_bytes;
+            ctx->leaf_stage_cap = skip_bytes + leaf_bytes;
+        }
+    }
+    if (pack_skip && n_packs) {
+        rc = ensure(ctx, ctx->pack_skip, live_off + live.size() * 4 + 16);
         if (rc) return rc;
         memcpy(slot.h_skip, pack_skip, n_packs);
         if (!live.empty()) memcpy((char *)slot.h_skip + live_off, live.data(), live.size() * 4);

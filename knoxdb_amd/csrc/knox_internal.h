@@ -163,6 +163,10 @@ struct knox_ctx {
     // the last numeric IN / NOT IN set as the device wants it (sorted unique order keys): a query runs the same set against every
     // run of its table, and sorting + uploading 64 Ki members took longer than matching 2^28 rows against them
     DevBuf inset_keys;
+    // while a scan is being enqueued: room in its result slot's page-locked staging for the leaves' value bytes (behind the skip list),
+    // so that their upload needs no stream synchronisation (knox_abi.cpp run_leaf_to_bits); null outside knox_scan_async
+    char *leaf_stage = nullptr;
+    size_t leaf_stage_off = 0, leaf_stage_cap = 0;
     std::vector<uint8_t> inset_raw;   // the caller's members as given: compared byte for byte before the prepared set is reused
     size_t inset_n = 0;
     int inset_dtype = -1;
