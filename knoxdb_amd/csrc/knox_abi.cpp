@@ -2184,19 +2184,19 @@ KNOX_API int knox_scan_async(knox_ctx *ctx, const knox_pred *nodes, int n_nodes,
             }
             if (all_leaves_skipped) slot.rows_scanned = n_rows - rows_pruned;
         }
-        // total count (slot 0 count word) from the final bitset -- with pruned packs, from the surviving packs only and together with
-        // the per-pack counts (one pass over a few packs instead of two over the whole bitset)
+        // total count (slot 0 count word) from the final bitset -- together with the per-pack counts when those are wanted or packs
+        // were pruned (then from the surviving packs only): one pass instead of two over the whole bitset
         unsigned long long *d_cnt = (unsigned long long *)((int64_t *)((AggStateDev *)ctx->states.p + 16));
         hipError_t e = launch_zero_bytes(ctx->stream, d_cnt, 8);   // (the runtime's fill kernel takes 11 us for these 8 bytes)
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-        if (pack_skip && n_packs && pack_rows && !(pack_rows & 63)) {
+        if ((pack_skip || want_pack_counts) && n_packs && pack_rows && !(pack_rows & 63)) {
             int64_t *pc = (int64_t *)((char *)ctx->states.p + res_base);
             if (!want_pack_counts) {
                 rc = ensure(ctx, ctx->pack_counts, n_packs * 8 + 64);
                 if (rc) return rc;
                 pc = (int64_t *)ctx->pack_counts.p;
             }
-            e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, pc, n_packs, skip.d_skip, d_cnt);
+            e = launch_popcount_segments(ctx->stream, bits, n_rows, pack_rows, pc, n_packs, pack_skip ? skip.d_skip : nullptr, d_cnt);
             packs_done = want_pack_counts;
         } else {
             e = launch_popcount(ctx->stream, bits, n_rows, d_cnt);
