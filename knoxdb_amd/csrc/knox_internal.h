@@ -165,6 +165,11 @@ struct knox_ctx {
     DevBuf inset_keys;
     // while a scan is being enqueued: room in its result slot's page-locked staging for the leaves' value bytes (behind the skip list),
     // so that their upload needs no stream synchronisation (knox_abi.cpp run_leaf_to_bits); null outside knox_scan_async
+    // knox_reduce_buckets_values -> reduce_windows: where Reducer.Value() per window goes when the finalize kernel can write it itself
+    void *win_values = nullptr;
+    uint8_t *win_seen = nullptr;
+    int win_func = 0;
+    bool win_values_done = false;
     char *leaf_stage = nullptr;
     size_t leaf_stage_off = 0, leaf_stage_cap = 0;
     std::vector<uint8_t> inset_raw;   // the caller's members as given: compared byte for byte before the prepared set is reused

@@ -165,7 +165,7 @@ hipError_t launch_bucket_reduce(hipStream_t s, int width, int grid, const ScanAr
 hipError_t launch_bucket_reduce_waves(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items);
 hipError_t launch_bucket_reduce_groups(hipStream_t s, int width, int grid, const ScanArgs &a, const BucketItem *items, uint32_t n_items, bool sums_only);
 hipError_t launch_bucket_finalize(hipStream_t s, int width, const AggPartial *partials, const uint32_t *item_start, uint32_t n_buckets,
-                                  const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out);
+                                  const void *agg_col, uint64_t row_base, int dtype, AggStateDev *state_out, int func = 0, void *values = nullptr, uint8_t *seen = nullptr);
 
 // var/std per window (second pass over the same work items); partials: 4 doubles per work item
 // group_rows != 0: the 16-lanes-per-window form (grid = workgroups of 16 windows; group_rows = the column's rows, the bitset's bound)

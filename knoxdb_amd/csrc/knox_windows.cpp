@@ -61,9 +61,14 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
                                        (const BucketItem *)(base + off_items), (uint32_t)n_items);
     else
         e = launch_bucket_reduce(ctx->stream, width, grid, a, (const BucketItem *)(base + off_items), (uint32_t)n_items);
-    if (e == hipSuccess)
+    if (e == hipSuccess) {
+        // values wanted and no var / std pass to come: the finalize kernel emits Value() itself and the states are never stored
+        const bool fuse_values = ctx->win_values != nullptr && !(flags & 2);
         e = launch_bucket_finalize(ctx->stream, width, a.partials, (const uint32_t *)(base + off_istart), (uint32_t)n_buckets, vals, row_base, dtype,
-                                   (AggStateDev *)(base + off_states));
+                                   fuse_values ? nullptr : (AggStateDev *)(base + off_states), ctx->win_func, fuse_values ? ctx->win_values : nullptr,
+                                   fuse_values ? ctx->win_seen : nullptr);
+        ctx->win_values_done = fuse_values && e == hipSuccess;
+    }
     if (e == hipSuccess && (flags & 2)) {
         // var/std: second pass over the same work items, each centred on its window's mean
         rc = ensure(ctx, ctx->mom_partials, (n_items + 1) * 4 * sizeof(double));
@@ -225,17 +230,25 @@ KNOX_API int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col,
     if (!values_view || !seen_view || func < KNOX_R_SUM || func > KNOX_R_COUNT) return KNOX_E_INVALID;
     if (func == KNOX_R_VAR || func == KNOX_R_STD) flags |= 2;
     const bool sums = func == KNOX_R_SUM || func == KNOX_R_COUNT || func == KNOX_R_MEAN || func == KNOX_R_VAR || func == KNOX_R_STD;
-    char *st = nullptr;
-    int rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, (flags & 0xffff) | kWindowsNoRowIds | (sums ? kWindowsSumsOnly : 0), &st);
-    if (rc) return rc;
+    if (!ctx || !value_col || n_buckets == 0 || n_buckets > (1u << 26)) return KNOX_E_INVALID;
     const size_t w = (size_t)value_col->width;
     const size_t off_seen = (n_buckets * w + 63) & ~(size_t)63, bytes = off_seen + n_buckets;
-    rc = ensure(ctx, ctx->pack_counts, bytes + 64);
+    int rc = ensure(ctx, ctx->pack_counts, bytes + 64);
     if (!rc) rc = ensure_host(ctx, ctx->h_view, ctx->h_view_cap, bytes);
     if (rc) return rc;
     char *d = (char *)ctx->pack_counts.p;
-    hipError_t e = launch_window_values(ctx->stream, (int)w, (const AggStateDev *)st, (uint32_t)n_buckets, func, d, (uint8_t *)d + off_seen);
-    if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    char *st = nullptr;
+    ctx->win_values = d;
+    ctx->win_seen = (uint8_t *)d + off_seen;
+    ctx->win_func = func;
+    ctx->win_values_done = false;
+    rc = reduce_buckets_dev(ctx, time_col, value_col, mask, t_from, step, n_buckets, 0, (flags & 0xffff) | kWindowsNoRowIds | (sums ? kWindowsSumsOnly : 0), &st);
+    ctx->win_values = nullptr;
+    if (rc) return rc;
+    if (!ctx->win_values_done) {
+        hipError_t e = launch_window_values(ctx->stream, (int)w, (const AggStateDev *)st, (uint32_t)n_buckets, func, d, (uint8_t *)d + off_seen);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+    }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_view, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *values_view = ctx->h_view;
