@@ -12,7 +12,9 @@
 #include <string.h>
 
 #if defined(__HIPCC__)
-#define KNOX_HD __host__ __device__
+// (always inlined in device code: called with a state that lives in registers -- as an out-of-line call the 144-byte state would be
+//  spilled to scratch memory to pass it by reference)
+#define KNOX_HD __host__ __device__ __attribute__((always_inline))
 #else
 #define KNOX_HD
 #endif
@@ -141,57 +143,68 @@ KNOX_HD inline uint64_t int_from_f64(int dtype, double v) {
 // *row = the row whose timestamp Time() would report.
 template <typename S>
 KNOX_HD inline int agg_value_bits(const S &st, int func, uint64_t *bits, int *seen, int64_t *row) {
+    // EVERY field is read here, unconditionally, and the branches below work on these copies: fields read inside the switch's cases
+    // are merged by the compiler into loads through a selected ADDRESS, which keeps a state that lives in registers --
+    // bucket_finalize_kernel's -- in scratch memory (found by tests/test_scan_shapes.py: ScratchSize 152)
     const int dtype = st.dtype;
+    const uint32_t flags = st.flags;
+    const int64_t count = st.count;
+    const uint64_t isum = st.isum;
+    const double fsum_hi = st.fsum_hi, fsum_lo = st.fsum_lo;
+    const uint64_t min_bits = st.min_bits, max_bits = st.max_bits, first_bits = st.first_bits, last_bits = st.last_bits;
+    const int64_t min_row = st.min_row, max_row = st.max_row, first_row = st.first_row, last_row = st.last_row;
+    const double m_dev_hi = st.m_dev_hi, m_dev_lo = st.m_dev_lo, m_sq_hi = st.m_sq_hi, m_sq_lo = st.m_sq_lo;
     const int w = width_of(dtype);
     if (w == 0) return -1;
     const bool isf = is_float(dtype);
-    const bool any = st.count > 0;
+    const bool any = count > 0;
     *seen = any ? 1 : 0;
-    *row = any ? st.first_row : -1;
+    *row = any ? first_row : -1;
     *bits = 0;
     if (!any) return 0;
     const uint64_t m = w == 8 ? ~0ull : ((1ull << (8 * w)) - 1);
     switch (func) {
     case 8:  // KNOX_R_COUNT: CountReducer counts in T (reducer.go:138-148)
-        *bits = isf ? float_bits(dtype, dtype == 9 ? (double)st.count : (double)(float)st.count) : ((uint64_t)st.count & m);
+        *bits = isf ? float_bits(dtype, dtype == 9 ? (double)count : (double)(float)count) : ((uint64_t)count & m);
         break;
     case 0:  // KNOX_R_SUM
-        *bits = isf ? float_bits(dtype, sum_value(st.fsum_hi, st.fsum_lo)) : (st.isum & m);  // wraps in T like Go
+        *bits = isf ? float_bits(dtype, sum_value(fsum_hi, fsum_lo)) : (isum & m);  // wraps in T like Go
         break;
     case 5: {  // KNOX_R_MEAN
-        const double mean = mean_value(st.fsum_hi, st.fsum_lo, st.count);
+        const double mean = mean_value(fsum_hi, fsum_lo, count);
         if (isf) *bits = float_bits(dtype, mean);
         else if (is_signed(dtype)) *bits = (uint64_t)(int64_t)mean & m;  // T(r.mean) truncates toward zero
         else *bits = (uint64_t)mean & m;
         break;
     }
     case 1:  // KNOX_R_FIRST
-        *bits = st.first_bits & m;
-        *row = st.first_row;
+        *bits = first_bits & m;
+        *row = first_row;
         break;
     case 2:  // KNOX_R_LAST
-        *bits = st.last_bits & m;
-        *row = st.last_row;
+        *bits = last_bits & m;
+        *row = last_row;
         break;
     case 3:    // KNOX_R_MIN
     case 4: {  // KNOX_R_MAX
         // a NaN first value is adopted and then sticks (reducer.go:256-296): r.v < NaN and r.v > NaN are false
-        const double f = isf ? value_as_f64(dtype, st.first_bits) : 0.0;
-        const bool mn = func == 3;
-        if ((isf && f != f) || (mn ? st.min_row : st.max_row) < 0) {
-            *bits = st.first_bits & m;
-            *row = st.first_row;
+        const double f = isf ? value_as_f64(dtype, first_bits) : 0.0;
+        const uint64_t xb = func == 3 ? min_bits : max_bits;
+        const int64_t xr = func == 3 ? min_row : max_row;
+        if ((isf && f != f) || xr < 0) {
+            *bits = first_bits & m;
+            *row = first_row;
             break;
         }
-        *bits = (mn ? st.min_bits : st.max_bits) & m;
-        *row = mn ? st.min_row : st.max_row;
+        *bits = xb & m;
+        *row = xr;
         break;
     }
     case 6:    // KNOX_R_VAR
     case 7: {  // KNOX_R_STD: VarReducer / StdReducer.Value (reducer.go:376-381, 416-421), NaN for n < 2
-        if (!(st.flags & 2u)) return -1;  // state carries no moments (knox_reduce_moments)
-        double v = var_value(st.m_sq_hi, st.m_sq_lo, st.m_dev_hi, st.m_dev_lo, st.count);
-        if (func == 7 && st.count >= 2) v = sqrt(v);
+        if (!(flags & 2u)) return -1;  // state carries no moments (knox_reduce_moments)
+        double v = var_value(m_sq_hi, m_sq_lo, m_dev_hi, m_dev_lo, count);
+        if (func == 7 && count >= 2) v = sqrt(v);
         *bits = isf ? float_bits(dtype, v) : (int_from_f64(dtype, v) & m);
         break;
     }
