@@ -464,3 +464,38 @@ def test_bytes_in_sets_prefix_search_and_general_form_agree(ctx, monkeypatch):
                 bits.free()
     monkeypatch.delenv("KNOX_BYTES_IN_FORM", raising=False)
     col.free()
+
+
+def test_bytes_ordered_modes_prefix_form_and_general_form_agree(ctx, monkeypatch):
+    """LT / LE / GT / GE / RANGE on bytes columns decide a row by its zero-padded 8-byte prefix and compare in full only on a tie
+    (knox_bytes.hip bytes_ord_kernel); KNOX_BYTES_ORD_FORM=general keeps the one-group-at-a-time kernel.  Values and rows that share
+    prefixes of exactly 8 and more bytes, rows that are proper prefixes of the value (and the other way round), zero bytes behind a
+    prefix, the empty string, rows shorter than 8 bytes"""
+    rng = np.random.default_rng(78)
+    n = 6 * 1024 + 77
+    stems = [b"", b"\x00", b"\x00\x00", b"a", b"ab", b"abcdefg", b"abcdefgh", b"abcdefgh\x00", b"abcdefgh\x00\x00", b"abcdefghi", b"abcdefghij" * 3,
+             b"\xff" * 7, b"\xff" * 8, b"\xff" * 9]
+    keys = stems + [bytes(rng.integers(0, 3, size=int(rng.integers(0, 14)), dtype=np.uint8)) for _ in range(300)]
+    vals = [keys[i] for i in rng.integers(0, len(keys), size=n)]
+    buf = np.frombuffer(b"".join(vals) + b"\x00" * 8, dtype=np.uint8)
+    lens = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    ptr = (offs << np.uint64(32)) | lens
+    col = ctx.upload_bytes(ptr, buf, 1024)
+    probes = stems + [b"abcdefgh\x01", b"b", bytes([1, 2, 0, 1])]
+    for a in probes:
+        for mode in (FilterMode.Lt, FilterMode.Le, FilterMode.Gt, FilterMode.Ge, FilterMode.Range):
+            b = probes[(probes.index(a) + 5) % len(probes)]
+            leaf = Leaf(0, mode, a, b) if mode == FilterMode.Range else Leaf(0, mode, a)
+            want = oracle_match(And(leaf), [(ptr, buf)], n)
+            for form in ("", "general"):
+                if form:
+                    monkeypatch.setenv("KNOX_BYTES_ORD_FORM", form)
+                else:
+                    monkeypatch.delenv("KNOX_BYTES_ORD_FORM", raising=False)
+                bits = ctx.bits(n)
+                ctx.scan(And(leaf), [col], bits_out=bits)
+                assert (bits.bytes(poison=32) == want).all(), (a, b, mode, form)
+                bits.free()
+    monkeypatch.delenv("KNOX_BYTES_ORD_FORM", raising=False)
+    col.free()
