@@ -196,13 +196,39 @@ __device__ __forceinline__ uint32_t bloom_tile_hashes(const H &hasher, uint64_t 
         // tags: the branches of XXH3 that need at most four 8-byte words) the rows' words are loaded eight rows at a time before any
         // arithmetic; the pools are allocated with 256 bytes of slack (knox_abi.cpp), so the first word of a short row may be read whole.
         uint64_t pr[kBinRowsPerThread];
-        bool fast = true;
+        bool fast = true, mid = true;   // every row <= 32 bytes / every row 33 ... 64 bytes
 #pragma unroll
         for (int i = 0; i < kBinRowsPerThread; i++) {
             const bool ok = (uint64_t)i * kBlock < left;
             pr[i] = hasher.ptr[ok ? r0 + (uint64_t)i * kBlock : r1 - 1];
             valid |= ok ? 1u << i : 0u;
             fast = fast && (uint32_t)pr[i] <= 32u;
+            mid = mid && ((uint32_t)pr[i] - 33u) <= 31u;
+        }
+        if (__all(mid)) {  // wave uniform: URLs, paths, long identifiers -- eight words per row, four rows loaded ahead
+            const uint8_t *pool = hasher.pool_base ? hasher.buf + hasher.pool_base[p] : hasher.buf;
+            static_assert(kBinRowsPerThread % 4 == 0, "quarters of four rows");
+#pragma unroll
+            for (int i0 = 0; i0 < kBinRowsPerThread; i0 += 4) {
+                uint64_t w[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint8_t *in = pool + (uint32_t)(pr[i0 + i] >> 32);
+                    const uint32_t len = (uint32_t)pr[i0 + i];
+                    w[i][0] = knox_xxh3::rd64(in);
+                    w[i][1] = knox_xxh3::rd64(in + 8);
+                    w[i][2] = knox_xxh3::rd64(in + 16);
+                    w[i][3] = knox_xxh3::rd64(in + 24);
+                    w[i][4] = knox_xxh3::rd64(in + len - 32);
+                    w[i][5] = knox_xxh3::rd64(in + len - 24);
+                    w[i][6] = knox_xxh3::rd64(in + len - 16);
+                    w[i][7] = knox_xxh3::rd64(in + len - 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    h[i0 + i] = knox_xxh3::hash_33_64_words(w[i][0], w[i][1], w[i][2], w[i][3], w[i][4], w[i][5], w[i][6], w[i][7], (uint32_t)pr[i0 + i]);
+            }
+            return valid;
         }
         if (__all(fast)) {  // wave uniform
             const uint8_t *pool = hasher.pool_base ? hasher.buf + hasher.pool_base[p] : hasher.buf;

@@ -94,6 +94,19 @@ KNOX_HD inline uint64_t hash_17_32_words(uint64_t a0, uint64_t a1, uint64_t b0, 
     return avalanche3(acc);
 }
 
+// XXH3_64bits of an input of 33 ... 64 bytes from its eight words already in registers: a = bytes [0, 16), b = bytes [16, 32),
+// c = bytes [len - 32, len - 16), d = bytes [len - 16, len) -- the 17..128 branch of hash() below for these lengths
+KNOX_HD inline uint64_t hash_33_64_words(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1, uint64_t c0, uint64_t c1, uint64_t d0, uint64_t d1,
+                                         uint64_t len) {
+    const uint8_t *s = kSecret;
+    uint64_t acc = len * P64_1;
+    acc += mul_fold(b0 ^ rd64(s + 32), b1 ^ rd64(s + 40));   // mix16(in + 16, s + 32)
+    acc += mul_fold(c0 ^ rd64(s + 48), c1 ^ rd64(s + 56));   // mix16(in + len - 32, s + 48)
+    acc += mul_fold(a0 ^ rd64(s), a1 ^ rd64(s + 8));         // mix16(in, s)
+    acc += mul_fold(d0 ^ rd64(s + 16), d1 ^ rd64(s + 24));   // mix16(in + len - 16, s + 16)
+    return avalanche3(acc);
+}
+
 // XXH3_64bits of an input of at most 32 bytes from words already in registers (every branch of hash() below up to 32 bytes, the
 // same arithmetic): w0 = the 8 bytes at in (read even when the input is shorter: the caller's buffer must be readable 7 bytes past
 // the input's end), w3 = the input's last 8 bytes (len >= 9), w1 = bytes [8, 16) and w2 = bytes [len - 16, len - 8) (len >= 17).

@@ -203,6 +203,33 @@ def test_bloom_build_bytes_rows_of_at_most_32_bytes(ctx):
     bloom2.free()
 
 
+def test_bloom_build_bytes_rows_of_33_to_64_bytes(ctx):
+    """the second batched-load path of the bytes build (every row of a wave's tile 33 ... 64 bytes long -- URLs, paths: the eight
+    8-byte words of four rows loaded before any arithmetic, knox_xxh3::hash_33_64_words): every length of the range, unaligned rows,
+    a pack with one row outside it (general path for its waves), filters byte-identical to the oracle's construction"""
+    rng = np.random.default_rng(93)
+    pack, n_packs = 8192, 2
+    n = pack * n_packs - 321
+    lens = rng.integers(33, 65, size=n)
+    lens[:32] = np.arange(33, 65)
+    lens[pack + 5] = 20
+    vals = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in lens]
+    buf = np.frombuffer(b"\x07\x07\x07" + b"".join(vals), dtype=np.uint8)
+    ln = np.array([len(v) for v in vals], dtype=np.uint64)
+    offs = (3 + np.concatenate([[0], np.cumsum(ln)[:-1]])).astype(np.uint64)
+    col = ctx.upload_bytes((offs << np.uint64(32)) | ln, buf, pack)
+    bloom = ctx.bloom_build(col, 2)
+    filters, offsets = bloom.download()
+    for p in range(n_packs):
+        vs = vals[p * pack:(p + 1) * pack]
+        f = O.bloom_new(len(vs), 2)
+        for v in vs:
+            O.bloom_add(f, O.xxh3_bytes(v))
+        assert (filters[int(offsets[p]):int(offsets[p + 1])] == f).all(), p
+    col.free()
+    bloom.free()
+
+
 def test_large_scan_properties(ctx):
     """2^26 rows (512 MiB): size-independent properties + sampled packs against the oracle."""
     n, pack = 1 << 26, 1 << 20
