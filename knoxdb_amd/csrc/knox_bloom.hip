@@ -659,7 +659,7 @@ hipError_t launch_bloom_build_one(hipStream_t s, int width, const void *col, con
     uint32_t *seg_cursor = (uint32_t *)(entries + np * epp);
     uint32_t *flag = seg_cursor + np * 256;
     *overflow_flag_dev = flag;
-    hipError_t e = hipMemsetAsync(seg_cursor, 0, np * 256 * 4 + 64, s);
+    hipError_t e = launch_zero_bytes(s, seg_cursor, np * 256 * 4 + 64);
     if (e != hipSuccess) return e;
     const dim3 grid1((unsigned)(np * tiles_pp)), block(kBlock);
     if (width == 0) {
@@ -698,7 +698,7 @@ hipError_t launch_bloom_build_part(hipStream_t s, int width, const void *col, co
     uint16_t *entries = (uint16_t *)scratch;
     uint32_t *seg_counts = (uint32_t *)(entries + np * epp);
     uint32_t *seg_base = seg_counts + np * 256;
-    hipError_t e = hipMemsetAsync(seg_counts, 0, np * 256 * 4, s);
+    hipError_t e = launch_zero_bytes(s, seg_counts, np * 256 * 4);
     if (e != hipSuccess) return e;
     const dim3 grid1((unsigned)(np * tiles_pp)), block(kBlock);
 #define KNOX_BLOOM_PASS(KERN, ...)                                                                                                       \
