@@ -372,7 +372,19 @@ hipError_t launch_window_sort_begin(hipStream_t s, const int64_t *time, uint64_t
                                     uint32_t n_buckets, WindowSortGeom g, uint32_t bits0, uint32_t *keys, uint32_t *hist, uint32_t *tot);
 hipError_t launch_window_sort_first(hipStream_t s, int width, const uint32_t *keys, const void *value_col, uint64_t n_rows, WindowSortGeom g,
                                     uint32_t bits0, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out, uint32_t *idx_out,
-                                    void *val_out);
+                                    void *val_out, const uint32_t *idx_in = nullptr);
+// a selection in front of the sort: the selected rows' (window index, [row id], value) compacted in row order by a streaming pass
+struct WindowCompactGeom {
+    uint64_t unit_rows;   // rows per unit (one wave each), a multiple of 256
+    uint32_t n_units;
+};
+WindowCompactGeom window_compact_geom(uint64_t n_rows, int n_cus);
+hipError_t launch_mask_unit_offsets(hipStream_t s, const uint8_t *mask, uint64_t n_rows, WindowCompactGeom g, uint32_t *counts,
+                                    unsigned long long *total_dev);
+hipError_t launch_window_compact(hipStream_t s, int width, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
+                                 WindowCompactGeom g, const uint32_t *unit_off, int64_t t_from, int64_t step, uint32_t n_buckets, uint32_t *keys_out,
+                                 uint32_t *idx_out, void *val_out);
+hipError_t launch_compact_keys_hist(hipStream_t s, const uint32_t *keys, uint64_t n, WindowSortGeom g, uint32_t bits0, uint32_t *hist, uint32_t *tot);
 hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
                                    WindowSortGeom g, uint32_t shift, uint32_t nbits, uint32_t *hist, uint32_t *tot, uint32_t *keys_out,
                                    uint32_t *idx_out, void *val_out);

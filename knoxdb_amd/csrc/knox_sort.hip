@@ -30,6 +30,22 @@ constexpr uint32_t kNoKey = 0xffffffffu;
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// window index of a timestamp: (t - t_from) / step when that is below n_buckets, else kNoKey.  The 64-bit division the compiler
+// emits is ~150 instructions per row (it was most of the key pass: 0.68 ms per 2^28 rows at 6 % VALU "busy", and 1.0 of the
+// compaction pass's first 1.3 ms); the quotient of interest is below 2^26, so a double-precision estimate is off by at most one and a
+// multiply-back settles it.  span = n_buckets * step (the host checked that every window edge fits int64), inv = 1.0 / step.
+__device__ __forceinline__ uint32_t window_index(int64_t t, int64_t t_from, uint64_t step, uint64_t span, double inv) {
+    const uint64_t d = (uint64_t)t - (uint64_t)t_from;
+    // the quotient is below 2^26 (n_buckets <= 2^26, checked by the host): the estimate is within one of it and is CONVERTED AS 32 BITS --
+    // one instruction where the 64-bit conversion is a dozen (this function was most of the 480 vector instructions the compaction
+    // spent per 512 rows)
+    uint32_t q = (uint32_t)((double)d * inv);
+    const uint64_t back = (uint64_t)q * step;
+    if (back > d) q--;                              // estimate one too high
+    else if (d - back >= step) q++;                 // one too low
+    return (t < t_from || d >= span) ? kNoKey : q;
+}
+
 // exclusive scan of one value per thread over the 256 threads of the workgroup; *total = sum.  `tmp` = 4 LDS words.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -63,6 +79,8 @@ __global__ void __launch_bounds__(kSortBlock) window_keys_hist_kernel(const int6
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
     __syncthreads();
+    const uint64_t span = (uint64_t)n_buckets * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < n_rows ? begin + per_block : n_rows;
     // four independent (timestamp, selection byte) loads per thread and loop iteration: with one, 89 % of the wave cycles
@@ -83,11 +101,7 @@ __global__ void __launch_bounds__(kSortBlock) window_keys_hist_kernel(const int6
         for (int u = 0; u < U; u++) {
             const uint64_t i = i0 + (uint64_t)u * kSortBlock;
             if (i >= end) break;
-            uint32_t k = kNoKey;
-            if (sel[u] && t[u] >= t_from) {
-                const uint64_t q = (uint64_t)(t[u] - t_from) / (uint64_t)step;  // host checked: every window edge fits int64
-                if (q < n_buckets) k = (uint32_t)q;
-            }
+            const uint32_t k = sel[u] ? window_index(t[u], t_from, (uint64_t)step, span, inv) : kNoKey;
             keys[i] = k;
             if (k != kNoKey) atomicAdd(&h[k & dmask], 1u);
         }
@@ -96,9 +110,210 @@ __global__ void __launch_bounds__(kSortBlock) window_keys_hist_kernel(const int6
     hist[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = h[threadIdx.x];
 }
 
+// ---- pass 0 behind a selection: compaction first ------------------------------------------------------------------------------
+// With a quarter of the rows selected the first scatter ranks, tile by tile, 4096 rows to keep 1024: it reads the key and the value
+// of EVERY row at its 3.5 TB/s (1.24 of the 2.5 ms of 2^28 shuffled rows -> 1024 windows).  A streaming pass does that part:
+// the column is cut into units of a few thousand rows, one wave each; (A) selected rows per unit (the bitset alone: 1/8 B per
+// row), an exclusive scan over the units, (B) the wave walks its unit and writes (window index, [row id], value) of the selected
+// rows to their place, in row order (ballots give every lane the selected rows before its own).  Rows outside every window keep
+// kNoKey and leave in the scatter, which now runs over the selected rows only.
+// Measured (2^28 rows, 25 % selected, whole calls on one box, KNOX_WINDOW_COMPACT=0 / 1): 1024 windows 2.56 / 2.54 ms with the
+// first form of (B), 2.3-2.5 ms with the vector form below; 16384 windows 2.95-3.08 / 2.6-2.8 ms.  (B) itself runs at 4.5-4.9 TB/s
+// (16 B read per row whatever the selection -- at 25 % every 64-byte line of the values holds a selected row -- + 12 B written per
+// selected one); what was tried to raise it and changed nothing: 2 .. 64 waves per SIMD-slot's worth of units, unit sizes that are
+// not powers of two, nontemporal loads and stores (kept), a three-stage software pipeline.
+__global__ void __launch_bounds__(kSortBlock) mask_unit_count_kernel(const uint8_t *__restrict__ mask, uint64_t n_rows, uint64_t unit_rows,
+                                                                     uint32_t n_units, uint32_t *__restrict__ counts) {
+    const uint32_t u = blockIdx.x * kSortWaves + (threadIdx.x >> 6), lane = lane_id();
+    if (u >= n_units) return;
+    const uint64_t r0 = (uint64_t)u * unit_rows, r1 = r0 + unit_rows < n_rows ? r0 + unit_rows : n_rows;
+    const uint64_t b0 = r0 >> 3, b1 = (r1 + 7) >> 3;   // unit_rows is a multiple of 256: whole bytes, the last unit's last byte may be ragged
+    uint32_t c = 0;
+    for (uint64_t b = b0 + lane; b < b1; b += 64) {
+        uint32_t x = mask[b];
+        if ((b + 1) * 8 > n_rows) x &= 0xffu >> (8 - (uint32_t)(n_rows & 7));
+        c += (uint32_t)__builtin_popcount(x);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0) counts[u] = c;
+}
+
+template <typename U>
+struct CompactPairOf {   // two neighbouring values of the column in one load
+    typedef U type __attribute__((ext_vector_type(2)));
+};
+template <typename U>
+using CompactPair = typename CompactPairOf<U>::type;
+
+// VEC: the clock is 16-byte and the value column 2-value aligned (device allocations are; a wrapped column may not be) -- a lane takes
+// two NEIGHBOURING rows of each 128-row half of the chunk, so that every load instruction of the wave covers one contiguous kilobyte
+// (a lane with four consecutive rows made each instruction touch every second 16 bytes of two kilobytes: four times the lines per
+// instruction through the vector L1, 1.35 ms for 2^28 rows at 25 % selected), and the selected rows of a chunk are put in order in
+// the wave's own piece of LDS first and leave it as whole runs -- one store instruction per array and 64 selected rows.
+template <typename U, bool VEC>
+__global__ void __launch_bounds__(kSortBlock) window_compact_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                    uint64_t n_rows, uint64_t unit_rows, uint32_t n_units, const uint32_t *__restrict__ unit_off,
+                                                                    int64_t t_from, int64_t step, uint32_t n_buckets, uint32_t *__restrict__ keys_out,
+                                                                    uint32_t *__restrict__ idx_out, U *__restrict__ val_out) {
+    __shared__ uint32_t s_key[VEC ? kSortWaves : 1][256], s_idx[VEC ? kSortWaves : 1][256];
+    __shared__ U s_val[VEC ? kSortWaves : 1][256];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the chunk addresses stay in scalar registers)
+    const uint32_t u = blockIdx.x * kSortWaves + wave, lane = lane_id();
+    if (u >= n_units) return;
+    const uint64_t r0 = (uint64_t)u * unit_rows, r1 = r0 + unit_rows < n_rows ? r0 + unit_rows : n_rows;
+    uint64_t out = unit_off[u];
+    const uint64_t span = (uint64_t)n_buckets * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    uint64_t c0 = r0;
+    if constexpr (VEC) {
+        // 512 rows per round, every load of the round asked for before the first is used: four selection bytes, four 16-byte pieces of
+        // the clock and four of the values per lane -- 8 KiB per wave and round trip to memory.  (With 256 rows per round and the value
+        // loads behind the selection bits -- two dependent round trips for 4 KiB -- the waves waited 62 % of their cycles; in this form
+        // 26 %, at the same 1.1 ms.)  Where a unit is thinly selected (under a sixteenth of its rows) the value loads do wait for the
+        // bits, and lines without a selected row are not fetched.
+        typedef long long t2 __attribute__((ext_vector_type(2)));
+        const bool dense = (uint64_t)(unit_off[u + 1] - unit_off[u]) * 16 >= r1 - r0;
+        const uint32_t sh = (2u * lane) & 7u;
+        for (; c0 + 512 <= r1; c0 += 512) {
+            uint32_t mb[4];
+            t2 t[4];
+            CompactPair<U> x[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) mb[h] = mask[(c0 + 128u * h + 2u * lane) >> 3];
+#pragma unroll
+            for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
+            if (dense) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    x[h] = CompactPair<U>{0, 0};
+                    if ((mb[h] >> sh) & 3u) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {     // the wave's piece of LDS holds 256 rows: two turns
+                uint32_t total = 0;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int h = 2 * half + k;
+                    const uint32_t m2 = (mb[h] >> sh) & 3u;
+                    const uint64_t ba = __ballot(m2 & 1u), bb = __ballot(m2 & 2u);
+                    uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, 0u)) +
+                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                    total += (uint32_t)__popcll(ba) + (uint32_t)__popcll(bb);
+                    const uint32_t row = (uint32_t)c0 + 128u * h + 2u * lane;
+                    if (m2 & 1u) {
+                        s_key[wave][pos] = window_index(t[h].x, t_from, (uint64_t)step, span, inv);
+                        s_idx[wave][pos] = row;
+                        s_val[wave][pos] = x[h].x;
+                        pos++;
+                    }
+                    if (m2 & 2u) {
+                        s_key[wave][pos] = window_index(t[h].y, t_from, (uint64_t)step, span, inv);
+                        s_idx[wave][pos] = row + 1;
+                        s_val[wave][pos] = x[h].y;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = lane; i < total; i += 64) {
+                    __builtin_nontemporal_store(s_key[wave][i], keys_out + out + i);
+                    if (idx_out != nullptr) __builtin_nontemporal_store(s_idx[wave][i], idx_out + out + i);
+                    __builtin_nontemporal_store(s_val[wave][i], val_out + out + i);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                out += total;
+            }
+        }
+    }
+    // the general form: a lane takes four consecutive rows; the ragged end of the column, and columns without the alignment
+    for (; c0 < r1; c0 += 256) {
+        const uint64_t row = c0 + 4ull * lane;      // this lane's four rows
+        uint32_t nib = 0;
+        int64_t t[4] = {0, 0, 0, 0};
+        U x[4] = {0, 0, 0, 0};
+        if (row < r1) {
+            nib = (mask[row >> 3] >> (row & 7)) & 0xfu;              // row is a multiple of 4: one nibble
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (row + j < r1) { t[j] = time[row + j]; x[j] = val[row + j]; }
+                else nib &= ~(1u << j);
+            }
+        }
+        uint32_t before = 0, total = 0;            // selected rows of the chunk in front of this lane's, and in all
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t b = __ballot((nib >> j) & 1u);
+            before += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            total += (uint32_t)__popcll(b);
+        }
+        uint64_t o = out + before;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((nib >> j) & 1u) {
+                keys_out[o] = window_index(t[j], t_from, (uint64_t)step, span, inv);
+                if (idx_out != nullptr) idx_out[o] = (uint32_t)(row + j);
+                val_out[o] = x[j];
+                o++;
+            }
+        }
+        out += total;
+    }
+}
+
+// units of the compaction: a few per CU and wave slot, whole multiples of 512 rows (the vector form's round)
+WindowCompactGeom window_compact_geom(uint64_t n_rows, int n_cus) {
+    WindowCompactGeom g;
+    uint64_t units = (uint64_t)n_cus * 64;
+    uint64_t per = (n_rows + units - 1) / units;
+    per = (per + 511) / 512 * 512;
+    if (per < 1024) per = 1024;
+    g.unit_rows = per;
+    g.n_units = (uint32_t)((n_rows + per - 1) / per);
+    return g;
+}
+
+// counts[0 .. n_units] <- exclusive offsets, counts[n_units] = *total_dev = the selected rows
+hipError_t launch_mask_unit_offsets(hipStream_t s, const uint8_t *mask, uint64_t n_rows, WindowCompactGeom g, uint32_t *counts,
+                                    unsigned long long *total_dev) {
+    hipLaunchKernelGGL(mask_unit_count_kernel, dim3((g.n_units + kSortWaves - 1) / kSortWaves), dim3(kSortBlock), 0, s, mask, n_rows, g.unit_rows,
+                       g.n_units, counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_idx_scan(s, counts, g.n_units, total_dev);
+}
+
+hipError_t launch_window_compact(hipStream_t s, int width, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
+                                 WindowCompactGeom g, const uint32_t *unit_off, int64_t t_from, int64_t step, uint32_t n_buckets, uint32_t *keys_out,
+                                 uint32_t *idx_out, void *val_out) {
+    const dim3 grid((g.n_units + kSortWaves - 1) / kSortWaves), block(kSortBlock);
+    const char *form = getenv("KNOX_COMPACT_FORM");   // "rows": the general form for every chunk (tests)
+    const bool vec = ((uintptr_t)time & 15) == 0 && ((uintptr_t)val % (2 * (size_t)width)) == 0 && !(form != nullptr && strcmp(form, "rows") == 0);
+#define KNOX_COMPACT(U)                                                                                                                                    \
+    if (vec)                                                                                                                                               \
+        hipLaunchKernelGGL((window_compact_kernel<U, true>), grid, block, 0, s, time, (const U *)val, mask, n_rows, g.unit_rows, g.n_units, unit_off, t_from, \
+                           step, n_buckets, keys_out, idx_out, (U *)val_out);                                                                              \
+    else                                                                                                                                                   \
+        hipLaunchKernelGGL((window_compact_kernel<U, false>), grid, block, 0, s, time, (const U *)val, mask, n_rows, g.unit_rows, g.n_units, unit_off, t_from, \
+                           step, n_buckets, keys_out, idx_out, (U *)val_out)
+    switch (width) {
+    case 8: KNOX_COMPACT(uint64_t); break;
+    case 4: KNOX_COMPACT(uint32_t); break;
+    case 2: KNOX_COMPACT(uint16_t); break;
+    case 1: KNOX_COMPACT(uint8_t); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_COMPACT
+    return hipGetLastError();
+}
+
 // ---- later passes, step 1: digit histogram of the keys as the previous pass left them --------------------------------
 __global__ void __launch_bounds__(kSortBlock) key_hist_kernel(const uint32_t *__restrict__ keys, uint64_t n, uint64_t per_block, uint32_t shift,
-                                                              uint32_t dmask, uint32_t *__restrict__ hist) {
+                                                              uint32_t dmask, uint32_t *__restrict__ hist, int skip_nokey) {
     __shared__ uint32_t h[kRadix];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -106,7 +321,20 @@ __global__ void __launch_bounds__(kSortBlock) key_hist_kernel(const uint32_t *__
     const uint64_t end = begin + per_block < n ? begin + per_block : n;
     // (Round 4: lanes with equal digits found by match-any ballots, one add per group instead of one per lane, in both histogram kernels:
     //  2^28 shuffled rows -> 1024 windows 2.75 ms against 2.51 ms with the plain adds -- dropped.)
-    for (uint64_t i = begin + threadIdx.x; i < end; i += kSortBlock) atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
+    constexpr int U = 4;    // independent loads per thread and round (one: 92 % of the wave cycles were waits, 2.8 TB/s)
+    for (uint64_t i0 = begin + threadIdx.x; i0 < end; i0 += (uint64_t)kSortBlock * U) {
+        uint32_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = i0 + (uint64_t)u * kSortBlock;
+            k[u] = i < end ? keys[i] : kNoKey;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool in = i0 + (uint64_t)u * kSortBlock < end;
+            if (in && (!skip_nokey || k[u] != kNoKey)) atomicAdd(&h[(k[u] >> shift) & dmask], 1u);   // (compacted keys still hold the rows outside every window)
+        }
+    }
     __syncthreads();
     hist[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = h[threadIdx.x];
 }
@@ -189,7 +417,7 @@ __global__ void __launch_bounds__(kSortBlock) sort_scatter_kernel(const uint32_t
             if (e < end) {
                 key[j] = keys_in[e];
                 if (FIRST) {
-                    row[j] = (uint32_t)e;
+                    row[j] = (with_idx && idx_in != nullptr) ? idx_in[e] : (uint32_t)e;   // compacted input: the caller's row ids travel with it
                 } else if (with_idx) {
                     row[j] = idx_in[e];
                 }
@@ -346,8 +574,8 @@ hipError_t launch_window_sort_begin(hipStream_t s, const int64_t *time, uint64_t
 // pass 0: (keys, row id, value_col) -> buffer A, dropping kNoKey rows
 hipError_t launch_window_sort_first(hipStream_t s, int width, const uint32_t *keys, const void *value_col, uint64_t n_rows, WindowSortGeom g,
                                     uint32_t bits0, const uint32_t *hist, const uint32_t *tot, uint32_t *keys_out, uint32_t *idx_out,
-                                    void *val_out) {
-    return scatter_any(s, width, true, g.nb, keys, nullptr, value_col, n_rows, g.per_block, 0, bits0, hist, tot, keys_out, idx_out, val_out);
+                                    void *val_out, const uint32_t *idx_in) {
+    return scatter_any(s, width, true, g.nb, keys, idx_in, value_col, n_rows, g.per_block, 0, bits0, hist, tot, keys_out, idx_out, val_out);
 }
 
 // pass p >= 1 over the n selected triples
@@ -355,9 +583,16 @@ hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *key
                                    WindowSortGeom g, uint32_t shift, uint32_t nbits, uint32_t *hist, uint32_t *tot, uint32_t *keys_out,
                                    uint32_t *idx_out, void *val_out) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(key_hist_kernel, dim3(g.nb), dim3(kSortBlock), 0, s, keys_in, n, g.per_block, shift, (1u << nbits) - 1, hist);
+    hipLaunchKernelGGL(key_hist_kernel, dim3(g.nb), dim3(kSortBlock), 0, s, keys_in, n, g.per_block, shift, (1u << nbits) - 1, hist, 0);
     hipLaunchKernelGGL(hist_scan_kernel, dim3(kRadix), dim3(kSortBlock), 0, s, hist, g.nb, tot);
     return scatter_any(s, width, false, g.nb, keys_in, idx_in, val_in, n, g.per_block, shift, nbits, hist, tot, keys_out, idx_out, val_out);
+}
+
+// the first digit's histogram of COMPACTED keys (kNoKey entries skipped), scanned: what launch_window_sort_begin leaves for uncompacted input
+hipError_t launch_compact_keys_hist(hipStream_t s, const uint32_t *keys, uint64_t n, WindowSortGeom g, uint32_t bits0, uint32_t *hist, uint32_t *tot) {
+    hipLaunchKernelGGL(key_hist_kernel, dim3(g.nb), dim3(kSortBlock), 0, s, keys, n, g.per_block, 0u, (1u << bits0) - 1, hist, 1);
+    hipLaunchKernelGGL(hist_scan_kernel, dim3(kRadix), dim3(kSortBlock), 0, s, hist, g.nb, tot);
+    return hipGetLastError();
 }
 
 // start[k] = first sorted position whose key is >= k, k = 0..n_buckets (start[n_buckets] = rows inside windows)

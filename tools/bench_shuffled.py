@@ -15,7 +15,9 @@ n = 1 << lg
 col = ctx.generate(B.Int64, 0, 2, n, lo=-(1 << 40), span=1 << 41, pack_rows=1 << 20)
 clock = ctx.generate(B.Int64, 0, 9, n, lo=1000, span=1 << 20, pack_rows=1 << 20)
 bits = ctx.bits(n, for_col=col)
-ctx.scan(And(Leaf(0, F.Range, -(1 << 38), 1 << 38)), [col], bits_out=bits)
+sel = int(os.environ.get("KNOX_SHUFFLED_SEL", "25"))   # per cent of the rows the bitset selects (values are uniform in [-2^40, 2^40))
+half = (1 << 40) * sel // 100
+ctx.scan(And(Leaf(0, F.Range, -half, half)), [col], bits_out=bits)
 
 
 def timed(fn):
@@ -30,8 +32,8 @@ def timed(fn):
 only = os.environ.get("KNOX_SHUFFLED_ONLY")   # "masked" | "all": one variant (a profile of one shape)
 for nb in (1024, 16384):
     step = (1 << 20) // nb
-    for m, tag in ((bits, "25 % selected"), (None, "all rows")):
-        if only and not tag.startswith("25" if only == "masked" else "all"):
+    for m, tag in ((bits, "%d %% selected" % sel), (None, "all rows")):
+        if only and (tag == "all rows") != (only == "all"):
             continue
         ms = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Sum, 1000, step, nb, mask=m))
         print("2^%d rows, shuffled clock, %6d windows, %-13s: %6.2f ms (%.1f G rows/s)" % (lg, nb, tag, ms, n / ms / 1e6), flush=True)
