@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run of the matchers whose kernels were rewritten in round 4 -- numeric IN / NOT IN (every lookup tier),
-bit-packed scans (LDS-staged and general form), bytes IN (prefix search), time windows (the three launch forms) -- against the
+bit-packed scans (LDS-staged and general form), bytes IN (prefix search), time windows (the three launch forms; out-of-order clocks
+anywhere in int64 with steps up to 2^44, with and without the compaction pass, against integer floor division) -- against the
 oracle, with random sizes, widths, set sizes, value ranges and ragged tails.  Not part of the test suite (minutes of oracle time);
 run after touching one of those kernels.  usage: fuzz_matchers.py [seconds=60] [seed=0]"""
 import os, sys, time
@@ -21,7 +22,7 @@ NP = {B.Int64: np.int64, B.Uint64: np.uint64, B.Int32: np.int32, B.Uint32: np.ui
       B.Uint8: np.uint8, B.Float64: np.float64, B.Float32: np.float32}
 OT = {B.Int64: O.I64, B.Uint64: O.U64, B.Int32: O.I32, B.Uint32: O.U32, B.Int16: O.I16, B.Uint16: O.U16, B.Int8: O.I8, B.Uint8: O.U8}
 t_end = time.time() + budget
-n_cases = {"inset": 0, "packed": 0, "bytes_in": 0, "windows": 0}
+n_cases = {"inset": 0, "packed": 0, "bytes_in": 0, "windows": 0, "shuffled": 0}
 
 
 def rand_values(bt, n):
@@ -43,7 +44,7 @@ def rand_values(bt, n):
 
 
 while time.time() < t_end:
-    which = rng.integers(0, 4)
+    which = rng.integers(0, 5)
     if which == 0:
         bt = list(NP)[rng.integers(0, len(NP))]
         n = int(rng.integers(1, 40000))
@@ -122,6 +123,49 @@ while time.time() < t_end:
             bits.free()
         col.free()
         n_cases["bytes_in"] += 1
+    elif which == 4:
+        # out-of-order time: the window index (a double-precision quotient estimate + multiply-back, knox_sort.hip window_index) against
+        # Python's integer floor division over steps from 1 to 2^44 and clocks anywhere in int64; with / without the compaction pass
+        n = int(rng.integers(100, 200000))
+        step = int(2 ** rng.uniform(0, 44)) + int(rng.integers(0, 3))
+        nb = int(rng.integers(1, 5000))
+        t_from = int(rng.integers(-(1 << 62), (1 << 62) - step * nb - 1))
+        span = step * nb
+        lo, hi = max(t_from - span // 4 - 5, -(1 << 63)), min(t_from + span + span // 4 + 5, (1 << 63) - 1)
+        t = rng.integers(lo, hi, n, dtype=np.int64, endpoint=True)
+        edge = rng.integers(0, nb + 1, size=min(n, 64)) * step + t_from + rng.integers(-1, 2, size=min(n, 64))   # timestamps on and beside window edges
+        t[rng.integers(0, n, size=edge.size)] = np.clip(edge, lo, hi)
+        bt = [B.Int64, B.Int16, B.Uint8, B.Uint32][rng.integers(0, 4)]
+        v = rand_values(bt, n)
+        sel = rng.random(n) < rng.random()
+        tcol, vcol = ctx.upload(t, 4096), ctx.upload(v, 4096)
+        mask = ctx.bits(n).upload(np.packbits(sel, bitorder="little"))
+        key = (t.astype(object) - t_from) // step
+        inside = sel & np.array([0 <= k < nb for k in key])
+        rows = np.flatnonzero(inside)
+        ks = np.array([int(key[r]) for r in rows], dtype=np.int64)
+        want_cnt = np.bincount(ks, minlength=nb)
+        first = np.full(nb, -1, dtype=np.int64)
+        for r, k in zip(rows[::-1], ks[::-1]):
+            first[k] = r
+        got = []
+        for compact, form in (("0", None), ("1", None), ("1", "rows")):
+            os.environ["KNOX_WINDOW_COMPACT"] = compact
+            os.environ.pop("KNOX_COMPACT_FORM", None)
+            if form:
+                os.environ["KNOX_COMPACT_FORM"] = form
+            st = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=mask)
+            assert [s.count for s in st] == want_cnt.tolist(), ("shuffled counts", n, step, nb, t_from, compact, form, seed)
+            assert [s.first_row for s in st] == first.tolist(), ("shuffled first rows", n, step, nb, t_from, compact, form, seed)
+            vals, seen = ctx.reduce_buckets_values(tcol, vcol, R.Last, t_from, step, nb, mask=mask)
+            last = (vals.tobytes(), seen.tobytes())      # (views of the context's result buffer: copied before the next *_view call)
+            got.append((bytes(ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=mask)),) + last)
+        os.environ.pop("KNOX_WINDOW_COMPACT", None)
+        os.environ.pop("KNOX_COMPACT_FORM", None)
+        assert got[0] == got[1] == got[2], ("shuffled forms", n, step, nb, t_from, seed)
+        for o in (tcol, vcol, mask):
+            o.free()
+        n_cases["shuffled"] += 1
     else:
         n = int(rng.integers(100, 300000))
         step = int(rng.integers(1, 400))
