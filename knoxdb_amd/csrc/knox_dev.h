@@ -32,6 +32,7 @@
 //     sum rounded once; integer sums wrap mod 2^64 exactly like Go.
 #pragma once
 #include "knox_kernels.h"
+#include "knox_finalize.h"
 #include <utility>
 
 namespace knox {
@@ -149,21 +150,7 @@ __device__ __forceinline__ void dd_add(double &hi, double &lo, double h2, double
     hi = s;
 }
 
-// exact 128-bit integer sum (|S| < 2^106, true for any column that fits one GPU) -> double-double with hi + lo == S
-__device__ __forceinline__ void int128_to_dd(uint64_t xlo, int64_t xhi, double &hi, double &lo) {
-    const double p1 = (double)xhi * 18446744073709551616.0;            // exact: |xhi| < 2^42
-    const double p2 = (double)(uint32_t)(xlo >> 32) * 4294967296.0;    // exact
-    const double p3 = (double)(uint32_t)xlo;                            // exact
-    double s = p1 + p2;
-    double bb = s - p1;
-    const double e1 = (p1 - (s - bb)) + (p2 - bb);                      // TwoSum: exact
-    const double s2 = s + p3;
-    bb = s2 - s;
-    const double e2 = (s - (s2 - bb)) + (p3 - bb);
-    const double l = e1 + e2;                                           // integers below 2^54: exact
-    hi = s2 + l;                                                        // renormalize (Fast2Sum, |s2| >= |l|)
-    lo = l - (hi - s2);
-}
+using knox_fin::int128_to_dd;   // (knox_finalize.h: shared with the sort-free window sums of knox_sort.hip)
 
 struct Acc {
     uint64_t count, isum;

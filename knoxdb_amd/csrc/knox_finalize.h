@@ -67,6 +67,21 @@ KNOX_HD inline dd dd_div_d(dd a, double n) {
     q.lo += q3;
     return fast_two_sum(q.hi, q.lo);
 }
+// exact 128-bit integer sum (|S| < 2^106, true for any column that fits one GPU) -> double-double with hi + lo == S
+KNOX_HD inline void int128_to_dd(uint64_t xlo, int64_t xhi, double &hi, double &lo) {
+    const double p1 = (double)xhi * 18446744073709551616.0;            // exact: |xhi| < 2^42
+    const double p2 = (double)(uint32_t)(xlo >> 32) * 4294967296.0;    // exact
+    const double p3 = (double)(uint32_t)xlo;                            // exact
+    double s = p1 + p2;
+    double bb = s - p1;
+    const double e1 = (p1 - (s - bb)) + (p2 - bb);                      // TwoSum: exact
+    const double s2 = s + p3;
+    bb = s2 - s;
+    const double e2 = (s - (s2 - bb)) + (p3 - bb);
+    const double l = e1 + e2;                                           // integers below 2^54: exact
+    hi = s2 + l;                                                        // renormalize (Fast2Sum, |s2| >= |l|)
+    lo = l - (hi - s2);
+}
 KNOX_HD inline bool finite_(double x) { return fabs(x) <= 1.7976931348623157e308; }
 
 KNOX_HD inline int width_of(int dtype) {  // knox_dtype -> bytes per value (numeric types)

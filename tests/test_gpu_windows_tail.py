@@ -312,3 +312,48 @@ def test_out_of_order_windows_behind_a_selection_compaction_forms_agree():
             os.environ.pop(k, None)
             if val is not None:
                 os.environ[k] = val
+
+
+def test_out_of_order_windows_order_free_values_without_the_sort():
+    """Sum / Count / Mean per window over out-of-order time and at most 4096 windows are pushed row by row into per-workgroup LDS
+    tables (window_direct_kernel) instead of being sorted first: byte-identical to the sorted path (KNOX_WINDOW_DIRECT=0), which the
+    tests above hold to the oracle -- every integer width, values at the ends of their range (the exact sum behind Mean leaves 64
+    bits), Count over a float column, no selection / thin / dense selections, window counts around the sizes at which the tables stop
+    fitting LDS (Mean over 8-byte values 7987, Sum ~19 Ki, Count ~39 Ki; above them the sort)."""
+    import os
+    rng = np.random.default_rng(777)
+    old = os.environ.pop("KNOX_WINDOW_DIRECT", None)
+    try:
+        with K.Context(0) as ctx:
+            for n, nb, step in ((1_000_003, 700, 9), (70_001, 4096, 3), (300, 1, 50), (200_000, 7987, 2), (200_000, 7988, 2), (511, 33, 1 << 33), (400_000, 19_000, 2),
+                                (400_000, 39_000, 2), (400_000, 70_000, 2)):
+                t_from = -5_000_000_000
+                key = rng.integers(-2, nb + 2, n)
+                t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
+                tcol = ctx.upload(t, 4096)
+                masks = [None] + [ctx.bits(n).upload(np.packbits(rng.random(n) < p, bitorder="little")) for p in (0.04, 0.6)]
+                sels = [np.ones(n, dtype=bool)] + [np.unpackbits(m.bytes(), bitorder="little")[:n].astype(bool) for m in masks[1:]]
+                for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8, B.Float64):
+                    v = _values(rng, bt, n)
+                    if bt == B.Int64:
+                        v[: n // 2] = np.iinfo(np.int64).max - rng.integers(0, 5, n // 2)      # sums far beyond 64 bits
+                    vcol = ctx.upload(v, 4096)
+                    for m, sel in zip(masks, sels):
+                        for f in ((R.Count,) if bt == B.Float64 else (R.Sum, R.Count, R.Mean)):
+                            os.environ["KNOX_WINDOW_DIRECT"] = "0"
+                            a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                            want = (a.tobytes(), b.tobytes())
+                            os.environ.pop("KNOX_WINDOW_DIRECT")
+                            a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                            assert (a.tobytes(), b.tobytes()) == want, (n, nb, bt, f, m is not None)
+                            if f == R.Count:
+                                inside = sel & (key >= 0) & (key < nb)
+                                cnt = np.bincount(key[inside], minlength=nb)
+                                assert (a.astype(np.float64) == cnt.astype(NP[bt]).astype(np.float64)).all() and (b == (cnt > 0)).all(), (n, nb, bt)
+                    vcol.free()
+                for o in [tcol] + masks[1:]:
+                    o.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_DIRECT", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_DIRECT"] = old

@@ -30,7 +30,7 @@ def timed(fn):
 
 
 only = os.environ.get("KNOX_SHUFFLED_ONLY")   # "masked" | "all": one variant (a profile of one shape)
-for nb in (1024, 16384):
+for nb in [int(x) for x in os.environ.get("KNOX_SHUFFLED_NB", "1024,16384").split(",")]:   # window counts (powers of two up to 2^20)
     step = (1 << 20) // nb
     for m, tag in ((bits, "%d %% selected" % sel), (None, "all rows")):
         if only and (tag == "all rows") != (only == "all"):
