@@ -384,15 +384,14 @@ hipError_t launch_mask_unit_offsets(hipStream_t s, const uint8_t *mask, uint64_t
 hipError_t launch_window_compact(hipStream_t s, int width, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
                                  WindowCompactGeom g, const uint32_t *unit_off, int64_t t_from, int64_t step, uint32_t n_buckets, uint32_t *keys_out,
                                  uint32_t *idx_out, void *val_out);
-// out-of-order time without the sort: Sum / Count / Mean per window by LDS adds (knox_sort.hip)
+// out-of-order time without the sort: Value() of the order-free reducers per window by LDS atomics (knox_sort.hip)
 struct WindowDirectGeom {
-    uint32_t grid, n_sums, n_cnt;   // grid 0: the table does not fit LDS (Count: ~39 Ki windows, Sum: ~19 Ki, Mean: ~13 Ki / ~7.9 Ki for 8-byte values)
+    uint32_t grid, n_slots, n_words;   // grid 0: no order-free form for (reducer, column type), or the table does not fit LDS
     size_t lds, scratch;
 };
-WindowDirectGeom window_direct_geom(int width, int func, uint32_t n_buckets, int n_cus);
-hipError_t launch_window_direct(hipStream_t s, int width, bool is_signed, int dtype, int func, WindowDirectGeom g, const int64_t *time, const void *val,
-                                const uint8_t *mask, uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values,
-                                uint8_t *seen);
+WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_buckets, int n_cus);
+hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, WindowDirectGeom g, const int64_t *time, const void *val, const uint8_t *mask,
+                                uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
 hipError_t launch_compact_keys_hist(hipStream_t s, const uint32_t *keys, uint64_t n, WindowSortGeom g, uint32_t bits0, uint32_t *hist, uint32_t *tot);
 hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
                                    WindowSortGeom g, uint32_t shift, uint32_t nbits, uint32_t *hist, uint32_t *tot, uint32_t *keys_out,

@@ -92,27 +92,25 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
     const size_t n_rows = value_col->n_rows;
     if (n_rows > 0xfffffff0ull) return KNOX_E_UNSUPPORTED;
     const size_t w = (size_t)value_col->width;
-    // Value() of an order-free reducer -- count, the integer sum, the mean rounded from the exact integer sum -- over as many windows
-    // as a workgroup's LDS holds a table for (Count ~39 Ki, Sum ~19 Ki, Mean ~13 Ki / ~7.9 Ki for 8-byte values): every row is pushed into its window where it lies (window_direct_kernel, knox_sort.hip), as NativeBucket.Push
-    // does; nothing is sorted.  KNOX_WINDOW_DIRECT=0 keeps the sort (measurements, the agreement test).
+    // Value() of a reducer with an order-free form -- count, first / last (the value of the lowest / highest selected row), and over
+    // integer columns sum, min, max and the mean rounded from the exact sum -- over as many windows as a workgroup's LDS holds a table
+    // for (8 B + a bit per window: ~19 Ki windows; Count ~39 Ki, Mean ~13 Ki / ~7.9 Ki for 8-byte values): every row is pushed into
+    // its window where it lies (window_direct_kernel, knox_sort.hip), as NativeBucket.Push does; nothing is sorted.
+    // KNOX_WINDOW_DIRECT=0 keeps the sort (measurements, the agreement test).
     if (ctx->win_values != nullptr && !(flags & 2) && n_buckets <= 65536) {
-        const int func = ctx->win_func, dt = value_col->dtype;
-        const bool integer = dt >= KNOX_INT64 && dt <= KNOX_UINT8;
         const char *env = getenv("KNOX_WINDOW_DIRECT");
-        if (((func == KNOX_R_COUNT && dt >= KNOX_INT64 && dt <= KNOX_FLOAT32) || ((func == KNOX_R_SUM || func == KNOX_R_MEAN) && integer)) &&
-            !(env && atoi(env) == 0)) {
-            const WindowDirectGeom dg = window_direct_geom((int)w, func, (uint32_t)n_buckets, ctx->n_cus);
-            if (dg.grid != 0) {     // (0: the table does not fit LDS)
-                int rc = ensure(ctx, ctx->sort_buf, dg.scratch);
-                if (rc) return rc;
-                hipError_t e = launch_window_direct(ctx->stream, (int)w, dt >= KNOX_INT64 && dt <= KNOX_INT8, dt, func, dg, (const int64_t *)time_col->dev,
-                                                    value_col->dev, mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets,
-                                                    ctx->sort_buf.p, ctx->win_values, ctx->win_seen);
-                if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-                ctx->win_values_done = true;
-                *states_dev = nullptr;
-                return KNOX_OK;
-            }
+        const WindowDirectGeom dg = (env && atoi(env) == 0) ? WindowDirectGeom{0, 0, 0, 0, 0}
+                                                            : window_direct_geom((int)w, value_col->dtype, ctx->win_func, (uint32_t)n_buckets, ctx->n_cus);
+        if (dg.grid != 0) {
+            int rc = ensure(ctx, ctx->sort_buf, dg.scratch);
+            if (rc) return rc;
+            hipError_t e = launch_window_direct(ctx->stream, (int)w, value_col->dtype, ctx->win_func, dg, (const int64_t *)time_col->dev, value_col->dev,
+                                                mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, ctx->sort_buf.p,
+                                                ctx->win_values, ctx->win_seen);
+            if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+            ctx->win_values_done = true;
+            *states_dev = nullptr;
+            return KNOX_OK;
         }
     }
     unsigned key_bits = 1;

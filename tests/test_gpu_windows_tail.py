@@ -315,8 +315,8 @@ def test_out_of_order_windows_behind_a_selection_compaction_forms_agree():
 
 
 def test_out_of_order_windows_order_free_values_without_the_sort():
-    """Sum / Count / Mean per window over out-of-order time and at most 4096 windows are pushed row by row into per-workgroup LDS
-    tables (window_direct_kernel) instead of being sorted first: byte-identical to the sorted path (KNOX_WINDOW_DIRECT=0), which the
+    """Value() per window of the reducers with an order-free form (count, first, last; over integers sum, mean, min, max) over
+    out-of-order time is folded row by row into per-workgroup LDS tables (window_direct_kernel) instead of being sorted first: byte-identical to the sorted path (KNOX_WINDOW_DIRECT=0), which the
     tests above hold to the oracle -- every integer width, values at the ends of their range (the exact sum behind Mean leaves 64
     bits), Count over a float column, no selection / thin / dense selections, window counts around the sizes at which the tables stop
     fitting LDS (Mean over 8-byte values 7987, Sum ~19 Ki, Count ~39 Ki; above them the sort)."""
@@ -339,7 +339,7 @@ def test_out_of_order_windows_order_free_values_without_the_sort():
                         v[: n // 2] = np.iinfo(np.int64).max - rng.integers(0, 5, n // 2)      # sums far beyond 64 bits
                     vcol = ctx.upload(v, 4096)
                     for m, sel in zip(masks, sels):
-                        for f in ((R.Count,) if bt == B.Float64 else (R.Sum, R.Count, R.Mean)):
+                        for f in ((R.Count, R.First, R.Last) if bt == B.Float64 else (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last)):
                             os.environ["KNOX_WINDOW_DIRECT"] = "0"
                             a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
                             want = (a.tobytes(), b.tobytes())
@@ -350,6 +350,16 @@ def test_out_of_order_windows_order_free_values_without_the_sort():
                                 inside = sel & (key >= 0) & (key < nb)
                                 cnt = np.bincount(key[inside], minlength=nb)
                                 assert (a.astype(np.float64) == cnt.astype(NP[bt]).astype(np.float64)).all() and (b == (cnt > 0)).all(), (n, nb, bt)
+                            if f in (R.First, R.Last):      # the value of the lowest / highest selected row of the window
+                                inside = sel & (key >= 0) & (key < nb)
+                                rows = np.flatnonzero(inside)
+                                pick = np.full(nb, -1, dtype=np.int64)
+                                if f == R.First:
+                                    pick[key[rows[::-1]]] = rows[::-1]
+                                else:
+                                    pick[key[rows]] = rows
+                                have = pick >= 0
+                                assert (b.astype(bool) == have).all() and a[have].tobytes() == v[pick[have]].tobytes(), (n, nb, bt, f)
                     vcol.free()
                 for o in [tcol] + masks[1:]:
                     o.free()
