@@ -392,6 +392,14 @@ struct WindowDirectGeom {
 WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_buckets, int n_cus);
 hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, WindowDirectGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                                 uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
+// ... and the whole state (integer columns): one walk below 8 bytes, two for 8-byte values
+struct WindowStateGeom {
+    uint32_t grid, n_slots, n_words;   // grid 0: not an integer column, or the table does not fit LDS
+    size_t lds, scratch;
+};
+WindowStateGeom window_state_geom(int width, int dtype, uint32_t n_buckets, int n_cus);
+hipError_t launch_window_state(hipStream_t s, int width, int dtype, WindowStateGeom g, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
+                               int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t row_base, void *scratch, AggStateDev *states_out);
 hipError_t launch_compact_keys_hist(hipStream_t s, const uint32_t *keys, uint64_t n, WindowSortGeom g, uint32_t bits0, uint32_t *hist, uint32_t *tot);
 hipError_t launch_window_sort_pass(hipStream_t s, int width, const uint32_t *keys_in, const uint32_t *idx_in, const void *val_in, uint64_t n,
                                    WindowSortGeom g, uint32_t shift, uint32_t nbits, uint32_t *hist, uint32_t *tot, uint32_t *keys_out,

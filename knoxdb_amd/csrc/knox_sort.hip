@@ -551,6 +551,305 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
     return hipGetLastError();
 }
 
+// ---- no sort at all, the whole state: every field of knox_agg_state as an order-free fold ---------------------------------------------
+// count, sums, first / last as above; "first occurrence wins" for min / max (reducer.go:256-296) asks for the LOWEST row holding the
+// window's smallest / largest value.  Below 8 bytes (order key, row id) fit ONE 64-bit atomic -- key << 32 | row under min,
+// key << 32 | ~row under max -- and one walk does it all (four 32-bit and three 64-bit atomics per selected row).  8-byte values: the
+// first walk folds the keys alone, one lane per window merges the workgroups' tables, and a second walk takes the lowest row among
+// the rows whose key EQUALS the window's merged min / max (atomics only for those).  Integer columns, no var / std pass, as many
+// windows as LDS holds a table for (36-44 B per window: ~3600-4400).
+template <typename U, bool SIGNED> struct StateShape {
+    static constexpr bool WIDE = sizeof(U) == 8;
+    static constexpr int NS = WIDE ? 4 : 3;                       // WIDE: A, B, minkey, maxkey; else: Z (zero-extended sum), minpack, maxpack
+    static constexpr int NW = WIDE ? 3 : (SIGNED ? 4 : 3);        // count, first row, last row + 1 [, values with the sign bit set]
+    static constexpr uint64_t SIGN = 1ull << (8 * sizeof(U) - 1);
+    __device__ static uint64_t key(U x) { return SIGNED ? ((uint64_t)x ^ SIGN) : (uint64_t)x; }
+};
+
+template <typename U, bool SIGNED>
+__global__ void __launch_bounds__(kDirectBlock) window_state_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                    uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint64_t *__restrict__ slots_out,
+                                                                    uint32_t *__restrict__ words_out) {
+    using SH = StateShape<U, SIGNED>;
+    constexpr int NS = SH::NS, NW = SH::NW;
+    extern __shared__ uint64_t direct_tab[];
+    uint64_t *slot = direct_tab;                                             // [NS][nb]
+    uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)NS * nb);   // [NW][nb]
+    for (uint32_t i = threadIdx.x; i < NS * nb; i += kDirectBlock) {
+        const uint32_t f = i / nb;
+        slot[i] = (SH::WIDE ? f == 2 : f == 1) ? ~0ull : 0ull;              // the minimum starts at the top
+    }
+    for (uint32_t i = threadIdx.x; i < NW * nb; i += kDirectBlock) word[i] = (i / nb) == 1 ? ~0u : 0u;   // so does the first row
+    __syncthreads();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    auto A64 = [&](int f, uint32_t q) { return reinterpret_cast<unsigned long long *>(&slot[(size_t)f * nb + q]); };
+    auto push = [&](int64_t t, U x, uint64_t row) {
+        const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
+        if (q == kNoKey) return;
+        const uint32_t r32 = (uint32_t)row;
+        const uint64_t key = SH::key(x);
+        atomicAdd(&word[q], 1u);
+        atomicMin(&word[nb + q], r32);
+        atomicMax(&word[2 * nb + q], r32 + 1u);
+        if constexpr (SH::WIDE) {
+            const uint64_t sx = (uint64_t)x;
+            atomicAdd(A64(0, q), (unsigned long long)(sx & 0xffffffffull));
+            atomicAdd(A64(1, q), (unsigned long long)(SIGNED ? (uint64_t)((int64_t)sx >> 32) : (sx >> 32)));
+            atomicMin(A64(2, q), (unsigned long long)key);
+            atomicMax(A64(3, q), (unsigned long long)key);
+        } else {
+            if constexpr (SIGNED) { if ((uint64_t)x & SH::SIGN) atomicAdd(&word[3 * nb + q], 1u); }
+            atomicAdd(A64(0, q), (unsigned long long)(uint64_t)x);
+            atomicMin(A64(1, q), (unsigned long long)((key << 32) | r32));
+            atomicMax(A64(2, q), (unsigned long long)((key << 32) | (uint32_t)~r32));
+        }
+    };
+    typedef long long t2 __attribute__((ext_vector_type(2)));
+    const uint32_t sh = (2u * lane) & 7u;
+    const uint64_t n_chunks = n_rows / 512;
+    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
+        const uint64_t c0 = c * 512;
+        uint32_t mb[4];
+        t2 t[4];
+        CompactPair<U> x[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) mb[h] = mask != nullptr ? mask[(c0 + 128u * h + 2u * lane) >> 3] : 0xffu;
+#pragma unroll
+        for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            x[h] = CompactPair<U>{0, 0};
+            if (mask == nullptr || ((mb[h] >> sh) & 3u)) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t m2 = (mb[h] >> sh) & 3u;
+            const uint64_t row = c0 + 128u * h + 2u * lane;
+            if (m2 & 1u) push(t[h].x, x[h].x, row);
+            if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
+            if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], val[r], r);
+    }
+    __syncthreads();
+    uint64_t *so = slots_out + (size_t)blockIdx.x * NS * nb;
+    uint32_t *wo = words_out + (size_t)blockIdx.x * NW * nb;
+    for (uint32_t i = threadIdx.x; i < NS * nb; i += kDirectBlock) so[i] = slot[i];
+    for (uint32_t i = threadIdx.x; i < NW * nb; i += kDirectBlock) wo[i] = word[i];
+}
+
+// one lane per window: the workgroups' tables folded -> merged[NS + NW][nb] (64-bit words)
+template <typename U, bool SIGNED>
+__global__ void __launch_bounds__(256) window_state_merge_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
+                                                                 uint64_t *__restrict__ merged) {
+    using SH = StateShape<U, SIGNED>;
+    constexpr int NS = SH::NS, NW = SH::NW;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    uint64_t f[NS], w[NW];
+#pragma unroll
+    for (int i = 0; i < NS; i++) f[i] = (SH::WIDE ? i == 2 : i == 1) ? ~0ull : 0ull;
+#pragma unroll
+    for (int i = 0; i < NW; i++) w[i] = i == 1 ? 0xffffffffull : 0ull;
+    for (uint32_t g = 0; g < grid; g++) {
+        const uint64_t *p = slots + (size_t)g * NS * nb + k;
+        const uint32_t *q = words + (size_t)g * NW * nb + k;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const uint64_t v = p[(size_t)i * nb];
+            const bool is_min = SH::WIDE ? i == 2 : i == 1, is_max = SH::WIDE ? i == 3 : i == 2;
+            f[i] = is_min ? (v < f[i] ? v : f[i]) : is_max ? (v > f[i] ? v : f[i]) : f[i] + v;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const uint64_t v = q[(size_t)i * nb];
+            w[i] = i == 1 ? (v < w[i] ? v : w[i]) : i == 2 ? (v > w[i] ? v : w[i]) : w[i] + v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++) merged[(size_t)i * nb + k] = f[i];
+#pragma unroll
+    for (int i = 0; i < NW; i++) merged[(size_t)(NS + i) * nb + k] = w[i];
+}
+
+// 8-byte values, second walk: the lowest row among those that hold the window's min / max key
+template <typename U, bool SIGNED>
+__global__ void __launch_bounds__(kDirectBlock) window_state_rows_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                         uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb,
+                                                                         const uint64_t *__restrict__ merged, uint32_t *__restrict__ rows_out) {
+    using SH = StateShape<U, SIGNED>;
+    extern __shared__ uint64_t direct_tab[];
+    uint64_t *gmin = direct_tab, *gmax = direct_tab + nb;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(direct_tab + 2 * (size_t)nb);      // min row | max row
+    for (uint32_t i = threadIdx.x; i < nb; i += kDirectBlock) {
+        gmin[i] = merged[2 * (size_t)nb + i];
+        gmax[i] = merged[3 * (size_t)nb + i];
+        rows[i] = ~0u;
+        rows[nb + i] = ~0u;
+    }
+    __syncthreads();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    auto push = [&](int64_t t, U x, uint64_t row) {
+        const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
+        if (q == kNoKey) return;
+        const uint64_t key = SH::key(x);
+        if (key == gmin[q]) atomicMin(&rows[q], (uint32_t)row);
+        if (key == gmax[q]) atomicMin(&rows[nb + q], (uint32_t)row);
+    };
+    typedef long long t2 __attribute__((ext_vector_type(2)));
+    const uint32_t sh = (2u * lane) & 7u;
+    const uint64_t n_chunks = n_rows / 512;
+    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
+        const uint64_t c0 = c * 512;
+        uint32_t mb[4];
+        t2 t[4];
+        CompactPair<U> x[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) mb[h] = mask != nullptr ? mask[(c0 + 128u * h + 2u * lane) >> 3] : 0xffu;
+#pragma unroll
+        for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            x[h] = CompactPair<U>{0, 0};
+            if (mask == nullptr || ((mb[h] >> sh) & 3u)) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t m2 = (mb[h] >> sh) & 3u;
+            const uint64_t row = c0 + 128u * h + 2u * lane;
+            if (m2 & 1u) push(t[h].x, x[h].x, row);
+            if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
+            if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], val[r], r);
+    }
+    __syncthreads();
+    uint32_t *ro = rows_out + (size_t)blockIdx.x * 2 * nb;
+    for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) ro[i] = rows[i];
+}
+
+// the states, as bucket_finalize_kernel writes them (rows2: the second walk's tables, 8-byte values only)
+template <typename U, bool SIGNED>
+__global__ void __launch_bounds__(256) window_state_finish_kernel(const uint64_t *__restrict__ merged, const uint32_t *__restrict__ rows2, uint32_t grid, uint32_t nb,
+                                                                  const U *__restrict__ val, uint64_t row_base, int dtype, AggStateDev *__restrict__ state_out) {
+    using SH = StateShape<U, SIGNED>;
+    constexpr int NS = SH::NS;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    const uint64_t count = merged[(size_t)(NS + 0) * nb + k], firstrow = merged[(size_t)(NS + 1) * nb + k], lastrow1 = merged[(size_t)(NS + 2) * nb + k];
+    uint64_t xlo, minkey, maxkey, minrow, maxrow;
+    int64_t xhi;
+    if constexpr (SH::WIDE) {
+        const uint64_t a = merged[k], b = merged[(size_t)nb + k];
+        const uint64_t blo = b << 32;
+        const int64_t bhi = SIGNED ? ((int64_t)b >> 32) : (int64_t)(b >> 32);
+        xlo = a + blo;
+        xhi = bhi + (int64_t)(xlo < a);
+        minkey = merged[2 * (size_t)nb + k];
+        maxkey = merged[3 * (size_t)nb + k];
+        uint32_t r0 = ~0u, r1 = ~0u;
+        for (uint32_t g = 0; g < grid; g++) {
+            const uint32_t a0 = rows2[(size_t)g * 2 * nb + k], a1 = rows2[(size_t)g * 2 * nb + nb + k];
+            r0 = a0 < r0 ? a0 : r0;
+            r1 = a1 < r1 ? a1 : r1;
+        }
+        minrow = r0;
+        maxrow = r1;
+    } else {
+        const uint64_t z = merged[k], minpack = merged[(size_t)nb + k], maxpack = merged[2 * (size_t)nb + k];
+        xlo = z;
+        xhi = 0;
+        if constexpr (SIGNED) {        // exact sum = zero-extended sum - 2^(8W) * (values with the sign bit set)
+            const uint64_t neg = merged[(size_t)(NS + 3) * nb + k] << (8 * sizeof(U));
+            xhi = -(int64_t)(xlo < neg);
+            xlo -= neg;
+        }
+        minkey = minpack >> 32;
+        maxkey = maxpack >> 32;
+        minrow = (uint32_t)minpack;
+        maxrow = (uint32_t)~(uint32_t)maxpack;
+    }
+    AggStateDev s;
+    s.dtype = dtype;
+    s.flags = 1u;
+    s.count = (int64_t)count;
+    s.isum = SH::WIDE ? xlo : merged[k];      // the wrapping sum of the zero-extended values
+    s.fsum_hi = 0.0;
+    s.fsum_lo = 0.0;
+    knox_fin::int128_to_dd(xlo, xhi, s.fsum_hi, s.fsum_lo);
+    const bool any = count != 0;
+    s.min_row = any ? (int64_t)(row_base + minrow) : -1;
+    s.max_row = any ? (int64_t)(row_base + maxrow) : -1;
+    s.first_row = any ? (int64_t)(row_base + firstrow) : -1;
+    s.last_row = any ? (int64_t)(row_base + lastrow1 - 1) : -1;
+    s.min_bits = any ? (SIGNED ? (minkey ^ SH::SIGN) : minkey) : 0;     // the key map is its own inverse
+    s.max_bits = any ? (SIGNED ? (maxkey ^ SH::SIGN) : maxkey) : 0;
+    s.first_bits = any ? (uint64_t)val[firstrow] : 0;
+    s.last_bits = any ? (uint64_t)val[lastrow1 - 1] : 0;
+    s.m_shift = 0.0; s.m_dev_hi = 0.0; s.m_dev_lo = 0.0; s.m_sq_hi = 0.0; s.m_sq_lo = 0.0;
+    state_out[k] = s;
+}
+
+WindowStateGeom window_state_geom(int width, int dtype, uint32_t n_buckets, int n_cus) {
+    WindowStateGeom g;
+    g.grid = 0;
+    g.lds = g.scratch = 0;
+    if (dtype < 1 || dtype > 8 || (width != 8 && width != 4 && width != 2 && width != 1)) return g;
+    const bool is_signed = dtype <= 4;
+    g.n_slots = width == 8 ? 4 : 3;
+    g.n_words = width == 8 ? 3 : (is_signed ? 4 : 3);
+    g.lds = (size_t)n_buckets * (8u * g.n_slots + 4u * g.n_words);
+    if (g.lds > 156 * 1024) return g;
+    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
+    // workgroup tables | merged | second walk's tables
+    g.scratch = (size_t)g.grid * g.lds + (size_t)(g.n_slots + g.n_words) * n_buckets * 8 + (size_t)g.grid * 2 * n_buckets * 4 + 1024;
+    return g;
+}
+
+hipError_t launch_window_state(hipStream_t s, int width, int dtype, WindowStateGeom g, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
+                               int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t row_base, void *scratch, AggStateDev *states_out) {
+    if (n_buckets == 0 || g.grid == 0) return hipErrorInvalidValue;
+    const bool is_signed = dtype >= 1 && dtype <= 4;
+    uint64_t *slots = (uint64_t *)scratch;
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.n_slots * n_buckets);
+    uint64_t *merged = (uint64_t *)((char *)scratch + (((size_t)g.grid * g.lds + 255) & ~(size_t)255));
+    uint32_t *rows2 = (uint32_t *)(merged + (size_t)(g.n_slots + g.n_words) * n_buckets);
+    const dim3 fgrid((n_buckets + 255) / 256), fblock(256);
+    const size_t lds2 = (size_t)n_buckets * 24;
+#define KNOX_STATE(U, S)                                                                                                                            \
+    do {                                                                                                                                            \
+        if (g.lds > 48 * 1024) {                                                                                                                    \
+            (void)hipFuncSetAttribute((const void *)window_state_kernel<U, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);             \
+            (void)hipFuncSetAttribute((const void *)window_state_rows_kernel<U, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);        \
+        }                                                                                                                                           \
+        hipLaunchKernelGGL((window_state_kernel<U, S>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
+                           slots, words);                                                                                                           \
+        hipLaunchKernelGGL((window_state_merge_kernel<U, S>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, merged); \
+        if (sizeof(U) == 8)                                                                                                                         \
+            hipLaunchKernelGGL((window_state_rows_kernel<U, S>), dim3(g.grid), dim3(kDirectBlock), lds2, s, time, (const U *)val, mask, n_rows, t_from, step,  \
+                               n_buckets, (const uint64_t *)merged, rows2);                                                                         \
+        hipLaunchKernelGGL((window_state_finish_kernel<U, S>), fgrid, fblock, 0, s, (const uint64_t *)merged, (const uint32_t *)rows2, g.grid, n_buckets, \
+                           (const U *)val, row_base, dtype, states_out);                                                                            \
+    } while (0)
+    switch (width) {
+    case 8: if (is_signed) KNOX_STATE(uint64_t, true); else KNOX_STATE(uint64_t, false); break;
+    case 4: if (is_signed) KNOX_STATE(uint32_t, true); else KNOX_STATE(uint32_t, false); break;
+    case 2: if (is_signed) KNOX_STATE(uint16_t, true); else KNOX_STATE(uint16_t, false); break;
+    case 1: if (is_signed) KNOX_STATE(uint8_t, true); else KNOX_STATE(uint8_t, false); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef KNOX_STATE
+    return hipGetLastError();
+}
+
 // ---- later passes, step 1: digit histogram of the keys as the previous pass left them --------------------------------
 __global__ void __launch_bounds__(kSortBlock) key_hist_kernel(const uint32_t *__restrict__ keys, uint64_t n, uint64_t per_block, uint32_t shift,
                                                               uint32_t dmask, uint32_t *__restrict__ hist, int skip_nokey) {

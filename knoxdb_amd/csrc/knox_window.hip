@@ -122,8 +122,24 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_kernel(const ScanArgs a,
         FirstLast fl;
         fl.init();
         uint32_t cnt32 = 0;
-        // aligned middle: whole wave tiles, vector path
-        const uint64_t a0 = (rb + WAVE_ROWS - 1) / WAVE_ROWS, a1 = re / WAVE_ROWS;  // tile indices [a0, a1)
+        const uint64_t a0 = (rb + WAVE_ROWS - 1) / WAVE_ROWS, a1 = re / WAVE_ROWS;  // tile indices [a0, a1) of the aligned middle
+        // ragged edges (or the whole item when it holds no aligned tile): one row per lane, exact per-row update.  A lane must meet its
+        // rows in ASCENDING order -- min / max adopt a value only when it is strictly better, which is what makes the first occurrence
+        // win --, so the head edge goes BEFORE the middle (it came after it until late in round 4: a window whose smallest value stood
+        // in its first, unaligned rows and again further down reported the later row; found by the sort-free states agreeing with numpy
+        // and not with this kernel)
+        const uint64_t e0 = a0 < a1 ? a0 * WAVE_ROWS : re;  // head edge [rb, e0)
+        const uint64_t e1 = a0 < a1 ? a1 * WAVE_ROWS : re;  // tail edge [e1, re)
+        auto edge = [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t row = lo + threadIdx.x; row < hi; row += blockDim.x) {
+                const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
+                acc.count += hit;
+                acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
+            }
+        };
+        edge(rb, e0);
+        // aligned middle: whole wave tiles, vector path (its first iteration takes the exact min / max path and reads the wave's bounds
+        // from the accumulators the head edge left)
         for (uint64_t t = a0 + wave; t < a1; t += kWavesPerBlock) {
             const uint64_t row0 = t * WAVE_ROWS;
             const u32x4 *p = (const u32x4 *)a.agg_col + row0 / K + lane;
@@ -141,18 +157,7 @@ __global__ void __launch_bounds__(kBlock) bucket_reduce_kernel(const ScanArgs a,
             }
             agg_iter<W, AGG, FLV>(acc, wm, fl, ra, q, row0, a.row_base, lane);
         }
-        // ragged edges (or the whole item when it holds no aligned tile): one row per lane, rows
-        // ascending per lane, exact per-row update
-        const uint64_t e0 = a0 < a1 ? a0 * WAVE_ROWS : re;  // head edge [rb, e0)
-        const uint64_t e1 = a0 < a1 ? a1 * WAVE_ROWS : re;  // tail edge [e1, re)
-        for (int part = 0; part < 2; part++) {
-            const uint64_t lo = part == 0 ? rb : e1, hi = part == 0 ? e0 : re;
-            for (uint64_t row = lo + threadIdx.x; row < hi; row += blockDim.x) {
-                const uint32_t hit = mask8 ? (uint32_t)((mask8[row >> 3] >> (row & 7)) & 1u) : 1u;
-                acc.count += hit;
-                acc_update<W, (AGG | A_FIRSTLAST)>(acc, load_elem<W>(a.agg_col, row), hit, a.row_base + row, FLV);
-            }
-        }
+        edge(e1, re);
         acc.count += cnt32;
         if constexpr ((AGG & A_FIRSTLAST) != 0) fl.template finish<K>(acc, a.row_base, lane);
         block_reduce_store(acc, a.partials + it);

@@ -113,6 +113,23 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             return KNOX_OK;
         }
     }
+    // ... and the whole state of every window the same way (integer columns, no var / std pass to follow, ~3600-4400 windows at most):
+    // window_state_kernel, one walk below 8 bytes, two for 8-byte values
+    if (!(flags & 2) && n_buckets <= 8192) {
+        const char *env = getenv("KNOX_WINDOW_DIRECT");
+        const WindowStateGeom sg = (env && atoi(env) == 0) ? WindowStateGeom{0, 0, 0, 0, 0} : window_state_geom((int)w, value_col->dtype, (uint32_t)n_buckets, ctx->n_cus);
+        if (sg.grid != 0) {
+            int rc = ensure(ctx, ctx->sort_buf, sg.scratch);
+            if (!rc) rc = ensure(ctx, ctx->tmp_vals, n_buckets * sizeof(AggStateDev) + 64);
+            if (rc) return rc;
+            hipError_t e = launch_window_state(ctx->stream, (int)w, value_col->dtype, sg, (const int64_t *)time_col->dev, value_col->dev,
+                                               mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, row_base, ctx->sort_buf.p,
+                                               (AggStateDev *)ctx->tmp_vals.p);
+            if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+            *states_dev = (char *)ctx->tmp_vals.p;
+            return KNOX_OK;
+        }
+    }
     unsigned key_bits = 1;
     while ((1ull << key_bits) < n_buckets) key_bits++;  // keys 0..n_buckets-1 (rows outside every window leave in the first pass)
     uint32_t bits[4] = {0, 0, 0, 0};

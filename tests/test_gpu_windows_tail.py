@@ -367,3 +367,84 @@ def test_out_of_order_windows_order_free_values_without_the_sort():
         os.environ.pop("KNOX_WINDOW_DIRECT", None)
         if old is not None:
             os.environ["KNOX_WINDOW_DIRECT"] = old
+
+
+def test_out_of_order_windows_whole_states_without_the_sort():
+    """knox_reduce_buckets over out-of-order time, integer columns, up to a few thousand windows: every state field folded by LDS
+    atomics where the rows lie (window_state_kernel; 8-byte values take a second walk for the rows of min / max) -- byte-identical
+    to the sorted path's states (KNOX_WINDOW_DIRECT=0), with ties for min / max (first occurrence wins), values at the ends of their
+    range, no / thin / dense selections, a row base, window counts around the LDS limits (3630 / 3993 / 4437) and the empty windows."""
+    import os
+    rng = np.random.default_rng(909)
+    old = os.environ.pop("KNOX_WINDOW_DIRECT", None)
+    try:
+        with K.Context(0) as ctx:
+            for n, nb, step in ((900_001, 700, 9), (300, 1, 50), (150_000, 3630, 2), (150_000, 3631, 2), (150_000, 3993, 2), (150_000, 4437, 2), (150_000, 4438, 2),
+                                (2_000, 3000, 1 << 30)):
+                t_from = 7_000_000_000
+                key = rng.integers(-2, nb + 2, n)
+                t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
+                tcol = ctx.upload(t, 4096)
+                masks = [None] + [ctx.bits(n).upload(np.packbits(rng.random(n) < p, bitorder="little")) for p in (0.04, 0.6)]
+                for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8):
+                    for narrow in (False, True):
+                        v = _values(rng, bt, n)
+                        if narrow:
+                            v = (v % 5).astype(v.dtype)           # many rows share a window's min / max: the lowest row must win
+                        elif bt == B.Int64:
+                            v[: n // 2] = np.iinfo(np.int64).min + rng.integers(0, 5, n // 2)
+                        vcol = ctx.upload(v, 4096)
+                        for m in masks:
+                            for base in (0, 1 << 33):
+                                os.environ["KNOX_WINDOW_DIRECT"] = "0"
+                                want = bytes(ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=m, row_base=base))
+                                os.environ.pop("KNOX_WINDOW_DIRECT")
+                                got = bytes(ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=m, row_base=base))
+                                assert got == want, (n, nb, bt, narrow, m is not None, base)
+                        vcol.free()
+                for o in [tcol] + masks[1:]:
+                    o.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_DIRECT", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_DIRECT"] = old
+
+
+def test_min_max_rows_are_first_occurrences_in_every_launch_form():
+    """MinReducer / MaxReducer adopt a value only when it is strictly better (reducer.go:256-296): among equal values the FIRST row
+    wins.  Windows that do not start on a tile boundary, few distinct values (the smallest stands in a window's first, unaligned rows
+    and again further down): min_row / max_row against numpy for the workgroup, wave and 16-lane forms of the reduce step.  (Until
+    late in round 4 the workgroup form walked a window's unaligned head AFTER its aligned middle and reported the later row.)"""
+    import os
+    rng = np.random.default_rng(5150)
+    n, nb, step, t_from = 700_003, 257, 11, 1000
+    key = np.sort(rng.integers(-1, nb + 1, n))
+    t = (t_from + key * step + np.sort(rng.integers(0, step, n)) * 0).astype(np.int64)
+    old = os.environ.pop("KNOX_WINDOW_FORM", None)
+    try:
+        with K.Context(0) as ctx:
+            tcol = ctx.upload(t, 4096)
+            mask = ctx.bits(n).upload(np.packbits(rng.random(n) < 0.7, bitorder="little"))
+            sel = np.unpackbits(mask.bytes(), bitorder="little")[:n].astype(bool)
+            for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8, B.Float64):
+                v = (rng.integers(0, 4, n) - 2).astype(NP[bt]) if bt != B.Float64 else (rng.integers(0, 4, n) / 2.0 - 1.0)
+                if np.dtype(NP[bt]).kind == "i":
+                    v[rng.random(n) < 0.2] = np.iinfo(NP[bt]).min
+                vcol = ctx.upload(v.astype(NP[bt]), 4096)
+                for m, s in ((None, np.ones(n, dtype=bool)), (mask, sel)):
+                    for form in ("block", "wave", "group"):
+                        os.environ["KNOX_WINDOW_FORM"] = form
+                        st = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=m)
+                        for k in range(nb):
+                            rows = np.flatnonzero((key == k) & s)
+                            if rows.size == 0:
+                                assert st[k].count == 0
+                                continue
+                            vv = v[rows].astype(np.float64)
+                            assert st[k].min_row == rows[np.argmin(vv)] and st[k].max_row == rows[np.argmax(vv)], (bt, form, k, m is not None)
+                vcol.free()
+            tcol.free(); mask.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_FORM", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_FORM"] = old
