@@ -325,20 +325,28 @@ hipError_t launch_window_compact(hipStream_t s, int width, const int64_t *time, 
 // Round 4 had built the same for EVERY state field at once (eight 64-bit atomics and a 64-bit division per row, two passes: 4.07 ms
 // for 2^28 rows -> 1024 windows against the sort's 2.88) and dropped it; with the division gone the walk runs at streaming rate
 // (0.74-0.84 ms, with or without a selection, 1024 .. 16384 windows) and it is the sort that loses.  The sort keeps: float sums and
-// means (double-double sums are not atomic), float min / max (-0 / +0 and NaN make them order-dependent), var / std (a second,
-// centred pass over each window's rows) and every window count whose table does not fit.
-enum { kDirectSum = 0, kDirectFirst = 1, kDirectLast = 2, kDirectMin = 3, kDirectMax = 4, kDirectMean = 5, kDirectCount = 8 };   // == knox_reducer
+// means (double-double sums are not atomic), var / std (a second, centred pass over each window's rows) and every window count whose
+// table does not fit.
+enum { kDirectSum = 0, kDirectFirst = 1, kDirectLast = 2, kDirectMin = 3, kDirectMax = 4, kDirectMean = 5, kDirectCount = 8,   // == knox_reducer
+       kDirectFMin = 16, kDirectFMax = 17 };   // min / max of a FLOAT column (below)
 constexpr int kDirectBlock = 1024;
 constexpr int kDirectWaves = kDirectBlock / 64;
 
 // what a mode keeps per window
+// Float min / max (reducer.go:256-296 as acc_update restates it, knox_dev.h): a NaN is never adopted, -0 and +0 compare equal (ONE
+// order key), the first occurrence wins, and a NaN as the window's FIRST value sticks.  Value() needs no row id, so the order only
+// matters where equal keys have different bits -- the two zeros: the slot folds the order key, one word the lowest selected row (its
+// value decides the NaN rule), another the lowest row holding a zero (read only when the winning key is zero's).
 template <int MODE, int W> struct DirectShape {
+    static constexpr bool FMINMAX = MODE == kDirectFMin || MODE == kDirectFMax;
     static constexpr int NS = MODE == kDirectCount ? 0 : (MODE == kDirectMean && W == 8) ? 2 : 1;              // 64-bit slots
     static constexpr bool COUNTS = MODE == kDirectCount || MODE == kDirectMean;                                 // a 32-bit count
     static constexpr bool BITS = MODE == kDirectSum || MODE == kDirectMin || MODE == kDirectMax;                // a "seen" bit
-    static constexpr bool VALUES = MODE == kDirectSum || MODE == kDirectMean || MODE == kDirectMin || MODE == kDirectMax;   // the walk reads the values
-    static constexpr uint64_t INIT = (MODE == kDirectMin || MODE == kDirectFirst) ? ~0ull : 0ull;              // first: lowest row; last: highest row + 1
-    __host__ __device__ static constexpr uint32_t words(uint32_t nb) { return COUNTS ? nb : BITS ? (nb + 31) / 32 : 0; }
+    static constexpr bool VALUES = MODE == kDirectSum || MODE == kDirectMean || MODE == kDirectMin || MODE == kDirectMax || FMINMAX;   // the walk reads the values
+    static constexpr uint64_t INIT = (MODE == kDirectMin || MODE == kDirectFirst || MODE == kDirectFMin) ? ~0ull : 0ull;   // first: lowest row; last: highest row + 1
+    static constexpr uint32_t WINIT = FMINMAX ? ~0u : 0u;
+    static constexpr int FUNC = MODE == kDirectFMin ? kDirectMin : MODE == kDirectFMax ? kDirectMax : MODE;     // the knox_reducer Value() is asked for
+    __host__ __device__ static constexpr uint32_t words(uint32_t nb) { return FMINMAX ? 2 * nb : COUNTS ? nb : BITS ? (nb + 31) / 32 : 0; }
 };
 
 template <typename U, bool SIGNED, int MODE>
@@ -352,7 +360,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
     uint32_t *cnt = reinterpret_cast<uint32_t *>(direct_tab + (size_t)NS * nb);
     const uint32_t nc = SH::words(nb);
     for (uint32_t i = threadIdx.x; i < NS * nb; i += kDirectBlock) direct_tab[i] = SH::INIT;
-    for (uint32_t i = threadIdx.x; i < nc; i += kDirectBlock) cnt[i] = 0;
+    for (uint32_t i = threadIdx.x; i < nc; i += kDirectBlock) cnt[i] = SH::WINIT;
     __syncthreads();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint64_t span = (uint64_t)nb * (uint64_t)step;
@@ -360,6 +368,20 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
     auto push = [&](int64_t t, U x, uint64_t row) {
         const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
         if (q == kNoKey) return;
+        if constexpr (SH::FMINMAX) {
+            constexpr U SIGN = (U)1 << (8 * sizeof(U) - 1);
+            constexpr U EXPMASK = sizeof(U) == 8 ? (U)0x7ff0000000000000ull : (U)0x7f800000u;
+            const U mag = x & (U)~SIGN;
+            atomicMin(&cnt[q], (uint32_t)row);
+            if (mag <= EXPMASK) {            // not a NaN
+                const U fk = mag == 0 ? SIGN : ((x & SIGN) ? (U)~x : (U)(x | SIGN));
+                unsigned long long *pk = reinterpret_cast<unsigned long long *>(&s0[q]);
+                if constexpr (MODE == kDirectFMin) atomicMin(pk, (unsigned long long)fk);
+                else atomicMax(pk, (unsigned long long)fk);
+                if (mag == 0) atomicMin(&cnt[nb + q], (uint32_t)row);
+            }
+            return;
+        }
         if constexpr (SH::BITS) atomicOr(&cnt[q >> 5], 1u << (q & 31));      // Value() asks only whether the window saw a row
         if constexpr (SH::COUNTS) atomicAdd(&cnt[q], 1u);
         unsigned long long *p0 = reinterpret_cast<unsigned long long *>(&s0[q]);
@@ -427,21 +449,43 @@ __global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_
                                                                    const U *__restrict__ val, int dtype, void *values, uint8_t *seen) {
     using SH = DirectShape<MODE, (int)sizeof(U)>;
     constexpr int NS = SH::NS;
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nb) return;
+    // 64 windows per workgroup, the tables dealt to its four waves (a lane per window and table in turn: 512 dependent-free but
+    // serial loads per lane took 108 us for 16384 windows, a seventh of the walk itself); the waves' folds meet in LDS
+    __shared__ uint64_t f_cnt[4][64], f_a[4][64], f_b[4][64];
+    __shared__ uint32_t f_fr[4][64], f_zr[4][64];
+    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64 + lane;
+    const bool valid = k < nb;
     const uint32_t nc = SH::words(nb);
     uint64_t count = 0, a = SH::INIT, b = 0;
-    for (uint32_t g = 0; g < grid; g++) {
-        if constexpr (SH::BITS) count |= (words[(size_t)g * nc + (k >> 5)] >> (k & 31)) & 1u;     // (0 / 1: "seen")
-        if constexpr (SH::COUNTS) count += words[(size_t)g * nc + k];
-        if constexpr (NS >= 1) {
-            const uint64_t v = slots[((size_t)g * NS + 0) * nb + k];
-            if constexpr (MODE == kDirectMin || MODE == kDirectFirst) a = v < a ? v : a;
-            else if constexpr (MODE == kDirectMax || MODE == kDirectLast) a = v > a ? v : a;
-            else a += v;
+    uint32_t frow = ~0u, zrow = ~0u;      // float min / max: the lowest selected row, the lowest row holding a zero
+    auto fold = [&](uint64_t c2, uint64_t a2, uint64_t b2, uint32_t f2, uint32_t z2) {
+        if constexpr (SH::BITS) count |= c2; else count += c2;
+        if constexpr (MODE == kDirectMin || MODE == kDirectFirst || MODE == kDirectFMin) a = a2 < a ? a2 : a;
+        else if constexpr (MODE == kDirectMax || MODE == kDirectLast || MODE == kDirectFMax) a = a2 > a ? a2 : a;
+        else a += a2;
+        b += b2;                               // two's complement: the signed high parts add as unsigned words
+        frow = f2 < frow ? f2 : frow;
+        zrow = z2 < zrow ? z2 : zrow;
+    };
+    if (valid) {
+#pragma unroll 4
+        for (uint32_t g = part; g < grid; g += 4) {
+            uint64_t c2 = 0, a2 = SH::INIT, b2 = 0;
+            uint32_t f2 = ~0u, z2 = ~0u;
+            if constexpr (SH::FMINMAX) { f2 = words[(size_t)g * nc + k]; z2 = words[(size_t)g * nc + nb + k]; }
+            if constexpr (SH::BITS) c2 = (words[(size_t)g * nc + (k >> 5)] >> (k & 31)) & 1u;     // (0 / 1: "seen")
+            if constexpr (SH::COUNTS) c2 = words[(size_t)g * nc + k];
+            if constexpr (NS >= 1) a2 = slots[((size_t)g * NS + 0) * nb + k];
+            if constexpr (NS == 2) b2 = slots[((size_t)g * NS + 1) * nb + k];
+            fold(c2, a2, b2, f2, z2);
         }
-        if constexpr (NS == 2) b += slots[((size_t)g * NS + 1) * nb + k];     // two's complement: the signed high parts add as unsigned words
     }
+    f_cnt[part][lane] = count; f_a[part][lane] = a; f_b[part][lane] = b; f_fr[part][lane] = frow; f_zr[part][lane] = zrow;
+    __syncthreads();
+    if (part != 0 || !valid) return;
+#pragma unroll
+    for (int w = 1; w < 4; w++) fold(f_cnt[w][lane], f_a[w][lane], f_b[w][lane], f_fr[w][lane], f_zr[w][lane]);
     AggStateDev s;
     s.dtype = dtype;
     s.flags = 1u;
@@ -466,6 +510,17 @@ __global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_
         const uint64_t raw = SIGNED ? (a ^ (1ull << (8 * sizeof(U) - 1))) : a;      // the key map is its own inverse
         s.min_bits = s.max_bits = raw;
         s.min_row = s.max_row = count ? 0 : -1;
+    } else if constexpr (SH::FMINMAX) {
+        constexpr uint64_t SIGN = 1ull << (8 * sizeof(U) - 1);
+        count = frow != ~0u;
+        if (count) {
+            s.first_bits = (uint64_t)val[frow];
+            if (a != SH::INIT) {          // a value that is not a NaN was seen
+                const uint64_t raw = a == SIGN ? (uint64_t)val[zrow] : ((a & SIGN) ? (a ^ SIGN) : (uint64_t)(U)~(U)a);
+                s.min_bits = s.max_bits = raw;
+                s.min_row = s.max_row = 0;
+            }
+        }
     } else if constexpr (MODE == kDirectFirst) {
         count = a != ~0ull;
         if (count) { s.first_bits = (uint64_t)val[a]; }
@@ -474,11 +529,11 @@ __global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_
         if (count) { s.last_bits = (uint64_t)val[a - 1]; s.last_row = (int64_t)(a - 1); }
     }
     s.count = (int64_t)count;
-    s.first_row = count ? (MODE == kDirectFirst ? (int64_t)a : 0) : -1;
+    s.first_row = count ? (MODE == kDirectFirst ? (int64_t)a : SH::FMINMAX ? (int64_t)frow : 0) : -1;
     uint64_t bits = 0;
     int sn = 0;
     int64_t row = -1;
-    const int rc = knox_fin::agg_value_bits(s, MODE, &bits, &sn, &row);
+    const int rc = knox_fin::agg_value_bits(s, SH::FUNC, &bits, &sn, &row);
     reinterpret_cast<U *>(values)[k] = (U)bits;
     seen[k] = (rc == 0 && sn) ? 1 : 0;
 }
@@ -492,11 +547,13 @@ WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_b
     g.n_slots = g.n_words = 0;
     g.lds = g.scratch = 0;
     const bool integer = dtype >= 1 && dtype <= 8, numeric = dtype >= 1 && dtype <= 10;
-    const bool ok = (func == kDirectCount || func == kDirectFirst || func == kDirectLast) ? numeric
-                  : (func == kDirectSum || func == kDirectMean || func == kDirectMin || func == kDirectMax) ? integer : false;
+    const bool fminmax = !integer && (func == kDirectMin || func == kDirectMax);
+    const bool ok = (func == kDirectCount || func == kDirectFirst || func == kDirectLast || func == kDirectMin || func == kDirectMax) ? numeric
+                  : (func == kDirectSum || func == kDirectMean) ? integer : false;
     if (!ok || (width != 8 && width != 4 && width != 2 && width != 1)) return g;
     g.n_slots = func == kDirectCount ? 0 : (func == kDirectMean && width == 8) ? 2 : 1;
-    g.n_words = (func == kDirectCount || func == kDirectMean) ? n_buckets : (func == kDirectFirst || func == kDirectLast) ? 0 : (n_buckets + 31) / 32;
+    g.n_words = fminmax ? 2 * n_buckets
+              : (func == kDirectCount || func == kDirectMean) ? n_buckets : (func == kDirectFirst || func == kDirectLast) ? 0 : (n_buckets + 31) / 32;
     g.lds = ((size_t)n_buckets * 8u * g.n_slots + (size_t)g.n_words * 4u + 7) & ~(size_t)7;
     if (g.lds > 156 * 1024) return g;
     g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);   // 1024 threads each: two fill a CU
@@ -508,10 +565,10 @@ WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_b
 hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, WindowDirectGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                                 uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen) {
     if (n_buckets == 0 || g.grid == 0) return hipErrorInvalidValue;
-    const bool is_signed = dtype >= 1 && dtype <= 4;
+    const bool is_signed = dtype >= 1 && dtype <= 4, is_float = dtype == 9 || dtype == 10;
     uint64_t *slots = (uint64_t *)scratch;
     uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.n_slots * n_buckets);
-    const dim3 fgrid((n_buckets + 255) / 256), fblock(256);
+    const dim3 fgrid((n_buckets + 63) / 64), fblock(256);
 #define KNOX_DIRECT(U, S, MODE)                                                                                                                     \
     do {                                                                                                                                            \
         if (g.lds > 48 * 1024)                                                                                                                      \
@@ -533,8 +590,8 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
         case kDirectLast: KNOX_DIRECT(U, false, kDirectLast); break;                          \
         case kDirectSum: KNOX_DIRECT_S(U, kDirectSum); break;                                 \
         case kDirectMean: KNOX_DIRECT_S(U, kDirectMean); break;                               \
-        case kDirectMin: KNOX_DIRECT_S(U, kDirectMin); break;                                 \
-        case kDirectMax: KNOX_DIRECT_S(U, kDirectMax); break;                                 \
+        case kDirectMin: if (is_float) KNOX_DIRECT(U, false, kDirectFMin); else KNOX_DIRECT_S(U, kDirectMin); break;   \
+        case kDirectMax: if (is_float) KNOX_DIRECT(U, false, kDirectFMax); else KNOX_DIRECT_S(U, kDirectMax); break;   \
         default: return hipErrorInvalidValue;                                                 \
         }                                                                                     \
     } while (0)
@@ -647,33 +704,45 @@ template <typename U, bool SIGNED>
 __global__ void __launch_bounds__(256) window_state_merge_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
                                                                  uint64_t *__restrict__ merged) {
     using SH = StateShape<U, SIGNED>;
-    constexpr int NS = SH::NS, NW = SH::NW;
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nb) return;
-    uint64_t f[NS], w[NW];
+    constexpr int NS = SH::NS, NW = SH::NW, NF = NS + NW;
+    // 64 windows per workgroup, the tables dealt to its four waves (see window_direct_finish_kernel)
+    __shared__ uint64_t part_f[4][NF][64];
+    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64 + lane;
+    const bool valid = k < nb;
+    uint64_t f[NF];
+    auto is_min = [](int i) { return i < NS ? (SH::WIDE ? i == 2 : i == 1) : (i - NS) == 1; };
+    auto is_max = [](int i) { return i < NS ? (SH::WIDE ? i == 3 : i == 2) : (i - NS) == 2; };
 #pragma unroll
-    for (int i = 0; i < NS; i++) f[i] = (SH::WIDE ? i == 2 : i == 1) ? ~0ull : 0ull;
+    for (int i = 0; i < NF; i++) f[i] = is_min(i) ? (i < NS ? ~0ull : 0xffffffffull) : 0ull;
+    if (valid) {
+#pragma unroll 2
+        for (uint32_t g = part; g < grid; g += 4) {
+            const uint64_t *p = slots + (size_t)g * NS * nb + k;
+            const uint32_t *q = words + (size_t)g * NW * nb + k;
+            uint64_t v[NF];
 #pragma unroll
-    for (int i = 0; i < NW; i++) w[i] = i == 1 ? 0xffffffffull : 0ull;
-    for (uint32_t g = 0; g < grid; g++) {
-        const uint64_t *p = slots + (size_t)g * NS * nb + k;
-        const uint32_t *q = words + (size_t)g * NW * nb + k;
+            for (int i = 0; i < NS; i++) v[i] = p[(size_t)i * nb];
 #pragma unroll
-        for (int i = 0; i < NS; i++) {
-            const uint64_t v = p[(size_t)i * nb];
-            const bool is_min = SH::WIDE ? i == 2 : i == 1, is_max = SH::WIDE ? i == 3 : i == 2;
-            f[i] = is_min ? (v < f[i] ? v : f[i]) : is_max ? (v > f[i] ? v : f[i]) : f[i] + v;
-        }
+            for (int i = 0; i < NW; i++) v[NS + i] = q[(size_t)i * nb];
 #pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const uint64_t v = q[(size_t)i * nb];
-            w[i] = i == 1 ? (v < w[i] ? v : w[i]) : i == 2 ? (v > w[i] ? v : w[i]) : w[i] + v;
+            for (int i = 0; i < NF; i++) f[i] = is_min(i) ? (v[i] < f[i] ? v[i] : f[i]) : is_max(i) ? (v[i] > f[i] ? v[i] : f[i]) : f[i] + v[i];
         }
     }
 #pragma unroll
-    for (int i = 0; i < NS; i++) merged[(size_t)i * nb + k] = f[i];
+    for (int i = 0; i < NF; i++) part_f[part][i][lane] = f[i];
+    __syncthreads();
+    if (part != 0 || !valid) return;
 #pragma unroll
-    for (int i = 0; i < NW; i++) merged[(size_t)(NS + i) * nb + k] = w[i];
+    for (int w = 1; w < 4; w++) {
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            const uint64_t v = part_f[w][i][lane];
+            f[i] = is_min(i) ? (v < f[i] ? v : f[i]) : is_max(i) ? (v > f[i] ? v : f[i]) : f[i] + v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF; i++) merged[(size_t)i * nb + k] = f[i];
 }
 
 // 8-byte values, second walk: the lowest row among those that hold the window's min / max key
@@ -832,7 +901,8 @@ hipError_t launch_window_state(hipStream_t s, int width, int dtype, WindowStateG
         }                                                                                                                                           \
         hipLaunchKernelGGL((window_state_kernel<U, S>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
                            slots, words);                                                                                                           \
-        hipLaunchKernelGGL((window_state_merge_kernel<U, S>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, merged); \
+        hipLaunchKernelGGL((window_state_merge_kernel<U, S>), dim3((n_buckets + 63) / 64), fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
+                           n_buckets, merged);                                                                                                      \
         if (sizeof(U) == 8)                                                                                                                         \
             hipLaunchKernelGGL((window_state_rows_kernel<U, S>), dim3(g.grid), dim3(kDirectBlock), lds2, s, time, (const U *)val, mask, n_rows, t_from, step,  \
                                n_buckets, (const uint64_t *)merged, rows2);                                                                         \

@@ -315,7 +315,7 @@ def test_out_of_order_windows_behind_a_selection_compaction_forms_agree():
 
 
 def test_out_of_order_windows_order_free_values_without_the_sort():
-    """Value() per window of the reducers with an order-free form (count, first, last; over integers sum, mean, min, max) over
+    """Value() per window of the reducers with an order-free form (count, first, last, min, max; over integers sum and mean) over
     out-of-order time is folded row by row into per-workgroup LDS tables (window_direct_kernel) instead of being sorted first: byte-identical to the sorted path (KNOX_WINDOW_DIRECT=0), which the
     tests above hold to the oracle -- every integer width, values at the ends of their range (the exact sum behind Mean leaves 64
     bits), Count over a float column, no selection / thin / dense selections, window counts around the sizes at which the tables stop
@@ -333,13 +333,17 @@ def test_out_of_order_windows_order_free_values_without_the_sort():
                 tcol = ctx.upload(t, 4096)
                 masks = [None] + [ctx.bits(n).upload(np.packbits(rng.random(n) < p, bitorder="little")) for p in (0.04, 0.6)]
                 sels = [np.ones(n, dtype=bool)] + [np.unpackbits(m.bytes(), bitorder="little")[:n].astype(bool) for m in masks[1:]]
-                for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8, B.Float64):
+                for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8, B.Float64, B.Float32):
                     v = _values(rng, bt, n)
                     if bt == B.Int64:
                         v[: n // 2] = np.iinfo(np.int64).max - rng.integers(0, 5, n // 2)      # sums far beyond 64 bits
+                    if bt in (B.Float64, B.Float32):      # zeros of both signs and NaNs everywhere: first occurrence, NaN-first rule
+                        v[rng.random(n) < 0.3] = 0.0
+                        v[rng.random(n) < 0.2] = -0.0
+                        v[rng.random(n) < 0.1] = np.nan
                     vcol = ctx.upload(v, 4096)
                     for m, sel in zip(masks, sels):
-                        for f in ((R.Count, R.First, R.Last) if bt == B.Float64 else (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last)):
+                        for f in ((R.Count, R.First, R.Last, R.Min, R.Max) if bt in (B.Float64, B.Float32) else (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last)):
                             os.environ["KNOX_WINDOW_DIRECT"] = "0"
                             a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
                             want = (a.tobytes(), b.tobytes())

@@ -135,8 +135,12 @@ while time.time() < t_end:
         t = rng.integers(lo, hi, n, dtype=np.int64, endpoint=True)
         edge = rng.integers(0, nb + 1, size=min(n, 64)) * step + t_from + rng.integers(-1, 2, size=min(n, 64))   # timestamps on and beside window edges
         t[rng.integers(0, n, size=edge.size)] = np.clip(edge, lo, hi)
-        bt = [B.Int64, B.Int16, B.Uint8, B.Uint32][rng.integers(0, 4)]
+        bt = [B.Int64, B.Int16, B.Uint8, B.Uint32, B.Float64, B.Float32][rng.integers(0, 6)]
         v = rand_values(bt, n)
+        if v.dtype.kind == "f":
+            v[rng.random(n) < 0.1] = 0.0
+            v[rng.random(n) < 0.1] = -0.0
+            v[rng.random(n) < 0.05] = np.nan
         sel = rng.random(n) < rng.random()
         tcol, vcol = ctx.upload(t, 4096), ctx.upload(v, 4096)
         mask = ctx.bits(n).upload(np.packbits(sel, bitorder="little"))
@@ -164,7 +168,7 @@ while time.time() < t_end:
         os.environ.pop("KNOX_COMPACT_FORM", None)
         assert got[0] == got[1] == got[2], ("shuffled forms", n, step, nb, t_from, seed)
         # Value() without the sort (window_direct_kernel) against the sorted path, every reducer that has the form
-        for f in (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last):
+        for f in ((R.Count, R.Min, R.Max, R.First, R.Last) if v.dtype.kind == "f" else (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last)):
             for m in (mask, None):
                 os.environ["KNOX_WINDOW_DIRECT"] = "0"
                 a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
