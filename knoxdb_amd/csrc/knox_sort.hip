@@ -825,7 +825,8 @@ __global__ void __launch_bounds__(256) window_state_finish_kernel(const uint64_t
         minkey = merged[2 * (size_t)nb + k];
         maxkey = merged[3 * (size_t)nb + k];
         uint32_t r0 = ~0u, r1 = ~0u;
-        for (uint32_t g = 0; g < grid; g++) {
+#pragma unroll 8
+        for (uint32_t g = 0; g < grid; g++) {      // (independent loads: eight tables per round trip)
             const uint32_t a0 = rows2[(size_t)g * 2 * nb + k], a1 = rows2[(size_t)g * 2 * nb + nb + k];
             r0 = a0 < r0 ? a0 : r0;
             r1 = a1 < r1 ? a1 : r1;
