@@ -332,6 +332,45 @@ enum { kDirectSum = 0, kDirectFirst = 1, kDirectLast = 2, kDirectMin = 3, kDirec
 constexpr int kDirectBlock = 1024;
 constexpr int kDirectWaves = kDirectBlock / 64;
 
+// the walk all sort-free kernels share: 512 rows per wave and round (the compaction pass's loads: two neighbouring rows per lane and
+// piece, everything asked for up front, values only where the pair holds a selected row), chunks dealt round-robin to the waves of the
+// grid; push(timestamp, value, row) for every selected row; the rows behind the last whole chunk by workgroup 0
+template <typename U, bool VALUES, typename Push>
+__device__ __forceinline__ void direct_walk(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask, uint64_t n_rows, Push push) {
+    typedef long long t2 __attribute__((ext_vector_type(2)));
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t sh = (2u * lane) & 7u;
+    const uint64_t n_chunks = n_rows / 512;
+    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
+        const uint64_t c0 = c * 512;
+        uint32_t mb[4];
+        t2 t[4];
+        CompactPair<U> x[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) mb[h] = mask != nullptr ? mask[(c0 + 128u * h + 2u * lane) >> 3] : 0xffu;
+#pragma unroll
+        for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            x[h] = CompactPair<U>{0, 0};
+            if constexpr (VALUES) {
+                if (mask == nullptr || ((mb[h] >> sh) & 3u)) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t m2 = (mb[h] >> sh) & 3u;
+            const uint64_t row = c0 + 128u * h + 2u * lane;
+            if (m2 & 1u) push(t[h].x, x[h].x, row);
+            if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
+            if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], VALUES ? val[r] : (U)0, r);
+    }
+}
+
 // what a mode keeps per window
 // Float min / max (reducer.go:256-296 as acc_update restates it, knox_dev.h): a NaN is never adopted, -0 and +0 compare equal (ONE
 // order key), the first occurrence wins, and a NaN as the window's FIRST value sticks.  Value() needs no row id, so the order only
@@ -362,7 +401,6 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
     for (uint32_t i = threadIdx.x; i < NS * nb; i += kDirectBlock) direct_tab[i] = SH::INIT;
     for (uint32_t i = threadIdx.x; i < nc; i += kDirectBlock) cnt[i] = SH::WINIT;
     __syncthreads();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint64_t span = (uint64_t)nb * (uint64_t)step;
     const double inv = 1.0 / (double)step;
     auto push = [&](int64_t t, U x, uint64_t row) {
@@ -405,37 +443,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
             atomicMax(p0, (unsigned long long)(row + 1));
         }
     };
-    typedef long long t2 __attribute__((ext_vector_type(2)));
-    const uint32_t sh = (2u * lane) & 7u;
-    const uint64_t n_chunks = n_rows / 512;
-    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
-        const uint64_t c0 = c * 512;
-        uint32_t mb[4];
-        t2 t[4];
-        CompactPair<U> x[4];
-#pragma unroll
-        for (int h = 0; h < 4; h++) mb[h] = mask != nullptr ? mask[(c0 + 128u * h + 2u * lane) >> 3] : 0xffu;
-#pragma unroll
-        for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            x[h] = CompactPair<U>{0, 0};
-            if constexpr (SH::VALUES) {
-                if (mask == nullptr || ((mb[h] >> sh) & 3u)) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            const uint32_t m2 = (mb[h] >> sh) & 3u;
-            const uint64_t row = c0 + 128u * h + 2u * lane;
-            if (m2 & 1u) push(t[h].x, x[h].x, row);
-            if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
-        }
-    }
-    if (blockIdx.x == 0) {      // the rows behind the last whole chunk
-        for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
-            if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], SH::VALUES ? val[r] : (U)0, r);
-    }
+    direct_walk<U, SH::VALUES>(time, val, mask, n_rows, push);
     __syncthreads();
     uint64_t *so = slots_out + (size_t)blockIdx.x * NS * nb;
     uint32_t *co = words_out + (size_t)blockIdx.x * nc;
@@ -638,7 +646,6 @@ __global__ void __launch_bounds__(kDirectBlock) window_state_kernel(const int64_
     }
     for (uint32_t i = threadIdx.x; i < NW * nb; i += kDirectBlock) word[i] = (i / nb) == 1 ? ~0u : 0u;   // so does the first row
     __syncthreads();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint64_t span = (uint64_t)nb * (uint64_t)step;
     const double inv = 1.0 / (double)step;
     auto A64 = [&](int f, uint32_t q) { return reinterpret_cast<unsigned long long *>(&slot[(size_t)f * nb + q]); };
@@ -663,35 +670,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_state_kernel(const int64_
             atomicMax(A64(2, q), (unsigned long long)((key << 32) | (uint32_t)~r32));
         }
     };
-    typedef long long t2 __attribute__((ext_vector_type(2)));
-    const uint32_t sh = (2u * lane) & 7u;
-    const uint64_t n_chunks = n_rows / 512;
-    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
-        const uint64_t c0 = c * 512;
-        uint32_t mb[4];
-        t2 t[4];
-        CompactPair<U> x[4];
-#pragma unroll
-        for (int h = 0; h < 4; h++) mb[h] = mask != nullptr ? mask[(c0 + 128u * h + 2u * lane) >> 3] : 0xffu;
-#pragma unroll
-        for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            x[h] = CompactPair<U>{0, 0};
-            if (mask == nullptr || ((mb[h] >> sh) & 3u)) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
-        }
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            const uint32_t m2 = (mb[h] >> sh) & 3u;
-            const uint64_t row = c0 + 128u * h + 2u * lane;
-            if (m2 & 1u) push(t[h].x, x[h].x, row);
-            if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
-        }
-    }
-    if (blockIdx.x == 0) {
-        for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
-            if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], val[r], r);
-    }
+    direct_walk<U, true>(time, val, mask, n_rows, push);
     __syncthreads();
     uint64_t *so = slots_out + (size_t)blockIdx.x * NS * nb;
     uint32_t *wo = words_out + (size_t)blockIdx.x * NW * nb;
@@ -761,7 +740,6 @@ __global__ void __launch_bounds__(kDirectBlock) window_state_rows_kernel(const i
         rows[nb + i] = ~0u;
     }
     __syncthreads();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint64_t span = (uint64_t)nb * (uint64_t)step;
     const double inv = 1.0 / (double)step;
     auto push = [&](int64_t t, U x, uint64_t row) {
@@ -771,35 +749,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_state_rows_kernel(const i
         if (key == gmin[q]) atomicMin(&rows[q], (uint32_t)row);
         if (key == gmax[q]) atomicMin(&rows[nb + q], (uint32_t)row);
     };
-    typedef long long t2 __attribute__((ext_vector_type(2)));
-    const uint32_t sh = (2u * lane) & 7u;
-    const uint64_t n_chunks = n_rows / 512;
-    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
-        const uint64_t c0 = c * 512;
-        uint32_t mb[4];
-        t2 t[4];
-        CompactPair<U> x[4];
-#pragma unroll
-        for (int h = 0; h < 4; h++) mb[h] = mask != nullptr ? mask[(c0 + 128u * h + 2u * lane) >> 3] : 0xffu;
-#pragma unroll
-        for (int h = 0; h < 4; h++) t[h] = __builtin_nontemporal_load(reinterpret_cast<const t2 *>(time + c0 + 128u * h + 2u * lane));
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            x[h] = CompactPair<U>{0, 0};
-            if (mask == nullptr || ((mb[h] >> sh) & 3u)) x[h] = __builtin_nontemporal_load(reinterpret_cast<const CompactPair<U> *>(val + c0 + 128u * h + 2u * lane));
-        }
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            const uint32_t m2 = (mb[h] >> sh) & 3u;
-            const uint64_t row = c0 + 128u * h + 2u * lane;
-            if (m2 & 1u) push(t[h].x, x[h].x, row);
-            if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
-        }
-    }
-    if (blockIdx.x == 0) {
-        for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
-            if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], val[r], r);
-    }
+    direct_walk<U, true>(time, val, mask, n_rows, push);
     __syncthreads();
     uint32_t *ro = rows_out + (size_t)blockIdx.x * 2 * nb;
     for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) ro[i] = rows[i];
