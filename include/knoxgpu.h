@@ -609,6 +609,15 @@ int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const kn
                                const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                                size_t n_buckets, int func, int flags, const void **values_view, const uint8_t **seen_view);
 
+/* Which way the last knox_reduce_buckets* call on this ctx took (diagnostics, tests): the time column was non-decreasing and the
+ * windows were reduced in place; out-of-order time through the stable sort (after a compaction of the selected rows); out-of-order
+ * time without a sort -- Value() of an order-free reducer, whole states of an integer column, exact float sums / means.          */
+enum knox_windows_path {
+    KNOX_WINDOWS_ORDERED = 1, KNOX_WINDOWS_SORTED = 2, KNOX_WINDOWS_SORTED_COMPACTED = 3,
+    KNOX_WINDOWS_DIRECT_VALUES = 4, KNOX_WINDOWS_DIRECT_STATES = 5, KNOX_WINDOWS_DIRECT_FLOAT_SUMS = 6
+};
+int knox_windows_last_path(const knox_ctx *ctx);
+
 /* The literal form of the same: window k's reducer is the reference's own, applied row by row
  * (one lane per window), so Value() is bit-exact for EVERY reducer -- Welford mean / var / std
  * and the join reducers KNOX_R_*_JOIN (reducer.go:432-731; join = the row's raw timestamp equals

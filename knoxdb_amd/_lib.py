@@ -189,6 +189,7 @@ SIGNATURES = {
     "knox_bloom_build_u64": (_i, [_vp, _vp, _i, _pp]),
     "knox_bloom_packs": (_sz, [_vp]),
     "knox_bloom_build_info": (_i, [_vp, _pi, _pi]),
+    "knox_windows_last_path": (_i, [_vp]),
     "knox_bloom_bytes": (_sz, [_vp]),
     "knox_bloom_download": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "knox_bloom_probe": (_i, [_vp, _vp, _u64, _vp]),

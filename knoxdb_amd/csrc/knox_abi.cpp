@@ -651,6 +651,7 @@ KNOX_API int knox_col_append_async(knox_ctx *ctx, knox_col *col, const void *hos
     if (n_rows > col->rows_cap - col->n_rows) return KNOX_E_RANGE;
     if (n_rows == 0) return KNOX_OK;
     col->sorted_state = -1;  // new rows: the order check runs again
+    col->fexp_max = -1;
     hipSetDevice(ctx->device);
     int rc = copy_stream_init(ctx);
     if (rc) return rc;
@@ -674,6 +675,7 @@ KNOX_API int knox_col_reset(knox_ctx *ctx, knox_col *col) {
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fence_ev, 0));
     col->n_rows = 0;
     col->sorted_state = -1;  // new content: what the order check found no longer holds
+    col->fexp_max = -1;
     return KNOX_OK;
 }
 

@@ -170,6 +170,7 @@ struct knox_ctx {
     uint8_t *win_seen = nullptr;
     int win_func = 0;
     bool win_values_done = false;
+    int win_path = 0;   // how the last window call reduced (knox_windows_last_path)
     char *leaf_stage = nullptr;
     size_t leaf_stage_off = 0, leaf_stage_cap = 0;
     std::vector<uint8_t> inset_raw;   // the caller's members as given: compared byte for byte before the prepared set is reused
@@ -267,12 +268,23 @@ struct knox_col {
     // itself (never for knox_col_wrap), dropped by everything that writes into the column again (append, reset).
     mutable int8_t sorted_state = -1;
     mutable size_t sorted_rows = 0;
+    // float columns: the largest finite biased float64 exponent of the values (-1 unknown), for the first `fexp_rows` rows -- what the
+    // exact window sums size their fixed-point form by (knox_sort.hip window_fsum_kernel).  Kept and dropped like sorted_state.
+    mutable int32_t fexp_max = -1;
+    mutable size_t fexp_rows = 0;
 };
 static inline int col_sorted_cached(const knox_col *c) { return (c->owned && c->sorted_state >= 0 && c->sorted_rows == c->n_rows) ? c->sorted_state : -1; }
 static inline void col_sorted_set(const knox_col *c, bool sorted) {
     if (!c->owned) return;
     c->sorted_state = sorted ? 1 : 0;
     c->sorted_rows = c->n_rows;
+}
+
+static inline int col_fexp_cached(const knox_col *c) { return (c->owned && c->fexp_max >= 0 && c->fexp_rows == c->n_rows) ? c->fexp_max : -1; }
+static inline void col_fexp_set(const knox_col *c, int e) {
+    if (!c->owned) return;
+    c->fexp_max = e;
+    c->fexp_rows = c->n_rows;
 }
 
 // a kernel on ctx->stream is about to read `col`: order it behind the column's last asynchronous upload

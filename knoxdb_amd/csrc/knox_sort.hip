@@ -616,6 +616,233 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
     return hipGetLastError();
 }
 
+// ---- float sums and means without the sort: exact --------------------------------------------------------------------------------
+// A double-double running sum is not an atomic, but an INTEGER is: every finite value is an integer multiple of 2^(B - 1075), B = the
+// lowest biased exponent the table represents, and a window's sum is kept as a 160-bit fixed-point number in five 64-bit adders of
+// 32-bit digits (a value's 53-bit mantissa, shifted to its place, is cut into at most three 32-bit pieces: three LDS adds; negative
+// values add the pieces' two's complements; 2^28 pieces of 32 bits stay far inside 64).  160 bits hold the exponents [E - 107, E]
+// below the column's largest finite exponent E (one pass over the values, kept with the column); a selected value below that range
+// raises a flag and the call is repeated through the sort.  The fold is exact, so the order of the rows is irrelevant and the result
+// is the correctly rounded exact sum -- what the sorted path's double-double sums deliver unless cancellation eats more than ~50 bits.
+// Non-finite values and negative zeros never enter the adders: a word of flags (+inf, -inf, NaN seen) and a count of negative zeros
+// per window reproduce IEEE's answers (inf - inf and NaN -> NaN; a sum of nothing but -0 is -0).
+constexpr int kFsumBins = 5;
+constexpr int kFsumRange = 107;
+
+template <typename U> __device__ __forceinline__ uint64_t as_f64_bits(U x) {
+    if constexpr (sizeof(U) == 8) return (uint64_t)x;
+    else return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));      // exact (a float32 denormal is a normal double)
+}
+
+// largest biased float64 exponent among the finite values of a column (0: nothing finite and non-zero)
+template <typename U>
+__global__ void __launch_bounds__(256) float_expmax_kernel(const U *__restrict__ val, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    constexpr int UN = 4;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * UN) {
+        U x[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) x[u] = i0 + u * stride < n ? val[i0 + u * stride] : (U)0;
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const uint64_t d = as_f64_bits(x[u]);
+            const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+            const uint32_t e = be == 0x7ffu ? 0u : be != 0 ? be : ((d << 12) != 0 ? 1u : 0u);
+            m = e > m ? e : m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+}
+
+hipError_t launch_float_expmax(hipStream_t s, int width, const void *val, uint64_t n_rows, uint32_t *out) {
+    uint64_t g = (n_rows + 256 * 4 - 1) / (256 * 4);
+    if (g > 4096) g = 4096;
+    if (g == 0) g = 1;
+    if (width == 8) hipLaunchKernelGGL(float_expmax_kernel<uint64_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint64_t *)val, n_rows, out);
+    else if (width == 4) hipLaunchKernelGGL(float_expmax_kernel<uint32_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint32_t *)val, n_rows, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <typename U>
+__global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                   uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base,
+                                                                   uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out, uint32_t *__restrict__ range_flag) {
+    extern __shared__ uint64_t direct_tab[];                                   // [kFsumBins][nb] adders, then [3][nb] words: count, negative zeros, flags
+    uint64_t *bin = direct_tab;
+    uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)kFsumBins * nb);
+    for (uint32_t i = threadIdx.x; i < kFsumBins * nb; i += kDirectBlock) bin[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 3 * nb; i += kDirectBlock) word[i] = 0;
+    __syncthreads();
+    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    bool below = false;
+    auto push = [&](int64_t t, U x, uint64_t) {
+        const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
+        if (q == kNoKey) return;
+        atomicAdd(&word[q], 1u);
+        const uint64_t d = as_f64_bits(x);
+        const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+        const uint64_t frac = d & 0xfffffffffffffull;
+        const bool neg = (d >> 63) != 0;
+        if (be == 0x7ffu) { atomicOr(&word[2 * nb + q], frac != 0 ? 4u : neg ? 2u : 1u); return; }
+        if (be == 0 && frac == 0) { if (neg) atomicAdd(&word[nb + q], 1u); return; }
+        const uint32_t lsb = be != 0 ? be : 1u;                 // the value is m * 2^(lsb - 1075)
+        if (lsb < base) { below = true; return; }               // finer than the table's last digit: the caller sorts instead
+        const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
+        const uint32_t sft = lsb - base, i0 = sft >> 5, r = sft & 31u;
+        const unsigned __int128 p = (unsigned __int128)m << r;  // <= 84 bits
+        const uint64_t piece[3] = {(uint64_t)p & 0xffffffffull, (uint64_t)(p >> 32) & 0xffffffffull, (uint64_t)(p >> 64)};
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (piece[j] != 0 && i0 + j < (uint32_t)kFsumBins)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&bin[(size_t)(i0 + j) * nb + q]), (unsigned long long)(neg ? 0ull - piece[j] : piece[j]));
+    };
+    direct_walk<U, true>(time, val, mask, n_rows, push);
+    if (__any(below) && (threadIdx.x & 63) == 0) atomicOr(range_flag, 1u);
+    __syncthreads();
+    uint64_t *so = slots_out + (size_t)blockIdx.x * kFsumBins * nb;
+    uint32_t *wo = words_out + (size_t)blockIdx.x * 3 * nb;
+    for (uint32_t i = threadIdx.x; i < kFsumBins * nb; i += kDirectBlock) so[i] = bin[i];
+    for (uint32_t i = threadIdx.x; i < 3 * nb; i += kDirectBlock) wo[i] = word[i];
+}
+
+// 64 windows per workgroup, the tables dealt to its four waves; the 160-bit sum -> a double-double -> Value() (knox_finalize.h)
+template <typename U>
+__global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
+                                                                 uint32_t base, int dtype, int func, void *values, uint8_t *seen) {
+    __shared__ uint64_t f_bin[4][kFsumBins][64];
+    __shared__ uint32_t f_w[4][3][64];
+    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64 + lane;
+    const bool valid = k < nb;
+    uint64_t b[kFsumBins] = {0, 0, 0, 0, 0};
+    uint32_t w[3] = {0, 0, 0};
+    if (valid) {
+#pragma unroll 2
+        for (uint32_t g = part; g < grid; g += 4) {
+#pragma unroll
+            for (int i = 0; i < kFsumBins; i++) b[i] += slots[((size_t)g * kFsumBins + i) * nb + k];
+            w[0] += words[((size_t)g * 3 + 0) * nb + k];
+            w[1] += words[((size_t)g * 3 + 1) * nb + k];
+            w[2] |= words[((size_t)g * 3 + 2) * nb + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kFsumBins; i++) f_bin[part][i][lane] = b[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) f_w[part][i][lane] = w[i];
+    __syncthreads();
+    if (part != 0 || !valid) return;
+#pragma unroll
+    for (int p = 1; p < 4; p++) {
+#pragma unroll
+        for (int i = 0; i < kFsumBins; i++) b[i] += f_bin[p][i][lane];
+        w[0] += f_w[p][0][lane];
+        w[1] += f_w[p][1][lane];
+        w[2] |= f_w[p][2][lane];
+    }
+    // T = sum of b[i] * 2^(32 i), every b[i] a signed 64-bit number: 192 bits in two's complement (lo | hi)
+    uint64_t lo = 0;
+    __int128 hi = 0;
+    auto add = [&](uint64_t lo_add, __int128 hi_add) {
+        const uint64_t nl = lo + lo_add;
+        hi += hi_add + (nl < lo ? 1 : 0);
+        lo = nl;
+    };
+    const __int128 v0 = (__int128)(int64_t)b[0], v1 = (__int128)(int64_t)b[1] * ((__int128)1 << 32);
+    add((uint64_t)v0, v0 >> 64);
+    add((uint64_t)v1, v1 >> 64);
+    add(0, (__int128)(int64_t)b[2]);
+    add(0, (__int128)(int64_t)b[3] * ((__int128)1 << 32));
+    add(0, (__int128)(int64_t)b[4] * ((__int128)1 << 64));
+    const bool neg = hi < 0;
+    if (neg) {
+        lo = ~lo + 1;
+        hi = ~hi + (lo == 0 ? 1 : 0);
+    }
+    const unsigned __int128 mh = (unsigned __int128)hi;
+    const uint32_t piece[6] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)mh, (uint32_t)(mh >> 32), (uint32_t)(mh >> 64), (uint32_t)(mh >> 96)};
+    // the six digits, from the top, into a three-term expansion (error-free two_sum steps), then a double-double
+    double s = ldexp((double)piece[5], 160), c = 0.0, c2 = 0.0;
+#pragma unroll
+    for (int j = 4; j >= 0; j--) {
+        const knox_fin::dd t1 = knox_fin::two_sum(s, ldexp((double)piece[j], 32 * j));
+        const knox_fin::dd t2 = knox_fin::two_sum(c, t1.lo);
+        s = t1.hi;
+        c = t2.hi;
+        c2 += t2.lo;
+    }
+    knox_fin::dd r = knox_fin::fast_two_sum(s, c + c2);
+    const int sc = (int)base - 1075;
+    double rh = ldexp(r.hi, sc), rl = ldexp(r.lo, sc);
+    if (neg) { rh = -rh; rl = -rl; }
+    if (rh == 0.0) rh = (w[0] != 0 && w[1] == w[0]) ? -0.0 : 0.0;     // nothing but negative zeros: -0
+    if (w[2] != 0) {                                                   // IEEE: NaN, inf - inf -> NaN; else the infinity
+        rl = 0.0;
+        rh = ((w[2] & 4u) || (w[2] & 3u) == 3u) ? __longlong_as_double(0x7ff8000000000000ll) : (w[2] & 1u) ? __longlong_as_double(0x7ff0000000000000ll)
+                                                                                                              : __longlong_as_double((long long)0xfff0000000000000ull);
+    }
+    AggStateDev st;
+    st.dtype = dtype;
+    st.flags = 1u;
+    st.count = (int64_t)w[0];
+    st.isum = 0;
+    st.fsum_hi = rh;
+    st.fsum_lo = rl;
+    st.min_bits = st.max_bits = st.first_bits = st.last_bits = 0;
+    st.min_row = st.max_row = st.last_row = -1;
+    st.first_row = w[0] ? 0 : -1;
+    st.m_shift = 0.0; st.m_dev_hi = 0.0; st.m_dev_lo = 0.0; st.m_sq_hi = 0.0; st.m_sq_lo = 0.0;
+    uint64_t bits = 0;
+    int sn = 0;
+    int64_t row = -1;
+    const int rc = knox_fin::agg_value_bits(st, func, &bits, &sn, &row);
+    reinterpret_cast<U *>(values)[k] = (U)bits;
+    seen[k] = (rc == 0 && sn) ? 1 : 0;
+}
+
+// exp_max: the column's largest finite biased float64 exponent (launch_float_expmax).  grid 0: the table does not fit LDS, or the
+// column holds nothing the fixed-point form is good for (tiny values whose scaled results would be denormal)
+WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t n_buckets, int n_cus) {
+    WindowFsumGeom g;
+    g.grid = 0;
+    g.base = 0;
+    g.lds = (size_t)n_buckets * (8u * kFsumBins + 12u);
+    g.scratch = 0;
+    if (exp_max < 200 || g.lds > 156 * 1024) return g;
+    g.base = exp_max - kFsumRange;
+    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
+    g.scratch = (size_t)g.grid * g.lds + 512;
+    return g;
+}
+
+// func: KNOX_R_SUM / KNOX_R_MEAN over a float column; *range_flag (zeroed by the caller) != 0 afterwards: a selected value lay below the
+// table's range -- values / seen are then meaningless and the caller takes the sorted path
+hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask,
+                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, uint32_t *range_flag, void *values, uint8_t *seen) {
+    if (n_buckets == 0 || g.grid == 0 || (func != 0 && func != 5)) return hipErrorInvalidValue;
+    uint64_t *slots = (uint64_t *)scratch;
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * kFsumBins * n_buckets);
+    const dim3 fgrid((n_buckets + 63) / 64), fblock(256);
+#define KNOX_FSUM(U)                                                                                                                                \
+    do {                                                                                                                                            \
+        if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fsum_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+        hipLaunchKernelGGL((window_fsum_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
+                           g.base, slots, words, range_flag);                                                                                       \
+        hipLaunchKernelGGL((window_fsum_finish_kernel<U>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, g.base, \
+                           dtype, func, values, seen);                                                                                              \
+    } while (0)
+    if (width == 8) KNOX_FSUM(uint64_t);
+    else if (width == 4) KNOX_FSUM(uint32_t);
+    else return hipErrorInvalidValue;
+#undef KNOX_FSUM
+    return hipGetLastError();
+}
+
 // ---- no sort at all, the whole state: every field of knox_agg_state as an order-free fold ---------------------------------------------
 // count, sums, first / last as above; "first occurrence wins" for min / max (reducer.go:256-296) asks for the LOWEST row holding the
 // window's smallest / largest value.  Below 8 bytes (order key, row id) fit ONE 64-bit atomic -- key << 32 | row under min,

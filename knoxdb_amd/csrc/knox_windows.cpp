@@ -108,9 +108,50 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
                                                 mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, ctx->sort_buf.p,
                                                 ctx->win_values, ctx->win_seen);
             if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+            ctx->win_path = KNOX_WINDOWS_DIRECT_VALUES;
             ctx->win_values_done = true;
             *states_dev = nullptr;
             return KNOX_OK;
+        }
+    }
+    // float sums / means: exact fixed-point adders sized by the column's largest exponent (one pass over the values the first time, kept
+    // with the column); a selected value too small for the table's range is reported and the call falls through to the sort
+    if (ctx->win_values != nullptr && !(flags & 2) && (ctx->win_func == KNOX_R_SUM || ctx->win_func == KNOX_R_MEAN) &&
+        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 4096) {
+        const char *env = getenv("KNOX_WINDOW_DIRECT");
+        if (!(env && atoi(env) == 0)) {
+            int rc = ensure(ctx, ctx->misc, 256);
+            if (rc) return rc;
+            uint32_t *d_exp = (uint32_t *)((char *)ctx->misc.p + 96), *d_range = d_exp + 1;
+            int emax = col_fexp_cached(value_col);
+            HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_exp, 8));
+            if (emax < 0) {
+                hipError_t e = launch_float_expmax(ctx->stream, (int)w, value_col->dev, n_rows, d_exp);
+                if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+                uint32_t h = 0;
+                HIPCHK(ctx, hipMemcpyAsync(&h, d_exp, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                emax = (int)h;
+                col_fexp_set(value_col, emax);
+            }
+            const WindowFsumGeom fg = window_fsum_geom((uint32_t)emax, (uint32_t)n_buckets, ctx->n_cus);
+            if (fg.grid != 0) {
+                rc = ensure(ctx, ctx->sort_buf, fg.scratch);
+                if (rc) return rc;
+                hipError_t e = launch_window_fsum(ctx->stream, (int)w, value_col->dtype, ctx->win_func, fg, (const int64_t *)time_col->dev, value_col->dev,
+                                                  mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, ctx->sort_buf.p, d_range,
+                                                  ctx->win_values, ctx->win_seen);
+                if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+                uint32_t below = 0;
+                HIPCHK(ctx, hipMemcpyAsync(&below, d_range, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                if (below == 0) {
+                    ctx->win_path = KNOX_WINDOWS_DIRECT_FLOAT_SUMS;
+                    ctx->win_values_done = true;
+                    *states_dev = nullptr;
+                    return KNOX_OK;
+                }
+            }
         }
     }
     // ... and the whole state of every window the same way (integer columns, no var / std pass to follow, ~3600-4400 windows at most):
@@ -126,6 +167,7 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
                                                mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, row_base, ctx->sort_buf.p,
                                                (AggStateDev *)ctx->tmp_vals.p);
             if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+            ctx->win_path = KNOX_WINDOWS_DIRECT_STATES;
             *states_dev = (char *)ctx->tmp_vals.p;
             return KNOX_OK;
         }
@@ -191,6 +233,7 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             vals_in = vals_c;
             idx_in = idx_c;
             compacted = true;
+            ctx->win_path = KNOX_WINDOWS_SORTED_COMPACTED;
         }
     }
     if (!compacted)
@@ -276,11 +319,14 @@ static int reduce_buckets_dev(knox_ctx *ctx, const knox_col *time_col, const kno
     //  LDS atomics into a per-workgroup table, two streaming passes, the second one for the lowest row holding each window's min / max --
     //  and measured at 2^28 shuffled rows -> 1024 windows: 4.07 ms against the sort's 2.88 ms.  Eight 64-bit LDS atomics per selected
     //  row ran at well under one per clock and CU; dropped, in the history at b06218a.)
+    ctx->win_path = unsorted ? KNOX_WINDOWS_SORTED : KNOX_WINDOWS_ORDERED;
     if (unsorted) return reduce_buckets_unordered(ctx, time_col, value_col, mask, t_from, step, n_buckets, row_base, flags, states_dev);
     // 3. reduce the windows' row ranges
     return reduce_windows(ctx, value_col->dev, value_col->dtype, mask ? (const uint32_t *)mask->dev : nullptr, n_rows, row_base, d_start, n_buckets,
                           flags, states_dev);
 }
+
+KNOX_API int knox_windows_last_path(const knox_ctx *ctx) { return ctx ? ctx->win_path : KNOX_E_INVALID; }
 
 KNOX_API int knox_reduce_buckets(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
                                  int64_t step, size_t n_buckets, uint64_t row_base, int flags, knox_agg_state *states) {

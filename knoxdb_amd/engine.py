@@ -692,6 +692,11 @@ class Context:
         check(self.L.knox_bits_collect(self.h, C.byref(a), C.byref(l), C.byref(c)), "knox_bits_collect")
         return (None if a.value < 0 else bool(a.value), None if l.value < 0 else bool(l.value), None if c.value < 0 else c.value)
 
+    def windows_last_path(self):
+        """how the last reduce_buckets* call reduced (include/knoxgpu.h knox_windows_path): 1 ordered, 2 sorted, 3 sorted after a
+        compaction, 4 / 5 / 6 without a sort (values / states / exact float sums)"""
+        return self.L.knox_windows_last_path(self.h)
+
     def reduce_buckets_sequential(self, time_col, value_col, func, t_from, step, n_buckets, mask=None, assume_sorted=False, form=None):
         """The reference's own reducer per window, row by row (bit-exact Value() for every reducer, join
         reducers included) -> (values[n_buckets], seen[n_buckets])."""

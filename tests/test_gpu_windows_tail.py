@@ -349,6 +349,8 @@ def test_out_of_order_windows_order_free_values_without_the_sort():
                             want = (a.tobytes(), b.tobytes())
                             os.environ.pop("KNOX_WINDOW_DIRECT")
                             a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                            if nb <= 4096:
+                                assert ctx.windows_last_path() == 4          # (no sort)
                             assert (a.tobytes(), b.tobytes()) == want, (n, nb, bt, f, m is not None)
                             if f == R.Count:
                                 inside = sel & (key >= 0) & (key < nb)
@@ -404,6 +406,8 @@ def test_out_of_order_windows_whole_states_without_the_sort():
                                 want = bytes(ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=m, row_base=base))
                                 os.environ.pop("KNOX_WINDOW_DIRECT")
                                 got = bytes(ctx.reduce_buckets_view(tcol, vcol, t_from, step, nb, mask=m, row_base=base))
+                                if nb <= 3630:
+                                    assert ctx.windows_last_path() == 5      # (the sort-free states ran)
                                 assert got == want, (n, nb, bt, narrow, m is not None, base)
                         vcol.free()
                 for o in [tcol] + masks[1:]:
@@ -452,3 +456,62 @@ def test_min_max_rows_are_first_occurrences_in_every_launch_form():
         os.environ.pop("KNOX_WINDOW_FORM", None)
         if old is not None:
             os.environ["KNOX_WINDOW_FORM"] = old
+
+
+def test_out_of_order_windows_float_sums_are_exact_without_the_sort():
+    """Sum / Mean of a float column per window over out-of-order time: every finite value enters a 160-bit fixed-point adder per
+    window (window_fsum_kernel: LDS adds of 32-bit digits), so the fold is exact whatever the order -- against math.fsum (the
+    correctly rounded exact sum) and against the sorted path's double-double sums (KNOX_WINDOW_DIRECT=0), float64 and float32, values
+    spread over ~2^70 in magnitude; infinities of both signs, NaNs and negative zeros follow IEEE (inf - inf and NaN -> NaN, a sum of
+    nothing but -0 is -0); a column whose exponents span more than the adders hold falls through to the sort."""
+    import math, os
+    rng = np.random.default_rng(31337)
+    old = os.environ.pop("KNOX_WINDOW_DIRECT", None)
+    try:
+        with K.Context(0) as ctx:
+            for n, nb, step in ((400_003, 300, 7), (50_000, 3072, 2), (50_000, 3073, 2)):
+                t_from = 10_000
+                key = rng.integers(-1, nb + 1, n)
+                t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
+                tcol = ctx.upload(t, 4096)
+                mask = ctx.bits(n).upload(np.packbits(rng.random(n) < 0.5, bitorder="little"))
+                sel = np.unpackbits(mask.bytes(), bitorder="little")[:n].astype(bool)
+                for bt in (B.Float64, B.Float32):
+                    for kind in ("wide", "specials", "too wide"):
+                        v = ((1.0 + rng.random(n)) * rng.choice([-1.0, 1.0], n) * 10.0 ** rng.integers(-6, 15, n)).astype(NP[bt])      # ~2^70 between the smallest and the largest
+                        if kind == "specials":
+                            v[rng.random(n) < 0.3] = -0.0
+                            idx = rng.integers(0, n, 40)
+                            v[idx[:10]] = np.inf
+                            v[idx[10:20]] = -np.inf
+                            v[idx[20:25]] = np.nan
+                            v[key == 3] = -0.0                       # a window of nothing but negative zeros
+                        if kind == "too wide" and bt == B.Float64:
+                            v[rng.integers(0, n, 50)] = 1e-250
+                            v[rng.integers(0, n, 50)] = 1e250
+                        vcol = ctx.upload(v, 4096)
+                        for m, s in ((None, np.ones(n, dtype=bool)), (mask, sel)):
+                            for f in (R.Sum, R.Mean):
+                                os.environ["KNOX_WINDOW_DIRECT"] = "0"
+                                a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                                want, want_seen = a.copy(), b.copy()
+                                os.environ.pop("KNOX_WINDOW_DIRECT")
+                                a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                                # 6 = the exact adders ran; 2 / 3 = the sort (more windows than LDS holds, exponents wider than the adders)
+                                sorts = nb > 3072 or (kind == "too wide" and bt == B.Float64)
+                                assert ctx.windows_last_path() in ((2, 3) if sorts else (6,)), (nb, kind, bt, ctx.windows_last_path())
+                                assert (b == want_seen).all(), (n, nb, bt, kind, f)
+                                assert np.array_equal(a, want, equal_nan=True) and (np.signbit(a) == np.signbit(want))[~np.isnan(want)].all(), (n, nb, bt, kind, f)
+                            if bt == B.Float64 and kind == "wide" and n > 100_000:
+                                a, b = ctx.reduce_buckets_values(tcol, vcol, R.Sum, t_from, step, nb, mask=m)
+                                for k in range(nb):
+                                    rows = np.flatnonzero((key == k) & s)
+                                    assert bool(b[k]) == (rows.size > 0)
+                                    if rows.size:
+                                        assert a[k] == math.fsum(v[rows].tolist()), (k, m is not None)
+                        vcol.free()
+                tcol.free(); mask.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_DIRECT", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_DIRECT"] = old

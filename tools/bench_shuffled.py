@@ -20,6 +20,12 @@ half = (1 << 40) * sel // 100
 ctx.scan(And(Leaf(0, F.Range, -half, half)), [col], bits_out=bits)
 
 
+if os.environ.get("KNOX_SHUFFLED_DTYPE") == "f64":     # Sum over a float64 column (uniform in [0, 1)): the exact fixed-point adders
+    vals = ctx.generate(B.Float64, 2, 5, n, pack_rows=1 << 20)
+else:
+    vals = col
+
+
 def timed(fn):
     fn(); ctx.sync()
     t0 = time.perf_counter()
@@ -35,5 +41,5 @@ for nb in [int(x) for x in os.environ.get("KNOX_SHUFFLED_NB", "1024,16384").spli
     for m, tag in ((bits, "%d %% selected" % sel), (None, "all rows")):
         if only and (tag == "all rows") != (only == "all"):
             continue
-        ms = timed(lambda: ctx.reduce_buckets_values(clock, col, R.Sum, 1000, step, nb, mask=m))
-        print("2^%d rows, shuffled clock, %6d windows, %-13s: %6.2f ms (%.1f G rows/s)" % (lg, nb, tag, ms, n / ms / 1e6), flush=True)
+        ms = timed(lambda: ctx.reduce_buckets_values(clock, vals, R.Sum, 1000, step, nb, mask=m))
+        print("2^%d rows, shuffled clock, %6d windows, %-13s: %6.2f ms (%.1f G rows/s) [path %d]" % (lg, nb, tag, ms, n / ms / 1e6, ctx.windows_last_path()), flush=True)
