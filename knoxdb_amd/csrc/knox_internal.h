@@ -268,9 +268,9 @@ struct knox_col {
     // itself (never for knox_col_wrap), dropped by everything that writes into the column again (append, reset).
     mutable int8_t sorted_state = -1;
     mutable size_t sorted_rows = 0;
-    // float columns: the largest finite biased float64 exponent of the values (-1 unknown), for the first `fexp_rows` rows -- what the
-    // exact window sums size their fixed-point form by (knox_sort.hip window_fsum_kernel).  Kept and dropped like sorted_state.
-    mutable int32_t fexp_max = -1;
+    // float columns: the largest / smallest finite non-zero biased float64 exponent of the values (-1 unknown), for the first `fexp_rows`
+    // rows -- what the exact window sums size their fixed-point form by (knox_sort.hip window_fsum_kernel).  Kept and dropped like sorted_state.
+    mutable int32_t fexp_max = -1, fexp_min = 0;
     mutable size_t fexp_rows = 0;
 };
 static inline int col_sorted_cached(const knox_col *c) { return (c->owned && c->sorted_state >= 0 && c->sorted_rows == c->n_rows) ? c->sorted_state : -1; }
@@ -281,9 +281,10 @@ static inline void col_sorted_set(const knox_col *c, bool sorted) {
 }
 
 static inline int col_fexp_cached(const knox_col *c) { return (c->owned && c->fexp_max >= 0 && c->fexp_rows == c->n_rows) ? c->fexp_max : -1; }
-static inline void col_fexp_set(const knox_col *c, int e) {
+static inline void col_fexp_set(const knox_col *c, int emax, int emin) {
     if (!c->owned) return;
-    c->fexp_max = e;
+    c->fexp_max = emax;
+    c->fexp_min = emin;
     c->fexp_rows = c->n_rows;
 }
 

@@ -394,13 +394,13 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
                                 uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
 // ... float sums / means: exact, as 160-bit fixed-point numbers (five 64-bit adders per window)
 struct WindowFsumGeom {
-    uint32_t grid, base;   // grid 0: not usable (table too large for LDS / the column's exponents unsuitable); base: lowest biased exponent held
+    uint32_t grid, base, nbins;   // grid 0: not usable; base: the lowest biased exponent held; nbins: 32-bit digits (<= 5)
     size_t lds, scratch;
 };
-hipError_t launch_float_expmax(hipStream_t s, int width, const void *val, uint64_t n_rows, uint32_t *out);
-WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t n_buckets, int n_cus);
+hipError_t launch_float_exprange(hipStream_t s, int width, const void *val, uint64_t n_rows, uint32_t *out /* [max, ~min], zeroed */);
+WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus);
 hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask,
-                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, uint32_t *range_flag, void *values, uint8_t *seen);
+                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
 // ... and the whole state (integer columns): one walk below 8 bytes, two for 8-byte values
 struct WindowStateGeom {
     uint32_t grid, n_slots, n_words;   // grid 0: not an integer column, or the table does not fit LDS

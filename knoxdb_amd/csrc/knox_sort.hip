@@ -620,9 +620,9 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
 // A double-double running sum is not an atomic, but an INTEGER is: every finite value is an integer multiple of 2^(B - 1075), B = the
 // lowest biased exponent the table represents, and a window's sum is kept as a 160-bit fixed-point number in five 64-bit adders of
 // 32-bit digits (a value's 53-bit mantissa, shifted to its place, is cut into at most three 32-bit pieces: three LDS adds; negative
-// values add the pieces' two's complements; 2^28 pieces of 32 bits stay far inside 64).  160 bits hold the exponents [E - 107, E]
-// below the column's largest finite exponent E (one pass over the values, kept with the column); a selected value below that range
-// raises a flag and the call is repeated through the sort.  The fold is exact, so the order of the rows is irrelevant and the result
+// values add the pieces' two's complements; 2^28 pieces of 32 bits stay far inside 64).  B and the number of digits come from the
+// column's smallest and largest finite exponent (one pass over the values, kept with the column): as many digits as the span needs --
+// three for values within 2^43 of each other --, at most five (107 binades; a wider column takes the sort).  The fold is exact, so the order of the rows is irrelevant and the result
 // is the correctly rounded exact sum -- what the sorted path's double-double sums deliver unless cancellation eats more than ~50 bits.
 // Non-finite values and negative zeros never enter the adders: a word of flags (+inf, -inf, NaN seen) and a count of negative zeros
 // per window reproduce IEEE's answers (inf - inf and NaN -> NaN; a sum of nothing but -0 is -0).
@@ -634,10 +634,11 @@ template <typename U> __device__ __forceinline__ uint64_t as_f64_bits(U x) {
     else return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));      // exact (a float32 denormal is a normal double)
 }
 
-// largest biased float64 exponent among the finite values of a column (0: nothing finite and non-zero)
+// largest and smallest biased float64 exponent among the finite non-zero values of a column: out[0] = max (0: there is none),
+// out[1] = ~min (an atomicMax as well; denormals count as exponent 1, whose last mantissa bit is theirs too)
 template <typename U>
-__global__ void __launch_bounds__(256) float_expmax_kernel(const U *__restrict__ val, uint64_t n, uint32_t *__restrict__ out) {
-    uint32_t m = 0;
+__global__ void __launch_bounds__(256) float_exprange_kernel(const U *__restrict__ val, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0, mn = 0x7ffu;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     constexpr int UN = 4;
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * UN) {
@@ -650,36 +651,44 @@ __global__ void __launch_bounds__(256) float_expmax_kernel(const U *__restrict__
             const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
             const uint32_t e = be == 0x7ffu ? 0u : be != 0 ? be : ((d << 12) != 0 ? 1u : 0u);
             m = e > m ? e : m;
+            mn = (e != 0 && e < mn) ? e : mn;
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(m, off, 64), o2 = __shfl_xor(mn, off, 64);
+        m = o > m ? o : m;
+        mn = o2 < mn ? o2 : mn;
+    }
+    if ((threadIdx.x & 63) == 0 && m != 0) {
+        atomicMax(out, m);
+        atomicMax(out + 1, ~mn);
+    }
 }
 
-hipError_t launch_float_expmax(hipStream_t s, int width, const void *val, uint64_t n_rows, uint32_t *out) {
+// out: two words, zeroed by the caller
+hipError_t launch_float_exprange(hipStream_t s, int width, const void *val, uint64_t n_rows, uint32_t *out) {
     uint64_t g = (n_rows + 256 * 4 - 1) / (256 * 4);
     if (g > 4096) g = 4096;
     if (g == 0) g = 1;
-    if (width == 8) hipLaunchKernelGGL(float_expmax_kernel<uint64_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint64_t *)val, n_rows, out);
-    else if (width == 4) hipLaunchKernelGGL(float_expmax_kernel<uint32_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint32_t *)val, n_rows, out);
+    if (width == 8) hipLaunchKernelGGL(float_exprange_kernel<uint64_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint64_t *)val, n_rows, out);
+    else if (width == 4) hipLaunchKernelGGL(float_exprange_kernel<uint32_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint32_t *)val, n_rows, out);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 template <typename U>
 __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
-                                                                   uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base,
-                                                                   uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out, uint32_t *__restrict__ range_flag) {
-    extern __shared__ uint64_t direct_tab[];                                   // [kFsumBins][nb] adders, then [3][nb] words: count, negative zeros, flags
+                                                                   uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base, uint32_t nbins,
+                                                                   uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out) {
+    extern __shared__ uint64_t direct_tab[];                                   // [nbins][nb] adders, then [3][nb] words: count, negative zeros, flags
     uint64_t *bin = direct_tab;
-    uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)kFsumBins * nb);
-    for (uint32_t i = threadIdx.x; i < kFsumBins * nb; i += kDirectBlock) bin[i] = 0;
+    uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)nbins * nb);
+    for (uint32_t i = threadIdx.x; i < nbins * nb; i += kDirectBlock) bin[i] = 0;
     for (uint32_t i = threadIdx.x; i < 3 * nb; i += kDirectBlock) word[i] = 0;
     __syncthreads();
     const uint64_t span = (uint64_t)nb * (uint64_t)step;
     const double inv = 1.0 / (double)step;
-    bool below = false;
     auto push = [&](int64_t t, U x, uint64_t) {
         const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
         if (q == kNoKey) return;
@@ -690,30 +699,28 @@ __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t
         const bool neg = (d >> 63) != 0;
         if (be == 0x7ffu) { atomicOr(&word[2 * nb + q], frac != 0 ? 4u : neg ? 2u : 1u); return; }
         if (be == 0 && frac == 0) { if (neg) atomicAdd(&word[nb + q], 1u); return; }
-        const uint32_t lsb = be != 0 ? be : 1u;                 // the value is m * 2^(lsb - 1075)
-        if (lsb < base) { below = true; return; }               // finer than the table's last digit: the caller sorts instead
+        const uint32_t lsb = be != 0 ? be : 1u;                 // the value is m * 2^(lsb - 1075); lsb >= base: base is the column's smallest
         const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
         const uint32_t sft = lsb - base, i0 = sft >> 5, r = sft & 31u;
         const unsigned __int128 p = (unsigned __int128)m << r;  // <= 84 bits
         const uint64_t piece[3] = {(uint64_t)p & 0xffffffffull, (uint64_t)(p >> 32) & 0xffffffffull, (uint64_t)(p >> 64)};
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            if (piece[j] != 0 && i0 + j < (uint32_t)kFsumBins)
+            if (piece[j] != 0 && i0 + j < nbins)
                 atomicAdd(reinterpret_cast<unsigned long long *>(&bin[(size_t)(i0 + j) * nb + q]), (unsigned long long)(neg ? 0ull - piece[j] : piece[j]));
     };
     direct_walk<U, true>(time, val, mask, n_rows, push);
-    if (__any(below) && (threadIdx.x & 63) == 0) atomicOr(range_flag, 1u);
     __syncthreads();
-    uint64_t *so = slots_out + (size_t)blockIdx.x * kFsumBins * nb;
+    uint64_t *so = slots_out + (size_t)blockIdx.x * nbins * nb;
     uint32_t *wo = words_out + (size_t)blockIdx.x * 3 * nb;
-    for (uint32_t i = threadIdx.x; i < kFsumBins * nb; i += kDirectBlock) so[i] = bin[i];
+    for (uint32_t i = threadIdx.x; i < nbins * nb; i += kDirectBlock) so[i] = bin[i];
     for (uint32_t i = threadIdx.x; i < 3 * nb; i += kDirectBlock) wo[i] = word[i];
 }
 
 // 64 windows per workgroup, the tables dealt to its four waves; the 160-bit sum -> a double-double -> Value() (knox_finalize.h)
 template <typename U>
 __global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
-                                                                 uint32_t base, int dtype, int func, void *values, uint8_t *seen) {
+                                                                 uint32_t base, uint32_t nbins, int dtype, int func, void *values, uint8_t *seen) {
     __shared__ uint64_t f_bin[4][kFsumBins][64];
     __shared__ uint32_t f_w[4][3][64];
     const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -725,7 +732,8 @@ __global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t 
 #pragma unroll 2
         for (uint32_t g = part; g < grid; g += 4) {
 #pragma unroll
-            for (int i = 0; i < kFsumBins; i++) b[i] += slots[((size_t)g * kFsumBins + i) * nb + k];
+            for (int i = 0; i < kFsumBins; i++)
+                if ((uint32_t)i < nbins) b[i] += slots[((size_t)g * nbins + i) * nb + k];
             w[0] += words[((size_t)g * 3 + 0) * nb + k];
             w[1] += words[((size_t)g * 3 + 1) * nb + k];
             w[2] |= words[((size_t)g * 3 + 2) * nb + k];
@@ -805,36 +813,38 @@ __global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t 
     seen[k] = (rc == 0 && sn) ? 1 : 0;
 }
 
-// exp_max: the column's largest finite biased float64 exponent (launch_float_expmax).  grid 0: the table does not fit LDS, or the
-// column holds nothing the fixed-point form is good for (tiny values whose scaled results would be denormal)
-WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t n_buckets, int n_cus) {
+// exp_max / exp_min: the column's largest / smallest finite non-zero biased float64 exponent (launch_float_exprange).  grid 0: the
+// exponents span more than the five digits hold (160 bits = 107 binades + a mantissa), the table does not fit LDS, or the column holds
+// nothing the fixed-point form is good for (no finite non-zero value; values so small that the scaled result would be denormal)
+WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus) {
     WindowFsumGeom g;
     g.grid = 0;
-    g.base = 0;
-    g.lds = (size_t)n_buckets * (8u * kFsumBins + 12u);
-    g.scratch = 0;
-    if (exp_max < 200 || g.lds > 156 * 1024) return g;
-    g.base = exp_max - kFsumRange;
+    g.base = g.nbins = 0;
+    g.lds = g.scratch = 0;
+    if (exp_max < 200 || exp_min == 0 || exp_min > exp_max || exp_max - exp_min > (uint32_t)kFsumRange) return g;
+    g.base = exp_min;
+    g.nbins = (exp_max - exp_min + 53 + 31) / 32;
+    g.lds = (size_t)n_buckets * (8u * g.nbins + 12u);
+    if (g.lds > 156 * 1024) return g;
     g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
     g.scratch = (size_t)g.grid * g.lds + 512;
     return g;
 }
 
-// func: KNOX_R_SUM / KNOX_R_MEAN over a float column; *range_flag (zeroed by the caller) != 0 afterwards: a selected value lay below the
-// table's range -- values / seen are then meaningless and the caller takes the sorted path
+// func: KNOX_R_SUM / KNOX_R_MEAN over a float column
 hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask,
-                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, uint32_t *range_flag, void *values, uint8_t *seen) {
+                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen) {
     if (n_buckets == 0 || g.grid == 0 || (func != 0 && func != 5)) return hipErrorInvalidValue;
     uint64_t *slots = (uint64_t *)scratch;
-    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * kFsumBins * n_buckets);
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.nbins * n_buckets);
     const dim3 fgrid((n_buckets + 63) / 64), fblock(256);
 #define KNOX_FSUM(U)                                                                                                                                \
     do {                                                                                                                                            \
         if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fsum_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
         hipLaunchKernelGGL((window_fsum_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
-                           g.base, slots, words, range_flag);                                                                                       \
+                           g.base, g.nbins, slots, words);                                                                                          \
         hipLaunchKernelGGL((window_fsum_finish_kernel<U>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, g.base, \
-                           dtype, func, values, seen);                                                                                              \
+                           g.nbins, dtype, func, values, seen);                                                                                     \
     } while (0)
     if (width == 8) KNOX_FSUM(uint64_t);
     else if (width == 4) KNOX_FSUM(uint32_t);

@@ -114,43 +114,39 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             return KNOX_OK;
         }
     }
-    // float sums / means: exact fixed-point adders sized by the column's largest exponent (one pass over the values the first time, kept
-    // with the column); a selected value too small for the table's range is reported and the call falls through to the sort
+    // float sums / means: exact fixed-point adders sized by the column's smallest and largest exponent (one pass over the values the first
+    // time, kept with the column); a column spanning more than 107 binades, or more windows than LDS holds adders for, takes the sort
     if (ctx->win_values != nullptr && !(flags & 2) && (ctx->win_func == KNOX_R_SUM || ctx->win_func == KNOX_R_MEAN) &&
-        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 4096) {
+        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 8192) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");
         if (!(env && atoi(env) == 0)) {
             int rc = ensure(ctx, ctx->misc, 256);
             if (rc) return rc;
-            uint32_t *d_exp = (uint32_t *)((char *)ctx->misc.p + 96), *d_range = d_exp + 1;
-            int emax = col_fexp_cached(value_col);
-            HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_exp, 8));
+            uint32_t *d_exp = (uint32_t *)((char *)ctx->misc.p + 96);
+            int emax = col_fexp_cached(value_col), emin = value_col->fexp_min;
             if (emax < 0) {
-                hipError_t e = launch_float_expmax(ctx->stream, (int)w, value_col->dev, n_rows, d_exp);
+                HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_exp, 8));
+                hipError_t e = launch_float_exprange(ctx->stream, (int)w, value_col->dev, n_rows, d_exp);
                 if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-                uint32_t h = 0;
-                HIPCHK(ctx, hipMemcpyAsync(&h, d_exp, 4, hipMemcpyDeviceToHost, ctx->stream));
+                uint32_t h[2] = {0, 0};
+                HIPCHK(ctx, hipMemcpyAsync(h, d_exp, 8, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                emax = (int)h;
-                col_fexp_set(value_col, emax);
+                emax = (int)h[0];
+                emin = emax ? (int)(~h[1]) : 0;
+                col_fexp_set(value_col, emax, emin);
             }
-            const WindowFsumGeom fg = window_fsum_geom((uint32_t)emax, (uint32_t)n_buckets, ctx->n_cus);
+            const WindowFsumGeom fg = window_fsum_geom((uint32_t)emax, (uint32_t)emin, (uint32_t)n_buckets, ctx->n_cus);
             if (fg.grid != 0) {
                 rc = ensure(ctx, ctx->sort_buf, fg.scratch);
                 if (rc) return rc;
                 hipError_t e = launch_window_fsum(ctx->stream, (int)w, value_col->dtype, ctx->win_func, fg, (const int64_t *)time_col->dev, value_col->dev,
-                                                  mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, ctx->sort_buf.p, d_range,
+                                                  mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, ctx->sort_buf.p,
                                                   ctx->win_values, ctx->win_seen);
                 if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-                uint32_t below = 0;
-                HIPCHK(ctx, hipMemcpyAsync(&below, d_range, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                if (below == 0) {
-                    ctx->win_path = KNOX_WINDOWS_DIRECT_FLOAT_SUMS;
-                    ctx->win_values_done = true;
-                    *states_dev = nullptr;
-                    return KNOX_OK;
-                }
+                ctx->win_path = KNOX_WINDOWS_DIRECT_FLOAT_SUMS;
+                ctx->win_values_done = true;
+                *states_dev = nullptr;
+                return KNOX_OK;
             }
         }
     }

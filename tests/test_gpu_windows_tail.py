@@ -463,13 +463,13 @@ def test_out_of_order_windows_float_sums_are_exact_without_the_sort():
     window (window_fsum_kernel: LDS adds of 32-bit digits), so the fold is exact whatever the order -- against math.fsum (the
     correctly rounded exact sum) and against the sorted path's double-double sums (KNOX_WINDOW_DIRECT=0), float64 and float32, values
     spread over ~2^70 in magnitude; infinities of both signs, NaNs and negative zeros follow IEEE (inf - inf and NaN -> NaN, a sum of
-    nothing but -0 is -0); a column whose exponents span more than the adders hold falls through to the sort."""
+    nothing but -0 is -0); a column whose exponents span more than the adders hold (107 binades) takes the sort."""
     import math, os
     rng = np.random.default_rng(31337)
     old = os.environ.pop("KNOX_WINDOW_DIRECT", None)
     try:
         with K.Context(0) as ctx:
-            for n, nb, step in ((400_003, 300, 7), (50_000, 3072, 2), (50_000, 3073, 2)):
+            for n, nb, step in ((400_003, 300, 7), (50_000, 3500, 2), (50_000, 8193, 2)):
                 t_from = 10_000
                 key = rng.integers(-1, nb + 1, n)
                 t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
@@ -498,7 +498,7 @@ def test_out_of_order_windows_float_sums_are_exact_without_the_sort():
                                 os.environ.pop("KNOX_WINDOW_DIRECT")
                                 a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
                                 # 6 = the exact adders ran; 2 / 3 = the sort (more windows than LDS holds, exponents wider than the adders)
-                                sorts = nb > 3072 or (kind == "too wide" and bt == B.Float64)
+                                sorts = nb > 8192 or (kind == "too wide" and bt == B.Float64)
                                 assert ctx.windows_last_path() in ((2, 3) if sorts else (6,)), (nb, kind, bt, ctx.windows_last_path())
                                 assert (b == want_seen).all(), (n, nb, bt, kind, f)
                                 assert np.array_equal(a, want, equal_nan=True) and (np.signbit(a) == np.signbit(want))[~np.isnan(want)].all(), (n, nb, bt, kind, f)
