@@ -5,6 +5,8 @@
   * the hand-written stable radix sort behind out-of-order time (knox_sort.hip): 1, 2, 3 and 4 digit passes, against a
     stable numpy argsort -- First / Last observe the stream order inside a window, which is exactly what stability means;
   * knox_bits_indexes_view == knox_bits_indexes; the async flag / count ring shared with knox_scan_async."""
+import os
+
 import numpy as np
 import pytest
 
@@ -90,25 +92,35 @@ def test_out_of_order_windows_sort_is_stable_for_every_pass_count(nb, n):
             info = np.iinfo(dt)
             v = rng.integers(info.min, info.max, n, endpoint=True, dtype=dt)
             vcol = ctx.upload(v, 4096)
-            got = {}
-            for f in (R.First, R.Last, R.Count, R.Sum, R.Max):
-                vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=mask)
-                got[f] = (vals.copy(), seen.copy())
-            seen = got[R.First][1]
-            assert np.flatnonzero(seen).tolist() == present.tolist()
-            assert (got[R.First][0][present] == v[order[first_pos]]).all(), bt
-            assert (got[R.Last][0][present] == v[order[last_pos]]).all(), bt
-            cnt = np.bincount(ks, minlength=nb)[present]
-            assert (got[R.Count][0][present] == cnt.astype(dt)).all(), bt          # CountReducer counts in T
-            sums = np.zeros(nb, dtype=np.uint64)
-            np.add.at(sums, ks, v[order].astype(np.int64).astype(np.uint64))
-            udt = np.dtype("u%d" % np.dtype(dt).itemsize)                            # SumReducer wraps in T
-            assert (got[R.Sum][0].view(udt)[present] == sums[present].astype(udt)).all(), bt
-            mx = np.full(nb, info.min, dtype=np.int64)
-            np.maximum.at(mx, ks, v[order].astype(np.int64))
-            assert (got[R.Max][0][present].astype(np.int64) == mx[present]).all(), bt
-            # windows without rows: Value() is the zero value, seen 0
-            assert not got[R.Sum][0][seen == 0].any()
+            for direct in ("0", None):        # through the sort, and (few windows) folded where the rows lie: the same oracle
+                keep = os.environ.pop("KNOX_WINDOW_DIRECT", None)
+                if direct is not None:
+                    os.environ["KNOX_WINDOW_DIRECT"] = direct
+                got = {}
+                try:
+                    for f in (R.First, R.Last, R.Count, R.Sum, R.Max):
+                        vals, seen = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=mask)
+                        got[f] = (vals.copy(), seen.copy())
+                        assert (ctx.windows_last_path() in (2, 3)) == (direct == "0" or nb > 19_000), (nb, f, direct)
+                finally:
+                    os.environ.pop("KNOX_WINDOW_DIRECT", None)
+                    if keep is not None:
+                        os.environ["KNOX_WINDOW_DIRECT"] = keep
+                seen = got[R.First][1]
+                assert np.flatnonzero(seen).tolist() == present.tolist()
+                assert (got[R.First][0][present] == v[order[first_pos]]).all(), bt
+                assert (got[R.Last][0][present] == v[order[last_pos]]).all(), bt
+                cnt = np.bincount(ks, minlength=nb)[present]
+                assert (got[R.Count][0][present] == cnt.astype(dt)).all(), bt          # CountReducer counts in T
+                sums = np.zeros(nb, dtype=np.uint64)
+                np.add.at(sums, ks, v[order].astype(np.int64).astype(np.uint64))
+                udt = np.dtype("u%d" % np.dtype(dt).itemsize)                            # SumReducer wraps in T
+                assert (got[R.Sum][0].view(udt)[present] == sums[present].astype(udt)).all(), bt
+                mx = np.full(nb, info.min, dtype=np.int64)
+                np.maximum.at(mx, ks, v[order].astype(np.int64))
+                assert (got[R.Max][0][present].astype(np.int64) == mx[present]).all(), bt
+                # windows without rows: Value() is the zero value, seen 0
+                assert not got[R.Sum][0][seen == 0].any()
             vcol.free()
         tcol.free(); mask.free()
 
