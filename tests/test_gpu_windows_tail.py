@@ -523,6 +523,26 @@ def test_out_of_order_windows_float_sums_are_exact_without_the_sort():
                                         assert a[k] == math.fsum(v[rows].tolist()), (k, m is not None)
                         vcol.free()
                 tcol.free(); mask.free()
+            # cancellation far beyond a double-double: every window holds pairs (x, -x) of magnitude ~1e15 and a few values near 1e-3 --
+            # the exact adders return math.fsum's answer (negative totals and two's-complement carries across all digits included)
+            n, nb, step, t_from = 200_000, 500, 5, 0
+            half = n // 2
+            key = rng.integers(0, nb, half)
+            big = rng.standard_normal(half) * 1e15
+            small = rng.standard_normal(half) * 1e-3
+            v = np.concatenate([big, -big + 0.0]).astype(np.float64)
+            v[rng.integers(0, n, n // 10)] = small[: n // 10]
+            keys = np.concatenate([key, key])
+            perm = rng.permutation(n)
+            v, keys = v[perm], keys[perm]
+            t = (t_from + keys * step + rng.integers(0, step, n)).astype(np.int64)
+            tcol, vcol = ctx.upload(t, 4096), ctx.upload(v, 4096)
+            a, b = ctx.reduce_buckets_values(tcol, vcol, R.Sum, t_from, step, nb)
+            assert ctx.windows_last_path() == 6
+            for k in range(nb):
+                rows = np.flatnonzero(keys == k)
+                assert a[k] == math.fsum(v[rows].tolist()), k
+            tcol.free(); vcol.free()
     finally:
         os.environ.pop("KNOX_WINDOW_DIRECT", None)
         if old is not None:

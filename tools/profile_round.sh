@@ -17,6 +17,9 @@ if [ "${KNOX_PROFILE_FAMILIES:-1}" = "1" ]; then
   bash tools/prof_cmd.sh $TAG encoded tools/bench_encoded.py 28 > gpurun_out/prof_${TAG}_encoded.log 2>&1
   export KNOX_SHUFFLED_ONLY=masked
   bash tools/prof_cmd.sh $TAG shuffled tools/bench_shuffled.py > gpurun_out/prof_${TAG}_shuffled.log 2>&1
+  export KNOX_SHUFFLED_DTYPE=f64  # Sum over float64: the exact fixed-point adders
+  bash tools/prof_cmd.sh $TAG shuffled_f64 tools/bench_shuffled.py > gpurun_out/prof_${TAG}_shuffled_f64.log 2>&1
+  unset KNOX_SHUFFLED_DTYPE
   export KNOX_WINDOW_DIRECT=0     # the same shape through the sort (what float sums, var / std and larger window counts still take)
   bash tools/prof_cmd.sh $TAG shuffled_sorted tools/bench_shuffled.py > gpurun_out/prof_${TAG}_shuffled_sorted.log 2>&1
   unset KNOX_WINDOW_DIRECT
