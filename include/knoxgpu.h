@@ -612,7 +612,7 @@ int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const kn
 
 /* Which way the last knox_reduce_buckets* call on this ctx took (diagnostics, tests): the time column was non-decreasing and the
  * windows were reduced in place; out-of-order time through the stable sort (after a compaction of the selected rows); out-of-order
- * time without a sort -- Value() of an order-free reducer, whole states of an integer column, exact float sums / means.          */
+ * time without a sort -- Value() of an order-free reducer, whole states, exact float sums / means.                                */
 enum knox_windows_path {
     KNOX_WINDOWS_ORDERED = 1, KNOX_WINDOWS_SORTED = 2, KNOX_WINDOWS_SORTED_COMPACTED = 3,
     KNOX_WINDOWS_DIRECT_VALUES = 4, KNOX_WINDOWS_DIRECT_STATES = 5, KNOX_WINDOWS_DIRECT_FLOAT_SUMS = 6

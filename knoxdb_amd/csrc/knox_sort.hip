@@ -677,6 +677,71 @@ hipError_t launch_float_exprange(hipStream_t s, int width, const void *val, uint
     return hipGetLastError();
 }
 
+// the adders of one window -> the exact sum as a double-double (hi = the sum rounded to nearest, lo = what is left, rounded), with
+// IEEE's answers for the values that never entered the adders: flags bit 0 / 1 / 2 = +inf / -inf / NaN seen
+__device__ __forceinline__ void fixed_sum_to_dd(const uint64_t (&b)[kFsumBins], uint32_t base, uint64_t count, uint64_t neg_zeros, uint32_t flags, double &rh_out,
+                                                double &rl_out) {
+    // T = sum of b[i] * 2^(32 i), every b[i] a signed 64-bit number: 192 bits in two's complement (lo | hi)
+    uint64_t lo = 0;
+    __int128 hi = 0;
+    auto add = [&](uint64_t lo_add, __int128 hi_add) {
+        const uint64_t nl = lo + lo_add;
+        hi += hi_add + (nl < lo ? 1 : 0);
+        lo = nl;
+    };
+    const __int128 v0 = (__int128)(int64_t)b[0], v1 = (__int128)(int64_t)b[1] * ((__int128)1 << 32);
+    add((uint64_t)v0, v0 >> 64);
+    add((uint64_t)v1, v1 >> 64);
+    add(0, (__int128)(int64_t)b[2]);
+    add(0, (__int128)(int64_t)b[3] * ((__int128)1 << 32));
+    add(0, (__int128)(int64_t)b[4] * ((__int128)1 << 64));
+    const bool neg = hi < 0;
+    if (neg) {
+        lo = ~lo + 1;
+        hi = ~hi + (lo == 0 ? 1 : 0);
+    }
+    const unsigned __int128 mh = (unsigned __int128)hi;
+    const uint32_t piece[6] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)mh, (uint32_t)(mh >> 32), (uint32_t)(mh >> 64), (uint32_t)(mh >> 96)};
+    // the six digits, from the top, into a three-term expansion (error-free two_sum steps), then a double-double
+    double s = ldexp((double)piece[5], 160), c = 0.0, c2 = 0.0;
+#pragma unroll
+    for (int j = 4; j >= 0; j--) {
+        const knox_fin::dd t1 = knox_fin::two_sum(s, ldexp((double)piece[j], 32 * j));
+        const knox_fin::dd t2 = knox_fin::two_sum(c, t1.lo);
+        s = t1.hi;
+        c = t2.hi;
+        c2 += t2.lo;
+    }
+    knox_fin::dd r = knox_fin::fast_two_sum(s, c + c2);
+    const int sc = (int)base - 1075;
+    double rh = ldexp(r.hi, sc), rl = ldexp(r.lo, sc);
+    if (neg) { rh = -rh; rl = -rl; }
+    if (rh == 0.0) rh = (count != 0 && neg_zeros == count) ? -0.0 : 0.0;     // nothing but negative zeros: -0
+    if (flags != 0) {                                                   // IEEE: NaN, inf - inf -> NaN; else the infinity
+        rl = 0.0;
+        rh = ((flags & 4u) || (flags & 3u) == 3u) ? __longlong_as_double(0x7ff8000000000000ll) : (flags & 1u) ? __longlong_as_double(0x7ff0000000000000ll)
+                                                                                                              : __longlong_as_double((long long)0xfff0000000000000ull);
+    }
+    rh_out = rh;
+    rl_out = rl;
+}
+
+// one finite non-zero value into the adders of window q (d: its float64 bits)
+__device__ __forceinline__ void fixed_sum_push(uint64_t *bin, uint32_t nb, uint32_t q, uint32_t nbins, uint32_t base, uint64_t d) {
+    const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+    const uint64_t frac = d & 0xfffffffffffffull;
+    const bool neg = (d >> 63) != 0;
+    const uint32_t lsb = be != 0 ? be : 1u;                 // the value is m * 2^(lsb - 1075); lsb >= base: base is the column's smallest
+    const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
+    const uint32_t sft = lsb - base, i0 = sft >> 5, r = sft & 31u;
+    const unsigned __int128 p = (unsigned __int128)m << r;  // <= 84 bits
+    const uint64_t piece[3] = {(uint64_t)p & 0xffffffffull, (uint64_t)(p >> 32) & 0xffffffffull, (uint64_t)(p >> 64)};
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (piece[j] != 0 && i0 + j < nbins)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&bin[(size_t)(i0 + j) * nb + q]), (unsigned long long)(neg ? 0ull - piece[j] : piece[j]));
+}
+
 template <typename U>
 __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
                                                                    uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base, uint32_t nbins,
@@ -699,15 +764,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t
         const bool neg = (d >> 63) != 0;
         if (be == 0x7ffu) { atomicOr(&word[2 * nb + q], frac != 0 ? 4u : neg ? 2u : 1u); return; }
         if (be == 0 && frac == 0) { if (neg) atomicAdd(&word[nb + q], 1u); return; }
-        const uint32_t lsb = be != 0 ? be : 1u;                 // the value is m * 2^(lsb - 1075); lsb >= base: base is the column's smallest
-        const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
-        const uint32_t sft = lsb - base, i0 = sft >> 5, r = sft & 31u;
-        const unsigned __int128 p = (unsigned __int128)m << r;  // <= 84 bits
-        const uint64_t piece[3] = {(uint64_t)p & 0xffffffffull, (uint64_t)(p >> 32) & 0xffffffffull, (uint64_t)(p >> 64)};
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            if (piece[j] != 0 && i0 + j < nbins)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&bin[(size_t)(i0 + j) * nb + q]), (unsigned long long)(neg ? 0ull - piece[j] : piece[j]));
+        fixed_sum_push(bin, nb, q, nbins, base, d);
     };
     direct_walk<U, true>(time, val, mask, n_rows, push);
     __syncthreads();
@@ -753,47 +810,8 @@ __global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t 
         w[1] += f_w[p][1][lane];
         w[2] |= f_w[p][2][lane];
     }
-    // T = sum of b[i] * 2^(32 i), every b[i] a signed 64-bit number: 192 bits in two's complement (lo | hi)
-    uint64_t lo = 0;
-    __int128 hi = 0;
-    auto add = [&](uint64_t lo_add, __int128 hi_add) {
-        const uint64_t nl = lo + lo_add;
-        hi += hi_add + (nl < lo ? 1 : 0);
-        lo = nl;
-    };
-    const __int128 v0 = (__int128)(int64_t)b[0], v1 = (__int128)(int64_t)b[1] * ((__int128)1 << 32);
-    add((uint64_t)v0, v0 >> 64);
-    add((uint64_t)v1, v1 >> 64);
-    add(0, (__int128)(int64_t)b[2]);
-    add(0, (__int128)(int64_t)b[3] * ((__int128)1 << 32));
-    add(0, (__int128)(int64_t)b[4] * ((__int128)1 << 64));
-    const bool neg = hi < 0;
-    if (neg) {
-        lo = ~lo + 1;
-        hi = ~hi + (lo == 0 ? 1 : 0);
-    }
-    const unsigned __int128 mh = (unsigned __int128)hi;
-    const uint32_t piece[6] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)mh, (uint32_t)(mh >> 32), (uint32_t)(mh >> 64), (uint32_t)(mh >> 96)};
-    // the six digits, from the top, into a three-term expansion (error-free two_sum steps), then a double-double
-    double s = ldexp((double)piece[5], 160), c = 0.0, c2 = 0.0;
-#pragma unroll
-    for (int j = 4; j >= 0; j--) {
-        const knox_fin::dd t1 = knox_fin::two_sum(s, ldexp((double)piece[j], 32 * j));
-        const knox_fin::dd t2 = knox_fin::two_sum(c, t1.lo);
-        s = t1.hi;
-        c = t2.hi;
-        c2 += t2.lo;
-    }
-    knox_fin::dd r = knox_fin::fast_two_sum(s, c + c2);
-    const int sc = (int)base - 1075;
-    double rh = ldexp(r.hi, sc), rl = ldexp(r.lo, sc);
-    if (neg) { rh = -rh; rl = -rl; }
-    if (rh == 0.0) rh = (w[0] != 0 && w[1] == w[0]) ? -0.0 : 0.0;     // nothing but negative zeros: -0
-    if (w[2] != 0) {                                                   // IEEE: NaN, inf - inf -> NaN; else the infinity
-        rl = 0.0;
-        rh = ((w[2] & 4u) || (w[2] & 3u) == 3u) ? __longlong_as_double(0x7ff8000000000000ll) : (w[2] & 1u) ? __longlong_as_double(0x7ff0000000000000ll)
-                                                                                                              : __longlong_as_double((long long)0xfff0000000000000ull);
-    }
+    double rh, rl;
+    fixed_sum_to_dd(b, base, w[0], w[1], w[2], rh, rl);
     AggStateDev st;
     st.dtype = dtype;
     st.flags = 1u;
@@ -850,6 +868,240 @@ hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, Win
     else if (width == 4) KNOX_FSUM(uint32_t);
     else return hipErrorInvalidValue;
 #undef KNOX_FSUM
+    return hipGetLastError();
+}
+
+// ---- ... and the whole state of a FLOAT column: the exact adders for the sum, the order keys of acc_update (knox_dev.h) for min / max --
+// a NaN is never a candidate, both zeros share one key, the lowest row among equal keys wins --, first / last rows.  float32: (key, row)
+// in one 64-bit atomic, one walk; float64: a second walk for the rows of min / max, as for 8-byte integers.
+template <typename U> struct FStateShape {
+    static constexpr bool WIDE = sizeof(U) == 8;
+    static constexpr U SIGN = (U)1 << (8 * sizeof(U) - 1);
+    static constexpr U EXPMASK = WIDE ? (U)0x7ff0000000000000ull : (U)0x7f800000u;
+    static constexpr int NW = 5;                                  // count, first row, last row + 1, negative zeros, non-finite flags
+    __device__ static bool is_nan(U x) { return (U)(x & (U)~SIGN) > EXPMASK; }
+    __device__ static uint64_t key(U x) {                         // x is not a NaN
+        const U mag = x & (U)~SIGN;
+        return (uint64_t)(mag == 0 ? SIGN : ((x & SIGN) ? (U)~x : (U)(x | SIGN)));
+    }
+};
+
+template <typename U>
+__global__ void __launch_bounds__(kDirectBlock) window_fstate_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                     uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base, uint32_t nbins,
+                                                                     uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out) {
+    using SH = FStateShape<U>;
+    extern __shared__ uint64_t direct_tab[];                                       // [nbins] adders | min | max, then the words
+    const uint32_t ns = nbins + 2;
+    uint64_t *slot = direct_tab;
+    uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)ns * nb);
+    for (uint32_t i = threadIdx.x; i < ns * nb; i += kDirectBlock) slot[i] = (i / nb) == nbins ? ~0ull : 0ull;
+    for (uint32_t i = threadIdx.x; i < SH::NW * nb; i += kDirectBlock) word[i] = (i / nb) == 1 ? ~0u : 0u;
+    __syncthreads();
+    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    auto push = [&](int64_t t, U x, uint64_t row) {
+        const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
+        if (q == kNoKey) return;
+        const uint32_t r32 = (uint32_t)row;
+        atomicAdd(&word[q], 1u);
+        atomicMin(&word[nb + q], r32);
+        atomicMax(&word[2 * nb + q], r32 + 1u);
+        if (!SH::is_nan(x)) {
+            const uint64_t k = SH::key(x);
+            unsigned long long *pmin = reinterpret_cast<unsigned long long *>(&slot[(size_t)nbins * nb + q]);
+            unsigned long long *pmax = reinterpret_cast<unsigned long long *>(&slot[(size_t)(nbins + 1) * nb + q]);
+            if constexpr (SH::WIDE) {
+                atomicMin(pmin, (unsigned long long)k);
+                atomicMax(pmax, (unsigned long long)k);
+            } else {
+                atomicMin(pmin, (unsigned long long)((k << 32) | r32));
+                atomicMax(pmax, (unsigned long long)((k << 32) | (uint32_t)~r32));
+            }
+        }
+        const uint64_t d = as_f64_bits(x);
+        const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+        const uint64_t frac = d & 0xfffffffffffffull;
+        const bool neg = (d >> 63) != 0;
+        if (be == 0x7ffu) { atomicOr(&word[4 * nb + q], frac != 0 ? 4u : neg ? 2u : 1u); return; }
+        if (be == 0 && frac == 0) { if (neg) atomicAdd(&word[3 * nb + q], 1u); return; }
+        fixed_sum_push(slot, nb, q, nbins, base, d);
+    };
+    direct_walk<U, true>(time, val, mask, n_rows, push);
+    __syncthreads();
+    uint64_t *so = slots_out + (size_t)blockIdx.x * ns * nb;
+    uint32_t *wo = words_out + (size_t)blockIdx.x * SH::NW * nb;
+    for (uint32_t i = threadIdx.x; i < ns * nb; i += kDirectBlock) so[i] = slot[i];
+    for (uint32_t i = threadIdx.x; i < SH::NW * nb; i += kDirectBlock) wo[i] = word[i];
+}
+
+// the workgroups' tables folded -> merged[kFsumBins + 2 + 5][nb] (64-bit words; unused adders 0)
+template <typename U>
+__global__ void __launch_bounds__(256) window_fstate_merge_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
+                                                                  uint32_t nbins, uint64_t *__restrict__ merged) {
+    constexpr int NF = kFsumBins + 2 + 5;
+    __shared__ uint64_t part_f[4][NF][64];
+    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64 + lane;
+    const bool valid = k < nb;
+    const uint32_t ns = nbins + 2;
+    uint64_t f[NF];
+#pragma unroll
+    for (int i = 0; i < NF; i++) f[i] = 0;
+    f[kFsumBins] = ~0ull;              // min key (pack)
+    f[kFsumBins + 3] = 0xffffffffull;  // first row
+    auto fold = [&](int i, uint64_t v) {
+        if (i == kFsumBins || i == kFsumBins + 3) f[i] = v < f[i] ? v : f[i];
+        else if (i == kFsumBins + 1 || i == kFsumBins + 4) f[i] = v > f[i] ? v : f[i];
+        else if (i == kFsumBins + 6) f[i] |= v;
+        else f[i] += v;
+    };
+    if (valid) {
+#pragma unroll 2
+        for (uint32_t g = part; g < grid; g += 4) {
+            const uint64_t *p = slots + (size_t)g * ns * nb + k;
+            const uint32_t *q = words + (size_t)g * 5 * nb + k;
+#pragma unroll
+            for (int i = 0; i < kFsumBins; i++)
+                if ((uint32_t)i < nbins) fold(i, p[(size_t)i * nb]);
+            fold(kFsumBins, p[(size_t)nbins * nb]);
+            fold(kFsumBins + 1, p[(size_t)(nbins + 1) * nb]);
+#pragma unroll
+            for (int i = 0; i < 5; i++) fold(kFsumBins + 2 + i, q[(size_t)i * nb]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF; i++) part_f[part][i][lane] = f[i];
+    __syncthreads();
+    if (part != 0 || !valid) return;
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+#pragma unroll
+        for (int i = 0; i < NF; i++) fold(i, part_f[w][i][lane]);
+    }
+#pragma unroll
+    for (int i = 0; i < NF; i++) merged[(size_t)i * nb + k] = f[i];
+}
+
+// float64, second walk: the lowest row among those that hold the window's min / max key
+template <typename U>
+__global__ void __launch_bounds__(kDirectBlock) window_fstate_rows_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                          uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb,
+                                                                          const uint64_t *__restrict__ merged, uint32_t *__restrict__ rows_out) {
+    using SH = FStateShape<U>;
+    extern __shared__ uint64_t direct_tab[];
+    uint64_t *gmin = direct_tab, *gmax = direct_tab + nb;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(direct_tab + 2 * (size_t)nb);      // min row | max row
+    for (uint32_t i = threadIdx.x; i < nb; i += kDirectBlock) {
+        gmin[i] = merged[(size_t)kFsumBins * nb + i];
+        gmax[i] = merged[(size_t)(kFsumBins + 1) * nb + i];
+        rows[i] = ~0u;
+        rows[nb + i] = ~0u;
+    }
+    __syncthreads();
+    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    auto push = [&](int64_t t, U x, uint64_t row) {
+        const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
+        if (q == kNoKey || SH::is_nan(x)) return;
+        const uint64_t key = SH::key(x);
+        if (key == gmin[q]) atomicMin(&rows[q], (uint32_t)row);
+        if (key == gmax[q]) atomicMin(&rows[nb + q], (uint32_t)row);
+    };
+    direct_walk<U, true>(time, val, mask, n_rows, push);
+    __syncthreads();
+    uint32_t *ro = rows_out + (size_t)blockIdx.x * 2 * nb;
+    for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) ro[i] = rows[i];
+}
+
+template <typename U>
+__global__ void __launch_bounds__(256) window_fstate_finish_kernel(const uint64_t *__restrict__ merged, const uint32_t *__restrict__ rows2, uint32_t grid, uint32_t nb,
+                                                                   uint32_t base, const U *__restrict__ val, uint64_t row_base, int dtype,
+                                                                   AggStateDev *__restrict__ state_out) {
+    using SH = FStateShape<U>;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    uint64_t b[kFsumBins];
+#pragma unroll
+    for (int i = 0; i < kFsumBins; i++) b[i] = merged[(size_t)i * nb + k];
+    const uint64_t minv = merged[(size_t)kFsumBins * nb + k], maxv = merged[(size_t)(kFsumBins + 1) * nb + k];
+    const uint64_t count = merged[(size_t)(kFsumBins + 2) * nb + k], firstrow = merged[(size_t)(kFsumBins + 3) * nb + k];
+    const uint64_t lastrow1 = merged[(size_t)(kFsumBins + 4) * nb + k], negz = merged[(size_t)(kFsumBins + 5) * nb + k];
+    const uint32_t flags = (uint32_t)merged[(size_t)(kFsumBins + 6) * nb + k];
+    const bool any = count != 0, cand = minv != ~0ull;        // cand: a value that is not a NaN was seen
+    uint64_t minrow = 0, maxrow = 0;
+    if constexpr (SH::WIDE) {
+        uint32_t r0 = ~0u, r1 = ~0u;
+#pragma unroll 8
+        for (uint32_t g = 0; g < grid; g++) {
+            const uint32_t a0 = rows2[(size_t)g * 2 * nb + k], a1 = rows2[(size_t)g * 2 * nb + nb + k];
+            r0 = a0 < r0 ? a0 : r0;
+            r1 = a1 < r1 ? a1 : r1;
+        }
+        minrow = r0;
+        maxrow = r1;
+    } else {
+        minrow = (uint32_t)minv;
+        maxrow = (uint32_t)~(uint32_t)maxv;
+    }
+    AggStateDev s;
+    s.dtype = dtype;
+    s.flags = 1u;
+    s.count = (int64_t)count;
+    s.isum = 0;
+    fixed_sum_to_dd(b, base, count, negz, flags, s.fsum_hi, s.fsum_lo);
+    s.min_row = (any && cand) ? (int64_t)(row_base + minrow) : -1;
+    s.max_row = (any && cand) ? (int64_t)(row_base + maxrow) : -1;
+    s.first_row = any ? (int64_t)(row_base + firstrow) : -1;
+    s.last_row = any ? (int64_t)(row_base + lastrow1 - 1) : -1;
+    s.min_bits = (any && cand) ? (uint64_t)val[minrow] : 0;
+    s.max_bits = (any && cand) ? (uint64_t)val[maxrow] : 0;
+    s.first_bits = any ? (uint64_t)val[firstrow] : 0;
+    s.last_bits = any ? (uint64_t)val[lastrow1 - 1] : 0;
+    s.m_shift = 0.0; s.m_dev_hi = 0.0; s.m_dev_lo = 0.0; s.m_sq_hi = 0.0; s.m_sq_lo = 0.0;
+    state_out[k] = s;
+}
+
+WindowFsumGeom window_fstate_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus) {
+    WindowFsumGeom g = window_fsum_geom(exp_max, exp_min, 1, n_cus);      // base / nbins, or grid 0
+    if (g.grid == 0) return g;
+    g.grid = 0;
+    g.lds = (size_t)n_buckets * (8u * (g.nbins + 2) + 20u);
+    if (g.lds > 156 * 1024) return g;
+    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
+    g.scratch = (size_t)g.grid * g.lds + (size_t)(kFsumBins + 7) * n_buckets * 8 + (size_t)g.grid * 2 * n_buckets * 4 + 1024;
+    return g;
+}
+
+hipError_t launch_window_fstate(hipStream_t s, int width, int dtype, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
+                                int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t row_base, void *scratch, AggStateDev *states_out) {
+    if (n_buckets == 0 || g.grid == 0) return hipErrorInvalidValue;
+    uint64_t *slots = (uint64_t *)scratch;
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * (g.nbins + 2) * n_buckets);
+    uint64_t *merged = (uint64_t *)((char *)scratch + (((size_t)g.grid * g.lds + 255) & ~(size_t)255));
+    uint32_t *rows2 = (uint32_t *)(merged + (size_t)(kFsumBins + 7) * n_buckets);
+    const dim3 fgrid((n_buckets + 255) / 256), mgrid((n_buckets + 63) / 64), fblock(256);
+    const size_t lds2 = (size_t)n_buckets * 24;
+    hipError_t ze = launch_zero_bytes(s, merged, (size_t)(kFsumBins + 7) * n_buckets * 8);      // (adders the column does not need stay 0)
+    if (ze != hipSuccess) return ze;
+#define KNOX_FSTATE(U)                                                                                                                              \
+    do {                                                                                                                                            \
+        if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fstate_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+        if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fstate_rows_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        hipLaunchKernelGGL((window_fstate_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
+                           g.base, g.nbins, slots, words);                                                                                          \
+        hipLaunchKernelGGL((window_fstate_merge_kernel<U>), mgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, g.nbins, \
+                           merged);                                                                                                                 \
+        if (sizeof(U) == 8)                                                                                                                         \
+            hipLaunchKernelGGL((window_fstate_rows_kernel<U>), dim3(g.grid), dim3(kDirectBlock), lds2, s, time, (const U *)val, mask, n_rows, t_from, step, \
+                               n_buckets, (const uint64_t *)merged, rows2);                                                                         \
+        hipLaunchKernelGGL((window_fstate_finish_kernel<U>), fgrid, fblock, 0, s, (const uint64_t *)merged, (const uint32_t *)rows2, g.grid, n_buckets, g.base, \
+                           (const U *)val, row_base, dtype, states_out);                                                                            \
+    } while (0)
+    if (width == 8) KNOX_FSTATE(uint64_t);
+    else if (width == 4) KNOX_FSTATE(uint32_t);
+    else return hipErrorInvalidValue;
+#undef KNOX_FSTATE
     return hipGetLastError();
 }
 

@@ -87,6 +87,29 @@ static int reduce_windows(knox_ctx *ctx, const void *vals, int dtype, const uint
 // are brought into window order by a STABLE radix sort of (window index, row id, value) triples (knox_sort.hip) -- rows
 // of one window keep their stream order, which is all the reducers can observe -- and the ordered pipeline runs on the
 // sorted copy of the values; the row ids inside the states are mapped back through the sorted row ids.
+// smallest / largest finite non-zero biased float64 exponent of a float column: one pass over the values the first time, kept with the
+// column afterwards (col_fexp_*); emax 0 = nothing finite and non-zero
+static int col_float_exprange(knox_ctx *ctx, const knox_col *col, int *emax_out, int *emin_out) {
+    int emax = col_fexp_cached(col), emin = col->fexp_min;
+    if (emax < 0) {
+        int rc = ensure(ctx, ctx->misc, 256);
+        if (rc) return rc;
+        uint32_t *d_exp = (uint32_t *)((char *)ctx->misc.p + 96);
+        HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_exp, 8));
+        hipError_t e = launch_float_exprange(ctx->stream, col->width, col->dev, col->n_rows, d_exp);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+        uint32_t h[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(h, d_exp, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        emax = (int)h[0];
+        emin = emax ? (int)(~h[1]) : 0;
+        col_fexp_set(col, emax, emin);
+    }
+    *emax_out = emax;
+    *emin_out = emin;
+    return KNOX_OK;
+}
+
 static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col, const knox_bits *mask, int64_t t_from,
                                     int64_t step, size_t n_buckets, uint64_t row_base, int flags, char **states_dev) {
     const size_t n_rows = value_col->n_rows;
@@ -120,21 +143,9 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
         (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 8192) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");
         if (!(env && atoi(env) == 0)) {
-            int rc = ensure(ctx, ctx->misc, 256);
+            int emax = 0, emin = 0;
+            int rc = col_float_exprange(ctx, value_col, &emax, &emin);
             if (rc) return rc;
-            uint32_t *d_exp = (uint32_t *)((char *)ctx->misc.p + 96);
-            int emax = col_fexp_cached(value_col), emin = value_col->fexp_min;
-            if (emax < 0) {
-                HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_exp, 8));
-                hipError_t e = launch_float_exprange(ctx->stream, (int)w, value_col->dev, n_rows, d_exp);
-                if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
-                uint32_t h[2] = {0, 0};
-                HIPCHK(ctx, hipMemcpyAsync(h, d_exp, 8, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                emax = (int)h[0];
-                emin = emax ? (int)(~h[1]) : 0;
-                col_fexp_set(value_col, emax, emin);
-            }
             const WindowFsumGeom fg = window_fsum_geom((uint32_t)emax, (uint32_t)emin, (uint32_t)n_buckets, ctx->n_cus);
             if (fg.grid != 0) {
                 rc = ensure(ctx, ctx->sort_buf, fg.scratch);
@@ -166,6 +177,28 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             ctx->win_path = KNOX_WINDOWS_DIRECT_STATES;
             *states_dev = (char *)ctx->tmp_vals.p;
             return KNOX_OK;
+        }
+    }
+    // ... float columns too: the exact adders for the sum, order keys with the reference's NaN / signed-zero rules for min / max
+    if (!(flags & 2) && n_buckets <= 8192 && (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32)) {
+        const char *env = getenv("KNOX_WINDOW_DIRECT");
+        if (!(env && atoi(env) == 0)) {
+            int emax = 0, emin = 0;
+            int rc = col_float_exprange(ctx, value_col, &emax, &emin);
+            if (rc) return rc;
+            const WindowFsumGeom sg = window_fstate_geom((uint32_t)emax, (uint32_t)emin, (uint32_t)n_buckets, ctx->n_cus);
+            if (sg.grid != 0) {
+                rc = ensure(ctx, ctx->sort_buf, sg.scratch);
+                if (!rc) rc = ensure(ctx, ctx->tmp_vals, n_buckets * sizeof(AggStateDev) + 64);
+                if (rc) return rc;
+                hipError_t e = launch_window_fstate(ctx->stream, (int)w, value_col->dtype, sg, (const int64_t *)time_col->dev, value_col->dev,
+                                                    mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, row_base,
+                                                    ctx->sort_buf.p, (AggStateDev *)ctx->tmp_vals.p);
+                if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+                ctx->win_path = KNOX_WINDOWS_DIRECT_STATES;
+                *states_dev = (char *)ctx->tmp_vals.p;
+                return KNOX_OK;
+            }
         }
     }
     unsigned key_bits = 1;

@@ -5,6 +5,7 @@
   * the hand-written stable radix sort behind out-of-order time (knox_sort.hip): 1, 2, 3 and 4 digit passes, against a
     stable numpy argsort -- First / Last observe the stream order inside a window, which is exactly what stability means;
   * knox_bits_indexes_view == knox_bits_indexes; the async flag / count ring shared with knox_scan_async."""
+import math
 import os
 
 import numpy as np
@@ -543,6 +544,63 @@ def test_out_of_order_windows_float_sums_are_exact_without_the_sort():
                 rows = np.flatnonzero(keys == k)
                 assert a[k] == math.fsum(v[rows].tolist()), k
             tcol.free(); vcol.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_DIRECT", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_DIRECT"] = old
+
+
+def test_out_of_order_windows_float_states_without_the_sort():
+    """knox_reduce_buckets over out-of-order time and a FLOAT column (window_fstate_kernel): every field against the sorted path's state
+    -- rows and bits of min / max with the reference's rules (a NaN is never a candidate, -0 == +0 and the first of them wins, windows
+    of nothing but NaNs have no min), first / last, count; the sum's value hi + lo is the same correctly rounded number on both paths and the
+    pairs agree to ~2^-95 of it (the sorted path's is a running double-double, this one's the exact sum split once)."""
+    rng = np.random.default_rng(2718)
+    old = os.environ.pop("KNOX_WINDOW_DIRECT", None)
+    try:
+        with K.Context(0) as ctx:
+            for n, nb, step in ((500_001, 400, 6), (60_000, 2000, 2), (300, 1, 40)):
+                t_from = -123_456
+                key = rng.integers(-1, nb + 1, n)
+                t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
+                tcol = ctx.upload(t, 4096)
+                mask = ctx.bits(n).upload(np.packbits(rng.random(n) < 0.4, bitorder="little"))
+                for bt in (B.Float64, B.Float32):
+                    for kind in ("ties and specials", "wide"):
+                        if kind == "wide":
+                            v = ((1.0 + rng.random(n)) * rng.choice([-1.0, 1.0], n) * 10.0 ** rng.integers(-6, 15, n)).astype(NP[bt])
+                        else:
+                            v = (rng.integers(-3, 4, n) / 2.0).astype(NP[bt])
+                            v[rng.random(n) < 0.2] = -0.0
+                            v[rng.random(n) < 0.1] = np.nan
+                            idx = rng.integers(0, n, 30)
+                            v[idx[:10]] = np.inf
+                            v[idx[10:20]] = -np.inf
+                            v[key == 2] = np.nan                      # a window of nothing but NaNs
+                        vcol = ctx.upload(v, 4096)
+                        for m in (None, mask):
+                            for base in (0, 1 << 34):
+                                os.environ["KNOX_WINDOW_DIRECT"] = "0"
+                                want = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=m, row_base=base)
+                                assert ctx.windows_last_path() in (2, 3)
+                                os.environ.pop("KNOX_WINDOW_DIRECT")
+                                got = ctx.reduce_buckets(tcol, vcol, t_from, step, nb, mask=m, row_base=base)
+                                assert ctx.windows_last_path() == 5
+                                for k in range(nb):
+                                    a, b = got[k], want[k]
+                                    for f in ("dtype", "flags", "count", "isum", "min_bits", "max_bits", "first_bits", "last_bits", "min_row", "max_row",
+                                              "first_row", "last_row"):
+                                        assert getattr(a, f) == getattr(b, f), (n, nb, bt, kind, k, f, getattr(a, f), getattr(b, f))
+                                    if math.isnan(b.fsum_hi) or math.isinf(b.fsum_hi):
+                                        assert (math.isnan(a.fsum_hi) and math.isnan(b.fsum_hi)) or a.fsum_hi == b.fsum_hi, (k, a.fsum_hi, b.fsum_hi)
+                                    else:
+                                        # (the sorted path's pair is not normalised -- its hi need not be the rounded sum --: the VALUE hi + lo is what
+                                        #  both must agree on, and the pairs as a whole to ~2^-95)
+                                        sa, sb = a.fsum_hi + a.fsum_lo, b.fsum_hi + b.fsum_lo
+                                        assert sa == sb and math.copysign(1.0, sa) == math.copysign(1.0, sb), (bt, kind, k, sa, sb)
+                                        assert abs((a.fsum_hi - b.fsum_hi) + (a.fsum_lo - b.fsum_lo)) <= abs(sb) * 2.0 ** -95, (bt, kind, k)   # (a few ulps of the lo words themselves)
+                        vcol.free()
+                tcol.free(); mask.free()
     finally:
         os.environ.pop("KNOX_WINDOW_DIRECT", None)
         if old is not None:
