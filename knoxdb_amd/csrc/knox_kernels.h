@@ -401,6 +401,13 @@ hipError_t launch_float_exprange(hipStream_t s, int width, const void *val, uint
 WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus);
 hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                               uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
+struct WindowFvarGeom {          // var / std of a float column: adders for the sum and for the sum of squares
+    uint32_t grid, base, nbins1, nbins2;
+    size_t lds, scratch;
+};
+WindowFvarGeom window_fvar_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus);
+hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, WindowFvarGeom g, const int64_t *time, const void *val, const uint8_t *mask,
+                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
 WindowFsumGeom window_fstate_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus);      // ... whole states of a float column
 hipError_t launch_window_fstate(hipStream_t s, int width, int dtype, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
                                 int64_t t_from, int64_t step, uint32_t n_buckets, uint64_t row_base, void *scratch, AggStateDev *states_out);

@@ -871,6 +871,222 @@ hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, Win
     return hipGetLastError();
 }
 
+// ---- var / std of a float column without the sort: exact -------------------------------------------------------------------------------
+// VarReducer.Value (reducer.go:376-381) is m2 / (n - 1), m2 the sum of squared deviations from the mean: n * m2 = n * S2 - S1^2 with
+// S1 = the sum of the values and S2 = the sum of their squares -- both exact in fixed point (a square has a 106-bit mantissa and twice
+// the exponent: up to five 32-bit digits per value, adders for twice the span), so T = n * S2 - S1^2 is an exact INTEGER (no cancellation
+// whatever the mean), formed by limb arithmetic in the finish and rounded once into a double-double; m2 = T / n and the division by
+// n - 1 run in double-double (knox_finalize.h var_value with D = 0).  One walk, nine LDS atomics per selected row at most.
+constexpr int kFvarBins2 = 10;        // digits of S2: 2 * 107 binades + 106 bits
+constexpr int kFvarLimbs = 14;        // 32-bit limbs of T (S1^2 < 2^378, n * S2 < 2^(320 + 60))
+
+template <typename U>
+__global__ void __launch_bounds__(kDirectBlock) window_fvar_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
+                                                                   uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base, uint32_t nbins1,
+                                                                   uint32_t nbins2, uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out) {
+    extern __shared__ uint64_t direct_tab[];                                   // [nbins1] adders of S1 | [nbins2] adders of S2, then [2][nb] words: count, flags
+    const uint32_t ns = nbins1 + nbins2;
+    uint64_t *bin1 = direct_tab, *bin2 = direct_tab + (size_t)nbins1 * nb;
+    uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)ns * nb);
+    for (uint32_t i = threadIdx.x; i < ns * nb; i += kDirectBlock) direct_tab[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) word[i] = 0;
+    __syncthreads();
+    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const double inv = 1.0 / (double)step;
+    auto push = [&](int64_t t, U x, uint64_t) {
+        const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
+        if (q == kNoKey) return;
+        atomicAdd(&word[q], 1u);
+        const uint64_t d = as_f64_bits(x);
+        const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+        const uint64_t frac = d & 0xfffffffffffffull;
+        if (be == 0x7ffu) { atomicOr(&word[nb + q], 1u); return; }        // any non-finite value: NaN, like Welford
+        if (be == 0 && frac == 0) return;
+        fixed_sum_push(bin1, nb, q, nbins1, base, d);
+        // the square: m^2 (<= 106 bits) * 2^(2 * (lsb - 1075)), in units of 2^(2 * (base - 1075))
+        const uint32_t lsb = be != 0 ? be : 1u;
+        const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
+        const unsigned __int128 m2 = (unsigned __int128)m * m;
+        const uint32_t sft = 2u * (lsb - base), i0 = sft >> 5, r = sft & 31u;
+        const uint64_t lo64 = (uint64_t)m2, hi64 = (uint64_t)(m2 >> 64);      // hi64 < 2^42
+        const uint64_t w0 = lo64 << r, w1 = (hi64 << r) | (r ? lo64 >> (64 - r) : 0ull), w2 = r ? hi64 >> (64 - r) : 0ull;
+        const uint64_t piece[5] = {w0 & 0xffffffffull, w0 >> 32, w1 & 0xffffffffull, w1 >> 32, w2};
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (piece[j] != 0 && i0 + j < nbins2) atomicAdd(reinterpret_cast<unsigned long long *>(&bin2[(size_t)(i0 + j) * nb + q]), (unsigned long long)piece[j]);
+    };
+    direct_walk<U, true>(time, val, mask, n_rows, push);
+    __syncthreads();
+    uint64_t *so = slots_out + (size_t)blockIdx.x * ns * nb;
+    uint32_t *wo = words_out + (size_t)blockIdx.x * 2 * nb;
+    for (uint32_t i = threadIdx.x; i < ns * nb; i += kDirectBlock) so[i] = direct_tab[i];
+    for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) wo[i] = word[i];
+}
+
+// one lane per window (the tables of a few hundred workgroups, read with independent loads): T = n * S2 - S1^2 in 32-bit limbs
+template <typename U>
+__global__ void __launch_bounds__(64) window_fvar_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
+                                                                uint32_t base, uint32_t nbins1, uint32_t nbins2, int dtype, int func, void *values, uint8_t *seen) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    const uint32_t ns = nbins1 + nbins2;
+    uint64_t b1[kFsumBins] = {0, 0, 0, 0, 0}, b2[kFvarBins2] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t count = 0;
+    uint32_t flags = 0;
+#pragma unroll 2
+    for (uint32_t g = 0; g < grid; g++) {
+        const uint64_t *p = slots + (size_t)g * ns * nb + k;
+#pragma unroll
+        for (int i = 0; i < kFsumBins; i++)
+            if ((uint32_t)i < nbins1) b1[i] += p[(size_t)i * nb];
+#pragma unroll
+        for (int i = 0; i < kFvarBins2; i++)
+            if ((uint32_t)i < nbins2) b2[i] += p[(size_t)(nbins1 + i) * nb];
+        count += words[(size_t)g * 2 * nb + k];
+        flags |= words[(size_t)g * 2 * nb + nb + k];
+    }
+    // |S1| as limbs: the signed adders -> 192-bit two's complement -> magnitude
+    uint32_t s1[7] = {0, 0, 0, 0, 0, 0, 0};
+    {
+        uint64_t lo = 0;
+        __int128 hi = 0;
+        auto add = [&](uint64_t lo_add, __int128 hi_add) {
+            const uint64_t nl = lo + lo_add;
+            hi += hi_add + (nl < lo ? 1 : 0);
+            lo = nl;
+        };
+        const __int128 v0 = (__int128)(int64_t)b1[0], v1 = (__int128)(int64_t)b1[1] * ((__int128)1 << 32);
+        add((uint64_t)v0, v0 >> 64);
+        add((uint64_t)v1, v1 >> 64);
+        add(0, (__int128)(int64_t)b1[2]);
+        add(0, (__int128)(int64_t)b1[3] * ((__int128)1 << 32));
+        add(0, (__int128)(int64_t)b1[4] * ((__int128)1 << 64));
+        if (hi < 0) {
+            lo = ~lo + 1;
+            hi = ~hi + (lo == 0 ? 1 : 0);
+        }
+        const unsigned __int128 mh = (unsigned __int128)hi;
+        s1[0] = (uint32_t)lo; s1[1] = (uint32_t)(lo >> 32);
+        s1[2] = (uint32_t)mh; s1[3] = (uint32_t)(mh >> 32); s1[4] = (uint32_t)(mh >> 64); s1[5] = (uint32_t)(mh >> 96);
+    }
+    // n * S2 (S2 = sum of b2[i] << 32 i, every b2[i] < 2^61)
+    uint32_t T[kFvarLimbs];
+#pragma unroll
+    for (int i = 0; i < kFvarLimbs; i++) T[i] = 0;
+    {
+        uint32_t s2[kFvarBins2 + 2];
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < kFvarBins2 + 2; i++) {
+            const uint64_t lo = i < kFvarBins2 ? (b2[i] & 0xffffffffull) : 0ull, hi_prev = (i >= 1 && i - 1 < kFvarBins2) ? (b2[i - 1] >> 32) : 0ull;
+            const uint64_t v = lo + hi_prev + carry;      // < 2^34
+            s2[i] = (uint32_t)v;
+            carry = v >> 32;
+        }
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < kFvarLimbs; i++) {
+            const uint64_t v = (i < kFvarBins2 + 2 ? (uint64_t)s2[i] * count : 0ull) + c;    // count < 2^32
+            T[i] = (uint32_t)v;
+            c = v >> 32;
+        }
+    }
+    // - S1^2 (schoolbook over the six limbs, subtracted limb by limb with borrow: T >= 0 by Cauchy-Schwarz)
+    {
+        uint32_t sq[kFvarLimbs];
+#pragma unroll
+        for (int i = 0; i < kFvarLimbs; i++) sq[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const uint64_t v = (uint64_t)s1[i] * s1[j] + sq[i + j] + c;
+                sq[i + j] = (uint32_t)v;
+                c = v >> 32;
+            }
+            sq[i + 6] += (uint32_t)c;       // (i + 6 <= 11; no carry out: the partial sums stay below 2^(32 (i + 7)))
+        }
+        int64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < kFvarLimbs; i++) {
+            const int64_t v = (int64_t)T[i] - (int64_t)sq[i] + borrow;
+            T[i] = (uint32_t)v;
+            borrow = v >> 32;               // 0 or -1
+        }
+    }
+    // T -> double-double (from the top limb down, error-free steps), / n, scaled by 2^(2 (base - 1075))
+    double s = 0.0, c = 0.0, c2 = 0.0;
+#pragma unroll
+    for (int j = kFvarLimbs - 1; j >= 0; j--) {
+        const knox_fin::dd t1 = knox_fin::two_sum(s, ldexp((double)T[j], 32 * j));
+        const knox_fin::dd t2 = knox_fin::two_sum(c, t1.lo);
+        s = t1.hi;
+        c = t2.hi;
+        c2 += t2.lo;
+    }
+    knox_fin::dd m2 = knox_fin::fast_two_sum(s, c + c2);
+    if (count > 0) m2 = knox_fin::dd_div_d(m2, (double)count);
+    const int sc = (int)base - 1075;
+    m2.hi = ldexp(ldexp(m2.hi, sc), sc);
+    m2.lo = ldexp(ldexp(m2.lo, sc), sc);
+    if (flags != 0) { m2.hi = __longlong_as_double(0x7ff8000000000000ll); m2.lo = 0.0; }
+    AggStateDev st;
+    st.dtype = dtype;
+    st.flags = 3u;                 // bit 1: the moments are present
+    st.count = (int64_t)count;
+    st.isum = 0;
+    st.fsum_hi = 0.0; st.fsum_lo = 0.0;
+    st.min_bits = st.max_bits = st.first_bits = st.last_bits = 0;
+    st.min_row = st.max_row = st.last_row = -1;
+    st.first_row = count ? 0 : -1;
+    st.m_shift = 0.0; st.m_dev_hi = 0.0; st.m_dev_lo = 0.0;      // deviations from the exact mean: their sum is 0
+    st.m_sq_hi = m2.hi; st.m_sq_lo = m2.lo;
+    uint64_t bits = 0;
+    int sn = 0;
+    int64_t row = -1;
+    const int rc = knox_fin::agg_value_bits(st, func, &bits, &sn, &row);
+    reinterpret_cast<U *>(values)[k] = (U)bits;
+    seen[k] = (rc == 0 && sn) ? 1 : 0;
+}
+
+WindowFvarGeom window_fvar_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus) {
+    WindowFvarGeom g;
+    g.grid = 0;
+    g.base = g.nbins1 = g.nbins2 = 0;
+    g.lds = g.scratch = 0;
+    if (exp_max < 200 || exp_min == 0 || exp_min > exp_max || exp_max - exp_min > (uint32_t)kFsumRange) return g;
+    g.base = exp_min;
+    g.nbins1 = (exp_max - exp_min + 53 + 31) / 32;
+    g.nbins2 = (2 * (exp_max - exp_min) + 106 + 31) / 32;
+    g.lds = (size_t)n_buckets * (8u * (g.nbins1 + g.nbins2) + 8u);
+    if (g.lds > 156 * 1024) return g;
+    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
+    g.scratch = (size_t)g.grid * g.lds + 512;
+    return g;
+}
+
+// func: KNOX_R_VAR / KNOX_R_STD over a float column
+hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, WindowFvarGeom g, const int64_t *time, const void *val, const uint8_t *mask,
+                              uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen) {
+    if (n_buckets == 0 || g.grid == 0 || (func != 6 && func != 7)) return hipErrorInvalidValue;
+    uint64_t *slots = (uint64_t *)scratch;
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * (g.nbins1 + g.nbins2) * n_buckets);
+#define KNOX_FVAR(U)                                                                                                                                \
+    do {                                                                                                                                            \
+        if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fvar_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+        hipLaunchKernelGGL((window_fvar_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
+                           g.base, g.nbins1, g.nbins2, slots, words);                                                                               \
+        hipLaunchKernelGGL((window_fvar_finish_kernel<U>), dim3((n_buckets + 63) / 64), dim3(64), 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
+                           n_buckets, g.base, g.nbins1, g.nbins2, dtype, func, values, seen);                                                       \
+    } while (0)
+    if (width == 8) KNOX_FVAR(uint64_t);
+    else if (width == 4) KNOX_FVAR(uint32_t);
+    else return hipErrorInvalidValue;
+#undef KNOX_FVAR
+    return hipGetLastError();
+}
+
 // ---- ... and the whole state of a FLOAT column: the exact adders for the sum, the order keys of acc_update (knox_dev.h) for min / max --
 // a NaN is never a candidate, both zeros share one key, the lowest row among equal keys wins --, first / last rows.  float32: (key, row)
 // in one 64-bit atomic, one walk; float64: a second walk for the rows of min / max, as for 8-byte integers.

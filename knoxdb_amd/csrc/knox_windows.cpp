@@ -137,6 +137,29 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             return KNOX_OK;
         }
     }
+    // var / std of a float column: exact sums of the values and of their squares, n * S2 - S1^2 as an integer (window_fvar_kernel)
+    if (ctx->win_values != nullptr && (ctx->win_func == KNOX_R_VAR || ctx->win_func == KNOX_R_STD) &&
+        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 8192) {
+        const char *env = getenv("KNOX_WINDOW_DIRECT");
+        if (!(env && atoi(env) == 0)) {
+            int emax = 0, emin = 0;
+            int rc = col_float_exprange(ctx, value_col, &emax, &emin);
+            if (rc) return rc;
+            const WindowFvarGeom vg = window_fvar_geom((uint32_t)emax, (uint32_t)emin, (uint32_t)n_buckets, ctx->n_cus);
+            if (vg.grid != 0) {
+                rc = ensure(ctx, ctx->sort_buf, vg.scratch);
+                if (rc) return rc;
+                hipError_t e = launch_window_fvar(ctx->stream, (int)w, value_col->dtype, ctx->win_func, vg, (const int64_t *)time_col->dev, value_col->dev,
+                                                  mask ? (const uint8_t *)mask->dev : nullptr, n_rows, t_from, step, (uint32_t)n_buckets, ctx->sort_buf.p,
+                                                  ctx->win_values, ctx->win_seen);
+                if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
+                ctx->win_path = KNOX_WINDOWS_DIRECT_FLOAT_SUMS;
+                ctx->win_values_done = true;
+                *states_dev = nullptr;
+                return KNOX_OK;
+            }
+        }
+    }
     // float sums / means: exact fixed-point adders sized by the column's smallest and largest exponent (one pass over the values the first
     // time, kept with the column); a column spanning more than 107 binades, or more windows than LDS holds adders for, takes the sort
     if (ctx->win_values != nullptr && !(flags & 2) && (ctx->win_func == KNOX_R_SUM || ctx->win_func == KNOX_R_MEAN) &&

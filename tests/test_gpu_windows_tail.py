@@ -605,3 +605,60 @@ def test_out_of_order_windows_float_states_without_the_sort():
         os.environ.pop("KNOX_WINDOW_DIRECT", None)
         if old is not None:
             os.environ["KNOX_WINDOW_DIRECT"] = old
+
+
+def test_out_of_order_windows_float_var_std_are_exact_without_the_sort():
+    """Var / Std of a float column per window over out-of-order time (window_fvar_kernel): exact fixed-point sums of the values and of
+    their squares, n * S2 - S1^2 as an integer -- against the exact rational variance (fractions) rounded once, and against the
+    sorted path's centred second pass; a mean 10^12 times the spread (what a naive sum of squares loses) included."""
+    from fractions import Fraction
+    rng = np.random.default_rng(1618)
+    old = os.environ.pop("KNOX_WINDOW_DIRECT", None)
+    try:
+        with K.Context(0) as ctx:
+            for n, nb, step in ((120_001, 200, 6), (30_000, 1500, 2)):
+                t_from = 77
+                key = rng.integers(-1, nb + 1, n)
+                t = (t_from + key * step + rng.integers(0, step, n)).astype(np.int64)
+                tcol = ctx.upload(t, 4096)
+                mask = ctx.bits(n).upload(np.packbits(rng.random(n) < 0.6, bitorder="little"))
+                sel = np.unpackbits(mask.bytes(), bitorder="little")[:n].astype(bool)
+                for bt in (B.Float64, B.Float32):
+                    for kind in ("wide", "large mean", "specials"):
+                        if kind == "wide":
+                            v = ((1.0 + rng.random(n)) * rng.choice([-1.0, 1.0], n) * 10.0 ** rng.integers(-4, 9, n)).astype(NP[bt])
+                        elif kind == "large mean":
+                            v = (1e9 + rng.standard_normal(n) * 1e-3).astype(NP[bt]) if bt == B.Float64 else (1e4 + rng.standard_normal(n)).astype(NP[bt])
+                        else:
+                            v = (rng.integers(-3, 4, n) / 2.0).astype(NP[bt])
+                            v[rng.integers(0, n, 20)] = np.inf
+                            v[rng.integers(0, n, 20)] = np.nan
+                            v[rng.random(n) < 0.2] = -0.0
+                        vcol = ctx.upload(v, 4096)
+                        for m, s in ((None, np.ones(n, dtype=bool)), (mask, sel)):
+                            for f in (R.Var, R.Std):
+                                os.environ["KNOX_WINDOW_DIRECT"] = "0"
+                                a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                                want, want_seen = a.copy(), b.copy()
+                                assert ctx.windows_last_path() in (2, 3)
+                                os.environ.pop("KNOX_WINDOW_DIRECT")
+                                a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                                assert ctx.windows_last_path() == 6
+                                assert (b == want_seen).all(), (n, nb, bt, kind, f)
+                                assert np.array_equal(a, want, equal_nan=True), (n, nb, bt, kind, f, np.flatnonzero(~((a == want) | (np.isnan(a) & np.isnan(want))))[:5])
+                            if bt == B.Float64 and kind != "specials" and n > 100_000:
+                                a, b = ctx.reduce_buckets_values(tcol, vcol, R.Var, t_from, step, nb, mask=m)
+                                for k in range(0, nb, 7):
+                                    rows = np.flatnonzero((key == k) & s)
+                                    if rows.size < 2:
+                                        continue
+                                    fr = [Fraction(float(x)) for x in v[rows]]
+                                    mean = sum(fr) / len(fr)
+                                    exact = sum((x - mean) ** 2 for x in fr) / (len(fr) - 1)
+                                    assert a[k] == float(exact), (kind, k, a[k], float(exact))
+                        vcol.free()
+                tcol.free(); mask.free()
+    finally:
+        os.environ.pop("KNOX_WINDOW_DIRECT", None)
+        if old is not None:
+            os.environ["KNOX_WINDOW_DIRECT"] = old

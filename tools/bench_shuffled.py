@@ -26,6 +26,10 @@ else:
     vals = col
 
 
+FUNC = {"sum": R.Sum, "mean": R.Mean, "min": R.Min, "max": R.Max, "first": R.First, "last": R.Last, "count": R.Count, "var": R.Var, "std": R.Std}[
+    os.environ.get("KNOX_SHUFFLED_FUNC", "sum")]
+
+
 def timed(fn):
     fn(); ctx.sync()
     t0 = time.perf_counter()
@@ -41,5 +45,5 @@ for nb in [int(x) for x in os.environ.get("KNOX_SHUFFLED_NB", "1024,16384").spli
     for m, tag in ((bits, "%d %% selected" % sel), (None, "all rows")):
         if only and (tag == "all rows") != (only == "all"):
             continue
-        ms = timed(lambda: ctx.reduce_buckets_values(clock, vals, R.Sum, 1000, step, nb, mask=m))
+        ms = timed(lambda: ctx.reduce_buckets_values(clock, vals, FUNC, 1000, step, nb, mask=m))
         print("2^%d rows, shuffled clock, %6d windows, %-13s: %6.2f ms (%.1f G rows/s) [path %d]" % (lg, nb, tag, ms, n / ms / 1e6, ctx.windows_last_path()), flush=True)
