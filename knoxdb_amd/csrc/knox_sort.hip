@@ -923,27 +923,49 @@ __global__ void __launch_bounds__(kDirectBlock) window_fvar_kernel(const int64_t
     for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) wo[i] = word[i];
 }
 
-// one lane per window (the tables of a few hundred workgroups, read with independent loads): T = n * S2 - S1^2 in 32-bit limbs
+// 64 windows per workgroup, the tables dealt to its four waves; then one lane per window: T = n * S2 - S1^2 in 32-bit limbs
 template <typename U>
-__global__ void __launch_bounds__(64) window_fvar_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
-                                                                uint32_t base, uint32_t nbins1, uint32_t nbins2, int dtype, int func, void *values, uint8_t *seen) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nb) return;
+__global__ void __launch_bounds__(256) window_fvar_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
+                                                                 uint32_t base, uint32_t nbins1, uint32_t nbins2, int dtype, int func, void *values, uint8_t *seen) {
+    __shared__ uint64_t f_b[4][kFsumBins + kFvarBins2 + 1][64];
+    __shared__ uint32_t f_fl[4][64];
+    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64 + lane;
+    const bool valid = k < nb;
     const uint32_t ns = nbins1 + nbins2;
     uint64_t b1[kFsumBins] = {0, 0, 0, 0, 0}, b2[kFvarBins2] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t count = 0;
     uint32_t flags = 0;
+    if (valid) {
 #pragma unroll 2
-    for (uint32_t g = 0; g < grid; g++) {
-        const uint64_t *p = slots + (size_t)g * ns * nb + k;
+        for (uint32_t g = part; g < grid; g += 4) {
+            const uint64_t *p = slots + (size_t)g * ns * nb + k;
 #pragma unroll
-        for (int i = 0; i < kFsumBins; i++)
-            if ((uint32_t)i < nbins1) b1[i] += p[(size_t)i * nb];
+            for (int i = 0; i < kFsumBins; i++)
+                if ((uint32_t)i < nbins1) b1[i] += p[(size_t)i * nb];
 #pragma unroll
-        for (int i = 0; i < kFvarBins2; i++)
-            if ((uint32_t)i < nbins2) b2[i] += p[(size_t)(nbins1 + i) * nb];
-        count += words[(size_t)g * 2 * nb + k];
-        flags |= words[(size_t)g * 2 * nb + nb + k];
+            for (int i = 0; i < kFvarBins2; i++)
+                if ((uint32_t)i < nbins2) b2[i] += p[(size_t)(nbins1 + i) * nb];
+            count += words[(size_t)g * 2 * nb + k];
+            flags |= words[(size_t)g * 2 * nb + nb + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kFsumBins; i++) f_b[part][i][lane] = b1[i];
+#pragma unroll
+    for (int i = 0; i < kFvarBins2; i++) f_b[part][kFsumBins + i][lane] = b2[i];
+    f_b[part][kFsumBins + kFvarBins2][lane] = count;
+    f_fl[part][lane] = flags;
+    __syncthreads();
+    if (part != 0 || !valid) return;
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+#pragma unroll
+        for (int i = 0; i < kFsumBins; i++) b1[i] += f_b[w][i][lane];
+#pragma unroll
+        for (int i = 0; i < kFvarBins2; i++) b2[i] += f_b[w][kFsumBins + i][lane];
+        count += f_b[w][kFsumBins + kFvarBins2][lane];
+        flags |= f_fl[w][lane];
     }
     // |S1| as limbs: the signed adders -> 192-bit two's complement -> magnitude
     uint32_t s1[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1077,7 +1099,7 @@ hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, Win
         if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fvar_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
         hipLaunchKernelGGL((window_fvar_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
                            g.base, g.nbins1, g.nbins2, slots, words);                                                                               \
-        hipLaunchKernelGGL((window_fvar_finish_kernel<U>), dim3((n_buckets + 63) / 64), dim3(64), 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
+        hipLaunchKernelGGL((window_fvar_finish_kernel<U>), dim3((n_buckets + 63) / 64), dim3(256), 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
                            n_buckets, g.base, g.nbins1, g.nbins2, dtype, func, values, seen);                                                       \
     } while (0)
     if (width == 8) KNOX_FVAR(uint64_t);
