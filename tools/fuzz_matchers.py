@@ -168,14 +168,14 @@ while time.time() < t_end:
         os.environ.pop("KNOX_COMPACT_FORM", None)
         assert got[0] == got[1] == got[2], ("shuffled forms", n, step, nb, t_from, seed)
         # Value() without the sort (window_direct_kernel) against the sorted path, every reducer that has the form
-        for f in (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last):
+        for f in (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last) + ((R.Var, R.Std) if v.dtype.kind == "f" else ()):
             for m in (mask, None):
                 os.environ["KNOX_WINDOW_DIRECT"] = "0"
                 a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
                 want = (a.copy(), b.copy())
                 os.environ.pop("KNOX_WINDOW_DIRECT")
                 a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
-                if v.dtype.kind == "f" and f in (R.Sum, R.Mean):      # (a NaN's payload is not part of Value()'s contract; its presence and every sign are)
+                if v.dtype.kind == "f" and f in (R.Sum, R.Mean, R.Var, R.Std):      # (a NaN's payload is not part of Value()'s contract; its presence and every sign are)
                     same = np.array_equal(a, want[0], equal_nan=True) and (np.signbit(a) == np.signbit(want[0]))[~np.isnan(want[0])].all()
                 else:
                     same = a.tobytes() == want[0].tobytes()
