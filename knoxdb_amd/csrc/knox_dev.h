@@ -150,7 +150,7 @@ __device__ __forceinline__ void dd_add(double &hi, double &lo, double h2, double
     hi = s;
 }
 
-using knox_fin::int128_to_dd;   // (knox_finalize.h: shared with the sort-free window sums of knox_sort.hip)
+using knox_fin::int128_to_dd;   // (knox_finalize.h: shared with the sort-free window sums of knox_fold.hip)
 
 struct Acc {
     uint64_t count, isum;

@@ -269,7 +269,7 @@ struct knox_col {
     mutable int8_t sorted_state = -1;
     mutable size_t sorted_rows = 0;
     // float columns: the largest / smallest finite non-zero biased float64 exponent of the values (-1 unknown), for the first `fexp_rows`
-    // rows -- what the exact window sums size their fixed-point form by (knox_sort.hip window_fsum_kernel).  Kept and dropped like sorted_state.
+    // rows -- what the exact window sums size their fixed-point form by (knox_fold.hip window_fsum_kernel).  Kept and dropped like sorted_state.
     mutable int32_t fexp_max = -1, fexp_min = 0;
     mutable size_t fexp_rows = 0;
 };

@@ -384,7 +384,7 @@ hipError_t launch_mask_unit_offsets(hipStream_t s, const uint8_t *mask, uint64_t
 hipError_t launch_window_compact(hipStream_t s, int width, const int64_t *time, const void *val, const uint8_t *mask, uint64_t n_rows,
                                  WindowCompactGeom g, const uint32_t *unit_off, int64_t t_from, int64_t step, uint32_t n_buckets, uint32_t *keys_out,
                                  uint32_t *idx_out, void *val_out);
-// out-of-order time without the sort: Value() of the order-free reducers per window by LDS atomics (knox_sort.hip)
+// out-of-order time without the sort: Value() of the order-free reducers per window by LDS atomics (knox_fold.hip)
 struct WindowDirectGeom {
     uint32_t grid, n_slots, n_words;   // grid 0: no order-free form for (reducer, column type), or the table does not fit LDS
     size_t lds, scratch;

@@ -118,7 +118,7 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
     // Value() of a reducer with an order-free form -- count, first / last (the value of the lowest / highest selected row), min / max
     // (floats: with the reference's NaN and signed-zero rules), and over integer columns the sum and the mean rounded from the exact sum -- over as many windows as a workgroup's LDS holds a table
     // for (8 B + a bit per window: ~19 Ki windows; Count ~39 Ki, Mean ~13 Ki / ~7.9 Ki for 8-byte values): every row is pushed into
-    // its window where it lies (window_direct_kernel, knox_sort.hip), as NativeBucket.Push does; nothing is sorted.
+    // its window where it lies (window_direct_kernel, knox_fold.hip), as NativeBucket.Push does; nothing is sorted.
     // KNOX_WINDOW_DIRECT=0 keeps the sort (measurements, the agreement test).
     if (ctx->win_values != nullptr && !(flags & 2) && n_buckets <= 65536) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");

@@ -83,10 +83,10 @@ def test_no_scan_instantiation_keeps_anything_in_scratch_memory():
 
 
 def test_no_kernel_of_any_family_keeps_anything_in_scratch_memory():
-    """the same figures for every other kernel family (knox_agg / window / bitset / bytes / bloom / decode / sort .res, left by the
+    """the same figures for every other kernel family (knox_agg / window / bitset / bytes / bloom / decode / sort / fold .res, left by the
     build): no kernel spills a register or holds an array in scratch memory"""
     seen = 0
-    for fam in ("knox_agg", "knox_window", "knox_bitset", "knox_bytes", "knox_bloom", "knox_decode", "knox_sort"):
+    for fam in ("knox_agg", "knox_window", "knox_bitset", "knox_bytes", "knox_bloom", "knox_decode", "knox_sort", "knox_fold"):
         path = os.path.join(CSRC, fam + ".res")
         assert os.path.exists(path), "build first (__graft_entry__.build): %s.res" % fam
         for b in open(path).read().split("Function Name: ")[1:]:
