@@ -334,14 +334,18 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
 constexpr int kFsumBins = 5;
 constexpr int kFsumRange = 107;
 
-template <typename U> __device__ __forceinline__ uint64_t as_f64_bits(U x) {
-    if constexpr (sizeof(U) == 8) return (uint64_t)x;
-    else return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));      // exact (a float32 denormal is a normal double)
+// the value as float64 bits, exactly: NUM 0 = a float column (a float32 denormal is a normal double), 1 / 2 = a signed / unsigned
+// integer column of at most 4 bytes (every such integer is a double)
+template <typename U, int NUM = 0> __device__ __forceinline__ uint64_t as_f64_bits(U x) {
+    if constexpr (NUM == 1) return (uint64_t)__double_as_longlong((double)(int32_t)(typename std::make_signed<U>::type)x);
+    else if constexpr (NUM == 2) return (uint64_t)__double_as_longlong((double)(uint32_t)x);
+    else if constexpr (sizeof(U) == 8) return (uint64_t)x;
+    else return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));
 }
 
 // largest and smallest biased float64 exponent among the finite non-zero values of a column: out[0] = max (0: there is none),
 // out[1] = ~min (an atomicMax as well; denormals count as exponent 1, whose last mantissa bit is theirs too)
-template <typename U>
+template <typename U, int NUM>
 __global__ void __launch_bounds__(256) float_exprange_kernel(const U *__restrict__ val, uint64_t n, uint32_t *__restrict__ out) {
     uint32_t m = 0, mn = 0x7ffu;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(256) float_exprange_kernel(const U *__restrict
         for (int u = 0; u < UN; u++) x[u] = i0 + u * stride < n ? val[i0 + u * stride] : (U)0;
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            const uint64_t d = as_f64_bits(x[u]);
+            const uint64_t d = as_f64_bits<U, NUM>(x[u]);
             const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
             const uint32_t e = be == 0x7ffu ? 0u : be != 0 ? be : ((d << 12) != 0 ? 1u : 0u);
             m = e > m ? e : m;
@@ -371,14 +375,20 @@ __global__ void __launch_bounds__(256) float_exprange_kernel(const U *__restrict
     }
 }
 
-// out: two words, zeroed by the caller
-hipError_t launch_float_exprange(hipStream_t s, int width, const void *val, uint64_t n_rows, uint32_t *out) {
+// out: two words, zeroed by the caller.  dtype: a float column, or an integer column of at most 4 bytes (its values as doubles)
+hipError_t launch_float_exprange(hipStream_t s, int width, int dtype, const void *val, uint64_t n_rows, uint32_t *out) {
     uint64_t g = (n_rows + 256 * 4 - 1) / (256 * 4);
     if (g > 4096) g = 4096;
     if (g == 0) g = 1;
-    if (width == 8) hipLaunchKernelGGL(float_exprange_kernel<uint64_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint64_t *)val, n_rows, out);
-    else if (width == 4) hipLaunchKernelGGL(float_exprange_kernel<uint32_t>, dim3((unsigned)g), dim3(256), 0, s, (const uint32_t *)val, n_rows, out);
+    const int num = dtype >= 9 ? 0 : dtype <= 4 ? 1 : 2;
+#define KNOX_EXPR(U, NUM) hipLaunchKernelGGL((float_exprange_kernel<U, NUM>), dim3((unsigned)g), dim3(256), 0, s, (const U *)val, n_rows, out)
+    if (num == 0 && width == 8) KNOX_EXPR(uint64_t, 0);
+    else if (num == 0 && width == 4) KNOX_EXPR(uint32_t, 0);
+    else if (num != 0 && width == 4) { if (num == 1) KNOX_EXPR(uint32_t, 1); else KNOX_EXPR(uint32_t, 2); }
+    else if (num != 0 && width == 2) { if (num == 1) KNOX_EXPR(uint16_t, 1); else KNOX_EXPR(uint16_t, 2); }
+    else if (num != 0 && width == 1) { if (num == 1) KNOX_EXPR(uint8_t, 1); else KNOX_EXPR(uint8_t, 2); }
     else return hipErrorInvalidValue;
+#undef KNOX_EXPR
     return hipGetLastError();
 }
 
@@ -585,7 +595,7 @@ hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, Win
 constexpr int kFvarBins2 = 10;        // digits of S2: 2 * 107 binades + 106 bits
 constexpr int kFvarLimbs = 14;        // 32-bit limbs of T (S1^2 < 2^378, n * S2 < 2^(320 + 60))
 
-template <typename U>
+template <typename U, int NUM>
 __global__ void __launch_bounds__(kDirectBlock) window_fvar_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
                                                                    uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base, uint32_t nbins1,
                                                                    uint32_t nbins2, uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out) {
@@ -602,7 +612,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_fvar_kernel(const int64_t
         const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
         if (q == kNoKey) return;
         atomicAdd(&word[q], 1u);
-        const uint64_t d = as_f64_bits(x);
+        const uint64_t d = as_f64_bits<U, NUM>(x);
         const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
         const uint64_t frac = d & 0xfffffffffffffull;
         if (be == 0x7ffu) { atomicOr(&word[nb + q], 1u); return; }        // any non-finite value: NaN, like Welford
@@ -793,22 +803,26 @@ WindowFvarGeom window_fvar_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_b
     return g;
 }
 
-// func: KNOX_R_VAR / KNOX_R_STD over a float column
+// func: KNOX_R_VAR / KNOX_R_STD over a float column or an integer column of at most 4 bytes
 hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, WindowFvarGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                               uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen) {
     if (n_buckets == 0 || g.grid == 0 || (func != 6 && func != 7)) return hipErrorInvalidValue;
     uint64_t *slots = (uint64_t *)scratch;
     uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * (g.nbins1 + g.nbins2) * n_buckets);
-#define KNOX_FVAR(U)                                                                                                                                \
+    const int num = dtype >= 9 ? 0 : dtype <= 4 ? 1 : 2;
+#define KNOX_FVAR(U, NUM)                                                                                                                           \
     do {                                                                                                                                            \
-        if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fvar_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
-        hipLaunchKernelGGL((window_fvar_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
+        if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fvar_kernel<U, NUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+        hipLaunchKernelGGL((window_fvar_kernel<U, NUM>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
                            g.base, g.nbins1, g.nbins2, slots, words);                                                                               \
         hipLaunchKernelGGL((window_fvar_finish_kernel<U>), dim3((n_buckets + 63) / 64), dim3(256), 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
                            n_buckets, g.base, g.nbins1, g.nbins2, dtype, func, values, seen);                                                       \
     } while (0)
-    if (width == 8) KNOX_FVAR(uint64_t);
-    else if (width == 4) KNOX_FVAR(uint32_t);
+    if (num == 0 && width == 8) KNOX_FVAR(uint64_t, 0);
+    else if (num == 0 && width == 4) KNOX_FVAR(uint32_t, 0);
+    else if (num != 0 && width == 4) { if (num == 1) KNOX_FVAR(uint32_t, 1); else KNOX_FVAR(uint32_t, 2); }
+    else if (num != 0 && width == 2) { if (num == 1) KNOX_FVAR(uint16_t, 1); else KNOX_FVAR(uint16_t, 2); }
+    else if (num != 0 && width == 1) { if (num == 1) KNOX_FVAR(uint8_t, 1); else KNOX_FVAR(uint8_t, 2); }
     else return hipErrorInvalidValue;
 #undef KNOX_FVAR
     return hipGetLastError();

@@ -96,7 +96,7 @@ static int col_float_exprange(knox_ctx *ctx, const knox_col *col, int *emax_out,
         if (rc) return rc;
         uint32_t *d_exp = (uint32_t *)((char *)ctx->misc.p + 96);
         HIPCHK(ctx, launch_zero_bytes(ctx->stream, d_exp, 8));
-        hipError_t e = launch_float_exprange(ctx->stream, col->width, col->dev, col->n_rows, d_exp);
+        hipError_t e = launch_float_exprange(ctx->stream, col->width, col->dtype, col->dev, col->n_rows, d_exp);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return KNOX_E_HIP; }
         uint32_t h[2] = {0, 0};
         HIPCHK(ctx, hipMemcpyAsync(h, d_exp, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -137,9 +137,10 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             return KNOX_OK;
         }
     }
-    // var / std of a float column: exact sums of the values and of their squares, n * S2 - S1^2 as an integer (window_fvar_kernel)
-    if (ctx->win_values != nullptr && (ctx->win_func == KNOX_R_VAR || ctx->win_func == KNOX_R_STD) &&
-        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 8192) {
+    // var / std of a float column, or of an integer column of at most 4 bytes (its values are doubles): exact sums of the values and of
+    // their squares, n * S2 - S1^2 as an integer (window_fvar_kernel)
+    if (ctx->win_values != nullptr && (ctx->win_func == KNOX_R_VAR || ctx->win_func == KNOX_R_STD) && n_buckets <= 8192 &&
+        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32 || (value_col->dtype >= KNOX_INT64 && value_col->dtype <= KNOX_UINT8 && w <= 4))) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");
         if (!(env && atoi(env) == 0)) {
             int emax = 0, emin = 0;

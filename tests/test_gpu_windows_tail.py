@@ -657,6 +657,20 @@ def test_out_of_order_windows_float_var_std_are_exact_without_the_sort():
                                     exact = sum((x - mean) ** 2 for x in fr) / (len(fr) - 1)
                                     assert a[k] == float(exact), (kind, k, a[k], float(exact))
                         vcol.free()
+                # integer columns of at most 4 bytes take the same adders (their values are doubles); Value() truncates toward zero in T
+                for bt in (B.Uint32, B.Int16, B.Uint8):
+                    v = _values(rng, bt, n)
+                    vcol = ctx.upload(v, 4096)
+                    for m in (None, mask):
+                        for f in (R.Var, R.Std):
+                            os.environ["KNOX_WINDOW_DIRECT"] = "0"
+                            a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                            want = (a.tobytes(), b.tobytes())
+                            os.environ.pop("KNOX_WINDOW_DIRECT")
+                            a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
+                            assert ctx.windows_last_path() == 6
+                            assert (a.tobytes(), b.tobytes()) == want, (n, nb, bt, f, m is not None)
+                    vcol.free()
                 tcol.free(); mask.free()
     finally:
         os.environ.pop("KNOX_WINDOW_DIRECT", None)
