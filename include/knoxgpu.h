@@ -603,8 +603,8 @@ int knox_reduce_buckets_view(knox_ctx *ctx, const knox_col *time_col, const knox
  * (0: the reference created no reducer for the window).  Both point into the context's page-locked result buffer and
  * stay valid until the next knox_reduce_buckets_values / knox_bits_indexes_view call on this ctx.  flags bit0 as above;
  * the var / std pass runs by itself for KNOX_R_VAR / KNOX_R_STD.  Feed the views to knox_fill_windows for Emit's gaps.
- * Out-of-order time: reducers whose fold is order-free (count, first, last, min, max, sum, mean, float var / std -- float sums as
- * exact fixed-point numbers) are folded where the
+ * Out-of-order time: every reducer has an order-free form (first / last as the lowest / highest row, float sums and the sums behind
+ * var / std as exact fixed-point numbers) and is folded where the
  * rows lie -- what NativeBucket.Push does --, everything else goes through the stable sort; the results are the same bytes. */
 int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                                const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,

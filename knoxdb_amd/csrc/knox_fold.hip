@@ -334,11 +334,11 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
 constexpr int kFsumBins = 5;
 constexpr int kFsumRange = 107;
 
-// the value as float64 bits, exactly: NUM 0 = a float column (a float32 denormal is a normal double), 1 / 2 = a signed / unsigned
-// integer column of at most 4 bytes (every such integer is a double)
+// the value as float64 bits: NUM 0 = a float column (exact: a float32 denormal is a normal double), 1 / 2 = a signed / unsigned integer
+// column -- Go's float64(v), which is what the reference's VarReducer works on (exact up to 2^53, rounded to nearest above)
 template <typename U, int NUM = 0> __device__ __forceinline__ uint64_t as_f64_bits(U x) {
-    if constexpr (NUM == 1) return (uint64_t)__double_as_longlong((double)(int32_t)(typename std::make_signed<U>::type)x);
-    else if constexpr (NUM == 2) return (uint64_t)__double_as_longlong((double)(uint32_t)x);
+    if constexpr (NUM == 1) return (uint64_t)__double_as_longlong((double)(int64_t)(typename std::make_signed<U>::type)x);
+    else if constexpr (NUM == 2) return (uint64_t)__double_as_longlong((double)(uint64_t)x);
     else if constexpr (sizeof(U) == 8) return (uint64_t)x;
     else return (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));
 }
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) float_exprange_kernel(const U *__restrict
     }
 }
 
-// out: two words, zeroed by the caller.  dtype: a float column, or an integer column of at most 4 bytes (its values as doubles)
+// out: two words, zeroed by the caller.  dtype: a float column, or an integer column (its values as Go's float64(v))
 hipError_t launch_float_exprange(hipStream_t s, int width, int dtype, const void *val, uint64_t n_rows, uint32_t *out) {
     uint64_t g = (n_rows + 256 * 4 - 1) / (256 * 4);
     if (g > 4096) g = 4096;
@@ -384,6 +384,7 @@ hipError_t launch_float_exprange(hipStream_t s, int width, int dtype, const void
 #define KNOX_EXPR(U, NUM) hipLaunchKernelGGL((float_exprange_kernel<U, NUM>), dim3((unsigned)g), dim3(256), 0, s, (const U *)val, n_rows, out)
     if (num == 0 && width == 8) KNOX_EXPR(uint64_t, 0);
     else if (num == 0 && width == 4) KNOX_EXPR(uint32_t, 0);
+    else if (num != 0 && width == 8) { if (num == 1) KNOX_EXPR(uint64_t, 1); else KNOX_EXPR(uint64_t, 2); }
     else if (num != 0 && width == 4) { if (num == 1) KNOX_EXPR(uint32_t, 1); else KNOX_EXPR(uint32_t, 2); }
     else if (num != 0 && width == 2) { if (num == 1) KNOX_EXPR(uint16_t, 1); else KNOX_EXPR(uint16_t, 2); }
     else if (num != 0 && width == 1) { if (num == 1) KNOX_EXPR(uint8_t, 1); else KNOX_EXPR(uint8_t, 2); }
@@ -441,20 +442,21 @@ __device__ __forceinline__ void fixed_sum_to_dd(const uint64_t (&b)[kFsumBins], 
     rl_out = rl;
 }
 
-// one finite non-zero value into the adders of window q (d: its float64 bits)
-__device__ __forceinline__ void fixed_sum_push(uint64_t *bin, uint32_t nb, uint32_t q, uint32_t nbins, uint32_t base, uint64_t d) {
-    const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
-    const uint64_t frac = d & 0xfffffffffffffull;
-    const bool neg = (d >> 63) != 0;
-    const uint32_t lsb = be != 0 ? be : 1u;                 // the value is m * 2^(lsb - 1075); lsb >= base: base is the column's smallest
-    const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
+// one non-zero value (-1)^neg * m * 2^(lsb - 1075) into the adders of window q (m <= 64 bits; lsb >= base)
+__device__ __forceinline__ void fixed_sum_push_m(uint64_t *bin, uint32_t nb, uint32_t q, uint32_t nbins, uint32_t base, uint64_t m, uint32_t lsb, bool neg) {
     const uint32_t sft = lsb - base, i0 = sft >> 5, r = sft & 31u;
-    const unsigned __int128 p = (unsigned __int128)m << r;  // <= 84 bits
+    const unsigned __int128 p = (unsigned __int128)m << r;  // <= 95 bits
     const uint64_t piece[3] = {(uint64_t)p & 0xffffffffull, (uint64_t)(p >> 32) & 0xffffffffull, (uint64_t)(p >> 64)};
 #pragma unroll
     for (int j = 0; j < 3; j++)
         if (piece[j] != 0 && i0 + j < nbins)
             atomicAdd(reinterpret_cast<unsigned long long *>(&bin[(size_t)(i0 + j) * nb + q]), (unsigned long long)(neg ? 0ull - piece[j] : piece[j]));
+}
+// ... a finite non-zero float64 given by its bits d (lsb >= base: base is the column's smallest)
+__device__ __forceinline__ void fixed_sum_push(uint64_t *bin, uint32_t nb, uint32_t q, uint32_t nbins, uint32_t base, uint64_t d) {
+    const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+    const uint64_t frac = d & 0xfffffffffffffull;
+    fixed_sum_push_m(bin, nb, q, nbins, base, be != 0 ? (frac | (1ull << 52)) : frac, be != 0 ? be : 1u, (d >> 63) != 0);
 }
 
 template <typename U>
@@ -612,18 +614,24 @@ __global__ void __launch_bounds__(kDirectBlock) window_fvar_kernel(const int64_t
         const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
         if (q == kNoKey) return;
         atomicAdd(&word[q], 1u);
-        const uint64_t d = as_f64_bits<U, NUM>(x);
-        const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
-        const uint64_t frac = d & 0xfffffffffffffull;
-        if (be == 0x7ffu) { atomicOr(&word[nb + q], 1u); return; }        // any non-finite value: NaN, like Welford
-        if (be == 0 && frac == 0) return;
-        fixed_sum_push(bin1, nb, q, nbins1, base, d);
-        // the square: m^2 (<= 106 bits) * 2^(2 * (lsb - 1075)), in units of 2^(2 * (base - 1075))
-        const uint32_t lsb = be != 0 ? be : 1u;
-        const uint64_t m = be != 0 ? (frac | (1ull << 52)) : frac;
+        uint64_t m;
+        uint32_t lsb;
+        bool neg;
+        {
+            const uint64_t d = as_f64_bits<U, NUM>(x);
+            const uint32_t be = (uint32_t)(d >> 52) & 0x7ffu;
+            const uint64_t frac = d & 0xfffffffffffffull;
+            if (be == 0x7ffu) { atomicOr(&word[nb + q], 1u); return; }        // any non-finite value: NaN, like Welford
+            if (be == 0 && frac == 0) return;
+            lsb = be != 0 ? be : 1u;
+            m = be != 0 ? (frac | (1ull << 52)) : frac;
+            neg = (d >> 63) != 0;
+        }
+        fixed_sum_push_m(bin1, nb, q, nbins1, base, m, lsb, neg);
+        // the square: m^2 (<= 128 bits) * 2^(2 * (lsb - 1075)), in units of 2^(2 * (base - 1075))
         const unsigned __int128 m2 = (unsigned __int128)m * m;
         const uint32_t sft = 2u * (lsb - base), i0 = sft >> 5, r = sft & 31u;
-        const uint64_t lo64 = (uint64_t)m2, hi64 = (uint64_t)(m2 >> 64);      // hi64 < 2^42
+        const uint64_t lo64 = (uint64_t)m2, hi64 = (uint64_t)(m2 >> 64);
         const uint64_t w0 = lo64 << r, w1 = (hi64 << r) | (r ? lo64 >> (64 - r) : 0ull), w2 = r ? hi64 >> (64 - r) : 0ull;
         const uint64_t piece[5] = {w0 & 0xffffffffull, w0 >> 32, w1 & 0xffffffffull, w1 >> 32, w2};
 #pragma unroll
@@ -803,7 +811,7 @@ WindowFvarGeom window_fvar_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_b
     return g;
 }
 
-// func: KNOX_R_VAR / KNOX_R_STD over a float column or an integer column of at most 4 bytes
+// func: KNOX_R_VAR / KNOX_R_STD over a float or an integer column
 hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, WindowFvarGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                               uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen) {
     if (n_buckets == 0 || g.grid == 0 || (func != 6 && func != 7)) return hipErrorInvalidValue;
@@ -819,6 +827,7 @@ hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, Win
                            n_buckets, g.base, g.nbins1, g.nbins2, dtype, func, values, seen);                                                       \
     } while (0)
     if (num == 0 && width == 8) KNOX_FVAR(uint64_t, 0);
+    else if (num != 0 && width == 8) { if (num == 1) KNOX_FVAR(uint64_t, 1); else KNOX_FVAR(uint64_t, 2); }
     else if (num == 0 && width == 4) KNOX_FVAR(uint32_t, 0);
     else if (num != 0 && width == 4) { if (num == 1) KNOX_FVAR(uint32_t, 1); else KNOX_FVAR(uint32_t, 2); }
     else if (num != 0 && width == 2) { if (num == 1) KNOX_FVAR(uint16_t, 1); else KNOX_FVAR(uint16_t, 2); }

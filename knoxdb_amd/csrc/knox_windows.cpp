@@ -137,10 +137,10 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
             return KNOX_OK;
         }
     }
-    // var / std of a float column, or of an integer column of at most 4 bytes (its values are doubles): exact sums of the values and of
-    // their squares, n * S2 - S1^2 as an integer (window_fvar_kernel)
+    // var / std: exact sums of the values and of their squares, n * S2 - S1^2 as an integer (window_fvar_kernel).  Integer columns enter
+    // as Go's float64(v) -- what the reference's VarReducer works on: exact up to 2^53, rounded to nearest above
     if (ctx->win_values != nullptr && (ctx->win_func == KNOX_R_VAR || ctx->win_func == KNOX_R_STD) && n_buckets <= 8192 &&
-        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32 || (value_col->dtype >= KNOX_INT64 && value_col->dtype <= KNOX_UINT8 && w <= 4))) {
+        value_col->dtype >= KNOX_INT64 && value_col->dtype <= KNOX_FLOAT32) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");
         if (!(env && atoi(env) == 0)) {
             int emax = 0, emin = 0;

@@ -657,9 +657,12 @@ def test_out_of_order_windows_float_var_std_are_exact_without_the_sort():
                                     exact = sum((x - mean) ** 2 for x in fr) / (len(fr) - 1)
                                     assert a[k] == float(exact), (kind, k, a[k], float(exact))
                         vcol.free()
-                # integer columns of at most 4 bytes take the same adders (their values are doubles); Value() truncates toward zero in T
-                for bt in (B.Uint32, B.Int16, B.Uint8):
+                # integer columns take the same adders (up to 4 bytes as doubles, 8-byte ones as they are); Value() truncates toward zero in T
+                for bt in (B.Int64, B.Uint32, B.Int16, B.Uint8):
                     v = _values(rng, bt, n)
+                    if bt == B.Int64:
+                        v[rng.integers(0, n, 50)] = np.iinfo(np.int64).min
+                        v[: n // 3] = 10 ** 15 + rng.integers(-5, 6, n // 3)      # a mean 10^15 times the spread
                     vcol = ctx.upload(v, 4096)
                     for m in (None, mask):
                         for f in (R.Var, R.Std):

@@ -168,7 +168,7 @@ while time.time() < t_end:
         os.environ.pop("KNOX_COMPACT_FORM", None)
         assert got[0] == got[1] == got[2], ("shuffled forms", n, step, nb, t_from, seed)
         # Value() without the sort (window_direct_kernel) against the sorted path, every reducer that has the form
-        for f in (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last) + ((R.Var, R.Std) if v.dtype.itemsize <= 4 or v.dtype.kind == "f" else ()):
+        for f in (R.Sum, R.Count, R.Mean, R.Min, R.Max, R.First, R.Last) + (R.Var, R.Std):
             for m in (mask, None):
                 os.environ["KNOX_WINDOW_DIRECT"] = "0"
                 a, b = ctx.reduce_buckets_values(tcol, vcol, f, t_from, step, nb, mask=m)
