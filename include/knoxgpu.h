@@ -604,8 +604,8 @@ int knox_reduce_buckets_view(knox_ctx *ctx, const knox_col *time_col, const knox
  * stay valid until the next knox_reduce_buckets_values / knox_bits_indexes_view call on this ctx.  flags bit0 as above;
  * the var / std pass runs by itself for KNOX_R_VAR / KNOX_R_STD.  Feed the views to knox_fill_windows for Emit's gaps.
  * Out-of-order time: every reducer has an order-free form (first / last as the lowest / highest row, float sums and the sums behind
- * var / std as exact fixed-point numbers) and is folded where the
- * rows lie -- what NativeBucket.Push does --, everything else goes through the stable sort; the results are the same bytes. */
+ * var / std as exact fixed-point numbers) and is folded where the rows lie -- what NativeBucket.Push does -- as long as the windows'
+ * table fits a workgroup's LDS (a few thousand windows); more windows go through the stable sort.  The results are the same bytes. */
 int knox_reduce_buckets_values(knox_ctx *ctx, const knox_col *time_col, const knox_col *value_col,
                                const knox_bits *mask /* nullable = all rows */, int64_t t_from, int64_t step,
                                size_t n_buckets, int func, int flags, const void **values_view, const uint8_t **seen_view);
