@@ -23,7 +23,8 @@ After the timed region (all outside it): the read-only ceiling, the 0 % / 100 % 
 in-run parity against the oracle (bitset memcmp on a 64-pack sample, XOR checksum of ALL bitset words, count and
 wrapping sum of the whole run), BASELINE configs[2] and configs[3] at the same size in the same context ("configs":
 cfg3 = 2 x float64 AND + min / max / mean, cfg4_u64 / cfg4_bytes = per-pack bloom -> EQ -> count; each with kernel_ms,
-GB/s, frac and its own parity verdict), "placement_off" (the headline, cfg3 and cfg4_bytes kernels once more in a second
+GB/s, frac and its own parity verdict; f1_windows = SURVEY.md 8(f) row 1, time windows over an out-of-order clock: 2^28 rows ->
+1024 windows as whole calls, with the path each took and the sorted path's time beside it), "placement_off" (the headline, cfg3 and cfg4_bytes kernels once more in a second
 context with knox_ctx_set_placement(ctx, 0), and the points of peak the arena gains on each; "placement.probe_ms" is what
 its probes cost), and the CPU baseline (scalar port @ 1 thread, AVX2 @ 1 thread, AVX2 @ all cores).
 
@@ -314,6 +315,51 @@ def secondary_configs(K, ctx, n_rows, pack_rows, steps, warmup, parity=True):
     line["setup_and_run_s"] = time.perf_counter() - t0
     out["cfg4_bytes"] = line
     note("cfg4_bytes: kernel %.4f ms, %.0f GB/s, frac %.3f" % (line["kernel_ms"], line["achieved_gb_per_s"], line["frac"]))
+    # ---- time windows over an out-of-order clock (NativeBucket.Push's find / insert) ---------------------
+    # 2^28 rows -> 1024 windows behind a 25 % selection, whole calls (wall clock around the C call, order of the clock known):
+    # Value() per window without a sort, whole states, float64 sum / std through the exact adders
+    try:
+        t0 = time.perf_counter()
+        nw = min(n_rows, 1 << 28)
+        clock = ctx.generate(BlockType.Int64, 0, 9, nw, lo=1000, span=1 << 20, pack_rows=pack_rows)
+        ival = ctx.generate(BlockType.Int64, 0, 2, nw, lo=-(1 << 40), span=1 << 41, pack_rows=pack_rows)
+        fval = ctx.generate(BlockType.Float64, 2, 5, nw, pack_rows=pack_rows)
+        wbits = ctx.bits(nw, for_col=ival)
+        ctx.scan(And(Leaf(0, FilterMode.Range, -(1 << 38), 1 << 38)), [ival], bits_out=wbits)
+        nb, wstep = 1024, (1 << 20) // 1024
+
+        def wall(fn, reps=5):
+            fn(); ctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            ctx.sync()
+            return (time.perf_counter() - t1) / reps * 1e3
+
+        f1 = {"workload": "2^%d rows, shuffled clock -> %d windows, 25 %% selected, whole calls" % (nw.bit_length() - 1, nb), "rows": nw}
+        for name, colv, fn in (("int64_sum", ival, R.Sum), ("int64_std", ival, R.Std), ("float64_sum", fval, R.Sum), ("float64_std", fval, R.Std)):
+            ms = wall(lambda: ctx.reduce_buckets_values(clock, colv, fn, 1000, wstep, nb, mask=wbits))
+            f1[name] = {"ms": ms, "rows_per_s": nw / ms * 1e3, "path": ctx.windows_last_path()}
+        ms = wall(lambda: ctx.reduce_buckets_view(clock, ival, 1000, wstep, nb, mask=wbits))
+        f1["int64_states"] = {"ms": ms, "rows_per_s": nw / ms * 1e3, "path": ctx.windows_last_path()}
+        # parity in the run: the sort-free fold against the sorted path, byte for byte
+        a, b = ctx.reduce_buckets_values(clock, ival, R.Sum, 1000, wstep, nb, mask=wbits)
+        direct = (a.tobytes(), b.tobytes())
+        os.environ["KNOX_WINDOW_DIRECT"] = "0"
+        try:
+            a, b = ctx.reduce_buckets_values(clock, ival, R.Sum, 1000, wstep, nb, mask=wbits)
+            f1["sorted_int64_sum_ms"] = wall(lambda: ctx.reduce_buckets_values(clock, ival, R.Sum, 1000, wstep, nb, mask=wbits))
+        finally:
+            os.environ.pop("KNOX_WINDOW_DIRECT", None)
+        f1["parity"] = "green" if direct == (a.tobytes(), b.tobytes()) else "RED"
+        f1["setup_and_run_s"] = time.perf_counter() - t0
+        for o in (clock, ival, fval, wbits):
+            o.free()
+        out["f1_windows"] = f1
+        note("f1_windows: int64 sum %.3f ms (sorted %.3f), states %.3f ms, float64 sum %.3f ms, std %.3f ms, parity %s" % (
+            f1["int64_sum"]["ms"], f1["sorted_int64_sum_ms"], f1["int64_states"]["ms"], f1["float64_sum"]["ms"], f1["float64_std"]["ms"], f1["parity"]))
+    except Exception as e:   # never at the cost of the configs above
+        out["f1_windows"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
