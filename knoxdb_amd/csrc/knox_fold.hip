@@ -646,14 +646,16 @@ __global__ void __launch_bounds__(kDirectBlock) window_fvar_kernel(const int64_t
     for (uint32_t i = threadIdx.x; i < 2 * nb; i += kDirectBlock) wo[i] = word[i];
 }
 
-// 64 windows per workgroup, the tables dealt to its four waves; then one lane per window: T = n * S2 - S1^2 in 32-bit limbs
+// 32 windows per workgroup, the tables dealt to eight groups of 32 lanes (17 words per window and table: with four waves per 64 windows
+// the fold took 155 us for 1024 windows, a tenth of the walk); then one lane per window: T = n * S2 - S1^2 in 32-bit limbs
 template <typename U>
 __global__ void __launch_bounds__(256) window_fvar_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
                                                                  uint32_t base, uint32_t nbins1, uint32_t nbins2, int dtype, int func, void *values, uint8_t *seen) {
-    __shared__ uint64_t f_b[4][kFsumBins + kFvarBins2 + 1][64];
-    __shared__ uint32_t f_fl[4][64];
-    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * 64 + lane;
+    constexpr int PARTS = 8, WPB = 32;
+    __shared__ uint64_t f_b[PARTS][kFsumBins + kFvarBins2 + 1][WPB];
+    __shared__ uint32_t f_fl[PARTS][WPB];
+    const uint32_t lane = threadIdx.x % WPB, part = threadIdx.x / WPB;
+    const uint32_t k = blockIdx.x * WPB + lane;
     const bool valid = k < nb;
     const uint32_t ns = nbins1 + nbins2;
     uint64_t b1[kFsumBins] = {0, 0, 0, 0, 0}, b2[kFvarBins2] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -661,7 +663,7 @@ __global__ void __launch_bounds__(256) window_fvar_finish_kernel(const uint64_t 
     uint32_t flags = 0;
     if (valid) {
 #pragma unroll 2
-        for (uint32_t g = part; g < grid; g += 4) {
+        for (uint32_t g = part; g < grid; g += PARTS) {
             const uint64_t *p = slots + (size_t)g * ns * nb + k;
 #pragma unroll
             for (int i = 0; i < kFsumBins; i++)
@@ -682,7 +684,7 @@ __global__ void __launch_bounds__(256) window_fvar_finish_kernel(const uint64_t 
     __syncthreads();
     if (part != 0 || !valid) return;
 #pragma unroll
-    for (int w = 1; w < 4; w++) {
+    for (int w = 1; w < PARTS; w++) {
 #pragma unroll
         for (int i = 0; i < kFsumBins; i++) b1[i] += f_b[w][i][lane];
 #pragma unroll
@@ -823,7 +825,7 @@ hipError_t launch_window_fvar(hipStream_t s, int width, int dtype, int func, Win
         if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fvar_kernel<U, NUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
         hipLaunchKernelGGL((window_fvar_kernel<U, NUM>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
                            g.base, g.nbins1, g.nbins2, slots, words);                                                                               \
-        hipLaunchKernelGGL((window_fvar_finish_kernel<U>), dim3((n_buckets + 63) / 64), dim3(256), 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
+        hipLaunchKernelGGL((window_fvar_finish_kernel<U>), dim3((n_buckets + 31) / 32), dim3(256), 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
                            n_buckets, g.base, g.nbins1, g.nbins2, dtype, func, values, seen);                                                       \
     } while (0)
     if (num == 0 && width == 8) KNOX_FVAR(uint64_t, 0);
