@@ -29,9 +29,9 @@ namespace knox {
 // the value is fetched from the winning row there).
 // Round 4 had built the same for EVERY state field at once (eight 64-bit atomics and a 64-bit division per row, two passes: 4.07 ms
 // for 2^28 rows -> 1024 windows against the sort's 2.88) and dropped it; with the division gone the walk runs at streaming rate
-// (0.74-0.84 ms, with or without a selection, 1024 .. 16384 windows) and it is the sort that loses.  The sort keeps: float sums and
-// means (double-double sums are not atomic), var / std (a second, centred pass over each window's rows) and every window count whose
-// table does not fit.
+// (0.67-0.84 ms, with or without a selection, 1024 .. 16384 windows) and it is the sort that loses.  Float sums / means and var / std
+// have their own kernels below (a double-double sum is not an atomic, an exact fixed-point integer is); the sort keeps the window counts
+// whose table does not fit and the states that carry var / std moments.
 enum { kDirectSum = 0, kDirectFirst = 1, kDirectLast = 2, kDirectMin = 3, kDirectMax = 4, kDirectMean = 5, kDirectCount = 8,   // == knox_reducer
        kDirectFMin = 16, kDirectFMax = 17 };   // min / max of a FLOAT column (below)
 constexpr int kDirectBlock = 1024;
@@ -588,7 +588,7 @@ hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, Win
     return hipGetLastError();
 }
 
-// ---- var / std of a float column without the sort: exact -------------------------------------------------------------------------------
+// ---- var / std without the sort: exact (float columns; integer columns as Go's float64(v), what the reference's VarReducer sees) ------
 // VarReducer.Value (reducer.go:376-381) is m2 / (n - 1), m2 the sum of squared deviations from the mean: n * m2 = n * S2 - S1^2 with
 // S1 = the sum of the values and S2 = the sum of their squares -- both exact in fixed point (a square has a 106-bit mantissa and twice
 // the exponent: up to five 32-bit digits per value, adders for twice the span), so T = n * S2 - S1^2 is an exact INTEGER (no cancellation
