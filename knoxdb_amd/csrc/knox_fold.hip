@@ -41,12 +41,13 @@ constexpr int kDirectWaves = kDirectBlock / 64;
 // piece, everything asked for up front, values only where the pair holds a selected row), chunks dealt round-robin to the waves of the
 // grid; push(timestamp, value, row) for every selected row; the rows behind the last whole chunk by workgroup 0
 template <typename U, bool VALUES, typename Push>
-__device__ __forceinline__ void direct_walk(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask, uint64_t n_rows, Push push) {
+__device__ __forceinline__ void direct_walk(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask, uint64_t n_rows, Push push,
+                                            uint32_t sub = blockIdx.x, uint32_t nsub = gridDim.x) {      // (sub of nsub: the workgroups that share the walk)
     typedef long long t2 __attribute__((ext_vector_type(2)));
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t sh = (2u * lane) & 7u;
     const uint64_t n_chunks = n_rows / 512;
-    for (uint64_t c = (uint64_t)blockIdx.x * kDirectWaves + wave; c < n_chunks; c += (uint64_t)gridDim.x * kDirectWaves) {
+    for (uint64_t c = (uint64_t)sub * kDirectWaves + wave; c < n_chunks; c += (uint64_t)nsub * kDirectWaves) {
         const uint64_t c0 = c * 512;
         uint32_t mb[4];
         t2 t[4];
@@ -70,7 +71,7 @@ __device__ __forceinline__ void direct_walk(const int64_t *__restrict__ time, co
             if (m2 & 2u) push(t[h].y, x[h].y, row + 1);
         }
     }
-    if (blockIdx.x == 0) {
+    if (sub == 0) {
         for (uint64_t r = n_chunks * 512 + threadIdx.x; r < n_rows; r += kDirectBlock)
             if (mask == nullptr || ((mask[r >> 3] >> (r & 7)) & 1u)) push(time[r], VALUES ? val[r] : (U)0, r);
     }
@@ -95,10 +96,17 @@ template <int MODE, int W> struct DirectShape {
 
 template <typename U, bool SIGNED, int MODE>
 __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
-                                                                     uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint64_t *__restrict__ slots_out,
-                                                                     uint32_t *__restrict__ words_out) {
+                                                                     uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb_all, uint32_t cap,
+                                                                     uint32_t n_ranges, uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out) {
     using SH = DirectShape<MODE, (int)sizeof(U)>;
     constexpr int NS = SH::NS;
+    // More windows than one table holds: the windows are cut into n_ranges ranges of `cap`, workgroup b folds range b % n_ranges -- a
+    // window grid of its own (its first edge, its count) -- and the workgroups of a range share one walk over ALL rows: the column
+    // is read n_ranges times, which up to four still beats the sort's passes.
+    const uint32_t rid = blockIdx.x % n_ranges, sub = blockIdx.x / n_ranges, nsub = gridDim.x / n_ranges;
+    t_from += (int64_t)((uint64_t)rid * cap) * step;
+    const uint32_t nb = cap;                                                    // the table's stride; the range's last windows may lie behind nb_all
+    const uint32_t nbr = rid * cap >= nb_all ? 0u : (nb_all - rid * cap < cap ? nb_all - rid * cap : cap);
     extern __shared__ uint64_t direct_tab[];           // NS x nb slots, then the counts / bits
     uint64_t *s0 = direct_tab, *s1 = s0 + nb;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(direct_tab + (size_t)NS * nb);
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
     for (uint32_t i = threadIdx.x; i < NS * nb; i += kDirectBlock) direct_tab[i] = SH::INIT;
     for (uint32_t i = threadIdx.x; i < nc; i += kDirectBlock) cnt[i] = SH::WINIT;
     __syncthreads();
-    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const uint64_t span = (uint64_t)nbr * (uint64_t)step;
     const double inv = 1.0 / (double)step;
     auto push = [&](int64_t t, U x, uint64_t row) {
         const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
@@ -148,7 +156,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
             atomicMax(p0, (unsigned long long)(row + 1));
         }
     };
-    direct_walk<U, SH::VALUES>(time, val, mask, n_rows, push);
+    direct_walk<U, SH::VALUES>(time, val, mask, n_rows, push, sub, nsub);
     __syncthreads();
     uint64_t *so = slots_out + (size_t)blockIdx.x * NS * nb;
     uint32_t *co = words_out + (size_t)blockIdx.x * nc;
@@ -158,8 +166,9 @@ __global__ void __launch_bounds__(kDirectBlock) window_direct_kernel(const int64
 
 // one lane per window: the workgroups' tables folded, Value() out (the state's other fields are never read for these reducers)
 template <typename U, bool SIGNED, int MODE>
-__global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
-                                                                   const U *__restrict__ val, int dtype, void *values, uint8_t *seen) {
+__global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid,
+                                                                   uint32_t nb_all, uint32_t cap, uint32_t n_ranges, const U *__restrict__ val, int dtype,
+                                                                   void *values, uint8_t *seen) {
     using SH = DirectShape<MODE, (int)sizeof(U)>;
     constexpr int NS = SH::NS;
     // 64 windows per workgroup, the tables dealt to its four waves (a lane per window and table in turn: 512 dependent-free but
@@ -167,8 +176,9 @@ __global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_
     __shared__ uint64_t f_cnt[4][64], f_a[4][64], f_b[4][64];
     __shared__ uint32_t f_fr[4][64], f_zr[4][64];
     const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * 64 + lane;
-    const bool valid = k < nb;
+    const uint32_t kw = blockIdx.x * 64 + lane;                  // the window; k: its place in its range's tables
+    const bool valid = kw < nb_all;
+    const uint32_t nb = cap, rid = kw / cap, k = kw - rid * cap, nsub = grid / n_ranges;
     const uint32_t nc = SH::words(nb);
     uint64_t count = 0, a = SH::INIT, b = 0;
     uint32_t frow = ~0u, zrow = ~0u;      // float min / max: the lowest selected row, the lowest row holding a zero
@@ -183,7 +193,8 @@ __global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_
     };
     if (valid) {
 #pragma unroll 4
-        for (uint32_t g = part; g < grid; g += 4) {
+        for (uint32_t sb = part; sb < nsub; sb += 4) {
+            const uint32_t g = sb * n_ranges + rid;
             uint64_t c2 = 0, a2 = SH::INIT, b2 = 0;
             uint32_t f2 = ~0u, z2 = ~0u;
             if constexpr (SH::FMINMAX) { f2 = words[(size_t)g * nc + k]; z2 = words[(size_t)g * nc + nb + k]; }
@@ -247,17 +258,18 @@ __global__ void __launch_bounds__(256) window_direct_finish_kernel(const uint64_
     int sn = 0;
     int64_t row = -1;
     const int rc = knox_fin::agg_value_bits(s, SH::FUNC, &bits, &sn, &row);
-    reinterpret_cast<U *>(values)[k] = (U)bits;
-    seen[k] = (rc == 0 && sn) ? 1 : 0;
+    reinterpret_cast<U *>(values)[kw] = (U)bits;
+    seen[kw] = (rc == 0 && sn) ? 1 : 0;
 }
 
 // grid == 0: the reducer has no order-free form for this column type, or the windows' table does not fit a workgroup's LDS (the
 // caller sorts).  (ONE table in device memory for any number of windows was built as well: device-scope atomics of the eight XCDs
 // on shared lines ran at 21 G adds/s -- 2^28 rows -> 16384 windows 25.5 ms against the sort's 5.2 -- dropped.)
-WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_buckets, int n_cus) {
+WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_buckets, int n_cus, bool masked) {
     WindowDirectGeom g;
     g.grid = 0;
-    g.n_slots = g.n_words = 0;
+    g.n_slots = g.n_words = g.cap = 0;
+    g.n_ranges = 1;
     g.lds = g.scratch = 0;
     const bool integer = dtype >= 1 && dtype <= 8, numeric = dtype >= 1 && dtype <= 10;
     const bool fminmax = !integer && (func == kDirectMin || func == kDirectMax);
@@ -265,12 +277,26 @@ WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_b
                   : (func == kDirectSum || func == kDirectMean) ? integer : false;
     if (!ok || (width != 8 && width != 4 && width != 2 && width != 1)) return g;
     g.n_slots = func == kDirectCount ? 0 : (func == kDirectMean && width == 8) ? 2 : 1;
-    g.n_words = fminmax ? 2 * n_buckets
-              : (func == kDirectCount || func == kDirectMean) ? n_buckets : (func == kDirectFirst || func == kDirectLast) ? 0 : (n_buckets + 31) / 32;
-    g.lds = ((size_t)n_buckets * 8u * g.n_slots + (size_t)g.n_words * 4u + 7) & ~(size_t)7;
-    if (g.lds > 156 * 1024) return g;
-    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);   // 1024 threads each: two fill a CU
-    g.scratch = (size_t)g.grid * ((size_t)n_buckets * 8u * g.n_slots + (size_t)g.n_words * 4u) + 512;
+    auto words_of = [&](uint32_t nb) {
+        return fminmax ? 2 * nb : (func == kDirectCount || func == kDirectMean) ? nb : (func == kDirectFirst || func == kDirectLast) ? 0u : (nb + 31) / 32;
+    };
+    auto lds_of = [&](uint32_t nb) { return ((size_t)nb * 8u * g.n_slots + (size_t)words_of(nb) * 4u + 7) & ~(size_t)7; };
+    // more windows than one table holds: up to four ranges without a selection, two behind one (every range reads all rows: measured against
+    // the sort's passes, 2^28 rows: 0.7 ms per range, the sort 5-7 ms for every row and 2.6-3.6 ms at 25 % selected)
+    const uint32_t max_ranges = masked ? 2u : 4u;
+    uint32_t r = 1;
+    uint32_t cap = n_buckets;
+    while (lds_of(cap) > 156 * 1024) {
+        if (++r > max_ranges) return g;
+        cap = (((n_buckets + r - 1) / r) + 31) & ~31u;
+    }
+    g.n_ranges = r;
+    g.cap = cap;
+    g.n_words = words_of(cap);
+    g.lds = lds_of(cap);
+    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
+    g.grid = g.grid / r * r;
+    g.scratch = (size_t)g.grid * ((size_t)cap * 8u * g.n_slots + (size_t)g.n_words * 4u) + 512;
     return g;
 }
 
@@ -280,16 +306,16 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
     if (n_buckets == 0 || g.grid == 0) return hipErrorInvalidValue;
     const bool is_signed = dtype >= 1 && dtype <= 4, is_float = dtype == 9 || dtype == 10;
     uint64_t *slots = (uint64_t *)scratch;
-    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.n_slots * n_buckets);
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.n_slots * g.cap);
     const dim3 fgrid((n_buckets + 63) / 64), fblock(256);
 #define KNOX_DIRECT(U, S, MODE)                                                                                                                     \
     do {                                                                                                                                            \
         if (g.lds > 48 * 1024)                                                                                                                      \
             (void)hipFuncSetAttribute((const void *)window_direct_kernel<U, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);      \
         hipLaunchKernelGGL((window_direct_kernel<U, S, MODE>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, \
-                           n_buckets, slots, words);                                                                                                \
+                           n_buckets, g.cap, g.n_ranges, slots, words);                                                                             \
         hipLaunchKernelGGL((window_direct_finish_kernel<U, S, MODE>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, \
-                           n_buckets, (const U *)val, dtype, values, seen);                                                                         \
+                           n_buckets, g.cap, g.n_ranges, (const U *)val, dtype, values, seen);                                                      \
     } while (0)
 #define KNOX_DIRECT_S(U, MODE)                                                                \
     do {                                                                                      \

@@ -386,10 +386,11 @@ hipError_t launch_window_compact(hipStream_t s, int width, const int64_t *time, 
                                  uint32_t *idx_out, void *val_out);
 // out-of-order time without the sort: Value() of the order-free reducers per window by LDS atomics (knox_fold.hip)
 struct WindowDirectGeom {
-    uint32_t grid, n_slots, n_words;   // grid 0: no order-free form for (reducer, column type), or the table does not fit LDS
+    uint32_t grid, n_slots, n_words;   // grid 0: no order-free form for (reducer, column type), or too many windows
+    uint32_t cap, n_ranges;            // windows per table; ranges of windows (each read all rows)
     size_t lds, scratch;
 };
-WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_buckets, int n_cus);
+WindowDirectGeom window_direct_geom(int width, int dtype, int func, uint32_t n_buckets, int n_cus, bool masked);
 hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, WindowDirectGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                                 uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
 // ... float sums / means: exact, as 160-bit fixed-point numbers (five 64-bit adders per window)

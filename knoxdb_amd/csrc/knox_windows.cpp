@@ -117,13 +117,14 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
     const size_t w = (size_t)value_col->width;
     // Value() of a reducer with an order-free form -- count, first / last (the value of the lowest / highest selected row), min / max
     // (floats: with the reference's NaN and signed-zero rules), and over integer columns the sum and the mean rounded from the exact sum -- over as many windows as a workgroup's LDS holds a table
-    // for (8 B + a bit per window: ~19 Ki windows; Count ~39 Ki, Mean ~13 Ki / ~7.9 Ki for 8-byte values): every row is pushed into
+    // for (8 B + a bit per window: ~19 Ki windows; Count ~39 Ki, Mean ~13 Ki / ~7.9 Ki for 8-byte values; up to four times that in ranges
+    // of windows, each of which reads all rows -- window_direct_geom): every row is pushed into
     // its window where it lies (window_direct_kernel, knox_fold.hip), as NativeBucket.Push does; nothing is sorted.
     // KNOX_WINDOW_DIRECT=0 keeps the sort (measurements, the agreement test).
-    if (ctx->win_values != nullptr && !(flags & 2) && n_buckets <= 65536) {
+    if (ctx->win_values != nullptr && !(flags & 2) && n_buckets <= (1u << 18)) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");
-        const WindowDirectGeom dg = (env && atoi(env) == 0) ? WindowDirectGeom{0, 0, 0, 0, 0}
-                                                            : window_direct_geom((int)w, value_col->dtype, ctx->win_func, (uint32_t)n_buckets, ctx->n_cus);
+        const WindowDirectGeom dg = (env && atoi(env) == 0) ? WindowDirectGeom{0, 0, 0, 0, 1, 0, 0}
+                                                            : window_direct_geom((int)w, value_col->dtype, ctx->win_func, (uint32_t)n_buckets, ctx->n_cus, mask != nullptr);
         if (dg.grid != 0) {
             int rc = ensure(ctx, ctx->sort_buf, dg.scratch);
             if (rc) return rc;
