@@ -128,7 +128,7 @@ while time.time() < t_end:
         # Python's integer floor division over steps from 1 to 2^44 and clocks anywhere in int64; with / without the compaction pass
         n = int(rng.integers(100, 200000))
         step = int(2 ** rng.uniform(0, 44)) + int(rng.integers(0, 3))
-        nb = int(rng.integers(1, 5000))
+        nb = int(rng.integers(1, 5000)) if rng.random() < 0.85 else int(rng.integers(15000, 90000))     # (many windows: several ranges of tables, or the sort)
         t_from = int(rng.integers(-(1 << 62), (1 << 62) - step * nb - 1))
         span = step * nb
         lo, hi = max(t_from - span // 4 - 5, -(1 << 63)), min(t_from + span + span // 4 + 5, (1 << 63) - 1)
