@@ -487,15 +487,21 @@ __device__ __forceinline__ void fixed_sum_push(uint64_t *bin, uint32_t nb, uint3
 
 template <typename U>
 __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t *__restrict__ time, const U *__restrict__ val, const uint8_t *__restrict__ mask,
-                                                                   uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb, uint32_t base, uint32_t nbins,
-                                                                   uint64_t *__restrict__ slots_out, uint32_t *__restrict__ words_out) {
+                                                                   uint64_t n_rows, int64_t t_from, int64_t step, uint32_t nb_all, uint32_t cap,
+                                                                   uint32_t n_ranges, uint32_t base, uint32_t nbins, uint64_t *__restrict__ slots_out,
+                                                                   uint32_t *__restrict__ words_out) {
+    // (ranges of windows as in window_direct_kernel: workgroup b folds range b % n_ranges over all rows)
+    const uint32_t rid = blockIdx.x % n_ranges, sub = blockIdx.x / n_ranges, nsub = gridDim.x / n_ranges;
+    t_from += (int64_t)((uint64_t)rid * cap) * step;
+    const uint32_t nb = cap;
+    const uint32_t nbr = rid * cap >= nb_all ? 0u : (nb_all - rid * cap < cap ? nb_all - rid * cap : cap);
     extern __shared__ uint64_t direct_tab[];                                   // [nbins][nb] adders, then [3][nb] words: count, negative zeros, flags
     uint64_t *bin = direct_tab;
     uint32_t *word = reinterpret_cast<uint32_t *>(direct_tab + (size_t)nbins * nb);
     for (uint32_t i = threadIdx.x; i < nbins * nb; i += kDirectBlock) bin[i] = 0;
     for (uint32_t i = threadIdx.x; i < 3 * nb; i += kDirectBlock) word[i] = 0;
     __syncthreads();
-    const uint64_t span = (uint64_t)nb * (uint64_t)step;
+    const uint64_t span = (uint64_t)nbr * (uint64_t)step;
     const double inv = 1.0 / (double)step;
     auto push = [&](int64_t t, U x, uint64_t) {
         const uint32_t q = window_index(t, t_from, (uint64_t)step, span, inv);
@@ -509,7 +515,7 @@ __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t
         if (be == 0 && frac == 0) { if (neg) atomicAdd(&word[nb + q], 1u); return; }
         fixed_sum_push(bin, nb, q, nbins, base, d);
     };
-    direct_walk<U, true>(time, val, mask, n_rows, push);
+    direct_walk<U, true>(time, val, mask, n_rows, push, sub, nsub);
     __syncthreads();
     uint64_t *so = slots_out + (size_t)blockIdx.x * nbins * nb;
     uint32_t *wo = words_out + (size_t)blockIdx.x * 3 * nb;
@@ -519,18 +525,21 @@ __global__ void __launch_bounds__(kDirectBlock) window_fsum_kernel(const int64_t
 
 // 64 windows per workgroup, the tables dealt to its four waves; the 160-bit sum -> a double-double -> Value() (knox_finalize.h)
 template <typename U>
-__global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid, uint32_t nb,
-                                                                 uint32_t base, uint32_t nbins, int dtype, int func, void *values, uint8_t *seen) {
+__global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ words, uint32_t grid,
+                                                                 uint32_t nb_all, uint32_t cap, uint32_t n_ranges, uint32_t base, uint32_t nbins, int dtype, int func,
+                                                                 void *values, uint8_t *seen) {
     __shared__ uint64_t f_bin[4][kFsumBins][64];
     __shared__ uint32_t f_w[4][3][64];
     const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * 64 + lane;
-    const bool valid = k < nb;
+    const uint32_t kw = blockIdx.x * 64 + lane;                  // the window; k: its place in its range's tables
+    const bool valid = kw < nb_all;
+    const uint32_t nb = cap, rid = kw / cap, k = kw - rid * cap, nsub = grid / n_ranges;
     uint64_t b[kFsumBins] = {0, 0, 0, 0, 0};
     uint32_t w[3] = {0, 0, 0};
     if (valid) {
 #pragma unroll 2
-        for (uint32_t g = part; g < grid; g += 4) {
+        for (uint32_t sb = part; sb < nsub; sb += 4) {
+            const uint32_t g = sb * n_ranges + rid;
 #pragma unroll
             for (int i = 0; i < kFsumBins; i++)
                 if ((uint32_t)i < nbins) b[i] += slots[((size_t)g * nbins + i) * nb + k];
@@ -570,24 +579,32 @@ __global__ void __launch_bounds__(256) window_fsum_finish_kernel(const uint64_t 
     int sn = 0;
     int64_t row = -1;
     const int rc = knox_fin::agg_value_bits(st, func, &bits, &sn, &row);
-    reinterpret_cast<U *>(values)[k] = (U)bits;
-    seen[k] = (rc == 0 && sn) ? 1 : 0;
+    reinterpret_cast<U *>(values)[kw] = (U)bits;
+    seen[kw] = (rc == 0 && sn) ? 1 : 0;
 }
 
 // exp_max / exp_min: the column's largest / smallest finite non-zero biased float64 exponent (launch_float_exprange).  grid 0: the
 // exponents span more than the five digits hold (160 bits = 107 binades + a mantissa), the table does not fit LDS, or the column holds
 // nothing the fixed-point form is good for (no finite non-zero value; values so small that the scaled result would be denormal)
-WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus) {
+WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus, bool masked) {
     WindowFsumGeom g;
     g.grid = 0;
-    g.base = g.nbins = 0;
+    g.base = g.nbins = g.cap = 0;
+    g.n_ranges = 1;
     g.lds = g.scratch = 0;
     if (exp_max < 200 || exp_min == 0 || exp_min > exp_max || exp_max - exp_min > (uint32_t)kFsumRange) return g;
     g.base = exp_min;
     g.nbins = (exp_max - exp_min + 53 + 31) / 32;
-    g.lds = (size_t)n_buckets * (8u * g.nbins + 12u);
-    if (g.lds > 156 * 1024) return g;
-    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u);
+    const uint32_t max_ranges = masked ? 2u : 4u;      // (as window_direct_geom)
+    uint32_t r = 1, cap = n_buckets;
+    while ((size_t)cap * (8u * g.nbins + 12u) > 156 * 1024) {
+        if (++r > max_ranges) return g;
+        cap = (((n_buckets + r - 1) / r) + 31) & ~31u;
+    }
+    g.n_ranges = r;
+    g.cap = cap;
+    g.lds = (size_t)cap * (8u * g.nbins + 12u);
+    g.grid = (uint32_t)n_cus * (g.lds <= 40 * 1024 ? 2u : 1u) / r * r;
     g.scratch = (size_t)g.grid * g.lds + 512;
     return g;
 }
@@ -597,15 +614,15 @@ hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, Win
                               uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen) {
     if (n_buckets == 0 || g.grid == 0 || (func != 0 && func != 5)) return hipErrorInvalidValue;
     uint64_t *slots = (uint64_t *)scratch;
-    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.nbins * n_buckets);
+    uint32_t *words = (uint32_t *)(slots + (size_t)g.grid * g.nbins * g.cap);
     const dim3 fgrid((n_buckets + 63) / 64), fblock(256);
 #define KNOX_FSUM(U)                                                                                                                                \
     do {                                                                                                                                            \
         if (g.lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)window_fsum_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
         hipLaunchKernelGGL((window_fsum_kernel<U>), dim3(g.grid), dim3(kDirectBlock), g.lds, s, time, (const U *)val, mask, n_rows, t_from, step, n_buckets, \
-                           g.base, g.nbins, slots, words);                                                                                          \
-        hipLaunchKernelGGL((window_fsum_finish_kernel<U>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, g.base, \
-                           g.nbins, dtype, func, values, seen);                                                                                     \
+                           g.cap, g.n_ranges, g.base, g.nbins, slots, words);                                                                       \
+        hipLaunchKernelGGL((window_fsum_finish_kernel<U>), fgrid, fblock, 0, s, (const uint64_t *)slots, (const uint32_t *)words, g.grid, n_buckets, g.cap, \
+                           g.n_ranges, g.base, g.nbins, dtype, func, values, seen);                                                                 \
     } while (0)
     if (width == 8) KNOX_FSUM(uint64_t);
     else if (width == 4) KNOX_FSUM(uint32_t);
@@ -1057,7 +1074,7 @@ __global__ void __launch_bounds__(256) window_fstate_finish_kernel(const uint64_
 }
 
 WindowFsumGeom window_fstate_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus) {
-    WindowFsumGeom g = window_fsum_geom(exp_max, exp_min, 1, n_cus);      // base / nbins, or grid 0
+    WindowFsumGeom g = window_fsum_geom(exp_max, exp_min, 1, n_cus, false);      // base / nbins, or grid 0
     if (g.grid == 0) return g;
     g.grid = 0;
     g.lds = (size_t)n_buckets * (8u * (g.nbins + 2) + 20u);

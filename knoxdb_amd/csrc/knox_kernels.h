@@ -396,10 +396,11 @@ hipError_t launch_window_direct(hipStream_t s, int width, int dtype, int func, W
 // ... float sums / means: exact, as 160-bit fixed-point numbers (five 64-bit adders per window)
 struct WindowFsumGeom {
     uint32_t grid, base, nbins;   // grid 0: not usable; base: the lowest biased exponent held; nbins: 32-bit digits (<= 5)
+    uint32_t cap, n_ranges;       // windows per table; ranges of windows (each read all rows)
     size_t lds, scratch;
 };
 hipError_t launch_float_exprange(hipStream_t s, int width, int dtype, const void *val, uint64_t n_rows, uint32_t *out /* [max, ~min], zeroed */);
-WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus);
+WindowFsumGeom window_fsum_geom(uint32_t exp_max, uint32_t exp_min, uint32_t n_buckets, int n_cus, bool masked);
 hipError_t launch_window_fsum(hipStream_t s, int width, int dtype, int func, WindowFsumGeom g, const int64_t *time, const void *val, const uint8_t *mask,
                               uint64_t n_rows, int64_t t_from, int64_t step, uint32_t n_buckets, void *scratch, void *values, uint8_t *seen);
 struct WindowFvarGeom {          // var / std of a float column: adders for the sum and for the sum of squares

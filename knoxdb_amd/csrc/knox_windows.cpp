@@ -165,13 +165,13 @@ static int reduce_buckets_unordered(knox_ctx *ctx, const knox_col *time_col, con
     // float sums / means: exact fixed-point adders sized by the column's smallest and largest exponent (one pass over the values the first
     // time, kept with the column); a column spanning more than 107 binades, or more windows than LDS holds adders for, takes the sort
     if (ctx->win_values != nullptr && !(flags & 2) && (ctx->win_func == KNOX_R_SUM || ctx->win_func == KNOX_R_MEAN) &&
-        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 8192) {
+        (value_col->dtype == KNOX_FLOAT64 || value_col->dtype == KNOX_FLOAT32) && n_buckets <= 32768) {
         const char *env = getenv("KNOX_WINDOW_DIRECT");
         if (!(env && atoi(env) == 0)) {
             int emax = 0, emin = 0;
             int rc = col_float_exprange(ctx, value_col, &emax, &emin);
             if (rc) return rc;
-            const WindowFsumGeom fg = window_fsum_geom((uint32_t)emax, (uint32_t)emin, (uint32_t)n_buckets, ctx->n_cus);
+            const WindowFsumGeom fg = window_fsum_geom((uint32_t)emax, (uint32_t)emin, (uint32_t)n_buckets, ctx->n_cus, mask != nullptr);
             if (fg.grid != 0) {
                 rc = ensure(ctx, ctx->sort_buf, fg.scratch);
                 if (rc) return rc;
